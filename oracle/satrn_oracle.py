@@ -1,0 +1,538 @@
+"""CPU oracle for the SATRN hot path.  *** TEST INFRASTRUCTURE ONLY ***
+
+A plain PyTorch-fp32 (CPU) restatement of the reference's EfficientSATRN / LiteSATRN
+forward path, written functionally over a ``state_dict`` that uses the reference's own key
+names.  Backward comes from autograd of this restatement.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this file; the
+product (``p4-fr-sorry-math-but-love-you_amd/``) never does and fails loudly without its HIP
+library.
+
+Parity pin: ``tests/golden/make_golden.py`` imports the reference itself (from
+/root/reference, authoring container only) and stores its outputs in ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks this file against those fixtures.  The 40
+EfficientNetV2-S blocks come from timm==0.4.9 (requirements.txt:16), which is NOT under
+/root/reference and not installable here: for the blocks themselves parity is UNPINNED
+(restated from the public architecture); everything around them is
+pinned through the reference's own ``EfficientSATRN`` class with these blocks injected.
+
+Every function cites the reference file:line it follows (paths relative to /root/reference).
+All dropout is p=0 here (parity mode); BN runs in batch-stat mode when ``train`` is True.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# vocabulary constants  (utils/data_utils.py:6-9,24-42; data/dataset.py:12-15)
+# --------------------------------------------------------------------------------------
+SOS_ID, EOS_ID, PAD_ID = 0, 1, 2
+NUM_CLASSES = 245  # 3 specials + 241 tokens + "" (configs/tokens.txt)
+
+# --------------------------------------------------------------------------------------
+# EfficientNetV2-S block table (timm==0.4.9 tf_efficientnetv2_s)
+#   (type, repeats, stride_first, expand, out_ch, se_ratio)
+# --------------------------------------------------------------------------------------
+EFFNETV2_S = [
+    ("cn", 2, 1, 1, 24, 0.0),
+    ("er", 4, 2, 4, 48, 0.0),
+    ("er", 4, 2, 4, 64, 0.0),
+    ("ir", 6, 2, 4, 128, 0.25),
+    ("ir", 9, 1, 6, 160, 0.25),
+    ("ir", 15, 2, 6, 256, 0.25),
+]
+BN_EPS_TF = 1e-3
+
+
+def effnet_blocks(stem_ch=24, table=EFFNETV2_S):
+    """Flat list of block descriptors: dict(stage, idx, type, cin, cout, mid, stride, se, skip)."""
+    out = []
+    cin = stem_ch
+    for s, (typ, rep, stride, exp, cout, se) in enumerate(table):
+        for i in range(rep):
+            st = stride if i == 0 else 1
+            mid = cin * exp
+            out.append(dict(stage=s, idx=i, type=typ, cin=cin, cout=cout, mid=mid, stride=st,
+                            se=int(cin * se) if se > 0 else 0, skip=(st == 1 and cin == cout)))
+            cin = cout
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# parameter specs (reference state_dict layout)
+# kinds: xavier (xavier_normal_), conv (kaiming-uniform default), linear_w/linear_b (torch
+# default), bn_w/bn_b/ln_w/ln_b, bn_rm/bn_rv/bn_nbt (buffers), embed (N(0,1))
+# --------------------------------------------------------------------------------------
+def _bn(spec, name, c):
+    spec[name + ".weight"] = ((c,), "bn_w")
+    spec[name + ".bias"] = ((c,), "bn_b")
+    spec[name + ".running_mean"] = ((c,), "bn_rm")
+    spec[name + ".running_var"] = ((c,), "bn_rv")
+    spec[name + ".num_batches_tracked"] = ((), "bn_nbt")
+
+
+def _mha(spec, name, qc, kc):
+    # networks/EfficientSATRN.py:176-196
+    spec[name + ".q_linear.weight"] = ((qc, qc), "xavier")
+    spec[name + ".q_linear.bias"] = ((qc,), "linear_b")
+    spec[name + ".k_linear.weight"] = ((qc, kc), "xavier")
+    spec[name + ".k_linear.bias"] = ((qc,), "linear_b")
+    spec[name + ".v_linear.weight"] = ((qc, kc), "xavier")
+    spec[name + ".v_linear.bias"] = ((qc,), "linear_b")
+    spec[name + ".out_linear.weight"] = ((qc, qc), "xavier")
+    spec[name + ".out_linear.bias"] = ((qc,), "linear_b")
+
+
+def param_specs(cfg):
+    """cfg: dict(network, rgb, enc_hidden, enc_filter, enc_heads, enc_layers, dec_src, dec_hidden,
+    dec_filter, dec_heads, dec_layers, num_classes)."""
+    s = OrderedDict()
+    D = cfg["enc_hidden"]
+    if cfg["network"] == "LiteSATRN":
+        # networks/LiteSATRN.py:21-48
+        chans = [cfg["rgb"], D // 2, D, D, D]
+        for i in range(4):
+            s[f"encoder.shallow_cnn.conv{i}.weight"] = ((chans[i + 1], chans[i], 3, 3), "xavier" if i < 3 else "conv")
+            _bn(s, f"encoder.shallow_cnn.batch_norm{i}", chans[i + 1])
+    else:
+        # networks/EfficientSATRN.py:63-79 + timm blocks
+        p = "encoder.shallow_cnn."
+        s[p + "conv_stem.weight"] = ((24, cfg["rgb"], 3, 3), "conv")
+        _bn(s, p + "bn1", 24)
+        for b in effnet_blocks():
+            q = f"{p}eff_block.{b['stage']}.{b['idx']}."
+            if b["type"] == "cn":
+                s[q + "conv.weight"] = ((b["cout"], b["cin"], 3, 3), "conv")
+                _bn(s, q + "bn1", b["cout"])
+            elif b["type"] == "er":
+                s[q + "conv_exp.weight"] = ((b["mid"], b["cin"], 3, 3), "conv")
+                _bn(s, q + "bn1", b["mid"])
+                s[q + "conv_pwl.weight"] = ((b["cout"], b["mid"], 1, 1), "conv")
+                _bn(s, q + "bn2", b["cout"])
+            else:
+                s[q + "conv_pw.weight"] = ((b["mid"], b["cin"], 1, 1), "conv")
+                _bn(s, q + "bn1", b["mid"])
+                s[q + "conv_dw.weight"] = ((b["mid"], 1, 3, 3), "conv")
+                _bn(s, q + "bn2", b["mid"])
+                s[q + "se.conv_reduce.weight"] = ((b["se"], b["mid"], 1, 1), "conv")
+                s[q + "se.conv_reduce.bias"] = ((b["se"],), "linear_b")
+                s[q + "se.conv_expand.weight"] = ((b["mid"], b["se"], 1, 1), "conv")
+                s[q + "se.conv_expand.bias"] = ((b["mid"],), "linear_b")
+                s[q + "conv_pwl.weight"] = ((b["cout"], b["mid"], 1, 1), "conv")
+                _bn(s, q + "bn3", b["cout"])
+        s[p + "conv_last.weight"] = ((D, 256, 1, 1), "conv")
+        _bn(s, p + "bn2", D)
+    # networks/EfficientSATRN.py:102-109
+    s["encoder.positional_encoding.dense0.weight"] = ((D // 2, D), "xavier")
+    s["encoder.positional_encoding.dense0.bias"] = ((D // 2,), "linear_b")
+    s["encoder.positional_encoding.dense1.weight"] = ((2 * D, D // 2), "xavier")
+    s["encoder.positional_encoding.dense1.bias"] = ((2 * D,), "linear_b")
+    Fe = cfg["enc_filter"]
+    for l in range(cfg["enc_layers"]):
+        q = f"encoder.attention_layers.{l}."
+        # networks/EfficientSATRN.py:235-257
+        s[q + "norm.weight"] = ((D,), "ln_w")
+        s[q + "norm.bias"] = ((D,), "ln_b")
+        _mha(s, q + "attention_layer", D, D)
+        s[q + "conv0.weight"] = ((Fe, D, 1, 1), "xavier")
+        _bn(s, q + "norm0", Fe)
+        s[q + "depthwise.weight"] = ((Fe, 1, 3, 3), "xavier")
+        s[q + "depthwise.bias"] = ((Fe,), "linear_b")
+        _bn(s, q + "depthwise_norm", Fe)
+        s[q + "conv1.weight"] = ((D, Fe, 1, 1), "xavier")
+        _bn(s, q + "norm1", D)
+    Dd, Ds, Ff = cfg["dec_hidden"], cfg["dec_src"], cfg["dec_filter"]
+    V = cfg["num_classes"]
+    s["decoder.embedding.weight"] = ((V + 1, Dd), "embed")  # :445
+    for l in range(cfg["dec_layers"]):
+        q = f"decoder.attention_layers.{l}."
+        # networks/EfficientSATRN.py:353-372
+        _mha(s, q + "self_attention_layer", Dd, Dd)
+        s[q + "self_attention_norm.weight"] = ((Dd,), "ln_w")
+        s[q + "self_attention_norm.bias"] = ((Dd,), "ln_b")
+        _mha(s, q + "attention_layer", Dd, Ds)
+        s[q + "attention_norm.weight"] = ((Dd,), "ln_w")
+        s[q + "attention_norm.bias"] = ((Dd,), "ln_b")
+        s[q + "feedforward_layer.linear0.weight"] = ((Ff, Dd), "xavier")
+        s[q + "feedforward_layer.linear0.bias"] = ((Ff,), "linear_b")
+        s[q + "feedforward_layer.linear1.weight"] = ((Dd, Ff), "xavier")
+        s[q + "feedforward_layer.linear1.bias"] = ((Dd,), "linear_b")
+        s[q + "feedforward_norm.weight"] = ((Dd,), "ln_w")
+        s[q + "feedforward_norm.bias"] = ((Dd,), "ln_b")
+    s["decoder.generator.weight"] = ((V, Dd), "linear_w")
+    s["decoder.generator.bias"] = ((V,), "linear_b")
+    return s
+
+
+CFG_LITE = dict(network="LiteSATRN", rgb=1, enc_hidden=256, enc_filter=256, enc_heads=4, enc_layers=1,
+                dec_src=256, dec_hidden=128, dec_filter=512, dec_heads=4, dec_layers=2,
+                num_classes=NUM_CLASSES)  # configs/LiteSATRN.yaml:5-16
+CFG_EFF = dict(network="EfficientSATRN", rgb=1, enc_hidden=512, enc_filter=512, enc_heads=8, enc_layers=2,
+               dec_src=512, dec_hidden=256, dec_filter=1024, dec_heads=8, dec_layers=3,
+               num_classes=NUM_CLASSES)  # configs/EfficientSATRN.yaml:5-16
+
+
+# --------------------------------------------------------------------------------------
+# deterministic weights / inputs: counter-based integer hash -> uniform.  Build-owned, so the
+# same tensors can be regenerated on the GPU box without shipping them.
+# --------------------------------------------------------------------------------------
+def _hash_uniform(n, seed):
+    """n float32 values in [-1, 1) from a 32-bit mix of (seed, index).  Pure integer math."""
+    i = torch.arange(n, dtype=torch.int64)
+    x = (i * 0x9E3779B1 + (seed + 1) * 0x85EBCA77) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return ((x >> 8).to(torch.float64) / float(1 << 23) - 1.0).to(torch.float32)
+
+
+def det_tensor(shape, seed, scale=1.0):
+    n = 1
+    for d in shape:
+        n *= d
+    return (_hash_uniform(max(n, 1), seed)[:n] * scale).reshape(shape)
+
+
+def _name_seed(name, seed):
+    h = seed * 1000003
+    for ch in name:
+        h = (h * 131 + ord(ch)) & 0x7FFFFFFF
+    return h
+
+
+def det_state_dict(cfg, seed=0):
+    """Deterministic, well-conditioned weights for every key of param_specs(cfg)."""
+    sd = OrderedDict()
+    for name, (shape, kind) in param_specs(cfg).items():
+        sk = _name_seed(name, seed)
+        if kind in ("xavier", "conv", "linear_w"):
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            fan_out = shape[0]
+            for d in shape[2:]:
+                fan_out *= d
+            if kind == "xavier":
+                a = math.sqrt(6.0 / (fan_in + fan_out))
+            else:
+                a = math.sqrt(3.0 / fan_in)
+            t = det_tensor(shape, sk, a)
+        elif kind == "linear_b":
+            t = det_tensor(shape, sk, 0.1)
+        elif kind in ("bn_w", "ln_w"):
+            t = 1.0 + det_tensor(shape, sk, 0.2)
+        elif kind in ("bn_b", "ln_b"):
+            t = det_tensor(shape, sk, 0.1)
+        elif kind == "bn_rm":
+            t = det_tensor(shape, sk, 0.1)
+        elif kind == "bn_rv":
+            t = 1.0 + det_tensor(shape, sk, 0.3)
+        elif kind == "bn_nbt":
+            t = torch.zeros((), dtype=torch.int64)
+        elif kind == "embed":
+            t = det_tensor(shape, sk, 1.0)
+        else:
+            raise ValueError(kind)
+        sd[name] = t
+    return sd
+
+
+def det_inputs(batch, rgb, height, width, seq_len, seed=21, pad_tail=0):
+    """Synthetic batch: images ~U(-1.7,1.7) (unit variance), expected [B, T+1] with
+    col 0 = SOS, last = EOS, rest uniform in 3..244; the last `pad_tail` columns of odd rows are
+    PAD (exercises ignore_index and pad_mask)."""
+    img = det_tensor((batch, rgb, height, width), seed * 7 + 1, 1.7320508)
+    u = _hash_uniform(batch * (seq_len + 1), seed * 7 + 2).reshape(batch, seq_len + 1)
+    ids = (3 + ((u + 1.0) * 0.5 * 242).floor().clamp(0, 241)).to(torch.int64)
+    ids[:, 0] = SOS_ID
+    ids[:, -1] = EOS_ID
+    if pad_tail > 0:
+        for b in range(1, batch, 2):
+            ids[b, -pad_tail:] = PAD_ID
+            ids[b, -pad_tail - 1] = EOS_ID
+    return img, ids
+
+
+# --------------------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------------------
+class _BNState:
+    """Collects running-stat updates so callers can compare them with the HIP path."""
+
+    def __init__(self):
+        self.updates = OrderedDict()
+
+
+def batch_norm(x, sd, name, train, eps, bnstate=None, momentum=0.1):
+    """nn.BatchNorm2d semantics (batch stats + running update in train, running stats in eval)."""
+    w, b = sd[name + ".weight"], sd[name + ".bias"]
+    rm, rv = sd[name + ".running_mean"], sd[name + ".running_var"]
+    if train:
+        rm2, rv2 = rm.detach().clone(), rv.detach().clone()
+        y = F.batch_norm(x, rm2, rv2, w, b, True, momentum, eps)
+        if bnstate is not None:
+            bnstate.updates[name + ".running_mean"] = rm2
+            bnstate.updates[name + ".running_var"] = rv2
+        return y
+    return F.batch_norm(x, rm, rv, w, b, False, momentum, eps)
+
+
+def same_pad(x, k, s):
+    """TF 'SAME' padding as timm Conv2dSame computes it (extra pixel goes bottom/right)."""
+    ih, iw = x.shape[-2:]
+    ph = max((math.ceil(ih / s) - 1) * s + k - ih, 0)
+    pw = max((math.ceil(iw / s) - 1) * s + k - iw, 0)
+    return F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
+
+
+def conv_same(x, w, stride, groups=1):
+    k = w.shape[-1]
+    if stride == 1:
+        return F.conv2d(x, w, None, 1, k // 2, 1, groups)
+    return F.conv2d(same_pad(x, k, stride), w, None, stride, 0, 1, groups)
+
+
+def effnet_block(x, sd, q, b, train, bnstate):
+    """One timm==0.4.9 EfficientNetV2-S block (third-party; parity UNPINNED, see module header)."""
+    sc = x
+    if b["type"] == "cn":
+        x = conv_same(x, sd[q + "conv.weight"], b["stride"])
+        x = F.silu(batch_norm(x, sd, q + "bn1", train, BN_EPS_TF, bnstate))
+    elif b["type"] == "er":
+        x = conv_same(x, sd[q + "conv_exp.weight"], b["stride"])
+        x = F.silu(batch_norm(x, sd, q + "bn1", train, BN_EPS_TF, bnstate))
+        x = F.conv2d(x, sd[q + "conv_pwl.weight"])
+        x = batch_norm(x, sd, q + "bn2", train, BN_EPS_TF, bnstate)
+    else:
+        x = F.conv2d(x, sd[q + "conv_pw.weight"])
+        x = F.silu(batch_norm(x, sd, q + "bn1", train, BN_EPS_TF, bnstate))
+        x = conv_same(x, sd[q + "conv_dw.weight"], b["stride"], groups=b["mid"])
+        x = F.silu(batch_norm(x, sd, q + "bn2", train, BN_EPS_TF, bnstate))
+        g = x.mean((2, 3), keepdim=True)
+        g = F.silu(F.conv2d(g, sd[q + "se.conv_reduce.weight"], sd[q + "se.conv_reduce.bias"]))
+        g = torch.sigmoid(F.conv2d(g, sd[q + "se.conv_expand.weight"], sd[q + "se.conv_expand.bias"]))
+        x = x * g
+        x = F.conv2d(x, sd[q + "conv_pwl.weight"])
+        x = batch_norm(x, sd, q + "bn3", train, BN_EPS_TF, bnstate)
+    if b["skip"]:
+        x = x + sc
+    return x
+
+
+def efficientnet_forward(x, sd, train, bnstate=None, p="encoder.shallow_cnn."):
+    """networks/EfficientSATRN.py:81-87 (conv_stem pad 0 stride 2, bn eps 1e-3, SiLU; blocks;
+    conv_last 1x1, bn eps 1e-5, SiLU)."""
+    x = F.conv2d(x, sd[p + "conv_stem.weight"], None, 2, 0)
+    x = F.silu(batch_norm(x, sd, p + "bn1", train, 1e-3, bnstate))
+    for b in effnet_blocks():
+        x = effnet_block(x, sd, f"{p}eff_block.{b['stage']}.{b['idx']}.", b, train, bnstate)
+    x = F.conv2d(x, sd[p + "conv_last.weight"])
+    x = F.silu(batch_norm(x, sd, p + "bn2", train, 1e-5, bnstate))
+    return x
+
+
+def shallow_cnn_forward(x, sd, train, bnstate=None, p="encoder.shallow_cnn."):
+    """networks/LiteSATRN.py:50-70: 4 x [conv3x3 p1 no-bias, BN, ReLU, maxpool 2x2]."""
+    for i in range(4):
+        x = F.conv2d(x, sd[f"{p}conv{i}.weight"], None, 1, 1)
+        x = F.relu(batch_norm(x, sd, f"{p}batch_norm{i}", train, 1e-5, bnstate))
+        x = F.max_pool2d(x, 2, 2)
+    return x
+
+
+def pos_table_2d(length, hidden):
+    """networks/EfficientSATRN.py:111-127: cat(sin, cos) (not interleaved), D/2 timescales."""
+    position = torch.arange(length).float()
+    nts = hidden // 2
+    inc = math.log(1.0e4 / 1.0) / (torch.FloatTensor([nts]) - 1)
+    inv = 1.0 * torch.exp(torch.arange(nts) * -inc)
+    st = position.unsqueeze(1) * inv.unsqueeze(0)
+    return torch.cat((torch.sin(st), torch.cos(st)), dim=1)  # [length, hidden]
+
+
+def positional_encoding_2d(x, sd, p="encoder.positional_encoding."):
+    """networks/EfficientSATRN.py:135-154."""
+    b, c, h, w = x.shape
+    hp = pos_table_2d(h, c).unsqueeze(1)  # [h,1,c]
+    wp = pos_table_2d(w, c).unsqueeze(0)  # [1,w,c]
+    g = x.mean((2, 3))
+    g = F.relu(F.linear(g, sd[p + "dense0.weight"], sd[p + "dense0.bias"]))
+    g = torch.sigmoid(F.linear(g, sd[p + "dense1.weight"], sd[p + "dense1.bias"]))
+    g = g.reshape(-1, 2, 1, c)
+    e = g[:, 0:1] * hp.unsqueeze(0) + g[:, 1:2] * wp.unsqueeze(0)  # [b,h,w,c]
+    return e.permute(0, 3, 1, 2) + x
+
+
+def mha(q_in, k_in, v_in, sd, p, heads, mask=None):
+    """networks/EfficientSATRN.py:198-228 with :164-172.  Temperature = sqrt(heads*head_dim)
+    (:187-189), mask True = -inf."""
+    b, ql, kl = q_in.size(0), q_in.size(1), k_in.size(1)
+    D = sd[p + ".q_linear.weight"].shape[0]
+    hd = D // heads
+    q = F.linear(q_in, sd[p + ".q_linear.weight"], sd[p + ".q_linear.bias"]).view(b, ql, heads, hd).transpose(1, 2)
+    k = F.linear(k_in, sd[p + ".k_linear.weight"], sd[p + ".k_linear.bias"]).view(b, kl, heads, hd).transpose(1, 2)
+    v = F.linear(v_in, sd[p + ".v_linear.weight"], sd[p + ".v_linear.bias"]).view(b, kl, heads, hd).transpose(1, 2)
+    attn = torch.matmul(q, k.transpose(2, 3)) / float((heads * hd) ** 0.5)
+    if mask is not None:
+        attn = attn.masked_fill(mask.unsqueeze(1), float("-inf"))
+    attn = torch.softmax(attn, dim=-1)
+    out = torch.matmul(attn, v).transpose(1, 2).contiguous().view(b, ql, D)
+    return F.linear(out, sd[p + ".out_linear.weight"], sd[p + ".out_linear.bias"])
+
+
+def encoder_layer(x, sd, q, heads, train, bnstate=None):
+    """networks/EfficientSATRN.py:259-281.  One LayerNorm used twice (:265,:268); raw reshape
+    [b,hw,c] -> [b,c,h,w] (:269) is a memory reinterpretation, not a transpose."""
+    b, c, h, w = x.shape
+    flat = x.view(b, c, h * w).transpose(1, 2)
+    nw, nb = sd[q + "norm.weight"], sd[q + "norm.bias"]
+    y = F.layer_norm(flat, (c,), nw, nb)
+    y = mha(y, y, y, sd, q + "attention_layer", heads)
+    y = F.layer_norm(y + flat, (c,), nw, nb)
+    y = y.reshape(-1, c, h, w)
+    y = F.conv2d(y, sd[q + "conv0.weight"])
+    y = F.relu(batch_norm(y, sd, q + "norm0", train, 1e-5, bnstate))
+    y = F.conv2d(y, sd[q + "depthwise.weight"], sd[q + "depthwise.bias"], 1, 1, 1, y.shape[1])
+    y = F.relu(batch_norm(y, sd, q + "depthwise_norm", train, 1e-5, bnstate))
+    y = F.conv2d(y, sd[q + "conv1.weight"])
+    y = F.relu(batch_norm(y, sd, q + "norm1", train, 1e-5, bnstate))
+    return y + x
+
+
+def encoder_forward(img, sd, cfg, train, bnstate=None):
+    """networks/EfficientSATRN.py:311-323 / networks/LiteSATRN.py SATRNEncoder.forward -> [b, hw, c]."""
+    if cfg["network"] == "LiteSATRN":
+        x = shallow_cnn_forward(img, sd, train, bnstate)
+    else:
+        x = efficientnet_forward(img, sd, train, bnstate)
+    x = positional_encoding_2d(x, sd)
+    for l in range(cfg["enc_layers"]):
+        x = encoder_layer(x, sd, f"encoder.attention_layers.{l}.", cfg["enc_heads"], train, bnstate)
+    b, c, h, w = x.shape
+    return x.view(b, c, h * w).transpose(1, 2)
+
+
+def pos_table_1d(channels, max_len=500):
+    """networks/EfficientSATRN.py:408-418: interleaved sin/cos."""
+    pos = torch.arange(max_len).float().unsqueeze(1)
+    i = torch.arange(channels).float().unsqueeze(0)
+    rates = 1 / torch.pow(10000, (2 * (i // 2)) / channels)
+    pe = pos * rates
+    pe[:, 0::2] = torch.sin(pe[:, 0::2])
+    pe[:, 1::2] = torch.cos(pe[:, 1::2])
+    return pe
+
+
+def text_embedding(ids, sd):
+    """networks/EfficientSATRN.py:480-483."""
+    e = F.embedding(ids, sd["decoder.embedding.weight"])
+    return e * math.sqrt(e.size(2))
+
+
+def feedforward(x, sd, q):
+    """networks/EfficientSATRN.py:339-346: ReLU after BOTH linears."""
+    x = F.relu(F.linear(x, sd[q + ".linear0.weight"], sd[q + ".linear0.bias"]))
+    return F.relu(F.linear(x, sd[q + ".linear1.weight"], sd[q + ".linear1.bias"]))
+
+
+def decoder_layer(tgt, tgt_prev, src, mask, sd, q, heads):
+    """networks/EfficientSATRN.py:374-397.  Step mode: K/V history = cat(prev OUTPUTS, current input)."""
+    Dd = tgt.shape[-1]
+    kv = tgt if tgt_prev is None else torch.cat([tgt_prev, tgt], 1)
+    att = mha(tgt, kv, kv, sd, q + "self_attention_layer", heads, mask)
+    out = F.layer_norm(att + tgt, (Dd,), sd[q + "self_attention_norm.weight"], sd[q + "self_attention_norm.bias"])
+    att = mha(out, src, src, sd, q + "attention_layer", heads)
+    out = F.layer_norm(att + out, (Dd,), sd[q + "attention_norm.weight"], sd[q + "attention_norm.bias"])
+    ff = feedforward(out, sd, q + "feedforward_layer")
+    return F.layer_norm(ff + out, (Dd,), sd[q + "feedforward_norm.weight"], sd[q + "feedforward_norm.bias"])
+
+
+def decoder_masks(text):
+    """networks/EfficientSATRN.py:469-478,492: (text==PAD with column 0 cleared) | strict upper triangle."""
+    pad = text == PAD_ID
+    pad[:, 0] = False
+    L = text.size(1)
+    order = torch.triu(torch.ones(L, L), diagonal=1).bool()
+    return pad.unsqueeze(1) | order.unsqueeze(0)
+
+
+def decoder_tf_forward(src, text, sd, cfg):
+    """networks/EfficientSATRN.py:490-495 (teacher-forced branch) -> logits [b, L, V]."""
+    Dd = cfg["dec_hidden"]
+    tgt = text_embedding(text, sd) + pos_table_1d(Dd)[: text.size(1)].unsqueeze(0)
+    mask = decoder_masks(text.clone())
+    for l in range(cfg["dec_layers"]):
+        tgt = decoder_layer(tgt, None, src, mask, sd, f"decoder.attention_layers.{l}.", cfg["dec_heads"])
+    return F.linear(tgt, sd["decoder.generator.weight"], sd["decoder.generator.bias"])
+
+
+def decoder_greedy_forward(src, num_steps, sd, cfg):
+    """networks/EfficientSATRN.py:528-561 (no DecodingManager).  Returns (logits [b,steps,V], ids [b,steps]).
+    argmax ties -> lowest index (torch.argmax)."""
+    b = src.size(0)
+    Dd = cfg["dec_hidden"]
+    pe = pos_table_1d(Dd)
+    target = torch.full((b,), SOS_ID, dtype=torch.int64)
+    feats = [None] * cfg["dec_layers"]
+    outs, ids = [], []
+    for t in range(num_steps):
+        tgt = text_embedding(target.view(b, 1), sd) + pe[t].view(1, 1, Dd)
+        for l in range(cfg["dec_layers"]):
+            tgt = decoder_layer(tgt, feats[l], src, None, sd, f"decoder.attention_layers.{l}.", cfg["dec_heads"])
+            feats[l] = tgt if feats[l] is None else torch.cat([feats[l], tgt], 1)
+        o = F.linear(tgt, sd["decoder.generator.weight"], sd["decoder.generator.bias"])
+        target = torch.argmax(o[:, -1, :], dim=-1)
+        outs.append(o[:, 0])
+        ids.append(target)
+    return torch.stack(outs, 1), torch.stack(ids, 1)
+
+
+def model_forward(img, expected, sd, cfg, is_train, teacher_forcing=True, bnstate=None):
+    """networks/EfficientSATRN.py:697-706 / networks/LiteSATRN.py:581-590."""
+    src = encoder_forward(img, sd, cfg, is_train, bnstate)
+    if is_train and teacher_forcing:
+        return decoder_tf_forward(src, expected[:, :-1], sd, cfg)
+    return decoder_greedy_forward(src, expected.size(1) - 1, sd, cfg)[0]
+
+
+def loss_fn(logits, expected):
+    """networks/EfficientSATRN.py:690-692 used as train_modules/train_single_opt.py:82,86."""
+    return F.cross_entropy(logits.transpose(1, 2), expected[:, 1:], ignore_index=PAD_ID)
+
+
+def trainable_names(cfg):
+    return [k for k, (_, kind) in param_specs(cfg).items() if not kind.startswith("bn_r") and kind != "bn_nbt"]
+
+
+def forward_backward(img, expected, sd, cfg):
+    """One teacher-forced training forward + CE + backward on the oracle.
+    Returns (loss, logits, grads{name}, bn_updates{name})."""
+    sd = OrderedDict((k, v.clone()) for k, v in sd.items())
+    names = trainable_names(cfg)
+    for n in names:
+        sd[n].requires_grad_(True)
+    st = _BNState()
+    logits = model_forward(img, expected, sd, cfg, True, True, st)
+    loss = loss_fn(logits, expected)
+    grads = torch.autograd.grad(loss, [sd[n] for n in names], allow_unused=True)
+    g = OrderedDict((n, (gi if gi is not None else torch.zeros_like(sd[n]))) for n, gi in zip(names, grads))
+    return loss.detach(), logits.detach(), g, st.updates
+
+
+def clip_adamw_step(params, grads, m, v, step, lr, wd=1e-6, max_norm=2.0, b1=0.9, b2=0.999, eps=1e-8):
+    """train_modules/train_single_opt.py:95-98: clip_grad_norm_(max_norm) then AdamW.step.
+    params/grads/m/v: dict name -> tensor (updated in place).  Returns total grad norm."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for n, p in params.items():
+        g = grads[n] * coef
+        p.mul_(1 - lr * wd)
+        m[n].mul_(b1).add_(g, alpha=1 - b1)
+        v[n].mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        denom = (v[n].sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m[n], denom, value=-lr / bc1)
+    return total
