@@ -1,0 +1,223 @@
+/* satrn_hip.h -- C ABI of libsatrn_hip.so: the MI355X (gfx950) hot path of EfficientSATRN / LiteSATRN.
+ *
+ * The reference (bcaitech1/p4-fr-sorry-math-but-love-you) has no FFI: its "plugin API" for this path is the
+ * Python nn.Module interface of networks/EfficientSATRN.py and networks/LiteSATRN.py.  Every entry point
+ * below names the reference code it replaces (paths relative to the reference repo).  The Python mirror
+ * that binds these symbols is p4-fr-sorry-math-but-love-you_amd/ (see INTEGRATION.md).
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers borrowed from the caller (PyTorch tensors); the library allocates no
+ *    device memory, never frees or retains a pointer beyond what is documented for satrn_model_bind /
+ *    satrn_model_set_workspace;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *  - return 0 on success, a negative code on error; satrn_last_error() gives the message (thread-local);
+ *    nothing throws across the ABI;
+ *  - dtype: 0 = f32 (exact-f32 MFMA; parity mode), 1 = bf16 storage with f32 accumulation;
+ *  - activations are NHWC ("channels last"): a [B,C,H,W] reference tensor is stored as [B,H,W,C];
+ *    for C == 1 inputs and for the encoder output [b, hw, c] the two layouts coincide;
+ *  - channel counts must be multiples of 8 (bf16) / 4 (f32) except the image channels and the vocabulary.
+ */
+#ifndef SATRN_HIP_H
+#define SATRN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SATRN_F32 0
+#define SATRN_BF16 1
+#define SATRN_ACT_NONE 0
+#define SATRN_ACT_RELU 1
+#define SATRN_ACT_SILU 2
+#define SATRN_ACT_SIGMOID 3
+
+const char* satrn_last_error(void);
+int satrn_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Operator level (one fwd/bwd pair per hot-path row of SURVEY.md section 8a)
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Re-layout fp32 master weights into the compute dtype.
+ * dense: w [N][K] -> fwd [N][K], bwd [K][ldb] (transposed, zero padded to ldb >= N).  nn.Linear / 1x1 conv.
+ * conv3x3: w [Co][Ci][3][3] -> fwd [Co][9][Ci], bwd [Ci][9][Co].   depthwise: w [C][1][3][3] -> [9][C]. */
+int satrn_pack_dense(int dtype, const float* w, void* fwd, void* bwd, int N, int K, int ldb, void* stream);
+int satrn_pack_conv3x3(int dtype, const float* w, void* fwd, void* bwd, int Co, int Ci, void* stream);
+int satrn_pack_dwconv3x3(int dtype, const float* w, void* out, int C, void* stream);
+
+/* y[M][N] = act(x[M][K] * Wfwd[N][K]^T + bias) with optional dropout.  Replaces nn.Linear / 1x1 nn.Conv2d
+ * (+ReLU/Sigmoid/Dropout that follow it): networks/EfficientSATRN.py:145-150 (PositionalEncoding dense0/1),
+ * :200-214,225 (q/k/v/out_linear), :243,249 (conv0/conv1), :339-346 (Feedforward), :461 (generator).
+ * out_f32 != 0 writes fp32 (the logits).  seed: device uint32 (may be NULL when drop_p == 0). */
+int satrn_linear_fwd(int dtype, const void* x, const void* w_fwd, const float* bias, void* y, int M, int N, int K,
+                     int act, int out_f32, float drop_p, const uint32_t* seed, uint32_t site, void* stream);
+/* dx[M][K] (+)= dy[M][ldy(>=N)] * W  using Wbwd [K][ldb]; `accumulate` adds into dx. */
+int satrn_linear_bwd_data(int dtype, const void* dy, int ldy, const void* w_bwd, int ldb, void* dx, int M, int N,
+                          int K, int accumulate, void* stream);
+/* dw[N][K] += dy^T x  (fp32, atomics: zero dw first);  db[N] += column sums of dy (db may be NULL). */
+int satrn_linear_bwd_weight(int dtype, const void* dy, int ldy, const void* x, float* dw, float* db, int M, int N,
+                            int K, void* stream);
+
+/* 3x3 convolution, NHWC, im2col-free implicit GEMM on MFMA.  Replaces nn.Conv2d(k=3) of
+ * networks/LiteSATRN.py:50-70 (ShallowCNN conv1..3) and the timm EfficientNetV2-S 3x3 convs behind
+ * networks/EfficientSATRN.py:74,84.  x [B,H,W,Ci], y [B,OH,OW,Co]; pt/pl = top/left padding (TF "SAME"
+ * strided convs pad bottom/right more). */
+int satrn_conv3x3_fwd(int dtype, const void* x, const void* w_fwd, void* y, int B, int H, int W, int Ci, int Co, int OH,
+                      int OW, int stride, int pt, int pl, void* stream);
+int satrn_conv3x3_bwd_data(int dtype, const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Ci, int Co,
+                           int OH, int OW, int stride, int pt, int pl, int accumulate, void* stream);
+/* dw in the torch layout [Co][Ci][3][3], fp32 atomics (zero first) */
+int satrn_conv3x3_bwd_weight(int dtype, const void* dy, const void* x, float* dw, int B, int H, int W, int Ci, int Co,
+                             int OH, int OW, int stride, int pt, int pl, void* stream);
+/* first conv on the fp32 NCHW image (Cin = 1 or 3): networks/EfficientSATRN.py:67-69,82 (conv_stem, stride 2
+ * pad 0) and networks/LiteSATRN.py:24-26,51 (conv0, stride 1 pad 1).  w is the fp32 master [Co][Cin][3][3]. */
+int satrn_stem_conv_fwd(int dtype, const float* img, const float* w, void* y, int B, int Cin, int H, int W, int Co,
+                        int stride, int pad, void* stream);
+int satrn_stem_conv_bwd_weight(int dtype, const float* img, const void* dy, float* dw, int B, int Cin, int H, int W,
+                               int Co, int stride, int pad, void* stream);
+/* depthwise 3x3 (+bias): networks/EfficientSATRN.py:245-247,274 and the timm MBConv conv_dw. */
+int satrn_dwconv3x3_fwd(int dtype, const void* x, const void* w_packed, const float* bias, void* y, int B, int H, int W,
+                        int C, int OH, int OW, int stride, int pt, int pl, void* stream);
+int satrn_dwconv3x3_bwd_data(int dtype, const void* dy, const void* w_packed, void* dx, int B, int H, int W, int C, int OH,
+                             int OW, int stride, int pt, int pl, int accumulate, void* stream);
+int satrn_dwconv3x3_bwd_weight(int dtype, const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W,
+                               int C, int OH, int OW, int stride, int pt, int pl, void* stream);
+
+/* BatchNorm2d (batch statistics when train != 0, running statistics otherwise) fused with the activation
+ * that follows it and an optional residual added AFTER the activation: z = act(bn(y)) (+ res).
+ * networks/LiteSATRN.py:52-69, networks/EfficientSATRN.py:83,86,272-279 and the timm blocks.
+ * scratch: 6*C floats; the first 2*C must be ZERO on entry; after the call scratch[2C..4C) = scale/shift and
+ * scratch[4C..6C) = mean/rstd, which satrn_batchnorm_act_bwd needs.  running_* are updated in place
+ * (momentum 0.1, unbiased variance) when train != 0. */
+int satrn_batchnorm_act_fwd(int dtype, const void* y, const float* weight, const float* bias, float* running_mean,
+                            float* running_var, int64_t* num_batches_tracked, float eps, int train, int act,
+                            const void* res, void* z, long M, int C, float* scratch, void* stream);
+/* dy = d(loss)/d(y) given dz; dweight/dbias accumulate (+=).  scratch2: 2*C floats, ZERO on entry. */
+int satrn_batchnorm_act_bwd(int dtype, const void* dz, const void* y, const float* weight, const float* scratch,
+                            int act, void* dy, float* dweight, float* dbias, long M, int C, float* scratch2,
+                            void* stream);
+
+/* MaxPool2d(2,2): networks/LiteSATRN.py:53,58,63,68.  bwd recomputes the argmax (first maximum wins). */
+int satrn_maxpool2x2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream);
+int satrn_maxpool2x2_bwd(int dtype, const void* x, const void* dy, void* dx, int B, int H, int W, int C, void* stream);
+
+/* LayerNorm over the last dim of (a + b) (b may be NULL): networks/EfficientSATRN.py:265,268,378,382,385.
+ * mean_rstd: 2*R floats saved for the backward. */
+int satrn_layernorm_fwd(int dtype, const void* a, const void* b, const float* weight, const float* bias, void* out,
+                        float* mean_rstd, long R, int C, float eps, void* stream);
+int satrn_layernorm_bwd(int dtype, const void* dout, const void* a, const void* b, const float* weight,
+                        const float* mean_rstd, void* da, void* db, int acc_a, int acc_b, float* dweight, float* dbias,
+                        long R, int C, void* stream);
+
+/* Adaptive 2D positional encoding, networks/EfficientSATRN.py:135-154: out = x + g0*hpos[h] + g1*wpos[w]
+ * with gate [B][2C] = sigmoid(dense1(relu(dense0(mean_hw x)))) computed by satrn_pool_hw + satrn_linear_fwd. */
+int satrn_pool_hw(int dtype, const void* x, void* out, int B, int HW, int C, void* stream);
+int satrn_posenc2d_fwd(int dtype, const void* x, const void* gate, const float* hpos, const float* wpos, void* out,
+                       int B, int H, int W, int C, void* stream);
+int satrn_posenc2d_bwd_gate(int dtype, const void* dout, const float* hpos, const float* wpos, void* dgate, int B, int H,
+                            int W, int C, void* stream);
+
+/* The EncoderLayer raw reshape (networks/EfficientSATRN.py:269): the [b,hw,c] buffer reinterpreted as
+ * [b,c,h,w], delivered in NHWC.  inverse != 0 routes gradients back. */
+int satrn_encoder_reshape(int dtype, int inverse, const void* in, void* out, int B, int HW, int C, int accumulate,
+                          void* stream);
+
+/* Scaled dot-product attention with the reference's temperature sqrt(heads*head_dim), -inf masks and
+ * attention-probability dropout: networks/EfficientSATRN.py:164-172 inside :198-228.
+ * q [B,Lq,ldq] / k,v [B,Lk,ldk] are column slices (head h at columns h*hd) of projection outputs; o [B,Lq,ldo].
+ * text (int64 [B][ld_text], may be NULL): key j>0 is masked when text[b][j] == pad_id (:469-473);
+ * causal != 0 masks key j > query i (:475-478).  lse [B,heads,Lq] is saved for the backward. */
+int satrn_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int heads,
+                        int Lq, int Lk, int hd, int ldq, int ldk, int ldv, int ldo, int causal, const int64_t* text,
+                        int ld_text, int pad_id, float temperature, float drop_p, const uint32_t* seed, uint32_t site,
+                        void* stream);
+/* ws: 2 * B*heads*Lq*roundup(Lk,32) elements of the compute dtype.  dq/dk/dv have the strides of q/k/v. */
+int satrn_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const float* lse,
+                        const void* d_o, void* dq, void* dk, void* dv, void* ws, int B, int heads, int Lq, int Lk, int hd,
+                        int ldq, int ldk, int ldv, int ldo, int causal, const int64_t* text, int ld_text, int pad_id,
+                        float temperature, float drop_p, const uint32_t* seed, uint32_t site, void* stream);
+
+/* Token embedding * sqrt(D) + interleaved sin/cos positional table (+dropout):
+ * networks/EfficientSATRN.py:480-483 and :400-426.  ids int64 [B][ld_ids]; pe fp32 [max_len][D]. */
+int satrn_embedding_fwd(int dtype, const int64_t* ids, int ld_ids, const float* table, const float* pe, void* out, int B,
+                        int L, int D, int pos0, float drop_p, const uint32_t* seed, uint32_t site, void* stream);
+int satrn_embedding_bwd(int dtype, const int64_t* ids, int ld_ids, const void* dout, float* dtable, int B, int L, int D,
+                        float drop_p, const uint32_t* seed, uint32_t site, void* stream);
+
+/* CrossEntropyLoss(ignore_index) on fp32 logits [B*T][V] against targets = &expected[0][1] (int64, row stride ld):
+ * networks/EfficientSATRN.py:690-692 as used by train_modules/train_single_opt.py:82,86.
+ * loss_out[0..2] = sum, count, mean.  dlogits [B*T][Vp] (compute dtype, zero padded) = d(mean loss)/d(logits).
+ * lse_ws: B*T floats. */
+int satrn_cross_entropy(int dtype, const float* logits, const int64_t* targets, int ld, int B, int T, int V, int Vp,
+                        int pad_id, float* loss_out, float* lse_ws, void* dlogits, void* stream);
+
+/* clip_grad_norm_(max_norm) + AdamW.step over flat fp32 buffers: train_modules/train_single_opt.py:95-98.
+ * gnorm_sq: device float, ZERO on entry (receives sum of squares).  hyper (device, 9 floats):
+ * lr, beta1, beta2, eps, weight_decay, max_norm, 1-beta1^t, 1-beta2^t, grad_scale. */
+int satrn_clip_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float* gnorm_sq,
+                     const float* hyper, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Model level: the whole nn.Module path behind one handle.
+ * Replaces EfficientSATRN / LiteSATRN .forward (networks/EfficientSATRN.py:697-706,
+ * networks/LiteSATRN.py:581-590), loss.backward() + clip + optimizer.step
+ * (train_modules/train_single_opt.py:86-98) and the greedy branch (networks/EfficientSATRN.py:528-561).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct satrn_model satrn_model;
+
+typedef struct satrn_config {
+  int network; /* 0 LiteSATRN, 1 EfficientSATRN */
+  int rgb;     /* FLAGS.data.rgb */
+  int height, width;
+  int enc_hidden, enc_filter, enc_heads, enc_layers;
+  int dec_src, dec_hidden, dec_filter, dec_heads, dec_layers;
+  int num_classes;
+  int pad_id, sos_id;
+  float dropout; /* FLAGS.dropout_rate */
+  int dtype;
+} satrn_config;
+
+satrn_model* satrn_model_create(const satrn_config* cfg);
+void satrn_model_destroy(satrn_model* m);
+/* state table = the reference's state_dict keys, in the engine's flat order */
+int satrn_model_num_state(const satrn_model* m);
+const char* satrn_model_state_name(const satrn_model* m, int i);
+/* kind: 0 parameter (fp32 flat), 1 fp32 buffer (BN running stats), 2 int64 buffer (num_batches_tracked);
+ * init: 0 xavier_normal, 1 conv default, 2 linear default, 3 bias default (fan_in), 4 ones, 5 zeros, 6 N(0,1) */
+int satrn_model_state_info(const satrn_model* m, int i, int* kind, int* ndim, int64_t* shape4, int64_t* offset,
+                           int* init, int* fan_in, int* fan_out);
+int64_t satrn_model_flat_size(const satrn_model* m, int kind);
+/* borrow flat buffers until the next bind / destroy (grads may be NULL for inference) */
+int satrn_model_bind(satrn_model* m, float* params, float* grads, float* buf_f32, int64_t* buf_i64);
+size_t satrn_model_workspace_bytes(satrn_model* m, int B, int L);
+int satrn_model_set_workspace(satrn_model* m, void* ws, size_t bytes, void* stream);
+int satrn_model_pack_weights(satrn_model* m, void* stream);
+/* teacher-forced forward; logits fp32 [B][L-1][V]; record != 0 keeps the tape for a backward */
+int satrn_model_forward(satrn_model* m, const float* images, const int64_t* expected, int B, int L, int train, int record,
+                        float* logits, void* stream);
+/* backward from d(loss)/d(logits) (fp32 [B][L-1][V]); parameter grads ACCUMULATE into the bound grads */
+int satrn_model_backward(satrn_model* m, const float* dlogits, void* stream);
+/* fused CE on the last forward's logits + backward (loss readable with satrn_model_read_loss) */
+int satrn_model_loss_backward(satrn_model* m, const int64_t* expected, int B, int L, void* stream);
+/* forward + CE + backward + clip + AdamW + re-pack; hyper9 is a HOST array (see satrn_clip_adamw; entries 6,7
+ * are filled in by the library).  use_graph != 0 replays one captured hipGraph per (B, L): images / expected must
+ * then stay at the same device addresses from call to call.  phase: bit 0 = zero grads + forward + CE + backward,
+ * bit 1 = clip + AdamW + re-pack (data-parallel callers all-reduce the flat gradient between the two). */
+int satrn_model_train_step(satrn_model* m, const float* images, const int64_t* expected, int B, int L,
+                           const float* hyper9, int use_graph, int phase, void* stream);
+int satrn_model_read_loss(satrn_model* m, float* out4_host, void* stream); /* sum, count, mean, gnorm^2; syncs */
+int satrn_model_encode(satrn_model* m, const float* images, int B, float* src_out, void* stream);
+/* KV-cached greedy decode; images may be NULL when src (fp32 [B][N][dec_src]) is given.
+ * logits fp32 [B][steps][V]; ids int64 [B][steps] */
+int satrn_model_greedy(satrn_model* m, const float* images, const float* src, int B, int steps, float* logits,
+                       int64_t* ids, void* stream);
+/* adam state access for checkpointing / tests (device pointers inside the workspace) */
+float* satrn_model_adam_state(satrn_model* m, int which /*0 exp_avg, 1 exp_avg_sq*/);
+int satrn_model_set_step(satrn_model* m, long t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,9 @@
+"""MI355X-native SATRN hot path: HIP kernels + C-ABI (csrc/, libsatrn_hip.so) and the host-side mirror of the
+reference's module interface (networks.py, utils.py).  No CPU fallback: every compute path goes through the library."""
+from . import _lib
+from ._lib import SatrnError
+from .networks import EfficientSATRN, LiteSATRN, EfficientSATRN_encoder, EfficientSATRN_decoder, SATRNCrossEntropy
+from .utils import get_network, load_vocab, Flags, START, END, PAD, SPECIAL_TOKENS
+
+__all__ = ["EfficientSATRN", "LiteSATRN", "EfficientSATRN_encoder", "EfficientSATRN_decoder", "SATRNCrossEntropy",
+           "get_network", "load_vocab", "Flags", "SatrnError", "START", "END", "PAD", "SPECIAL_TOKENS"]

@@ -1,0 +1,157 @@
+// Shared device helpers for the SATRN gfx950 kernels: 16-byte chunk I/O, bf16/f32 traits,
+// MFMA fragments and the swizzled LDS "k-panel" layout used by every contraction kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+typedef __bf16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define DEVI __device__ __forceinline__
+
+
+template <typename T> struct TT;
+template <> struct TT<float> {
+  static constexpr int CH = 4;   // elements per 16-byte chunk
+  static constexpr int CPR = 8;  // chunks per 32-element panel row
+};
+template <> struct TT<bf16_t> {
+  static constexpr int CH = 8;
+  static constexpr int CPR = 4;
+};
+
+DEVI float to_f(float x) { return x; }
+DEVI float to_f(bf16_t x) { return (float)x; }
+template <typename T> DEVI T from_f(float x);
+template <> DEVI float from_f<float>(float x) { return x; }
+template <> DEVI bf16_t from_f<bf16_t>(float x) { return (bf16_t)x; }
+
+// ---- 16-byte chunks -----------------------------------------------------------------
+DEVI uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+DEVI void st16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+DEVI uint4 zero16() { return make_uint4(0u, 0u, 0u, 0u); }
+
+template <typename T> DEVI void unpack(uint4 v, float* o);
+template <> DEVI void unpack<float>(uint4 v, float* o) {
+  o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y);
+  o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+}
+template <> DEVI void unpack<bf16_t>(uint4 v, float* o) {
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+  o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+DEVI uint32_t pack2bf(float a, float b) {
+  uint16_t lo = __builtin_bit_cast(uint16_t, (bf16_t)a);
+  uint16_t hi = __builtin_bit_cast(uint16_t, (bf16_t)b);
+  return (uint32_t)lo | ((uint32_t)hi << 16);
+}
+template <typename T> DEVI uint4 pack(const float* i);
+template <> DEVI uint4 pack<float>(const float* i) {
+  return make_uint4(__float_as_uint(i[0]), __float_as_uint(i[1]), __float_as_uint(i[2]), __float_as_uint(i[3]));
+}
+template <> DEVI uint4 pack<bf16_t>(const float* i) {
+  return make_uint4(pack2bf(i[0], i[1]), pack2bf(i[2], i[3]), pack2bf(i[4], i[5]), pack2bf(i[6], i[7]));
+}
+
+// ---- activations ----------------------------------------------------------------------
+DEVI float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+DEVI float act_fwd(float u, int act) {
+  if (act == ACT_RELU) return u > 0.f ? u : 0.f;
+  if (act == ACT_SILU) return u * sigmoidf_(u);
+  if (act == ACT_SIGMOID) return sigmoidf_(u);
+  return u;
+}
+// derivative of act at pre-activation u
+DEVI float act_bwd(float u, int act) {
+  if (act == ACT_RELU) return u > 0.f ? 1.f : 0.f;
+  if (act == ACT_SILU) { float s = sigmoidf_(u); return s * (1.f + u * (1.f - s)); }
+  if (act == ACT_SIGMOID) { float s = sigmoidf_(u); return s * (1.f - s); }
+  return 1.f;
+}
+
+// ---- counter-based dropout: keep-scale for element `idx` of dropout site `site` ------------
+// seed lives in device memory so a captured hipGraph sees a fresh value every replay.
+DEVI uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+DEVI float drop_scale(uint32_t seed, uint32_t site, uint32_t idx, float p) {
+  // p == 0 -> always 1
+  uint32_t h = mix32(idx * 0x9E3779B1u + mix32(seed + site * 0x85EBCA77u));
+  float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  return u < p ? 0.f : 1.0f / (1.0f - p);
+}
+
+// ---- wave reductions (64 lanes) ----------------------------------------------------------
+DEVI float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+DEVI float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- LDS k-panel layout ---------------------------------------------------------------------
+// An operand tile [rows][K] (K contiguous = the contraction dim) is stored as ceil(K/32) panels
+// of [rows][32] elements; inside a panel row the 16-byte chunks are XOR-swizzled so that the
+// MFMA fragment reads (lane -> row lane&15, k-group lane>>4) are bank-conflict free.
+template <typename T> DEVI int swz(int row, int chunk);
+template <> DEVI int swz<bf16_t>(int row, int chunk) { return chunk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3); }
+template <> DEVI int swz<float>(int row, int chunk) { return chunk ^ (row & 7); }
+
+// element offset of (row, k) inside ONE panel (k in [0,32))
+template <typename T> DEVI int panel_elem(int row, int k) {
+  constexpr int CH = TT<T>::CH;
+  return row * 32 + swz<T>(row, k / CH) * CH + (k % CH);
+}
+// element offset of chunk `c` (16 bytes) of `row`
+template <typename T> DEVI int panel_chunk(int row, int c) { return row * 32 + swz<T>(row, c) * TT<T>::CH; }
+
+// ---- MFMA fragments: 8 consecutive k-elements of one row, k-group q = lane>>4 ---------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { uint4 v; };
+template <> struct Frag<float> { uint4 v0, v1; };
+
+template <typename T> DEVI Frag<T> load_frag(const T* panel, int row, int q);
+template <> DEVI Frag<bf16_t> load_frag<bf16_t>(const bf16_t* panel, int row, int q) {
+  Frag<bf16_t> f;
+  f.v = ld16(panel + panel_chunk<bf16_t>(row, q));
+  return f;
+}
+template <> DEVI Frag<float> load_frag<float>(const float* panel, int row, int q) {
+  Frag<float> f;
+  f.v0 = ld16(panel + panel_chunk<float>(row, 2 * q));
+  f.v1 = ld16(panel + panel_chunk<float>(row, 2 * q + 1));
+  return f;
+}
+
+// acc(16x16) += A(16x32) * B(32x16).  Lane l holds A[l&15][8*(l>>4)+j] and B[8*(l>>4)+j][l&15];
+// result: col = l&15, row = (l>>4)*4 + reg.  For f32 the 32-deep step is eight exact-f32
+// 16x16x4 MFMAs; the k order inside the step is permuted identically for A and B.
+DEVI void mma(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, b.v), c, 0, 0, 0);
+}
+DEVI void mma(const Frag<float>& a, const Frag<float>& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.v0.x), __uint_as_float(b.v0.x), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.v0.y), __uint_as_float(b.v0.y), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.v0.z), __uint_as_float(b.v0.z), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.v0.w), __uint_as_float(b.v0.w), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.v1.x), __uint_as_float(b.v1.x), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.v1.y), __uint_as_float(b.v1.y), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.v1.z), __uint_as_float(b.v1.z), c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.v1.w), __uint_as_float(b.v1.w), c, 0, 0, 0);
+}
+
+// XCD-aware block remap (bijective for any grid size): consecutive logical tiles land on one XCD.
+DEVI int xcd_remap(int bid, int nwg) {
+  int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}

@@ -1,0 +1,1030 @@
+// SATRN engine: model tables, op tape (forward + recorded backward), training step, greedy decode.
+// Reference behaviour followed (paths relative to the reference repo):
+//   networks/EfficientSATRN.py:63-87 (EfficientNet), :90-154 (PositionalEncoding), :157-228 (attention),
+//   :231-281 (EncoderLayer, shared LayerNorm + raw reshape), :326-397 (Feedforward / TransformerDecoderLayer),
+//   :400-426 (PositionEncoder1D), :429-566 (SATRNDecoder), networks/LiteSATRN.py:21-70 (ShallowCNN),
+//   train_modules/train_single_opt.py:80-98 (loss, backward, clip, AdamW).
+#include "engine.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+void launch_act_fwd(int dt, const void* u, void* z, long n, int act, hipStream_t s);
+
+#define LCH(e, call) do { if (!(e).dry) { call; } } while (0)
+
+// =====================================================================================================
+// Exec: arena + tape
+// =====================================================================================================
+void Exec::reset(char* b, size_t c, char* zb, size_t zc) {
+  base = b; cap = c; off = 0; zbase = zb; zcap = zc; zoff = 0; site = 1;
+  tape.clear(); tens.clear(); logits = nullptr; src = nullptr; oom = false;
+}
+void* Exec::alloc(size_t bytes) {
+  size_t a = (off + 255) & ~(size_t)255;
+  off = a + bytes;
+  if (off > peak) peak = off;
+  if (!dry && off > cap) { oom = true; return base; }
+  return base + a;
+}
+float* Exec::zalloc(size_t n) {
+  size_t a = (zoff + 63) & ~(size_t)63;
+  zoff = a + n * sizeof(float);
+  if (zoff > zcap) { oom = true; return (float*)zbase; }
+  return (float*)(zbase + a);
+}
+Tensor* Exec::newt(long rows, int C, int B, int H, int W, bool f32) {
+  tens.emplace_back(new Tensor());
+  Tensor* t = tens.back().get();
+  t->rows = rows; t->C = C; t->B = B; t->H = H; t->W = W; t->f32 = f32;
+  t->p = alloc((size_t)rows * C * (f32 ? 4 : esz()));
+  return t;
+}
+void* Exec::grad(Tensor* t, int* beta) {
+  if (!t->g) t->g = alloc((size_t)t->rows * t->C * esz());
+  if (beta) *beta = t->g_init ? 1 : 0;
+  t->g_init = true;
+  return t->g;
+}
+
+// =====================================================================================================
+// model tables
+// =====================================================================================================
+namespace {
+struct Builder {
+  Model* m;
+  int64_t addp(const std::string& name, std::vector<int64_t> shape, int init, int fan_in, int fan_out) {
+    StateEntry e;
+    e.name = name; e.shape = shape; e.kind = ST_PARAM; e.offset = m->n_params; e.init = init;
+    e.fan_in = fan_in; e.fan_out = fan_out;
+    e.numel = 1;
+    for (auto d : shape) e.numel *= d;
+    m->n_params += e.numel;
+    m->state.push_back(e);
+    return e.offset;
+  }
+  int64_t addb(const std::string& name, std::vector<int64_t> shape, int kind, int init) {
+    StateEntry e;
+    e.name = name; e.shape = shape; e.kind = kind; e.init = init; e.fan_in = e.fan_out = 0;
+    e.numel = 1;
+    for (auto d : shape) e.numel *= d;
+    if (kind == ST_BUF_F32) { e.offset = m->n_buf_f32; m->n_buf_f32 += e.numel; }
+    else { e.offset = m->n_buf_i64; m->n_buf_i64 += e.numel; }
+    m->state.push_back(e);
+    return e.offset;
+  }
+  Vec vec(const std::string& name, int n, int init, int fan_in = 0) {
+    Vec v; v.n = n; v.off = addp(name, {n}, init, fan_in, 0);
+    return v;
+  }
+  Wt dense(const std::string& name, int N, int K, int init, bool conv_shape = false) {
+    Wt w; w.kind = WK_DENSE; w.N = N; w.K = K; w.Co = N; w.Ci = K; w.taps = 1; w.ldb = (N + 7) & ~7;
+    std::vector<int64_t> shp = conv_shape ? std::vector<int64_t>{N, K, 1, 1} : std::vector<int64_t>{N, K};
+    w.off = addp(name, shp, init, K, N);
+    return w;
+  }
+  Wt conv3(const std::string& name, int Co, int Ci, int init, bool stem = false) {
+    Wt w; w.kind = stem ? WK_STEM : WK_CONV3; w.N = Co; w.K = 9 * Ci; w.Co = Co; w.Ci = Ci; w.taps = 9; w.ldb = Co;
+    w.off = addp(name, {Co, Ci, 3, 3}, init, Ci * 9, Co * 9);
+    return w;
+  }
+  Wt dwc(const std::string& name, int C, int init) {
+    Wt w; w.kind = WK_DW; w.N = C; w.K = 9; w.Co = C; w.Ci = 1; w.taps = 9;
+    w.off = addp(name, {C, 1, 3, 3}, init, 9, C * 9);
+    return w;
+  }
+  BNp bn(const std::string& name, int C, float eps) {
+    BNp b; b.C = C; b.eps = eps;
+    b.w = vec(name + ".weight", C, 4);
+    b.b = vec(name + ".bias", C, 5);
+    b.rm_off = addb(name + ".running_mean", {C}, ST_BUF_F32, 5);
+    b.rv_off = addb(name + ".running_var", {C}, ST_BUF_F32, 4);
+    b.nbt_off = addb(name + ".num_batches_tracked", {}, ST_BUF_I64, 5);
+    return b;
+  }
+  LNp ln(const std::string& name, int C) {
+    LNp l; l.C = C;
+    l.w = vec(name + ".weight", C, 4);
+    l.b = vec(name + ".bias", C, 5);
+    return l;
+  }
+  // flat order: q.w k.w v.w q.b k.b v.b out.w out.b  (so [q;k;v] and [k;v] are contiguous fused operands)
+  MHAp mha(const std::string& name, int D, int Ksrc, int heads) {
+    MHAp a; a.D = D; a.heads = heads; a.cross = (Ksrc != D);
+    int64_t qo = addp(name + ".q_linear.weight", {D, D}, 0, D, D);
+    int64_t ko = addp(name + ".k_linear.weight", {D, Ksrc}, 0, Ksrc, D);
+    addp(name + ".v_linear.weight", {D, Ksrc}, 0, Ksrc, D);
+    int64_t qb = addp(name + ".q_linear.bias", {D}, 3, D, 0);
+    int64_t kb = addp(name + ".k_linear.bias", {D}, 3, Ksrc, 0);
+    addp(name + ".v_linear.bias", {D}, 3, Ksrc, 0);
+    a.qkv.kind = WK_DENSE; a.qkv.off = qo; a.qkv.K = D; a.qkv.N = a.cross ? D : 3 * D;
+    a.qkv.ldb = a.qkv.N; a.qkv.Co = a.qkv.N; a.qkv.Ci = D;
+    a.bqkv.off = qb; a.bqkv.n = a.qkv.N;
+    // kv view always exists (the step decoder projects K/V separately from Q)
+    a.kv.kind = WK_DENSE; a.kv.off = ko; a.kv.K = Ksrc; a.kv.N = 2 * D; a.kv.ldb = 2 * D; a.kv.Co = 2 * D; a.kv.Ci = Ksrc;
+    a.bkv.off = kb; a.bkv.n = 2 * D;
+    a.out = dense(name + ".out_linear.weight", D, D, 0);
+    a.bout = vec(name + ".out_linear.bias", D, 3, D);
+    return a;
+  }
+};
+
+// EfficientNetV2-S block table (timm==0.4.9 tf_efficientnetv2_s; third-party)
+struct StageDef { int type, rep, stride, exp, cout; float se; };
+const StageDef kEffV2S[6] = {{0, 2, 1, 1, 24, 0.f},   {1, 4, 2, 4, 48, 0.f},   {1, 4, 2, 4, 64, 0.f},
+                             {2, 6, 2, 4, 128, .25f}, {2, 9, 1, 6, 160, .25f}, {2, 15, 2, 6, 256, .25f}};
+}  // namespace
+
+Model* model_create(const SatrnConfig& cfg) {
+  Model* m = new Model();
+  m->cfg = cfg;
+  Builder b{m};
+  const int D = cfg.enc_hidden;
+  if (cfg.network == 0) {
+    int ch[5] = {cfg.rgb, D / 2, D, D, D};
+    for (int i = 0; i < 4; ++i) {
+      std::string n = "encoder.shallow_cnn.conv" + std::to_string(i) + ".weight";
+      m->lite_conv.push_back(b.conv3(n, ch[i + 1], ch[i], i < 3 ? 0 : 1, i == 0));
+      m->lite_bn.push_back(b.bn("encoder.shallow_cnn.batch_norm" + std::to_string(i), ch[i + 1], 1e-5f));
+    }
+  } else {
+    const std::string p = "encoder.shallow_cnn.";
+    m->stem = b.conv3(p + "conv_stem.weight", 24, cfg.rgb, 1, true);
+    m->stem_bn = b.bn(p + "bn1", 24, 1e-3f);
+    int cin = 24;
+    for (int s = 0; s < 6; ++s) {
+      for (int i = 0; i < kEffV2S[s].rep; ++i) {
+        const StageDef& sd = kEffV2S[s];
+        EffBlock eb;
+        eb.type = sd.type; eb.cin = cin; eb.cout = sd.cout; eb.mid = cin * sd.exp; eb.stride = i == 0 ? sd.stride : 1;
+        eb.se = sd.se > 0 ? (int)(cin * sd.se) : 0;
+        eb.skip = eb.stride == 1 && cin == sd.cout;
+        std::string q = p + "eff_block." + std::to_string(s) + "." + std::to_string(i) + ".";
+        if (sd.type == 0) {
+          eb.c0 = b.conv3(q + "conv.weight", eb.cout, cin, 1);
+          eb.bn1 = b.bn(q + "bn1", eb.cout, 1e-3f);
+        } else if (sd.type == 1) {
+          eb.c0 = b.conv3(q + "conv_exp.weight", eb.mid, cin, 1);
+          eb.bn1 = b.bn(q + "bn1", eb.mid, 1e-3f);
+          eb.c1 = b.dense(q + "conv_pwl.weight", eb.cout, eb.mid, 1, true);
+          eb.bn2 = b.bn(q + "bn2", eb.cout, 1e-3f);
+        } else {
+          eb.c0 = b.dense(q + "conv_pw.weight", eb.mid, cin, 1, true);
+          eb.bn1 = b.bn(q + "bn1", eb.mid, 1e-3f);
+          eb.dw = b.dwc(q + "conv_dw.weight", eb.mid, 1);
+          eb.bn2 = b.bn(q + "bn2", eb.mid, 1e-3f);
+          eb.se_r = b.dense(q + "se.conv_reduce.weight", eb.se, eb.mid, 1, true);
+          eb.se_rb = b.vec(q + "se.conv_reduce.bias", eb.se, 3, eb.mid);
+          eb.se_e = b.dense(q + "se.conv_expand.weight", eb.mid, eb.se, 1, true);
+          eb.se_eb = b.vec(q + "se.conv_expand.bias", eb.mid, 3, eb.se);
+          eb.c1 = b.dense(q + "conv_pwl.weight", eb.cout, eb.mid, 1, true);
+          eb.bn3 = b.bn(q + "bn3", eb.cout, 1e-3f);
+        }
+        m->blocks.push_back(eb);
+        cin = sd.cout;
+      }
+    }
+    m->conv_last = b.dense(p + "conv_last.weight", D, 256, 1, true);
+    m->bn_last = b.bn(p + "bn2", D, 1e-5f);
+  }
+  m->pe_d0 = b.dense("encoder.positional_encoding.dense0.weight", D / 2, D, 0);
+  m->pe_b0 = b.vec("encoder.positional_encoding.dense0.bias", D / 2, 3, D);
+  m->pe_d1 = b.dense("encoder.positional_encoding.dense1.weight", 2 * D, D / 2, 0);
+  m->pe_b1 = b.vec("encoder.positional_encoding.dense1.bias", 2 * D, 3, D / 2);
+  const int Fe = cfg.enc_filter;
+  for (int l = 0; l < cfg.enc_layers; ++l) {
+    std::string q = "encoder.attention_layers." + std::to_string(l) + ".";
+    EncLayer el;
+    el.norm = b.ln(q + "norm", D);
+    el.att = b.mha(q + "attention_layer", D, D, cfg.enc_heads);
+    el.conv0 = b.dense(q + "conv0.weight", Fe, D, 0, true);
+    el.norm0 = b.bn(q + "norm0", Fe, 1e-5f);
+    el.dw = b.dwc(q + "depthwise.weight", Fe, 0);
+    el.dwb = b.vec(q + "depthwise.bias", Fe, 3, 9);
+    el.dwnorm = b.bn(q + "depthwise_norm", Fe, 1e-5f);
+    el.conv1 = b.dense(q + "conv1.weight", D, Fe, 0, true);
+    el.norm1 = b.bn(q + "norm1", D, 1e-5f);
+    m->enc.push_back(el);
+  }
+  const int Dd = cfg.dec_hidden, Ds = cfg.dec_src, Ff = cfg.dec_filter, V = cfg.num_classes;
+  m->embed.kind = WK_STEM; m->embed.N = V + 1; m->embed.K = Dd;
+  m->embed.off = b.addp("decoder.embedding.weight", {V + 1, Dd}, 6, 0, 0);
+  for (int l = 0; l < cfg.dec_layers; ++l) {
+    std::string q = "decoder.attention_layers." + std::to_string(l) + ".";
+    DecLayer dl;
+    dl.self_att = b.mha(q + "self_attention_layer", Dd, Dd, cfg.dec_heads);
+    dl.ln1 = b.ln(q + "self_attention_norm", Dd);
+    dl.cross_att = b.mha(q + "attention_layer", Dd, Ds, cfg.dec_heads);
+    dl.cross_att.cross = true;
+    dl.cross_att.qkv.N = Dd; dl.cross_att.qkv.ldb = Dd; dl.cross_att.qkv.Co = Dd; dl.cross_att.bqkv.n = Dd;
+    dl.ln2 = b.ln(q + "attention_norm", Dd);
+    dl.lin0 = b.dense(q + "feedforward_layer.linear0.weight", Ff, Dd, 0);
+    dl.b0 = b.vec(q + "feedforward_layer.linear0.bias", Ff, 3, Dd);
+    dl.lin1 = b.dense(q + "feedforward_layer.linear1.weight", Dd, Ff, 0);
+    dl.b1 = b.vec(q + "feedforward_layer.linear1.bias", Dd, 3, Ff);
+    dl.ln3 = b.ln(q + "feedforward_norm", Dd);
+    m->dec.push_back(dl);
+  }
+  m->gen = b.dense("decoder.generator.weight", V, Dd, 2);
+  m->gen_b = b.vec("decoder.generator.bias", V, 3, Dd);
+
+  // registries (pointers into the now-stable containers)
+  auto regw = [&](Wt& w) { m->all_w.push_back(&w); };
+  auto regv = [&](Vec& v) { m->all_v.push_back(&v); };
+  auto regbn = [&](BNp& x) { m->all_bn.push_back(&x); regv(x.w); regv(x.b); };
+  auto regln = [&](LNp& x) { regv(x.w); regv(x.b); };
+  auto regmha = [&](MHAp& a) { regw(a.qkv); regw(a.kv); regv(a.bqkv); regv(a.bkv); regw(a.out); regv(a.bout); };
+  if (cfg.network == 0) {
+    for (auto& w : m->lite_conv) regw(w);
+    for (auto& x : m->lite_bn) regbn(x);
+  } else {
+    regw(m->stem); regbn(m->stem_bn);
+    for (auto& eb : m->blocks) {
+      regw(eb.c0); regbn(eb.bn1);
+      if (eb.type >= 1) { regw(eb.c1); regbn(eb.bn2); }
+      if (eb.type == 2) { regw(eb.dw); regw(eb.se_r); regw(eb.se_e); regv(eb.se_rb); regv(eb.se_eb); regbn(eb.bn3); }
+    }
+    regw(m->conv_last); regbn(m->bn_last);
+  }
+  regw(m->pe_d0); regw(m->pe_d1); regv(m->pe_b0); regv(m->pe_b1);
+  for (auto& el : m->enc) {
+    regln(el.norm); regmha(el.att); regw(el.conv0); regw(el.conv1); regw(el.dw); regv(el.dwb);
+    regbn(el.norm0); regbn(el.dwnorm); regbn(el.norm1);
+  }
+  regw(m->embed);
+  for (auto& dl : m->dec) {
+    regmha(dl.self_att); regmha(dl.cross_att); regln(dl.ln1); regln(dl.ln2); regln(dl.ln3);
+    regw(dl.lin0); regw(dl.lin1); regv(dl.b0); regv(dl.b1);
+  }
+  regw(m->gen); regv(m->gen_b);
+
+  // persistent-region layout: packed weights first
+  size_t esz = cfg.dtype == DT_BF16 ? 2 : 4;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t a = (o + 255) & ~(size_t)255; o = a + bytes; return a; };
+  for (Wt* w : m->all_w) {
+    if (w->kind == WK_DENSE) {
+      w->pk_fwd_off = take((size_t)w->N * w->K * esz);
+      w->pk_bwd_off = take((size_t)w->K * w->ldb * esz);
+    } else if (w->kind == WK_CONV3) {
+      w->pk_fwd_off = take((size_t)w->N * w->K * esz);
+      w->pk_bwd_off = take((size_t)w->Ci * 9 * w->Co * esz);
+    } else if (w->kind == WK_DW) {
+      w->pk_fwd_off = take((size_t)9 * w->Co * esz);
+    }
+  }
+  m->off_packed = 0;
+  m->off_adam_m = take((size_t)m->n_params * 4);
+  m->off_adam_v = take((size_t)m->n_params * 4);
+  m->off_scalars = take(SC_COUNT * 4);
+  m->off_pe1d = take((size_t)500 * Dd * 4);
+  if (cfg.network == 0) { m->feat_h = cfg.height / 16; m->feat_w = cfg.width / 16; }
+  else { m->feat_h = cfg.height / 32; m->feat_w = cfg.width / 32; }
+  m->off_hpos = take((size_t)std::max(m->feat_h, 1) * D * 4);
+  m->off_wpos = take((size_t)std::max(m->feat_w, 1) * D * 4);
+  m->zero_bytes = 8u << 20;
+  m->off_zero = take(m->zero_bytes);
+  m->persist_bytes = (o + 255) & ~(size_t)255;
+  m->ex = new Exec();
+  m->ex->m = m;
+  return m;
+}
+
+void model_destroy(Model* m) {
+  if (!m) return;
+  for (int i = 0; i < 4; ++i) if (m->graphs[i]) (void)hipGraphExecDestroy(m->graphs[i]);
+  if (m->hy_pinned) (void)hipHostFree(m->hy_pinned);
+  delete m->ex;
+  delete m;
+}
+
+int model_bind(Model* m, float* params, float* grads, float* buf_f32, int64_t* buf_i64) {
+  m->params = params; m->grads = grads; m->buf_f32 = buf_f32; m->buf_i64 = buf_i64;
+  for (Wt* w : m->all_w) { w->p = params + w->off; w->g = grads ? grads + w->off : nullptr; }
+  for (Vec* v : m->all_v) { v->p = params + v->off; v->g = grads ? grads + v->off : nullptr; }
+  for (BNp* b : m->all_bn) { b->rm = buf_f32 + b->rm_off; b->rv = buf_f32 + b->rv_off; b->nbt = buf_i64 ? buf_i64 + b->nbt_off : nullptr; }
+  m->bound = true;
+  for (int i = 0; i < 4; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
+  return 0;
+}
+
+static float* scal(Model* m) { return (float*)(m->ws + m->off_scalars); }
+
+int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s) {
+  if (bytes < m->persist_bytes + (1u << 20)) { m->err = "workspace too small"; return -2; }
+  m->ws = (char*)ws; m->ws_bytes = bytes;
+  for (Wt* w : m->all_w) {
+    w->fwd = w->pk_fwd_off >= 0 ? m->ws + w->pk_fwd_off : nullptr;
+    w->bwd = w->pk_bwd_off >= 0 ? m->ws + w->pk_bwd_off : nullptr;
+  }
+  for (int i = 0; i < 4; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
+  // tables: 1-D PE (networks/EfficientSATRN.py:408-418) and 2-D PE (:111-127), built in fp32 like the reference
+  const int Dd = m->cfg.dec_hidden, D = m->cfg.enc_hidden;
+  std::vector<float> pe((size_t)500 * Dd);
+  for (int pos = 0; pos < 500; ++pos)
+    for (int i = 0; i < Dd; ++i) {
+      float rate = 1.0f / powf(10000.0f, (float)(2 * (i / 2)) / (float)Dd);
+      float a = (float)pos * rate;
+      pe[(size_t)pos * Dd + i] = (i & 1) ? cosf(a) : sinf(a);
+    }
+  (void)hipMemcpyAsync(m->ws + m->off_pe1d, pe.data(), pe.size() * 4, hipMemcpyHostToDevice, s);
+  auto tab2d = [&](int len, size_t off) {
+    std::vector<float> t((size_t)std::max(len, 1) * D);
+    int nts = D / 2;
+    float inc = logf(1.0e4f / 1.0f) / ((float)nts - 1.0f);
+    for (int pos = 0; pos < len; ++pos)
+      for (int k = 0; k < nts; ++k) {
+        float inv = expf((float)k * -inc);
+        float st = (float)pos * inv;
+        t[(size_t)pos * D + k] = sinf(st);
+        t[(size_t)pos * D + nts + k] = cosf(st);
+      }
+    (void)hipMemcpyAsync(m->ws + off, t.data(), t.size() * 4, hipMemcpyHostToDevice, s);
+    (void)hipStreamSynchronize(s);
+  };
+  (void)hipStreamSynchronize(s);
+  tab2d(m->feat_h, m->off_hpos);
+  tab2d(m->feat_w, m->off_wpos);
+  (void)hipMemsetAsync(m->ws + m->off_adam_m, 0, (size_t)m->n_params * 4, s);
+  (void)hipMemsetAsync(m->ws + m->off_adam_v, 0, (size_t)m->n_params * 4, s);
+  (void)hipMemsetAsync(m->ws + m->off_scalars, 0, SC_COUNT * 4, s);
+  float one = 1.0f;
+  uint32_t seed0 = 0x1234567u;
+  (void)hipMemcpyAsync(scal(m) + SC_ONE, &one, 4, hipMemcpyHostToDevice, s);
+  (void)hipMemcpyAsync(scal(m) + SC_SEED, &seed0, 4, hipMemcpyHostToDevice, s);
+  (void)hipStreamSynchronize(s);
+  m->ws_set = true;
+  m->adam_t = 0;
+  return 0;
+}
+
+int model_pack_weights(Model* m, hipStream_t s) {
+  if (!m->bound || !m->ws_set) { m->err = "bind + workspace first"; return -1; }
+  const int dt = m->cfg.dtype;
+  for (Wt* w : m->all_w) {
+    if (w->kind == WK_DENSE) launch_pack_dense_ld(dt, w->p, w->fwd, w->bwd, w->N, w->K, w->ldb, s);
+    else if (w->kind == WK_CONV3) launch_pack_conv(dt, w->p, w->fwd, w->bwd, w->Co, w->Ci, 9, s);
+    else if (w->kind == WK_DW) launch_pack_dw(dt, w->p, w->fwd, w->Co, s);
+  }
+  return 0;
+}
+
+// =====================================================================================================
+// ops (forward launch + recorded backward)
+// =====================================================================================================
+namespace {
+struct Geo { int H, W, Ci, OH, OW, KW, stride, pt, pl; };
+
+static void acc_grad(Exec& e, Tensor* t, const void* src) {
+  int beta;
+  void* g = e.grad(t, &beta);
+  long n = t->rows * t->C;
+  if (beta) LCH(e, launch_add(e.dt, g, src, g, n, e.s));
+  else LCH(e, (void)hipMemcpyAsync(g, src, (size_t)n * e.esz(), hipMemcpyDeviceToDevice, e.s));
+}
+
+// y[M][N] = act(gather(x) * W^T + bias) (+dropout).  geo == nullptr: dense over x rows.
+Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, const Geo* geo, int B = 0, bool out_f32 = false,
+                void* out_ptr = nullptr) {
+  const long M = geo ? (long)B * geo->OH * geo->OW : x->rows;
+  const int N = w->N;
+  Tensor* y;
+  if (out_ptr) {
+    e.tens.emplace_back(new Tensor());
+    y = e.tens.back().get();
+    y->rows = M; y->C = N; y->f32 = out_f32; y->p = out_ptr;
+  } else {
+    y = e.newt(M, N, B, geo ? geo->OH : 0, geo ? geo->OW : 0, out_f32);
+  }
+  if (!e.train) drop_p = 0.f;
+  const uint32_t site = drop_p > 0.f ? e.site++ : 0;
+  const uint32_t* seed = (const uint32_t*)(scal(e.m) + SC_SEED);
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = x->p; p.Bw = w->fwd; p.C = y->p; p.bias = bias ? bias->p : nullptr;
+  p.M = (int)M; p.N = N; p.K = w->K; p.lda = x->C; p.ldc = N;
+  p.act = act; p.out_f32 = out_f32 ? 1 : 0; p.drop_p = drop_p; p.seed = seed; p.site = site;
+  if (geo) { p.H = geo->H; p.W = geo->W; p.Ci = geo->Ci; p.OH = geo->OH; p.OW = geo->OW; p.KW = geo->KW; p.stride = geo->stride; p.pt = geo->pt; p.pl = geo->pl; }
+  LCH(e, launch_gemm(e.dt, geo ? AM_CONV : AM_DENSE, p, e.s));
+  if (e.rec) {
+    Geo g{};
+    if (geo) g = *geo;
+    const bool hasgeo = geo != nullptr;
+    e.tape.push_back([&e, x, y, w, bias, act, drop_p, site, seed, g, hasgeo, M, N, B, out_f32]() {
+      if (!y->g) return;
+      const int ldy = out_f32 ? w->ldb : N;
+      void* dY = y->g;
+      if (act == ACT_RELU) LCH(e, launch_act_bwd(e.dt, dY, y->p, dY, M * N, ACT_RELU, drop_p, e.s));
+      else if (act == ACT_SIGMOID) LCH(e, launch_act_bwd(e.dt, dY, y->p, dY, M * N, ACT_SIGMOID, 0.f, e.s));
+      else if (drop_p > 0.f) LCH(e, launch_dropout_bwd(e.dt, dY, dY, M, N, drop_p, seed, site, e.s));
+      if (bias) LCH(e, launch_colsum(e.dt, dY, M, N, ldy, bias->g, e.s));
+      WgradP q;
+      memset(&q, 0, sizeof(q));
+      q.dY = dY; q.A = x->p; q.dW = w->g; q.M = (int)M; q.N = N; q.K = w->K; q.ldy = ldy; q.lda = x->C;
+      q.nbatch = 1; q.nb_inner = 1;
+      if (hasgeo) { q.conv = 1; q.H = g.H; q.W = g.W; q.Ci = g.Ci; q.OH = g.OH; q.OW = g.OW; q.KW = g.KW; q.stride = g.stride; q.pt = g.pt; q.pl = g.pl; }
+      LCH(e, launch_wgrad(e.dt, q, e.s));
+      int beta;
+      void* dx = e.grad(x, &beta);
+      GemmP d;
+      memset(&d, 0, sizeof(d));
+      d.A = dY; d.Bw = w->bwd; d.C = dx; d.beta = beta;
+      if (!hasgeo) {
+        d.M = (int)M; d.N = w->K; d.K = w->ldb; d.lda = ldy; d.ldc = x->C;
+        LCH(e, launch_gemm(e.dt, AM_DENSE, d, e.s));
+      } else {
+        d.M = (int)((long)B * g.H * g.W); d.N = g.Ci; d.K = 9 * w->Co; d.ldc = g.Ci;
+        d.H = g.OH; d.W = g.OW; d.Ci = w->Co; d.OH = g.H; d.OW = g.W; d.KW = g.KW; d.stride = g.stride; d.pt = g.pt; d.pl = g.pl;
+        LCH(e, launch_gemm(e.dt, AM_DGRAD, d, e.s));
+      }
+    });
+  }
+  return y;
+}
+
+Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res) {
+  const int C = bn->C;
+  const long M = y->rows;
+  float* ss = (float*)e.alloc((size_t)2 * C * 4);
+  float* mr = (float*)e.alloc((size_t)2 * C * 4);
+  if (e.train) {
+    float* sums = e.zalloc(2 * C);
+    LCH(e, launch_colstats(e.dt, y->p, M, C, sums, e.s));
+    LCH(e, launch_bn_finalize(sums, M, C, bn->w.p, bn->b.p, bn->rm, bn->rv, bn->nbt, bn->eps, 0.1f, 1, ss, mr, e.s));
+  } else {
+    LCH(e, launch_bn_finalize(nullptr, M, C, bn->w.p, bn->b.p, bn->rm, bn->rv, nullptr, bn->eps, 0.1f, 0, ss, mr, e.s));
+  }
+  Tensor* z = e.newt(M, C, y->B, y->H, y->W);
+  LCH(e, launch_bn_act(e.dt, y->p, ss, res ? res->p : nullptr, z->p, M, C, act, e.s));
+  if (e.rec) {
+    e.tape.push_back([&e, y, z, bn, act, res, ss, mr, M, C]() {
+      if (!z->g) return;
+      float* red = e.zalloc(2 * C);
+      LCH(e, launch_bn_bwd_reduce(e.dt, z->g, y->p, ss, mr, M, C, act, red, e.s));
+      void* dy = e.grad(y, nullptr);
+      LCH(e, launch_bn_bwd_apply(e.dt, z->g, y->p, ss, mr, bn->w.p, red, M, C, act, dy, bn->w.g, bn->b.g, e.s));
+      if (res) acc_grad(e, res, z->g);
+    });
+  }
+  return z;
+}
+
+Tensor* op_stem(Exec& e, const float* img, Wt* w, int B, int Cin, int H, int W, int stride, int pad) {
+  const int OH = (H + 2 * pad - 3) / stride + 1, OW = (W + 2 * pad - 3) / stride + 1;
+  Tensor* y = e.newt((long)B * OH * OW, w->Co, B, OH, OW);
+  LCH(e, launch_stem_conv(e.dt, img, w->p, y->p, B, Cin, H, W, w->Co, OH, OW, stride, pad, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, img, w, y, B, Cin, H, W, OH, OW, stride, pad]() {
+      if (!y->g) return;
+      LCH(e, launch_stem_wgrad(e.dt, img, y->g, w->g, B, Cin, H, W, w->Co, OH, OW, stride, pad, e.s));
+    });
+  return y;
+}
+
+Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int OW, int pt, int pl) {
+  const int B = x->B, H = x->H, W = x->W, C = x->C;
+  Tensor* y = e.newt((long)B * OH * OW, C, B, OH, OW);
+  LCH(e, launch_dwconv(e.dt, 0, x->p, w->fwd, bias ? bias->p : nullptr, y->p, B, H, W, C, OH, OW, stride, pt, pl, 0, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, x, y, w, bias, B, H, W, C, OH, OW, stride, pt, pl]() {
+      if (!y->g) return;
+      LCH(e, launch_dwconv_wgrad(e.dt, x->p, y->g, w->g, bias ? bias->g : nullptr, B, H, W, C, OH, OW, stride, pt, pl, e.s));
+      int beta;
+      void* dx = e.grad(x, &beta);
+      LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, e.s));
+    });
+  return y;
+}
+
+Tensor* op_maxpool(Exec& e, Tensor* x) {
+  const int B = x->B, H = x->H, W = x->W, C = x->C;
+  Tensor* y = e.newt((long)B * (H / 2) * (W / 2), C, B, H / 2, W / 2);
+  LCH(e, launch_maxpool(e.dt, 0, x->p, nullptr, y->p, B, H, W, C, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, x, y, B, H, W, C]() {
+      if (!y->g) return;
+      void* dx = e.grad(x, nullptr);
+      if ((H & 1) || (W & 1)) LCH(e, launch_fill(dx, 0, (size_t)x->rows * C * e.esz(), e.s));
+      LCH(e, launch_maxpool(e.dt, 1, x->p, y->g, dx, B, H, W, C, e.s));
+    });
+  return y;
+}
+
+Tensor* op_pool(Exec& e, Tensor* x) {  // mean over HW -> [B][C]
+  const int B = x->B, HW = x->H * x->W, C = x->C;
+  Tensor* y = e.newt(B, C);
+  LCH(e, launch_pool_hw(e.dt, x->p, y->p, B, HW, C, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, x, y, B, HW, C]() {
+      if (!y->g) return;
+      int beta;
+      void* dx = e.grad(x, &beta);
+      if (!beta) LCH(e, launch_fill(dx, 0, (size_t)x->rows * C * e.esz(), e.s));
+      LCH(e, launch_bcast_add_hw(e.dt, y->g, dx, B, HW, C, 1.0f / (float)HW, e.s));
+    });
+  return y;
+}
+
+Tensor* op_act(Exec& e, Tensor* u, int act) {
+  Tensor* z = e.newt(u->rows, u->C);
+  LCH(e, launch_act_fwd(e.dt, u->p, z->p, u->rows * u->C, act, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, u, z, act]() {
+      if (!z->g) return;
+      void* du = e.grad(u, nullptr);
+      LCH(e, launch_act_bwd(e.dt, z->g, u->p, du, u->rows * u->C, act, 0.f, e.s));
+    });
+  return z;
+}
+
+Tensor* op_se_scale(Exec& e, Tensor* x, Tensor* gate) {
+  const int B = x->B, HW = x->H * x->W, C = x->C;
+  Tensor* y = e.newt(x->rows, C, B, x->H, x->W);
+  LCH(e, launch_se_scale(e.dt, x->p, gate->p, y->p, B, HW, C, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, x, gate, y, B, HW, C]() {
+      if (!y->g) return;
+      void* dg = e.grad(gate, nullptr);
+      LCH(e, launch_se_bwd_gate(e.dt, y->g, x->p, dg, B, HW, C, e.s));
+      int beta;
+      void* dx = e.grad(x, &beta);
+      LCH(e, launch_se_bwd_x(e.dt, y->g, gate->p, nullptr, dx, B, HW, C, beta, e.s));
+    });
+  return y;
+}
+
+Tensor* op_posenc_apply(Exec& e, Tensor* x, Tensor* gate) {
+  Model* m = e.m;
+  const int B = x->B, H = x->H, W = x->W, C = x->C;
+  const float* hpos = (const float*)(m->ws + m->off_hpos);
+  const float* wpos = (const float*)(m->ws + m->off_wpos);
+  Tensor* y = e.newt(x->rows, C, B, H, W);
+  LCH(e, launch_posenc2d(e.dt, x->p, gate->p, hpos, wpos, y->p, B, H, W, C, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, x, gate, y, hpos, wpos, B, H, W, C]() {
+      if (!y->g) return;
+      void* dg = e.grad(gate, nullptr);
+      LCH(e, launch_posenc2d_bwd(e.dt, y->g, hpos, wpos, dg, B, H, W, C, e.s));
+      acc_grad(e, x, y->g);
+    });
+  return y;
+}
+
+Tensor* op_ln(Exec& e, Tensor* a, Tensor* b, LNp* ln) {
+  const long R = a->rows;
+  const int C = a->C;
+  Tensor* y = e.newt(R, C, a->B, a->H, a->W);
+  float* mr = (float*)e.alloc((size_t)2 * R * 4);
+  LCH(e, launch_layernorm(e.dt, a->p, b ? b->p : nullptr, ln->w.p, ln->b.p, y->p, mr, R, C, 1e-5f, 0.f, nullptr, 0, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, a, b, y, ln, mr, R, C]() {
+      if (!y->g) return;
+      int ba = 0, bb = 0;
+      void* da = e.grad(a, &ba);
+      void* db = b ? e.grad(b, &bb) : nullptr;
+      LCH(e, launch_layernorm_bwd(e.dt, y->g, a->p, b ? b->p : nullptr, ln->w.p, mr, da, db, ba, bb, ln->w.g, ln->b.g, R, C,
+                                  0.f, nullptr, 0, e.s));
+    });
+  return y;
+}
+
+Tensor* op_quirk(Exec& e, Tensor* yv) {  // networks/EfficientSATRN.py:269
+  const int B = yv->B, HW = yv->H * yv->W, C = yv->C;
+  Tensor* z = e.newt(yv->rows, C, B, yv->H, yv->W);
+  LCH(e, launch_reshape_quirk(e.dt, 0, yv->p, z->p, B, HW, C, 0, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, yv, z, B, HW, C]() {
+      if (!z->g) return;
+      int beta;
+      void* dy = e.grad(yv, &beta);
+      LCH(e, launch_reshape_quirk(e.dt, 1, z->g, dy, B, HW, C, beta, e.s));
+    });
+  return z;
+}
+
+// attention over column slices of projection outputs: Q = qt[:, qoff:qoff+D], K = kvt[:, koff:], V = kvt[:, voff:]
+Tensor* op_attn(Exec& e, Tensor* qt, int qoff, Tensor* kvt, int koff, int voff, int B, int Lq, int Lk, int heads, int D,
+                int causal, const int64_t* text, int ld_text, float drop_p) {
+  const int hd = D / heads;
+  Tensor* o = e.newt((long)B * Lq, D, B);
+  float* lse = (float*)e.alloc((size_t)B * heads * Lq * 4);
+  if (!e.train) drop_p = 0.f;
+  const uint32_t site = drop_p > 0.f ? e.site++ : 0;
+  const uint32_t* seed = (const uint32_t*)(scal(e.m) + SC_SEED);
+  const size_t es = e.esz();
+  AttnP p;
+  memset(&p, 0, sizeof(p));
+  p.Q = (char*)qt->p + qoff * es; p.K = (char*)kvt->p + koff * es; p.V = (char*)kvt->p + voff * es; p.O = o->p; p.lse = lse;
+  p.text = text; p.ld_text = ld_text; p.B = B; p.H = heads; p.Lq = Lq; p.Lk = Lk; p.hd = hd;
+  p.ldq = qt->C; p.ldk = kvt->C; p.ldv = kvt->C; p.ldo = D;
+  p.sq_b = (long)Lq * qt->C; p.sk_b = (long)Lk * kvt->C; p.sv_b = (long)Lk * kvt->C; p.so_b = (long)Lq * D;
+  p.causal = causal; p.pad_id = e.m->cfg.pad_id; p.inv_temp = 1.0f / sqrtf((float)D); p.drop_p = drop_p; p.seed = seed; p.site = site;
+  LCH(e, launch_attn(e.dt, 0, p, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, qt, qoff, kvt, koff, voff, o, p, B, Lq, Lk, heads, hd, D, es]() {
+      if (!o->g) return;
+      const size_t LkP = attn_lkp(Lk);
+      void* dS = e.alloc((size_t)B * heads * Lq * LkP * es);
+      void* Pd = e.alloc((size_t)B * heads * Lq * LkP * es);
+      void* dq = e.grad(qt, nullptr);
+      void* dkv = e.grad(kvt, nullptr);
+      AttnP q = p;
+      q.dO = o->g; q.dQ = (char*)dq + qoff * es; q.dS = dS; q.Pd = Pd;
+      LCH(e, launch_attn(e.dt, 1, q, e.s));
+      WgradP w;
+      memset(&w, 0, sizeof(w));
+      w.M = Lq; w.N = Lk; w.K = hd; w.ldy = (int)LkP; w.out_t = 1; w.nbatch = B * heads; w.nb_inner = heads;
+      w.sY_o = (long)heads * Lq * LkP; w.sY_i = (long)Lq * LkP;
+      w.sW_o = (long)Lk * kvt->C; w.sW_i = hd; w.ldw = kvt->C;
+      // dV = Pd^T dO
+      w.dY = Pd; w.A = o->g; w.lda = D; w.sA_o = (long)Lq * D; w.sA_i = hd; w.dW = (char*)dkv + voff * es;
+      LCH(e, launch_wgrad(e.dt, w, e.s));
+      // dK = dS^T Q
+      w.dY = dS; w.A = (char*)qt->p + qoff * es; w.lda = qt->C; w.sA_o = (long)Lq * qt->C; w.sA_i = hd; w.dW = (char*)dkv + koff * es;
+      LCH(e, launch_wgrad(e.dt, w, e.s));
+    });
+  return o;
+}
+
+Tensor* op_embed(Exec& e, const int64_t* ids, int ld_ids, int B, int L, int pos0, float drop_p) {
+  Model* m = e.m;
+  const int D = m->cfg.dec_hidden;
+  Tensor* y = e.newt((long)B * L, D, B);
+  if (!e.train) drop_p = 0.f;
+  const uint32_t site = drop_p > 0.f ? e.site++ : 0;
+  const uint32_t* seed = (const uint32_t*)(scal(m) + SC_SEED);
+  const float* pe = (const float*)(m->ws + m->off_pe1d);
+  LCH(e, launch_embed(e.dt, ids, m->embed.p, pe, y->p, B, L, ld_ids, D, pos0, drop_p, seed, site, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, m, ids, ld_ids, y, B, L, D, drop_p, seed, site]() {
+      if (!y->g) return;
+      LCH(e, launch_embed_bwd(e.dt, ids, y->g, m->embed.g, B, L, ld_ids, D, drop_p, seed, site, e.s));
+    });
+  return y;
+}
+
+// ---- composite blocks ---------------------------------------------------------------------------------
+static void same_geo(int H, int W, int Ci, int stride, Geo* g) {
+  g->H = H; g->W = W; g->Ci = Ci; g->KW = 3; g->stride = stride;
+  if (stride == 1) { g->OH = H; g->OW = W; g->pt = 1; g->pl = 1; }
+  else {
+    g->OH = (H + stride - 1) / stride; g->OW = (W + stride - 1) / stride;
+    int ph = std::max((g->OH - 1) * stride + 3 - H, 0), pw = std::max((g->OW - 1) * stride + 3 - W, 0);
+    g->pt = ph / 2; g->pl = pw / 2;
+  }
+}
+
+Tensor* mha_self(Exec& e, Tensor* x, MHAp* a, int B, int L, int causal, const int64_t* text, int ld_text, float out_drop) {
+  const int D = a->D;
+  Tensor* qkv = op_gemm(e, x, &a->qkv, &a->bqkv, ACT_NONE, 0.f, nullptr);
+  Tensor* att = op_attn(e, qkv, 0, qkv, D, 2 * D, B, L, L, a->heads, D, causal, text, ld_text, e.drop);
+  return op_gemm(e, att, &a->out, &a->bout, ACT_NONE, out_drop, nullptr);
+}
+
+Tensor* encoder_layer(Exec& e, Tensor* x, EncLayer* el) {
+  const int B = x->B, H = x->H, W = x->W;
+  const float p = e.drop;
+  Tensor* y1 = op_ln(e, x, nullptr, &el->norm);
+  // MultiHeadAttention.dropout followed by EncoderLayer.dropout0: two independent masks == one mask with 1-(1-p)^2
+  Tensor* o = mha_self(e, y1, &el->att, B, H * W, 0, nullptr, 0, 1.f - (1.f - p) * (1.f - p));
+  Tensor* y2 = op_ln(e, o, x, &el->norm);
+  y2->B = B; y2->H = H; y2->W = W;
+  Tensor* z = op_quirk(e, y2);
+  Tensor* c0 = op_gemm(e, z, &el->conv0, nullptr, ACT_NONE, 0.f, nullptr);
+  c0->B = B; c0->H = H; c0->W = W;
+  Tensor* b0 = op_bn_act(e, c0, &el->norm0, ACT_RELU, nullptr);
+  Tensor* d = op_dwconv(e, b0, &el->dw, &el->dwb, 1, H, W, 1, 1);
+  Tensor* b1 = op_bn_act(e, d, &el->dwnorm, ACT_RELU, nullptr);
+  Tensor* c1 = op_gemm(e, b1, &el->conv1, nullptr, ACT_NONE, 0.f, nullptr);
+  c1->B = B; c1->H = H; c1->W = W;
+  return op_bn_act(e, c1, &el->norm1, ACT_RELU, x);
+}
+
+Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
+  const int B = x->B, H = x->H, W = x->W;
+  Geo g;
+  same_geo(H, W, eb->cin, eb->stride, &g);
+  Tensor* skip = eb->skip ? x : nullptr;
+  if (eb->type == 0) {
+    Tensor* y = op_gemm(e, x, &eb->c0, nullptr, ACT_NONE, 0.f, &g, B);
+    return op_bn_act(e, y, &eb->bn1, ACT_SILU, skip);
+  }
+  if (eb->type == 1) {
+    Tensor* y = op_gemm(e, x, &eb->c0, nullptr, ACT_NONE, 0.f, &g, B);
+    Tensor* z = op_bn_act(e, y, &eb->bn1, ACT_SILU, nullptr);
+    Tensor* y2 = op_gemm(e, z, &eb->c1, nullptr, ACT_NONE, 0.f, nullptr);
+    y2->B = B; y2->H = g.OH; y2->W = g.OW;
+    return op_bn_act(e, y2, &eb->bn2, ACT_NONE, skip);
+  }
+  Tensor* y = op_gemm(e, x, &eb->c0, nullptr, ACT_NONE, 0.f, nullptr);
+  y->B = B; y->H = H; y->W = W;
+  Tensor* z = op_bn_act(e, y, &eb->bn1, ACT_SILU, nullptr);
+  Tensor* y2 = op_dwconv(e, z, &eb->dw, nullptr, eb->stride, g.OH, g.OW, g.pt, g.pl);
+  Tensor* z2 = op_bn_act(e, y2, &eb->bn2, ACT_SILU, nullptr);
+  Tensor* pooled = op_pool(e, z2);
+  Tensor* u1 = op_gemm(e, pooled, &eb->se_r, &eb->se_rb, ACT_NONE, 0.f, nullptr);
+  Tensor* s1 = op_act(e, u1, ACT_SILU);
+  Tensor* gate = op_gemm(e, s1, &eb->se_e, &eb->se_eb, ACT_SIGMOID, 0.f, nullptr);
+  Tensor* z3 = op_se_scale(e, z2, gate);
+  Tensor* y3 = op_gemm(e, z3, &eb->c1, nullptr, ACT_NONE, 0.f, nullptr);
+  y3->B = B; y3->H = g.OH; y3->W = g.OW;
+  return op_bn_act(e, y3, &eb->bn3, ACT_NONE, skip);
+}
+
+Tensor* encoder_forward(Exec& e, const float* img, int B) {
+  Model* m = e.m;
+  const SatrnConfig& c = m->cfg;
+  Tensor* x;
+  if (c.network == 0) {
+    x = op_stem(e, img, &m->lite_conv[0], B, c.rgb, c.height, c.width, 1, 1);
+    x = op_bn_act(e, x, &m->lite_bn[0], ACT_RELU, nullptr);
+    x = op_maxpool(e, x);
+    for (int i = 1; i < 4; ++i) {
+      Geo g;
+      same_geo(x->H, x->W, x->C, 1, &g);
+      x = op_gemm(e, x, &m->lite_conv[i], nullptr, ACT_NONE, 0.f, &g, B);
+      x = op_bn_act(e, x, &m->lite_bn[i], ACT_RELU, nullptr);
+      x = op_maxpool(e, x);
+    }
+  } else {
+    x = op_stem(e, img, &m->stem, B, c.rgb, c.height, c.width, 2, 0);
+    x = op_bn_act(e, x, &m->stem_bn, ACT_SILU, nullptr);
+    for (auto& eb : m->blocks) x = eff_block(e, x, &eb);
+    int H = x->H, W = x->W;
+    x = op_gemm(e, x, &m->conv_last, nullptr, ACT_NONE, 0.f, nullptr);
+    x->B = B; x->H = H; x->W = W;
+    x = op_bn_act(e, x, &m->bn_last, ACT_SILU, nullptr);
+  }
+  if (x->H != m->feat_h || x->W != m->feat_w) { m->err = "feature map size does not match input_size/32 (or /16)"; e.oom = true; }
+  // adaptive 2D positional encoding (networks/EfficientSATRN.py:135-154)
+  Tensor* pooled = op_pool(e, x);
+  Tensor* h0 = op_gemm(e, pooled, &m->pe_d0, &m->pe_b0, ACT_RELU, e.drop, nullptr);
+  Tensor* gate = op_gemm(e, h0, &m->pe_d1, &m->pe_b1, ACT_SIGMOID, 0.f, nullptr);
+  x = op_posenc_apply(e, x, gate);
+  for (auto& el : m->enc) x = encoder_layer(e, x, &el);
+  return x;  // [B*HW][D] == [b, hw, c]
+}
+
+Tensor* decoder_tf(Exec& e, Tensor* src, const int64_t* expected, int B, int L, float* logits_out) {
+  Model* m = e.m;
+  const SatrnConfig& c = m->cfg;
+  const int T = L - 1, Dd = c.dec_hidden, Nsrc = (int)(src->rows / B);
+  Tensor* t = op_embed(e, expected, L, B, T, 0, e.drop);
+  for (auto& dl : m->dec) {
+    Tensor* o = mha_self(e, t, &dl.self_att, B, T, 1, expected, L, e.drop);
+    Tensor* t1 = op_ln(e, o, t, &dl.ln1);
+    Tensor* q = op_gemm(e, t1, &dl.cross_att.qkv, &dl.cross_att.bqkv, ACT_NONE, 0.f, nullptr);
+    Tensor* kv = op_gemm(e, src, &dl.cross_att.kv, &dl.cross_att.bkv, ACT_NONE, 0.f, nullptr);
+    Tensor* a2 = op_attn(e, q, 0, kv, 0, Dd, B, T, Nsrc, c.dec_heads, Dd, 0, nullptr, 0, e.drop);
+    Tensor* o2 = op_gemm(e, a2, &dl.cross_att.out, &dl.cross_att.bout, ACT_NONE, e.drop, nullptr);
+    Tensor* t2 = op_ln(e, o2, t1, &dl.ln2);
+    const float fp = e.train ? 0.1f : 0.f;  // Feedforward dropout is hard-wired to 0.1 (networks/EfficientSATRN.py:327)
+    Tensor* f0 = op_gemm(e, t2, &dl.lin0, &dl.b0, ACT_RELU, e.drop > 0.f ? fp : 0.f, nullptr);
+    Tensor* f1 = op_gemm(e, f0, &dl.lin1, &dl.b1, ACT_RELU, e.drop > 0.f ? fp : 0.f, nullptr);
+    t = op_ln(e, f1, t2, &dl.ln3);
+  }
+  return op_gemm(e, t, &m->gen, &m->gen_b, ACT_NONE, 0.f, nullptr, 0, true, logits_out);
+}
+}  // namespace
+
+// =====================================================================================================
+// model-level entry points
+// =====================================================================================================
+static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) {
+  Exec& e = *m->ex;
+  e.s = s; e.dt = m->cfg.dtype; e.train = train; e.rec = rec; e.dry = dry;
+  e.drop = train ? m->cfg.dropout : 0.f;
+  e.reset(m->ws + m->persist_bytes, m->ws_bytes > m->persist_bytes ? m->ws_bytes - m->persist_bytes : 0,
+          m->ws + m->off_zero, m->zero_bytes);
+  e.peak = 0;
+  if (!dry) (void)hipMemsetAsync(m->ws + m->off_zero, 0, m->zero_bytes, s);
+}
+
+size_t model_workspace_bytes(Model* m, int B, int L) {
+  // dry-run the training forward + backward (and the greedy decoder's buffers) with a counting arena
+  Exec& e = *m->ex;
+  char* save_ws = m->ws;
+  m->ws = nullptr;
+  exec_begin(m, nullptr, true, true, true);
+  e.cap = (size_t)1 << 60; e.zcap = m->zero_bytes;
+  Tensor* src = encoder_forward(e, nullptr, B);
+  std::vector<int64_t> dummy;
+  Tensor* lg = decoder_tf(e, src, nullptr, B, L, nullptr);
+  lg->g = e.alloc((size_t)lg->rows * m->gen.ldb * e.esz());
+  e.alloc((size_t)lg->rows * 4);
+  for (auto it = e.tape.rbegin(); it != e.tape.rend(); ++it) (*it)();
+  size_t train_peak = e.peak;
+  e.tape.clear(); e.tens.clear();
+  // greedy: encoder (eval) + caches
+  size_t es = e.esz();
+  size_t dec = (size_t)m->cfg.dec_layers * ((size_t)B * 512 * 2 * m->cfg.dec_hidden * es + (size_t)B * m->feat_h * m->feat_w * 2 * m->cfg.dec_hidden * es) +
+               (size_t)64 * B * std::max(m->cfg.dec_filter, 3 * m->cfg.dec_hidden) * 4 + (1u << 20);
+  m->ws = save_ws;
+  size_t need = m->persist_bytes + std::max(train_peak, train_peak / 2 + dec) + (16u << 20);
+  return need;
+}
+
+int model_forward(Model* m, const float* img, const int64_t* expected, int B, int L, bool train, bool record,
+                  float* logits_out, hipStream_t s) {
+  if (!m->bound || !m->ws_set) { m->err = "bind parameters and set a workspace first"; return -1; }
+  Exec& e = *m->ex;
+  exec_begin(m, s, train, record, false);
+  e.src = encoder_forward(e, img, B);
+  e.logits = decoder_tf(e, e.src, expected, B, L, logits_out);
+  if (e.oom) { if (m->err.empty()) m->err = "workspace exhausted"; return -2; }
+  return 0;
+}
+
+static void run_tape(Exec& e) {
+  for (auto it = e.tape.rbegin(); it != e.tape.rend(); ++it) (*it)();
+  e.tape.clear();
+}
+
+int model_backward(Model* m, const float* dlogits, hipStream_t s) {
+  Exec& e = *m->ex;
+  if (!e.logits || e.tape.empty()) { m->err = "no recorded forward"; return -1; }
+  e.s = s;
+  Tensor* lg = e.logits;
+  const int Vp = m->gen.ldb;
+  lg->g = e.alloc((size_t)lg->rows * Vp * e.esz());
+  lg->g_init = true;
+  launch_cast_pad(e.dt, dlogits, lg->g, lg->rows, m->cfg.num_classes, Vp, s);
+  run_tape(e);
+  if (e.oom) { m->err = "workspace exhausted in backward"; return -2; }
+  return 0;
+}
+
+int model_loss_backward(Model* m, const int64_t* expected, int B, int L, hipStream_t s) {
+  Exec& e = *m->ex;
+  if (!e.logits) { m->err = "no forward"; return -1; }
+  e.s = s;
+  Tensor* lg = e.logits;
+  const int Vp = m->gen.ldb, V = m->cfg.num_classes;
+  float* lse = (float*)e.alloc((size_t)lg->rows * 4);
+  void* dl = nullptr;
+  if (!e.tape.empty()) { lg->g = e.alloc((size_t)lg->rows * Vp * e.esz()); lg->g_init = true; dl = lg->g; }
+  else dl = e.alloc((size_t)lg->rows * Vp * e.esz());
+  launch_ce_full(e.dt, (const float*)lg->p, expected, L, 1, B, L - 1, V, Vp, m->cfg.pad_id, scal(m) + SC_LOSS, lse, dl,
+                 nullptr, s);
+  run_tape(e);
+  if (e.oom) { m->err = "workspace exhausted in backward"; return -2; }
+  return 0;
+}
+
+
+int model_train_step(Model* m, const float* img, const int64_t* expected, int B, int L, const float* hyper9,
+                     int use_graph, int phase, hipStream_t s) {
+  phase &= 3;
+  if (!phase) return 0;
+  if (!m->bound || !m->ws_set || !m->grads) { m->err = "bind parameters/grads and set a workspace first"; return -1; }
+  // hyper-parameters for this step (lr changes every iteration in the reference's scheduler)
+  if (phase & 2) m->adam_t += 1;
+  if (!m->hy_pinned && hipHostMalloc((void**)&m->hy_pinned, 64 * 16 * sizeof(float), 0) != hipSuccess) { m->err = "hipHostMalloc failed"; return -5; }
+  float* hy = m->hy_pinned + (m->adam_t % 64) * 16;
+  memcpy(hy, hyper9, 9 * sizeof(float));
+  hy[6] = 1.0f - powf(hy[1], (float)m->adam_t);
+  hy[7] = 1.0f - powf(hy[2], (float)m->adam_t);
+  (void)hipMemcpyAsync(scal(m) + SC_HYPER, hy, 9 * sizeof(float), hipMemcpyHostToDevice, s);
+  auto body = [&]() -> int {
+    if (phase & 1) {
+      launch_seed_advance((uint32_t*)(scal(m) + SC_SEED), s);
+      (void)hipMemsetAsync(m->grads, 0, (size_t)m->n_params * 4, s);
+      int rc = model_forward(m, img, expected, B, L, true, true, nullptr, s);
+      if (rc) return rc;
+      rc = model_loss_backward(m, expected, B, L, s);
+      if (rc) return rc;
+    }
+    if (phase & 2) {
+      (void)hipMemsetAsync(scal(m) + SC_GNORM, 0, 4, s);
+      launch_sumsq(m->grads, m->n_params, scal(m) + SC_GNORM, s);
+      launch_adamw(m->params, m->grads, (float*)(m->ws + m->off_adam_m), (float*)(m->ws + m->off_adam_v), m->n_params,
+                   scal(m) + SC_GNORM, scal(m) + SC_HYPER, s);
+      return model_pack_weights(m, s);
+    }
+    return 0;
+  };
+  if (!use_graph) return body();
+  if (m->graph_B != B || m->graph_L != L) {
+    for (int i = 0; i < 4; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
+    m->graph_B = B; m->graph_L = L;
+  }
+  hipGraphExec_t& gx = m->graphs[phase];
+  if (!gx) {
+    // the caller must keep img / expected at the same addresses across replays (bench + trainer use staging buffers)
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) { m->err = "stream capture failed"; return -3; }
+    int rc = body();
+    hipError_t er = hipStreamEndCapture(s, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (er != hipSuccess || !g) { m->err = "graph capture failed"; return -3; }
+    if (hipGraphInstantiate(&gx, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); m->err = "graph instantiate failed"; return -3; }
+    (void)hipGraphDestroy(g);
+  }
+  if (hipGraphLaunch(gx, s) != hipSuccess) { m->err = "graph launch failed"; return -3; }
+  return 0;
+}
+
+int model_read_loss(Model* m, float* out4, hipStream_t s) {
+  (void)hipMemcpyAsync(out4, scal(m) + SC_LOSS, 16, hipMemcpyDeviceToHost, s);
+  (void)hipMemcpyAsync(out4 + 3, scal(m) + SC_GNORM, 4, hipMemcpyDeviceToHost, s);
+  (void)hipStreamSynchronize(s);
+  return 0;
+}
+
+int model_encode(Model* m, const float* img, int B, float* src_out, hipStream_t s) {
+  if (!m->bound || !m->ws_set) { m->err = "bind parameters and set a workspace first"; return -1; }
+  Exec& e = *m->ex;
+  exec_begin(m, s, false, false, false);
+  e.src = encoder_forward(e, img, B);
+  if (e.oom) { if (m->err.empty()) m->err = "workspace exhausted"; return -2; }
+  if (src_out) launch_cast(e.dt, DT_F32, e.src->p, src_out, e.src->rows * e.src->C, s);
+  return 0;
+}
+
+// Greedy decode with the reference's step semantics (networks/EfficientSATRN.py:528-561, :386-396): the
+// self-attention history of a layer is k/v_linear of that layer's previous OUTPUTS plus the current INPUT.
+// KV-cached: slot t first holds k/v(input_t), is attended, then is overwritten with k/v(output_t).
+int model_greedy(Model* m, const float* img, const float* src_in, int B, int steps, float* logits_out, int64_t* ids_out,
+                 hipStream_t s) {
+  if (!m->bound || !m->ws_set) { m->err = "bind parameters and set a workspace first"; return -1; }
+  if (steps > 500) { m->err = "max 500 decode steps (PositionEncoder1D max_len)"; return -1; }
+  Exec& e = *m->ex;
+  const SatrnConfig& c = m->cfg;
+  const int Dd = c.dec_hidden, V = c.num_classes;
+  exec_begin(m, s, false, false, false);
+  Tensor* src;
+  if (src_in) {
+    const int N = m->feat_h * m->feat_w;
+    src = e.newt((long)B * N, c.dec_src, B);
+    launch_cast(DT_F32, e.dt, src_in, src->p, src->rows * src->C, s);
+  } else {
+    src = encoder_forward(e, img, B);
+  }
+  const int Nsrc = (int)(src->rows / B);
+  const size_t es = e.esz();
+  const int L = (int)m->dec.size();
+  std::vector<Tensor*> crossKV(L), cache(L);
+  for (int l = 0; l < L; ++l) {
+    crossKV[l] = op_gemm(e, src, &m->dec[l].cross_att.kv, &m->dec[l].cross_att.bkv, ACT_NONE, 0.f, nullptr);
+    cache[l] = e.newt((long)B * steps, 2 * Dd, B);
+  }
+  int64_t* sos = (int64_t*)e.alloc((size_t)B * 8);
+  {
+    std::vector<int64_t> h(B, c.sos_id);
+    (void)hipMemcpyAsync(sos, h.data(), (size_t)B * 8, hipMemcpyHostToDevice, s);
+    (void)hipStreamSynchronize(s);
+  }
+  const size_t mark = e.off;
+  const size_t keep = e.tens.size();
+  const float inv_temp = 1.0f / sqrtf((float)Dd);
+  for (int t = 0; t < steps; ++t) {
+    e.off = mark;  // per-step scratch is reused
+    Tensor* x = op_embed(e, t == 0 ? sos : ids_out + (t - 1), t == 0 ? 1 : steps, B, 1, t, 0.f);
+    for (int l = 0; l < L; ++l) {
+      DecLayer& dl = m->dec[l];
+      MHAp& sa = dl.self_att;
+      // q = x Wq ; [k v](x) -> cache slot t
+      Wt wq = sa.qkv; wq.N = Dd;
+      Vec bq = sa.bqkv; bq.n = Dd;
+      Tensor* q = op_gemm(e, x, &wq, &bq, ACT_NONE, 0.f, nullptr);
+      GemmP g;
+      memset(&g, 0, sizeof(g));
+      g.A = x->p; g.Bw = (char*)sa.qkv.fwd + (size_t)Dd * Dd * es; g.bias = sa.bqkv.p + Dd;
+      g.C = (char*)cache[l]->p + (size_t)t * 2 * Dd * es; g.M = B; g.N = 2 * Dd; g.K = Dd; g.lda = Dd; g.ldc = steps * 2 * Dd;
+      launch_gemm(e.dt, AM_DENSE, g, s);
+      Tensor* att = e.newt(B, Dd, B);
+      AttnP p;
+      memset(&p, 0, sizeof(p));
+      p.Q = q->p; p.K = cache[l]->p; p.V = (char*)cache[l]->p + (size_t)Dd * es; p.O = att->p;
+      p.B = B; p.H = c.dec_heads; p.Lq = 1; p.Lk = t + 1; p.hd = Dd / c.dec_heads;
+      p.ldq = Dd; p.ldk = 2 * Dd; p.ldv = 2 * Dd; p.ldo = Dd;
+      p.sq_b = Dd; p.sk_b = (long)steps * 2 * Dd; p.sv_b = p.sk_b; p.so_b = Dd;
+      p.inv_temp = inv_temp; p.pad_id = c.pad_id;
+      if (launch_attn_checked(e.dt, 0, p, s)) { m->err = "attention shape unsupported (Lk > 512?)"; return -4; }
+      Tensor* o = op_gemm(e, att, &sa.out, &sa.bout, ACT_NONE, 0.f, nullptr);
+      Tensor* t1 = op_ln(e, o, x, &dl.ln1);
+      Tensor* q2 = op_gemm(e, t1, &dl.cross_att.qkv, &dl.cross_att.bqkv, ACT_NONE, 0.f, nullptr);
+      Tensor* a2 = op_attn(e, q2, 0, crossKV[l], 0, Dd, B, 1, Nsrc, c.dec_heads, Dd, 0, nullptr, 0, 0.f);
+      Tensor* o2 = op_gemm(e, a2, &dl.cross_att.out, &dl.cross_att.bout, ACT_NONE, 0.f, nullptr);
+      Tensor* t2 = op_ln(e, o2, t1, &dl.ln2);
+      Tensor* f0 = op_gemm(e, t2, &dl.lin0, &dl.b0, ACT_RELU, 0.f, nullptr);
+      Tensor* f1 = op_gemm(e, f0, &dl.lin1, &dl.b1, ACT_RELU, 0.f, nullptr);
+      x = op_ln(e, f1, t2, &dl.ln3);
+      // history entry for the following steps: k/v of this layer's OUTPUT
+      g.A = x->p;
+      launch_gemm(e.dt, AM_DENSE, g, s);
+    }
+    GemmP g;
+    memset(&g, 0, sizeof(g));
+    g.A = x->p; g.Bw = m->gen.fwd; g.bias = m->gen_b.p; g.C = logits_out + (size_t)t * V; g.M = B; g.N = V; g.K = Dd;
+    g.lda = Dd; g.ldc = steps * V; g.out_f32 = 1;
+    launch_gemm(e.dt, AM_DENSE, g, s);
+    launch_argmax(logits_out + (size_t)t * V, ids_out + t, B, V, steps * V, steps, s);
+    e.tens.resize(keep);
+  }
+  if (e.oom) { m->err = "workspace exhausted"; return -2; }
+  return 0;
+}

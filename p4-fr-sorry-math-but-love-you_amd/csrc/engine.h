@@ -1,0 +1,144 @@
+// SATRN engine: a static-plan executor for the EfficientSATRN / LiteSATRN hot path.
+// The engine owns no device memory: parameters, gradients, BN buffers and one workspace are borrowed
+// from the caller (PyTorch tensors).  A forward pass records a tape of backward closures; a whole
+// training step (forward + CE + backward + clip + AdamW + weight re-pack) is captured into one hipGraph.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+struct SatrnConfig {
+  int network;  // 0 LiteSATRN, 1 EfficientSATRN
+  int rgb;
+  int height, width;
+  int enc_hidden, enc_filter, enc_heads, enc_layers;
+  int dec_src, dec_hidden, dec_filter, dec_heads, dec_layers;
+  int num_classes;
+  int pad_id, sos_id;
+  float dropout;
+  int dtype;  // DT_F32 / DT_BF16
+};
+
+enum { ST_PARAM = 0, ST_BUF_F32 = 1, ST_BUF_I64 = 2 };
+struct StateEntry {
+  std::string name;
+  std::vector<int64_t> shape;
+  int kind;
+  int64_t offset;  // element offset inside the flat buffer of its kind
+  int64_t numel;
+  int init;  // 0 xavier, 1 conv(kaiming-uniform), 2 linear_w, 3 linear_b(fan_in given), 4 ones, 5 zeros, 6 normal
+  int fan_in, fan_out;
+};
+
+struct Vec { float* p = nullptr; float* g = nullptr; int n = 0; int64_t off = -1; };
+enum { WK_DENSE = 0, WK_CONV3 = 1, WK_DW = 2, WK_STEM = 3 };
+struct Wt {
+  int kind = WK_DENSE;
+  int N = 0, K = 0;        // GEMM view: N outputs, K = taps*Ci contraction
+  int Co = 0, Ci = 0, taps = 1;
+  int ldb = 0;             // row length of the transposed (backward) copy
+  int64_t off = -1;        // element offset in flat params / grads
+  float* p = nullptr; float* g = nullptr;
+  void* fwd = nullptr; void* bwd = nullptr;  // packed compute copies
+  int64_t pk_fwd_off = -1, pk_bwd_off = -1;  // byte offsets inside the persistent region
+};
+struct BNp { Vec w, b; int64_t rm_off = -1, rv_off = -1, nbt_off = -1; float* rm = nullptr; float* rv = nullptr; int64_t* nbt = nullptr; int C = 0; float eps = 1e-5f; };
+struct LNp { Vec w, b; int C = 0; };
+struct MHAp { Wt qkv;   /* fused [3D][K] when q and kv share the input width, else q only */
+              Wt kv;    /* cross attention: [2D][Ksrc] */
+              Vec bqkv; /* fused bias [3D] (or [D] for q when cross) */
+              Vec bkv; Wt out; Vec bout; int D = 0, heads = 0; bool cross = false; };
+
+struct Tensor {
+  void* p = nullptr; void* g = nullptr;
+  long rows = 0; int C = 0;
+  int B = 0, H = 0, W = 0;
+  bool g_init = false;
+  bool f32 = false;  // logits
+};
+
+struct EffBlock { int type, cin, cout, mid, stride, se; bool skip; Wt c0, c1, dw, se_r, se_e; Vec se_rb, se_eb; BNp bn1, bn2, bn3; };
+struct EncLayer { LNp norm; MHAp att; Wt conv0, conv1, dw; Vec dwb; BNp norm0, dwnorm, norm1; };
+struct DecLayer { MHAp self_att, cross_att; LNp ln1, ln2, ln3; Wt lin0, lin1; Vec b0, b1; };
+
+struct Model {
+  SatrnConfig cfg;
+  std::vector<StateEntry> state;
+  int64_t n_params = 0, n_buf_f32 = 0, n_buf_i64 = 0;
+  // architecture
+  Wt stem; BNp stem_bn;
+  std::vector<Wt> lite_conv; std::vector<BNp> lite_bn;
+  std::vector<EffBlock> blocks;
+  Wt conv_last; BNp bn_last;
+  Wt pe_d0, pe_d1; Vec pe_b0, pe_b1;
+  std::vector<EncLayer> enc;
+  Wt embed;  // [V+1][Dd] (gathered directly from the fp32 master)
+  std::vector<DecLayer> dec;
+  Wt gen; Vec gen_b;
+  std::vector<Wt*> all_w; std::vector<Vec*> all_v; std::vector<BNp*> all_bn;
+  // bound memory
+  float* params = nullptr; float* grads = nullptr; float* buf_f32 = nullptr; int64_t* buf_i64 = nullptr;
+  char* ws = nullptr; size_t ws_bytes = 0;
+  // persistent region layout (byte offsets inside ws)
+  size_t persist_bytes = 0;
+  size_t off_packed = 0, off_adam_m = 0, off_adam_v = 0, off_scalars = 0, off_pe1d = 0, off_hpos = 0, off_wpos = 0,
+         off_stage_img = 0, off_stage_tgt = 0, off_zero = 0;
+  size_t zero_bytes = 0;
+  int stage_B = 0, stage_L = 0;
+  int feat_h = 0, feat_w = 0;
+  bool bound = false, ws_set = false, tables_ready = false;
+  // execution state
+  struct Exec* ex = nullptr;
+  hipGraphExec_t graphs[4] = {nullptr, nullptr, nullptr, nullptr}; int graph_B = 0, graph_L = 0;
+  long adam_t = 0;
+  float* hy_pinned = nullptr;
+  std::string err;
+};
+
+// scalars block (floats unless noted), all in device memory inside the persistent region
+enum { SC_SEED = 0 /*uint32*/, SC_GNORM = 1, SC_LOSS = 4 /*4 floats*/, SC_HYPER = 8 /*9 floats*/, SC_ONE = 20, SC_COUNT = 32 };
+
+struct Exec {
+  Model* m = nullptr;
+  hipStream_t s = nullptr;
+  int dt = 0;
+  bool train = false, rec = false, dry = false;
+  float drop = 0.f;
+  char* base = nullptr; size_t cap = 0, off = 0, peak = 0;  // bump arena
+  char* zbase = nullptr; size_t zcap = 0, zoff = 0;          // zero pool
+  uint32_t site = 1;
+  std::vector<std::function<void()>> tape;
+  std::vector<std::unique_ptr<Tensor>> tens;
+  Tensor* logits = nullptr; Tensor* src = nullptr;
+  bool oom = false;
+
+  void* alloc(size_t bytes);
+  float* zalloc(size_t nfloats);
+  Tensor* newt(long rows, int C, int B = 0, int H = 0, int W = 0, bool f32 = false);
+  size_t esz() const { return dt == DT_BF16 ? 2 : 4; }
+  void* grad(Tensor* t, int* beta);
+  void reset(char* b, size_t c, char* zb, size_t zc);
+};
+
+Model* model_create(const SatrnConfig& cfg);
+void model_destroy(Model* m);
+size_t model_workspace_bytes(Model* m, int B, int L);
+int model_bind(Model* m, float* params, float* grads, float* buf_f32, int64_t* buf_i64);
+int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s);
+int model_pack_weights(Model* m, hipStream_t s);
+int model_forward(Model* m, const float* img, const int64_t* expected, int B, int L, bool train, bool record,
+                  float* logits_out, hipStream_t s);
+int model_backward(Model* m, const float* dlogits, hipStream_t s);
+int model_loss_backward(Model* m, const int64_t* expected, int B, int L, hipStream_t s);
+int model_train_step(Model* m, const float* img, const int64_t* expected, int B, int L, const float* hyper9,
+                     int use_graph, int phase, hipStream_t s);
+int model_read_loss(Model* m, float* out4, hipStream_t s);
+int model_encode(Model* m, const float* img, int B, float* src_out, hipStream_t s);
+int model_greedy(Model* m, const float* img, const float* src_or_null, int B, int steps, float* logits_out,
+                 int64_t* ids_out, hipStream_t s);

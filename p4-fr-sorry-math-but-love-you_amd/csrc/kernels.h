@@ -1,0 +1,121 @@
+// Host-side launch API of the SATRN gfx950 kernels (internal; the public C-ABI is include/satrn_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+enum { AM_DENSE = 0, AM_CONV = 1, AM_DGRAD = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3 };
+
+// C[M,N] = act(gatherA[M,K] * Bw[N,K]^T + bias) (+dropout) (+= if beta)
+struct GemmP {
+  const void* A; const void* Bw; void* C; const float* bias;
+  int M, N, K, lda, ldc;
+  // conv geometry: source tensor [Bn, H, W, Ci] (AM_CONV: the input; AM_DGRAD: dY), output rows = Bn*OH*OW
+  int H, W, Ci, OH, OW, KW, stride, pt, pl;
+  int act, beta, out_f32;
+  float drop_p; const uint32_t* seed; uint32_t site;
+  const float* ascale; int ascale_hw;  // optional A[m][k] *= ascale[(m/ascale_hw)*K + k]  (SE gate), dense only
+};
+void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s);
+
+// dW[n][k] (+)= sum_m dY[m][n] * gatherA[m][k]
+struct WgradP {
+  const void* dY; const void* A; void* dW;
+  int M, N, K, ldy, lda;
+  int H, W, Ci, OH, OW, KW, stride, pt, pl;  // AM_CONV: A is the conv input [Bn,H,W,Ci], rows m = Bn*OH*OW
+  int conv;        // 0 dense, 1 conv (im2col gather of A; dW written in [N][Ci][KH][KW] torch layout)
+  int out_t;       // 0: fp32 atomicAdd into dW (zeroed by caller); 1: store as T (batched attention use)
+  int nbatch, nb_inner;                    // batched: z -> (z / nb_inner, z % nb_inner)
+  long sY_o, sY_i, sA_o, sA_i, sW_o, sW_i;  // element strides per outer/inner batch index
+  int ldw;                                 // out_t==1: row stride of dW
+  const float* ascale; int ascale_hw;      // optional A[m][k] *= ascale[(m/ascale_hw)*K + k]
+};
+void launch_wgrad(int dt, const WgradP& p, hipStream_t s);
+
+// ---- attention ---------------------------------------------------------------------------
+struct AttnP {
+  const void* Q; const void* K; const void* V; void* O; float* lse;   // lse [B,H,Lq]
+  const void* dO; void* dQ; void* dS; void* Pd;                       // backward (mode 1): dS,Pd [B,H,Lq,LkP] as T
+  const int64_t* text; int ld_text;  // token ids [B][ld_text] for the pad mask (nullptr = none)
+  int B, H, Lq, Lk, hd;
+  int ldq, ldk, ldv, ldo;  // row strides (elements)
+  int causal, pad_id;
+  float inv_temp, drop_p; const uint32_t* seed; uint32_t site;
+  int q_pos0;              // step mode: absolute position of query row 0 (causal uses q_pos0 + i)
+  long sq_b, sk_b, sv_b, so_b;  // batch strides (elements) of Q / K / V / O(dO,dQ use sq_b/so_b)
+};
+void launch_attn(int dt, int mode, const AttnP& p, hipStream_t s);
+size_t attn_lkp(int Lk);  // padded key count used for dS/Pd workspaces
+
+// ---- elementwise / reductions (all NHWC, C % (16/sizeof(T)) == 0 unless stated) ------------
+void launch_colstats(int dt, const void* y, long M, int C, float* sums /*[2C], zeroed*/, hipStream_t s);
+void launch_bn_finalize(const float* sums, long M, int C, const float* w, const float* b, float* rm, float* rv,
+                        int64_t* nbt, float eps, float mom, int train, float* scale_shift /*[2C]*/,
+                        float* mean_rstd /*[2C]*/, hipStream_t s);
+void launch_bn_act(int dt, const void* y, const float* scale_shift, const void* res, void* z, long M, int C, int act,
+                   hipStream_t s);
+void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* scale_shift, const float* mean_rstd,
+                          long M, int C, int act, float* red /*[2C] zeroed*/, hipStream_t s);
+void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* scale_shift, const float* mean_rstd,
+                         const float* w, const float* red, long M, int C, int act, void* dy, float* dw, float* db,
+                         hipStream_t s);
+void launch_stem_conv(int dt, const float* img, const float* w, void* y, int B, int Cin, int H, int W, int Co, int OH,
+                      int OW, int stride, int pad, hipStream_t s);
+void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int B, int Cin, int H, int W, int Co,
+                       int OH, int OW, int stride, int pad, hipStream_t s);
+void launch_dwconv(int dt, int mode /*0 fwd,1 dgrad*/, const void* x, const void* wp /*[9][C] as T*/, const float* bias,
+                   void* y, int B, int H, int W, int C, int OH, int OW, int stride, int pt, int pl, int beta,
+                   hipStream_t s);
+void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw /*[C][9] torch layout*/, float* dbias, int B,
+                         int H, int W, int C, int OH, int OW, int stride, int pt, int pl, hipStream_t s);
+void launch_maxpool(int dt, int bwd, const void* x, const void* dy_or_null, void* out, int B, int H, int W, int C,
+                    hipStream_t s);
+void launch_pool_hw(int dt, const void* x, void* out /*[B,C] as T*/, int B, int HW, int C, hipStream_t s);
+void launch_se_scale(int dt, const void* x, const void* gate /*[B,C] T*/, void* out, int B, int HW, int C, hipStream_t s);
+// dx (+)= dout*gate + dpool[b,c]/HW ; dgate[b,c] = sum_hw dout*x   (two kernels)
+void launch_se_bwd_gate(int dt, const void* dout, const void* x, void* dgate /*[B,C] T*/, int B, int HW, int C, hipStream_t s);
+void launch_se_bwd_x(int dt, const void* dout, const void* gate, const void* dpool /*[B,C] T or null*/, void* dx, int B,
+                     int HW, int C, int beta, hipStream_t s);
+void launch_bcast_add_hw(int dt, const void* dpool /*[B,C]*/, void* dx, int B, int HW, int C, float scale, hipStream_t s);
+void launch_posenc2d(int dt, const void* x, const void* gate /*[B,2C] T*/, const float* hpos, const float* wpos, void* out,
+                     int B, int H, int W, int C, hipStream_t s);
+void launch_posenc2d_bwd(int dt, const void* dout, const float* hpos, const float* wpos, void* dgate /*[B,2C] T*/, int B,
+                         int H, int W, int C, hipStream_t s);
+void launch_layernorm(int dt, const void* a, const void* b_or_null, const float* w, const float* bias, void* out,
+                      float* mean_rstd /*[2R]*/, long R, int C, float eps, float drop_p, const uint32_t* seed,
+                      uint32_t site, hipStream_t s);
+void launch_layernorm_bwd(int dt, const void* dout, const void* a, const void* b_or_null, const float* w,
+                          const float* mean_rstd, void* da, void* db_or_null, int beta_a, int beta_b, float* dw,
+                          float* dbias, long R, int C, float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s);
+void launch_reshape_quirk(int dt, int inverse, const void* in, void* out, int B, int HW, int C, int beta, hipStream_t s);
+void launch_embed(int dt, const int64_t* ids, const float* table, const float* pe, void* out, int B, int L, int ld_ids,
+                  int D, int pos0, float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s);
+void launch_embed_bwd(int dt, const int64_t* ids, const void* dout, float* dtable, int B, int L, int ld_ids, int D,
+                      float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s);
+void launch_colsum(int dt, const void* x, long M, int C, int ld, float* out /*[C] +=*/, hipStream_t s);
+void launch_act_bwd(int dt, const void* dz, const void* z_post, void* du, long n, int act, float drop_p, hipStream_t s);
+void launch_dropout_bwd(int dt, const void* dz, void* du, long M, int N, float drop_p, const uint32_t* seed, uint32_t site,
+                        hipStream_t s);
+// loss_out [4]: sum, count, mean; lse_ws [B*T]; dlogits [B*T][Vp] written as dt_out (zero padded), scaled by *upstream
+void launch_ce_full(int dt_out, const float* logits, const int64_t* tgt, int ld_tgt, int tgt_off, int B, int T, int V,
+                    int Vp, int pad_id, float* loss_out, float* lse_ws, void* dlogits, const float* upstream,
+                    hipStream_t s);
+void launch_act_fwd(int dt, const void* u, void* z, long n, int act, hipStream_t s);
+void launch_cast_pad(int dt_out, const float* in, void* out, long R, int C, int Cp, hipStream_t s);
+void launch_pack_dense_ld(int dt, const float* w, void* fwd, void* bwd, int N, int K, int ldb, hipStream_t s);
+int launch_attn_checked(int dt, int mode, const AttnP& p, hipStream_t s);
+void launch_cast(int dt_in, int dt_out, const void* in, void* out, long n, hipStream_t s);
+void launch_fill(void* p, int value_byte, size_t bytes, hipStream_t s);
+void launch_add(int dt, const void* a, const void* b, void* out, long n, hipStream_t s);
+void launch_argmax(const float* logits, int64_t* ids, int R, int V, int ld_in, int ld_out, hipStream_t s);
+void launch_seed_advance(uint32_t* seed, hipStream_t s);
+
+// ---- weight packing + optimizer --------------------------------------------------------------
+void launch_pack_dense(int dt, const float* w, void* fwd /*[N][K]*/, void* bwd /*[K][N]*/, int N, int K, hipStream_t s);
+void launch_pack_conv(int dt, const float* w /*[Co][Ci][T]*/, void* fwd /*[Co][T][Ci]*/, void* bwd /*[Ci][T][Co]*/, int Co,
+                      int Ci, int taps, hipStream_t s);
+void launch_pack_dw(int dt, const float* w /*[C][9]*/, void* out /*[9][C]*/, int C, hipStream_t s);
+void launch_sumsq(const float* g, long n, float* out /*[1] +=*/, hipStream_t s);
+void launch_adamw(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, const float* hyper,
+                  hipStream_t s);

@@ -1,0 +1,1173 @@
+// HBM-bound kernels of the SATRN path (NHWC activations, 16-byte vector access along channels):
+// BatchNorm (batch-stat) forward/backward, activations, depthwise 3x3, stem conv, max-pool, SE gate,
+// adaptive 2D positional encoding, LayerNorm, embedding, cross-entropy, packing, clip + AdamW.
+#include "common.h"
+#include "kernels.h"
+
+#define DISPATCH_T(dt, ...)                      \
+  do {                                           \
+    if ((dt) == DT_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+    else { typedef float T; __VA_ARGS__; }       \
+  } while (0)
+
+static inline int grid_for(long work, int per_block = 256, int cap = 4096) {
+  long g = (work + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+// =============================================================================================
+// generic column reduction over a [M][C] matrix (C % CH == 0): up to NO sums per column.
+// block = TX column-chunk threads x TY row threads; partials go through LDS atomics, then one global
+// atomicAdd per column per block.  F::operator()(row, col0, float out[NO][CH]) adds the row's terms.
+// =============================================================================================
+template <typename T, int NO, typename F>
+__global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int rows_per_block, int tx_log2,
+                                                        float* o0, float* o1, int nmain) {
+  constexpr int CH = TT<T>::CH;
+  extern __shared__ float red[];  // [NO][TXC*CH]
+  const int TX = 1 << tx_log2, TY = 256 >> tx_log2;
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> tx_log2;
+  const int CC = C / CH;
+  const int cbase = blockIdx.y * TX;
+  const int c = cbase + tx;
+  for (int i = threadIdx.x; i < NO * TX * CH; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float acc[NO][CH];
+#pragma unroll
+  for (int k = 0; k < NO; ++k)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[k][j] = 0.f;
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  if (c < CC) {
+    for (long r = r0 + ty; r < r1; r += TY) f(r, c * CH, acc);
+#pragma unroll
+    for (int k = 0; k < NO; ++k)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) atomicAdd(&red[(k * TX + tx) * CH + j], acc[k][j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NO * TX * CH; i += 256) {
+    int k = i / (TX * CH), cj = i % (TX * CH);
+    int col = cbase * CH + cj;
+    if (col < C) {
+      // sums k < nmain go to o0[col*nmain + k]; the remaining one goes to o1[col]
+      if (k < nmain) atomicAdd(o0 + (long)col * nmain + k, red[i]);
+      else if (o1) atomicAdd(o1 + col, red[i]);
+    }
+  }
+}
+
+template <typename T, int NO, typename F>
+static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain, hipStream_t s) {
+  constexpr int CH = TT<T>::CH;
+  int CC = C / CH;
+  int txl = 0;
+  while ((1 << txl) < CC && txl < 8) ++txl;
+  int TX = 1 << txl, TY = 256 >> txl;
+  int gy = (CC + TX - 1) / TX;
+  long want_blocks = 1024 / gy;
+  if (want_blocks < 1) want_blocks = 1;
+  long rpb = (M + want_blocks - 1) / want_blocks;
+  long minr = (long)TY * 8;
+  if (rpb < minr) rpb = minr;
+  int gx = (int)((M + rpb - 1) / rpb);
+  size_t sh = (size_t)NO * TX * CH * sizeof(float);
+  hipLaunchKernelGGL((colreduce_kernel<T, NO, F>), dim3(gx, gy), dim3(256), sh, s, f, M, C, (int)rpb, txl, o0, o1,
+                     nmain);
+}
+
+// ---- BN batch statistics ------------------------------------------------------------------
+template <typename T> struct StatsF {
+  const T* y; int C;
+  __device__ void operator()(long r, int c0, float (*acc)[TT<T>::CH]) const {
+    float v[TT<T>::CH];
+    unpack<T>(ld16(y + r * C + c0), v);
+#pragma unroll
+    for (int j = 0; j < TT<T>::CH; ++j) { acc[0][j] += v[j]; acc[1][j] += v[j] * v[j]; }
+  }
+};
+void launch_colstats(int dt, const void* y, long M, int C, float* sums, hipStream_t s) {
+  DISPATCH_T(dt, { StatsF<T> f{(const T*)y, C}; launch_colreduce<T, 2>(f, M, C, sums, sums + C, 1, s); });
+}
+
+__global__ void bn_finalize_kernel(const float* sums, float invM, float unbias, int C, const float* w, const float* b,
+                                   float* rm, float* rv, int64_t* nbt, float eps, float mom, int train, float* ss,
+                                   float* mr) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (train) {
+    mean = sums[c] * invM;
+    var = fmaxf(sums[C + c] * invM - mean * mean, 0.f);
+    rm[c] = (1.f - mom) * rm[c] + mom * mean;
+    rv[c] = (1.f - mom) * rv[c] + mom * var * unbias;
+    if (c == 0 && nbt) *nbt += 1;
+  } else {
+    mean = rm[c];
+    var = rv[c];
+  }
+  float rstd = rsqrtf(var + eps);
+  float sc = w[c] * rstd;
+  ss[c] = sc;
+  ss[C + c] = b[c] - mean * sc;
+  mr[c] = mean;
+  mr[C + c] = rstd;
+}
+void launch_bn_finalize(const float* sums, long M, int C, const float* w, const float* b, float* rm, float* rv,
+                        int64_t* nbt, float eps, float mom, int train, float* ss, float* mr, hipStream_t s) {
+  float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, 1.0f / (float)M, unbias, C, w, b,
+                     rm, rv, nbt, eps, mom, train, ss, mr);
+}
+
+template <typename T>
+__global__ void bn_act_kernel(const T* y, const float* ss, const T* res, T* z, long nchunks, int C, int act) {
+  constexpr int CH = TT<T>::CH;
+  const int CC = C / CH;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    int c0 = (int)(i % CC) * CH;
+    float v[CH], r[CH];
+    unpack<T>(ld16(y + i * CH), v);
+    if (res) unpack<T>(ld16(res + i * CH), r);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      float u = act_fwd(v[j] * ss[c0 + j] + ss[C + c0 + j], act);
+      v[j] = res ? u + r[j] : u;
+    }
+    st16(z + i * CH, pack<T>(v));
+  }
+}
+void launch_bn_act(int dt, const void* y, const float* ss, const void* res, void* z, long M, int C, int act,
+                   hipStream_t s) {
+  DISPATCH_T(dt, {
+    long n = M * C / TT<T>::CH;
+    hipLaunchKernelGGL((bn_act_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)y, ss, (const T*)res, (T*)z, n,
+                       C, act);
+  });
+}
+
+template <typename T> struct BnBwdRedF {
+  const T* dz; const T* y; const float* ss; const float* mr; int C; int act;
+  __device__ void operator()(long r, int c0, float (*acc)[TT<T>::CH]) const {
+    constexpr int CH = TT<T>::CH;
+    float d[CH], v[CH];
+    unpack<T>(ld16(dz + r * C + c0), d);
+    unpack<T>(ld16(y + r * C + c0), v);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      float u = v[j] * ss[c0 + j] + ss[C + c0 + j];
+      float g = d[j] * act_bwd(u, act);
+      float xh = (v[j] - mr[c0 + j]) * mr[C + c0 + j];
+      acc[0][j] += g;
+      acc[1][j] += g * xh;
+    }
+  }
+};
+void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* ss, const float* mr, long M, int C,
+                          int act, float* red, hipStream_t s) {
+  DISPATCH_T(dt, {
+    BnBwdRedF<T> f{(const T*)dz, (const T*)y, ss, mr, C, act};
+    launch_colreduce<T, 2>(f, M, C, red, red + C, 1, s);
+  });
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* dz, const T* y, const float* ss, const float* mr, const float* w,
+                                    const float* red, float invM, long nchunks, int C, int act, T* dy, float* dw,
+                                    float* db) {
+  constexpr int CH = TT<T>::CH;
+  const int CC = C / CH;
+  long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i0 < C && dw) {  // parameter grads (grad buffers are zeroed per step: accumulate)
+    dw[i0] += red[C + i0];
+    db[i0] += red[i0];
+  }
+  for (long i = i0; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    int c0 = (int)(i % CC) * CH;
+    float d[CH], v[CH];
+    unpack<T>(ld16(dz + i * CH), d);
+    unpack<T>(ld16(y + i * CH), v);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      int c = c0 + j;
+      float u = v[j] * ss[c] + ss[C + c];
+      float g = d[j] * act_bwd(u, act);
+      float rstd = mr[C + c];
+      float xh = (v[j] - mr[c]) * rstd;
+      d[j] = w[c] * rstd * (g - red[c] * invM - xh * red[C + c] * invM);
+    }
+    st16(dy + i * CH, pack<T>(d));
+  }
+}
+void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* ss, const float* mr, const float* w,
+                         const float* red, long M, int C, int act, void* dy, float* dw, float* db, hipStream_t s) {
+  DISPATCH_T(dt, {
+    long n = M * C / TT<T>::CH;
+    int g = grid_for(n);
+    if ((long)g * 256 < C) g = (C + 255) / 256;
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g), dim3(256), 0, s, (const T*)dz, (const T*)y, ss, mr, w, red,
+                       1.0f / (float)M, n, C, act, (T*)dy, dw, db);
+  });
+}
+
+// ---- stem conv (Cin = 1 or 3, 3x3): direct, fp32 image + fp32 master weights -------------------
+template <typename T>
+__global__ void stem_conv_kernel(const float* img, const float* w, T* y, int B, int Cin, int H, int W, int Co, int OH,
+                                 int OW, int stride, int pad) {
+  constexpr int CH = TT<T>::CH;
+  const int CC = Co / CH;
+  long total = (long)B * OH * OW * CC;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int cc = (int)(i % CC);
+    long pix = i / CC;
+    int ox = (int)(pix % OW);
+    int oy = (int)((pix / OW) % OH);
+    int b = (int)(pix / ((long)OW * OH));
+    float acc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int kh = 0; kh < 3; ++kh) {
+        int sy = oy * stride - pad + kh;
+        if (sy < 0 || sy >= H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          int sx = ox * stride - pad + kw;
+          if (sx < 0 || sx >= W) continue;
+          float x = img[(((long)b * Cin + ci) * H + sy) * W + sx];
+#pragma unroll
+          for (int j = 0; j < CH; ++j) acc[j] += x * w[(((cc * CH + j) * Cin + ci) * 3 + kh) * 3 + kw];
+        }
+      }
+    st16(y + pix * Co + cc * CH, pack<T>(acc));
+  }
+}
+void launch_stem_conv(int dt, const float* img, const float* w, void* y, int B, int Cin, int H, int W, int Co, int OH,
+                      int OW, int stride, int pad, hipStream_t s) {
+  DISPATCH_T(dt, {
+    long n = (long)B * OH * OW * (Co / TT<T>::CH);
+    hipLaunchKernelGGL((stem_conv_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, img, w, (T*)y, B, Cin, H, W, Co, OH,
+                       OW, stride, pad);
+  });
+}
+
+// dW[co][ci][kh][kw] += sum_pix dy[pix][co] * img[b][ci][sy][sx]; LDS accumulation then global atomics
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* img, const T* dy, float* dw, int B, int Cin,
+                                                         int H, int W, int Co, int OH, int OW, int stride, int pad,
+                                                         int pix_per_block) {
+  constexpr int CH = TT<T>::CH;
+  extern __shared__ float red[];  // [Co*Cin*9]
+  const int nW = Co * Cin * 9;
+  for (int i = threadIdx.x; i < nW; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int CC = Co / CH;
+  long p0 = (long)blockIdx.x * pix_per_block;
+  long p1 = p0 + pix_per_block;
+  long NP = (long)B * OH * OW;
+  if (p1 > NP) p1 = NP;
+  // thread -> channel chunk (fixed) and a strided set of pixels
+  int cc = threadIdx.x % CC;
+  int lane_p = threadIdx.x / CC, np = 256 / CC;
+  if (lane_p < np) {
+    for (int ci = 0; ci < Cin; ++ci) {
+      float acc[9][CH];
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[t][j] = 0.f;
+      for (long pix = p0 + lane_p; pix < p1; pix += np) {
+        int ox = (int)(pix % OW);
+        int oy = (int)((pix / OW) % OH);
+        int b = (int)(pix / ((long)OW * OH));
+        float d[CH];
+        unpack<T>(ld16(dy + pix * Co + cc * CH), d);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          int sy = oy * stride - pad + kh;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            int sx = ox * stride - pad + kw;
+            float x = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? img[(((long)b * Cin + ci) * H + sy) * W + sx] : 0.f;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) acc[kh * 3 + kw][j] += d[j] * x;
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) atomicAdd(&red[((cc * CH + j) * Cin + ci) * 9 + t], acc[t][j]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nW; i += 256) atomicAdd(dw + i, red[i]);
+}
+void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int B, int Cin, int H, int W, int Co,
+                       int OH, int OW, int stride, int pad, hipStream_t s) {
+  DISPATCH_T(dt, {
+    long NP = (long)B * OH * OW;
+    int ppb = 2048;
+    int g = (int)((NP + ppb - 1) / ppb);
+    hipLaunchKernelGGL((stem_wgrad_kernel<T>), dim3(g), dim3(256), (size_t)Co * Cin * 9 * sizeof(float), s, img,
+                       (const T*)dy, dw, B, Cin, H, W, Co, OH, OW, stride, pad, ppb);
+  });
+}
+
+// ---- depthwise 3x3 (forward gather / transposed gather for the data gradient) -----------------------
+template <typename T, int MODE>
+__global__ void dwconv_kernel(const T* x, const T* wp, const float* bias, T* y, int B, int H, int W, int C, int OH,
+                              int OW, int stride, int pt, int pl, int beta) {
+  // MODE 0: x = input [B,H,W,C], y = output [B,OH,OW,C].  MODE 1: x = dY [B,H,W,C] (H,W = conv OUTPUT dims),
+  // y = dX [B,OH,OW,C] (OH,OW = conv INPUT dims).
+  constexpr int CH = TT<T>::CH;
+  const int CC = C / CH;
+  long total = (long)B * OH * OW * CC;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int cc = (int)(i % CC);
+    long pix = i / CC;
+    int ox = (int)(pix % OW);
+    int oy = (int)((pix / OW) % OH);
+    int b = (int)(pix / ((long)OW * OH));
+    float acc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] = (bias && MODE == 0) ? bias[cc * CH + j] : 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        int sy, sx;
+        bool ok;
+        if (MODE == 0) {
+          sy = oy * stride - pt + kh; sx = ox * stride - pl + kw;
+          ok = sy >= 0 && sy < H && sx >= 0 && sx < W;
+        } else {
+          int ty = oy + pt - kh, tx = ox + pl - kw;
+          sy = ty / stride; sx = tx / stride;
+          ok = ty >= 0 && tx >= 0 && sy * stride == ty && sx * stride == tx && sy < H && sx < W;
+        }
+        if (ok) {
+          float v[CH], wv[CH];
+          unpack<T>(ld16(x + (((long)b * H + sy) * W + sx) * C + cc * CH), v);
+          unpack<T>(ld16(wp + (kh * 3 + kw) * C + cc * CH), wv);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) acc[j] += v[j] * wv[j];
+        }
+      }
+    }
+    T* o = y + pix * C + cc * CH;
+    if (beta) {
+      float old[CH];
+      unpack<T>(ld16(o), old);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[j] += old[j];
+    }
+    st16(o, pack<T>(acc));
+  }
+}
+void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float* bias, void* y, int B, int H, int W,
+                   int C, int OH, int OW, int stride, int pt, int pl, int beta, hipStream_t s) {
+  DISPATCH_T(dt, {
+    long n = (long)B * OH * OW * (C / TT<T>::CH);
+    if (mode == 0)
+      hipLaunchKernelGGL((dwconv_kernel<T, 0>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)wp, bias,
+                         (T*)y, B, H, W, C, OH, OW, stride, pt, pl, beta);
+    else
+      hipLaunchKernelGGL((dwconv_kernel<T, 1>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)wp, bias,
+                         (T*)y, B, H, W, C, OH, OW, stride, pt, pl, beta);
+  });
+}
+
+template <typename T> struct DwWgradF {
+  const T* x; const T* dy; int H, W, C, OH, OW, stride, pt, pl;
+  __device__ void operator()(long r, int c0, float (*acc)[TT<T>::CH]) const {
+    constexpr int CH = TT<T>::CH;
+    int ox = (int)(r % OW);
+    int oy = (int)((r / OW) % OH);
+    int b = (int)(r / ((long)OW * OH));
+    float d[CH];
+    unpack<T>(ld16(dy + r * C + c0), d);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[9][j] += d[j];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        int sy = oy * stride - pt + kh, sx = ox * stride - pl + kw;
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+          float v[CH];
+          unpack<T>(ld16(x + (((long)b * H + sy) * W + sx) * C + c0), v);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) acc[kh * 3 + kw][j] += d[j] * v[j];
+        }
+      }
+  }
+};
+void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int C,
+                         int OH, int OW, int stride, int pt, int pl, hipStream_t s);
+
+// ---- max-pool 2x2 s2 -----------------------------------------------------------------------------
+template <typename T, int BWD>
+__global__ void maxpool_kernel(const T* x, const T* dy, T* out, int B, int H, int W, int C) {
+  constexpr int CH = TT<T>::CH;
+  const int CC = C / CH, OH = H / 2, OW = W / 2;
+  long total = (long)B * OH * OW * CC;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int cc = (int)(i % CC);
+    long pix = i / CC;
+    int ox = (int)(pix % OW);
+    int oy = (int)((pix / OW) % OH);
+    int b = (int)(pix / ((long)OW * OH));
+    float v[4][CH];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      unpack<T>(ld16(x + (((long)b * H + oy * 2 + (t >> 1)) * W + ox * 2 + (t & 1)) * C + cc * CH), v[t]);
+    if (!BWD) {
+      float m[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) m[j] = fmaxf(fmaxf(v[0][j], v[1][j]), fmaxf(v[2][j], v[3][j]));
+      st16(out + pix * C + cc * CH, pack<T>(m));
+    } else {
+      float d[CH], g[4][CH];
+      unpack<T>(ld16(dy + pix * C + cc * CH), d);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        int best = 0;
+        float m = v[0][j];
+#pragma unroll
+        for (int t = 1; t < 4; ++t) if (v[t][j] > m) { m = v[t][j]; best = t; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) g[t][j] = (t == best) ? d[j] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        st16(out + (((long)b * H + oy * 2 + (t >> 1)) * W + ox * 2 + (t & 1)) * C + cc * CH, pack<T>(g[t]));
+    }
+  }
+}
+void launch_maxpool(int dt, int bwd, const void* x, const void* dy, void* out, int B, int H, int W, int C,
+                    hipStream_t s) {
+  DISPATCH_T(dt, {
+    long n = (long)B * (H / 2) * (W / 2) * (C / TT<T>::CH);
+    if (bwd)
+      hipLaunchKernelGGL((maxpool_kernel<T, 1>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)out,
+                         B, H, W, C);
+    else
+      hipLaunchKernelGGL((maxpool_kernel<T, 0>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)out,
+                         B, H, W, C);
+  });
+}
+
+// ---- per-image reductions over HW: out[b][c (+C)] = sum_hw f(...)  ---------------------------------
+// MODE 0: mean x ; 1: sum a*b ; 2: posenc dgate (sum dout*hpos[h], sum dout*wpos[w] -> out[b][2C])
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void hw_reduce_kernel(const T* a, const T* bb, const float* hpos, const float* wpos,
+                                                        T* out, int HW, int Wd, int C, float scale) {
+  constexpr int CH = TT<T>::CH;
+  __shared__ float red[2][4][64 * CH];
+  const int CC = C / CH;
+  const int b = blockIdx.x;
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  float s0[CH], s1[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) s0[j] = s1[j] = 0.f;
+  if (c < CC) {
+    for (int p = rg; p < HW; p += 4) {
+      float v[CH];
+      unpack<T>(ld16(a + ((long)b * HW + p) * C + c * CH), v);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) s0[j] += v[j];
+      } else if (MODE == 1) {
+        float w[CH];
+        unpack<T>(ld16(bb + ((long)b * HW + p) * C + c * CH), w);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) s0[j] += v[j] * w[j];
+      } else {
+        int h = p / Wd, w_ = p - h * Wd;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          s0[j] += v[j] * hpos[h * C + c * CH + j];
+          s1[j] += v[j] * wpos[w_ * C + c * CH + j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { red[0][rg][cl * CH + j] = s0[j]; red[1][rg][cl * CH + j] = s1[j]; }
+  __syncthreads();
+  if (rg == 0 && c < CC) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      s0[j] = (red[0][0][cl * CH + j] + red[0][1][cl * CH + j] + red[0][2][cl * CH + j] + red[0][3][cl * CH + j]) * scale;
+      s1[j] = (red[1][0][cl * CH + j] + red[1][1][cl * CH + j] + red[1][2][cl * CH + j] + red[1][3][cl * CH + j]) * scale;
+    }
+    if (MODE == 2) {
+      st16(out + (long)b * 2 * C + c * CH, pack<T>(s0));
+      st16(out + (long)b * 2 * C + C + c * CH, pack<T>(s1));
+    } else {
+      st16(out + (long)b * C + c * CH, pack<T>(s0));
+    }
+  }
+}
+void launch_pool_hw(int dt, const void* x, void* out, int B, int HW, int C, hipStream_t s) {
+  DISPATCH_T(dt, {
+    int gy = (C / TT<T>::CH + 63) / 64;
+    hipLaunchKernelGGL((hw_reduce_kernel<T, 0>), dim3(B, gy), dim3(256), 0, s, (const T*)x, (const T*)nullptr, nullptr,
+                       nullptr, (T*)out, HW, 1, C, 1.0f / (float)HW);
+  });
+}
+void launch_se_bwd_gate(int dt, const void* dout, const void* x, void* dgate, int B, int HW, int C, hipStream_t s) {
+  DISPATCH_T(dt, {
+    int gy = (C / TT<T>::CH + 63) / 64;
+    hipLaunchKernelGGL((hw_reduce_kernel<T, 1>), dim3(B, gy), dim3(256), 0, s, (const T*)dout, (const T*)x, nullptr,
+                       nullptr, (T*)dgate, HW, 1, C, 1.0f);
+  });
+}
+void launch_posenc2d_bwd(int dt, const void* dout, const float* hpos, const float* wpos, void* dgate, int B, int H,
+                         int W, int C, hipStream_t s) {
+  DISPATCH_T(dt, {
+    int gy = (C / TT<T>::CH + 63) / 64;
+    hipLaunchKernelGGL((hw_reduce_kernel<T, 2>), dim3(B, gy), dim3(256), 0, s, (const T*)dout, (const T*)nullptr, hpos,
+                       wpos, (T*)dgate, H * W, W, C, 1.0f);
+  });
+}
+
+// ---- per-image broadcast elementwise ops ------------------------------------------------------------
+// MODE 0: out = x*gate[b][c]          (SE scale)
+// MODE 1: dx (+)= dout*gate[b][c] + dpool[b][c]*scale   (SE backward wrt x)
+// MODE 2: dx += dpool[b][c]*scale     (mean-pool backward)
+// MODE 3: out = x + g[b][c]*hpos[h][c] + g[b][C+c]*wpos[w][c]   (adaptive 2D positional encoding)
+template <typename T, int MODE>
+__global__ void bcast_kernel(const T* x, const T* gate, const T* dpool, const float* hpos, const float* wpos, T* out,
+                             long nchunks, int HW, int Wd, int C, float scale, int beta) {
+  constexpr int CH = TT<T>::CH;
+  const int CC = C / CH;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    int c0 = (int)(i % CC) * CH;
+    long pix = i / CC;
+    int b = (int)(pix / HW);
+    float v[CH], g[CH], r[CH];
+    if (MODE != 2) unpack<T>(ld16(x + i * CH), v);
+    if (MODE == 0) {
+      unpack<T>(ld16(gate + (long)b * C + c0), g);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) r[j] = v[j] * g[j];
+    } else if (MODE == 1) {
+      unpack<T>(ld16(gate + (long)b * C + c0), g);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) r[j] = v[j] * g[j];
+      if (dpool) {
+        unpack<T>(ld16(dpool + (long)b * C + c0), g);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) r[j] += g[j] * scale;
+      }
+      if (beta) {
+        unpack<T>(ld16(out + i * CH), g);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) r[j] += g[j];
+      }
+    } else if (MODE == 2) {
+      unpack<T>(ld16(dpool + (long)b * C + c0), g);
+      unpack<T>(ld16(out + i * CH), v);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) r[j] = v[j] + g[j] * scale;
+    } else {
+      int p = (int)(pix % HW);
+      int h = p / Wd, w_ = p - h * Wd;
+      float g1[CH];
+      unpack<T>(ld16(gate + (long)b * 2 * C + c0), g);
+      unpack<T>(ld16(gate + (long)b * 2 * C + C + c0), g1);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) r[j] = v[j] + g[j] * hpos[h * C + c0 + j] + g1[j] * wpos[w_ * C + c0 + j];
+    }
+    st16(out + i * CH, pack<T>(r));
+  }
+}
+void launch_se_scale(int dt, const void* x, const void* gate, void* out, int B, int HW, int C, hipStream_t s) {
+  DISPATCH_T(dt, {
+    long n = (long)B * HW * C / TT<T>::CH;
+    hipLaunchKernelGGL((bcast_kernel<T, 0>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)gate,
+                       (const T*)nullptr, nullptr, nullptr, (T*)out, n, HW, 1, C, 1.f, 0);
+  });
+}
+void launch_se_bwd_x(int dt, const void* dout, const void* gate, const void* dpool, void* dx, int B, int HW, int C,
+                     int beta, hipStream_t s) {
+  DISPATCH_T(dt, {
+    long n = (long)B * HW * C / TT<T>::CH;
+    hipLaunchKernelGGL((bcast_kernel<T, 1>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)dout, (const T*)gate,
+                       (const T*)dpool, nullptr, nullptr, (T*)dx, n, HW, 1, C, 1.0f / (float)HW, beta);
+  });
+}
+void launch_bcast_add_hw(int dt, const void* dpool, void* dx, int B, int HW, int C, float scale, hipStream_t s) {
+  DISPATCH_T(dt, {
+    long n = (long)B * HW * C / TT<T>::CH;
+    hipLaunchKernelGGL((bcast_kernel<T, 2>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)nullptr, (const T*)nullptr,
+                       (const T*)dpool, nullptr, nullptr, (T*)dx, n, HW, 1, C, scale, 1);
+  });
+}
+void launch_posenc2d(int dt, const void* x, const void* gate, const float* hpos, const float* wpos, void* out, int B,
+                     int H, int W, int C, hipStream_t s) {
+  DISPATCH_T(dt, {
+    long n = (long)B * H * W * C / TT<T>::CH;
+    hipLaunchKernelGGL((bcast_kernel<T, 3>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)gate,
+                       (const T*)nullptr, hpos, wpos, (T*)out, n, H * W, W, C, 1.f, 0);
+  });
+}
+
+// ---- depthwise wgrad launcher: 9 tap sums -> dw[c*9+t] (torch [C][1][3][3]), 10th sum -> dbias[c] ------------
+void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int C,
+                         int OH, int OW, int stride, int pt, int pl, hipStream_t s) {
+  DISPATCH_T(dt, {
+    DwWgradF<T> f{(const T*)x, (const T*)dy, H, W, C, OH, OW, stride, pt, pl};
+    launch_colreduce<T, 10>(f, (long)B * OH * OW, C, dw, dbias, 9, s);
+  });
+}
+
+// ---- LayerNorm: one wave per row ----------------------------------------------------------------------
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* a, const T* b, const float* w, const float* bias,
+                                                        T* out, float* mr, long R, int C, float eps) {
+  constexpr int CH = TT<T>::CH;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int CC = C / CH;
+  for (long r = (long)blockIdx.x * 4 + wv; r < R; r += (long)gridDim.x * 4) {
+    float v[NCH][CH];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      int c = lane + k * 64;
+      if (c < CC) {
+        unpack<T>(ld16(a + r * C + c * CH), v[k]);
+        if (b) {
+          float t[CH];
+          unpack<T>(ld16(b + r * C + c * CH), t);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) v[k][j] += t[j];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) sum += v[k][j];
+      }
+    }
+    float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      int c = lane + k * 64;
+      if (c < CC) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { float d = v[k][j] - mean; sq += d * d; }
+      }
+    }
+    float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    if (lane == 0 && mr) { mr[r] = mean; mr[R + r] = rstd; }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      int c = lane + k * 64;
+      if (c < CC) {
+        float o[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) o[j] = (v[k][j] - mean) * rstd * w[c * CH + j] + bias[c * CH + j];
+        st16(out + r * C + c * CH, pack<T>(o));
+      }
+    }
+  }
+}
+void launch_layernorm(int dt, const void* a, const void* b, const float* w, const float* bias, void* out, float* mr,
+                      long R, int C, float eps, float, const uint32_t*, uint32_t, hipStream_t s) {
+  DISPATCH_T(dt, {
+    int cc = C / TT<T>::CH;
+    int g = grid_for(R, 4, 2048);
+    if (cc <= 64)
+      hipLaunchKernelGGL((layernorm_kernel<T, 1>), dim3(g), dim3(256), 0, s, (const T*)a, (const T*)b, w, bias, (T*)out,
+                         mr, R, C, eps);
+    else if (cc <= 128)
+      hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(g), dim3(256), 0, s, (const T*)a, (const T*)b, w, bias, (T*)out,
+                         mr, R, C, eps);
+    else
+      hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(g), dim3(256), 0, s, (const T*)a, (const T*)b, w, bias, (T*)out,
+                         mr, R, C, eps);
+  });
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const T* a, const T* b, const float* w,
+                                                            const float* mr, T* da, T* db, int beta_a, int beta_b,
+                                                            float* dw, float* dbias, long R, int C) {
+  constexpr int CH = TT<T>::CH;
+  extern __shared__ float red[];  // [2][C]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int CC = C / CH;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float gw[NCH][CH], gb[NCH][CH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) gw[k][j] = gb[k][j] = 0.f;
+  for (long r = (long)blockIdx.x * 4 + wv; r < R; r += (long)gridDim.x * 4) {
+    const float mean = mr[r], rstd = mr[R + r];
+    float xh[NCH][CH], g[NCH][CH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      int c = lane + k * 64;
+      if (c < CC) {
+        float d[CH];
+        unpack<T>(ld16(a + r * C + c * CH), xh[k]);
+        if (b) {
+          float t[CH];
+          unpack<T>(ld16(b + r * C + c * CH), t);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) xh[k][j] += t[j];
+        }
+        unpack<T>(ld16(dout + r * C + c * CH), d);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          xh[k][j] = (xh[k][j] - mean) * rstd;
+          g[k][j] = d[j] * w[c * CH + j];
+          s1 += g[k][j];
+          s2 += g[k][j] * xh[k][j];
+          gw[k][j] += d[j] * xh[k][j];
+          gb[k][j] += d[j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      int c = lane + k * 64;
+      if (c < CC) {
+        float o[CH], t[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) o[j] = rstd * (g[k][j] - s1 - xh[k][j] * s2);
+        if (beta_a) {
+          unpack<T>(ld16(da + r * C + c * CH), t);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) t[j] += o[j];
+          st16(da + r * C + c * CH, pack<T>(t));
+        } else {
+          st16(da + r * C + c * CH, pack<T>(o));
+        }
+        if (db) {
+          if (beta_b) {
+            unpack<T>(ld16(db + r * C + c * CH), t);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) t[j] += o[j];
+            st16(db + r * C + c * CH, pack<T>(t));
+          } else {
+            st16(db + r * C + c * CH, pack<T>(o));
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    int c = lane + k * 64;
+    if (c < CC) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        atomicAdd(&red[c * CH + j], gw[k][j]);
+        atomicAdd(&red[C + c * CH + j], gb[k][j]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    atomicAdd(dw + i, red[i]);
+    atomicAdd(dbias + i, red[C + i]);
+  }
+}
+void launch_layernorm_bwd(int dt, const void* dout, const void* a, const void* b, const float* w, const float* mr,
+                          void* da, void* db, int beta_a, int beta_b, float* dw, float* dbias, long R, int C, float,
+                          const uint32_t*, uint32_t, hipStream_t s) {
+  DISPATCH_T(dt, {
+    int cc = C / TT<T>::CH;
+    int g = grid_for(R, 16, 512);
+    size_t sh = (size_t)2 * C * sizeof(float);
+    if (cc <= 64)
+      hipLaunchKernelGGL((layernorm_bwd_kernel<T, 1>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a,
+                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C);
+    else if (cc <= 128)
+      hipLaunchKernelGGL((layernorm_bwd_kernel<T, 2>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a,
+                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C);
+    else
+      hipLaunchKernelGGL((layernorm_bwd_kernel<T, 4>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a,
+                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C);
+  });
+}
+
+// ---- EncoderLayer raw reshape: [b,hw,c] buffer reinterpreted as [b,c,h,w] (reference :269) -----------
+// forward: Z[b][p][c] (NHWC of the reinterpreted tensor) = Y[b].flat[c*HW + p]; inverse scatters gradients back.
+template <typename T>
+__global__ void reshape_quirk_kernel(const T* in, T* out, int HW, int C, long total, int inverse, int beta) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long b = i / ((long)HW * C);
+    int r = (int)(i - b * (long)HW * C);
+    if (!inverse) {
+      int p = r / C, c = r - p * C;  // output element Z[b][p][c]
+      out[i] = in[b * (long)HW * C + (long)c * HW + p];
+    } else {
+      int c = r / HW, p = r - c * HW;  // output element dY[b].flat[c*HW+p] = dZ[b][p][c]
+      float v = to_f(in[b * (long)HW * C + (long)p * C + c]);
+      out[i] = from_f<T>(beta ? to_f(out[i]) + v : v);
+    }
+  }
+}
+void launch_reshape_quirk(int dt, int inverse, const void* in, void* out, int B, int HW, int C, int beta, hipStream_t s) {
+  DISPATCH_T(dt, {
+    long n = (long)B * HW * C;
+    hipLaunchKernelGGL((reshape_quirk_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)in, (T*)out, HW, C, n,
+                       inverse, beta);
+  });
+}
+
+// ---- embedding * sqrt(D) + 1-D positional encoding (+dropout) ----------------------------------------
+template <typename T>
+__global__ void embed_kernel(const int64_t* ids, const float* table, const float* pe, T* out, int L, int ld_ids, int D,
+                             int pos0, long total, float drop_p, const uint32_t* seedp, uint32_t site) {
+  const float sc = sqrtf((float)D);
+  const uint32_t seed = drop_p > 0.f ? *seedp : 0u;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int d = (int)(i % D);
+    long bt = i / D;
+    int t = (int)(bt % L);
+    long b = bt / L;
+    int64_t id = ids[b * ld_ids + t];
+    float v = table[id * D + d] * sc + pe[(long)(pos0 + t) * D + d];
+    if (drop_p > 0.f) v *= drop_scale(seed, site, (uint32_t)i, drop_p);
+    out[i] = from_f<T>(v);
+  }
+}
+void launch_embed(int dt, const int64_t* ids, const float* table, const float* pe, void* out, int B, int L, int ld_ids,
+                  int D, int pos0, float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s) {
+  DISPATCH_T(dt, {
+    long n = (long)B * L * D;
+    hipLaunchKernelGGL((embed_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, ids, table, pe, (T*)out, L, ld_ids, D,
+                       pos0, n, drop_p, seed, site);
+  });
+}
+template <typename T>
+__global__ void embed_bwd_kernel(const int64_t* ids, const T* dout, float* dtable, int L, int ld_ids, int D, long total,
+                                 float drop_p, const uint32_t* seedp, uint32_t site) {
+  const float sc = sqrtf((float)D);
+  const uint32_t seed = drop_p > 0.f ? *seedp : 0u;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int d = (int)(i % D);
+    long bt = i / D;
+    int t = (int)(bt % L);
+    long b = bt / L;
+    int64_t id = ids[b * ld_ids + t];
+    float g = to_f(dout[i]) * sc;
+    if (drop_p > 0.f) g *= drop_scale(seed, site, (uint32_t)i, drop_p);
+    atomicAdd(dtable + id * D + d, g);
+  }
+}
+void launch_embed_bwd(int dt, const int64_t* ids, const void* dout, float* dtable, int B, int L, int ld_ids, int D,
+                      float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s) {
+  DISPATCH_T(dt, {
+    long n = (long)B * L * D;
+    hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, ids, (const T*)dout, dtable, L,
+                       ld_ids, D, n, drop_p, seed, site);
+  });
+}
+
+// ---- bias gradients: out[c] += sum_rows x[row*ld + c] --------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long M, int C, int ld, float* out, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  long r0 = (long)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  float sum = 0.f;
+  if (c < C)
+    for (long r = r0 + rg; r < r1; r += 4) sum += to_f(x[r * ld + c]);
+  red[rg][cl] = sum;
+  __syncthreads();
+  if (rg == 0 && c < C) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+void launch_colsum(int dt, const void* x, long M, int C, int ld, float* out, hipStream_t s) {
+  DISPATCH_T(dt, {
+    int gy = (C + 63) / 64;
+    long want = 512 / gy;
+    if (want < 1) want = 1;
+    long rpb = (M + want - 1) / want;
+    if (rpb < 32) rpb = 32;
+    int gx = (int)((M + rpb - 1) / rpb);
+    hipLaunchKernelGGL((colsum_kernel<T>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, M, C, ld, out, (int)rpb);
+  });
+}
+
+// ---- activation backward for GEMM-epilogue activations -------------------------------------------------
+// RELU (+dropout): from the stored post-activation z.  SIGMOID: from post z.  SILU: from the PRE-activation u.
+template <typename T>
+__global__ void act_bwd_kernel(const T* dz, const T* zu, T* du, long n, int act, float keep_inv) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float d = to_f(dz[i]), z = to_f(zu[i]), r;
+    if (act == ACT_RELU) r = z > 0.f ? d * keep_inv : 0.f;
+    else if (act == ACT_SIGMOID) r = d * z * (1.f - z);
+    else if (act == ACT_SILU) r = d * act_bwd(z, ACT_SILU);
+    else r = d;
+    du[i] = from_f<T>(r);
+  }
+}
+void launch_act_bwd(int dt, const void* dz, const void* zu, void* du, long n, int act, float drop_p, hipStream_t s) {
+  DISPATCH_T(dt, {
+    hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)dz, (const T*)zu, (T*)du, n,
+                       act, 1.0f / (1.0f - drop_p));
+  });
+}
+template <typename T>
+__global__ void act_fwd_kernel(const T* u, T* z, long n, int act) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    z[i] = from_f<T>(act_fwd(to_f(u[i]), act));
+}
+void launch_act_fwd(int dt, const void* u, void* z, long n, int act, hipStream_t s) {
+  DISPATCH_T(dt, {
+    hipLaunchKernelGGL((act_fwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)u, (T*)z, n, act);
+  });
+}
+template <typename T>
+__global__ void dropout_bwd_kernel(const T* dz, T* du, long n, float p, const uint32_t* seedp, uint32_t site) {
+  const uint32_t seed = *seedp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    du[i] = from_f<T>(to_f(dz[i]) * drop_scale(seed, site, (uint32_t)i, p));
+}
+void launch_dropout_bwd(int dt, const void* dz, void* du, long M, int N, float p, const uint32_t* seed, uint32_t site,
+                        hipStream_t s) {
+  DISPATCH_T(dt, {
+    long n = M * N;
+    hipLaunchKernelGGL((dropout_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)dz, (T*)du, n, p, seed,
+                       site);
+  });
+}
+
+// ---- cross-entropy (ignore_index) on fp32 logits [R][V]: one wave per row ---------------------------------
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const int64_t* tgt, int ld_tgt, int tgt_off,
+                                                     int T_, int V, int pad_id, long R, float* out, float* lse_ws) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float lsum = 0.f, lcnt = 0.f;
+  for (long r = (long)blockIdx.x * 4 + wv; r < R; r += (long)gridDim.x * 4) {
+    const float* x = logits + r * V;
+    float m = -INFINITY;
+    for (int c = lane; c < V; c += 64) m = fmaxf(m, x[c]);
+    m = wave_max(m);
+    float se = 0.f;
+    for (int c = lane; c < V; c += 64) se += __expf(x[c] - m);
+    se = wave_sum(se);
+    float lse = m + __logf(se);
+    if (lane == 0) {
+      lse_ws[r] = lse;
+      int64_t t = tgt[(r / T_) * ld_tgt + tgt_off + (r % T_)];
+      if (t != pad_id) { lsum += lse - x[t]; lcnt += 1.f; }
+    }
+  }
+  if (lane == 0 && lcnt > 0.f) { atomicAdd(out, lsum); atomicAdd(out + 1, lcnt); }
+}
+template <typename TO>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, const int64_t* tgt, int ld_tgt, int tgt_off,
+                                                     int T_, int V, int Vp, int pad_id, long R, float* out,
+                                                     const float* lse_ws, TO* dlogits, const float* upstream) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float cnt = out[1];
+  const float sc = (cnt > 0.f ? 1.0f / cnt : 0.f) * (upstream ? *upstream : 1.0f);
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[2] = cnt > 0.f ? out[0] / cnt : 0.f;
+  for (long r = (long)blockIdx.x * 4 + wv; r < R; r += (long)gridDim.x * 4) {
+    const float* x = logits + r * V;
+    int64_t t = tgt[(r / T_) * ld_tgt + tgt_off + (r % T_)];
+    const float lse = lse_ws[r];
+    const bool valid = t != pad_id;
+    for (int c = lane; c < Vp; c += 64) {
+      float g = 0.f;
+      if (valid && c < V) g = (__expf(x[c] - lse) - (c == t ? 1.f : 0.f)) * sc;
+      dlogits[r * Vp + c] = from_f<TO>(g);
+    }
+  }
+}
+// loss_out: [0]=sum, [1]=count, [2]=mean (written by the backward kernel), [4..4+R) = per-row lse scratch
+void launch_ce(const float* logits, const int64_t* tgt, int ld_tgt, int tgt_off, int B, int T_, int V, int pad_id,
+               float* loss_out, float* dlogits, hipStream_t s);
+
+template <typename TO>
+static void launch_ce_bwd_t(const float* logits, const int64_t* tgt, int ld_tgt, int tgt_off, int B, int T_, int V,
+                            int Vp, int pad_id, float* out, const float* lse_ws, void* dl, const float* upstream,
+                            hipStream_t s) {
+  long R = (long)B * T_;
+  hipLaunchKernelGGL((ce_bwd_kernel<TO>), dim3(grid_for(R, 4, 2048)), dim3(256), 0, s, logits, tgt, ld_tgt, tgt_off, T_,
+                     V, Vp, pad_id, R, out, lse_ws, (TO*)dl, upstream);
+}
+void launch_ce_full(int dt_out, const float* logits, const int64_t* tgt, int ld_tgt, int tgt_off, int B, int T_, int V,
+                    int Vp, int pad_id, float* loss_out /*[4]*/, float* lse_ws /*[R]*/, void* dlogits,
+                    const float* upstream, hipStream_t s) {
+  long R = (long)B * T_;
+  (void)hipMemsetAsync(loss_out, 0, 4 * sizeof(float), s);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid_for(R, 4, 2048)), dim3(256), 0, s, logits, tgt, ld_tgt, tgt_off, T_, V,
+                     pad_id, R, loss_out, lse_ws);
+  if (dt_out == DT_BF16) launch_ce_bwd_t<bf16_t>(logits, tgt, ld_tgt, tgt_off, B, T_, V, Vp, pad_id, loss_out, lse_ws, dlogits, upstream, s);
+  else launch_ce_bwd_t<float>(logits, tgt, ld_tgt, tgt_off, B, T_, V, Vp, pad_id, loss_out, lse_ws, dlogits, upstream, s);
+}
+
+// ---- misc -----------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* in, TO* out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = from_f<TO>(to_f(in[i]));
+}
+void launch_cast(int dt_in, int dt_out, const void* in, void* out, long n, hipStream_t s) {
+  int g = grid_for(n);
+  if (dt_in == DT_F32 && dt_out == DT_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)in, (bf16_t*)out, n);
+  else if (dt_in == DT_BF16 && dt_out == DT_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)in, (float*)out, n);
+  else if (dt_in == DT_F32) (void)hipMemcpyAsync(out, in, n * 4, hipMemcpyDeviceToDevice, s);
+  else (void)hipMemcpyAsync(out, in, n * 2, hipMemcpyDeviceToDevice, s);
+}
+// padded cast: in [R][C] fp32 -> out [R][Cp] as T with zero fill
+template <typename TO>
+__global__ void cast_pad_kernel(const float* in, TO* out, long R, int C, int Cp) {
+  long n = R * Cp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long r = i / Cp;
+    int c = (int)(i - r * Cp);
+    out[i] = from_f<TO>(c < C ? in[r * C + c] : 0.f);
+  }
+}
+void launch_cast_pad(int dt_out, const float* in, void* out, long R, int C, int Cp, hipStream_t s) {
+  int g = grid_for(R * Cp);
+  if (dt_out == DT_BF16) hipLaunchKernelGGL((cast_pad_kernel<bf16_t>), dim3(g), dim3(256), 0, s, in, (bf16_t*)out, R, C, Cp);
+  else hipLaunchKernelGGL((cast_pad_kernel<float>), dim3(g), dim3(256), 0, s, in, (float*)out, R, C, Cp);
+}
+void launch_fill(void* p, int value_byte, size_t bytes, hipStream_t s) { (void)hipMemsetAsync(p, value_byte, bytes, s); }
+
+template <typename T>
+__global__ void add_kernel(const T* a, const T* b, T* out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = from_f<T>(to_f(a[i]) + to_f(b[i]));
+}
+void launch_add(int dt, const void* a, const void* b, void* out, long n, hipStream_t s) {
+  DISPATCH_T(dt, { hipLaunchKernelGGL((add_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)a, (const T*)b, (T*)out, n); });
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int64_t* ids, int R, int V, int ld_in, int ld_out) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int r = blockIdx.x * 4 + wv;
+  if (r >= R) return;
+  const float* x = logits + (long)r * ld_in;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < V; c += 64) {
+    float v = x[c];
+    if (v > best) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ob = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) ids[(long)r * ld_out] = bi;
+}
+void launch_argmax(const float* logits, int64_t* ids, int R, int V, int ld_in, int ld_out, hipStream_t s) {
+  hipLaunchKernelGGL(argmax_kernel, dim3((R + 3) / 4), dim3(256), 0, s, logits, ids, R, V, ld_in, ld_out);
+}
+__global__ void seed_advance_kernel(uint32_t* seed) { *seed = mix32(*seed + 0x9E3779B9u); }
+void launch_seed_advance(uint32_t* seed, hipStream_t s) { hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, s, seed); }
+
+// ---- weight packing (fp32 master -> compute dtype, contraction-major copies) --------------------------------
+template <typename T>
+__global__ void pack_dense_kernel(const float* w, T* fwd, T* bwd, int N, int K, int ldb) {
+  long n = (long)N * K;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int r = (int)(i / K), k = (int)(i - (long)r * K);
+    T v = from_f<T>(w[i]);
+    if (fwd) fwd[i] = v;
+    if (bwd) bwd[(long)k * ldb + r] = v;
+  }
+}
+void launch_pack_dense(int dt, const float* w, void* fwd, void* bwd, int N, int K, hipStream_t s);
+void launch_pack_dense_ld(int dt, const float* w, void* fwd, void* bwd, int N, int K, int ldb, hipStream_t s) {
+  DISPATCH_T(dt, {
+    hipLaunchKernelGGL((pack_dense_kernel<T>), dim3(grid_for((long)N * K)), dim3(256), 0, s, w, (T*)fwd, (T*)bwd, N, K, ldb);
+  });
+}
+void launch_pack_dense(int dt, const float* w, void* fwd, void* bwd, int N, int K, hipStream_t s) {
+  launch_pack_dense_ld(dt, w, fwd, bwd, N, K, N, s);
+}
+template <typename T>
+__global__ void pack_conv_kernel(const float* w, T* fwd, T* bwd, int Co, int Ci, int taps) {
+  long n = (long)Co * Ci * taps;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int t = (int)(i % taps);
+    int ci = (int)((i / taps) % Ci);
+    int co = (int)(i / ((long)taps * Ci));
+    T v = from_f<T>(w[i]);
+    fwd[((long)co * taps + t) * Ci + ci] = v;
+    bwd[((long)ci * taps + t) * Co + co] = v;
+  }
+}
+void launch_pack_conv(int dt, const float* w, void* fwd, void* bwd, int Co, int Ci, int taps, hipStream_t s) {
+  DISPATCH_T(dt, {
+    hipLaunchKernelGGL((pack_conv_kernel<T>), dim3(grid_for((long)Co * Ci * taps)), dim3(256), 0, s, w, (T*)fwd, (T*)bwd, Co, Ci, taps);
+  });
+}
+template <typename T>
+__global__ void pack_dw_kernel(const float* w, T* out, int C) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * 9) return;
+  int c = i / 9, t = i % 9;
+  out[t * C + c] = from_f<T>(w[i]);
+}
+void launch_pack_dw(int dt, const float* w, void* out, int C, hipStream_t s) {
+  DISPATCH_T(dt, { hipLaunchKernelGGL((pack_dw_kernel<T>), dim3((C * 9 + 255) / 256), dim3(256), 0, s, w, (T*)out, C); });
+}
+
+// ---- global grad-norm clip + AdamW over the flat parameter buffer ----------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4;
+  long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    float4 v = *reinterpret_cast<const float4*>(g + i);
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  for (; i < n; i += stride)
+    for (long j = i; j < n && j < i + 4; ++j) s += g[j] * g[j];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+void launch_sumsq(const float* g, long n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, 256, 1024)), dim3(256), 0, s, g, n, out);
+}
+// hyper: [0] lr [1] beta1 [2] beta2 [3] eps [4] weight_decay [5] max_norm [6] 1-beta1^t [7] 1-beta2^t [8] grad_scale
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq,
+                             const float* hy) {
+  const float lr = hy[0], b1 = hy[1], b2 = hy[2], eps = hy[3], wd = hy[4], maxn = hy[5], bc1 = hy[6], bc2 = hy[7],
+              gs = hy[8];
+  float coef = gs;
+  if (maxn > 0.f) {
+    float norm = sqrtf(*gnorm_sq) * gs;
+    coef *= fminf(1.f, maxn / (norm + 1e-6f));
+  }
+  const float rs2 = rsqrtf(bc2);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * coef;
+    float pi = p[i] * (1.f - lr * wd);
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - (lr / bc1) * mi / (sqrtf(vi) * rs2 + eps);
+  }
+}
+void launch_adamw(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, const float* hyper,
+                  hipStream_t s) {
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, p, g, m, v, n, gnorm_sq, hyper);
+}

@@ -1,0 +1,356 @@
+// Contraction kernels for gfx950 (MFMA 16x16x32 bf16 / exact-f32 16x16x4):
+//   gemm_kernel : C[M,N] = epilogue(gather(A)[M,K] * Bw[N,K]^T)   -- linear layers, 1x1 conv, im2col-free
+//                 3x3 conv forward (AM_CONV) and data-gradient (AM_DGRAD) over NHWC activations.
+//   wgrad_kernel: dW[N,K] += dY[M,N]^T * gather(A)[M,K]           -- weight gradients (split over M) and
+//                 the batched P^T*dO / dS^T*Q products of attention backward.
+// Both stage 32-deep k-panels through LDS (swizzled, double buffered, one barrier per step); the global
+// loads of step t+1 are in flight while step t's MFMAs run.
+#include "common.h"
+#include "kernels.h"
+
+template <int AM> struct RowInfo { int by, bx, img; bool ok; };
+
+template <typename T, int BM, int BN, int AM>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  constexpr int CH = TT<T>::CH, CPR = TT<T>::CPR;
+  constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;
+  constexpr int MT = BM / 64, NT = BN / 16;
+  __shared__ __attribute__((aligned(16))) T lds[2 * (BM + BN) * 32];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntn = (p.N + BN - 1) / BN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = wg % ntn, tile_m = wg / ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const T* A = (const T*)p.A;
+  const T* Bw = (const T*)p.Bw;
+
+  // ---- per-thread staging assignments (chunk column is the same for all of a thread's chunks)
+  const int cc = tid % CPR;
+  RowInfo<AM> ri[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    int idx = tid + i * 256;
+    int row = idx / CPR;
+    int m = m0 + row;
+    ri[i].ok = (idx < BM * CPR) && (m < p.M);
+    if (AM == AM_DENSE) {
+      ri[i].img = m;
+      ri[i].by = ri[i].bx = 0;
+    } else {
+      int ohw = p.OH * p.OW;
+      int b = m / ohw, r = m - b * ohw;
+      int oy = r / p.OW, ox = r - oy * p.OW;
+      ri[i].img = b * p.H * p.W;
+      if (AM == AM_CONV) { ri[i].by = oy * p.stride - p.pt; ri[i].bx = ox * p.stride - p.pl; }
+      else { ri[i].by = oy + p.pt; ri[i].bx = ox + p.pl; }
+    }
+  }
+  int tap = 0, ci = cc * CH;  // k position of this thread's chunk column (conv modes)
+  if (AM != AM_DENSE) { while (ci >= p.Ci) { ci -= p.Ci; ++tap; } }
+
+  uint4 ra[NA], rb[NB];
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * 32 + cc * CH;
+    const bool kok = k0 < p.K;
+    int kh = 0, kw = 0;
+    if (AM != AM_DENSE) { kh = (p.KW == 1) ? 0 : (tap * 11) >> 5; kw = tap - kh * p.KW; }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      uint4 v = zero16();
+      if (ri[i].ok && kok) {
+        if (AM == AM_DENSE) {
+          v = ld16(A + (long)ri[i].img * p.lda + k0);
+          if (p.ascale) {
+            float f[CH];
+            unpack<T>(v, f);
+            const float* gp = p.ascale + (long)(ri[i].img / p.ascale_hw) * p.K + k0;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) f[j] *= gp[j];
+            v = pack<T>(f);
+          }
+        } else if (AM == AM_CONV) {
+          int sy = ri[i].by + kh, sx = ri[i].bx + kw;
+          if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
+            v = ld16(A + ((long)(ri[i].img + sy * p.W + sx)) * p.Ci + ci);
+        } else {
+          int ty = ri[i].by - kh, tx = ri[i].bx - kw;
+          if (ty >= 0 && tx >= 0) {
+            int sy = ty / p.stride, sx = tx / p.stride;
+            if (sy * p.stride == ty && sx * p.stride == tx && sy < p.H && sx < p.W)
+              v = ld16(A + ((long)(ri[i].img + sy * p.W + sx)) * p.Ci + ci);
+          }
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int idx = tid + i * 256;
+      int row = idx / CPR, n = n0 + row;
+      uint4 v = zero16();
+      if (idx < BN * CPR && n < p.N && kok) v = ld16(Bw + (long)n * p.K + k0);
+      rb[i] = v;
+    }
+    if (AM != AM_DENSE) { ci += 32; while (ci >= p.Ci) { ci -= p.Ci; ++tap; } }
+  };
+  auto store_tiles = [&](int buf) {
+    T* la = lds + buf * (BM + BN) * 32;
+    T* lb = la + BM * 32;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int idx = tid + i * 256;
+      if (idx < BM * CPR) st16(la + panel_chunk<T>(idx / CPR, cc), ra[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int idx = tid + i * 256;
+      if (idx < BN * CPR) st16(lb + panel_chunk<T>(idx / CPR, cc), rb[i]);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + 31) / 32;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const T* la = lds + cur * (BM + BN) * 32;
+    const T* lb = la + BM * 32;
+    Frag<T> af[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = load_frag<T>(la, wave * (BM / 4) + i * 16 + fr, fq);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      Frag<T> bf = load_frag<T>(lb, j * 16 + fr, fq);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) mma(af[i], bf, acc[i][j]);
+    }
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C layout col = lane&15, row = (lane>>4)*4 + reg
+  const uint32_t seed = (p.drop_p > 0.f) ? *p.seed : 0u;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + j * 16 + fr;
+      if (col >= p.N) continue;
+      const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wave * (BM / 4) + i * 16 + fq * 4 + r;
+        if (row >= p.M) continue;
+        float v = act_fwd(acc[i][j][r] + bias, p.act);
+        if (p.drop_p > 0.f) v *= drop_scale(seed, p.site, (uint32_t)(row * p.N + col), p.drop_p);
+        const long o = (long)row * p.ldc + col;
+        if (p.out_f32) {
+          float* c = (float*)p.C;
+          c[o] = p.beta ? c[o] + v : v;
+        } else {
+          T* c = (T*)p.C;
+          c[o] = from_f<T>(p.beta ? to_f(c[o]) + v : v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int AM>
+static void launch_gemm_t(const GemmP& p, hipStream_t s) {
+  // tile choice: narrow-N problems get tall tiles; small problems get small tiles to fill 256 CUs
+  auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  if (p.N <= 32) {
+    hipLaunchKernelGGL((gemm_kernel<T, 256, 32, AM>), dim3(blocks(256, 32)), dim3(256), 0, s, p);
+  } else if (p.N <= 64 || blocks(128, 128) < 256) {
+    if (blocks(128, 64) >= 512)
+      hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AM>), dim3(blocks(128, 64)), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<T, 128, 128, AM>), dim3(blocks(128, 128)), dim3(256), 0, s, p);
+  }
+}
+
+void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s) {
+  if (p.M <= 0 || p.N <= 0) return;
+  if (dt == DT_BF16) {
+    if (amode == AM_DENSE) launch_gemm_t<bf16_t, AM_DENSE>(p, s);
+    else if (amode == AM_CONV) launch_gemm_t<bf16_t, AM_CONV>(p, s);
+    else launch_gemm_t<bf16_t, AM_DGRAD>(p, s);
+  } else {
+    if (amode == AM_DENSE) launch_gemm_t<float, AM_DENSE>(p, s);
+    else if (amode == AM_CONV) launch_gemm_t<float, AM_CONV>(p, s);
+    else launch_gemm_t<float, AM_DGRAD>(p, s);
+  }
+}
+
+// =========================================================================================
+// wgrad: dW[n][k] += sum_m dY[m][n] * A[m][k].  Output tile 64(n) x 64(k); each block reduces a slice
+// of M in 32-row steps.  Both operands are transposed on their way into LDS (m becomes the panel's
+// contiguous k axis) so the MFMA fragment reads are the same 16-byte reads as in gemm_kernel.
+// =========================================================================================
+template <typename T, int CONV>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split) {
+  constexpr int CH = TT<T>::CH;
+  constexpr int CPT = 64 / CH;             // chunks per 64-wide tile row (8 bf16 / 16 f32)
+  constexpr int NC = (32 * CPT) / 256;      // chunks per thread per operand (1 / 2)
+  __shared__ __attribute__((aligned(16))) T lds[2 * 2 * 64 * 32];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntk = (p.K + 63) / 64;
+  const int tile_k = blockIdx.x % ntk, tile_n = blockIdx.x / ntk;
+  const int n0 = tile_n * 64, k0 = tile_k * 64;
+  const int z = blockIdx.z;
+  const int zo = z / p.nb_inner, zi = z % p.nb_inner;
+  const T* dY = (const T*)p.dY + zo * p.sY_o + zi * p.sY_i;
+  const T* A = (const T*)p.A + zo * p.sA_o + zi * p.sA_i;
+  const int m_begin = blockIdx.y * rows_per_split;
+  const int m_end = min(p.M, m_begin + rows_per_split);
+
+  // thread -> (m within step = tid % 32, chunk = tid / 32 [+ 8 for second chunk])
+  const int tm = tid & 31;
+  int ycol[NC], acol[NC], atap[NC], aci[NC];
+  bool yok[NC], aok[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    int c = (tid >> 5) + i * 8;
+    ycol[i] = n0 + c * CH;
+    yok[i] = ycol[i] < p.N;
+    acol[i] = k0 + c * CH;
+    aok[i] = acol[i] < p.K;
+    if (CONV) { atap[i] = acol[i] / p.Ci; aci[i] = acol[i] - atap[i] * p.Ci; } else { atap[i] = 0; aci[i] = acol[i]; }
+  }
+  uint4 ry[NC], rx[NC];
+  auto load_tiles = [&](int mstep) {
+    const int m = mstep + tm;
+    const bool mok = m < m_end;
+    int img = 0, by = 0, bx = 0;
+    if (CONV && mok) {
+      int ohw = p.OH * p.OW;
+      int b = m / ohw, r = m - b * ohw;
+      int oy = r / p.OW, ox = r - oy * p.OW;
+      img = b * p.H * p.W; by = oy * p.stride - p.pt; bx = ox * p.stride - p.pl;
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      ry[i] = (mok && yok[i]) ? ld16(dY + (long)m * p.ldy + ycol[i]) : zero16();
+      uint4 v = zero16();
+      if (mok && aok[i]) {
+        if (CONV) {
+          int kh = (p.KW == 1) ? 0 : (atap[i] * 11) >> 5, kw = atap[i] - kh * p.KW;
+          int sy = by + kh, sx = bx + kw;
+          if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) v = ld16(A + ((long)(img + sy * p.W + sx)) * p.Ci + aci[i]);
+        } else {
+          v = ld16(A + (long)m * p.lda + acol[i]);
+          if (p.ascale) {
+            float f[CH];
+            unpack<T>(v, f);
+            const float* gp = p.ascale + (long)(m / p.ascale_hw) * p.K + acol[i];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) f[j] *= gp[j];
+            v = pack<T>(f);
+          }
+        }
+      }
+      rx[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    T* ly = lds + buf * (2 * 64 * 32);
+    T* lx = ly + 64 * 32;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      int c = (tid >> 5) + i * 8;
+      const T* ey = (const T*)&ry[i];
+      const T* ex = (const T*)&rx[i];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        ly[panel_elem<T>(c * CH + j, tm)] = ey[j];
+        lx[panel_elem<T>(c * CH + j, tm)] = ex[j];
+      }
+    }
+  };
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  if (m_begin < m_end) {
+    load_tiles(m_begin);
+    store_tiles(0);
+    __syncthreads();
+    int cur = 0;
+    for (int ms = m_begin; ms < m_end; ms += 32) {
+      const bool more = ms + 32 < m_end;
+      if (more) load_tiles(ms + 32);
+      const T* ly = lds + cur * (2 * 64 * 32);
+      const T* lx = ly + 64 * 32;
+      Frag<T> af = load_frag<T>(ly, wave * 16 + fr, fq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        Frag<T> bf = load_frag<T>(lx, j * 16 + fr, fq);
+        mma(af, bf, acc[j]);
+      }
+      if (more) store_tiles(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  const int taps = CONV ? (p.KW * p.KW) : 1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + j * 16 + fr;
+    if (k >= p.K) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wave * 16 + fq * 4 + r;
+      if (n >= p.N) continue;
+      if (p.out_t) {
+        T* o = (T*)p.dW + zo * p.sW_o + zi * p.sW_i;
+        o[(long)n * p.ldw + k] = from_f<T>(acc[j][r]);
+      } else {
+        long dst;
+        if (CONV) { int tp = k / p.Ci, c = k - tp * p.Ci; dst = ((long)n * p.Ci + c) * taps + tp; }
+        else dst = (long)n * p.K + k;
+        atomicAdd((float*)p.dW + dst, acc[j][r]);
+      }
+    }
+  }
+}
+
+void launch_wgrad(int dt, const WgradP& p, hipStream_t s) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return;
+  const int tiles = ((p.N + 63) / 64) * ((p.K + 63) / 64);
+  const int nb = p.nbatch > 0 ? p.nbatch : 1;
+  int splits = 1;
+  if (!p.out_t) {
+    splits = (int)((2048 + (long)tiles * nb - 1) / ((long)tiles * nb));
+    int maxs = (p.M + 255) / 256;
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+  }
+  int rps = (p.M + splits - 1) / splits;
+  rps = ((rps + 31) / 32) * 32;
+  splits = (p.M + rps - 1) / rps;
+  WgradP q = p;
+  if (q.nb_inner <= 0) q.nb_inner = 1;
+  dim3 grid(tiles, splits, nb);
+  if (dt == DT_BF16) {
+    if (p.conv) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1>), grid, dim3(256), 0, s, q, rps);
+    else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 0>), grid, dim3(256), 0, s, q, rps);
+  } else {
+    if (p.conv) hipLaunchKernelGGL((wgrad_kernel<float, 1>), grid, dim3(256), 0, s, q, rps);
+    else hipLaunchKernelGGL((wgrad_kernel<float, 0>), grid, dim3(256), 0, s, q, rps);
+  }
+}

@@ -1,0 +1,363 @@
+// extern "C" boundary of libsatrn_hip.so (declarations + reference citations: include/satrn_hip.h).
+#include <string.h>
+
+#include <string>
+
+#include "../../include/satrn_hip.h"
+#include "engine.h"
+
+void launch_act_fwd(int dt, const void* u, void* z, long n, int act, hipStream_t s);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+static int done(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(-10, std::string(what) + ": " + hipGetErrorString(e));
+  return 0;
+}
+#define S(x) ((hipStream_t)(x))
+#define CHK_DT(dt) do { if ((dt) != 0 && (dt) != 1) return fail(-1, "dtype must be 0 (f32) or 1 (bf16)"); } while (0)
+static int chk_c(int dt, int c, const char* what) {
+  int ch = dt == DT_BF16 ? 8 : 4;
+  if (c <= 0 || c % ch) return fail(-1, std::string(what) + " must be a positive multiple of " + std::to_string(ch));
+  return 0;
+}
+
+extern "C" {
+
+const char* satrn_last_error(void) { return g_err.c_str(); }
+int satrn_abi_version(void) { return 1; }
+
+int satrn_pack_dense(int dt, const float* w, void* fwd, void* bwd, int N, int K, int ldb, void* st) {
+  CHK_DT(dt);
+  launch_pack_dense_ld(dt, w, fwd, bwd, N, K, ldb, S(st));
+  return done("pack_dense");
+}
+int satrn_pack_conv3x3(int dt, const float* w, void* fwd, void* bwd, int Co, int Ci, void* st) {
+  CHK_DT(dt);
+  launch_pack_conv(dt, w, fwd, bwd, Co, Ci, 9, S(st));
+  return done("pack_conv3x3");
+}
+int satrn_pack_dwconv3x3(int dt, const float* w, void* out, int C, void* st) {
+  CHK_DT(dt);
+  launch_pack_dw(dt, w, out, C, S(st));
+  return done("pack_dwconv3x3");
+}
+
+int satrn_linear_fwd(int dt, const void* x, const void* w, const float* bias, void* y, int M, int N, int K, int act,
+                     int out_f32, float drop_p, const uint32_t* seed, uint32_t site, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, K, "K")) return -1;
+  if (drop_p > 0.f && !seed) return fail(-1, "dropout needs a device seed");
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = x; p.Bw = w; p.C = y; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldc = N; p.act = act;
+  p.out_f32 = out_f32; p.drop_p = drop_p; p.seed = seed; p.site = site;
+  launch_gemm(dt, AM_DENSE, p, S(st));
+  return done("linear_fwd");
+}
+int satrn_linear_bwd_data(int dt, const void* dy, int ldy, const void* wb, int ldb, void* dx, int M, int N, int K,
+                          int accumulate, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, ldb, "ldb") || chk_c(dt, ldy, "ldy")) return -1;
+  (void)N;
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = dy; p.Bw = wb; p.C = dx; p.M = M; p.N = K; p.K = ldb; p.lda = ldy; p.ldc = K; p.beta = accumulate;
+  launch_gemm(dt, AM_DENSE, p, S(st));
+  return done("linear_bwd_data");
+}
+int satrn_linear_bwd_weight(int dt, const void* dy, int ldy, const void* x, float* dw, float* db, int M, int N, int K,
+                            void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, K, "K") || chk_c(dt, ldy, "ldy")) return -1;
+  WgradP q;
+  memset(&q, 0, sizeof(q));
+  q.dY = dy; q.A = x; q.dW = dw; q.M = M; q.N = N; q.K = K; q.ldy = ldy; q.lda = K; q.nbatch = 1; q.nb_inner = 1;
+  launch_wgrad(dt, q, S(st));
+  if (db) launch_colsum(dt, dy, M, N, ldy, db, S(st));
+  return done("linear_bwd_weight");
+}
+
+static void conv_geo(GemmP& p, int H, int W, int Ci, int OH, int OW, int stride, int pt, int pl) {
+  p.H = H; p.W = W; p.Ci = Ci; p.OH = OH; p.OW = OW; p.KW = 3; p.stride = stride; p.pt = pt; p.pl = pl;
+}
+int satrn_conv3x3_fwd(int dt, const void* x, const void* w, void* y, int B, int H, int W, int Ci, int Co, int OH, int OW,
+                      int stride, int pt, int pl, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, Ci, "Ci") || chk_c(dt, Co, "Co")) return -1;
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = x; p.Bw = w; p.C = y; p.M = B * OH * OW; p.N = Co; p.K = 9 * Ci; p.ldc = Co;
+  conv_geo(p, H, W, Ci, OH, OW, stride, pt, pl);
+  launch_gemm(dt, AM_CONV, p, S(st));
+  return done("conv3x3_fwd");
+}
+int satrn_conv3x3_bwd_data(int dt, const void* dy, const void* wb, void* dx, int B, int H, int W, int Ci, int Co, int OH,
+                           int OW, int stride, int pt, int pl, int accumulate, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, Ci, "Ci") || chk_c(dt, Co, "Co")) return -1;
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = dy; p.Bw = wb; p.C = dx; p.M = B * H * W; p.N = Ci; p.K = 9 * Co; p.ldc = Ci; p.beta = accumulate;
+  conv_geo(p, OH, OW, Co, H, W, stride, pt, pl);
+  launch_gemm(dt, AM_DGRAD, p, S(st));
+  return done("conv3x3_bwd_data");
+}
+int satrn_conv3x3_bwd_weight(int dt, const void* dy, const void* x, float* dw, int B, int H, int W, int Ci, int Co,
+                             int OH, int OW, int stride, int pt, int pl, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, Ci, "Ci") || chk_c(dt, Co, "Co")) return -1;
+  WgradP q;
+  memset(&q, 0, sizeof(q));
+  q.dY = dy; q.A = x; q.dW = dw; q.M = B * OH * OW; q.N = Co; q.K = 9 * Ci; q.ldy = Co; q.conv = 1; q.nbatch = 1; q.nb_inner = 1;
+  q.H = H; q.W = W; q.Ci = Ci; q.OH = OH; q.OW = OW; q.KW = 3; q.stride = stride; q.pt = pt; q.pl = pl;
+  launch_wgrad(dt, q, S(st));
+  return done("conv3x3_bwd_weight");
+}
+int satrn_stem_conv_fwd(int dt, const float* img, const float* w, void* y, int B, int Cin, int H, int W, int Co, int stride,
+                        int pad, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, Co, "Co")) return -1;
+  int OH = (H + 2 * pad - 3) / stride + 1, OW = (W + 2 * pad - 3) / stride + 1;
+  launch_stem_conv(dt, img, w, y, B, Cin, H, W, Co, OH, OW, stride, pad, S(st));
+  return done("stem_conv_fwd");
+}
+int satrn_stem_conv_bwd_weight(int dt, const float* img, const void* dy, float* dw, int B, int Cin, int H, int W, int Co,
+                               int stride, int pad, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, Co, "Co")) return -1;
+  int OH = (H + 2 * pad - 3) / stride + 1, OW = (W + 2 * pad - 3) / stride + 1;
+  launch_stem_wgrad(dt, img, dy, dw, B, Cin, H, W, Co, OH, OW, stride, pad, S(st));
+  return done("stem_conv_bwd_weight");
+}
+int satrn_dwconv3x3_fwd(int dt, const void* x, const void* wp, const float* bias, void* y, int B, int H, int W, int C,
+                        int OH, int OW, int stride, int pt, int pl, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  launch_dwconv(dt, 0, x, wp, bias, y, B, H, W, C, OH, OW, stride, pt, pl, 0, S(st));
+  return done("dwconv3x3_fwd");
+}
+int satrn_dwconv3x3_bwd_data(int dt, const void* dy, const void* wp, void* dx, int B, int H, int W, int C, int OH, int OW,
+                             int stride, int pt, int pl, int accumulate, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  launch_dwconv(dt, 1, dy, wp, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, accumulate, S(st));
+  return done("dwconv3x3_bwd_data");
+}
+int satrn_dwconv3x3_bwd_weight(int dt, const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int C,
+                               int OH, int OW, int stride, int pt, int pl, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  launch_dwconv_wgrad(dt, x, dy, dw, dbias, B, H, W, C, OH, OW, stride, pt, pl, S(st));
+  return done("dwconv3x3_bwd_weight");
+}
+
+int satrn_batchnorm_act_fwd(int dt, const void* y, const float* w, const float* b, float* rm, float* rv, int64_t* nbt,
+                            float eps, int train, int act, const void* res, void* z, long M, int C, float* scratch,
+                            void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  if (train) launch_colstats(dt, y, M, C, scratch, S(st));
+  launch_bn_finalize(scratch, M, C, w, b, rm, rv, nbt, eps, 0.1f, train, scratch + 2 * C, scratch + 4 * C, S(st));
+  launch_bn_act(dt, y, scratch + 2 * C, res, z, M, C, act, S(st));
+  return done("batchnorm_act_fwd");
+}
+int satrn_batchnorm_act_bwd(int dt, const void* dz, const void* y, const float* w, const float* scratch, int act,
+                            void* dy, float* dw, float* db, long M, int C, float* scratch2, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  launch_bn_bwd_reduce(dt, dz, y, scratch + 2 * C, scratch + 4 * C, M, C, act, scratch2, S(st));
+  launch_bn_bwd_apply(dt, dz, y, scratch + 2 * C, scratch + 4 * C, w, scratch2, M, C, act, dy, dw, db, S(st));
+  return done("batchnorm_act_bwd");
+}
+
+int satrn_maxpool2x2_fwd(int dt, const void* x, void* y, int B, int H, int W, int C, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  launch_maxpool(dt, 0, x, nullptr, y, B, H, W, C, S(st));
+  return done("maxpool_fwd");
+}
+int satrn_maxpool2x2_bwd(int dt, const void* x, const void* dy, void* dx, int B, int H, int W, int C, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  launch_maxpool(dt, 1, x, dy, dx, B, H, W, C, S(st));
+  return done("maxpool_bwd");
+}
+
+int satrn_layernorm_fwd(int dt, const void* a, const void* b, const float* w, const float* bias, void* out, float* mr,
+                        long R, int C, float eps, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  launch_layernorm(dt, a, b, w, bias, out, mr, R, C, eps, 0.f, nullptr, 0, S(st));
+  return done("layernorm_fwd");
+}
+int satrn_layernorm_bwd(int dt, const void* dout, const void* a, const void* b, const float* w, const float* mr, void* da,
+                        void* db, int acc_a, int acc_b, float* dw, float* dbias, long R, int C, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  launch_layernorm_bwd(dt, dout, a, b, w, mr, da, db, acc_a, acc_b, dw, dbias, R, C, 0.f, nullptr, 0, S(st));
+  return done("layernorm_bwd");
+}
+
+int satrn_pool_hw(int dt, const void* x, void* out, int B, int HW, int C, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  launch_pool_hw(dt, x, out, B, HW, C, S(st));
+  return done("pool_hw");
+}
+int satrn_posenc2d_fwd(int dt, const void* x, const void* gate, const float* hpos, const float* wpos, void* out, int B,
+                       int H, int W, int C, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  launch_posenc2d(dt, x, gate, hpos, wpos, out, B, H, W, C, S(st));
+  return done("posenc2d_fwd");
+}
+int satrn_posenc2d_bwd_gate(int dt, const void* dout, const float* hpos, const float* wpos, void* dgate, int B, int H,
+                            int W, int C, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  launch_posenc2d_bwd(dt, dout, hpos, wpos, dgate, B, H, W, C, S(st));
+  return done("posenc2d_bwd_gate");
+}
+int satrn_encoder_reshape(int dt, int inverse, const void* in, void* out, int B, int HW, int C, int accumulate, void* st) {
+  CHK_DT(dt);
+  launch_reshape_quirk(dt, inverse, in, out, B, HW, C, accumulate, S(st));
+  return done("encoder_reshape");
+}
+
+static void fill_attn(AttnP& p, const void* q, const void* k, const void* v, int B, int heads, int Lq, int Lk, int hd,
+                      int ldq, int ldk, int ldv, int ldo, int causal, const int64_t* text, int ld_text, int pad_id,
+                      float temperature, float drop_p, const uint32_t* seed, uint32_t site) {
+  memset(&p, 0, sizeof(p));
+  p.Q = q; p.K = k; p.V = v; p.B = B; p.H = heads; p.Lq = Lq; p.Lk = Lk; p.hd = hd; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
+  p.ldo = ldo; p.sq_b = (long)Lq * ldq; p.sk_b = (long)Lk * ldk; p.sv_b = (long)Lk * ldv; p.so_b = (long)Lq * ldo;
+  p.causal = causal; p.text = text; p.ld_text = ld_text; p.pad_id = pad_id; p.inv_temp = 1.0f / temperature;
+  p.drop_p = drop_p; p.seed = seed; p.site = site;
+}
+int satrn_attention_fwd(int dt, const void* q, const void* k, const void* v, void* o, float* lse, int B, int heads, int Lq,
+                        int Lk, int hd, int ldq, int ldk, int ldv, int ldo, int causal, const int64_t* text, int ld_text,
+                        int pad_id, float temperature, float drop_p, const uint32_t* seed, uint32_t site, void* st) {
+  CHK_DT(dt);
+  AttnP p;
+  fill_attn(p, q, k, v, B, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, causal, text, ld_text, pad_id, temperature, drop_p, seed, site);
+  p.O = o; p.lse = lse;
+  if (launch_attn_checked(dt, 0, p, S(st))) return fail(-1, "attention: unsupported shape (Lk <= 256, head_dim <= 64, LDS fit)");
+  return done("attention_fwd");
+}
+int satrn_attention_bwd(int dt, const void* q, const void* k, const void* v, const void* o, const float* lse,
+                        const void* d_o, void* dq, void* dk, void* dv, void* ws, int B, int heads, int Lq, int Lk, int hd,
+                        int ldq, int ldk, int ldv, int ldo, int causal, const int64_t* text, int ld_text, int pad_id,
+                        float temperature, float drop_p, const uint32_t* seed, uint32_t site, void* st) {
+  CHK_DT(dt);
+  AttnP p;
+  fill_attn(p, q, k, v, B, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, causal, text, ld_text, pad_id, temperature, drop_p, seed, site);
+  const size_t es = dt == DT_BF16 ? 2 : 4;
+  const size_t LkP = attn_lkp(Lk);
+  p.O = (void*)o; p.lse = (float*)lse; p.dO = d_o; p.dQ = dq; p.dS = ws; p.Pd = (char*)ws + (size_t)B * heads * Lq * LkP * es;
+  if (launch_attn_checked(dt, 1, p, S(st))) return fail(-1, "attention: unsupported shape (Lk <= 256, head_dim <= 64, LDS fit)");
+  WgradP w;
+  memset(&w, 0, sizeof(w));
+  w.M = Lq; w.N = Lk; w.K = hd; w.ldy = (int)LkP; w.out_t = 1; w.nbatch = B * heads; w.nb_inner = heads;
+  w.sY_o = (long)heads * Lq * LkP; w.sY_i = (long)Lq * LkP;
+  w.dY = p.Pd; w.A = d_o; w.lda = ldo; w.sA_o = (long)Lq * ldo; w.sA_i = hd; w.dW = dv; w.sW_o = (long)Lk * ldv; w.sW_i = hd; w.ldw = ldv;
+  launch_wgrad(dt, w, S(st));
+  w.dY = p.dS; w.A = q; w.lda = ldq; w.sA_o = (long)Lq * ldq; w.sA_i = hd; w.dW = dk; w.sW_o = (long)Lk * ldk; w.ldw = ldk;
+  launch_wgrad(dt, w, S(st));
+  return done("attention_bwd");
+}
+
+int satrn_embedding_fwd(int dt, const int64_t* ids, int ld_ids, const float* table, const float* pe, void* out, int B,
+                        int L, int D, int pos0, float drop_p, const uint32_t* seed, uint32_t site, void* st) {
+  CHK_DT(dt);
+  launch_embed(dt, ids, table, pe, out, B, L, ld_ids, D, pos0, drop_p, seed, site, S(st));
+  return done("embedding_fwd");
+}
+int satrn_embedding_bwd(int dt, const int64_t* ids, int ld_ids, const void* dout, float* dtable, int B, int L, int D,
+                        float drop_p, const uint32_t* seed, uint32_t site, void* st) {
+  CHK_DT(dt);
+  launch_embed_bwd(dt, ids, dout, dtable, B, L, ld_ids, D, drop_p, seed, site, S(st));
+  return done("embedding_bwd");
+}
+int satrn_cross_entropy(int dt, const float* logits, const int64_t* targets, int ld, int B, int T, int V, int Vp,
+                        int pad_id, float* loss_out, float* lse_ws, void* dlogits, void* st) {
+  CHK_DT(dt);
+  launch_ce_full(dt, logits, targets, ld, 0, B, T, V, Vp, pad_id, loss_out, lse_ws, dlogits, nullptr, S(st));
+  return done("cross_entropy");
+}
+int satrn_clip_adamw(float* p, const float* g, float* m, float* v, long n, float* gnorm_sq, const float* hyper, void* st) {
+  launch_sumsq(g, n, gnorm_sq, S(st));
+  launch_adamw(p, g, m, v, n, gnorm_sq, hyper, S(st));
+  return done("clip_adamw");
+}
+
+// ---- model level -------------------------------------------------------------------------------------------
+struct satrn_model { Model* m; };
+
+satrn_model* satrn_model_create(const satrn_config* c) {
+  if (!c) { g_err = "null config"; return nullptr; }
+  if (c->dtype != 0 && c->dtype != 1) { g_err = "dtype must be 0 or 1"; return nullptr; }
+  const int ch = c->dtype == DT_BF16 ? 8 : 4;
+  if (c->enc_hidden % 16 || c->dec_hidden % ch || c->enc_filter % ch || c->dec_filter % ch || c->dec_src != c->enc_hidden) {
+    g_err = "hidden sizes must be multiples of 16 (encoder) / 8 and dec_src == enc_hidden";
+    return nullptr;
+  }
+  if (c->enc_hidden % c->enc_heads || c->dec_hidden % c->dec_heads) { g_err = "hidden_dim must divide by head_num"; return nullptr; }
+  SatrnConfig k;
+  k.network = c->network; k.rgb = c->rgb; k.height = c->height; k.width = c->width;
+  k.enc_hidden = c->enc_hidden; k.enc_filter = c->enc_filter; k.enc_heads = c->enc_heads; k.enc_layers = c->enc_layers;
+  k.dec_src = c->dec_src; k.dec_hidden = c->dec_hidden; k.dec_filter = c->dec_filter; k.dec_heads = c->dec_heads;
+  k.dec_layers = c->dec_layers; k.num_classes = c->num_classes; k.pad_id = c->pad_id; k.sos_id = c->sos_id;
+  k.dropout = c->dropout; k.dtype = c->dtype;
+  satrn_model* h = new satrn_model();
+  h->m = model_create(k);
+  return h;
+}
+void satrn_model_destroy(satrn_model* h) { if (h) { model_destroy(h->m); delete h; } }
+int satrn_model_num_state(const satrn_model* h) { return (int)h->m->state.size(); }
+const char* satrn_model_state_name(const satrn_model* h, int i) { return h->m->state[i].name.c_str(); }
+int satrn_model_state_info(const satrn_model* h, int i, int* kind, int* ndim, int64_t* shape4, int64_t* offset, int* init,
+                           int* fan_in, int* fan_out) {
+  if (i < 0 || i >= (int)h->m->state.size()) return fail(-1, "state index out of range");
+  const StateEntry& e = h->m->state[i];
+  *kind = e.kind; *ndim = (int)e.shape.size(); *offset = e.offset; *init = e.init; *fan_in = e.fan_in; *fan_out = e.fan_out;
+  for (int d = 0; d < 4; ++d) shape4[d] = d < (int)e.shape.size() ? e.shape[d] : 1;
+  return 0;
+}
+int64_t satrn_model_flat_size(const satrn_model* h, int kind) {
+  return kind == 0 ? h->m->n_params : kind == 1 ? h->m->n_buf_f32 : h->m->n_buf_i64;
+}
+static int mret(satrn_model* h, int rc, const char* what) {
+  if (rc) return fail(rc, std::string(what) + ": " + h->m->err);
+  return done(what);
+}
+int satrn_model_bind(satrn_model* h, float* p, float* g, float* bf, int64_t* bi) { return mret(h, model_bind(h->m, p, g, bf, bi), "bind"); }
+size_t satrn_model_workspace_bytes(satrn_model* h, int B, int L) { return model_workspace_bytes(h->m, B, L); }
+int satrn_model_set_workspace(satrn_model* h, void* ws, size_t bytes, void* st) { return mret(h, model_set_workspace(h->m, ws, bytes, S(st)), "set_workspace"); }
+int satrn_model_pack_weights(satrn_model* h, void* st) { return mret(h, model_pack_weights(h->m, S(st)), "pack_weights"); }
+int satrn_model_forward(satrn_model* h, const float* img, const int64_t* exp, int B, int L, int train, int record,
+                        float* logits, void* st) {
+  return mret(h, model_forward(h->m, img, exp, B, L, train != 0, record != 0, logits, S(st)), "forward");
+}
+int satrn_model_backward(satrn_model* h, const float* dl, void* st) { return mret(h, model_backward(h->m, dl, S(st)), "backward"); }
+int satrn_model_loss_backward(satrn_model* h, const int64_t* exp, int B, int L, void* st) {
+  return mret(h, model_loss_backward(h->m, exp, B, L, S(st)), "loss_backward");
+}
+int satrn_model_train_step(satrn_model* h, const float* img, const int64_t* exp, int B, int L, const float* hyper9,
+                           int use_graph, int phase, void* st) {
+  return mret(h, model_train_step(h->m, img, exp, B, L, hyper9, use_graph, phase, S(st)), "train_step");
+}
+int satrn_model_read_loss(satrn_model* h, float* out4, void* st) { return mret(h, model_read_loss(h->m, out4, S(st)), "read_loss"); }
+int satrn_model_encode(satrn_model* h, const float* img, int B, float* src, void* st) { return mret(h, model_encode(h->m, img, B, src, S(st)), "encode"); }
+int satrn_model_greedy(satrn_model* h, const float* img, const float* src, int B, int steps, float* logits, int64_t* ids,
+                       void* st) {
+  return mret(h, model_greedy(h->m, img, src, B, steps, logits, ids, S(st)), "greedy");
+}
+float* satrn_model_adam_state(satrn_model* h, int which) {
+  Model* m = h->m;
+  if (!m->ws) return nullptr;
+  return (float*)(m->ws + (which == 0 ? m->off_adam_m : m->off_adam_v));
+}
+int satrn_model_set_step(satrn_model* h, long t) { h->m->adam_t = t; return 0; }
+
+}  // extern "C"

@@ -1,0 +1,397 @@
+"""Host-side mirror of the reference's module interface for the accelerated path.
+
+Same constructor signatures, attribute tree (.encoder / .decoder / .criterion), forward signature and
+state_dict keys as networks/EfficientSATRN.py:664-706 and networks/LiteSATRN.py:548-590, but every FLOP runs in
+libsatrn_hip.so (hand-written gfx950 kernels) through the C-ABI of include/satrn_hip.h.  PyTorch only owns the
+memory (flat parameter / gradient / buffer tensors, one workspace), the stream and autograd's outer graph.
+"""
+import ctypes
+import math
+import random
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import SatrnError, check, ptr, satrn_config
+from .utils import PAD, START
+
+_DT = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, 0: 0, 1: 1}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Node(nn.Module):
+    """Plain container node of the mirrored module tree (holds parameters / buffers / children only)."""
+
+
+class SATRNCrossEntropy(nn.Module):
+    """nn.CrossEntropyLoss(ignore_index=PAD) as the reference builds it (networks/EfficientSATRN.py:690-692) and
+    calls it (train_modules/train_single_opt.py:82,86): input [B, V, T] (= logits.transpose(1, 2)), target [B, T]."""
+
+    def __init__(self, ignore_index):
+        super().__init__()
+        self.ignore_index = int(ignore_index)
+
+    def forward(self, input, target):
+        return _CEFunction.apply(input, target, self.ignore_index)
+
+
+class _CEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, target, pad_id):
+        lib = _lib.load()
+        if not input.is_cuda:
+            raise SatrnError("SATRNCrossEntropy needs CUDA/HIP tensors (no CPU fallback)")
+        lg = input.transpose(1, 2)
+        if not lg.is_contiguous() or lg.dtype != torch.float32:
+            lg = lg.contiguous().float()
+        B, T, V = lg.shape
+        if target.stride(1) != 1:
+            target = target.contiguous()
+        out = torch.zeros(4, dtype=torch.float32, device=lg.device)
+        lse = torch.empty(B * T, dtype=torch.float32, device=lg.device)
+        dl = torch.empty(B, T, V, dtype=torch.float32, device=lg.device)
+        check(lib.satrn_cross_entropy(0, ptr(lg), ptr(target), target.stride(0), B, T, V, V, pad_id, ptr(out), ptr(lse),
+                                      ptr(dl), _stream()), "satrn_cross_entropy")
+        ctx.save_for_backward(dl)
+        return out[2].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return (dl * g).transpose(1, 2), None, None
+
+
+class _TFFunction(torch.autograd.Function):
+    """Teacher-forced forward of the whole model as ONE autograd node; backward replays the engine's tape."""
+
+    @staticmethod
+    def forward(ctx, model, anchor, input, expected, record):
+        ctx.model = model
+        ctx.gen = model._run_forward(input, expected, record=record)
+        return model._last_logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        if ctx.gen != model._gen:
+            raise SatrnError("backward() of a stale forward: the engine keeps one tape (the latest forward)")
+        model._run_backward(dlogits)
+        return None, torch.zeros_like(model._anchor), None, None, None
+
+
+class _SATRNBase(nn.Module):
+    _NETWORK = 1
+    _DEFAULT_DTYPE = "bf16"
+
+    def __init__(self, FLAGS, train_dataset, checkpoint=None, decoding_manager=None, dtype=None):
+        super().__init__()
+        if decoding_manager is not None:
+            raise NotImplementedError("DecodingManager runs on the host in the reference (postprocessing/postprocessing.py); "
+                                      "it is not part of the accelerated path yet")
+        lib = _lib.load()
+        self._lib = lib
+        dt = _DT[self._DEFAULT_DTYPE if dtype is None else dtype]
+        c = satrn_config()
+        c.network = self._NETWORK
+        c.rgb = int(FLAGS.data.rgb)
+        c.height, c.width = int(FLAGS.input_size.height), int(FLAGS.input_size.width)
+        e, d = FLAGS.SATRN.encoder, FLAGS.SATRN.decoder
+        c.enc_hidden, c.enc_filter, c.enc_heads, c.enc_layers = int(e.hidden_dim), int(e.filter_dim), int(e.head_num), int(e.layer_num)
+        c.dec_src, c.dec_hidden, c.dec_filter = int(d.src_dim), int(d.hidden_dim), int(d.filter_dim)
+        c.dec_heads, c.dec_layers = int(d.head_num), int(d.layer_num)
+        c.num_classes = len(train_dataset.id_to_token)
+        c.pad_id, c.sos_id = int(train_dataset.token_to_id[PAD]), int(train_dataset.token_to_id[START])
+        c.dropout = float(FLAGS.dropout_rate)
+        c.dtype = dt
+        self._cfg = c
+        self._h = lib.satrn_model_create(ctypes.byref(c))
+        if not self._h:
+            raise SatrnError("satrn_model_create: " + lib.satrn_last_error().decode())
+        self.encoder = _Node()
+        self.decoder = _Node()
+        self._build_state()
+        # attributes the reference's callers read
+        self.decoder.layer_num = c.dec_layers
+        self.decoder.st_id = c.sos_id
+        self.decoder.pad_id = c.pad_id
+        self.decoder.num_classes = c.num_classes
+        self.decoder.hidden_dim = c.dec_hidden
+        self.decoder.filter_dim = c.dec_filter
+        self.criterion = SATRNCrossEntropy(ignore_index=c.pad_id)
+        self._anchor = torch.zeros(1, requires_grad=True)
+        self._gen = 0
+        self._ws = None
+        self._ws_key = (0, 0)
+        self._ws_cache = {}
+        self._packed_version = -1
+        self._bound = None
+        self._last_logits = None
+        self._stage = None
+        if checkpoint:
+            self.load_state_dict(checkpoint)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.satrn_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ state table -> module tree
+    def _build_state(self):
+        lib, h = self._lib, self._h
+        n = lib.satrn_model_num_state(h)
+        sizes = [lib.satrn_model_flat_size(h, k) for k in range(3)]
+        flats = [torch.zeros(max(sizes[0], 1)), torch.zeros(max(sizes[1], 1)), torch.zeros(max(sizes[2], 1), dtype=torch.int64)]
+        self._entries = []
+        kind, ndim, init, fi, fo = (ctypes.c_int() for _ in range(5))
+        shape = (ctypes.c_int64 * 4)()
+        off = ctypes.c_int64()
+        for i in range(n):
+            name = lib.satrn_model_state_name(h, i).decode()
+            check(lib.satrn_model_state_info(h, i, ctypes.byref(kind), ctypes.byref(ndim), shape, ctypes.byref(off),
+                                             ctypes.byref(init), ctypes.byref(fi), ctypes.byref(fo)), "state_info")
+            shp = tuple(int(shape[d]) for d in range(ndim.value))
+            numel = 1
+            for s in shp:
+                numel *= s
+            view = flats[kind.value][off.value: off.value + numel].view(shp)
+            self._init_tensor(view, init.value, fi.value, fo.value)
+            node = self
+            parts = name.split(".")
+            for p in parts[:-1]:
+                if not hasattr(node, p):
+                    node.add_module(p, _Node())
+                node = getattr(node, p)
+            if kind.value == 0:
+                node.register_parameter(parts[-1], nn.Parameter(view))
+            else:
+                node.register_buffer(parts[-1], view)
+            self._entries.append((name, kind.value, shp, off.value, numel, node, parts[-1]))
+        self._flat = flats
+        self._gflat = None
+
+    @staticmethod
+    def _init_tensor(t, init, fan_in, fan_out):
+        with torch.no_grad():
+            if init == 0:  # xavier_normal_
+                t.normal_(0.0, math.sqrt(2.0 / float(fan_in + fan_out)))
+            elif init in (1, 2):  # conv / linear default: kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in))
+                b = 1.0 / math.sqrt(fan_in)
+                t.uniform_(-b, b)
+            elif init == 3:
+                b = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+                t.uniform_(-b, b)
+            elif init == 4:
+                t.fill_(1)
+            elif init == 5:
+                t.zero_()
+            elif init == 6:
+                t.normal_(0.0, 1.0)
+
+    def _tensor_of(self, entry):
+        return getattr(entry[5], entry[6])
+
+    # ------------------------------------------------------------------ device binding
+    def _ensure_bound(self, device):
+        if device.type != "cuda":
+            raise SatrnError("the SATRN engine runs on MI355X only: move the model and inputs to 'cuda' (no CPU fallback)")
+        first = self._tensor_of(self._entries[0])
+        if self._bound == device and first.data_ptr() == self._flat[self._entries[0][1]].data_ptr() + 4 * self._entries[0][3]:
+            return
+        flats = [torch.zeros(f.numel(), dtype=f.dtype, device=device) for f in self._flat]
+        with torch.no_grad():
+            for name, kind, shp, off, numel, node, leaf in self._entries:
+                t = getattr(node, leaf)
+                view = flats[kind][off: off + numel].view(shp)
+                view.copy_(t.detach().to(device=device, dtype=view.dtype))
+                if kind == 0:
+                    t.data = view
+                    t.grad = None
+                else:
+                    node._buffers[leaf] = view
+        self._flat = flats
+        self._gflat = torch.zeros_like(flats[0])
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        check(self._lib.satrn_model_bind(self._h, ptr(flats[0]), ptr(self._gflat), ptr(flats[1]), ptr(flats[2])), "bind")
+        self._bound = device
+        self._packed_version = -1
+        if self._ws is not None and self._ws.device != device:
+            self._ws = None
+            self._ws_key = (0, 0)
+
+    def _ensure_ws(self, B, L, device):
+        if self._ws is not None and B <= self._ws_key[0] and L <= self._ws_key[1]:
+            return
+        B2, L2 = max(B, self._ws_key[0]), max(L, self._ws_key[1])
+        need = self._lib.satrn_model_workspace_bytes(self._h, B2, L2)
+        self._ws = None
+        self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        check(self._lib.satrn_model_set_workspace(self._h, ptr(self._ws), need, _stream()), "set_workspace")
+        self._ws_key = (B2, L2)
+        self._packed_version = -1
+        self._stage = None
+
+    def _param_version(self):
+        v = 0
+        for e in self._entries:
+            if e[1] == 0:
+                v += self._tensor_of(e)._version
+        return v
+
+    def _ensure_packed(self):
+        v = self._param_version()
+        if v != self._packed_version:
+            check(self._lib.satrn_model_pack_weights(self._h, _stream()), "pack_weights")
+            self._packed_version = v
+
+    def _prepare(self, input, B, L):
+        self._ensure_bound(input.device)
+        self._ensure_ws(B, L, input.device)
+        self._ensure_packed()
+
+    @staticmethod
+    def _img(input):
+        if input.dtype != torch.float32 or not input.is_contiguous():
+            input = input.float().contiguous()
+        return input
+
+    # ------------------------------------------------------------------ engine calls
+    def _run_forward(self, input, expected, record):
+        input = self._img(input)
+        expected = expected.contiguous()
+        B, L = expected.shape
+        self._prepare(input, B, L)
+        logits = torch.empty(B, L - 1, self._cfg.num_classes, dtype=torch.float32, device=input.device)
+        self._gen += 1
+        check(self._lib.satrn_model_forward(self._h, ptr(input), ptr(expected), B, L, int(self.training), int(record),
+                                            ptr(logits), _stream()), "satrn_model_forward")
+        self._last_logits = logits
+        self._keep = (input, expected)  # the tape reads them in backward
+        return self._gen
+
+    def _attach_grads(self):
+        """param.grad views into the flat gradient buffer; a None grad (after zero_grad) means 'start from zero'."""
+        fresh = False
+        for name, kind, shp, off, numel, node, leaf in self._entries:
+            if kind != 0:
+                continue
+            p = getattr(node, leaf)
+            if p.grad is None or p.grad.data_ptr() != self._gflat.data_ptr() + 4 * off:
+                fresh = fresh or p.grad is None
+                p.grad = self._gflat[off: off + numel].view(shp)
+        return fresh
+
+    def _run_backward(self, dlogits):
+        first = self._tensor_of(self._entries[0])
+        if first.grad is None:
+            self._gflat.zero_()
+        self._attach_grads()
+        dl = dlogits.contiguous().float()
+        check(self._lib.satrn_model_backward(self._h, ptr(dl), _stream()), "satrn_model_backward")
+
+    def forward(self, input, expected, is_train, teacher_forcing_ratio):
+        """networks/EfficientSATRN.py:697-706: -> [B, L-1, V] (teacher-forced logits, or greedy-step logits)."""
+        if is_train and random.random() < teacher_forcing_ratio:
+            self._ensure_bound(input.device)
+            return _TFFunction.apply(self, self._anchor, input, expected, torch.is_grad_enabled())
+        if is_train and torch.is_grad_enabled():
+            raise NotImplementedError("train-time autoregressive branch (networks/EfficientSATRN.py:496-525) needs gradients "
+                                      "through the step loop; not built yet -- use teacher_forcing_ratio=1.0")
+        return self.greedy(input, expected.size(1) - 1)[0]
+
+    @torch.no_grad()
+    def greedy(self, input, num_steps):
+        """networks/EfficientSATRN.py:528-561 (no DecodingManager): -> (logits [B, steps, V], ids [B, steps])."""
+        input = self._img(input)
+        B = input.size(0)
+        self._prepare(input, B, num_steps + 1)
+        V = self._cfg.num_classes
+        logits = torch.empty(B, num_steps, V, dtype=torch.float32, device=input.device)
+        ids = torch.empty(B, num_steps, dtype=torch.int64, device=input.device)
+        was_training = self.training
+        check(self._lib.satrn_model_greedy(self._h, ptr(input), None, B, num_steps, ptr(logits), ptr(ids), _stream()),
+              "satrn_model_greedy")
+        return logits, ids
+
+    @torch.no_grad()
+    def encode(self, input):
+        """SATRNEncoder.forward (networks/EfficientSATRN.py:311-323) in eval mode -> [B, hw, c] fp32."""
+        input = self._img(input)
+        B = input.size(0)
+        self._prepare(input, B, 2)
+        n = (self._cfg.height // (32 if self._NETWORK == 1 else 16)) * (self._cfg.width // (32 if self._NETWORK == 1 else 16))
+        src = torch.empty(B, n, self._cfg.enc_hidden, dtype=torch.float32, device=input.device)
+        check(self._lib.satrn_model_encode(self._h, ptr(input), B, ptr(src), _stream()), "satrn_model_encode")
+        return src
+
+    # ------------------------------------------------------------------ fused training step (bench / trainer fast path)
+    def train_step(self, input, expected, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6, max_grad_norm=2.0,
+                   grad_scale=1.0, use_graph=True, phase=3):
+        """forward + CE + backward + clip_grad_norm_ + AdamW + weight re-pack in one captured hipGraph
+        (train_modules/train_single_opt.py:80-98 with teacher forcing).  phase: 1 = forward/backward only,
+        2 = clip + AdamW only (data-parallel callers all-reduce the flat gradient in between), 3 = both."""
+        input = self._img(input)
+        B, L = expected.shape
+        self._ensure_bound(input.device)
+        self._ensure_ws(B, L, input.device)
+        if self._packed_version == -1:
+            self._ensure_packed()
+        if self._stage is None or self._stage[0].shape != input.shape or self._stage[1].shape != expected.shape:
+            self._stage = (torch.empty_like(input), torch.empty_like(expected.contiguous()))
+        self._stage[0].copy_(input, non_blocking=True)
+        self._stage[1].copy_(expected, non_blocking=True)
+        hy = (ctypes.c_float * 9)(lr, betas[0], betas[1], eps, weight_decay, max_grad_norm, 0.0, 0.0, grad_scale)
+        check(self._lib.satrn_model_train_step(self._h, ptr(self._stage[0]), ptr(self._stage[1]), B, L, hy, int(use_graph),
+                                               int(phase), _stream()), "satrn_model_train_step")
+        self._gen += 1
+        self._packed_version = -2  # parameters were updated and re-packed inside the step
+
+    def flat_grad(self):
+        return self._gflat
+
+    def flat_params(self):
+        return self._flat[0]
+
+    def read_loss(self):
+        """-> (mean loss, valid-token count, grad-norm) of the last train_step / loss pass (synchronises)."""
+        out = (ctypes.c_float * 4)()
+        check(self._lib.satrn_model_read_loss(self._h, out, _stream()), "read_loss")
+        return float(out[2]), float(out[1]), math.sqrt(max(float(out[3]), 0.0))
+
+
+class EfficientSATRN(_SATRNBase):
+    """Drop-in for networks/EfficientSATRN.py:664 (EfficientNetV2-S backbone, /32)."""
+    _NETWORK = 1
+
+
+class LiteSATRN(_SATRNBase):
+    """Drop-in for networks/LiteSATRN.py:548 (ShallowCNN backbone, /16)."""
+    _NETWORK = 0
+
+
+class EfficientSATRN_encoder(nn.Module):
+    """networks/EfficientSATRN.py:870-894: encoder-only wrapper used by the ensemble path; forward(input) -> [B, N, D]."""
+
+    def __init__(self, FLAGS, train_dataset, checkpoint=None, dtype=None):
+        super().__init__()
+        self._full = EfficientSATRN(FLAGS, train_dataset, None, None, dtype)
+        self.encoder = self._full.encoder
+        if checkpoint:
+            self.load_state_dict(checkpoint, strict=False)
+
+    def forward(self, input):
+        return self._full.encode(input)
+
+
+class EfficientSATRN_decoder(nn.Module):
+    """networks/EfficientSATRN.py:897-952 (step_forward / reset_status ensemble API) -- not on the built path yet."""
+
+    def __init__(self, FLAGS, train_dataset, checkpoint=None, dtype=None):
+        super().__init__()
+        raise NotImplementedError("step-wise ensemble decoder API is a 'next' row (SURVEY.md 8f rank 2); not built yet")

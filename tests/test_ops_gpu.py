@@ -1,0 +1,429 @@
+"""GPU parity tests, operator level: every C-ABI operator of include/satrn_hip.h against a plain PyTorch fp32 CPU
+reference of the same op (the oracle's building blocks), in both compute dtypes.
+Tolerances: f32 mode = exact-f32 MFMA, compared at 2e-4 of the output scale; bf16 mode = bf16 storage with f32
+accumulation, compared at 3e-2 of the output scale (inputs are rounded to bf16 on both sides first)."""
+import ctypes
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = ["f32", "bf16"]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import satrn_amd
+    return satrn_amd._lib.load()
+
+
+def st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def P(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def tdt(dt):
+    return torch.float32 if dt == "f32" else torch.bfloat16
+
+
+def dti(dt):
+    return 0 if dt == "f32" else 1
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def q(x, dt):
+    """round to the compute dtype and back (so both sides start from identical values)"""
+    return x.to(tdt(dt)).float()
+
+
+def dev(x, dt=None):
+    x = x.cuda()
+    return x.to(tdt(dt)).contiguous() if dt else x.contiguous()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, ref, dt, what="", f32_tol=2e-4, bf16_tol=3e-2):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float()
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    tol = (f32_tol if dt == "f32" else bf16_tol) * scale
+    print(f"[{what}:{dt}] max|err|={err:.3e} scale={scale:.3e} tol={tol:.3e}")
+    assert err <= tol, f"{what}:{dt} max err {err} > {tol} (scale {scale})"
+    assert torch.isfinite(got).all()
+
+
+def ok(lib, rc):
+    assert rc == 0, lib.satrn_last_error().decode()
+
+
+def pack_dense(lib, w, dt, ldb=None):
+    N, K = w.shape
+    ldb = ldb or ((N + 7) // 8 * 8)
+    fwd = torch.zeros(N, K, dtype=tdt(dt), device="cuda")
+    bwd = torch.zeros(K, ldb, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_pack_dense(dti(dt), P(dev(w)), P(fwd), P(bwd), N, K, ldb, st()))
+    return fwd, bwd, ldb
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K,act", [(100, 64, 64, 0), (300, 24, 216, 1), (257, 245, 256, 0), (4096, 1024, 256, 1),
+                                       (64, 768, 256, 3), (1536, 512, 512, 0), (33, 40, 960, 0)])
+def test_linear(lib, dt, M, N, K, act):
+    x, w, b = q(rnd(M, K, seed=1), dt), q(rnd(N, K, seed=2, scale=1 / math.sqrt(K)), dt), rnd(N, seed=3, scale=0.1)
+    fwd, bwd, ldb = pack_dense(lib, w, dt)
+    out_f32 = int(N == 245)
+    y = torch.empty(M, N, dtype=torch.float32 if out_f32 else tdt(dt), device="cuda")
+    ok(lib, lib.satrn_linear_fwd(dti(dt), P(dev(x, dt)), P(fwd), P(dev(b)), P(y), M, N, K, act, out_f32, 0.0, None, 0, st()))
+    ref = F.linear(x, w, b)
+    ref = {0: ref, 1: F.relu(ref), 3: torch.sigmoid(ref)}[act]
+    close(y, ref, dt, f"linear_fwd {M}x{N}x{K}")
+    # backward: data and weight
+    dy = q(rnd(M, N, seed=4), dt)
+    dyp = torch.zeros(M, ldb, dtype=tdt(dt), device="cuda")
+    dyp[:, :N] = dev(dy, dt)
+    dx = torch.empty(M, K, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_linear_bwd_data(dti(dt), P(dyp), ldb, P(bwd), ldb, P(dx), M, N, K, 0, st()))
+    close(dx, dy @ w, dt, "linear_bwd_data")
+    ok(lib, lib.satrn_linear_bwd_data(dti(dt), P(dyp), ldb, P(bwd), ldb, P(dx), M, N, K, 1, st()))
+    close(dx, 2 * (dy @ w), dt, "linear_bwd_data(acc)")
+    dw = torch.zeros(N, K, device="cuda")
+    db = torch.zeros(N, device="cuda")
+    ok(lib, lib.satrn_linear_bwd_weight(dti(dt), P(dyp), ldb, P(dev(x, dt)), P(dw), P(db), M, N, K, st()))
+    close(dw, dy.t() @ x, dt, "linear_bwd_weight")
+    close(db, dy.sum(0), dt, "linear_bwd_bias")
+
+
+def same_geo(H, W, s):
+    if s == 1:
+        return H, W, 1, 1, (1, 1, 1, 1)
+    OH, OW = -(-H // s), -(-W // s)
+    ph, pw = max((OH - 1) * s + 3 - H, 0), max((OW - 1) * s + 3 - W, 0)
+    return OH, OW, ph // 2, pw // 2, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,W,Ci,Co,s", [(2, 8, 12, 16, 24, 1), (2, 15, 21, 24, 96, 2), (2, 16, 24, 48, 192, 2),
+                                           (3, 9, 7, 128, 64, 1), (2, 63, 191, 24, 24, 1)])
+def test_conv3x3(lib, dt, B, H, W, Ci, Co, s):
+    x, w = q(rnd(B, Ci, H, W, seed=1), dt), q(rnd(Co, Ci, 3, 3, seed=2, scale=1 / math.sqrt(9 * Ci)), dt)
+    OH, OW, pt, pl, pads = same_geo(H, W, s)
+    fwd = torch.empty(Co, 9, Ci, dtype=tdt(dt), device="cuda")
+    bwd = torch.empty(Ci, 9, Co, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_pack_conv3x3(dti(dt), P(dev(w)), P(fwd), P(bwd), Co, Ci, st()))
+    xd = dev(nhwc(x), dt)
+    y = torch.empty(B, OH, OW, Co, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_conv3x3_fwd(dti(dt), P(xd), P(fwd), P(y), B, H, W, Ci, Co, OH, OW, s, pt, pl, st()))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(F.pad(xr, pads), wr, None, s, 0)
+    assert ref.shape[2:] == (OH, OW)
+    close(nchw(y.float()), ref, dt, f"conv3x3_fwd s{s}")
+    dy = q(rnd(*ref.shape, seed=5), dt)
+    ref.backward(dy)
+    dyd = dev(nhwc(dy), dt)
+    dx = torch.empty(B, H, W, Ci, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_conv3x3_bwd_data(dti(dt), P(dyd), P(bwd), P(dx), B, H, W, Ci, Co, OH, OW, s, pt, pl, 0, st()))
+    close(nchw(dx.float()), xr.grad, dt, f"conv3x3_bwd_data s{s}")
+    dw = torch.zeros(Co, Ci, 3, 3, device="cuda")
+    ok(lib, lib.satrn_conv3x3_bwd_weight(dti(dt), P(dyd), P(xd), P(dw), B, H, W, Ci, Co, OH, OW, s, pt, pl, st()))
+    close(dw, wr.grad, dt, f"conv3x3_bwd_weight s{s}")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,Cin,H,W,Co,s,pad", [(2, 1, 32, 48, 24, 2, 0), (2, 1, 16, 24, 16, 1, 1), (2, 3, 17, 23, 128, 1, 1)])
+def test_stem_conv(lib, dt, B, Cin, H, W, Co, s, pad):
+    x, w = rnd(B, Cin, H, W, seed=1), rnd(Co, Cin, 3, 3, seed=2, scale=0.3)
+    xr, wr = x.clone(), w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, s, pad)
+    OH, OW = ref.shape[2:]
+    y = torch.empty(B, OH, OW, Co, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_stem_conv_fwd(dti(dt), P(dev(x)), P(dev(w)), P(y), B, Cin, H, W, Co, s, pad, st()))
+    close(nchw(y.float()), ref, dt, "stem_fwd", bf16_tol=1e-2)
+    dy = q(rnd(*ref.shape, seed=3), dt)
+    ref.backward(dy)
+    dw = torch.zeros(Co, Cin, 3, 3, device="cuda")
+    ok(lib, lib.satrn_stem_conv_bwd_weight(dti(dt), P(dev(x)), P(dev(nhwc(dy), dt)), P(dw), B, Cin, H, W, Co, s, pad, st()))
+    close(dw, wr.grad, dt, "stem_wgrad")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,s", [(2, 8, 12, 64, 1), (2, 16, 24, 256, 2), (2, 9, 13, 40, 2), (3, 4, 12, 512, 1)])
+def test_dwconv(lib, dt, B, H, W, C, s):
+    x, w, b = q(rnd(B, C, H, W, seed=1), dt), q(rnd(C, 1, 3, 3, seed=2, scale=0.3), dt), rnd(C, seed=3, scale=0.1)
+    OH, OW, pt, pl, pads = same_geo(H, W, s)
+    wp = torch.empty(9, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_pack_dwconv3x3(dti(dt), P(dev(w)), P(wp), C, st()))
+    xd = dev(nhwc(x), dt)
+    y = torch.empty(B, OH, OW, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_dwconv3x3_fwd(dti(dt), P(xd), P(wp), P(dev(b)), P(y), B, H, W, C, OH, OW, s, pt, pl, st()))
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(F.pad(xr, pads), wr, br, s, 0, 1, C)
+    close(nchw(y.float()), ref, dt, f"dwconv_fwd s{s}")
+    dy = q(rnd(*ref.shape, seed=4), dt)
+    ref.backward(dy)
+    dyd = dev(nhwc(dy), dt)
+    dx = torch.empty(B, H, W, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_dwconv3x3_bwd_data(dti(dt), P(dyd), P(wp), P(dx), B, H, W, C, OH, OW, s, pt, pl, 0, st()))
+    close(nchw(dx.float()), xr.grad, dt, f"dwconv_bwd_data s{s}")
+    dw = torch.zeros(C, 1, 3, 3, device="cuda")
+    db = torch.zeros(C, device="cuda")
+    ok(lib, lib.satrn_dwconv3x3_bwd_weight(dti(dt), P(xd), P(dyd), P(dw), P(db), B, H, W, C, OH, OW, s, pt, pl, st()))
+    close(dw, wr.grad, dt, "dwconv_wgrad")
+    close(db, br.grad, dt, "dwconv_bgrad")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,C,act,res", [(96, 64, 2, False), (1000, 24, 1, True), (3000, 1536, 0, True), (48, 512, 2, False)])
+def test_batchnorm_act(lib, dt, M, C, act, res):
+    y = q(rnd(M, C, seed=1) * 2 + 0.5, dt)
+    r = q(rnd(M, C, seed=2), dt) if res else None
+    w, b = 1 + rnd(C, seed=3, scale=0.2), rnd(C, seed=4, scale=0.1)
+    rm, rv = rnd(C, seed=5, scale=0.1), 1 + rnd(C, seed=6, scale=0.3)
+    eps = 1e-3
+    actf = {0: lambda t: t, 1: F.relu, 2: F.silu}[act]
+    for train in (1, 0):
+        yr, wr, br = y.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        rmr, rvr = rm.clone(), rv.clone()
+        zr = actf(F.batch_norm(yr, rmr, rvr, wr, br, bool(train), 0.1, eps))
+        if res:
+            rr = r.clone().requires_grad_(True)
+            zr = zr + rr
+        rmd, rvd = dev(rm), dev(rv)
+        nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        scratch = torch.zeros(6 * C, device="cuda")
+        z = torch.empty(M, C, dtype=tdt(dt), device="cuda")
+        yd = dev(y, dt)
+        ok(lib, lib.satrn_batchnorm_act_fwd(dti(dt), P(yd), P(dev(w)), P(dev(b)), P(rmd), P(rvd), P(nbt), eps, train, act,
+                                            P(dev(r, dt)) if res else None, P(z), M, C, P(scratch), st()))
+        close(z, zr, dt, f"bn_act_fwd train={train}", f32_tol=5e-4)
+        if train:
+            close(rmd, rmr, "f32", "bn running_mean", f32_tol=1e-4)
+            close(rvd, rvr, "f32", "bn running_var", f32_tol=1e-4)
+            assert nbt.item() == 1
+            dz = q(rnd(M, C, seed=7), dt)
+            zr.backward(dz)
+            dy = torch.empty(M, C, dtype=tdt(dt), device="cuda")
+            dwd, dbd = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+            s2 = torch.zeros(2 * C, device="cuda")
+            ok(lib, lib.satrn_batchnorm_act_bwd(dti(dt), P(dev(dz, dt)), P(yd), P(dev(w)), P(scratch), act, P(dy), P(dwd),
+                                                P(dbd), M, C, P(s2), st()))
+            close(dy, yr.grad, dt, "bn_act_bwd dy", f32_tol=1e-3, bf16_tol=5e-2)
+            close(dwd, wr.grad, dt, "bn_act_bwd dw", f32_tol=1e-3)
+            close(dbd, br.grad, dt, "bn_act_bwd db", f32_tol=1e-3)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_maxpool(lib, dt):
+    B, C, H, W = 2, 32, 8, 12
+    x = q(rnd(B, C, H, W, seed=1), dt)
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 2, 2)
+    xd = dev(nhwc(x), dt)
+    y = torch.empty(B, H // 2, W // 2, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_maxpool2x2_fwd(dti(dt), P(xd), P(y), B, H, W, C, st()))
+    close(nchw(y.float()), ref, dt, "maxpool_fwd", bf16_tol=1e-6)
+    dy = q(rnd(*ref.shape, seed=2), dt)
+    ref.backward(dy)
+    dx = torch.empty(B, H, W, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_maxpool2x2_bwd(dti(dt), P(xd), P(dev(nhwc(dy), dt)), P(dx), B, H, W, C, st()))
+    close(nchw(dx.float()), xr.grad, dt, "maxpool_bwd", bf16_tol=1e-6)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("R,C,two", [(100, 256, True), (1536, 512, True), (7, 32, False), (300, 1024, False)])
+def test_layernorm(lib, dt, R, C, two):
+    a = q(rnd(R, C, seed=1), dt)
+    b = q(rnd(R, C, seed=2), dt) if two else None
+    w, bias = 1 + rnd(C, seed=3, scale=0.2), rnd(C, seed=4, scale=0.1)
+    ar, wr, br = a.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    bb = b.clone().requires_grad_(True) if two else None
+    ref = F.layer_norm(ar + bb if two else ar, (C,), wr, br)
+    out = torch.empty(R, C, dtype=tdt(dt), device="cuda")
+    mr = torch.empty(2 * R, device="cuda")
+    ad, bd = dev(a, dt), (dev(b, dt) if two else None)
+    ok(lib, lib.satrn_layernorm_fwd(dti(dt), P(ad), P(bd), P(dev(w)), P(dev(bias)), P(out), P(mr), R, C, 1e-5, st()))
+    close(out, ref, dt, "layernorm_fwd")
+    do = q(rnd(R, C, seed=5), dt)
+    ref.backward(do)
+    da = torch.empty(R, C, dtype=tdt(dt), device="cuda")
+    db = torch.empty(R, C, dtype=tdt(dt), device="cuda") if two else None
+    dw, dbi = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    ok(lib, lib.satrn_layernorm_bwd(dti(dt), P(dev(do, dt)), P(ad), P(bd), P(dev(w)), P(mr), P(da), P(db), 0, 0, P(dw), P(dbi),
+                                    R, C, st()))
+    close(da, ar.grad, dt, "layernorm_bwd da", f32_tol=1e-3, bf16_tol=5e-2)
+    if two:
+        close(db, bb.grad, dt, "layernorm_bwd db", f32_tol=1e-3, bf16_tol=5e-2)
+    close(dw, wr.grad, dt, "layernorm_bwd dw", f32_tol=1e-3)
+    close(dbi, br.grad, dt, "layernorm_bwd dbias", f32_tol=1e-3)
+
+
+def ref_attention(qh, kh, vh, temp, mask):
+    s = torch.matmul(qh, kh.transpose(2, 3)) / temp
+    if mask is not None:
+        s = s.masked_fill(mask, float("-inf"))
+    return torch.matmul(torch.softmax(s, -1), vh)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,Lq,Lk,hd,causal,pad", [(2, 8, 48, 48, 64, 0, 0), (2, 8, 37, 37, 32, 1, 1), (2, 8, 128, 128, 32, 1, 1),
+                                                     (3, 4, 37, 48, 32, 0, 0), (4, 8, 1, 5, 32, 0, 0), (2, 4, 6, 6, 8, 1, 1),
+                                                     (2, 8, 230, 230, 32, 1, 0)])
+def test_attention(lib, dt, B, H, Lq, Lk, hd, causal, pad):
+    D = H * hd
+    # fused projection layout: q|k|v column slices of one [B, L, 3D] buffer when Lq == Lk
+    qkv = q(rnd(B, max(Lq, Lk), 3 * D, seed=1), dt)
+    Q, K, V = qkv[:, :Lq, :D], qkv[:, :Lk, D:2 * D], qkv[:, :Lk, 2 * D:]
+    temp = math.sqrt(D)
+    text = None
+    mask = None
+    if causal or pad:
+        mask = torch.zeros(B, 1, Lq, Lk, dtype=torch.bool)
+        if causal:
+            mask |= torch.triu(torch.ones(Lq, Lk), diagonal=1).bool()[None, None]
+        if pad:
+            text = torch.randint(3, 200, (B, Lk + 1), generator=torch.Generator().manual_seed(3))
+            text[1, Lk - 2:] = 2
+            pm = text[:, :Lk] == 2
+            pm[:, 0] = False
+            mask |= pm[:, None, None, :]
+    Qr, Kr, Vr = (t.clone().requires_grad_(True) for t in (Q, K, V))
+    sp = lambda t, L: t.view(B, L, H, hd).transpose(1, 2)
+    ref = ref_attention(sp(Qr, Lq), sp(Kr, Lk), sp(Vr, Lk), temp, mask).transpose(1, 2).reshape(B, Lq, D)
+    buf = dev(qkv, dt)
+    Lmax = max(Lq, Lk)
+    es = buf.element_size()
+    o = torch.empty(B, Lq, D, dtype=tdt(dt), device="cuda")
+    lse = torch.empty(B, H, Lq, device="cuda")
+    textd = dev(text) if text is not None else None
+    base = buf.data_ptr()
+    pq, pk, pv = ctypes.c_void_p(base), ctypes.c_void_p(base + D * es), ctypes.c_void_p(base + 2 * D * es)
+    # NB: batch stride of the slices is Lmax*3D; the op-level ABI assumes L*ld, so use contiguous per-tensor copies
+    Qd, Kd, Vd = dev(Q.contiguous(), dt), dev(K.contiguous(), dt), dev(V.contiguous(), dt)
+    ok(lib, lib.satrn_attention_fwd(dti(dt), P(Qd), P(Kd), P(Vd), P(o), P(lse), B, H, Lq, Lk, hd, D, D, D, D, causal, P(textd),
+                                    Lk + 1, 2, temp, 0.0, None, 0, st()))
+    close(o, ref, dt, f"attention_fwd Lq{Lq} Lk{Lk} hd{hd}")
+    do = q(rnd(B, Lq, D, seed=5), dt)
+    ref.backward(do)
+    LkP = (Lk + 31) // 32 * 32
+    ws = torch.zeros(2 * B * H * Lq * LkP, dtype=tdt(dt), device="cuda")
+    dq, dk, dv = (torch.zeros_like(t) for t in (Qd, Kd, Vd))
+    ok(lib, lib.satrn_attention_bwd(dti(dt), P(Qd), P(Kd), P(Vd), P(o), P(lse), P(dev(do, dt)), P(dq), P(dk), P(dv), P(ws), B, H,
+                                    Lq, Lk, hd, D, D, D, D, causal, P(textd), Lk + 1, 2, temp, 0.0, None, 0, st()))
+    close(dq, Qr.grad, dt, "attention_bwd dq", f32_tol=1e-3, bf16_tol=5e-2)
+    close(dk, Kr.grad, dt, "attention_bwd dk", f32_tol=1e-3, bf16_tol=5e-2)
+    close(dv, Vr.grad, dt, "attention_bwd dv", f32_tol=1e-3, bf16_tol=5e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_posenc_pool_reshape(lib, dt):
+    from oracle import satrn_oracle as O
+    B, C, H, W = 3, 64, 4, 12
+    x = q(rnd(B, C, H, W, seed=1), dt)
+    xd = dev(nhwc(x), dt)
+    pooled = torch.empty(B, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_pool_hw(dti(dt), P(xd), P(pooled), B, H * W, C, st()))
+    close(pooled, x.mean((2, 3)), dt, "pool_hw")
+    gate = q(torch.sigmoid(rnd(B, 2 * C, seed=2)), dt)
+    hpos, wpos = O.pos_table_2d(H, C), O.pos_table_2d(W, C)
+    g = gate.reshape(B, 2, 1, C)
+    ref = (g[:, 0:1] * hpos.unsqueeze(1).unsqueeze(0) + g[:, 1:2] * wpos.unsqueeze(0).unsqueeze(0)).permute(0, 3, 1, 2) + x
+    out = torch.empty(B, H, W, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_posenc2d_fwd(dti(dt), P(xd), P(dev(gate, dt)), P(dev(hpos)), P(dev(wpos)), P(out), B, H, W, C, st()))
+    close(nchw(out.float()), ref, dt, "posenc2d_fwd")
+    do = q(rnd(B, C, H, W, seed=3), dt)
+    dgr = torch.cat([(do.permute(0, 2, 3, 1) * hpos.view(1, H, 1, C)).sum((1, 2)), (do.permute(0, 2, 3, 1) * wpos.view(1, 1, W, C)).sum((1, 2))], 1)
+    dg = torch.empty(B, 2 * C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_posenc2d_bwd_gate(dti(dt), P(dev(nhwc(do), dt)), P(dev(hpos)), P(dev(wpos)), P(dg), B, H, W, C, st()))
+    close(dg, dgr, dt, "posenc2d_bwd_gate")
+    # raw reshape quirk: [b,hw,c] buffer viewed as [b,c,h,w]
+    y = q(rnd(B, H * W, C, seed=4), dt)
+    z = torch.empty(B, H * W, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_encoder_reshape(dti(dt), 0, P(dev(y, dt)), P(z), B, H * W, C, 0, st()))
+    zr = y.reshape(B, C, H, W)  # the reference's x.reshape(-1, c, h, w)
+    close(z.view(B, H, W, C).permute(0, 3, 1, 2), zr, dt, "encoder_reshape", bf16_tol=1e-6)
+    back = torch.empty(B, H * W, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_encoder_reshape(dti(dt), 1, P(z), P(back), B, H * W, C, 0, st()))
+    close(back, y, dt, "encoder_reshape inverse", bf16_tol=1e-6)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_embedding_ce_adamw(lib, dt):
+    from oracle import satrn_oracle as O
+    B, L, D, V = 3, 7, 64, 245
+    ids = torch.randint(0, V + 1, (B, L + 1), generator=torch.Generator().manual_seed(1))
+    table = rnd(V + 1, D, seed=2)
+    pe = O.pos_table_1d(D)
+    out = torch.empty(B, L, D, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_embedding_fwd(dti(dt), P(dev(ids)), L + 1, P(dev(table)), P(dev(pe)), P(out), B, L, D, 0, 0.0, None, 0, st()))
+    tr = table.clone().requires_grad_(True)
+    ref = F.embedding(ids[:, :L], tr) * math.sqrt(D) + pe[:L].unsqueeze(0)
+    close(out, ref, dt, "embedding_fwd", bf16_tol=1e-2)
+    do = q(rnd(B, L, D, seed=3), dt)
+    ref.backward(do)
+    dtab = torch.zeros(V + 1, D, device="cuda")
+    ok(lib, lib.satrn_embedding_bwd(dti(dt), P(dev(ids)), L + 1, P(dev(do, dt)), P(dtab), B, L, D, 0.0, None, 0, st()))
+    close(dtab, tr.grad, dt, "embedding_bwd")
+    # cross entropy with ignore_index
+    T = 9
+    logits = rnd(B, T, V, seed=4, scale=3.0)
+    exp = torch.randint(3, V, (B, T + 1), generator=torch.Generator().manual_seed(5))
+    exp[1, -3:] = 2
+    lr_ = logits.clone().requires_grad_(True)
+    loss = F.cross_entropy(lr_.transpose(1, 2), exp[:, 1:], ignore_index=2)
+    loss.backward()
+    Vp = 256
+    outl = torch.zeros(4, device="cuda")
+    lse = torch.empty(B * T, device="cuda")
+    dl = torch.empty(B * T, Vp, dtype=tdt(dt), device="cuda")
+    expd = dev(exp)
+    tgt = ctypes.c_void_p(expd.data_ptr() + 8)
+    ok(lib, lib.satrn_cross_entropy(dti(dt), P(dev(logits)), tgt, T + 1, B, T, V, Vp, 2, P(outl), P(lse), P(dl), st()))
+    assert abs(outl[2].item() - loss.item()) < 1e-4 * max(1, abs(loss.item()))
+    assert outl[1].item() == (exp[:, 1:] != 2).sum().item()
+    close(dl.view(B, T, Vp)[:, :, :V], lr_.grad, dt, "cross_entropy dlogits", bf16_tol=1e-2)
+    assert dl.view(B, T, Vp)[:, :, V:].abs().max().item() == 0
+    if dt == "f32":
+        n = 10007
+        p, g = rnd(n, seed=6), rnd(n, seed=7, scale=0.5)
+        m, v = torch.zeros(n), torch.zeros(n)
+        pr = {"p": p.clone()}
+        O.clip_adamw_step(pr, {"p": g.clone()}, {"p": m.clone()}, {"p": v.clone()}, 1, 5e-4)
+        pd, md, vd = dev(p), dev(m), dev(v)
+        gn = torch.zeros(1, device="cuda")
+        hy = dev(torch.tensor([5e-4, 0.9, 0.999, 1e-8, 1e-6, 2.0, 1 - 0.9, 1 - 0.999, 1.0]))
+        ok(lib, lib.satrn_clip_adamw(P(pd), P(dev(g)), P(md), P(vd), n, P(gn), P(hy), st()))
+        close(pd, pr["p"], "f32", "clip_adamw", f32_tol=1e-6)
+        assert abs(math.sqrt(gn.item()) - g.norm().item()) < 1e-3
+
+
+def test_dropout_statistics(lib):
+    M, N, K = 512, 256, 64
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    fwd, _, _ = pack_dense(lib, w, "f32")
+    seed = torch.tensor([1234], dtype=torch.int32, device="cuda")
+    y0 = torch.empty(M, N, device="cuda")
+    y1 = torch.empty(M, N, device="cuda")
+    ok(lib, lib.satrn_linear_fwd(0, P(dev(x)), P(fwd), None, P(y0), M, N, K, 0, 0, 0.0, None, 0, st()))
+    ok(lib, lib.satrn_linear_fwd(0, P(dev(x)), P(fwd), None, P(y1), M, N, K, 0, 0, 0.1, P(seed), 7, st()))
+    kept = y1 != 0
+    frac = 1 - kept.float().mean().item()
+    assert abs(frac - 0.1) < 0.01, frac
+    torch.testing.assert_close(y1[kept], y0[kept] / 0.9, rtol=1e-5, atol=1e-6)
