@@ -213,6 +213,10 @@ int satrn_model_encode(satrn_model* m, const float* images, int B, float* src_ou
  * logits fp32 [B][steps][V]; ids int64 [B][steps] */
 int satrn_model_greedy(satrn_model* m, const float* images, const float* src, int B, int steps, float* logits,
                        int64_t* ids, void* stream);
+/* One EAGER forward + CE + backward with every kernel launch bracketed by HIP events on `stream`; writes a JSON array
+ * [{"kernel", "launches", "ms", "flops", "bytes"}...] (per kernel family, algorithmic flops / bytes) to json_out. */
+int satrn_model_profile_step(satrn_model* m, const float* images, const int64_t* expected, int B, int L, char* json_out,
+                             size_t cap, void* stream);
 /* adam state access for checkpointing / tests (device pointers inside the workspace) */
 float* satrn_model_adam_state(satrn_model* m, int which /*0 exp_avg, 1 exp_avg_sq*/);
 int satrn_model_set_step(satrn_model* m, long t);

@@ -356,8 +356,8 @@ def pos_table_2d(length, hidden):
 def positional_encoding_2d(x, sd, p="encoder.positional_encoding."):
     """networks/EfficientSATRN.py:135-154."""
     b, c, h, w = x.shape
-    hp = pos_table_2d(h, c).unsqueeze(1)  # [h,1,c]
-    wp = pos_table_2d(w, c).unsqueeze(0)  # [1,w,c]
+    hp = pos_table_2d(h, c).unsqueeze(1).to(x.dtype)  # [h,1,c]
+    wp = pos_table_2d(w, c).unsqueeze(0).to(x.dtype)  # [1,w,c]
     g = x.mean((2, 3))
     g = F.relu(F.linear(g, sd[p + "dense0.weight"], sd[p + "dense0.bias"]))
     g = torch.sigmoid(F.linear(g, sd[p + "dense1.weight"], sd[p + "dense1.bias"]))
@@ -462,7 +462,8 @@ def decoder_masks(text):
 def decoder_tf_forward(src, text, sd, cfg):
     """networks/EfficientSATRN.py:490-495 (teacher-forced branch) -> logits [b, L, V]."""
     Dd = cfg["dec_hidden"]
-    tgt = text_embedding(text, sd) + pos_table_1d(Dd)[: text.size(1)].unsqueeze(0)
+    tgt = text_embedding(text, sd)
+    tgt = tgt + pos_table_1d(Dd)[: text.size(1)].unsqueeze(0).to(tgt.dtype)
     mask = decoder_masks(text.clone())
     for l in range(cfg["dec_layers"]):
         tgt = decoder_layer(tgt, None, src, mask, sd, f"decoder.attention_layers.{l}.", cfg["dec_heads"])
@@ -507,19 +508,23 @@ def trainable_names(cfg):
     return [k for k, (_, kind) in param_specs(cfg).items() if not kind.startswith("bn_r") and kind != "bn_nbt"]
 
 
-def forward_backward(img, expected, sd, cfg):
+def forward_backward(img, expected, sd, cfg, dtype=None):
     """One teacher-forced training forward + CE + backward on the oracle.
-    Returns (loss, logits, grads{name}, bn_updates{name})."""
+    Returns (loss, logits, grads{name}, bn_updates{name}).  dtype=torch.bfloat16 runs the same graph with every tensor
+    in bf16 (PyTorch's own bf16 kernels): the yardstick for how much gradient noise bf16 storage costs."""
     sd = OrderedDict((k, v.clone()) for k, v in sd.items())
+    if dtype is not None:
+        sd = OrderedDict((k, (v.to(dtype) if v.is_floating_point() else v)) for k, v in sd.items())
+        img = img.to(dtype)
     names = trainable_names(cfg)
     for n in names:
         sd[n].requires_grad_(True)
     st = _BNState()
     logits = model_forward(img, expected, sd, cfg, True, True, st)
-    loss = loss_fn(logits, expected)
+    loss = loss_fn(logits.float(), expected)
     grads = torch.autograd.grad(loss, [sd[n] for n in names], allow_unused=True)
-    g = OrderedDict((n, (gi if gi is not None else torch.zeros_like(sd[n]))) for n, gi in zip(names, grads))
-    return loss.detach(), logits.detach(), g, st.updates
+    g = OrderedDict((n, (gi if gi is not None else torch.zeros_like(sd[n])).float()) for n, gi in zip(names, grads))
+    return loss.detach(), logits.detach().float(), g, st.updates
 
 
 def clip_adamw_step(params, grads, m, v, step, lr, wd=1e-6, max_norm=2.0, b1=0.9, b2=0.999, eps=1e-8):

@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""Headline benchmark: EfficientSATRN training step (BASELINE.json configs[1]): bf16, batch 32 per GPU, 1x128x384
+synthetic images, teacher-forced seq_len 128, dropout 0.1, CE + backward + clip_grad_norm_(2.0) + AdamW(lr 5e-4).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Rank 0 prints ONE JSON line (contract in the round prompt): whole-job images/s, plus
+  roofline     : the dominant kernel family of the step, timed live with HIP events on the engine's stream
+  cpu_baseline : the CPU oracle (oracle/satrn_oracle.py, kind "port") timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16 (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+FLOP_PER_IMG_TRAIN = 20.17e9  # conv+GEMM, 2xMAC, forward 6.725 GFLOP/img x 3
+
+CFG = dict(network="EfficientSATRN", rgb=1, enc_hidden=512, enc_filter=512, enc_heads=8, enc_layers=2, dec_src=512,
+           dec_hidden=256, dec_filter=1024, dec_heads=8, dec_layers=3, num_classes=245)
+
+
+class _DS:
+    token_to_id = {"<SOS>": 0, "<EOS>": 1, "<PAD>": 2}
+    id_to_token = {i: str(i) for i in range(245)}
+
+
+def make_model(dtype, H, W, dropout):
+    import satrn_amd
+    flags = satrn_amd.Flags(dict(
+        network="EfficientSATRN", input_size=dict(height=H, width=W),
+        SATRN=dict(encoder=dict(hidden_dim=512, filter_dim=512, layer_num=2, head_num=8),
+                   decoder=dict(src_dim=512, hidden_dim=256, filter_dim=1024, layer_num=3, head_num=8)),
+        data=dict(rgb=1), dropout_rate=dropout)).get()
+    return satrn_amd.EfficientSATRN(flags, _DS(), None, dtype=dtype)
+
+
+def synth(B, H, W, T, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, 1, H, W, generator=g)
+    exp = torch.randint(3, 245, (B, T + 1), generator=g)
+    exp[:, 0] = 0
+    exp[:, -1] = 1
+    return img.to(device), exp.to(device)
+
+
+def cpu_baseline(B, H, W, T, budget_s=25.0):
+    """The CPU oracle (PyTorch fp32 restatement pinned to the reference) on the host cores: fwd + CE + bwd + clip + AdamW."""
+    from oracle import satrn_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = dict(O.CFG_EFF)
+    sd = O.det_state_dict(cfg, 0)
+    img, exp = O.det_inputs(B, 1, H, W, T, seed=21)
+    names = O.trainable_names(cfg)
+    m = {n: torch.zeros_like(sd[n]) for n in names}
+    v = {n: torch.zeros_like(sd[n]) for n in names}
+    times = []
+    t_all = time.time()
+    for it in range(4):
+        t0 = time.time()
+        _, _, grads, _ = O.forward_backward(img, exp, sd, cfg)
+        p = {n: sd[n] for n in names}
+        O.clip_adamw_step(p, grads, m, v, it + 1, 5e-4)
+        times.append(time.time() - t0)
+        if time.time() - t_all > budget_s:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return dict(value=round(B / best, 3), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle fp32 train step, batch {B} of the same 1x{H}x{W}/T={T} workload, best of {len(times)} steps")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    H, W, T, B = 128, 384, 128, args.batch
+    torch.manual_seed(21)
+    model = make_model(args.dtype, H, W, 0.1).to(dev)
+    if world > 1:  # identical initial weights on every rank
+        model._ensure_bound(dev)
+        dist.broadcast(model.flat_params(), 0)
+    model.train()
+    img, exp = synth(B, H, W, T, 21 + rank, dev)
+    lr = 5e-4
+    graph = not args.no_graph
+
+    def step():
+        if world == 1:
+            model.train_step(img, exp, lr, use_graph=graph)
+        else:
+            model.train_step(img, exp, lr, use_graph=graph, phase=1)
+            dist.all_reduce(model.flat_grad())
+            model.train_step(img, exp, lr, use_graph=graph, phase=2, grad_scale=1.0 / world)
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss, cnt, gnorm = model.read_loss()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        # ---- roofline of the dominant kernel family: live HIP-event timing of every launch of one eager step
+        prof = model.profile_step(img, exp)
+        tot_ms = sum(p["ms"] for p in prof)
+        dom = prof[0]
+        if dom["flops"] > 0:
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            roof = dict(bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 5), traffic=None)
+        else:
+            ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            roof = dict(bound="hbm", achieved=round(ach, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 5), traffic=None)
+        roof["kernel"] = dom["kernel"]
+        roof["launches_per_step"] = dom["launches"]
+        roof["avg_launch_us"] = round(dom["ms"] * 1e3 / max(dom["launches"], 1), 3)
+        roof["share_of_step_kernel_time"] = round(dom["ms"] / max(tot_ms, 1e-9), 4)
+        roof["whole_step_mfma_frac"] = round(FLOP_PER_IMG_TRAIN * B / (ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 5)
+        out = dict(metric="train images/sec (whole node) EfficientSATRN bs32/GPU 128x384", value=round(value, 2), unit="images/s",
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True,
+                   scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
+                   config=dict(workload="EfficientSATRN train step (fwd+CE+bwd+clip+AdamW), bs32/GPU, 1x128x384, teacher-forced T=128, dropout 0.1 (BASELINE configs[1])",
+                               global_batch=world * B, seq_len=T, parallelism=f"dp{world}", hipgraph=graph),
+                   roofline=roof, final_loss=round(loss, 4), grad_norm=round(gnorm, 4),
+                   kernel_breakdown=[dict(kernel=p["kernel"], launches=p["launches"], ms=round(p["ms"], 3)) for p in prof[:12]])
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(2, H, W, T)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

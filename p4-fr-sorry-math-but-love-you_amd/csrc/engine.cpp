@@ -14,11 +14,26 @@
 
 void launch_act_fwd(int dt, const void* u, void* z, long n, int act, hipStream_t s);
 
-#define LCH(e, call) do { if (!(e).dry) { call; } } while (0)
+// launch wrapper: skipped in dry (sizing) runs; with profiling on, each launch is bracketed by HIP events on the
+// engine's stream and attributed to a kernel family (the launcher's name) with its algorithmic flops / bytes.
+#define LCH(e, call) do { if (!(e).dry) { if ((e).prof) (e).prof_begin(#call); call; if ((e).prof) (e).prof_end(); } (e).nflops = 0; (e).nbytes = 0; } while (0)
 
 // =====================================================================================================
 // Exec: arena + tape
 // =====================================================================================================
+void Exec::prof_begin(const char* call) {
+  ProfRec r;
+  const char* p = strstr(call, "launch_");
+  std::string nm = p ? p : call;
+  size_t q = nm.find('(');
+  if (q != std::string::npos) nm = nm.substr(0, q);
+  r.name = nm; r.flops = nflops; r.bytes = nbytes;
+  (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+  (void)hipEventRecord(r.a, s);
+  prof->push_back(r);
+}
+void Exec::prof_end() { (void)hipEventRecord(prof->back().b, s); }
+
 void Exec::reset(char* b, size_t c, char* zb, size_t zc) {
   base = b; cap = c; off = 0; zbase = zb; zcap = zc; zoff = 0; site = 1;
   tape.clear(); tens.clear(); logits = nullptr; src = nullptr; oom = false;
@@ -382,6 +397,7 @@ static void acc_grad(Exec& e, Tensor* t, const void* src) {
   int beta;
   void* g = e.grad(t, &beta);
   long n = t->rows * t->C;
+  e.nbytes = (double)n * e.esz() * (beta ? 3 : 2);
   if (beta) LCH(e, launch_add(e.dt, g, src, g, n, e.s));
   else LCH(e, (void)hipMemcpyAsync(g, src, (size_t)n * e.esz(), hipMemcpyDeviceToDevice, e.s));
 }
@@ -408,6 +424,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
   p.M = (int)M; p.N = N; p.K = w->K; p.lda = x->C; p.ldc = N;
   p.act = act; p.out_f32 = out_f32 ? 1 : 0; p.drop_p = drop_p; p.seed = seed; p.site = site;
   if (geo) { p.H = geo->H; p.W = geo->W; p.Ci = geo->Ci; p.OH = geo->OH; p.OW = geo->OW; p.KW = geo->KW; p.stride = geo->stride; p.pt = geo->pt; p.pl = geo->pl; }
+  e.nflops = 2.0 * (double)M * N * w->K; e.nbytes = ((double)x->rows * x->C + (double)M * N + (double)N * w->K) * e.esz();
   LCH(e, launch_gemm(e.dt, geo ? AM_CONV : AM_DENSE, p, e.s));
   if (e.rec) {
     Geo g{};
@@ -426,6 +443,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       q.dY = dY; q.A = x->p; q.dW = w->g; q.M = (int)M; q.N = N; q.K = w->K; q.ldy = ldy; q.lda = x->C;
       q.nbatch = 1; q.nb_inner = 1;
       if (hasgeo) { q.conv = 1; q.H = g.H; q.W = g.W; q.Ci = g.Ci; q.OH = g.OH; q.OW = g.OW; q.KW = g.KW; q.stride = g.stride; q.pt = g.pt; q.pl = g.pl; }
+      e.nflops = 2.0 * (double)M * N * w->K;
       LCH(e, launch_wgrad(e.dt, q, e.s));
       int beta;
       void* dx = e.grad(x, &beta);
@@ -434,10 +452,12 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       d.A = dY; d.Bw = w->bwd; d.C = dx; d.beta = beta;
       if (!hasgeo) {
         d.M = (int)M; d.N = w->K; d.K = w->ldb; d.lda = ldy; d.ldc = x->C;
+        e.nflops = 2.0 * (double)d.M * d.N * w->N;
         LCH(e, launch_gemm(e.dt, AM_DENSE, d, e.s));
       } else {
         d.M = (int)((long)B * g.H * g.W); d.N = g.Ci; d.K = 9 * w->Co; d.ldc = g.Ci;
         d.H = g.OH; d.W = g.OW; d.Ci = w->Co; d.OH = g.H; d.OW = g.W; d.KW = g.KW; d.stride = g.stride; d.pt = g.pt; d.pl = g.pl;
+        e.nflops = 2.0 * (double)M * N * w->K;
         LCH(e, launch_gemm(e.dt, AM_DGRAD, d, e.s));
       }
     });
@@ -452,19 +472,23 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res) {
   float* mr = (float*)e.alloc((size_t)2 * C * 4);
   if (e.train) {
     float* sums = e.zalloc(2 * C);
+    e.nbytes = (double)M * C * e.esz();
     LCH(e, launch_colstats(e.dt, y->p, M, C, sums, e.s));
     LCH(e, launch_bn_finalize(sums, M, C, bn->w.p, bn->b.p, bn->rm, bn->rv, bn->nbt, bn->eps, 0.1f, 1, ss, mr, e.s));
   } else {
     LCH(e, launch_bn_finalize(nullptr, M, C, bn->w.p, bn->b.p, bn->rm, bn->rv, nullptr, bn->eps, 0.1f, 0, ss, mr, e.s));
   }
   Tensor* z = e.newt(M, C, y->B, y->H, y->W);
+  e.nbytes = (double)M * C * e.esz() * (res ? 3 : 2);
   LCH(e, launch_bn_act(e.dt, y->p, ss, res ? res->p : nullptr, z->p, M, C, act, e.s));
   if (e.rec) {
     e.tape.push_back([&e, y, z, bn, act, res, ss, mr, M, C]() {
       if (!z->g) return;
       float* red = e.zalloc(2 * C);
+      e.nbytes = (double)M * C * e.esz() * 2;
       LCH(e, launch_bn_bwd_reduce(e.dt, z->g, y->p, ss, mr, M, C, act, red, e.s));
       void* dy = e.grad(y, nullptr);
+      e.nbytes = (double)M * C * e.esz() * 3;
       LCH(e, launch_bn_bwd_apply(e.dt, z->g, y->p, ss, mr, bn->w.p, red, M, C, act, dy, bn->w.g, bn->b.g, e.s));
       if (res) acc_grad(e, res, z->g);
     });
@@ -622,6 +646,7 @@ Tensor* op_attn(Exec& e, Tensor* qt, int qoff, Tensor* kvt, int koff, int voff, 
   p.ldq = qt->C; p.ldk = kvt->C; p.ldv = kvt->C; p.ldo = D;
   p.sq_b = (long)Lq * qt->C; p.sk_b = (long)Lk * kvt->C; p.sv_b = (long)Lk * kvt->C; p.so_b = (long)Lq * D;
   p.causal = causal; p.pad_id = e.m->cfg.pad_id; p.inv_temp = 1.0f / sqrtf((float)D); p.drop_p = drop_p; p.seed = seed; p.site = site;
+  e.nflops = 4.0 * (double)B * heads * Lq * Lk * hd;
   LCH(e, launch_attn(e.dt, 0, p, e.s));
   if (e.rec)
     e.tape.push_back([&e, qt, qoff, kvt, koff, voff, o, p, B, Lq, Lk, heads, hd, D, es]() {
@@ -633,6 +658,7 @@ Tensor* op_attn(Exec& e, Tensor* qt, int qoff, Tensor* kvt, int koff, int voff, 
       void* dkv = e.grad(kvt, nullptr);
       AttnP q = p;
       q.dO = o->g; q.dQ = (char*)dq + qoff * es; q.dS = dS; q.Pd = Pd;
+      e.nflops = 6.0 * (double)B * heads * Lq * Lk * hd;
       LCH(e, launch_attn(e.dt, 1, q, e.s));
       WgradP w;
       memset(&w, 0, sizeof(w));
@@ -640,9 +666,11 @@ Tensor* op_attn(Exec& e, Tensor* qt, int qoff, Tensor* kvt, int koff, int voff, 
       w.sY_o = (long)heads * Lq * LkP; w.sY_i = (long)Lq * LkP;
       w.sW_o = (long)Lk * kvt->C; w.sW_i = hd; w.ldw = kvt->C;
       // dV = Pd^T dO
+      e.nflops = 2.0 * (double)B * heads * Lq * Lk * hd;
       w.dY = Pd; w.A = o->g; w.lda = D; w.sA_o = (long)Lq * D; w.sA_i = hd; w.dW = (char*)dkv + voff * es;
       LCH(e, launch_wgrad(e.dt, w, e.s));
       // dK = dS^T Q
+      e.nflops = 2.0 * (double)B * heads * Lq * Lk * hd;
       w.dY = dS; w.A = (char*)qt->p + qoff * es; w.lda = qt->C; w.sA_o = (long)Lq * qt->C; w.sA_i = hd; w.dW = (char*)dkv + koff * es;
       LCH(e, launch_wgrad(e.dt, w, e.s));
     });
@@ -1027,4 +1055,40 @@ int model_greedy(Model* m, const float* img, const float* src_in, int B, int ste
   }
   if (e.oom) { m->err = "workspace exhausted"; return -2; }
   return 0;
+}
+
+// ---- per-family event profile of ONE eager training step (forward + CE + backward; no optimizer) -----------------
+int model_profile_step(Model* m, const float* img, const int64_t* expected, int B, int L, char* out, size_t out_cap,
+                       hipStream_t s) {
+  if (!m->bound || !m->ws_set || !m->grads) { m->err = "bind parameters/grads and set a workspace first"; return -1; }
+  Exec& e = *m->ex;
+  std::vector<ProfRec> recs;
+  e.prof = &recs;
+  (void)hipMemsetAsync(m->grads, 0, (size_t)m->n_params * 4, s);
+  int rc = model_forward(m, img, expected, B, L, true, true, nullptr, s);
+  if (!rc) rc = model_loss_backward(m, expected, B, L, s);
+  e.prof = nullptr;
+  (void)hipStreamSynchronize(s);
+  struct Agg { double ms = 0, flops = 0, bytes = 0; long n = 0; };
+  std::vector<std::pair<std::string, Agg>> agg;
+  for (auto& r : recs) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    size_t i = 0;
+    for (; i < agg.size(); ++i) if (agg[i].first == r.name) break;
+    if (i == agg.size()) agg.push_back({r.name, Agg()});
+    agg[i].second.ms += ms; agg[i].second.flops += r.flops; agg[i].second.bytes += r.bytes; agg[i].second.n += 1;
+  }
+  std::sort(agg.begin(), agg.end(), [](const std::pair<std::string, Agg>& a, const std::pair<std::string, Agg>& b) { return a.second.ms > b.second.ms; });
+  std::string js = "[";
+  for (size_t i = 0; i < agg.size(); ++i) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s{\"kernel\": \"%s\", \"launches\": %ld, \"ms\": %.4f, \"flops\": %.6e, \"bytes\": %.6e}", i ? ", " : "",
+             agg[i].first.c_str(), agg[i].second.n, agg[i].second.ms, agg[i].second.flops, agg[i].second.bytes);
+    js += buf;
+  }
+  js += "]";
+  if (out && out_cap) { strncpy(out, js.c_str(), out_cap - 1); out[out_cap - 1] = 0; }
+  return rc;
 }

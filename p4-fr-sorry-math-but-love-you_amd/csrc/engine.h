@@ -104,8 +104,12 @@ struct Model {
 // scalars block (floats unless noted), all in device memory inside the persistent region
 enum { SC_SEED = 0 /*uint32*/, SC_GNORM = 1, SC_LOSS = 4 /*4 floats*/, SC_HYPER = 8 /*9 floats*/, SC_ONE = 20, SC_COUNT = 32 };
 
+struct ProfRec { std::string name; double flops = 0, bytes = 0; hipEvent_t a = nullptr, b = nullptr; };
+
 struct Exec {
   Model* m = nullptr;
+  std::vector<ProfRec>* prof = nullptr; double nflops = 0, nbytes = 0;
+  void prof_begin(const char* call); void prof_end();
   hipStream_t s = nullptr;
   int dt = 0;
   bool train = false, rec = false, dry = false;
@@ -142,3 +146,5 @@ int model_read_loss(Model* m, float* out4, hipStream_t s);
 int model_encode(Model* m, const float* img, int B, float* src_out, hipStream_t s);
 int model_greedy(Model* m, const float* img, const float* src_or_null, int B, int steps, float* logits_out,
                  int64_t* ids_out, hipStream_t s);
+int model_profile_step(Model* m, const float* img, const int64_t* expected, int B, int L, char* out, size_t out_cap,
+                       hipStream_t s);

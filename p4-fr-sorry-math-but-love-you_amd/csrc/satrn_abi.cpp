@@ -353,6 +353,10 @@ int satrn_model_greedy(satrn_model* h, const float* img, const float* src, int B
                        void* st) {
   return mret(h, model_greedy(h->m, img, src, B, steps, logits, ids, S(st)), "greedy");
 }
+int satrn_model_profile_step(satrn_model* h, const float* img, const int64_t* exp, int B, int L, char* json_out,
+                             size_t cap, void* st) {
+  return mret(h, model_profile_step(h->m, img, exp, B, L, json_out, cap, S(st)), "profile_step");
+}
 float* satrn_model_adam_state(satrn_model* h, int which) {
   Model* m = h->m;
   if (!m->ws) return nullptr;

@@ -131,6 +131,8 @@ class _SATRNBase(nn.Module):
         self._bound = None
         self._last_logits = None
         self._stage = None
+        self._side = None
+        self._warm = set()
         if checkpoint:
             self.load_state_dict(checkpoint)
 
@@ -236,6 +238,7 @@ class _SATRNBase(nn.Module):
         self._ws_key = (B2, L2)
         self._packed_version = -1
         self._stage = None
+        self._warm = set()
 
     def _param_version(self):
         v = 0
@@ -347,8 +350,19 @@ class _SATRNBase(nn.Module):
         self._stage[0].copy_(input, non_blocking=True)
         self._stage[1].copy_(expected, non_blocking=True)
         hy = (ctypes.c_float * 9)(lr, betas[0], betas[1], eps, weight_decay, max_grad_norm, 0.0, 0.0, grad_scale)
-        check(self._lib.satrn_model_train_step(self._h, ptr(self._stage[0]), ptr(self._stage[1]), B, L, hy, int(use_graph),
-                                               int(phase), _stream()), "satrn_model_train_step")
+        # graphs are captured on a private stream (the legacy default stream cannot capture); the first step of a shape
+        # runs eagerly so that one-time kernel attribute setup never lands inside a capture
+        key = (B, L, int(phase))
+        warm = key in self._warm
+        self._warm.add(key)
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=input.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            check(self._lib.satrn_model_train_step(self._h, ptr(self._stage[0]), ptr(self._stage[1]), B, L, hy,
+                                                   int(use_graph and warm), int(phase), _stream()), "satrn_model_train_step")
+        cur.wait_stream(self._side)
         self._gen += 1
         self._packed_version = -2  # parameters were updated and re-packed inside the step
 

@@ -46,9 +46,22 @@ def q(x, dt):
     return x.to(tdt(dt)).float()
 
 
+_KEEP = []
+
+
 def dev(x, dt=None):
+    """copy to the GPU and keep the tensor alive until the test ends (raw pointers are handed to the library)"""
     x = x.cuda()
-    return x.to(tdt(dt)).contiguous() if dt else x.contiguous()
+    x = x.to(tdt(dt)).contiguous() if dt else x.contiguous()
+    _KEEP.append(x)
+    return x
+
+
+@pytest.fixture(autouse=True)
+def _keepalive():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def nhwc(x):
