@@ -366,6 +366,20 @@ class _SATRNBase(nn.Module):
         self._gen += 1
         self._packed_version = -2  # parameters were updated and re-packed inside the step
 
+    def profile_step(self, input, expected):
+        """One eager forward + CE + backward with HIP events around every launch -> list of per-kernel-family dicts
+        (kernel, launches, ms, flops, bytes), sorted by time."""
+        import json
+        input = self._img(input)
+        expected = expected.contiguous()
+        B, L = expected.shape
+        self._prepare(input, B, L)
+        buf = ctypes.create_string_buffer(1 << 16)
+        check(self._lib.satrn_model_profile_step(self._h, ptr(input), ptr(expected), B, L, buf, len(buf), _stream()),
+              "satrn_model_profile_step")
+        self._gen += 1
+        return json.loads(buf.value.decode())
+
     def flat_grad(self):
         return self._gflat
 
