@@ -55,7 +55,12 @@ def synth(B, H, W, T, seed, device):
 def cpu_baseline(B, H, W, T, budget_s=25.0):
     """The CPU oracle (PyTorch fp32 restatement pinned to the reference) on the host cores: fwd + CE + bwd + clip + AdamW."""
     from oracle import satrn_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives a one-GPU job a 16-CPU share: more threads than that only oversubscribes
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, ncpu)))
     cfg = dict(O.CFG_EFF)
     sd = O.det_state_dict(cfg, 0)
     img, exp = O.det_inputs(B, 1, H, W, T, seed=21)
@@ -75,6 +80,10 @@ def cpu_baseline(B, H, W, T, budget_s=25.0):
     best = min(times[1:]) if len(times) > 1 else times[0]
     return dict(value=round(B / best, 3), unit="images/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"oracle fp32 train step, batch {B} of the same 1x{H}x{W}/T={T} workload, best of {len(times)} steps")
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
 
 
 def main():
@@ -118,8 +127,11 @@ def main():
             dist.all_reduce(model.flat_grad())
             model.train_step(img, exp, lr, use_graph=graph, phase=2, grad_scale=1.0 / world)
 
-    for _ in range(max(args.warmup, 2)):
+    for i in range(max(args.warmup, 2)):
         step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"warmup {i} done, loss {model.read_loss()[0]:.4f}")
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -137,12 +149,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     loss, cnt, gnorm = model.read_loss()
+    if rank == 0:
+        log(f"timed {args.steps} steps in {dt:.3f}s")
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
         # ---- roofline of the dominant kernel family: live HIP-event timing of every launch of one eager step
         prof = model.profile_step(img, exp)
+        log("profile:", json.dumps(prof))
         tot_ms = sum(p["ms"] for p in prof)
         dom = prof[0]
         if dom["flops"] > 0:
@@ -165,6 +180,7 @@ def main():
                    roofline=roof, final_loss=round(loss, 4), grad_norm=round(gnorm, 4),
                    kernel_breakdown=[dict(kernel=p["kernel"], launches=p["launches"], ms=round(p["ms"], 3)) for p in prof[:12]])
         if not args.no_cpu_baseline and world == 1:
+            log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(2, H, W, T)
         print(json.dumps(out), flush=True)
     if dist is not None:
