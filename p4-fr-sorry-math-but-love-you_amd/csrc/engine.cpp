@@ -300,6 +300,8 @@ Model* model_create(const SatrnConfig& cfg) {
   else { m->feat_h = cfg.height / 32; m->feat_w = cfg.width / 32; }
   m->off_hpos = take((size_t)std::max(m->feat_h, 1) * D * 4);
   m->off_wpos = take((size_t)std::max(m->feat_w, 1) * D * 4);
+  m->packdesc_bytes = (m->all_w.size() + 8) * sizeof(PackDesc);
+  m->off_packdesc = take(m->packdesc_bytes);
   m->zero_bytes = 8u << 20;
   m->off_zero = take(m->zero_bytes);
   m->persist_bytes = (o + 255) & ~(size_t)255;
@@ -322,6 +324,7 @@ int model_bind(Model* m, float* params, float* grads, float* buf_f32, int64_t* b
   for (Vec* v : m->all_v) { v->p = params + v->off; v->g = grads ? grads + v->off : nullptr; }
   for (BNp* b : m->all_bn) { b->rm = buf_f32 + b->rm_off; b->rv = buf_f32 + b->rv_off; b->nbt = buf_i64 ? buf_i64 + b->nbt_off : nullptr; }
   m->bound = true;
+  m->pack_dirty = true;
   for (int i = 0; i < 4; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
   return 0;
 }
@@ -331,6 +334,10 @@ static float* scal(Model* m) { return (float*)(m->ws + m->off_scalars); }
 int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s) {
   if (bytes < m->persist_bytes + (1u << 20)) { m->err = "workspace too small"; return -2; }
   m->ws = (char*)ws; m->ws_bytes = bytes;
+  // packed weights carry zero padding (generator: 245 -> 256 columns) that kernels multiply with zero gradients:
+  // the padding must be finite, so clear everything once
+  (void)hipMemsetAsync(m->ws, 0, bytes, s);
+  (void)hipStreamSynchronize(s);
   for (Wt* w : m->all_w) {
     w->fwd = w->pk_fwd_off >= 0 ? m->ws + w->pk_fwd_off : nullptr;
     w->bwd = w->pk_bwd_off >= 0 ? m->ws + w->pk_bwd_off : nullptr;
@@ -372,6 +379,7 @@ int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s) {
   (void)hipMemcpyAsync(scal(m) + SC_SEED, &seed0, 4, hipMemcpyHostToDevice, s);
   (void)hipStreamSynchronize(s);
   m->ws_set = true;
+  m->pack_dirty = true;
   m->adam_t = 0;
   return 0;
 }
@@ -379,11 +387,24 @@ int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s) {
 int model_pack_weights(Model* m, hipStream_t s) {
   if (!m->bound || !m->ws_set) { m->err = "bind + workspace first"; return -1; }
   const int dt = m->cfg.dtype;
-  for (Wt* w : m->all_w) {
-    if (w->kind == WK_DENSE) launch_pack_dense_ld(dt, w->p, w->fwd, w->bwd, w->N, w->K, w->ldb, s);
-    else if (w->kind == WK_CONV3) launch_pack_conv(dt, w->p, w->fwd, w->bwd, w->Co, w->Ci, 9, s);
-    else if (w->kind == WK_DW) launch_pack_dw(dt, w->p, w->fwd, w->Co, s);
+  if (m->pack_dirty) {  // (re)build the descriptor table: one entry per packed weight
+    std::vector<PackDesc> d;
+    long total = 0;
+    for (Wt* w : m->all_w) {
+      PackDesc e;
+      e.src = w->p; e.fwd = w->fwd; e.bwd = w->bwd; e.start = total; e.ldb = w->ldb;
+      if (w->kind == WK_DENSE) { e.kind = 0; e.N = w->N; e.K = w->K; total += (long)w->N * w->K; }
+      else if (w->kind == WK_CONV3) { e.kind = 1; e.N = w->Co; e.K = w->Ci; total += (long)w->Co * w->Ci * 9; }
+      else if (w->kind == WK_DW) { e.kind = 2; e.N = w->Co; e.K = 1; total += (long)w->Co * 9; }
+      else continue;
+      d.push_back(e);
+    }
+    if (d.size() * sizeof(PackDesc) > m->packdesc_bytes) { m->err = "pack descriptor table overflow"; return -1; }
+    (void)hipMemcpyAsync(m->ws + m->off_packdesc, d.data(), d.size() * sizeof(PackDesc), hipMemcpyHostToDevice, s);
+    (void)hipStreamSynchronize(s);
+    m->pack_n = (int)d.size(); m->pack_total = total; m->pack_dirty = false;
   }
+  launch_pack_all(dt, (const PackDesc*)(m->ws + m->off_packdesc), m->pack_n, m->pack_total, s);
   return 0;
 }
 
@@ -394,6 +415,8 @@ namespace {
 struct Geo { int H, W, Ci, OH, OW, KW, stride, pt, pl; };
 
 static void acc_grad(Exec& e, Tensor* t, const void* src) {
+  // first contribution: alias the producer's gradient buffer (it has no reader left once its own backward ran)
+  if (!t->g) { t->g = const_cast<void*>(src); t->g_init = true; return; }
   int beta;
   void* g = e.grad(t, &beta);
   long n = t->rows * t->C;

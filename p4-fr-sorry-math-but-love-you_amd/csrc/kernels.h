@@ -116,6 +116,9 @@ void launch_pack_dense(int dt, const float* w, void* fwd /*[N][K]*/, void* bwd /
 void launch_pack_conv(int dt, const float* w /*[Co][Ci][T]*/, void* fwd /*[Co][T][Ci]*/, void* bwd /*[Ci][T][Co]*/, int Co,
                       int Ci, int taps, hipStream_t s);
 void launch_pack_dw(int dt, const float* w /*[C][9]*/, void* out /*[9][C]*/, int C, hipStream_t s);
+// kind 0 dense (N,K,ldb), 1 conv3x3 (N=Co, K=Ci), 2 depthwise (N=C)
+struct PackDesc { const float* src; void* fwd; void* bwd; long start; int kind, N, K, ldb; };
+void launch_pack_all(int dt, const PackDesc* d, int nd, long total, hipStream_t s);
 void launch_sumsq(const float* g, long n, float* out /*[1] +=*/, hipStream_t s);
 void launch_adamw(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, const float* hyper,
                   hipStream_t s);

@@ -10,6 +10,13 @@
     else { typedef float T; __VA_ARGS__; }       \
   } while (0)
 
+DEVI void ldv(const float* p, float* o, int n) {  // n (multiple of 4) floats through 16-byte loads
+  for (int j = 0; j < n; j += 4) {
+    float4 v = *reinterpret_cast<const float4*>(p + j);
+    o[j] = v.x; o[j + 1] = v.y; o[j + 2] = v.z; o[j + 3] = v.w;
+  }
+}
+
 static inline int grid_for(long work, int per_block = 256, int cap = 4096) {
   long g = (work + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -43,6 +50,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int 
   long r1 = r0 + rows_per_block;
   if (r1 > M) r1 = M;
   if (c < CC) {
+    f.prep(c * CH);
     for (long r = r0 + ty; r < r1; r += TY) f(r, c * CH, acc);
 #pragma unroll
     for (int k = 0; k < NO; ++k)
@@ -65,24 +73,27 @@ template <typename T, int NO, typename F>
 static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain, hipStream_t s) {
   constexpr int CH = TT<T>::CH;
   int CC = C / CH;
+  // at most 32 column chunks per block (>= 8 row lanes), >= 32 rows per thread when M allows: keeps the number of
+  // global atomics (NO * TX * CH per block) small next to the streamed bytes
   int txl = 0;
-  while ((1 << txl) < CC && txl < 8) ++txl;
+  while ((1 << txl) < CC && txl < 5) ++txl;
   int TX = 1 << txl, TY = 256 >> txl;
   int gy = (CC + TX - 1) / TX;
-  long want_blocks = 1024 / gy;
-  if (want_blocks < 1) want_blocks = 1;
-  long rpb = (M + want_blocks - 1) / want_blocks;
-  long minr = (long)TY * 8;
-  if (rpb < minr) rpb = minr;
-  int gx = (int)((M + rpb - 1) / rpb);
+  // ~4 rows per thread, at most ~1024 blocks: these reductions are latency-bound per thread, and the float atomics
+  // they end with (NO * TX * CH per block) are cheap next to the streamed bytes
+  long rpb = (long)TY * 4;
+  long gx = (M + rpb - 1) / rpb;
+  long cap = 1024 / gy < 1 ? 1 : 1024 / gy;
+  if (gx > cap) { gx = cap; rpb = (M + gx - 1) / gx; rpb = ((rpb + TY - 1) / TY) * TY; gx = (M + rpb - 1) / rpb; }
   size_t sh = (size_t)NO * TX * CH * sizeof(float);
-  hipLaunchKernelGGL((colreduce_kernel<T, NO, F>), dim3(gx, gy), dim3(256), sh, s, f, M, C, (int)rpb, txl, o0, o1,
+  hipLaunchKernelGGL((colreduce_kernel<T, NO, F>), dim3((int)gx, gy), dim3(256), sh, s, f, M, C, (int)rpb, txl, o0, o1,
                      nmain);
 }
 
 // ---- BN batch statistics ------------------------------------------------------------------
 template <typename T> struct StatsF {
   const T* y; int C;
+  __device__ void prep(int) {}
   __device__ void operator()(long r, int c0, float (*acc)[TT<T>::CH]) const {
     float v[TT<T>::CH];
     unpack<T>(ld16(y + r * C + c0), v);
@@ -124,18 +135,35 @@ void launch_bn_finalize(const float* sums, long M, int C, const float* w, const 
                      rm, rv, nbt, eps, mom, train, ss, mr);
 }
 
+// grid for streaming kernels with per-channel parameters: total threads is a multiple of the chunk count CC, so a
+// thread always meets the same channel chunk and keeps its parameters in registers
+static inline int grid_chan(long nchunks, int CC) {
+  int g = grid_for(nchunks);
+  int a = CC, b = 256;
+  while (b) { int t = a % b; a = b; b = t; }
+  int q = CC / a;
+  return ((g + q - 1) / q) * q;
+}
+
 template <typename T>
 __global__ void bn_act_kernel(const T* y, const float* ss, const T* res, T* z, long nchunks, int C, int act) {
   constexpr int CH = TT<T>::CH;
   const int CC = C / CH;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
-    int c0 = (int)(i % CC) * CH;
+  const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+  const int c0 = (int)(tid % CC) * CH;
+  float sc[CH], sh[CH];
+  for (int j = 0; j < CH; j += 4) {
+    float4 a = *reinterpret_cast<const float4*>(ss + c0 + j), b = *reinterpret_cast<const float4*>(ss + C + c0 + j);
+    sc[j] = a.x; sc[j + 1] = a.y; sc[j + 2] = a.z; sc[j + 3] = a.w;
+    sh[j] = b.x; sh[j + 1] = b.y; sh[j + 2] = b.z; sh[j + 3] = b.w;
+  }
+  for (long i = tid; i < nchunks; i += nth) {
     float v[CH], r[CH];
     unpack<T>(ld16(y + i * CH), v);
     if (res) unpack<T>(ld16(res + i * CH), r);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      float u = act_fwd(v[j] * ss[c0 + j] + ss[C + c0 + j], act);
+      float u = act_fwd(v[j] * sc[j] + sh[j], act);
       v[j] = res ? u + r[j] : u;
     }
     st16(z + i * CH, pack<T>(v));
@@ -145,13 +173,17 @@ void launch_bn_act(int dt, const void* y, const float* ss, const void* res, void
                    hipStream_t s) {
   DISPATCH_T(dt, {
     long n = M * C / TT<T>::CH;
-    hipLaunchKernelGGL((bn_act_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)y, ss, (const T*)res, (T*)z, n,
-                       C, act);
+    hipLaunchKernelGGL((bn_act_kernel<T>), dim3(grid_chan(n, C / TT<T>::CH)), dim3(256), 0, s, (const T*)y, ss, (const T*)res,
+                       (T*)z, n, C, act);
   });
 }
 
 template <typename T> struct BnBwdRedF {
   const T* dz; const T* y; const float* ss; const float* mr; int C; int act;
+  float sc[TT<T>::CH], sh[TT<T>::CH], mu[TT<T>::CH], rs[TT<T>::CH];
+  __device__ void prep(int c0) {
+    ldv(ss + c0, sc, TT<T>::CH); ldv(ss + C + c0, sh, TT<T>::CH); ldv(mr + c0, mu, TT<T>::CH); ldv(mr + C + c0, rs, TT<T>::CH);
+  }
   __device__ void operator()(long r, int c0, float (*acc)[TT<T>::CH]) const {
     constexpr int CH = TT<T>::CH;
     float d[CH], v[CH];
@@ -159,9 +191,9 @@ template <typename T> struct BnBwdRedF {
     unpack<T>(ld16(y + r * C + c0), v);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      float u = v[j] * ss[c0 + j] + ss[C + c0 + j];
+      float u = v[j] * sc[j] + sh[j];
       float g = d[j] * act_bwd(u, act);
-      float xh = (v[j] - mr[c0 + j]) * mr[C + c0 + j];
+      float xh = (v[j] - mu[j]) * rs[j];
       acc[0][j] += g;
       acc[1][j] += g * xh;
     }
@@ -170,35 +202,46 @@ template <typename T> struct BnBwdRedF {
 void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* ss, const float* mr, long M, int C,
                           int act, float* red, hipStream_t s) {
   DISPATCH_T(dt, {
-    BnBwdRedF<T> f{(const T*)dz, (const T*)y, ss, mr, C, act};
+    BnBwdRedF<T> f;
+    f.dz = (const T*)dz; f.y = (const T*)y; f.ss = ss; f.mr = mr; f.C = C; f.act = act;
     launch_colreduce<T, 2>(f, M, C, red, red + C, 1, s);
   });
 }
 
+// dy = A*g + Bc + Cc*y with g = dz*act'(y*scale+shift): per-channel coefficients computed once per thread
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* dz, const T* y, const float* ss, const float* mr, const float* w,
                                     const float* red, float invM, long nchunks, int C, int act, T* dy, float* dw,
                                     float* db) {
   constexpr int CH = TT<T>::CH;
   const int CC = C / CH;
-  long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (i0 < C && dw) {  // parameter grads (grad buffers are zeroed per step: accumulate)
-    dw[i0] += red[C + i0];
-    db[i0] += red[i0];
+  const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+  if (tid < C && dw) {  // parameter grads (grad buffers are zeroed per step: accumulate)
+    dw[tid] += red[C + tid];
+    db[tid] += red[tid];
   }
-  for (long i = i0; i < nchunks; i += (long)gridDim.x * blockDim.x) {
-    int c0 = (int)(i % CC) * CH;
+  const int c0 = (int)(tid % CC) * CH;
+  float sc[CH], sh[CH], A[CH], Bc[CH], Cc[CH];
+  {
+    float mu[CH], rs[CH], ww[CH], r0[CH], r1[CH];
+    ldv(ss + c0, sc, CH); ldv(ss + C + c0, sh, CH); ldv(mr + c0, mu, CH); ldv(mr + C + c0, rs, CH);
+    ldv(w + c0, ww, CH); ldv(red + c0, r0, CH); ldv(red + C + c0, r1, CH);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      float a = ww[j] * rs[j], m1 = r0[j] * invM, m2 = r1[j] * invM;
+      A[j] = a;
+      Cc[j] = -a * rs[j] * m2;
+      Bc[j] = -a * m1 + a * rs[j] * mu[j] * m2;
+    }
+  }
+  for (long i = tid; i < nchunks; i += nth) {
     float d[CH], v[CH];
     unpack<T>(ld16(dz + i * CH), d);
     unpack<T>(ld16(y + i * CH), v);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      int c = c0 + j;
-      float u = v[j] * ss[c] + ss[C + c];
-      float g = d[j] * act_bwd(u, act);
-      float rstd = mr[C + c];
-      float xh = (v[j] - mr[c]) * rstd;
-      d[j] = w[c] * rstd * (g - red[c] * invM - xh * red[C + c] * invM);
+      float g = d[j] * act_bwd(v[j] * sc[j] + sh[j], act);
+      d[j] = A[j] * g + Bc[j] + Cc[j] * v[j];
     }
     st16(dy + i * CH, pack<T>(d));
   }
@@ -207,8 +250,8 @@ void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* ss,
                          const float* red, long M, int C, int act, void* dy, float* dw, float* db, hipStream_t s) {
   DISPATCH_T(dt, {
     long n = M * C / TT<T>::CH;
-    int g = grid_for(n);
-    if ((long)g * 256 < C) g = (C + 255) / 256;
+    int g = grid_chan(n, C / TT<T>::CH);
+    while ((long)g * 256 < C) g *= 2;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g), dim3(256), 0, s, (const T*)dz, (const T*)y, ss, mr, w, red,
                        1.0f / (float)M, n, C, act, (T*)dy, dw, db);
   });
@@ -383,6 +426,7 @@ void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float*
 
 template <typename T> struct DwWgradF {
   const T* x; const T* dy; int H, W, C, OH, OW, stride, pt, pl;
+  __device__ void prep(int) {}
   __device__ void operator()(long r, int c0, float (*acc)[TT<T>::CH]) const {
     constexpr int CH = TT<T>::CH;
     int ox = (int)(r % OW);
@@ -1124,6 +1168,38 @@ __global__ void pack_dw_kernel(const float* w, T* out, int C) {
 }
 void launch_pack_dw(int dt, const float* w, void* out, int C, hipStream_t s) {
   DISPATCH_T(dt, { hipLaunchKernelGGL((pack_dw_kernel<T>), dim3((C * 9 + 255) / 256), dim3(256), 0, s, w, (T*)out, C); });
+}
+
+// one launch for every weight: descriptor table + binary search on the element prefix
+template <typename T>
+__global__ void pack_all_kernel(const PackDesc* d, int nd, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = nd - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (d[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc e = d[lo];
+    const long j = i - e.start;
+    const T v = from_f<T>(e.src[j]);
+    if (e.kind == 0) {  // dense [N][K] -> fwd [N][K], bwd [K][ldb]
+      int r = (int)(j / e.K), k = (int)(j - (long)r * e.K);
+      ((T*)e.fwd)[j] = v;
+      ((T*)e.bwd)[(long)k * e.ldb + r] = v;
+    } else if (e.kind == 1) {  // conv3x3 [Co][Ci][9] -> fwd [Co][9][Ci], bwd [Ci][9][Co]
+      int t = (int)(j % 9);
+      int ci = (int)((j / 9) % e.K);
+      int co = (int)(j / (9L * e.K));
+      ((T*)e.fwd)[((long)co * 9 + t) * e.K + ci] = v;
+      ((T*)e.bwd)[((long)ci * 9 + t) * e.N + co] = v;
+    } else {  // depthwise [C][9] -> [9][C]
+      int c = (int)(j / 9), t = (int)(j - (long)c * 9);
+      ((T*)e.fwd)[(long)t * e.N + c] = v;
+    }
+  }
+}
+void launch_pack_all(int dt, const PackDesc* d, int nd, long total, hipStream_t s) {
+  DISPATCH_T(dt, { hipLaunchKernelGGL((pack_all_kernel<T>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, d, nd, total); });
 }
 
 // ---- global grad-norm clip + AdamW over the flat parameter buffer ----------------------------------------------

@@ -10,12 +10,15 @@
 
 template <int AM> struct RowInfo { int by, bx, img; bool ok; };
 
-template <typename T, int BM, int BN, int AM>
+template <typename T, int BM, int BN, int AM, int KP>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  // KP = 32-deep k-panels staged per barrier: latency-bound small-grid GEMMs (late 1x1 convs, decoder linears) take
+  // KP = 2/4 so that one global round trip feeds 64/128 of K
   constexpr int CH = TT<T>::CH, CPR = TT<T>::CPR;
   constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;
   constexpr int MT = BM / 64, NT = BN / 16;
-  __shared__ __attribute__((aligned(16))) T lds[2 * (BM + BN) * 32];
+  constexpr int STAGE = KP * (BM + BN) * 32;
+  __shared__ __attribute__((aligned(16))) T lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntn = (p.N + BN - 1) / BN;
@@ -46,66 +49,74 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       else { ri[i].by = oy + p.pt; ri[i].bx = ox + p.pl; }
     }
   }
-  int tap = 0, ci = cc * CH;  // k position of this thread's chunk column (conv modes)
-  if (AM != AM_DENSE) { while (ci >= p.Ci) { ci -= p.Ci; ++tap; } }
 
-  uint4 ra[NA], rb[NB];
+  uint4 ra[KP][NA], rb[KP][NB];
   auto load_tiles = [&](int kt) {
-    const int k0 = kt * 32 + cc * CH;
-    const bool kok = k0 < p.K;
-    int kh = 0, kw = 0;
-    if (AM != AM_DENSE) { kh = (p.KW == 1) ? 0 : (tap * 11) >> 5; kw = tap - kh * p.KW; }
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      uint4 v = zero16();
-      if (ri[i].ok && kok) {
-        if (AM == AM_DENSE) {
-          v = ld16(A + (long)ri[i].img * p.lda + k0);
-          if (p.ascale) {
-            float f[CH];
-            unpack<T>(v, f);
-            const float* gp = p.ascale + (long)(ri[i].img / p.ascale_hw) * p.K + k0;
+    for (int pp = 0; pp < KP; ++pp) {
+      const int k0 = (kt * KP + pp) * 32 + cc * CH;
+      const bool kok = k0 < p.K;
+      int kh = 0, kw = 0, ci = 0;
+      if (AM != AM_DENSE) {
+        int tap = k0 / p.Ci;
+        ci = k0 - tap * p.Ci;
+        kh = (p.KW == 1) ? 0 : (tap * 11) >> 5;
+        kw = tap - kh * p.KW;
+      }
 #pragma unroll
-            for (int j = 0; j < CH; ++j) f[j] *= gp[j];
-            v = pack<T>(f);
-          }
-        } else if (AM == AM_CONV) {
-          int sy = ri[i].by + kh, sx = ri[i].bx + kw;
-          if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
-            v = ld16(A + ((long)(ri[i].img + sy * p.W + sx)) * p.Ci + ci);
-        } else {
-          int ty = ri[i].by - kh, tx = ri[i].bx - kw;
-          if (ty >= 0 && tx >= 0) {
-            int sy = ty / p.stride, sx = tx / p.stride;
-            if (sy * p.stride == ty && sx * p.stride == tx && sy < p.H && sx < p.W)
+      for (int i = 0; i < NA; ++i) {
+        uint4 v = zero16();
+        if (ri[i].ok && kok) {
+          if (AM == AM_DENSE) {
+            v = ld16(A + (long)ri[i].img * p.lda + k0);
+            if (p.ascale) {
+              float f[CH];
+              unpack<T>(v, f);
+              const float* gp = p.ascale + (long)(ri[i].img / p.ascale_hw) * p.K + k0;
+#pragma unroll
+              for (int j = 0; j < CH; ++j) f[j] *= gp[j];
+              v = pack<T>(f);
+            }
+          } else if (AM == AM_CONV) {
+            int sy = ri[i].by + kh, sx = ri[i].bx + kw;
+            if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
               v = ld16(A + ((long)(ri[i].img + sy * p.W + sx)) * p.Ci + ci);
+          } else {
+            int ty = ri[i].by - kh, tx = ri[i].bx - kw;
+            if (ty >= 0 && tx >= 0) {
+              int sy = ty / p.stride, sx = tx / p.stride;
+              if (sy * p.stride == ty && sx * p.stride == tx && sy < p.H && sx < p.W)
+                v = ld16(A + ((long)(ri[i].img + sy * p.W + sx)) * p.Ci + ci);
+            }
           }
         }
+        ra[pp][i] = v;
       }
-      ra[i] = v;
-    }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      int idx = tid + i * 256;
-      int row = idx / CPR, n = n0 + row;
-      uint4 v = zero16();
-      if (idx < BN * CPR && n < p.N && kok) v = ld16(Bw + (long)n * p.K + k0);
-      rb[i] = v;
+      for (int i = 0; i < NB; ++i) {
+        int idx = tid + i * 256;
+        int row = idx / CPR, n = n0 + row;
+        uint4 v = zero16();
+        if (idx < BN * CPR && n < p.N && kok) v = ld16(Bw + (long)n * p.K + k0);
+        rb[pp][i] = v;
+      }
     }
-    if (AM != AM_DENSE) { ci += 32; while (ci >= p.Ci) { ci -= p.Ci; ++tap; } }
   };
   auto store_tiles = [&](int buf) {
-    T* la = lds + buf * (BM + BN) * 32;
-    T* lb = la + BM * 32;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      int idx = tid + i * 256;
-      if (idx < BM * CPR) st16(la + panel_chunk<T>(idx / CPR, cc), ra[i]);
-    }
+    for (int pp = 0; pp < KP; ++pp) {
+      T* la = lds + buf * STAGE + pp * (BM + BN) * 32;
+      T* lb = la + BM * 32;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      int idx = tid + i * 256;
-      if (idx < BN * CPR) st16(lb + panel_chunk<T>(idx / CPR, cc), rb[i]);
+      for (int i = 0; i < NA; ++i) {
+        int idx = tid + i * 256;
+        if (idx < BM * CPR) st16(la + panel_chunk<T>(idx / CPR, cc), ra[pp][i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        int idx = tid + i * 256;
+        if (idx < BN * CPR) st16(lb + panel_chunk<T>(idx / CPR, cc), rb[pp][i]);
+      }
     }
   };
 
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + 31) / 32;
+  const int nk = (p.K + 32 * KP - 1) / (32 * KP);
   load_tiles(0);
   store_tiles(0);
   __syncthreads();
@@ -123,16 +134,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tiles(kt + 1);
-    const T* la = lds + cur * (BM + BN) * 32;
-    const T* lb = la + BM * 32;
-    Frag<T> af[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) af[i] = load_frag<T>(la, wave * (BM / 4) + i * 16 + fr, fq);
+    for (int pp = 0; pp < KP; ++pp) {
+      const T* la = lds + cur * STAGE + pp * (BM + BN) * 32;
+      const T* lb = la + BM * 32;
+      Frag<T> af[MT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      Frag<T> bf = load_frag<T>(lb, j * 16 + fr, fq);
+      for (int i = 0; i < MT; ++i) af[i] = load_frag<T>(la, wave * (BM / 4) + i * 16 + fr, fq);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) mma(af[i], bf, acc[i][j]);
+      for (int j = 0; j < NT; ++j) {
+        Frag<T> bf = load_frag<T>(lb, j * 16 + fr, fq);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) mma(af[i], bf, acc[i][j]);
+      }
     }
     if (kt + 1 < nk) store_tiles(cur ^ 1);
     __syncthreads();
@@ -168,17 +182,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
 template <typename T, int AM>
 static void launch_gemm_t(const GemmP& p, hipStream_t s) {
-  // tile choice: narrow-N problems get tall tiles; small problems get small tiles to fill 256 CUs
+  // tile choice: narrow-N problems get tall tiles; small problems get small tiles to fill 256 CUs; deep-K dense
+  // problems stage several k-panels per barrier (64 KiB of LDS per block at most)
+  constexpr bool BF = sizeof(T) == 2;
   auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  const int nk32 = (p.K + 31) / 32;
+  const bool deep = (AM == AM_DENSE) && nk32 >= 4;
   if (p.N <= 32) {
-    hipLaunchKernelGGL((gemm_kernel<T, 256, 32, AM>), dim3(blocks(256, 32)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((gemm_kernel<T, 256, 32, AM, 1>), dim3(blocks(256, 32)), dim3(256), 0, s, p);
   } else if (p.N <= 64 || blocks(128, 128) < 256) {
-    if (blocks(128, 64) >= 512)
-      hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AM>), dim3(blocks(128, 64)), dim3(256), 0, s, p);
-    else
-      hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
+    if (blocks(128, 64) >= 512) {
+      if (deep) hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AM, (AM == AM_DENSE ? 2 : 1)>), dim3(blocks(128, 64)), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AM, 1>), dim3(blocks(128, 64)), dim3(256), 0, s, p);
+    } else {
+      if (deep && nk32 >= 8) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, (AM == AM_DENSE ? (BF ? 4 : 2) : 1)>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
+      else if (deep) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, (AM == AM_DENSE ? 2 : 1)>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, 1>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
+    }
   } else {
-    hipLaunchKernelGGL((gemm_kernel<T, 128, 128, AM>), dim3(blocks(128, 128)), dim3(256), 0, s, p);
+    if (deep && BF) hipLaunchKernelGGL((gemm_kernel<T, 128, 128, AM, (AM == AM_DENSE && BF ? 2 : 1)>), dim3(blocks(128, 128)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<T, 128, 128, AM, 1>), dim3(blocks(128, 128)), dim3(256), 0, s, p);
   }
 }
 
