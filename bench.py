@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,13 +120,10 @@ def main():
     lr = 5e-4
     graph = not args.no_graph
 
+    from satrn_amd import dp
+
     def step():
-        if world == 1:
-            model.train_step(img, exp, lr, use_graph=graph)
-        else:
-            model.train_step(img, exp, lr, use_graph=graph, phase=1)
-            dist.all_reduce(model.flat_grad())
-            model.train_step(img, exp, lr, use_graph=graph, phase=2, grad_scale=1.0 / world)
+        dp.dp_train_step(model, img, exp, lr, use_graph=graph)
 
     for i in range(max(args.warmup, 2)):
         step()
@@ -179,6 +177,22 @@ def main():
                                global_batch=world * B, seq_len=T, parallelism=f"dp{world}", hipgraph=graph),
                    roofline=roof, final_loss=round(loss, 4), grad_norm=round(gnorm, 4),
                    kernel_breakdown=[dict(kernel=p["kernel"], launches=p["launches"], ms=round(p["ms"], 3)) for p in prof[:12]])
+        if world == 1 and not args.no_decode:
+            # second half of BASELINE's metric: KV-cached greedy decode, EfficientSATRN, batch 64, 231 steps (configs[4])
+            log("greedy decode ...")
+            model.eval()
+            dimg, _ = synth(64, H, W, 4, 5, dev)
+            model.greedy(dimg, 231)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                model.greedy(dimg, 231)
+            torch.cuda.synchronize()
+            dsec = (time.perf_counter() - t1) / reps
+            out["greedy_decode"] = dict(value=round(64 * 231 / dsec, 1), unit="tokens/s", batch=64, steps=231,
+                                        ms_per_batch=round(dsec * 1e3, 2), includes="encoder + 231 decoder steps")
+            model.train()
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(2, H, W, T)

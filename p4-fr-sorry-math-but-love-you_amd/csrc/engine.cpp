@@ -302,6 +302,12 @@ Model* model_create(const SatrnConfig& cfg) {
   m->off_wpos = take((size_t)std::max(m->feat_w, 1) * D * 4);
   m->packdesc_bytes = (m->all_w.size() + 8) * sizeof(PackDesc);
   m->off_packdesc = take(m->packdesc_bytes);
+  {
+    size_t nb = 0;
+    for (Wt* w : m->all_w) nb += ((size_t)w->N * w->K + PACK_BLK - 1) / PACK_BLK + 1;
+    m->packblk_bytes = nb * 2 * sizeof(int);
+    m->off_packblk = take(m->packblk_bytes);
+  }
   m->zero_bytes = 8u << 20;
   m->off_zero = take(m->zero_bytes);
   m->persist_bytes = (o + 255) & ~(size_t)255;
@@ -400,11 +406,18 @@ int model_pack_weights(Model* m, hipStream_t s) {
       d.push_back(e);
     }
     if (d.size() * sizeof(PackDesc) > m->packdesc_bytes) { m->err = "pack descriptor table overflow"; return -1; }
+    std::vector<int> blk;  // (descriptor, chunk) pairs
+    for (size_t i = 0; i < d.size(); ++i) {
+      long n = d[i].kind == 0 ? (long)d[i].N * d[i].K : (d[i].kind == 1 ? (long)d[i].N * d[i].K * 9 : (long)d[i].N * 9);
+      for (long c = 0; c * PACK_BLK < n; ++c) { blk.push_back((int)i); blk.push_back((int)c); }
+    }
+    if (blk.size() * sizeof(int) > m->packblk_bytes) { m->err = "pack block table overflow"; return -1; }
     (void)hipMemcpyAsync(m->ws + m->off_packdesc, d.data(), d.size() * sizeof(PackDesc), hipMemcpyHostToDevice, s);
+    (void)hipMemcpyAsync(m->ws + m->off_packblk, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice, s);
     (void)hipStreamSynchronize(s);
-    m->pack_n = (int)d.size(); m->pack_total = total; m->pack_dirty = false;
+    m->pack_n = (int)(blk.size() / 2); m->pack_total = total; m->pack_dirty = false;
   }
-  launch_pack_all(dt, (const PackDesc*)(m->ws + m->off_packdesc), m->pack_n, m->pack_total, s);
+  launch_pack_all(dt, (const PackDesc*)(m->ws + m->off_packdesc), m->ws + m->off_packblk, m->pack_n, s);
   return 0;
 }
 
@@ -427,7 +440,7 @@ static void acc_grad(Exec& e, Tensor* t, const void* src) {
 
 // y[M][N] = act(gather(x) * W^T + bias) (+dropout).  geo == nullptr: dense over x rows.
 Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, const Geo* geo, int B = 0, bool out_f32 = false,
-                void* out_ptr = nullptr) {
+                void* out_ptr = nullptr, bool want_stats = false) {
   const long M = geo ? (long)B * geo->OH * geo->OW : x->rows;
   const int N = w->N;
   Tensor* y;
@@ -446,6 +459,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
   p.A = x->p; p.Bw = w->fwd; p.C = y->p; p.bias = bias ? bias->p : nullptr;
   p.M = (int)M; p.N = N; p.K = w->K; p.lda = x->C; p.ldc = N;
   p.act = act; p.out_f32 = out_f32 ? 1 : 0; p.drop_p = drop_p; p.seed = seed; p.site = site;
+  if (want_stats && e.train) { y->stats = e.zalloc(2 * N); p.stats = y->stats; }
   if (geo) { p.H = geo->H; p.W = geo->W; p.Ci = geo->Ci; p.OH = geo->OH; p.OW = geo->OW; p.KW = geo->KW; p.stride = geo->stride; p.pt = geo->pt; p.pl = geo->pl; }
   e.nflops = 2.0 * (double)M * N * w->K; e.nbytes = ((double)x->rows * x->C + (double)M * N + (double)N * w->K) * e.esz();
   LCH(e, launch_gemm(e.dt, geo ? AM_CONV : AM_DENSE, p, e.s));
@@ -493,17 +507,19 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res) {
   const long M = y->rows;
   float* ss = (float*)e.alloc((size_t)2 * C * 4);
   float* mr = (float*)e.alloc((size_t)2 * C * 4);
+  float* sums = nullptr;
   if (e.train) {
-    float* sums = e.zalloc(2 * C);
-    e.nbytes = (double)M * C * e.esz();
-    LCH(e, launch_colstats(e.dt, y->p, M, C, sums, e.s));
-    LCH(e, launch_bn_finalize(sums, M, C, bn->w.p, bn->b.p, bn->rm, bn->rv, bn->nbt, bn->eps, 0.1f, 1, ss, mr, e.s));
-  } else {
-    LCH(e, launch_bn_finalize(nullptr, M, C, bn->w.p, bn->b.p, bn->rm, bn->rv, nullptr, bn->eps, 0.1f, 0, ss, mr, e.s));
+    sums = y->stats;
+    if (!sums) {  // producer without a fused statistics epilogue (the stem conv)
+      sums = e.zalloc(2 * C);
+      e.nbytes = (double)M * C * e.esz();
+      LCH(e, launch_colstats(e.dt, y->p, M, C, sums, e.s));
+    }
   }
   Tensor* z = e.newt(M, C, y->B, y->H, y->W);
   e.nbytes = (double)M * C * e.esz() * (res ? 3 : 2);
-  LCH(e, launch_bn_act(e.dt, y->p, ss, res ? res->p : nullptr, z->p, M, C, act, e.s));
+  LCH(e, launch_bn_act(e.dt, y->p, sums, bn->w.p, bn->b.p, bn->rm, bn->rv, e.train ? bn->nbt : nullptr, bn->eps, 0.1f, ss, mr,
+                       res ? res->p : nullptr, z->p, M, C, act, e.s));
   if (e.rec) {
     e.tape.push_back([&e, y, z, bn, act, res, ss, mr, M, C]() {
       if (!z->g) return;
@@ -531,17 +547,18 @@ Tensor* op_stem(Exec& e, const float* img, Wt* w, int B, int Cin, int H, int W, 
   return y;
 }
 
-Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int OW, int pt, int pl) {
+Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int OW, int pt, int pl, bool want_stats = true) {
   const int B = x->B, H = x->H, W = x->W, C = x->C;
   Tensor* y = e.newt((long)B * OH * OW, C, B, OH, OW);
-  LCH(e, launch_dwconv(e.dt, 0, x->p, w->fwd, bias ? bias->p : nullptr, y->p, B, H, W, C, OH, OW, stride, pt, pl, 0, e.s));
+  if (want_stats && e.train) y->stats = e.zalloc(2 * C);
+  LCH(e, launch_dwconv(e.dt, 0, x->p, w->fwd, bias ? bias->p : nullptr, y->p, B, H, W, C, OH, OW, stride, pt, pl, 0, y->stats, e.s));
   if (e.rec)
     e.tape.push_back([&e, x, y, w, bias, B, H, W, C, OH, OW, stride, pt, pl]() {
       if (!y->g) return;
       LCH(e, launch_dwconv_wgrad(e.dt, x->p, y->g, w->g, bias ? bias->g : nullptr, B, H, W, C, OH, OW, stride, pt, pl, e.s));
       int beta;
       void* dx = e.grad(x, &beta);
-      LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, e.s));
+      LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, nullptr, e.s));
     });
   return y;
 }
@@ -744,12 +761,12 @@ Tensor* encoder_layer(Exec& e, Tensor* x, EncLayer* el) {
   Tensor* y2 = op_ln(e, o, x, &el->norm);
   y2->B = B; y2->H = H; y2->W = W;
   Tensor* z = op_quirk(e, y2);
-  Tensor* c0 = op_gemm(e, z, &el->conv0, nullptr, ACT_NONE, 0.f, nullptr);
+  Tensor* c0 = op_gemm(e, z, &el->conv0, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   c0->B = B; c0->H = H; c0->W = W;
   Tensor* b0 = op_bn_act(e, c0, &el->norm0, ACT_RELU, nullptr);
   Tensor* d = op_dwconv(e, b0, &el->dw, &el->dwb, 1, H, W, 1, 1);
   Tensor* b1 = op_bn_act(e, d, &el->dwnorm, ACT_RELU, nullptr);
-  Tensor* c1 = op_gemm(e, b1, &el->conv1, nullptr, ACT_NONE, 0.f, nullptr);
+  Tensor* c1 = op_gemm(e, b1, &el->conv1, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   c1->B = B; c1->H = H; c1->W = W;
   return op_bn_act(e, c1, &el->norm1, ACT_RELU, x);
 }
@@ -760,17 +777,17 @@ Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
   same_geo(H, W, eb->cin, eb->stride, &g);
   Tensor* skip = eb->skip ? x : nullptr;
   if (eb->type == 0) {
-    Tensor* y = op_gemm(e, x, &eb->c0, nullptr, ACT_NONE, 0.f, &g, B);
+    Tensor* y = op_gemm(e, x, &eb->c0, nullptr, ACT_NONE, 0.f, &g, B, false, nullptr, true);
     return op_bn_act(e, y, &eb->bn1, ACT_SILU, skip);
   }
   if (eb->type == 1) {
-    Tensor* y = op_gemm(e, x, &eb->c0, nullptr, ACT_NONE, 0.f, &g, B);
+    Tensor* y = op_gemm(e, x, &eb->c0, nullptr, ACT_NONE, 0.f, &g, B, false, nullptr, true);
     Tensor* z = op_bn_act(e, y, &eb->bn1, ACT_SILU, nullptr);
-    Tensor* y2 = op_gemm(e, z, &eb->c1, nullptr, ACT_NONE, 0.f, nullptr);
+    Tensor* y2 = op_gemm(e, z, &eb->c1, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
     y2->B = B; y2->H = g.OH; y2->W = g.OW;
     return op_bn_act(e, y2, &eb->bn2, ACT_NONE, skip);
   }
-  Tensor* y = op_gemm(e, x, &eb->c0, nullptr, ACT_NONE, 0.f, nullptr);
+  Tensor* y = op_gemm(e, x, &eb->c0, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   y->B = B; y->H = H; y->W = W;
   Tensor* z = op_bn_act(e, y, &eb->bn1, ACT_SILU, nullptr);
   Tensor* y2 = op_dwconv(e, z, &eb->dw, nullptr, eb->stride, g.OH, g.OW, g.pt, g.pl);
@@ -780,7 +797,7 @@ Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
   Tensor* s1 = op_act(e, u1, ACT_SILU);
   Tensor* gate = op_gemm(e, s1, &eb->se_e, &eb->se_eb, ACT_SIGMOID, 0.f, nullptr);
   Tensor* z3 = op_se_scale(e, z2, gate);
-  Tensor* y3 = op_gemm(e, z3, &eb->c1, nullptr, ACT_NONE, 0.f, nullptr);
+  Tensor* y3 = op_gemm(e, z3, &eb->c1, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   y3->B = B; y3->H = g.OH; y3->W = g.OW;
   return op_bn_act(e, y3, &eb->bn3, ACT_NONE, skip);
 }
@@ -796,7 +813,7 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
     for (int i = 1; i < 4; ++i) {
       Geo g;
       same_geo(x->H, x->W, x->C, 1, &g);
-      x = op_gemm(e, x, &m->lite_conv[i], nullptr, ACT_NONE, 0.f, &g, B);
+      x = op_gemm(e, x, &m->lite_conv[i], nullptr, ACT_NONE, 0.f, &g, B, false, nullptr, true);
       x = op_bn_act(e, x, &m->lite_bn[i], ACT_RELU, nullptr);
       x = op_maxpool(e, x);
     }
@@ -805,7 +822,7 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
     x = op_bn_act(e, x, &m->stem_bn, ACT_SILU, nullptr);
     for (auto& eb : m->blocks) x = eff_block(e, x, &eb);
     int H = x->H, W = x->W;
-    x = op_gemm(e, x, &m->conv_last, nullptr, ACT_NONE, 0.f, nullptr);
+    x = op_gemm(e, x, &m->conv_last, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
     x->B = B; x->H = H; x->W = W;
     x = op_bn_act(e, x, &m->bn_last, ACT_SILU, nullptr);
   }

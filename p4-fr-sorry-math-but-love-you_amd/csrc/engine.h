@@ -61,6 +61,7 @@ struct Tensor {
   int B = 0, H = 0, W = 0;
   bool g_init = false;
   bool f32 = false;  // logits
+  float* stats = nullptr;  // [2C] column sum / sum of squares written by the producing kernel (BatchNorm input)
 };
 
 struct EffBlock { int type, cin, cout, mid, stride, se; bool skip; Wt c0, c1, dw, se_r, se_e; Vec se_rb, se_eb; BNp bn1, bn2, bn3; };
@@ -90,7 +91,7 @@ struct Model {
   size_t off_packed = 0, off_adam_m = 0, off_adam_v = 0, off_scalars = 0, off_pe1d = 0, off_hpos = 0, off_wpos = 0,
          off_stage_img = 0, off_stage_tgt = 0, off_zero = 0;
   size_t zero_bytes = 0;
-  size_t off_packdesc = 0, packdesc_bytes = 0; int pack_n = 0; long pack_total = 0; bool pack_dirty = true;
+  size_t off_packdesc = 0, packdesc_bytes = 0, off_packblk = 0, packblk_bytes = 0; int pack_n = 0; long pack_total = 0; bool pack_dirty = true;
   int stage_B = 0, stage_L = 0;
   int feat_h = 0, feat_w = 0;
   bool bound = false, ws_set = false, tables_ready = false;

@@ -16,6 +16,7 @@ struct GemmP {
   int act, beta, out_f32;
   float drop_p; const uint32_t* seed; uint32_t site;
   const float* ascale; int ascale_hw;  // optional A[m][k] *= ascale[(m/ascale_hw)*K + k]  (SE gate), dense only
+  float* stats;  // optional [2N] (zeroed): per-column sum / sum of squares of the output (for the BatchNorm that follows)
 };
 void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s);
 
@@ -53,8 +54,11 @@ void launch_colstats(int dt, const void* y, long M, int C, float* sums /*[2C], z
 void launch_bn_finalize(const float* sums, long M, int C, const float* w, const float* b, float* rm, float* rv,
                         int64_t* nbt, float eps, float mom, int train, float* scale_shift /*[2C]*/,
                         float* mean_rstd /*[2C]*/, hipStream_t s);
-void launch_bn_act(int dt, const void* y, const float* scale_shift, const void* res, void* z, long M, int C, int act,
-                   hipStream_t s);
+// finalize folded in: sums != null -> batch statistics (running stats updated, momentum mom), else running statistics;
+// writes scale/shift and mean/rstd for the backward
+void launch_bn_act(int dt, const void* y, const float* sums, const float* w, const float* b, float* rm, float* rv,
+                   int64_t* nbt, float eps, float mom, float* scale_shift, float* mean_rstd, const void* res, void* z,
+                   long M, int C, int act, hipStream_t s);
 void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* scale_shift, const float* mean_rstd,
                           long M, int C, int act, float* red /*[2C] zeroed*/, hipStream_t s);
 void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* scale_shift, const float* mean_rstd,
@@ -66,7 +70,7 @@ void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int 
                        int OH, int OW, int stride, int pad, hipStream_t s);
 void launch_dwconv(int dt, int mode /*0 fwd,1 dgrad*/, const void* x, const void* wp /*[9][C] as T*/, const float* bias,
                    void* y, int B, int H, int W, int C, int OH, int OW, int stride, int pt, int pl, int beta,
-                   hipStream_t s);
+                   float* stats /*optional [2C] zeroed: column sums of y (mode 0)*/, hipStream_t s);
 void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw /*[C][9] torch layout*/, float* dbias, int B,
                          int H, int W, int C, int OH, int OW, int stride, int pt, int pl, hipStream_t s);
 void launch_maxpool(int dt, int bwd, const void* x, const void* dy_or_null, void* out, int B, int H, int W, int C,
@@ -118,7 +122,8 @@ void launch_pack_conv(int dt, const float* w /*[Co][Ci][T]*/, void* fwd /*[Co][T
 void launch_pack_dw(int dt, const float* w /*[C][9]*/, void* out /*[9][C]*/, int C, hipStream_t s);
 // kind 0 dense (N,K,ldb), 1 conv3x3 (N=Co, K=Ci), 2 depthwise (N=C)
 struct PackDesc { const float* src; void* fwd; void* bwd; long start; int kind, N, K, ldb; };
-void launch_pack_all(int dt, const PackDesc* d, int nd, long total, hipStream_t s);
+#define PACK_BLK 4096
+void launch_pack_all(int dt, const PackDesc* d, const void* blk_table /*int2 (desc, chunk) per block*/, int nblk, hipStream_t s);
 void launch_sumsq(const float* g, long n, float* out /*[1] +=*/, hipStream_t s);
 void launch_adamw(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, const float* hyper,
                   hipStream_t s);

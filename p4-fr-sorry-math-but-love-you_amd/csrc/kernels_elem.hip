@@ -33,14 +33,12 @@ template <typename T, int NO, typename F>
 __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int rows_per_block, int tx_log2,
                                                         float* o0, float* o1, int nmain) {
   constexpr int CH = TT<T>::CH;
-  extern __shared__ float red[];  // [NO][TXC*CH]
+  __shared__ float red[256 * CH];  // [TY][TX*CH]
   const int TX = 1 << tx_log2, TY = 256 >> tx_log2;
   const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> tx_log2;
   const int CC = C / CH;
   const int cbase = blockIdx.y * TX;
   const int c = cbase + tx;
-  for (int i = threadIdx.x; i < NO * TX * CH; i += 256) red[i] = 0.f;
-  __syncthreads();
   float acc[NO][CH];
 #pragma unroll
   for (int k = 0; k < NO; ++k)
@@ -51,21 +49,25 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int 
   if (r1 > M) r1 = M;
   if (c < CC) {
     f.prep(c * CH);
+#pragma unroll 4
     for (long r = r0 + ty; r < r1; r += TY) f(r, c * CH, acc);
-#pragma unroll
-    for (int k = 0; k < NO; ++k)
-#pragma unroll
-      for (int j = 0; j < CH; ++j) atomicAdd(&red[(k * TX + tx) * CH + j], acc[k][j]);
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < NO * TX * CH; i += 256) {
-    int k = i / (TX * CH), cj = i % (TX * CH);
-    int col = cbase * CH + cj;
-    if (col < C) {
-      // sums k < nmain go to o0[col*nmain + k]; the remaining one goes to o1[col]
-      if (k < nmain) atomicAdd(o0 + (long)col * nmain + k, red[i]);
-      else if (o1) atomicAdd(o1 + col, red[i]);
+#pragma unroll
+  for (int k = 0; k < NO; ++k) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) red[(ty * TX + tx) * CH + j] = acc[k][j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < TX * CH; i += 256) {
+      float sum = 0.f;
+      for (int y = 0; y < TY; ++y) sum += red[y * TX * CH + i];
+      int col = cbase * CH + i;
+      if (col < C) {
+        // sums k < nmain go to o0[col*nmain + k]; the remaining one goes to o1[col]
+        if (k < nmain) atomicAdd(o0 + (long)col * nmain + k, sum);
+        else if (o1) atomicAdd(o1 + col, sum);
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -85,8 +87,7 @@ static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain
   long gx = (M + rpb - 1) / rpb;
   long cap = 1024 / gy < 1 ? 1 : 1024 / gy;
   if (gx > cap) { gx = cap; rpb = (M + gx - 1) / gx; rpb = ((rpb + TY - 1) / TY) * TY; gx = (M + rpb - 1) / rpb; }
-  size_t sh = (size_t)NO * TX * CH * sizeof(float);
-  hipLaunchKernelGGL((colreduce_kernel<T, NO, F>), dim3((int)gx, gy), dim3(256), sh, s, f, M, C, (int)rpb, txl, o0, o1,
+  hipLaunchKernelGGL((colreduce_kernel<T, NO, F>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1,
                      nmain);
 }
 
@@ -146,16 +147,41 @@ static inline int grid_chan(long nchunks, int CC) {
 }
 
 template <typename T>
-__global__ void bn_act_kernel(const T* y, const float* ss, const T* res, T* z, long nchunks, int C, int act) {
+__global__ void bn_act_kernel(const T* y, const float* sums, const float* w, const float* b, float* rm, float* rv,
+                              int64_t* nbt, float eps, float mom, float invM, float unbias, float* ss, float* mr,
+                              const T* res, T* z, long nchunks, int C, int act) {
   constexpr int CH = TT<T>::CH;
   const int CC = C / CH;
   const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
   const int c0 = (int)(tid % CC) * CH;
+  // BatchNorm finalize, redone by every thread for its own channel chunk (a handful of loads); the first CC threads
+  // also publish scale/shift + mean/rstd for the backward and update the running statistics
   float sc[CH], sh[CH];
-  for (int j = 0; j < CH; j += 4) {
-    float4 a = *reinterpret_cast<const float4*>(ss + c0 + j), b = *reinterpret_cast<const float4*>(ss + C + c0 + j);
-    sc[j] = a.x; sc[j + 1] = a.y; sc[j + 2] = a.z; sc[j + 3] = a.w;
-    sh[j] = b.x; sh[j + 1] = b.y; sh[j + 2] = b.z; sh[j + 3] = b.w;
+  {
+    float mean[CH], var[CH], ww[CH], bb[CH];
+    if (sums) {
+      ldv(sums + c0, mean, CH); ldv(sums + C + c0, var, CH);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { mean[j] *= invM; var[j] = fmaxf(var[j] * invM - mean[j] * mean[j], 0.f); }
+    } else {
+      ldv(rm + c0, mean, CH); ldv(rv + c0, var, CH);
+    }
+    ldv(w + c0, ww, CH); ldv(b + c0, bb, CH);
+    const bool pub = tid < CC;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      float rstd = rsqrtf(var[j] + eps);
+      sc[j] = ww[j] * rstd;
+      sh[j] = bb[j] - mean[j] * sc[j];
+      if (pub) {
+        ss[c0 + j] = sc[j]; ss[C + c0 + j] = sh[j]; mr[c0 + j] = mean[j]; mr[C + c0 + j] = rstd;
+        if (sums) {
+          rm[c0 + j] = (1.f - mom) * rm[c0 + j] + mom * mean[j];
+          rv[c0 + j] = (1.f - mom) * rv[c0 + j] + mom * var[j] * unbias;
+        }
+      }
+    }
+    if (tid == 0 && sums && nbt) *nbt += 1;
   }
   for (long i = tid; i < nchunks; i += nth) {
     float v[CH], r[CH];
@@ -169,12 +195,17 @@ __global__ void bn_act_kernel(const T* y, const float* ss, const T* res, T* z, l
     st16(z + i * CH, pack<T>(v));
   }
 }
-void launch_bn_act(int dt, const void* y, const float* ss, const void* res, void* z, long M, int C, int act,
-                   hipStream_t s) {
+void launch_bn_act(int dt, const void* y, const float* sums, const float* w, const float* b, float* rm, float* rv,
+                   int64_t* nbt, float eps, float mom, float* ss, float* mr, const void* res, void* z, long M, int C,
+                   int act, hipStream_t s) {
+  float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
   DISPATCH_T(dt, {
     long n = M * C / TT<T>::CH;
-    hipLaunchKernelGGL((bn_act_kernel<T>), dim3(grid_chan(n, C / TT<T>::CH)), dim3(256), 0, s, (const T*)y, ss, (const T*)res,
-                       (T*)z, n, C, act);
+    int CC = C / TT<T>::CH;
+    int g = grid_chan(n, CC);
+    while ((long)g * 256 < CC) g *= 2;
+    hipLaunchKernelGGL((bn_act_kernel<T>), dim3(g), dim3(256), 0, s, (const T*)y, sums, w, b, rm, rv, nbt, eps, mom,
+                       1.0f / (float)M, unbias, ss, mr, (const T*)res, (T*)z, n, C, act);
   });
 }
 
@@ -362,22 +393,34 @@ void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int 
 
 // ---- depthwise 3x3 (forward gather / transposed gather for the data gradient) -----------------------
 template <typename T, int MODE>
-__global__ void dwconv_kernel(const T* x, const T* wp, const float* bias, T* y, int B, int H, int W, int C, int OH,
-                              int OW, int stride, int pt, int pl, int beta) {
+__global__ __launch_bounds__(256) void dwconv_kernel(const T* x, const T* wp, const float* bias, T* y, int B, int H, int W,
+                                                     int C, int OH, int OW, int stride, int pt, int pl, int beta, float* stats) {
   // MODE 0: x = input [B,H,W,C], y = output [B,OH,OW,C].  MODE 1: x = dY [B,H,W,C] (H,W = conv OUTPUT dims),
-  // y = dX [B,OH,OW,C] (OH,OW = conv INPUT dims).
+  // y = dX [B,OH,OW,C] (OH,OW = conv INPUT dims).  Total threads is a multiple of the chunk count, so each thread keeps
+  // its channel chunk's nine tap weights (and, for the forward, the BatchNorm column sums) in registers.
   constexpr int CH = TT<T>::CH;
+  extern __shared__ float sred[];  // [2][C] when stats
   const int CC = C / CH;
-  long total = (long)B * OH * OW * CC;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int cc = (int)(i % CC);
+  const long total = (long)B * OH * OW * CC;
+  const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+  const int cc = (int)(tid % CC);
+  float wv[9][CH], bv[CH], s1[CH], s2[CH];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) unpack<T>(ld16(wp + t * C + cc * CH), wv[t]);
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { bv[j] = (bias && MODE == 0) ? bias[cc * CH + j] : 0.f; s1[j] = s2[j] = 0.f; }
+  if (stats) {
+    for (int i = threadIdx.x; i < 2 * C; i += 256) sred[i] = 0.f;
+    __syncthreads();
+  }
+  for (long i = tid; i < total; i += nth) {
     long pix = i / CC;
     int ox = (int)(pix % OW);
     int oy = (int)((pix / OW) % OH);
     int b = (int)(pix / ((long)OW * OH));
     float acc[CH];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) acc[j] = (bias && MODE == 0) ? bias[cc * CH + j] : 0.f;
+    for (int j = 0; j < CH; ++j) acc[j] = bv[j];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
@@ -393,11 +436,10 @@ __global__ void dwconv_kernel(const T* x, const T* wp, const float* bias, T* y, 
           ok = ty >= 0 && tx >= 0 && sy * stride == ty && sx * stride == tx && sy < H && sx < W;
         }
         if (ok) {
-          float v[CH], wv[CH];
+          float v[CH];
           unpack<T>(ld16(x + (((long)b * H + sy) * W + sx) * C + cc * CH), v);
-          unpack<T>(ld16(wp + (kh * 3 + kw) * C + cc * CH), wv);
 #pragma unroll
-          for (int j = 0; j < CH; ++j) acc[j] += v[j] * wv[j];
+          for (int j = 0; j < CH; ++j) acc[j] += v[j] * wv[kh * 3 + kw][j];
         }
       }
     }
@@ -408,19 +450,34 @@ __global__ void dwconv_kernel(const T* x, const T* wp, const float* bias, T* y, 
 #pragma unroll
       for (int j = 0; j < CH; ++j) acc[j] += old[j];
     }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { s1[j] += acc[j]; s2[j] += acc[j] * acc[j]; }
     st16(o, pack<T>(acc));
+  }
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { atomicAdd(&sred[cc * CH + j], s1[j]); atomicAdd(&sred[C + cc * CH + j], s2[j]); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(stats + i, sred[i]);
   }
 }
 void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float* bias, void* y, int B, int H, int W,
-                   int C, int OH, int OW, int stride, int pt, int pl, int beta, hipStream_t s) {
+                   int C, int OH, int OW, int stride, int pt, int pl, int beta, float* stats, hipStream_t s) {
   DISPATCH_T(dt, {
-    long n = (long)B * OH * OW * (C / TT<T>::CH);
+    int CC = C / TT<T>::CH;
+    long n = (long)B * OH * OW * CC;
+    int a = CC, b2 = 256;
+    while (b2) { int t = a % b2; a = b2; b2 = t; }
+    int q = CC / a;
+    int g = grid_for(n, 256, stats ? 768 : 4096);
+    g = ((g + q - 1) / q) * q;
+    size_t sh = stats ? (size_t)2 * C * sizeof(float) : 0;
     if (mode == 0)
-      hipLaunchKernelGGL((dwconv_kernel<T, 0>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)wp, bias,
-                         (T*)y, B, H, W, C, OH, OW, stride, pt, pl, beta);
+      hipLaunchKernelGGL((dwconv_kernel<T, 0>), dim3(g), dim3(256), sh, s, (const T*)x, (const T*)wp, bias, (T*)y, B, H, W,
+                         C, OH, OW, stride, pt, pl, beta, stats);
     else
-      hipLaunchKernelGGL((dwconv_kernel<T, 1>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)wp, bias,
-                         (T*)y, B, H, W, C, OH, OW, stride, pt, pl, beta);
+      hipLaunchKernelGGL((dwconv_kernel<T, 1>), dim3(g), dim3(256), 0, s, (const T*)x, (const T*)wp, bias, (T*)y, B, H, W,
+                         C, OH, OW, stride, pt, pl, beta, (float*)nullptr);
   });
 }
 
@@ -520,6 +577,7 @@ __global__ __launch_bounds__(256) void hw_reduce_kernel(const T* a, const T* bb,
 #pragma unroll
   for (int j = 0; j < CH; ++j) s0[j] = s1[j] = 0.f;
   if (c < CC) {
+#pragma unroll 4
     for (int p = rg; p < HW; p += 4) {
       float v[CH];
       unpack<T>(ld16(a + ((long)b * HW + p) * C + c * CH), v);
@@ -1170,36 +1228,35 @@ void launch_pack_dw(int dt, const float* w, void* out, int C, hipStream_t s) {
   DISPATCH_T(dt, { hipLaunchKernelGGL((pack_dw_kernel<T>), dim3((C * 9 + 255) / 256), dim3(256), 0, s, w, (T*)out, C); });
 }
 
-// one launch for every weight: descriptor table + binary search on the element prefix
+// one launch for every weight: blockIdx -> (descriptor, first element) through a host-built table, PACK_BLK elements per block
 template <typename T>
-__global__ void pack_all_kernel(const PackDesc* d, int nd, long total) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int lo = 0, hi = nd - 1;
-    while (lo < hi) {
-      int mid = (lo + hi + 1) >> 1;
-      if (d[mid].start <= i) lo = mid; else hi = mid - 1;
-    }
-    const PackDesc e = d[lo];
-    const long j = i - e.start;
+__global__ void pack_all_kernel(const PackDesc* d, const int2* blk) {
+  const int2 bi = blk[blockIdx.x];
+  const PackDesc e = d[bi.x];
+  const long n = e.kind == 0 ? (long)e.N * e.K : (e.kind == 1 ? (long)e.N * e.K * 9 : (long)e.N * 9);
+  const long j0 = (long)bi.y * PACK_BLK;
+  for (int t = threadIdx.x; t < PACK_BLK; t += 256) {
+    const long j = j0 + t;
+    if (j >= n) break;
     const T v = from_f<T>(e.src[j]);
     if (e.kind == 0) {  // dense [N][K] -> fwd [N][K], bwd [K][ldb]
       int r = (int)(j / e.K), k = (int)(j - (long)r * e.K);
       ((T*)e.fwd)[j] = v;
       ((T*)e.bwd)[(long)k * e.ldb + r] = v;
     } else if (e.kind == 1) {  // conv3x3 [Co][Ci][9] -> fwd [Co][9][Ci], bwd [Ci][9][Co]
-      int t = (int)(j % 9);
+      int t9 = (int)(j % 9);
       int ci = (int)((j / 9) % e.K);
       int co = (int)(j / (9L * e.K));
-      ((T*)e.fwd)[((long)co * 9 + t) * e.K + ci] = v;
-      ((T*)e.bwd)[((long)ci * 9 + t) * e.N + co] = v;
+      ((T*)e.fwd)[((long)co * 9 + t9) * e.K + ci] = v;
+      ((T*)e.bwd)[((long)ci * 9 + t9) * e.N + co] = v;
     } else {  // depthwise [C][9] -> [9][C]
-      int c = (int)(j / 9), t = (int)(j - (long)c * 9);
-      ((T*)e.fwd)[(long)t * e.N + c] = v;
+      int c = (int)(j / 9), t9 = (int)(j - (long)c * 9);
+      ((T*)e.fwd)[(long)t9 * e.N + c] = v;
     }
   }
 }
-void launch_pack_all(int dt, const PackDesc* d, int nd, long total, hipStream_t s) {
-  DISPATCH_T(dt, { hipLaunchKernelGGL((pack_all_kernel<T>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, d, nd, total); });
+void launch_pack_all(int dt, const PackDesc* d, const void* blk, int nblk, hipStream_t s) {
+  DISPATCH_T(dt, { hipLaunchKernelGGL((pack_all_kernel<T>), dim3(nblk), dim3(256), 0, s, d, (const int2*)blk); });
 }
 
 // ---- global grad-norm clip + AdamW over the flat parameter buffer ----------------------------------------------

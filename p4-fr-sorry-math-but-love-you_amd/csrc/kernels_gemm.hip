@@ -154,19 +154,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
   // ---- epilogue: C layout col = lane&15, row = (lane>>4)*4 + reg
   const uint32_t seed = (p.drop_p > 0.f) ? *p.seed : 0u;
+  float* sred = reinterpret_cast<float*>(lds);  // [2][BN] column sums for the BatchNorm that follows (LDS is free now)
+  if (p.stats) {
+    for (int i = tid; i < 2 * BN; i += 256) sred[i] = 0.f;
+    __syncthreads();
+  }
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + j * 16 + fr;
+    const float bias = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + j * 16 + fr;
-      if (col >= p.N) continue;
-      const float bias = p.bias ? p.bias[col] : 0.f;
+    for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wave * (BM / 4) + i * 16 + fq * 4 + r;
-        if (row >= p.M) continue;
+        if (row >= p.M || col >= p.N) continue;
         float v = act_fwd(acc[i][j][r] + bias, p.act);
         if (p.drop_p > 0.f) v *= drop_scale(seed, p.site, (uint32_t)(row * p.N + col), p.drop_p);
+        s1 += v; s2 += v * v;
         const long o = (long)row * p.ldc + col;
         if (p.out_f32) {
           float* c = (float*)p.C;
@@ -176,6 +182,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
           c[o] = from_f<T>(p.beta ? to_f(c[o]) + v : v);
         }
       }
+    }
+    if (p.stats) {
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (fq == 0) { atomicAdd(&sred[j * 16 + fr], s1); atomicAdd(&sred[BN + j * 16 + fr], s2); }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += 256) {
+      int c = i < BN ? i : i - BN, col = n0 + c;
+      if (col < p.N) atomicAdd(p.stats + (i < BN ? 0 : p.N) + col, sred[i]);
     }
   }
 }

@@ -135,14 +135,14 @@ int satrn_dwconv3x3_fwd(int dt, const void* x, const void* wp, const float* bias
                         int OH, int OW, int stride, int pt, int pl, void* st) {
   CHK_DT(dt);
   if (chk_c(dt, C, "C")) return -1;
-  launch_dwconv(dt, 0, x, wp, bias, y, B, H, W, C, OH, OW, stride, pt, pl, 0, S(st));
+  launch_dwconv(dt, 0, x, wp, bias, y, B, H, W, C, OH, OW, stride, pt, pl, 0, nullptr, S(st));
   return done("dwconv3x3_fwd");
 }
 int satrn_dwconv3x3_bwd_data(int dt, const void* dy, const void* wp, void* dx, int B, int H, int W, int C, int OH, int OW,
                              int stride, int pt, int pl, int accumulate, void* st) {
   CHK_DT(dt);
   if (chk_c(dt, C, "C")) return -1;
-  launch_dwconv(dt, 1, dy, wp, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, accumulate, S(st));
+  launch_dwconv(dt, 1, dy, wp, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, accumulate, nullptr, S(st));
   return done("dwconv3x3_bwd_data");
 }
 int satrn_dwconv3x3_bwd_weight(int dt, const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int C,
@@ -159,8 +159,8 @@ int satrn_batchnorm_act_fwd(int dt, const void* y, const float* w, const float* 
   CHK_DT(dt);
   if (chk_c(dt, C, "C")) return -1;
   if (train) launch_colstats(dt, y, M, C, scratch, S(st));
-  launch_bn_finalize(scratch, M, C, w, b, rm, rv, nbt, eps, 0.1f, train, scratch + 2 * C, scratch + 4 * C, S(st));
-  launch_bn_act(dt, y, scratch + 2 * C, res, z, M, C, act, S(st));
+  launch_bn_act(dt, y, train ? scratch : nullptr, w, b, rm, rv, train ? nbt : nullptr, eps, 0.1f, scratch + 2 * C, scratch + 4 * C,
+                res, z, M, C, act, S(st));
   return done("batchnorm_act_fwd");
 }
 int satrn_batchnorm_act_bwd(int dt, const void* dz, const void* y, const float* w, const float* scratch, int act,

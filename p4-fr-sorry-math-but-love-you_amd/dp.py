@@ -1,0 +1,57 @@
+"""Data-parallel helpers (new: the reference has no multi-GPU path).  One process per GPU; the model is a full
+replica; gradients live in ONE flat fp32 buffer, so the exchange step is a single (optionally bucketed) all-reduce.
+Backend "nccl" is RCCL on ROCm; the same code runs over "gloo" on CPU tensors (used by the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def bucket_bounds(numel, bucket_elems):
+    """[(start, end)) slices of a flat buffer, every bucket a multiple of 4 elements except the last."""
+    bucket_elems = max(4, (int(bucket_elems) // 4) * 4)
+    out, s = [], 0
+    while s < numel:
+        e = min(numel, s + bucket_elems)
+        out.append((s, e))
+        s = e
+    return out
+
+
+def allreduce_flat(flat, bucket_elems=None, average=False, group=None):
+    """Sum (or mean) `flat` over the ranks in place.  bucket_elems=None -> one collective (xGMI all-reduce of the whole
+    108.9 MB EfficientSATRN gradient is ~1 ms); otherwise one async collective per bucket, waited at the end."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat
+    if bucket_elems is None:
+        dist.all_reduce(flat, group=group)
+    else:
+        works = [dist.all_reduce(flat[s:e], group=group, async_op=True) for s, e in bucket_bounds(flat.numel(), bucket_elems)]
+        for w in works:
+            w.wait()
+    if average:
+        flat.mul_(1.0 / world)
+    return flat
+
+
+def broadcast_flat(flat, src=0, group=None):
+    if dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src, group=group)
+    return flat
+
+
+def shard_batch(n_items, rank, world):
+    """contiguous shard [start, end) of a global batch for this rank (independent samples: no data-path collective)"""
+    per = (n_items + world - 1) // world
+    s = min(n_items, rank * per)
+    return s, min(n_items, s + per)
+
+
+def dp_train_step(model, images, expected, lr, **kw):
+    """forward/backward graph -> flat-gradient all-reduce -> clip + AdamW graph (grad_scale = 1/world)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        model.train_step(images, expected, lr, **kw)
+        return
+    model.train_step(images, expected, lr, phase=1, **kw)
+    allreduce_flat(model.flat_grad())
+    model.train_step(images, expected, lr, phase=2, grad_scale=1.0 / world, **kw)
