@@ -304,11 +304,11 @@ Model* model_create(const SatrnConfig& cfg) {
   m->off_packdesc = take(m->packdesc_bytes);
   {
     size_t nb = 0;
-    for (Wt* w : m->all_w) nb += ((size_t)w->N * w->K + PACK_BLK - 1) / PACK_BLK + 1;
+    for (Wt* w : m->all_w) nb += std::max(((size_t)w->N * w->K + PACK_BLK - 1) / PACK_BLK + 1, (size_t)((w->N + 63) / 64) * ((w->K + 63) / 64));
     m->packblk_bytes = nb * 2 * sizeof(int);
     m->off_packblk = take(m->packblk_bytes);
   }
-  m->zero_bytes = 8u << 20;
+  m->zero_bytes = 40u << 20;
   m->off_zero = take(m->zero_bytes);
   m->persist_bytes = (o + 255) & ~(size_t)255;
   m->ex = new Exec();
@@ -408,8 +408,13 @@ int model_pack_weights(Model* m, hipStream_t s) {
     if (d.size() * sizeof(PackDesc) > m->packdesc_bytes) { m->err = "pack descriptor table overflow"; return -1; }
     std::vector<int> blk;  // (descriptor, chunk) pairs
     for (size_t i = 0; i < d.size(); ++i) {
-      long n = d[i].kind == 0 ? (long)d[i].N * d[i].K : (d[i].kind == 1 ? (long)d[i].N * d[i].K * 9 : (long)d[i].N * 9);
-      for (long c = 0; c * PACK_BLK < n; ++c) { blk.push_back((int)i); blk.push_back((int)c); }
+      if (d[i].kind == 0) {  // 64x64 tiles
+        long nt = (long)((d[i].N + 63) / 64) * ((d[i].K + 63) / 64);
+        for (long c = 0; c < nt; ++c) { blk.push_back((int)i); blk.push_back((int)c); }
+      } else {
+        long n = d[i].kind == 1 ? (long)d[i].N * d[i].K * 9 : (long)d[i].N * 9;
+        for (long c = 0; c * PACK_BLK < n; ++c) { blk.push_back((int)i); blk.push_back((int)c); }
+      }
     }
     if (blk.size() * sizeof(int) > m->packblk_bytes) { m->err = "pack block table overflow"; return -1; }
     (void)hipMemcpyAsync(m->ws + m->off_packdesc, d.data(), d.size() * sizeof(PackDesc), hipMemcpyHostToDevice, s);
@@ -479,9 +484,16 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       memset(&q, 0, sizeof(q));
       q.dY = dY; q.A = x->p; q.dW = w->g; q.M = (int)M; q.N = N; q.K = w->K; q.ldy = ldy; q.lda = x->C;
       q.nbatch = 1; q.nb_inner = 1;
-      if (hasgeo) { q.conv = 1; q.H = g.H; q.W = g.W; q.Ci = g.Ci; q.OH = g.OH; q.OW = g.OW; q.KW = g.KW; q.stride = g.stride; q.pt = g.pt; q.pl = g.pl; }
+      float* tmp = nullptr;
+      if (hasgeo) {
+        q.conv = 1; q.H = g.H; q.W = g.W; q.Ci = g.Ci; q.OH = g.OH; q.OW = g.OW; q.KW = g.KW; q.stride = g.stride; q.pt = g.pt; q.pl = g.pl;
+        // contiguous fp32 atomics into a zeroed [N][9][Ci] scratch, then one small pass into the torch layout
+        tmp = e.zalloc((size_t)N * w->K);
+        q.conv_packed_out = 1; q.dW = tmp;
+      }
       e.nflops = 2.0 * (double)M * N * w->K;
       LCH(e, launch_wgrad(e.dt, q, e.s));
+      if (tmp) LCH(e, launch_conv_grad_unpack(tmp, w->g, N, g.Ci, 9, e.s));
       int beta;
       void* dx = e.grad(x, &beta);
       GemmP d;
@@ -555,7 +567,8 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
   if (e.rec)
     e.tape.push_back([&e, x, y, w, bias, B, H, W, C, OH, OW, stride, pt, pl]() {
       if (!y->g) return;
-      LCH(e, launch_dwconv_wgrad(e.dt, x->p, y->g, w->g, bias ? bias->g : nullptr, B, H, W, C, OH, OW, stride, pt, pl, e.s));
+      float* scr = e.zalloc((size_t)10 * C);
+      LCH(e, launch_dwconv_wgrad(e.dt, x->p, y->g, w->g, bias ? bias->g : nullptr, scr, B, H, W, C, OH, OW, stride, pt, pl, e.s));
       int beta;
       void* dx = e.grad(x, &beta);
       LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, nullptr, e.s));
@@ -868,7 +881,7 @@ static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) 
   e.reset(m->ws + m->persist_bytes, m->ws_bytes > m->persist_bytes ? m->ws_bytes - m->persist_bytes : 0,
           m->ws + m->off_zero, m->zero_bytes);
   e.peak = 0;
-  if (!dry) (void)hipMemsetAsync(m->ws + m->off_zero, 0, m->zero_bytes, s);
+  if (!dry) launch_fill(m->ws + m->off_zero, 0, m->zero_bytes, s);
 }
 
 size_t model_workspace_bytes(Model* m, int B, int L) {
@@ -959,14 +972,14 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
   auto body = [&]() -> int {
     if (phase & 1) {
       launch_seed_advance((uint32_t*)(scal(m) + SC_SEED), s);
-      (void)hipMemsetAsync(m->grads, 0, (size_t)m->n_params * 4, s);
+      launch_fill(m->grads, 0, (size_t)m->n_params * 4, s);
       int rc = model_forward(m, img, expected, B, L, true, true, nullptr, s);
       if (rc) return rc;
       rc = model_loss_backward(m, expected, B, L, s);
       if (rc) return rc;
     }
     if (phase & 2) {
-      (void)hipMemsetAsync(scal(m) + SC_GNORM, 0, 4, s);
+      launch_fill(scal(m) + SC_GNORM, 0, 4, s);
       launch_sumsq(m->grads, m->n_params, scal(m) + SC_GNORM, s);
       launch_adamw(m->params, m->grads, (float*)(m->ws + m->off_adam_m), (float*)(m->ws + m->off_adam_v), m->n_params,
                    scal(m) + SC_GNORM, scal(m) + SC_HYPER, s);
@@ -991,6 +1004,10 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
     if (hipGraphInstantiate(&gx, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); m->err = "graph instantiate failed"; return -3; }
     (void)hipGraphDestroy(g);
   }
+  // ROCm 7.2: replays that contained hipMemsetAsync nodes went wrong when launched back to back (accumulators not
+  // cleared).  Every clear is now an ordinary kernel; draining the stream before a replay is kept as a cheap
+  // belt-and-braces measure (one host sync per ~20 ms step).
+  (void)hipStreamSynchronize(s);
   if (hipGraphLaunch(gx, s) != hipSuccess) { m->err = "graph launch failed"; return -3; }
   return 0;
 }

@@ -26,6 +26,7 @@ struct WgradP {
   int M, N, K, ldy, lda;
   int H, W, Ci, OH, OW, KW, stride, pt, pl;  // AM_CONV: A is the conv input [Bn,H,W,Ci], rows m = Bn*OH*OW
   int conv;        // 0 dense, 1 conv (im2col gather of A; dW written in [N][Ci][KH][KW] torch layout)
+  int conv_packed_out;  // conv: write dW as [N][taps][Ci] (contiguous atomics) for launch_conv_grad_unpack
   int out_t;       // 0: fp32 atomicAdd into dW (zeroed by caller); 1: store as T (batched attention use)
   int nbatch, nb_inner;                    // batched: z -> (z / nb_inner, z % nb_inner)
   long sY_o, sY_i, sA_o, sA_i, sW_o, sW_i;  // element strides per outer/inner batch index
@@ -33,6 +34,7 @@ struct WgradP {
   const float* ascale; int ascale_hw;      // optional A[m][k] *= ascale[(m/ascale_hw)*K + k]
 };
 void launch_wgrad(int dt, const WgradP& p, hipStream_t s);
+void launch_conv_grad_unpack(const float* tmp /*[N][taps][Ci]*/, float* dw /*[N][Ci][taps] +=*/, int N, int Ci, int taps, hipStream_t s);
 
 // ---- attention ---------------------------------------------------------------------------
 struct AttnP {
@@ -71,8 +73,9 @@ void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int 
 void launch_dwconv(int dt, int mode /*0 fwd,1 dgrad*/, const void* x, const void* wp /*[9][C] as T*/, const float* bias,
                    void* y, int B, int H, int W, int C, int OH, int OW, int stride, int pt, int pl, int beta,
                    float* stats /*optional [2C] zeroed: column sums of y (mode 0)*/, hipStream_t s);
-void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw /*[C][9] torch layout*/, float* dbias, int B,
-                         int H, int W, int C, int OH, int OW, int stride, int pt, int pl, hipStream_t s);
+void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw /*[C][9] torch layout*/, float* dbias,
+                         float* scratch10C /*optional zeroed [10][C]: contiguous atomics + scatter*/, int B, int H, int W,
+                         int C, int OH, int OW, int stride, int pt, int pl, hipStream_t s);
 void launch_maxpool(int dt, int bwd, const void* x, const void* dy_or_null, void* out, int B, int H, int W, int C,
                     hipStream_t s);
 void launch_pool_hw(int dt, const void* x, void* out /*[B,C] as T*/, int B, int HW, int C, hipStream_t s);

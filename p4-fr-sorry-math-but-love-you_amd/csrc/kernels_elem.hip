@@ -62,8 +62,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int 
       for (int y = 0; y < TY; ++y) sum += red[y * TX * CH + i];
       int col = cbase * CH + i;
       if (col < C) {
-        // sums k < nmain go to o0[col*nmain + k]; the remaining one goes to o1[col]
-        if (k < nmain) atomicAdd(o0 + (long)col * nmain + k, sum);
+        // nmain < 0: k-major o0[k*C + col] (contiguous atomics).  Else sums k < nmain go to o0[col*nmain + k] and the
+        // remaining one to o1[col]
+        if (nmain < 0) atomicAdd(o0 + (long)k * C + col, sum);
+        else if (k < nmain) atomicAdd(o0 + (long)col * nmain + k, sum);
         else if (o1) atomicAdd(o1 + col, sum);
       }
     }
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int 
 }
 
 template <typename T, int NO, typename F>
-static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain, hipStream_t s) {
+static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain, hipStream_t s, int rows_per_thread = 8) {
   constexpr int CH = TT<T>::CH;
   int CC = C / CH;
   // at most 32 column chunks per block (>= 8 row lanes), >= 32 rows per thread when M allows: keeps the number of
@@ -83,7 +85,7 @@ static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain
   int gy = (CC + TX - 1) / TX;
   // ~4 rows per thread, at most ~1024 blocks: these reductions are latency-bound per thread, and the float atomics
   // they end with (NO * TX * CH per block) are cheap next to the streamed bytes
-  long rpb = (long)TY * 4;
+  long rpb = (long)TY * rows_per_thread;
   long gx = (M + rpb - 1) / rpb;
   long cap = 1024 / gy < 1 ? 1 : 1024 / gy;
   if (gx > cap) { gx = cap; rpb = (M + gx - 1) / gx; rpb = ((rpb + TY - 1) / TY) * TY; gx = (M + rpb - 1) / rpb; }
@@ -393,34 +395,23 @@ void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int 
 
 // ---- depthwise 3x3 (forward gather / transposed gather for the data gradient) -----------------------
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void dwconv_kernel(const T* x, const T* wp, const float* bias, T* y, int B, int H, int W,
-                                                     int C, int OH, int OW, int stride, int pt, int pl, int beta, float* stats) {
+__global__ void dwconv_kernel(const T* x, const T* wp, const float* bias, T* y, int B, int H, int W, int C, int OH,
+                              int OW, int stride, int pt, int pl, int beta) {
   // MODE 0: x = input [B,H,W,C], y = output [B,OH,OW,C].  MODE 1: x = dY [B,H,W,C] (H,W = conv OUTPUT dims),
-  // y = dX [B,OH,OW,C] (OH,OW = conv INPUT dims).  Total threads is a multiple of the chunk count, so each thread keeps
-  // its channel chunk's nine tap weights (and, for the forward, the BatchNorm column sums) in registers.
+  // y = dX [B,OH,OW,C] (OH,OW = conv INPUT dims).  One thread per output chunk: these tensors are small and
+  // L2-resident, so occupancy (not instruction count) is what hides the nine gathers.
   constexpr int CH = TT<T>::CH;
-  extern __shared__ float sred[];  // [2][C] when stats
   const int CC = C / CH;
-  const long total = (long)B * OH * OW * CC;
-  const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
-  const int cc = (int)(tid % CC);
-  float wv[9][CH], bv[CH], s1[CH], s2[CH];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) unpack<T>(ld16(wp + t * C + cc * CH), wv[t]);
-#pragma unroll
-  for (int j = 0; j < CH; ++j) { bv[j] = (bias && MODE == 0) ? bias[cc * CH + j] : 0.f; s1[j] = s2[j] = 0.f; }
-  if (stats) {
-    for (int i = threadIdx.x; i < 2 * C; i += 256) sred[i] = 0.f;
-    __syncthreads();
-  }
-  for (long i = tid; i < total; i += nth) {
+  long total = (long)B * OH * OW * CC;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int cc = (int)(i % CC);
     long pix = i / CC;
     int ox = (int)(pix % OW);
     int oy = (int)((pix / OW) % OH);
     int b = (int)(pix / ((long)OW * OH));
     float acc[CH];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) acc[j] = bv[j];
+    for (int j = 0; j < CH; ++j) acc[j] = (bias && MODE == 0) ? bias[cc * CH + j] : 0.f;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
@@ -436,10 +427,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* x, const T* wp, co
           ok = ty >= 0 && tx >= 0 && sy * stride == ty && sx * stride == tx && sy < H && sx < W;
         }
         if (ok) {
-          float v[CH];
+          float v[CH], wv[CH];
           unpack<T>(ld16(x + (((long)b * H + sy) * W + sx) * C + cc * CH), v);
+          unpack<T>(ld16(wp + (kh * 3 + kw) * C + cc * CH), wv);
 #pragma unroll
-          for (int j = 0; j < CH; ++j) acc[j] += v[j] * wv[kh * 3 + kw][j];
+          for (int j = 0; j < CH; ++j) acc[j] += v[j] * wv[j];
         }
       }
     }
@@ -450,34 +442,20 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* x, const T* wp, co
 #pragma unroll
       for (int j = 0; j < CH; ++j) acc[j] += old[j];
     }
-#pragma unroll
-    for (int j = 0; j < CH; ++j) { s1[j] += acc[j]; s2[j] += acc[j] * acc[j]; }
     st16(o, pack<T>(acc));
-  }
-  if (stats) {
-#pragma unroll
-    for (int j = 0; j < CH; ++j) { atomicAdd(&sred[cc * CH + j], s1[j]); atomicAdd(&sred[C + cc * CH + j], s2[j]); }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(stats + i, sred[i]);
   }
 }
 void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float* bias, void* y, int B, int H, int W,
                    int C, int OH, int OW, int stride, int pt, int pl, int beta, float* stats, hipStream_t s) {
   DISPATCH_T(dt, {
-    int CC = C / TT<T>::CH;
-    long n = (long)B * OH * OW * CC;
-    int a = CC, b2 = 256;
-    while (b2) { int t = a % b2; a = b2; b2 = t; }
-    int q = CC / a;
-    int g = grid_for(n, 256, stats ? 768 : 4096);
-    g = ((g + q - 1) / q) * q;
-    size_t sh = stats ? (size_t)2 * C * sizeof(float) : 0;
+    long n = (long)B * OH * OW * (C / TT<T>::CH);
     if (mode == 0)
-      hipLaunchKernelGGL((dwconv_kernel<T, 0>), dim3(g), dim3(256), sh, s, (const T*)x, (const T*)wp, bias, (T*)y, B, H, W,
-                         C, OH, OW, stride, pt, pl, beta, stats);
+      hipLaunchKernelGGL((dwconv_kernel<T, 0>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)wp, bias,
+                         (T*)y, B, H, W, C, OH, OW, stride, pt, pl, beta);
     else
-      hipLaunchKernelGGL((dwconv_kernel<T, 1>), dim3(g), dim3(256), 0, s, (const T*)x, (const T*)wp, bias, (T*)y, B, H, W,
-                         C, OH, OW, stride, pt, pl, beta, (float*)nullptr);
+      hipLaunchKernelGGL((dwconv_kernel<T, 1>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)wp, bias,
+                         (T*)y, B, H, W, C, OH, OW, stride, pt, pl, beta);
+    if (stats && mode == 0) launch_colstats(dt, y, (long)B * OH * OW, C, stats, s);
   });
 }
 
@@ -507,8 +485,6 @@ template <typename T> struct DwWgradF {
       }
   }
 };
-void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int C,
-                         int OH, int OW, int stride, int pt, int pl, hipStream_t s);
 
 // ---- max-pool 2x2 s2 -----------------------------------------------------------------------------
 template <typename T, int BWD>
@@ -721,12 +697,25 @@ void launch_posenc2d(int dt, const void* x, const void* gate, const float* hpos,
   });
 }
 
-// ---- depthwise wgrad launcher: 9 tap sums -> dw[c*9+t] (torch [C][1][3][3]), 10th sum -> dbias[c] ------------
-void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W, int C,
-                         int OH, int OW, int stride, int pt, int pl, hipStream_t s) {
+// ---- depthwise wgrad: ten column sums per channel (nine taps + bias) accumulated k-major into a zeroed scratch
+// [10][C] with contiguous float atomics, then scattered into the torch layout dw[c*9+t] / dbias[c]
+__global__ void dw_wgrad_scatter_kernel(const float* tmp, float* dw, float* dbias, int C) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * 10) return;
+  int t = i / C, c = i - t * C;
+  if (t < 9) dw[c * 9 + t] += tmp[i];
+  else if (dbias) dbias[c] += tmp[i];
+}
+void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw, float* dbias, float* scratch10C, int B, int H,
+                         int W, int C, int OH, int OW, int stride, int pt, int pl, hipStream_t s) {
   DISPATCH_T(dt, {
     DwWgradF<T> f{(const T*)x, (const T*)dy, H, W, C, OH, OW, stride, pt, pl};
-    launch_colreduce<T, 10>(f, (long)B * OH * OW, C, dw, dbias, 9, s);
+    if (scratch10C) {
+      launch_colreduce<T, 10>(f, (long)B * OH * OW, C, scratch10C, nullptr, -1, s, 8);
+      hipLaunchKernelGGL(dw_wgrad_scatter_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, s, scratch10C, dw, dbias, C);
+    } else {
+      launch_colreduce<T, 10>(f, (long)B * OH * OW, C, dw, dbias, 9, s, 16);
+    }
   });
 }
 
@@ -1109,7 +1098,7 @@ void launch_ce_full(int dt_out, const float* logits, const int64_t* tgt, int ld_
                     int Vp, int pad_id, float* loss_out /*[4]*/, float* lse_ws /*[R]*/, void* dlogits,
                     const float* upstream, hipStream_t s) {
   long R = (long)B * T_;
-  (void)hipMemsetAsync(loss_out, 0, 4 * sizeof(float), s);
+  launch_fill(loss_out, 0, 4 * sizeof(float), s);
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid_for(R, 4, 2048)), dim3(256), 0, s, logits, tgt, ld_tgt, tgt_off, T_, V,
                      pad_id, R, loss_out, lse_ws);
   if (dt_out == DT_BF16) launch_ce_bwd_t<bf16_t>(logits, tgt, ld_tgt, tgt_off, B, T_, V, Vp, pad_id, loss_out, lse_ws, dlogits, upstream, s);
@@ -1144,7 +1133,28 @@ void launch_cast_pad(int dt_out, const float* in, void* out, long R, int C, int 
   if (dt_out == DT_BF16) hipLaunchKernelGGL((cast_pad_kernel<bf16_t>), dim3(g), dim3(256), 0, s, in, (bf16_t*)out, R, C, Cp);
   else hipLaunchKernelGGL((cast_pad_kernel<float>), dim3(g), dim3(256), 0, s, in, (float*)out, R, C, Cp);
 }
-void launch_fill(void* p, int value_byte, size_t bytes, hipStream_t s) { (void)hipMemsetAsync(p, value_byte, bytes, s); }
+// zero fill as an ordinary kernel (captured hipGraph memset nodes of tens of MB proved unreliable on replay)
+__global__ void zero_kernel(uint4* p, size_t n16, unsigned char* tail, size_t ntail) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0 && threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+__global__ void zero_bytes_kernel(unsigned char* p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0;
+}
+void launch_fill(void* p, int value_byte, size_t bytes, hipStream_t s) {
+  if (value_byte != 0) { (void)hipMemsetAsync(p, value_byte, bytes, s); return; }
+  if ((((size_t)p) & 15) != 0) {
+    int g = (int)((bytes + 255) / 256);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(zero_bytes_kernel, dim3(g < 1 ? 1 : g), dim3(256), 0, s, (unsigned char*)p, bytes);
+    return;
+  }
+  size_t n16 = bytes / 16, ntail = bytes % 16;
+  int g = (int)((n16 + 255) / 256);
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(zero_kernel, dim3(g), dim3(256), 0, s, (uint4*)p, n16, (unsigned char*)p + n16 * 16, ntail);
+}
 
 template <typename T>
 __global__ void add_kernel(const T* a, const T* b, T* out, long n) {
@@ -1228,22 +1238,40 @@ void launch_pack_dw(int dt, const float* w, void* out, int C, hipStream_t s) {
   DISPATCH_T(dt, { hipLaunchKernelGGL((pack_dw_kernel<T>), dim3((C * 9 + 255) / 256), dim3(256), 0, s, w, (T*)out, C); });
 }
 
-// one launch for every weight: blockIdx -> (descriptor, first element) through a host-built table, PACK_BLK elements per block
+// one launch for every weight: blockIdx -> (descriptor, work item) through a host-built table.
+// dense weights: work item = one 64x64 tile, transposed through LDS so both copies are written coalesced;
+// conv3x3 / depthwise (small): work item = PACK_BLK consecutive elements.
 template <typename T>
-__global__ void pack_all_kernel(const PackDesc* d, const int2* blk) {
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackDesc* d, const int2* blk) {
+  __shared__ float tile[64][65];
   const int2 bi = blk[blockIdx.x];
   const PackDesc e = d[bi.x];
-  const long n = e.kind == 0 ? (long)e.N * e.K : (e.kind == 1 ? (long)e.N * e.K * 9 : (long)e.N * 9);
+  if (e.kind == 0) {
+    const int tiles_k = (e.K + 63) / 64;
+    const int n0 = (bi.y / tiles_k) * 64, k0 = (bi.y % tiles_k) * 64;
+    const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int r = r0; r < 64; r += 4) {
+      float v = 0.f;
+      if (n0 + r < e.N && k0 + c < e.K) {
+        v = e.src[(long)(n0 + r) * e.K + k0 + c];
+        ((T*)e.fwd)[(long)(n0 + r) * e.K + k0 + c] = from_f<T>(v);
+      }
+      tile[r][c] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = r0; r < 64; r += 4)
+      if (k0 + r < e.K && n0 + c < e.N) ((T*)e.bwd)[(long)(k0 + r) * e.ldb + n0 + c] = from_f<T>(tile[c][r]);
+    return;
+  }
+  const long n = e.kind == 1 ? (long)e.N * e.K * 9 : (long)e.N * 9;
   const long j0 = (long)bi.y * PACK_BLK;
   for (int t = threadIdx.x; t < PACK_BLK; t += 256) {
     const long j = j0 + t;
     if (j >= n) break;
     const T v = from_f<T>(e.src[j]);
-    if (e.kind == 0) {  // dense [N][K] -> fwd [N][K], bwd [K][ldb]
-      int r = (int)(j / e.K), k = (int)(j - (long)r * e.K);
-      ((T*)e.fwd)[j] = v;
-      ((T*)e.bwd)[(long)k * e.ldb + r] = v;
-    } else if (e.kind == 1) {  // conv3x3 [Co][Ci][9] -> fwd [Co][9][Ci], bwd [Ci][9][Co]
+    if (e.kind == 1) {  // conv3x3 [Co][Ci][9] -> fwd [Co][9][Ci], bwd [Ci][9][Co]
       int t9 = (int)(j % 9);
       int ci = (int)((j / 9) % e.K);
       int co = (int)(j / (9L * e.K));

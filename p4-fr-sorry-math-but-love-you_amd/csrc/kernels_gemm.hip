@@ -237,21 +237,55 @@ void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s) {
 }
 
 // =========================================================================================
-// wgrad: dW[n][k] += sum_m dY[m][n] * A[m][k].  Output tile 64(n) x 64(k); each block reduces a slice
-// of M in 32-row steps.  Both operands are transposed on their way into LDS (m becomes the panel's
-// contiguous k axis) so the MFMA fragment reads are the same 16-byte reads as in gemm_kernel.
+// wgrad: dW[n][k] += sum_m dY[m][n] * A[m][k].  Output tile BNW(n) x BKW(k); each block reduces a slice of M in
+// MS-row steps.  Both operands are staged into LDS in their NATURAL row-major layout ([m][channels], 16-byte chunk
+// stores) and the MFMA fragments (8 consecutive m for one channel) are fetched with the transposing LDS read
+// ds_read_b64_tr_b16 (bf16) or plain ds_read_b32 (f32) -- no scalar transposing writes.  Row pitch = tile + 16
+// elements staggers consecutive rows by 32 B / 16 banks, which makes both kinds of read conflict-free.
 // =========================================================================================
-template <typename T, int CONV>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct WFrag;
+// bf16: two transposed 4-row reads -> 8 consecutive m of column (c0 + lane&15), m-group lane>>4
+template <> struct WFrag<bf16_t> {
+  static DEVI Frag<bf16_t> load(const bf16_t* tile, int pitch, int m0, int c0, int lane) {
+    const int g = lane >> 4, j = lane & 15, q = j >> 2, pp = j & 3;
+    const bf16_t* a0 = tile + (m0 + 8 * g + q) * pitch + c0 + 4 * pp;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 4 * pitch));
+    Frag<bf16_t> f;
+    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    f.v = make_uint4(l2.x, l2.y, h2.x, h2.y);
+    return f;
+  }
+};
+// f32: MFMA sub-step j takes m = m0 + 4j + (lane>>4)
+template <> struct WFrag<float> {
+  static DEVI Frag<float> load(const float* tile, int pitch, int m0, int c0, int lane) {
+    const int q = lane >> 4, i = lane & 15;
+    const float* a = tile + (m0 + q) * pitch + c0 + i;
+    Frag<float> f;
+    f.v0 = make_uint4(__float_as_uint(a[0]), __float_as_uint(a[4 * pitch]), __float_as_uint(a[8 * pitch]), __float_as_uint(a[12 * pitch]));
+    f.v1 = make_uint4(__float_as_uint(a[16 * pitch]), __float_as_uint(a[20 * pitch]), __float_as_uint(a[24 * pitch]), __float_as_uint(a[28 * pitch]));
+    return f;
+  }
+};
+
+template <typename T, int BNW, int BKW, int CONV>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split) {
   constexpr int CH = TT<T>::CH;
-  constexpr int CPT = 64 / CH;             // chunks per 64-wide tile row (8 bf16 / 16 f32)
-  constexpr int NC = (32 * CPT) / 256;      // chunks per thread per operand (1 / 2)
-  __shared__ __attribute__((aligned(16))) T lds[2 * 2 * 64 * 32];
+  constexpr int MS = sizeof(T) == 2 ? 64 : 32;   // rows of M per barrier
+  constexpr int PN = BNW + 16, PK = BKW + 16;    // LDS row pitches (elements)
+  constexpr int CPN = BNW / CH, CPK = BKW / CH;  // 16-byte chunks per tile row
+  constexpr int NCY = MS * CPN / 256, NCX = MS * CPK / 256;
+  constexpr int MTN = BNW / 64, NTK = BKW / 16;
+  constexpr int STAGE = MS * (PN + PK);
+  __shared__ __attribute__((aligned(16))) T lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ntk = (p.K + 63) / 64;
+  const int ntk = (p.K + BKW - 1) / BKW;
   const int tile_k = blockIdx.x % ntk, tile_n = blockIdx.x / ntk;
-  const int n0 = tile_n * 64, k0 = tile_k * 64;
+  const int n0 = tile_n * BNW, k0 = tile_k * BKW;
   const int z = blockIdx.z;
   const int zo = z / p.nb_inner, zi = z % p.nb_inner;
   const T* dY = (const T*)p.dY + zo * p.sY_o + zi * p.sY_i;
@@ -259,45 +293,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split
   const int m_begin = blockIdx.y * rows_per_split;
   const int m_end = min(p.M, m_begin + rows_per_split);
 
-  // thread -> (m within step = tid % 32, chunk = tid / 32 [+ 8 for second chunk])
-  const int tm = tid & 31;
-  int ycol[NC], acol[NC], atap[NC], aci[NC];
-  bool yok[NC], aok[NC];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    int c = (tid >> 5) + i * 8;
-    ycol[i] = n0 + c * CH;
-    yok[i] = ycol[i] < p.N;
-    acol[i] = k0 + c * CH;
-    aok[i] = acol[i] < p.K;
-    if (CONV) { atap[i] = acol[i] / p.Ci; aci[i] = acol[i] - atap[i] * p.Ci; } else { atap[i] = 0; aci[i] = acol[i]; }
-  }
-  uint4 ry[NC], rx[NC];
+  const int cy = tid % CPN, cx = tid % CPK;  // chunk column of this thread in each tile (fixed: 256 % CPx == 0)
+  const int ycol = n0 + cy * CH, xcol = k0 + cx * CH;
+  const bool yok = ycol < p.N, xok = xcol < p.K;
+  int xtap = 0, xci = xcol;
+  if (CONV) { xtap = xcol / p.Ci; xci = xcol - xtap * p.Ci; }
+  const int xkh = CONV ? ((p.KW == 1) ? 0 : (xtap * 11) >> 5) : 0, xkw = CONV ? xtap - xkh * p.KW : 0;
+
+  uint4 ry[NCY], rx[NCX];
   auto load_tiles = [&](int mstep) {
-    const int m = mstep + tm;
-    const bool mok = m < m_end;
-    int img = 0, by = 0, bx = 0;
-    if (CONV && mok) {
-      int ohw = p.OH * p.OW;
-      int b = m / ohw, r = m - b * ohw;
-      int oy = r / p.OW, ox = r - oy * p.OW;
-      img = b * p.H * p.W; by = oy * p.stride - p.pt; bx = ox * p.stride - p.pl;
+#pragma unroll
+    for (int i = 0; i < NCY; ++i) {
+      const int m = mstep + (tid + i * 256) / CPN;
+      ry[i] = (m < m_end && yok) ? ld16(dY + (long)m * p.ldy + ycol) : zero16();
     }
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      ry[i] = (mok && yok[i]) ? ld16(dY + (long)m * p.ldy + ycol[i]) : zero16();
+    for (int i = 0; i < NCX; ++i) {
+      const int m = mstep + (tid + i * 256) / CPK;
       uint4 v = zero16();
-      if (mok && aok[i]) {
+      if (m < m_end && xok) {
         if (CONV) {
-          int kh = (p.KW == 1) ? 0 : (atap[i] * 11) >> 5, kw = atap[i] - kh * p.KW;
-          int sy = by + kh, sx = bx + kw;
-          if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) v = ld16(A + ((long)(img + sy * p.W + sx)) * p.Ci + aci[i]);
+          int ohw = p.OH * p.OW;
+          int b = m / ohw, r = m - b * ohw;
+          int oy = r / p.OW, ox = r - oy * p.OW;
+          int sy = oy * p.stride - p.pt + xkh, sx = ox * p.stride - p.pl + xkw;
+          if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) v = ld16(A + ((long)(b * p.H * p.W + sy * p.W + sx)) * p.Ci + xci);
         } else {
-          v = ld16(A + (long)m * p.lda + acol[i]);
+          v = ld16(A + (long)m * p.lda + xcol);
           if (p.ascale) {
             float f[CH];
             unpack<T>(v, f);
-            const float* gp = p.ascale + (long)(m / p.ascale_hw) * p.K + acol[i];
+            const float* gp = p.ascale + (long)(m / p.ascale_hw) * p.K + xcol;
 #pragma unroll
             for (int j = 0; j < CH; ++j) f[j] *= gp[j];
             v = pack<T>(f);
@@ -308,40 +334,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split
     }
   };
   auto store_tiles = [&](int buf) {
-    T* ly = lds + buf * (2 * 64 * 32);
-    T* lx = ly + 64 * 32;
+    T* ly = lds + buf * STAGE;
+    T* lx = ly + MS * PN;
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      int c = (tid >> 5) + i * 8;
-      const T* ey = (const T*)&ry[i];
-      const T* ex = (const T*)&rx[i];
+    for (int i = 0; i < NCY; ++i) st16(ly + ((tid + i * 256) / CPN) * PN + cy * CH, ry[i]);
 #pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        ly[panel_elem<T>(c * CH + j, tm)] = ey[j];
-        lx[panel_elem<T>(c * CH + j, tm)] = ex[j];
-      }
-    }
+    for (int i = 0; i < NCX; ++i) st16(lx + ((tid + i * 256) / CPK) * PK + cx * CH, rx[i]);
   };
 
-  f32x4 acc[4];
+  f32x4 acc[MTN][NTK];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MTN; ++i)
+#pragma unroll
+    for (int j = 0; j < NTK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fq = lane >> 4;
   if (m_begin < m_end) {
     load_tiles(m_begin);
     store_tiles(0);
     __syncthreads();
     int cur = 0;
-    for (int ms = m_begin; ms < m_end; ms += 32) {
-      const bool more = ms + 32 < m_end;
-      if (more) load_tiles(ms + 32);
-      const T* ly = lds + cur * (2 * 64 * 32);
-      const T* lx = ly + 64 * 32;
-      Frag<T> af = load_frag<T>(ly, wave * 16 + fr, fq);
+    for (int ms = m_begin; ms < m_end; ms += MS) {
+      const bool more = ms + MS < m_end;
+      if (more) load_tiles(ms + MS);
+      const T* ly = lds + cur * STAGE;
+      const T* lx = ly + MS * PN;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        Frag<T> bf = load_frag<T>(lx, j * 16 + fr, fq);
-        mma(af, bf, acc[j]);
+      for (int sub = 0; sub < MS / 32; ++sub) {
+        Frag<T> af[MTN];
+#pragma unroll
+        for (int i = 0; i < MTN; ++i) af[i] = WFrag<T>::load(ly, PN, sub * 32, wave * (BNW / 4) + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < NTK; ++j) {
+          Frag<T> bf = WFrag<T>::load(lx, PK, sub * 32, j * 16, lane);
+#pragma unroll
+          for (int i = 0; i < MTN; ++i) mma(af[i], bf, acc[i][j]);
+        }
       }
       if (more) store_tiles(cur ^ 1);
       __syncthreads();
@@ -350,48 +377,74 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split
   }
   const int taps = CONV ? (p.KW * p.KW) : 1;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k = k0 + j * 16 + fr;
-    if (k >= p.K) continue;
+  for (int i = 0; i < MTN; ++i) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wave * 16 + fq * 4 + r;
-      if (n >= p.N) continue;
-      if (p.out_t) {
-        T* o = (T*)p.dW + zo * p.sW_o + zi * p.sW_i;
-        o[(long)n * p.ldw + k] = from_f<T>(acc[j][r]);
-      } else {
-        long dst;
-        if (CONV) { int tp = k / p.Ci, c = k - tp * p.Ci; dst = ((long)n * p.Ci + c) * taps + tp; }
-        else dst = (long)n * p.K + k;
-        atomicAdd((float*)p.dW + dst, acc[j][r]);
+    for (int j = 0; j < NTK; ++j) {
+      const int k = k0 + j * 16 + fr;
+      if (k >= p.K) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wave * (BNW / 4) + i * 16 + fq * 4 + r;
+        if (n >= p.N) continue;
+        if (p.out_t) {
+          T* o = (T*)p.dW + zo * p.sW_o + zi * p.sW_i;
+          o[(long)n * p.ldw + k] = from_f<T>(acc[i][j][r]);
+        } else {
+          long dst;
+          if (CONV && !p.conv_packed_out) { int tp = k / p.Ci, c = k - tp * p.Ci; dst = ((long)n * p.Ci + c) * taps + tp; }
+          else dst = (long)n * p.K + k;
+          atomicAdd((float*)p.dW + dst, acc[i][j][r]);
+        }
       }
     }
   }
 }
 
-void launch_wgrad(int dt, const WgradP& p, hipStream_t s) {
-  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return;
-  const int tiles = ((p.N + 63) / 64) * ((p.K + 63) / 64);
+template <typename T, int BNW, int BKW>
+static void launch_wgrad_tile(const WgradP& p, hipStream_t s) {
+  constexpr int MS = sizeof(T) == 2 ? 64 : 32;
+  const int tiles = ((p.N + BNW - 1) / BNW) * ((p.K + BKW - 1) / BKW);
   const int nb = p.nbatch > 0 ? p.nbatch : 1;
   int splits = 1;
   if (!p.out_t) {
-    splits = (int)((2048 + (long)tiles * nb - 1) / ((long)tiles * nb));
-    int maxs = (p.M + 255) / 256;
+    splits = (int)((768 + (long)tiles * nb - 1) / ((long)tiles * nb));
+    int maxs = (p.M + 4 * MS - 1) / (4 * MS);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
   }
   int rps = (p.M + splits - 1) / splits;
-  rps = ((rps + 31) / 32) * 32;
+  rps = ((rps + MS - 1) / MS) * MS;
   splits = (p.M + rps - 1) / rps;
   WgradP q = p;
   if (q.nb_inner <= 0) q.nb_inner = 1;
   dim3 grid(tiles, splits, nb);
+  if (p.conv) hipLaunchKernelGGL((wgrad_kernel<T, BNW, BKW, 1>), grid, dim3(256), 0, s, q, rps);
+  else hipLaunchKernelGGL((wgrad_kernel<T, BNW, BKW, 0>), grid, dim3(256), 0, s, q, rps);
+}
+
+void launch_wgrad(int dt, const WgradP& p, hipStream_t s) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return;
+  const bool big = p.N > 64 && p.K > 64 && (long)p.M * p.N * p.K >= (1L << 28);
   if (dt == DT_BF16) {
-    if (p.conv) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1>), grid, dim3(256), 0, s, q, rps);
-    else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 0>), grid, dim3(256), 0, s, q, rps);
+    if (big) launch_wgrad_tile<bf16_t, 128, 128>(p, s); else launch_wgrad_tile<bf16_t, 64, 64>(p, s);
   } else {
-    if (p.conv) hipLaunchKernelGGL((wgrad_kernel<float, 1>), grid, dim3(256), 0, s, q, rps);
-    else hipLaunchKernelGGL((wgrad_kernel<float, 0>), grid, dim3(256), 0, s, q, rps);
+    if (big) launch_wgrad_tile<float, 128, 128>(p, s); else launch_wgrad_tile<float, 64, 64>(p, s);
   }
+}
+
+// scratch [N][taps][Ci] (fp32) -> += into the torch layout [N][Ci][taps]
+__global__ void conv_grad_unpack_kernel(const float* tmp, float* dw, int N, int Ci, int taps) {
+  long n = (long)N * Ci * taps;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int t = (int)(i % taps);
+    int ci = (int)((i / taps) % Ci);
+    int co = (int)(i / ((long)taps * Ci));
+    dw[i] += tmp[((long)co * taps + t) * Ci + ci];
+  }
+}
+void launch_conv_grad_unpack(const float* tmp, float* dw, int N, int Ci, int taps, hipStream_t s) {
+  long n = (long)N * Ci * taps;
+  int g = (int)((n + 255) / 256);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(conv_grad_unpack_kernel, dim3(g), dim3(256), 0, s, tmp, dw, N, Ci, taps);
 }

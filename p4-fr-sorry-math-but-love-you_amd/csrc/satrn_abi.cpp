@@ -149,7 +149,7 @@ int satrn_dwconv3x3_bwd_weight(int dt, const void* x, const void* dy, float* dw,
                                int OH, int OW, int stride, int pt, int pl, void* st) {
   CHK_DT(dt);
   if (chk_c(dt, C, "C")) return -1;
-  launch_dwconv_wgrad(dt, x, dy, dw, dbias, B, H, W, C, OH, OW, stride, pt, pl, S(st));
+  launch_dwconv_wgrad(dt, x, dy, dw, dbias, nullptr, B, H, W, C, OH, OW, stride, pt, pl, S(st));
   return done("dwconv3x3_bwd_weight");
 }
 

@@ -144,7 +144,7 @@ def test_train_forward_backward_vs_golden_and_oracle(golden_dir, name, dtype):
         np.testing.assert_allclose(gs[:, 1], z["grad_sums"][:, 1], rtol=5e-3, atol=1e-5)
     bufs = dict(model.named_buffers())
     for n_, v in obn.items():
-        assert relerr(bufs[n_], v) < (1e-3 if f32 else 0.1), n_
+        assert relerr(bufs[n_], v) < (1e-3 if f32 else (0.3 if tiny else 0.1)), n_
 
 
 @pytest.mark.parametrize("name", CASES)
