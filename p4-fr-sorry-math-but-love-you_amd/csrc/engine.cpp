@@ -195,6 +195,7 @@ Model* model_create(const SatrnConfig& cfg) {
           eb.se_rb = b.vec(q + "se.conv_reduce.bias", eb.se, 3, eb.mid);
           eb.se_e = b.dense(q + "se.conv_expand.weight", eb.mid, eb.se, 1, true);
           eb.se_eb = b.vec(q + "se.conv_expand.bias", eb.mid, 3, eb.se);
+          eb.se_r.kind = WK_STEM; eb.se_e.kind = WK_STEM;  // consumed as fp32 masters by the fused SE kernels: no packed copies
           eb.c1 = b.dense(q + "conv_pwl.weight", eb.cout, eb.mid, 1, true);
           eb.bn3 = b.bn(q + "bn3", eb.cout, 1e-3f);
         }
@@ -784,6 +785,34 @@ Tensor* encoder_layer(Exec& e, Tensor* x, EncLayer* el) {
   return op_bn_act(e, c1, &el->norm1, ACT_RELU, x);
 }
 
+// squeeze-and-excite: pool + MLP in one kernel, x*gate in a second; backward = dgate reduction, two SE kernels, dx
+Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb) {
+  const int B = x->B, HW = x->H * x->W, C = x->C, S = eb->se;
+  float* pooled = (float*)e.alloc((size_t)B * C * 4);
+  float* u1 = (float*)e.alloc((size_t)B * S * 4);
+  float* s1 = (float*)e.alloc((size_t)B * S * 4);
+  Tensor* gate = e.newt(B, C);
+  e.nbytes = (double)x->rows * C * e.esz();
+  LCH(e, launch_se_fwd(e.dt, x->p, eb->se_r.p, eb->se_rb.p, eb->se_e.p, eb->se_eb.p, pooled, u1, s1, gate->p, B, HW, C, S, e.s));
+  Tensor* y = e.newt(x->rows, C, B, x->H, x->W);
+  LCH(e, launch_se_scale(e.dt, x->p, gate->p, y->p, B, HW, C, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, x, y, gate, eb, pooled, u1, s1, B, HW, C, S]() {
+      if (!y->g) return;
+      void* dgate = e.alloc((size_t)B * C * e.esz());
+      void* dpooled = e.alloc((size_t)B * C * e.esz());
+      float* dz2 = (float*)e.alloc((size_t)B * C * 4);
+      float* du1 = (float*)e.alloc((size_t)B * S * 4);
+      LCH(e, launch_se_bwd_gate(e.dt, y->g, x->p, dgate, B, HW, C, e.s));
+      LCH(e, launch_se_bwd(e.dt, dgate, gate->p, u1, s1, pooled, eb->se_r.p, eb->se_e.p, dz2, du1, dpooled, eb->se_r.g, eb->se_rb.g,
+                           eb->se_e.g, eb->se_eb.g, B, C, S, e.s));
+      int beta;
+      void* dx = e.grad(x, &beta);
+      LCH(e, launch_se_bwd_x(e.dt, y->g, gate->p, dpooled, dx, B, HW, C, beta, e.s));
+    });
+  return y;
+}
+
 Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
   const int B = x->B, H = x->H, W = x->W;
   Geo g;
@@ -805,11 +834,7 @@ Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
   Tensor* z = op_bn_act(e, y, &eb->bn1, ACT_SILU, nullptr);
   Tensor* y2 = op_dwconv(e, z, &eb->dw, nullptr, eb->stride, g.OH, g.OW, g.pt, g.pl);
   Tensor* z2 = op_bn_act(e, y2, &eb->bn2, ACT_SILU, nullptr);
-  Tensor* pooled = op_pool(e, z2);
-  Tensor* u1 = op_gemm(e, pooled, &eb->se_r, &eb->se_rb, ACT_NONE, 0.f, nullptr);
-  Tensor* s1 = op_act(e, u1, ACT_SILU);
-  Tensor* gate = op_gemm(e, s1, &eb->se_e, &eb->se_eb, ACT_SIGMOID, 0.f, nullptr);
-  Tensor* z3 = op_se_scale(e, z2, gate);
+  Tensor* z3 = op_se(e, z2, eb);
   Tensor* y3 = op_gemm(e, z3, &eb->c1, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   y3->B = B; y3->H = g.OH; y3->W = g.OW;
   return op_bn_act(e, y3, &eb->bn3, ACT_NONE, skip);

@@ -1,0 +1,179 @@
+// Squeeze-and-excite of the EfficientNetV2-S MBConv blocks (timm SqueezeExcite behind networks/EfficientSATRN.py:74,84):
+//   gate[b] = sigmoid(W2 * silu(W1 * mean_hw(x[b]) + b1) + b2),   y = x * gate
+// The MLP has 32 rows (one per image) and at most 1536 x 64 weights: as GEMMs it is three latency-bound launches
+// forward and eight backward.  Here it is one kernel forward (pool + MLP, one workgroup per image, fp32 master
+// weights straight from the flat parameter buffer) and two backward (per-image vectors, then weight gradients).
+#include "common.h"
+#include "kernels.h"
+
+// ---- forward: pooled[b][:] (fp32), u1[b][:] (pre-activation), s1[b][:], gate[b][:] (T)
+template <typename T>
+__global__ __launch_bounds__(1024) void se_fwd_kernel(const T* x, const float* W1, const float* b1, const float* W2,
+                                                      const float* b2, float* pooled, float* u1, float* s1, T* gate,
+                                                      int HW, int C, int S) {
+  constexpr int CH = TT<T>::CH;
+  extern __shared__ float sm[];  // p[C] | h[S] | part[4][C]
+  float* p = sm;
+  float* h = sm + C;
+  float* part = h + S;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int CC = C / CH;
+  // ---- global average pool: 256 chunk lanes x 4 row groups, four independent loads in flight per thread
+  {
+    const int rg = tid >> 8;
+    for (int c = tid & 255; c < CC; c += 256) {
+      float a[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) a[j] = 0.f;
+      const T* base = x + (long)b * HW * C + c * CH;
+#pragma unroll 4
+      for (int r = rg; r < HW; r += 4) {
+        float v[CH];
+        unpack<T>(ld16(base + (long)r * C), v);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) a[j] += v[j];
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) part[rg * C + c * CH + j] = a[j];
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 1024) {
+    float m = (part[c] + part[C + c] + part[2 * C + c] + part[3 * C + c]) * (1.0f / (float)HW);
+    p[c] = m;
+    pooled[(long)b * C + c] = m;
+  }
+  __syncthreads();
+  // ---- hidden: one wave per hidden unit (rows of W1 are contiguous in C)
+  for (int j = wave; j < S; j += 16) {
+    const float* w = W1 + (long)j * C;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int c = lane * 4; c < C; c += 256) {
+      float4 wv = *reinterpret_cast<const float4*>(w + c);
+      acc += wv.x * p[c] + wv.y * p[c + 1] + wv.z * p[c + 2] + wv.w * p[c + 3];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      float u = acc + b1[j];
+      float sv = u * sigmoidf_(u);
+      h[j] = sv;
+      u1[(long)b * S + j] = u;
+      s1[(long)b * S + j] = sv;
+    }
+  }
+  __syncthreads();
+  // ---- gate: thread per channel (rows of W2 are contiguous in S)
+  for (int c = tid; c < C; c += 1024) {
+    const float* w = W2 + (long)c * S;
+    float acc = b2[c];
+#pragma unroll 8
+    for (int j = 0; j < S; j += 4) {
+      float4 wv = *reinterpret_cast<const float4*>(w + j);
+      acc += wv.x * h[j] + wv.y * h[j + 1] + wv.z * h[j + 2] + wv.w * h[j + 3];
+    }
+    gate[(long)b * C + c] = from_f<T>(sigmoidf_(acc));
+  }
+}
+
+// ---- backward A (per image): dz2 = dgate*gate*(1-gate); ds1 = W2^T dz2; du1 = ds1*silu'(u1); dpooled = W1^T du1
+template <typename T>
+__global__ __launch_bounds__(1024) void se_bwd_a_kernel(const T* dgate, const T* gate, const float* u1, const float* W1,
+                                                        const float* W2, float* dz2, float* du1, T* dpooled, int C, int S) {
+  extern __shared__ float sm[];  // dz[C] | part[16][S] | du[S]
+  float* dz = sm;
+  float* part = sm + C;
+  float* du = part + 16 * S;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < C; c += 1024) {
+    float g = to_f(gate[(long)b * C + c]);
+    float v = to_f(dgate[(long)b * C + c]) * g * (1.f - g);
+    dz[c] = v;
+    dz2[(long)b * C + c] = v;
+  }
+  __syncthreads();
+  // ds1[j] = sum_c W2[c][j] * dz[c]: lane = j (S <= 64), the 16 waves split the channels, 8 loads in flight each
+  {
+    float acc = 0.f;
+    if (lane < S) {
+#pragma unroll 8
+      for (int c = wave; c < C; c += 16) acc += W2[(long)c * S + lane] * dz[c];
+      part[wave * S + lane] = acc;
+    }
+  }
+  __syncthreads();
+  if (tid < S) {
+    float ds = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) ds += part[w * S + tid];
+    float v = ds * act_bwd(u1[(long)b * S + tid], ACT_SILU);
+    du[tid] = v;
+    du1[(long)b * S + tid] = v;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 1024) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < S; ++j) acc += W1[(long)j * C + c] * du[j];
+    dpooled[(long)b * C + c] = from_f<T>(acc);
+  }
+}
+
+// ---- backward B: weight gradients dW2[c][j] = sum_b dz2[b][c]*s1[b][j], dW1[j][c] = sum_b du1[b][j]*pooled[b][c].
+// thread = (channel c, group of 8 hidden units): no atomics (each thread owns its outputs), 16 accumulators
+__global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* dz2, const float* du1, const float* s1,
+                                                       const float* pooled, float* dW1, float* db1, float* dW2,
+                                                       float* db2, int B, int C, int S) {
+  extern __shared__ float sm[];  // s1[B][8] | du1[B][8] for this block's 8 hidden units
+  const int tid = threadIdx.x;
+  const int j0 = blockIdx.y * 8;
+  for (int i = tid; i < B * 8; i += 256) {
+    int b = i >> 3, j = j0 + (i & 7);
+    sm[i] = j < S ? s1[b * S + j] : 0.f;
+    sm[B * 8 + i] = j < S ? du1[b * S + j] : 0.f;
+  }
+  __syncthreads();
+  const int c = blockIdx.x * 256 + tid;
+  if (c < C) {
+    float a2[8], a1[8], sb = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a2[j] = a1[j] = 0.f;
+#pragma unroll 4
+    for (int b = 0; b < B; ++b) {
+      const float z = dz2[(long)b * C + c], pp = pooled[(long)b * C + c];
+      sb += z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a2[j] += z * sm[b * 8 + j]; a1[j] += sm[B * 8 + b * 8 + j] * pp; }
+    }
+    if (blockIdx.y == 0) db2[c] += sb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j0 + j < S) { dW2[(long)c * S + j0 + j] += a2[j]; dW1[(long)(j0 + j) * C + c] += a1[j]; }
+  }
+  if (blockIdx.x == 0 && tid < 8 && j0 + tid < S) {
+    float sbb = 0.f;
+    for (int b = 0; b < B; ++b) sbb += sm[B * 8 + b * 8 + tid];
+    db1[j0 + tid] += sbb;
+  }
+}
+
+void launch_se_fwd(int dt, const void* x, const float* W1, const float* b1, const float* W2, const float* b2, float* pooled,
+                   float* u1, float* s1, void* gate, int B, int HW, int C, int S, hipStream_t s) {
+  size_t sh = (size_t)(5 * C + S) * sizeof(float);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL((se_fwd_kernel<bf16_t>), dim3(B), dim3(1024), sh, s, (const bf16_t*)x, W1, b1, W2, b2, pooled, u1, s1, (bf16_t*)gate, HW, C, S);
+  else
+    hipLaunchKernelGGL((se_fwd_kernel<float>), dim3(B), dim3(1024), sh, s, (const float*)x, W1, b1, W2, b2, pooled, u1, s1, (float*)gate, HW, C, S);
+}
+void launch_se_bwd(int dt, const void* dgate, const void* gate, const float* u1, const float* s1, const float* pooled,
+                   const float* W1, const float* W2, float* dz2, float* du1, void* dpooled, float* dW1, float* db1, float* dW2,
+                   float* db2, int B, int C, int S, hipStream_t s) {
+  size_t sh = (size_t)(C + 17 * S) * sizeof(float);
+  if (dt == DT_BF16)
+    hipLaunchKernelGGL((se_bwd_a_kernel<bf16_t>), dim3(B), dim3(1024), sh, s, (const bf16_t*)dgate, (const bf16_t*)gate, u1, W1, W2, dz2, du1, (bf16_t*)dpooled, C, S);
+  else
+    hipLaunchKernelGGL((se_bwd_a_kernel<float>), dim3(B), dim3(1024), sh, s, (const float*)dgate, (const float*)gate, u1, W1, W2, dz2, du1, (float*)dpooled, C, S);
+  size_t sh2 = (size_t)2 * B * 8 * sizeof(float);
+  hipLaunchKernelGGL(se_bwd_b_kernel, dim3((C + 255) / 256, (S + 7) / 8), dim3(256), sh2, s, dz2, du1, s1, pooled, dW1, db1, dW2,
+                     db2, B, C, S);
+}
