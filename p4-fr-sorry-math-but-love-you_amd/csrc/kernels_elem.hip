@@ -85,7 +85,11 @@ static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain
   int gy = (CC + TX - 1) / TX;
   // ~4 rows per thread, at most ~1024 blocks: these reductions are latency-bound per thread, and the float atomics
   // they end with (NO * TX * CH per block) are cheap next to the streamed bytes
-  long rpb = (long)TY * rows_per_thread;
+  // rows per thread: as many as keep >= ~512 blocks in flight (these kernels are latency-bound, not byte-bound)
+  long rpt = (M * gy) / ((long)TY * 512);
+  if (rpt < 1) rpt = 1;
+  if (rpt > rows_per_thread) rpt = rows_per_thread;
+  long rpb = (long)TY * rpt;
   long gx = (M + rpb - 1) / rpb;
   long cap = 1024 / gy < 1 ? 1 : 1024 / gy;
   if (gx > cap) { gx = cap; rpb = (M + gx - 1) / gx; rpb = ((rpb + TY - 1) / TY) * TY; gx = (M + rpb - 1) / rpb; }

@@ -5,6 +5,9 @@
 //                 the batched P^T*dO / dS^T*Q products of attention backward.
 // Both stage 32-deep k-panels through LDS (swizzled, double buffered, one barrier per step); the global
 // loads of step t+1 are in flight while step t's MFMAs run.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -204,22 +207,34 @@ static void launch_gemm_t(const GemmP& p, hipStream_t s) {
   // problems stage several k-panels per barrier (64 KiB of LDS per block at most)
   constexpr bool BF = sizeof(T) == 2;
   auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  // tuning hook (tools/gemm_bench.py): SATRN_GEMM_FORCE=<bm>x<bn>x<kp> forces one dense bf16 configuration
+  static const char* force = getenv("SATRN_GEMM_FORCE");
+  if (force && AM == AM_DENSE && BF) {
+    int bm = 0, bn = 0, kp = 0;
+    if (sscanf(force, "%dx%dx%d", &bm, &bn, &kp) == 3) {
+#define FORCE_CASE(BM_, BN_, KP_) if (bm == BM_ && bn == BN_ && kp == KP_) { hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, AM, (AM == AM_DENSE && BF) ? KP_ : 1>), dim3(blocks(BM_, BN_)), dim3(256), 0, s, p); return; }
+      FORCE_CASE(64, 64, 1) FORCE_CASE(64, 64, 2) FORCE_CASE(64, 64, 4) FORCE_CASE(128, 64, 1) FORCE_CASE(128, 64, 2)
+      FORCE_CASE(128, 128, 1) FORCE_CASE(128, 128, 2) FORCE_CASE(256, 32, 1)
+#undef FORCE_CASE
+    }
+  }
   const int nk32 = (p.K + 31) / 32;
-  const bool deep = (AM == AM_DENSE) && nk32 >= 4;
+  // measured on MI355X (tools/gemm_bench.py): 64x64 tiles win until the 128x128 grid has >= 4 blocks per CU; staging
+  // KP panels per barrier pays only while >= 3 barriers remain (K=256: KP=2 beats KP=4 by 35 %)
+  constexpr bool D = AM == AM_DENSE;
+  const int kp = !D ? 1 : (nk32 >= 16 ? 4 : (nk32 >= 6 ? 2 : 1));
   if (p.N <= 32) {
     hipLaunchKernelGGL((gemm_kernel<T, 256, 32, AM, 1>), dim3(blocks(256, 32)), dim3(256), 0, s, p);
-  } else if (p.N <= 64 || blocks(128, 128) < 256) {
-    if (blocks(128, 64) >= 512) {
-      if (deep) hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AM, (AM == AM_DENSE ? 2 : 1)>), dim3(blocks(128, 64)), dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AM, 1>), dim3(blocks(128, 64)), dim3(256), 0, s, p);
-    } else {
-      if (deep && nk32 >= 8) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, (AM == AM_DENSE ? (BF ? 4 : 2) : 1)>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
-      else if (deep) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, (AM == AM_DENSE ? 2 : 1)>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, 1>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
-    }
-  } else {
-    if (deep && BF) hipLaunchKernelGGL((gemm_kernel<T, 128, 128, AM, (AM == AM_DENSE && BF ? 2 : 1)>), dim3(blocks(128, 128)), dim3(256), 0, s, p);
+  } else if (p.N <= 64 && blocks(128, 64) >= 512) {
+    if (kp >= 2) hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AM, (D ? 2 : 1)>), dim3(blocks(128, 64)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AM, 1>), dim3(blocks(128, 64)), dim3(256), 0, s, p);
+  } else if (p.N > 64 && blocks(128, 128) >= 1024) {
+    if (kp >= 2 && BF) hipLaunchKernelGGL((gemm_kernel<T, 128, 128, AM, (D && BF ? 2 : 1)>), dim3(blocks(128, 128)), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<T, 128, 128, AM, 1>), dim3(blocks(128, 128)), dim3(256), 0, s, p);
+  } else {
+    if (kp == 4 && BF) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, (D && BF ? 4 : 1)>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
+    else if (kp >= 2) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, (D ? 2 : 1)>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, 1>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
   }
 }
 
