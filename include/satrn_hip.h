@@ -154,10 +154,11 @@ int satrn_cross_entropy(int dtype, const float* logits, const int64_t* targets, 
                         int pad_id, float* loss_out, float* lse_ws, void* dlogits, void* stream);
 
 /* clip_grad_norm_(max_norm) + AdamW.step over flat fp32 buffers: train_modules/train_single_opt.py:95-98.
- * gnorm_sq: device float, ZERO on entry (receives sum of squares).  hyper (device, 9 floats):
+ * gnorm_sq: device float, ZERO on entry (receives sum of squares, reduced in a fixed order so that data-parallel
+ * replicas stay bit-identical); scratch1024: 1024 device floats.  hyper (device, 9 floats):
  * lr, beta1, beta2, eps, weight_decay, max_norm, 1-beta1^t, 1-beta2^t, grad_scale. */
 int satrn_clip_adamw(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float* gnorm_sq,
-                     const float* hyper, void* stream);
+                     float* scratch1024, const float* hyper, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Model level: the whole nn.Module path behind one handle.

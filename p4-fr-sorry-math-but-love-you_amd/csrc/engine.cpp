@@ -296,6 +296,7 @@ Model* model_create(const SatrnConfig& cfg) {
   m->off_adam_m = take((size_t)m->n_params * 4);
   m->off_adam_v = take((size_t)m->n_params * 4);
   m->off_scalars = take(SC_COUNT * 4);
+  m->off_sumsq = take(1024 * 4);
   m->off_pe1d = take((size_t)500 * Dd * 4);
   if (cfg.network == 0) { m->feat_h = cfg.height / 16; m->feat_w = cfg.width / 16; }
   else { m->feat_h = cfg.height / 32; m->feat_w = cfg.width / 32; }
@@ -1005,7 +1006,7 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
     }
     if (phase & 2) {
       launch_fill(scal(m) + SC_GNORM, 0, 4, s);
-      launch_sumsq(m->grads, m->n_params, scal(m) + SC_GNORM, s);
+      launch_sumsq(m->grads, m->n_params, scal(m) + SC_GNORM, (float*)(m->ws + m->off_sumsq), s);
       launch_adamw(m->params, m->grads, (float*)(m->ws + m->off_adam_m), (float*)(m->ws + m->off_adam_v), m->n_params,
                    scal(m) + SC_GNORM, scal(m) + SC_HYPER, s);
       return model_pack_weights(m, s);

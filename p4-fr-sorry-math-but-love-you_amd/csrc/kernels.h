@@ -127,7 +127,7 @@ void launch_pack_dw(int dt, const float* w /*[C][9]*/, void* out /*[9][C]*/, int
 struct PackDesc { const float* src; void* fwd; void* bwd; long start; int kind, N, K, ldb; };
 #define PACK_BLK 4096
 void launch_pack_all(int dt, const PackDesc* d, const void* blk_table /*int2 (desc, chunk) per block*/, int nblk, hipStream_t s);
-void launch_sumsq(const float* g, long n, float* out /*[1] +=*/, hipStream_t s);
+void launch_sumsq(const float* g, long n, float* out /*[1] +=*/, float* partial /*[1024] scratch*/, hipStream_t s);
 void launch_adamw(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, const float* hyper,
                   hipStream_t s);
 

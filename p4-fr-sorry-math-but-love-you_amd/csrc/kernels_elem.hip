@@ -1292,7 +1292,10 @@ void launch_pack_all(int dt, const PackDesc* d, const void* blk, int nblk, hipSt
 }
 
 // ---- global grad-norm clip + AdamW over the flat parameter buffer ----------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* out) {
+// deterministic two-stage sum of squares (fixed grid, fixed reduction order): data-parallel replicas must derive
+// bit-identical clip factors from their identical all-reduced gradients, or they drift apart
+#define SUMSQ_BLOCKS 1024
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* partial) {
   __shared__ float red[4];
   float s = 0.f;
   long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4;
@@ -1306,10 +1309,20 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, floa
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-void launch_sumsq(const float* g, long n, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, 256, 1024)), dim3(256), 0, s, g, n, out);
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* partial, int nb, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out += (red[0] + red[1]) + (red[2] + red[3]);
+}
+void launch_sumsq(const float* g, long n, float* out, float* partial /*[SUMSQ_BLOCKS] scratch*/, hipStream_t s) {
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, g, n, partial);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, partial, SUMSQ_BLOCKS, out);
 }
 // hyper: [0] lr [1] beta1 [2] beta2 [3] eps [4] weight_decay [5] max_norm [6] 1-beta1^t [7] 1-beta2^t [8] grad_scale
 __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq,

@@ -285,8 +285,9 @@ int satrn_cross_entropy(int dt, const float* logits, const int64_t* targets, int
   launch_ce_full(dt, logits, targets, ld, 0, B, T, V, Vp, pad_id, loss_out, lse_ws, dlogits, nullptr, S(st));
   return done("cross_entropy");
 }
-int satrn_clip_adamw(float* p, const float* g, float* m, float* v, long n, float* gnorm_sq, const float* hyper, void* st) {
-  launch_sumsq(g, n, gnorm_sq, S(st));
+int satrn_clip_adamw(float* p, const float* g, float* m, float* v, long n, float* gnorm_sq, float* scratch1024,
+                     const float* hyper, void* st) {
+  launch_sumsq(g, n, gnorm_sq, scratch1024, S(st));
   launch_adamw(p, g, m, v, n, gnorm_sq, hyper, S(st));
   return done("clip_adamw");
 }

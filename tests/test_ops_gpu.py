@@ -422,7 +422,8 @@ def test_embedding_ce_adamw(lib, dt):
         pd, md, vd = dev(p), dev(m), dev(v)
         gn = torch.zeros(1, device="cuda")
         hy = dev(torch.tensor([5e-4, 0.9, 0.999, 1e-8, 1e-6, 2.0, 1 - 0.9, 1 - 0.999, 1.0]))
-        ok(lib, lib.satrn_clip_adamw(P(pd), P(dev(g)), P(md), P(vd), n, P(gn), P(hy), st()))
+        scr = torch.zeros(1024, device="cuda")
+        ok(lib, lib.satrn_clip_adamw(P(pd), P(dev(g)), P(md), P(vd), n, P(gn), P(scr), P(hy), st()))
         close(pd, pr["p"], "f32", "clip_adamw", f32_tol=1e-6)
         assert abs(math.sqrt(gn.item()) - g.norm().item()) < 1e-3
 
