@@ -211,9 +211,10 @@ int satrn_model_train_step(satrn_model* m, const float* images, const int64_t* e
 int satrn_model_read_loss(satrn_model* m, float* out4_host, void* stream); /* sum, count, mean, gnorm^2; syncs */
 int satrn_model_encode(satrn_model* m, const float* images, int B, float* src_out, void* stream);
 /* KV-cached greedy decode; images may be NULL when src (fp32 [B][N][dec_src]) is given.
- * logits fp32 [B][steps][V]; ids int64 [B][steps] */
+ * logits fp32 [B][steps][V]; ids int64 [B][steps].  use_graph != 0 captures the whole decode (encoder + all steps)
+ * once per (B, steps, buffer addresses) and replays it: the four buffers must then stay at the same addresses. */
 int satrn_model_greedy(satrn_model* m, const float* images, const float* src, int B, int steps, float* logits,
-                       int64_t* ids, void* stream);
+                       int64_t* ids, int use_graph, void* stream);
 /* One EAGER forward + CE + backward with every kernel launch bracketed by HIP events on `stream`; writes a JSON array
  * [{"kernel", "launches", "ms", "flops", "bytes"}...] (per kernel family, algorithmic flops / bytes) to json_out. */
 int satrn_model_profile_step(satrn_model* m, const float* images, const int64_t* expected, int B, int L, char* json_out,

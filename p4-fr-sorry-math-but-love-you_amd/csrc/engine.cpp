@@ -334,6 +334,7 @@ int model_bind(Model* m, float* params, float* grads, float* buf_f32, int64_t* b
   m->bound = true;
   m->pack_dirty = true;
   for (int i = 0; i < 4; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
+  if (m->decode_graph) { (void)hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
   return 0;
 }
 
@@ -351,6 +352,7 @@ int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s) {
     w->bwd = w->pk_bwd_off >= 0 ? m->ws + w->pk_bwd_off : nullptr;
   }
   for (int i = 0; i < 4; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
+  if (m->decode_graph) { (void)hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
   // tables: 1-D PE (networks/EfficientSATRN.py:408-418) and 2-D PE (:111-127), built in fp32 like the reference
   const int Dd = m->cfg.dec_hidden, D = m->cfg.enc_hidden;
   std::vector<float> pe((size_t)500 * Dd);
@@ -1016,6 +1018,7 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
   if (!use_graph) return body();
   if (m->graph_B != B || m->graph_L != L) {
     for (int i = 0; i < 4; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
+  if (m->decode_graph) { (void)hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
     m->graph_B = B; m->graph_L = L;
   }
   hipGraphExec_t& gx = m->graphs[phase];
@@ -1058,10 +1061,8 @@ int model_encode(Model* m, const float* img, int B, float* src_out, hipStream_t 
 // Greedy decode with the reference's step semantics (networks/EfficientSATRN.py:528-561, :386-396): the
 // self-attention history of a layer is k/v_linear of that layer's previous OUTPUTS plus the current INPUT.
 // KV-cached: slot t first holds k/v(input_t), is attended, then is overwritten with k/v(output_t).
-int model_greedy(Model* m, const float* img, const float* src_in, int B, int steps, float* logits_out, int64_t* ids_out,
-                 hipStream_t s) {
-  if (!m->bound || !m->ws_set) { m->err = "bind parameters and set a workspace first"; return -1; }
-  if (steps > 500) { m->err = "max 500 decode steps (PositionEncoder1D max_len)"; return -1; }
+static int greedy_body(Model* m, const float* img, const float* src_in, int B, int steps, float* logits_out, int64_t* ids_out,
+                       hipStream_t s) {
   Exec& e = *m->ex;
   const SatrnConfig& c = m->cfg;
   const int Dd = c.dec_hidden, V = c.num_classes;
@@ -1083,11 +1084,7 @@ int model_greedy(Model* m, const float* img, const float* src_in, int B, int ste
     cache[l] = e.newt((long)B * steps, 2 * Dd, B);
   }
   int64_t* sos = (int64_t*)e.alloc((size_t)B * 8);
-  {
-    std::vector<int64_t> h(B, c.sos_id);
-    (void)hipMemcpyAsync(sos, h.data(), (size_t)B * 8, hipMemcpyHostToDevice, s);
-    (void)hipStreamSynchronize(s);
-  }
+  launch_fill_i64(sos, c.sos_id, B, s);
   const size_t mark = e.off;
   const size_t keep = e.tens.size();
   const float inv_temp = 1.0f / sqrtf((float)Dd);
@@ -1174,4 +1171,29 @@ int model_profile_step(Model* m, const float* img, const int64_t* expected, int 
   js += "]";
   if (out && out_cap) { strncpy(out, js.c_str(), out_cap - 1); out[out_cap - 1] = 0; }
   return rc;
+}
+
+// Greedy decode entry: eager, or (use_graph) the whole decode -- encoder + every step's ~45 launches -- captured once
+// per (B, steps, buffer addresses) and replayed, which removes the host launch cost of ~10^4 kernels per batch.
+int model_greedy(Model* m, const float* img, const float* src_in, int B, int steps, float* logits_out, int64_t* ids_out,
+                 int use_graph, hipStream_t s) {
+  if (!m->bound || !m->ws_set) { m->err = "bind parameters and set a workspace first"; return -1; }
+  if (steps > 500) { m->err = "max 500 decode steps (PositionEncoder1D max_len)"; return -1; }
+  if (!use_graph) return greedy_body(m, img, src_in, B, steps, logits_out, ids_out, s);
+  const void* key[6] = {img, src_in, logits_out, ids_out, (void*)(intptr_t)B, (void*)(intptr_t)steps};
+  if (m->decode_graph && memcmp(key, m->decode_key, sizeof(key)) != 0) { (void)hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
+  if (!m->decode_graph) {
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) { m->err = "stream capture failed"; return -3; }
+    int rc = greedy_body(m, img, src_in, B, steps, logits_out, ids_out, s);
+    hipError_t er = hipStreamEndCapture(s, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (er != hipSuccess || !g) { m->err = "decode graph capture failed"; return -3; }
+    if (hipGraphInstantiate(&m->decode_graph, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); m->err = "decode graph instantiate failed"; return -3; }
+    (void)hipGraphDestroy(g);
+    memcpy(m->decode_key, key, sizeof(key));
+  }
+  (void)hipStreamSynchronize(s);
+  if (hipGraphLaunch(m->decode_graph, s) != hipSuccess) { m->err = "decode graph launch failed"; return -3; }
+  return 0;
 }

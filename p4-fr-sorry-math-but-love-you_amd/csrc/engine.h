@@ -100,6 +100,7 @@ struct Model {
   struct Exec* ex = nullptr;
   hipGraphExec_t graphs[4] = {nullptr, nullptr, nullptr, nullptr}; int graph_B = 0, graph_L = 0;
   long adam_t = 0;
+  hipGraphExec_t decode_graph = nullptr; const void* decode_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float* hy_pinned = nullptr;
   std::string err;
 };
@@ -148,6 +149,6 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
 int model_read_loss(Model* m, float* out4, hipStream_t s);
 int model_encode(Model* m, const float* img, int B, float* src_out, hipStream_t s);
 int model_greedy(Model* m, const float* img, const float* src_or_null, int B, int steps, float* logits_out,
-                 int64_t* ids_out, hipStream_t s);
+                 int64_t* ids_out, int use_graph, hipStream_t s);
 int model_profile_step(Model* m, const float* img, const int64_t* expected, int B, int L, char* out, size_t out_cap,
                        hipStream_t s);

@@ -117,6 +117,7 @@ void launch_fill(void* p, int value_byte, size_t bytes, hipStream_t s);
 void launch_add(int dt, const void* a, const void* b, void* out, long n, hipStream_t s);
 void launch_argmax(const float* logits, int64_t* ids, int R, int V, int ld_in, int ld_out, hipStream_t s);
 void launch_seed_advance(uint32_t* seed, hipStream_t s);
+void launch_fill_i64(int64_t* p, int64_t v, long n, hipStream_t s);
 
 // ---- weight packing + optimizer --------------------------------------------------------------
 void launch_pack_dense(int dt, const float* w, void* fwd /*[N][K]*/, void* bwd /*[K][N]*/, int N, int K, hipStream_t s);

@@ -1191,6 +1191,10 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int64_
 void launch_argmax(const float* logits, int64_t* ids, int R, int V, int ld_in, int ld_out, hipStream_t s) {
   hipLaunchKernelGGL(argmax_kernel, dim3((R + 3) / 4), dim3(256), 0, s, logits, ids, R, V, ld_in, ld_out);
 }
+__global__ void fill_i64_kernel(int64_t* p, int64_t v, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill_i64(int64_t* p, int64_t v, long n, hipStream_t s) { hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, v, n); }
 __global__ void seed_advance_kernel(uint32_t* seed) { *seed = mix32(*seed + 0x9E3779B9u); }
 void launch_seed_advance(uint32_t* seed, hipStream_t s) { hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, s, seed); }
 

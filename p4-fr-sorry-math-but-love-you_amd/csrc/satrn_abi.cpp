@@ -351,8 +351,8 @@ int satrn_model_train_step(satrn_model* h, const float* img, const int64_t* exp,
 int satrn_model_read_loss(satrn_model* h, float* out4, void* st) { return mret(h, model_read_loss(h->m, out4, S(st)), "read_loss"); }
 int satrn_model_encode(satrn_model* h, const float* img, int B, float* src, void* st) { return mret(h, model_encode(h->m, img, B, src, S(st)), "encode"); }
 int satrn_model_greedy(satrn_model* h, const float* img, const float* src, int B, int steps, float* logits, int64_t* ids,
-                       void* st) {
-  return mret(h, model_greedy(h->m, img, src, B, steps, logits, ids, S(st)), "greedy");
+                       int use_graph, void* st) {
+  return mret(h, model_greedy(h->m, img, src, B, steps, logits, ids, use_graph, S(st)), "greedy");
 }
 int satrn_model_profile_step(satrn_model* h, const float* img, const int64_t* exp, int B, int L, char* json_out,
                              size_t cap, void* st) {
