@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (single chain) instead of eager two-stream launches")
     ap.add_argument("--no-decode", action="store_true")
     args = ap.parse_args()
 
@@ -118,7 +118,7 @@ def main():
     model.train()
     img, exp = synth(B, H, W, T, 21 + rank, dev)
     lr = 5e-4
-    graph = not args.no_graph
+    graph = args.graph
 
     from satrn_amd import dp
 
@@ -174,7 +174,7 @@ def main():
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                    config=dict(workload="EfficientSATRN train step (fwd+CE+bwd+clip+AdamW), bs32/GPU, 1x128x384, teacher-forced T=128, dropout 0.1 (BASELINE configs[1])",
-                               global_batch=world * B, seq_len=T, parallelism=f"dp{world}", hipgraph=graph),
+                               global_batch=world * B, seq_len=T, parallelism=f"dp{world}", hipgraph=graph, streams=1 if graph else 2),
                    roofline=roof, final_loss=round(loss, 4), grad_norm=round(gnorm, 4),
                    kernel_breakdown=[dict(kernel=p["kernel"], launches=p["launches"], ms=round(p["ms"], 3)) for p in prof[:12]])
         if world == 1 and not args.no_decode:

@@ -8,6 +8,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -34,9 +35,43 @@ void Exec::prof_begin(const char* call) {
 }
 void Exec::prof_end() { (void)hipEventRecord(prof->back().b, s); }
 
+// Fork: everything launched on side() after this call may run concurrently with the main chain from this point on.
+// Weight gradients are off the critical path (they are only needed by the optimizer), and the small late-stage kernels
+// leave most CUs idle, so they go to the side stream; join() makes the main stream wait for all of them.
+hipStream_t Exec::side() {
+  if (!s2 || dry) return s;
+  forked = true;
+  return s2;
+}
+// Side launches are queued (they only need their inputs, which the main stream has already been asked to produce) and
+// flushed a few closures later behind ONE event: keeps the host cost of forking at ~1/8 of an event pair per launch.
+void Exec::defer(std::function<void(hipStream_t)> fn) {
+  if (!s2 || dry) { fn(s); return; }
+  pending.push_back(std::move(fn));
+  if (pending.size() >= 8) flush_side();
+}
+void Exec::flush_side() {
+  if (pending.empty()) return;
+  if (nfork >= (int)evs.size()) { hipEvent_t ev; (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming); evs.push_back(ev); }
+  hipEvent_t ev = evs[nfork++];
+  (void)hipEventRecord(ev, s);
+  (void)hipStreamWaitEvent(s2, ev, 0);
+  for (auto& f : pending) f(s2);
+  pending.clear();
+  forked = true;
+}
+void Exec::join() {
+  flush_side();
+  if (!s2 || dry || !forked) return;
+  if (!evj) (void)hipEventCreateWithFlags(&evj, hipEventDisableTiming);
+  (void)hipEventRecord(evj, s2);
+  (void)hipStreamWaitEvent(s, evj, 0);
+  forked = false;
+}
+
 void Exec::reset(char* b, size_t c, char* zb, size_t zc) {
   base = b; cap = c; off = 0; zbase = zb; zcap = zc; zoff = 0; site = 1;
-  tape.clear(); tens.clear(); logits = nullptr; src = nullptr; oom = false;
+  tape.clear(); tens.clear(); logits = nullptr; src = nullptr; oom = false; nfork = 0; forked = false;
 }
 void* Exec::alloc(size_t bytes) {
   size_t a = (off + 255) & ~(size_t)255;
@@ -315,6 +350,7 @@ Model* model_create(const SatrnConfig& cfg) {
   m->persist_bytes = (o + 255) & ~(size_t)255;
   m->ex = new Exec();
   m->ex->m = m;
+  if (!getenv("SATRN_NO_SIDE_STREAM")) (void)hipStreamCreateWithFlags(&m->ex->s2, hipStreamNonBlocking);
   return m;
 }
 
@@ -483,7 +519,6 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       if (act == ACT_RELU) LCH(e, launch_act_bwd(e.dt, dY, y->p, dY, M * N, ACT_RELU, drop_p, e.s));
       else if (act == ACT_SIGMOID) LCH(e, launch_act_bwd(e.dt, dY, y->p, dY, M * N, ACT_SIGMOID, 0.f, e.s));
       else if (drop_p > 0.f) LCH(e, launch_dropout_bwd(e.dt, dY, dY, M, N, drop_p, seed, site, e.s));
-      if (bias) LCH(e, launch_colsum(e.dt, dY, M, N, ldy, bias->g, e.s));
       WgradP q;
       memset(&q, 0, sizeof(q));
       q.dY = dY; q.A = x->p; q.dW = w->g; q.M = (int)M; q.N = N; q.K = w->K; q.ldy = ldy; q.lda = x->C;
@@ -495,9 +530,22 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
         tmp = e.zalloc((size_t)N * w->K);
         q.conv_packed_out = 1; q.dW = tmp;
       }
-      e.nflops = 2.0 * (double)M * N * w->K;
-      LCH(e, launch_wgrad(e.dt, q, e.s));
-      if (tmp) LCH(e, launch_conv_grad_unpack(tmp, w->g, N, g.Ci, 9, e.s));
+      {
+        const int dt = e.dt; const bool dry = e.dry;
+        float* bg = bias ? bias->g : nullptr; float* wg = w->g; const int Ci = g.Ci;
+        if (e.prof || dry) {
+          if (bias) LCH(e, launch_colsum(dt, dY, M, N, ldy, bg, e.s));
+          e.nflops = 2.0 * (double)M * N * w->K;
+          LCH(e, launch_wgrad(dt, q, e.s));
+          if (tmp) LCH(e, launch_conv_grad_unpack(tmp, wg, N, Ci, 9, e.s));
+        } else {
+          e.defer([=](hipStream_t ws) {
+            if (bg) launch_colsum(dt, dY, M, N, ldy, bg, ws);
+            launch_wgrad(dt, q, ws);
+            if (tmp) launch_conv_grad_unpack(tmp, wg, N, Ci, 9, ws);
+          });
+        }
+      }
       int beta;
       void* dx = e.grad(x, &beta);
       GemmP d;
@@ -572,7 +620,11 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
     e.tape.push_back([&e, x, y, w, bias, B, H, W, C, OH, OW, stride, pt, pl]() {
       if (!y->g) return;
       float* scr = e.zalloc((size_t)10 * C);
-      LCH(e, launch_dwconv_wgrad(e.dt, x->p, y->g, w->g, bias ? bias->g : nullptr, scr, B, H, W, C, OH, OW, stride, pt, pl, e.s));
+      {
+        const int dt = e.dt; void* xp = x->p; void* yg = y->g; float* wg = w->g; float* bg = bias ? bias->g : nullptr;
+        if (e.prof || e.dry) LCH(e, launch_dwconv_wgrad(dt, xp, yg, wg, bg, scr, B, H, W, C, OH, OW, stride, pt, pl, e.s));
+        else e.defer([=](hipStream_t ws) { launch_dwconv_wgrad(dt, xp, yg, wg, bg, scr, B, H, W, C, OH, OW, stride, pt, pl, ws); });
+      }
       int beta;
       void* dx = e.grad(x, &beta);
       LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, nullptr, e.s));
@@ -950,6 +1002,7 @@ int model_forward(Model* m, const float* img, const int64_t* expected, int B, in
 static void run_tape(Exec& e) {
   for (auto it = e.tape.rbegin(); it != e.tape.rend(); ++it) (*it)();
   e.tape.clear();
+  e.join();
 }
 
 int model_backward(Model* m, const float* dlogits, hipStream_t s) {
@@ -1144,10 +1197,13 @@ int model_profile_step(Model* m, const float* img, const int64_t* expected, int 
   Exec& e = *m->ex;
   std::vector<ProfRec> recs;
   e.prof = &recs;
+  hipStream_t keep_s2 = e.s2;
+  e.s2 = nullptr;  // per-launch event timing needs a single stream
   (void)hipMemsetAsync(m->grads, 0, (size_t)m->n_params * 4, s);
   int rc = model_forward(m, img, expected, B, L, true, true, nullptr, s);
   if (!rc) rc = model_loss_backward(m, expected, B, L, s);
   e.prof = nullptr;
+  e.s2 = keep_s2;
   (void)hipStreamSynchronize(s);
   struct Agg { double ms = 0, flops = 0, bytes = 0; long n = 0; };
   std::vector<std::pair<std::string, Agg>> agg;

@@ -125,6 +125,9 @@ struct Exec {
   std::vector<std::unique_ptr<Tensor>> tens;
   Tensor* logits = nullptr; Tensor* src = nullptr;
   bool oom = false;
+  hipStream_t s2 = nullptr; std::vector<hipEvent_t> evs; hipEvent_t evj = nullptr; int nfork = 0; bool forked = false;
+  hipStream_t side(); void join();
+  std::vector<std::function<void(hipStream_t)>> pending; void defer(std::function<void(hipStream_t)> fn); void flush_side();
 
   void* alloc(size_t bytes);
   float* zalloc(size_t nfloats);
