@@ -166,6 +166,13 @@ def main():
             ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
             roof = dict(bound="hbm", achieved=round(ach, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 5), traffic=None)
         roof["kernel"] = dom["kernel"]
+        try:  # HBM bytes per launch of this kernel family from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["families"].get(dom["kernel"])
+            if pmc:
+                roof["traffic"] = pmc["hbm_bytes_per_launch"]
+                roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(dom["launches"], 1))
+        except Exception:
+            pass
         roof["launches_per_step"] = dom["launches"]
         roof["avg_launch_us"] = round(dom["ms"] * 1e3 / max(dom["launches"], 1), 3)
         roof["share_of_step_kernel_time"] = round(dom["ms"] / max(tot_ms, 1e-9), 4)
