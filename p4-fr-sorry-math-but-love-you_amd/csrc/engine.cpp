@@ -504,7 +504,11 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
   p.A = x->p; p.Bw = w->fwd; p.C = y->p; p.bias = bias ? bias->p : nullptr;
   p.M = (int)M; p.N = N; p.K = w->K; p.lda = x->C; p.ldc = N;
   p.act = act; p.out_f32 = out_f32 ? 1 : 0; p.drop_p = drop_p; p.seed = seed; p.site = site;
-  if (want_stats && e.train) { y->stats = e.zalloc(2 * N); p.stats = y->stats; }
+  if (want_stats && e.train) {
+    // tall, narrow outputs (early backbone stages): many row tiles hit the same 2N addresses -> spread over replicas
+    const int rep = (N <= 64 && M >= 65536) ? 16 : ((N <= 256 && M >= 16384) ? 4 : 1);
+    y->stats = e.zalloc((size_t)rep * 2 * N); y->stats_rep = rep; p.stats = y->stats; p.stats_rep = rep;
+  }
   if (geo) { p.H = geo->H; p.W = geo->W; p.Ci = geo->Ci; p.OH = geo->OH; p.OW = geo->OW; p.KW = geo->KW; p.stride = geo->stride; p.pt = geo->pt; p.pl = geo->pl; }
   e.nflops = 2.0 * (double)M * N * w->K; e.nbytes = ((double)x->rows * x->C + (double)M * N + (double)N * w->K) * e.esz();
   LCH(e, launch_gemm(e.dt, geo ? AM_CONV : AM_DENSE, p, e.s));
@@ -582,7 +586,7 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res) {
   }
   Tensor* z = e.newt(M, C, y->B, y->H, y->W);
   e.nbytes = (double)M * C * e.esz() * (res ? 3 : 2);
-  LCH(e, launch_bn_act(e.dt, y->p, sums, bn->w.p, bn->b.p, bn->rm, bn->rv, e.train ? bn->nbt : nullptr, bn->eps, 0.1f, ss, mr,
+  LCH(e, launch_bn_act(e.dt, y->p, sums, y->stats ? y->stats_rep : 1, bn->w.p, bn->b.p, bn->rm, bn->rv, e.train ? bn->nbt : nullptr, bn->eps, 0.1f, ss, mr,
                        res ? res->p : nullptr, z->p, M, C, act, e.s));
   if (e.rec) {
     e.tape.push_back([&e, y, z, bn, act, res, ss, mr, M, C]() {

@@ -61,6 +61,7 @@ struct Tensor {
   int B = 0, H = 0, W = 0;
   bool g_init = false;
   bool f32 = false;  // logits
+  int stats_rep = 1;
   float* stats = nullptr;  // [2C] column sum / sum of squares written by the producing kernel (BatchNorm input)
 };
 

@@ -16,7 +16,8 @@ struct GemmP {
   int act, beta, out_f32;
   float drop_p; const uint32_t* seed; uint32_t site;
   const float* ascale; int ascale_hw;  // optional A[m][k] *= ascale[(m/ascale_hw)*K + k]  (SE gate), dense only
-  float* stats;  // optional [2N] (zeroed): per-column sum / sum of squares of the output (for the BatchNorm that follows)
+  float* stats;  // optional [stats_rep][2N] (zeroed): per-column sum / sum of squares of the output (for the BatchNorm that follows)
+  int stats_rep; // replicas (>= 1) the row tiles spread their atomics over; the consumer sums them
 };
 void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s);
 
@@ -58,9 +59,9 @@ void launch_bn_finalize(const float* sums, long M, int C, const float* w, const 
                         float* mean_rstd /*[2C]*/, hipStream_t s);
 // finalize folded in: sums != null -> batch statistics (running stats updated, momentum mom), else running statistics;
 // writes scale/shift and mean/rstd for the backward
-void launch_bn_act(int dt, const void* y, const float* sums, const float* w, const float* b, float* rm, float* rv,
-                   int64_t* nbt, float eps, float mom, float* scale_shift, float* mean_rstd, const void* res, void* z,
-                   long M, int C, int act, hipStream_t s);
+void launch_bn_act(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm,
+                   float* rv, int64_t* nbt, float eps, float mom, float* scale_shift, float* mean_rstd, const void* res,
+                   void* z, long M, int C, int act, hipStream_t s);
 void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* scale_shift, const float* mean_rstd,
                           long M, int C, int act, float* red /*[2C] zeroed*/, hipStream_t s);
 void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* scale_shift, const float* mean_rstd,

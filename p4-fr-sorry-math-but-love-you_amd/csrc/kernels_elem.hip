@@ -153,7 +153,7 @@ static inline int grid_chan(long nchunks, int CC) {
 }
 
 template <typename T>
-__global__ void bn_act_kernel(const T* y, const float* sums, const float* w, const float* b, float* rm, float* rv,
+__global__ void bn_act_kernel(const T* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv,
                               int64_t* nbt, float eps, float mom, float invM, float unbias, float* ss, float* mr,
                               const T* res, T* z, long nchunks, int C, int act) {
   constexpr int CH = TT<T>::CH;
@@ -167,6 +167,12 @@ __global__ void bn_act_kernel(const T* y, const float* sums, const float* w, con
     float mean[CH], var[CH], ww[CH], bb[CH];
     if (sums) {
       ldv(sums + c0, mean, CH); ldv(sums + C + c0, var, CH);
+      for (int rp = 1; rp < sums_rep; ++rp) {
+        float t0[CH], t1[CH];
+        ldv(sums + (size_t)rp * 2 * C + c0, t0, CH); ldv(sums + (size_t)rp * 2 * C + C + c0, t1, CH);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { mean[j] += t0[j]; var[j] += t1[j]; }
+      }
 #pragma unroll
       for (int j = 0; j < CH; ++j) { mean[j] *= invM; var[j] = fmaxf(var[j] * invM - mean[j] * mean[j], 0.f); }
     } else {
@@ -201,16 +207,16 @@ __global__ void bn_act_kernel(const T* y, const float* sums, const float* w, con
     st16(z + i * CH, pack<T>(v));
   }
 }
-void launch_bn_act(int dt, const void* y, const float* sums, const float* w, const float* b, float* rm, float* rv,
-                   int64_t* nbt, float eps, float mom, float* ss, float* mr, const void* res, void* z, long M, int C,
-                   int act, hipStream_t s) {
+void launch_bn_act(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm,
+                   float* rv, int64_t* nbt, float eps, float mom, float* ss, float* mr, const void* res, void* z, long M,
+                   int C, int act, hipStream_t s) {
   float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
   DISPATCH_T(dt, {
     long n = M * C / TT<T>::CH;
     int CC = C / TT<T>::CH;
     int g = grid_chan(n, CC);
     while ((long)g * 256 < CC) g *= 2;
-    hipLaunchKernelGGL((bn_act_kernel<T>), dim3(g), dim3(256), 0, s, (const T*)y, sums, w, b, rm, rv, nbt, eps, mom,
+    hipLaunchKernelGGL((bn_act_kernel<T>), dim3(g), dim3(256), 0, s, (const T*)y, sums, sums_rep < 1 ? 1 : sums_rep, w, b, rm, rv, nbt, eps, mom,
                        1.0f / (float)M, unbias, ss, mr, (const T*)res, (T*)z, n, C, act);
   });
 }
@@ -1064,7 +1070,14 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const 
       if (t != pad_id) { lsum += lse - x[t]; lcnt += 1.f; }
     }
   }
-  if (lane == 0 && lcnt > 0.f) { atomicAdd(out, lsum); atomicAdd(out + 1, lcnt); }
+  // one pair of atomics per BLOCK (thousands of same-address float atomics serialise at ~20 ns each)
+  __shared__ float bsum[2][4];
+  if (lane == 0) { bsum[0][wv] = lsum; bsum[1][wv] = lcnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = bsum[0][0] + bsum[0][1] + bsum[0][2] + bsum[0][3], b = bsum[1][0] + bsum[1][1] + bsum[1][2] + bsum[1][3];
+    if (b > 0.f) { atomicAdd(out, a); atomicAdd(out + 1, b); }
+  }
 }
 template <typename TO>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, const int64_t* tgt, int ld_tgt, int tgt_off,
@@ -1103,7 +1116,7 @@ void launch_ce_full(int dt_out, const float* logits, const int64_t* tgt, int ld_
                     const float* upstream, hipStream_t s) {
   long R = (long)B * T_;
   launch_fill(loss_out, 0, 4 * sizeof(float), s);
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid_for(R, 4, 2048)), dim3(256), 0, s, logits, tgt, ld_tgt, tgt_off, T_, V,
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid_for(R, 16, 256)), dim3(256), 0, s, logits, tgt, ld_tgt, tgt_off, T_, V,
                      pad_id, R, loss_out, lse_ws);
   if (dt_out == DT_BF16) launch_ce_bwd_t<bf16_t>(logits, tgt, ld_tgt, tgt_off, B, T_, V, Vp, pad_id, loss_out, lse_ws, dlogits, upstream, s);
   else launch_ce_bwd_t<float>(logits, tgt, ld_tgt, tgt_off, B, T_, V, Vp, pad_id, loss_out, lse_ws, dlogits, upstream, s);

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     __syncthreads();
     for (int i = tid; i < 2 * BN; i += 256) {
       int c = i < BN ? i : i - BN, col = n0 + c;
-      if (col < p.N) atomicAdd(p.stats + (i < BN ? 0 : p.N) + col, sred[i]);
+      // narrow outputs with a tall grid: spread the same-address atomics over stats_rep replicas of [2N]
+      if (col < p.N) atomicAdd(p.stats + (size_t)(tile_m % p.stats_rep) * 2 * p.N + (i < BN ? 0 : p.N) + col, sred[i]);
     }
   }
 }

@@ -159,7 +159,7 @@ int satrn_batchnorm_act_fwd(int dt, const void* y, const float* w, const float* 
   CHK_DT(dt);
   if (chk_c(dt, C, "C")) return -1;
   if (train) launch_colstats(dt, y, M, C, scratch, S(st));
-  launch_bn_act(dt, y, train ? scratch : nullptr, w, b, rm, rv, train ? nbt : nullptr, eps, 0.1f, scratch + 2 * C, scratch + 4 * C,
+  launch_bn_act(dt, y, train ? scratch : nullptr, 1, w, b, rm, rv, train ? nbt : nullptr, eps, 0.1f, scratch + 2 * C, scratch + 4 * C,
                 res, z, M, C, act, S(st));
   return done("batchnorm_act_fwd");
 }
