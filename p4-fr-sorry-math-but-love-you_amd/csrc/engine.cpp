@@ -1142,6 +1142,28 @@ static int greedy_body(Model* m, const float* img, const float* src_in, int B, i
   }
   int64_t* sos = (int64_t*)e.alloc((size_t)B * 8);
   launch_fill_i64(sos, c.sos_id, B, s);
+  // ---- fast path: the persistent one-launch decoder (one workgroup per image for the whole decode)
+  if (!getenv("SATRN_DECODE_STEPWISE") && L <= 4) {
+    DecodeP dp;
+    memset(&dp, 0, sizeof(dp));
+    for (int l = 0; l < L; ++l) {
+      DecLayer& dl = m->dec[l];
+      DecLayerW& w = dp.L[l];
+      w.wqkv = dl.self_att.qkv.fwd; w.bqkv = dl.self_att.bqkv.p; w.wo = dl.self_att.out.fwd; w.bo = dl.self_att.bout.p;
+      w.wq2 = dl.cross_att.qkv.fwd; w.bq2 = dl.cross_att.bqkv.p; w.wo2 = dl.cross_att.out.fwd; w.bo2 = dl.cross_att.bout.p;
+      w.w0 = dl.lin0.fwd; w.b0 = dl.b0.p; w.w1 = dl.lin1.fwd; w.b1 = dl.b1.p;
+      w.wkv = (char*)dl.self_att.qkv.fwd + (size_t)Dd * Dd * es; w.bkv = dl.self_att.bqkv.p + Dd;
+      w.ln1w = dl.ln1.w.p; w.ln1b = dl.ln1.b.p; w.ln2w = dl.ln2.w.p; w.ln2b = dl.ln2.b.p; w.ln3w = dl.ln3.w.p; w.ln3b = dl.ln3.b.p;
+      w.crossKV = crossKV[l]->p; w.cache = cache[l]->p;
+    }
+    dp.nlayers = L; dp.embed = m->embed.p; dp.pe = (const float*)(m->ws + m->off_pe1d); dp.wgen = m->gen.fwd; dp.bgen = m->gen_b.p;
+    dp.logits = logits_out; dp.ids = ids_out; dp.B = B; dp.steps = steps; dp.D = Dd; dp.F = c.dec_filter; dp.V = V;
+    dp.H = c.dec_heads; dp.Nsrc = Nsrc; dp.sos = c.sos_id;
+    if (launch_decode_greedy(e.dt, dp, s) == 0) {
+      if (e.oom) { m->err = "workspace exhausted"; return -2; }
+      return 0;
+    }
+  }
   const size_t mark = e.off;
   const size_t keep = e.tens.size();
   const float inv_temp = 1.0f / sqrtf((float)Dd);

@@ -139,3 +139,20 @@ void launch_se_fwd(int dt, const void* x, const float* W1, const float* b1, cons
 void launch_se_bwd(int dt, const void* dgate, const void* gate, const float* u1, const float* s1, const float* pooled,
                    const float* W1, const float* W2, float* dz2, float* du1, void* dpooled, float* dW1, float* db1, float* dW2,
                    float* db2, int B, int C, int S, hipStream_t s);
+
+// persistent greedy decoder (kernels_decode.hip): weights are the packed [N][K] compute copies, biases / LN fp32
+struct DecLayerW {
+  const void *wqkv, *wo, *wq2, *wo2, *w0, *w1, *wkv;
+  const float *bqkv, *bo, *bq2, *bo2, *b0, *b1, *bkv, *ln1w, *ln1b, *ln2w, *ln2b, *ln3w, *ln3b;
+  const void* crossKV;  // [B][Nsrc][2D]
+  void* cache;          // [B][steps][2D] scratch
+};
+struct DecodeP {
+  DecLayerW L[4];
+  int nlayers;
+  const float* embed; const float* pe; const void* wgen; const float* bgen;
+  float* logits; int64_t* ids;
+  int B, steps, D, F, V, H, Nsrc, sos;
+  int dbg;  // timing ablation bits (SATRN_DEC_DBG), 0 in production
+};
+int launch_decode_greedy(int dt, const DecodeP& p, hipStream_t s);

@@ -1,0 +1,265 @@
+// Persistent greedy decoder (reference networks/EfficientSATRN.py:528-561 with TransformerDecoderLayer step mode
+// :386-396).  Greedy decoding of one image never looks at another image, so ONE workgroup owns one batch row for the
+// WHOLE decode: all steps, all layers, generator, argmax and the next token's embedding run inside a single kernel
+// launch with no inter-workgroup synchronisation.  Weights (compute dtype, [N][K] row-major) are streamed from
+// L2/Infinity Cache by every workgroup each step; the row's self-attention K/V history lives in a private slice of a
+// global cache, its activations in LDS.  The reference's history quirk is kept: slot t holds k/v(layer input) while
+// step t is attended, then is overwritten with k/v(layer output) for the following steps.
+#include <stdlib.h>
+
+#include "common.h"
+#include "kernels.h"
+
+#define DEC_THREADS 1024
+#define DEC_WAVES (DEC_THREADS / 64)
+
+template <typename T> DEVI void ld4(const T* p, float* o);
+template <> DEVI void ld4<float>(const float* p, float* o) {
+  float4 v = *reinterpret_cast<const float4*>(p);
+  o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <> DEVI void ld4<bf16_t>(const bf16_t* p, float* o) {
+  uint2 v = *reinterpret_cast<const uint2*>(p);
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
+// y[n] = act(bias[n] + sum_k W[n][k] * x[k]) for n in [0,N).  Matrix-vector product on the MFMA: a wave owns 16 outputs
+// at a time, the weight rows are the A operand fetched straight from global memory (16-byte loads, 64 contiguous bytes
+// per row and k-group), the activation vector is the B operand broadcast into all 16 columns from LDS, and the K
+// reduction happens inside the MFMA -- no cross-lane shuffles, and the unrolled k loop keeps 8+ loads in flight per
+// lane, which is what a latency-bound weight stream needs.  xT: the input vector in the compute dtype (LDS).
+template <typename T>
+DEVI void gemv(const T* __restrict__ W, const float* __restrict__ bias, const T* xT, float* y, int N, int K, int act) {
+  constexpr int CH = TT<T>::CH;
+  constexpr int GU = 2;  // 16-output groups per wave iteration: 2 x 8 weight loads in flight per lane
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int ng = (N + 15) >> 4;
+  const T* xr = xT + fq * 8;
+  for (int g0 = wave * GU; g0 < ng; g0 += DEC_WAVES * GU) {
+    const T* wr[GU];
+    f32x4 acc[GU];
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      int row = (g0 + u) * 16 + fr;
+      if (row >= N) row = N - 1;
+      wr[u] = W + (long)row * K + fq * 8;
+      acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 8
+    for (int kk = 0; kk < K; kk += 32) {
+      Frag<T> a[GU], b;
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        reinterpret_cast<uint4*>(&a[u])[0] = ld16(wr[u] + kk);
+        if (CH == 4) reinterpret_cast<uint4*>(&a[u])[1] = ld16(wr[u] + kk + 4);
+      }
+      reinterpret_cast<uint4*>(&b)[0] = ld16(xr + kk);
+      if (CH == 4) reinterpret_cast<uint4*>(&b)[1] = ld16(xr + kk + 4);
+#pragma unroll
+      for (int u = 0; u < GU; ++u) mma(a[u], b, acc[u]);
+    }
+    if (fr == 0) {
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = (g0 + u) * 16 + fq * 4 + r;
+          if (n < N) {
+            float v = acc[u][r] + (bias ? bias[n] : 0.f);
+            y[n] = act == ACT_RELU ? fmaxf(v, 0.f) : v;
+          }
+        }
+    }
+  }
+}
+// f32 vector -> compute dtype (LDS to LDS)
+template <typename T> DEVI void to_t(const float* src, T* dst, int n) {
+  for (int i = threadIdx.x; i < n; i += DEC_THREADS) dst[i] = from_f<T>(src[i]);
+  __syncthreads();
+}
+
+// v[0..D) <- LayerNorm(v + r) * w + b   (in place; red = LDS scratch of 2*DEC_WAVES floats)
+DEVI void add_layernorm(float* v, const float* r, const float* w, const float* b, int D, float* red) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float x = 0.f;
+  if (tid < D) x = v[tid] + r[tid];
+  float s = wave_sum(tid < D ? x : 0.f);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int i = 0; i < DEC_WAVES; ++i) mean += red[i];
+  mean /= (float)D;
+  float d = tid < D ? x - mean : 0.f;
+  float q = wave_sum(d * d);
+  if (lane == 0) red[DEC_WAVES + wave] = q;
+  __syncthreads();
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < DEC_WAVES; ++i) var += red[DEC_WAVES + i];
+  float rstd = rsqrtf(var / (float)D + 1e-5f);
+  if (tid < D) v[tid] = d * rstd * w[tid] + b[tid];
+  __syncthreads();
+}
+
+// o[0..D) = softmax(q K^T / temp) V over `nk` keys; K at kv[j*ld + h*hd], V at kv[j*ld + voff + h*hd]
+template <typename T>
+DEVI void attend(const float* q, const T* kv, long ld, int voff, int nk, int H, int hd, float inv_temp, float* sc /*[H][nkP]*/,
+                 int nkP, float* o) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int D = H * hd;
+  for (int idx = tid; idx < nk * H; idx += DEC_THREADS) {
+    const int j = idx / H, h = idx - j * H;
+    const T* kp = kv + (long)j * ld + h * hd;
+    const float* qp = q + h * hd;
+    float acc = 0.f;
+    for (int d = 0; d < hd; d += 4) {
+      float f[4];
+      ld4<T>(kp + d, f);
+      acc += f[0] * qp[d] + f[1] * qp[d + 1] + f[2] * qp[d + 2] + f[3] * qp[d + 3];
+    }
+    sc[h * nkP + j] = acc * inv_temp;
+  }
+  __syncthreads();
+  for (int h = wave; h < H; h += DEC_WAVES) {
+    float m = -INFINITY;
+    for (int j = lane; j < nk; j += 64) m = fmaxf(m, sc[h * nkP + j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < nk; j += 64) { float e = __expf(sc[h * nkP + j] - m); sc[h * nkP + j] = e; s += e; }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int j = lane; j < nk; j += 64) sc[h * nkP + j] *= inv;
+  }
+  __syncthreads();
+  // two half-ranges of keys per output element when there are spare threads
+  const int parts = DEC_THREADS / D >= 4 ? 4 : (DEC_THREADS / D > 1 ? 2 : 1);
+  const int d = tid % D, part = tid / D;
+  float acc = 0.f;
+  if (part < parts) {
+    const int h = d / hd;
+    const T* vp = kv + voff + d;
+#pragma unroll 8
+    for (int j = part; j < nk; j += parts) acc += sc[h * nkP + j] * to_f(vp[(long)j * ld]);
+  }
+  __syncthreads();  // sc reuse as reduction scratch below
+  if (parts > 1) {
+    if (part > 0 && part < parts) sc[(part - 1) * D + d] = acc;
+    __syncthreads();
+    if (part == 0) {
+      for (int q2 = 1; q2 < parts; ++q2) acc += sc[(q2 - 1) * D + d];
+      o[d] = acc;
+    }
+  } else if (part == 0) {
+    o[d] = acc;
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
+  extern __shared__ float sm[];
+  const int D = p.D, F = p.F, V = p.V, H = p.H, hd = D / H;
+  const int nkP = ((p.steps > p.Nsrc ? p.steps : p.Nsrc) + 3) & ~3;
+  float* x = sm;                 // [D] layer input / running activation
+  float* qkv = x + D;            // [3D]
+  float* att = qkv + 3 * D;      // [D]
+  float* tmp = att + D;          // [D]
+  float* ff = tmp + D;           // [F]
+  float* sc = ff + F;            // [H][nkP]
+  float* red = sc + (H * nkP > 3 * D ? H * nkP : 3 * D);  // [2*DEC_WAVES]  (sc doubles as a 3D-wide reduction scratch)
+  float* lg = red + 2 * DEC_WAVES;  // [V] (padded to a multiple of 4)
+  T* xT = reinterpret_cast<T*>(lg + ((V + 3) & ~3));  // [max(D,F)] current GEMV input in the compute dtype (16-byte aligned)
+  __shared__ int s_tok;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float inv_temp = rsqrtf((float)D);
+  const float emb_scale = sqrtf((float)D);
+  int tok = p.sos;
+  for (int t = 0; t < p.steps; ++t) {
+    // ---- embedding * sqrt(D) + PE(t)   (networks/EfficientSATRN.py:480-483, :425)
+    if (tid < D) x[tid] = p.embed[(long)tok * D + tid] * emb_scale + p.pe[(long)t * D + tid];
+    __syncthreads();
+    for (int l = 0; l < p.nlayers; ++l) {
+      const DecLayerW& w = p.L[l];
+      T* cache = (T*)w.cache + (long)b * p.steps * 2 * D;  // this row's [steps][2D]
+      // q | k | v of the layer INPUT
+      to_t<T>(x, xT, D);
+      if (!(p.dbg & 8)) gemv<T>((const T*)w.wqkv, w.bqkv, xT, qkv, 3 * D, D, ACT_NONE);
+      __syncthreads();
+      for (int i = tid; i < 2 * D; i += DEC_THREADS) cache[(long)t * 2 * D + i] = from_f<T>(qkv[D + i]);
+      __syncthreads();
+      attend<T>(qkv, cache, 2 * D, D, (p.dbg & 1) ? 1 : t + 1, H, hd, inv_temp, sc, nkP, att);
+      to_t<T>(att, xT, D);
+      gemv<T>((const T*)w.wo, w.bo, xT, tmp, D, D, ACT_NONE);
+      __syncthreads();
+      add_layernorm(tmp, x, w.ln1w, w.ln1b, D, red);          // tmp = t1
+      to_t<T>(tmp, xT, D);
+      gemv<T>((const T*)w.wq2, w.bq2, xT, qkv, D, D, ACT_NONE);
+      __syncthreads();
+      attend<T>(qkv, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D, 2 * D, D, (p.dbg & 2) ? 1 : p.Nsrc, H, hd, inv_temp, sc, nkP, att);
+      to_t<T>(att, xT, D);
+      gemv<T>((const T*)w.wo2, w.bo2, xT, x, D, D, ACT_NONE);
+      __syncthreads();
+      add_layernorm(x, tmp, w.ln2w, w.ln2b, D, red);           // x = t2
+      to_t<T>(x, xT, D);
+      if (!(p.dbg & 4)) gemv<T>((const T*)w.w0, w.b0, xT, ff, F, D, ACT_RELU);
+      __syncthreads();
+      to_t<T>(ff, xT, F);
+      if (!(p.dbg & 4)) gemv<T>((const T*)w.w1, w.b1, xT, tmp, D, F, ACT_RELU);
+      __syncthreads();
+      add_layernorm(tmp, x, w.ln3w, w.ln3b, D, red);           // tmp = t3 (layer output)
+      if (tid < D) x[tid] = tmp[tid];
+      __syncthreads();
+      // history entry for later steps: k/v of the layer OUTPUT
+      to_t<T>(x, xT, D);
+      if (!(p.dbg & 16)) gemv<T>((const T*)w.wkv, w.bkv, xT, qkv, 2 * D, D, ACT_NONE);
+      __syncthreads();
+      for (int i = tid; i < 2 * D; i += DEC_THREADS) cache[(long)t * 2 * D + i] = from_f<T>(qkv[i]);
+      __syncthreads();
+    }
+    // ---- generator + argmax (lowest index wins ties, like torch.argmax)
+    to_t<T>(x, xT, D);
+    gemv<T>((const T*)p.wgen, p.bgen, xT, lg, V, D, ACT_NONE);
+    __syncthreads();
+    float* out = p.logits + ((long)b * p.steps + t) * V;
+    for (int i = tid; i < V; i += DEC_THREADS) out[i] = lg[i];
+    if (tid < 64) {
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int c = tid; c < V; c += 64) { float v = lg[c]; if (v > best) { best = v; bi = c; } }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (tid == 0) { s_tok = bi; p.ids[(long)b * p.steps + t] = bi; }
+    }
+    __syncthreads();
+    tok = s_tok;
+    __syncthreads();
+  }
+}
+
+int launch_decode_greedy(int dt, const DecodeP& p0, hipStream_t s) {
+  DecodeP p = p0;
+  static const char* dbg = getenv("SATRN_DEC_DBG");  // timing-only ablations (outputs wrong)
+  p.dbg = dbg ? atoi(dbg) : 0;
+  if (p.D % 32 || p.F % 32 || p.D > DEC_THREADS || p.nlayers > 4 || (p.D / p.H) % 4) return -1;
+  const int nkP = ((p.steps > p.Nsrc ? p.steps : p.Nsrc) + 3) & ~3;
+  const int scn = p.H * nkP > 3 * p.D ? p.H * nkP : 3 * p.D;
+  size_t sh = (size_t)(6 * p.D + p.F + scn + 2 * DEC_WAVES + ((p.V + 3) & ~3) + (p.F > p.D ? p.F : p.D)) * sizeof(float);
+  if (sh > 140 * 1024) return -1;
+  if (dt == DT_BF16) {
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute((const void*)decode_greedy_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); a = true; }
+    hipLaunchKernelGGL((decode_greedy_kernel<bf16_t>), dim3(p.B), dim3(DEC_THREADS), sh, s, p);
+  } else {
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute((const void*)decode_greedy_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); a = true; }
+    hipLaunchKernelGGL((decode_greedy_kernel<float>), dim3(p.B), dim3(DEC_THREADS), sh, s, p);
+  }
+  return 0;
+}
