@@ -195,9 +195,11 @@ int satrn_model_bind(satrn_model* m, float* params, float* grads, float* buf_f32
 size_t satrn_model_workspace_bytes(satrn_model* m, int B, int L);
 int satrn_model_set_workspace(satrn_model* m, void* ws, size_t bytes, void* stream);
 int satrn_model_pack_weights(satrn_model* m, void* stream);
-/* teacher-forced forward; logits fp32 [B][L-1][V]; record != 0 keeps the tape for a backward */
+/* training-graph forward; logits fp32 [B][L-1][V]; record != 0 keeps the tape for a backward.
+ * teacher_forced != 0: networks/EfficientSATRN.py:490-495 (expected[:, :-1] is the decoder input);
+ * teacher_forced == 0: the autoregressive branch with gradients, :496-525 (expected only gives the length). */
 int satrn_model_forward(satrn_model* m, const float* images, const int64_t* expected, int B, int L, int train, int record,
-                        float* logits, void* stream);
+                        int teacher_forced, float* logits, void* stream);
 /* backward from d(loss)/d(logits) (fp32 [B][L-1][V]); parameter grads ACCUMULATE into the bound grads */
 int satrn_model_backward(satrn_model* m, const float* dlogits, void* stream);
 /* fused CE on the last forward's logits + backward (loss readable with satrn_model_read_loss) */

@@ -176,6 +176,9 @@ struct Builder {
     // kv view always exists (the step decoder projects K/V separately from Q)
     a.kv.kind = WK_DENSE; a.kv.off = ko; a.kv.K = Ksrc; a.kv.N = 2 * D; a.kv.ldb = 2 * D; a.kv.Co = 2 * D; a.kv.Ci = Ksrc;
     a.bkv.off = kb; a.bkv.n = 2 * D;
+    // q-only view (the step decoder projects the single query row separately from the history's K/V)
+    a.qonly.kind = WK_DENSE; a.qonly.off = qo; a.qonly.K = D; a.qonly.N = D; a.qonly.ldb = D; a.qonly.Co = D; a.qonly.Ci = D;
+    a.bq.off = qb; a.bq.n = D;
     a.out = dense(name + ".out_linear.weight", D, D, 0);
     a.bout = vec(name + ".out_linear.bias", D, 3, D);
     return a;
@@ -287,7 +290,7 @@ Model* model_create(const SatrnConfig& cfg) {
   auto regv = [&](Vec& v) { m->all_v.push_back(&v); };
   auto regbn = [&](BNp& x) { m->all_bn.push_back(&x); regv(x.w); regv(x.b); };
   auto regln = [&](LNp& x) { regv(x.w); regv(x.b); };
-  auto regmha = [&](MHAp& a) { regw(a.qkv); regw(a.kv); regv(a.bqkv); regv(a.bkv); regw(a.out); regv(a.bout); };
+  auto regmha = [&](MHAp& a) { regw(a.qkv); regw(a.kv); regw(a.qonly); regv(a.bqkv); regv(a.bkv); regv(a.bq); regw(a.out); regv(a.bout); };
   if (cfg.network == 0) {
     for (auto& w : m->lite_conv) regw(w);
     for (auto& x : m->lite_bn) regbn(x);
@@ -767,15 +770,17 @@ Tensor* op_attn(Exec& e, Tensor* qt, int qoff, Tensor* kvt, int koff, int voff, 
       const size_t LkP = attn_lkp(Lk);
       void* dS = e.alloc((size_t)B * heads * Lq * LkP * es);
       void* Pd = e.alloc((size_t)B * heads * Lq * LkP * es);
-      void* dq = e.grad(qt, nullptr);
-      void* dkv = e.grad(kvt, nullptr);
+      int bq = 0, bkv = 0;
+      void* dq = e.grad(qt, &bq);
+      void* dkv = qt == kvt ? dq : e.grad(kvt, &bkv);  // K/V shared by several attention calls (step decoder): accumulate
+      (void)bq;
       AttnP q = p;
       q.dO = o->g; q.dQ = (char*)dq + qoff * es; q.dS = dS; q.Pd = Pd;
       e.nflops = 6.0 * (double)B * heads * Lq * Lk * hd;
       LCH(e, launch_attn(e.dt, 1, q, e.s));
       WgradP w;
       memset(&w, 0, sizeof(w));
-      w.M = Lq; w.N = Lk; w.K = hd; w.ldy = (int)LkP; w.out_t = 1; w.nbatch = B * heads; w.nb_inner = heads;
+      w.M = Lq; w.N = Lk; w.K = hd; w.ldy = (int)LkP; w.out_t = 1; w.out_accum = bkv; w.nbatch = B * heads; w.nb_inner = heads;
       w.sY_o = (long)heads * Lq * LkP; w.sY_i = (long)Lq * LkP;
       w.sW_o = (long)Lk * kvt->C; w.sW_i = hd; w.ldw = kvt->C;
       // dV = Pd^T dO
@@ -933,6 +938,111 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
   return x;  // [B*HW][D] == [b, hw, c]
 }
 
+// out rows (b, j<n) = src rows (b*sbs + soff + j); backward scatters (accumulating) into src's gradient
+Tensor* op_rows(Exec& e, Tensor* src, int B, int n, long sbs, long soff) {
+  const int C = src->C;
+  Tensor* y = e.newt((long)B * n, C, B);
+  LCH(e, launch_copy_rows(e.dt, src->p, y->p, B, n, C, sbs, soff, n, 0, 0, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, src, y, B, n, C, sbs, soff]() {
+      if (!y->g) return;
+      int beta;
+      void* g = e.grad(src, &beta);
+      if (!beta) LCH(e, launch_fill(g, 0, (size_t)src->rows * C * e.esz(), e.s));
+      LCH(e, launch_copy_rows(e.dt, y->g, g, B, n, C, n, 0, sbs, soff, 1, e.s));
+    });
+  return y;
+}
+// dst rows (b*dbs + doff + j) = x rows (b*n + j), in place inside an existing tensor; backward routes dst's gradient
+// rows back to x (x is the only writer of those rows)
+void op_store_rows(Exec& e, Tensor* dst, Tensor* x, int B, int n, long dbs, long doff) {
+  const int C = x->C;
+  LCH(e, launch_copy_rows(e.dt, x->p, dst->p, B, n, C, n, 0, dbs, doff, 0, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, dst, x, B, n, C, dbs, doff]() {
+      if (!dst->g) return;
+      int beta;
+      void* gx = e.grad(x, &beta);
+      LCH(e, launch_copy_rows(e.dt, dst->g, gx, B, n, C, dbs, doff, n, 0, beta, e.s));
+    });
+}
+// hist = [F rows (b, 0..t-1) ; x row b]  ->  [B*(t+1)][C]
+Tensor* op_hist(Exec& e, Tensor* F, Tensor* x, int B, int T, int t) {
+  const int C = x->C;
+  Tensor* h = e.newt((long)B * (t + 1), C, B);
+  if (t > 0) LCH(e, launch_copy_rows(e.dt, F->p, h->p, B, t, C, T, 0, t + 1, 0, 0, e.s));
+  LCH(e, launch_copy_rows(e.dt, x->p, h->p, B, 1, C, 1, 0, t + 1, t, 0, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, F, x, h, B, T, t, C]() {
+      if (!h->g) return;
+      if (t > 0) {
+        int bf;
+        void* gF = e.grad(F, &bf);
+        if (!bf) LCH(e, launch_fill(gF, 0, (size_t)F->rows * C * e.esz(), e.s));
+        LCH(e, launch_copy_rows(e.dt, h->g, gF, B, t, C, t + 1, 0, T, 0, 1, e.s));
+      }
+      int bx;
+      void* gx = e.grad(x, &bx);
+      LCH(e, launch_copy_rows(e.dt, h->g, gx, B, 1, C, t + 1, t, 1, 0, bx, e.s));
+    });
+  return h;
+}
+
+// Train-time autoregressive branch WITH gradients (networks/EfficientSATRN.py:496-525): every step feeds the argmax of
+// the previous step, the self-attention history of a layer is k/v_linear over [its previous outputs ; current input]
+// (recomputed per step like the reference, so gradients reach every earlier output), dropout stays active.
+Tensor* decoder_ar(Exec& e, Tensor* src, int B, int L, float* logits_out) {
+  Model* m = e.m;
+  const SatrnConfig& c = m->cfg;
+  const int T = L - 1, Dd = c.dec_hidden, V = c.num_classes, Nsrc = (int)(src->rows / B);
+  const int nl = (int)m->dec.size();
+  int64_t* ids = (int64_t*)e.alloc((size_t)B * T * 8);
+  int64_t* sos = (int64_t*)e.alloc((size_t)B * 8);
+  LCH(e, launch_fill_i64(sos, c.sos_id, B, e.s));
+  std::vector<Tensor*> F(nl), crossKV(nl);
+  for (int l = 0; l < nl; ++l) {
+    F[l] = e.newt((long)B * T, Dd, B);
+    crossKV[l] = op_gemm(e, src, &m->dec[l].cross_att.kv, &m->dec[l].cross_att.bkv, ACT_NONE, 0.f, nullptr);
+  }
+  // full logits tensor [B*T][V] (fp32, caller's buffer); its gradient arrives as [B*T][Vp] in the compute dtype
+  e.tens.emplace_back(new Tensor());
+  Tensor* full = e.tens.back().get();
+  full->rows = (long)B * T; full->C = V; full->f32 = true; full->p = logits_out;
+  const int Vp = m->gen.ldb;
+  const float fp = (e.train && e.drop > 0.f) ? 0.1f : 0.f;
+  for (int t = 0; t < T; ++t) {
+    Tensor* x = op_embed(e, t == 0 ? sos : ids + (t - 1), t == 0 ? 1 : T, B, 1, t, 0.f);
+    for (int l = 0; l < nl; ++l) {
+      DecLayer& dl = m->dec[l];
+      Tensor* hist = op_hist(e, F[l], x, B, T, t);
+      Tensor* q = op_gemm(e, x, &dl.self_att.qonly, &dl.self_att.bq, ACT_NONE, 0.f, nullptr);
+      Tensor* kv = op_gemm(e, hist, &dl.self_att.kv, &dl.self_att.bkv, ACT_NONE, 0.f, nullptr);
+      Tensor* att = op_attn(e, q, 0, kv, 0, Dd, B, 1, t + 1, c.dec_heads, Dd, 0, nullptr, 0, e.drop);
+      Tensor* o = op_gemm(e, att, &dl.self_att.out, &dl.self_att.bout, ACT_NONE, e.drop, nullptr);
+      Tensor* t1 = op_ln(e, o, x, &dl.ln1);
+      Tensor* q2 = op_gemm(e, t1, &dl.cross_att.qkv, &dl.cross_att.bqkv, ACT_NONE, 0.f, nullptr);
+      Tensor* a2 = op_attn(e, q2, 0, crossKV[l], 0, Dd, B, 1, Nsrc, c.dec_heads, Dd, 0, nullptr, 0, e.drop);
+      Tensor* o2 = op_gemm(e, a2, &dl.cross_att.out, &dl.cross_att.bout, ACT_NONE, e.drop, nullptr);
+      Tensor* t2 = op_ln(e, o2, t1, &dl.ln2);
+      Tensor* f0 = op_gemm(e, t2, &dl.lin0, &dl.b0, ACT_RELU, fp, nullptr);
+      Tensor* f1 = op_gemm(e, f0, &dl.lin1, &dl.b1, ACT_RELU, fp, nullptr);
+      x = op_ln(e, f1, t2, &dl.ln3);
+      op_store_rows(e, F[l], x, B, 1, T, t);
+    }
+    Tensor* lt = op_gemm(e, x, &m->gen, &m->gen_b, ACT_NONE, 0.f, nullptr, 0, true);  // [B][V] fp32
+    LCH(e, launch_copy_rows(DT_F32, lt->p, logits_out, B, 1, V, 1, 0, T, t, 0, e.s));
+    LCH(e, launch_argmax((const float*)lt->p, ids + t, B, V, V, T, e.s));
+    if (e.rec)
+      e.tape.push_back([&e, full, lt, B, T, t, Vp]() {
+        if (!full->g) return;
+        lt->g = e.alloc((size_t)B * Vp * e.esz());
+        lt->g_init = true;
+        LCH(e, launch_copy_rows(e.dt, full->g, lt->g, B, 1, Vp, T, t, 1, 0, 0, e.s));
+      });
+  }
+  return full;
+}
+
 Tensor* decoder_tf(Exec& e, Tensor* src, const int64_t* expected, int B, int L, float* logits_out) {
   Model* m = e.m;
   const SatrnConfig& c = m->cfg;
@@ -976,13 +1086,24 @@ size_t model_workspace_bytes(Model* m, int B, int L) {
   exec_begin(m, nullptr, true, true, true);
   e.cap = (size_t)1 << 60; e.zcap = m->zero_bytes;
   Tensor* src = encoder_forward(e, nullptr, B);
-  std::vector<int64_t> dummy;
   Tensor* lg = decoder_tf(e, src, nullptr, B, L, nullptr);
   lg->g = e.alloc((size_t)lg->rows * m->gen.ldb * e.esz());
   e.alloc((size_t)lg->rows * 4);
   for (auto it = e.tape.rbegin(); it != e.tape.rend(); ++it) (*it)();
   size_t train_peak = e.peak;
   e.tape.clear(); e.tens.clear();
+  // the autoregressive training branch keeps O(T^2) history tensors: size it as well
+  {
+    exec_begin(m, nullptr, true, true, true);
+    e.cap = (size_t)1 << 60; e.zcap = m->zero_bytes;
+    Tensor* s2 = encoder_forward(e, nullptr, B);
+    Tensor* l2 = decoder_ar(e, s2, B, L, nullptr);
+    l2->g = e.alloc((size_t)l2->rows * m->gen.ldb * e.esz());
+    e.alloc((size_t)l2->rows * 4);
+    for (auto it = e.tape.rbegin(); it != e.tape.rend(); ++it) (*it)();
+    if (e.peak > train_peak) train_peak = e.peak;
+    e.tape.clear(); e.tens.clear();
+  }
   // greedy: encoder (eval) + caches
   size_t es = e.esz();
   size_t dec = (size_t)m->cfg.dec_layers * ((size_t)B * 512 * 2 * m->cfg.dec_hidden * es + (size_t)B * m->feat_h * m->feat_w * 2 * m->cfg.dec_hidden * es) +
@@ -993,12 +1114,12 @@ size_t model_workspace_bytes(Model* m, int B, int L) {
 }
 
 int model_forward(Model* m, const float* img, const int64_t* expected, int B, int L, bool train, bool record,
-                  float* logits_out, hipStream_t s) {
+                  float* logits_out, hipStream_t s, bool teacher_forced) {
   if (!m->bound || !m->ws_set) { m->err = "bind parameters and set a workspace first"; return -1; }
   Exec& e = *m->ex;
   exec_begin(m, s, train, record, false);
   e.src = encoder_forward(e, img, B);
-  e.logits = decoder_tf(e, e.src, expected, B, L, logits_out);
+  e.logits = teacher_forced ? decoder_tf(e, e.src, expected, B, L, logits_out) : decoder_ar(e, e.src, B, L, logits_out);
   if (e.oom) { if (m->err.empty()) m->err = "workspace exhausted"; return -2; }
   return 0;
 }

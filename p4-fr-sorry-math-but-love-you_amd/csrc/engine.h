@@ -53,7 +53,7 @@ struct LNp { Vec w, b; int C = 0; };
 struct MHAp { Wt qkv;   /* fused [3D][K] when q and kv share the input width, else q only */
               Wt kv;    /* cross attention: [2D][Ksrc] */
               Vec bqkv; /* fused bias [3D] (or [D] for q when cross) */
-              Vec bkv; Wt out; Vec bout; int D = 0, heads = 0; bool cross = false; };
+              Vec bkv; Wt out; Vec bout; Wt qonly; Vec bq; int D = 0, heads = 0; bool cross = false; };
 
 struct Tensor {
   void* p = nullptr; void* g = nullptr;
@@ -145,7 +145,7 @@ int model_bind(Model* m, float* params, float* grads, float* buf_f32, int64_t* b
 int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s);
 int model_pack_weights(Model* m, hipStream_t s);
 int model_forward(Model* m, const float* img, const int64_t* expected, int B, int L, bool train, bool record,
-                  float* logits_out, hipStream_t s);
+                  float* logits_out, hipStream_t s, bool teacher_forced = true);
 int model_backward(Model* m, const float* dlogits, hipStream_t s);
 int model_loss_backward(Model* m, const int64_t* expected, int B, int L, hipStream_t s);
 int model_train_step(Model* m, const float* img, const int64_t* expected, int B, int L, const float* hyper9,

@@ -29,6 +29,7 @@ struct WgradP {
   int conv;        // 0 dense, 1 conv (im2col gather of A; dW written in [N][Ci][KH][KW] torch layout)
   int conv_packed_out;  // conv: write dW as [N][taps][Ci] (contiguous atomics) for launch_conv_grad_unpack
   int out_t;       // 0: fp32 atomicAdd into dW (zeroed by caller); 1: store as T (batched attention use)
+  int out_accum;   // out_t == 1: add to the existing values (K/V shared by several attention calls)
   int nbatch, nb_inner;                    // batched: z -> (z / nb_inner, z % nb_inner)
   long sY_o, sY_i, sA_o, sA_i, sW_o, sW_i;  // element strides per outer/inner batch index
   int ldw;                                 // out_t==1: row stride of dW
@@ -118,6 +119,8 @@ void launch_fill(void* p, int value_byte, size_t bytes, hipStream_t s);
 void launch_add(int dt, const void* a, const void* b, void* out, long n, hipStream_t s);
 void launch_argmax(const float* logits, int64_t* ids, int R, int V, int ld_in, int ld_out, hipStream_t s);
 void launch_seed_advance(uint32_t* seed, hipStream_t s);
+void launch_copy_rows(int dt, const void* src, void* dst, int B, int n, int C, long src_bstride, long src_off,
+                      long dst_bstride, long dst_off, int beta, hipStream_t s);
 void launch_fill_i64(int64_t* p, int64_t v, long n, hipStream_t s);
 
 // ---- weight packing + optimizer --------------------------------------------------------------

@@ -1204,6 +1204,28 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int64_
 void launch_argmax(const float* logits, int64_t* ids, int R, int V, int ld_in, int ld_out, hipStream_t s) {
   hipLaunchKernelGGL(argmax_kernel, dim3((R + 3) / 4), dim3(256), 0, s, logits, ids, R, V, ld_in, ld_out);
 }
+// dst[(b*dbs + doff + j)][:] (+)= src[(b*sbs + soff + j)][:] for b < B, j < n: row gather/scatter of the step decoder
+template <typename T>
+__global__ void copy_rows_kernel(const T* src, T* dst, int n, int C, long sbs, long soff, long dbs, long doff, long total,
+                                 int beta) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long r = i / C;
+    int j = (int)(r % n);
+    long b = r / n;
+    const long so = (b * sbs + soff + j) * C + c, d_o = (b * dbs + doff + j) * C + c;
+    dst[d_o] = beta ? from_f<T>(to_f(dst[d_o]) + to_f(src[so])) : src[so];
+  }
+}
+void launch_copy_rows(int dt, const void* src, void* dst, int B, int n, int C, long sbs, long soff, long dbs, long doff,
+                      int beta, hipStream_t s) {
+  long total = (long)B * n * C;
+  if (total <= 0) return;
+  DISPATCH_T(dt, {
+    hipLaunchKernelGGL((copy_rows_kernel<T>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)src, (T*)dst, n, C, sbs, soff,
+                       dbs, doff, total, beta);
+  });
+}
 __global__ void fill_i64_kernel(int64_t* p, int64_t v, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }

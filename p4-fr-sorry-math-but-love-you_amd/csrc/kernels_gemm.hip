@@ -404,7 +404,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split
         if (n >= p.N) continue;
         if (p.out_t) {
           T* o = (T*)p.dW + zo * p.sW_o + zi * p.sW_i;
-          o[(long)n * p.ldw + k] = from_f<T>(acc[i][j][r]);
+          T* op = o + (long)n * p.ldw + k;
+          *op = from_f<T>(p.out_accum ? to_f(*op) + acc[i][j][r] : acc[i][j][r]);
         } else {
           long dst;
           if (CONV && !p.conv_packed_out) { int tp = k / p.Ci, c = k - tp * p.Ci; dst = ((long)n * p.Ci + c) * taps + tp; }

@@ -337,8 +337,8 @@ size_t satrn_model_workspace_bytes(satrn_model* h, int B, int L) { return model_
 int satrn_model_set_workspace(satrn_model* h, void* ws, size_t bytes, void* st) { return mret(h, model_set_workspace(h->m, ws, bytes, S(st)), "set_workspace"); }
 int satrn_model_pack_weights(satrn_model* h, void* st) { return mret(h, model_pack_weights(h->m, S(st)), "pack_weights"); }
 int satrn_model_forward(satrn_model* h, const float* img, const int64_t* exp, int B, int L, int train, int record,
-                        float* logits, void* st) {
-  return mret(h, model_forward(h->m, img, exp, B, L, train != 0, record != 0, logits, S(st)), "forward");
+                        int teacher_forced, float* logits, void* st) {
+  return mret(h, model_forward(h->m, img, exp, B, L, train != 0, record != 0, logits, S(st), teacher_forced != 0), "forward");
 }
 int satrn_model_backward(satrn_model* h, const float* dl, void* st) { return mret(h, model_backward(h->m, dl, S(st)), "backward"); }
 int satrn_model_loss_backward(satrn_model* h, const int64_t* exp, int B, int L, void* st) {

@@ -69,9 +69,9 @@ class _TFFunction(torch.autograd.Function):
     """Teacher-forced forward of the whole model as ONE autograd node; backward replays the engine's tape."""
 
     @staticmethod
-    def forward(ctx, model, anchor, input, expected, record):
+    def forward(ctx, model, anchor, input, expected, record, teacher_forced):
         ctx.model = model
-        ctx.gen = model._run_forward(input, expected, record=record)
+        ctx.gen = model._run_forward(input, expected, record=record, teacher_forced=teacher_forced)
         return model._last_logits
 
     @staticmethod
@@ -80,7 +80,7 @@ class _TFFunction(torch.autograd.Function):
         if ctx.gen != model._gen:
             raise SatrnError("backward() of a stale forward: the engine keeps one tape (the latest forward)")
         model._run_backward(dlogits)
-        return None, torch.zeros_like(model._anchor), None, None, None
+        return None, torch.zeros_like(model._anchor), None, None, None, None
 
 
 class _SATRNBase(nn.Module):
@@ -267,7 +267,7 @@ class _SATRNBase(nn.Module):
         return input
 
     # ------------------------------------------------------------------ engine calls
-    def _run_forward(self, input, expected, record):
+    def _run_forward(self, input, expected, record, teacher_forced=True):
         input = self._img(input)
         expected = expected.contiguous()
         B, L = expected.shape
@@ -275,7 +275,7 @@ class _SATRNBase(nn.Module):
         logits = torch.empty(B, L - 1, self._cfg.num_classes, dtype=torch.float32, device=input.device)
         self._gen += 1
         check(self._lib.satrn_model_forward(self._h, ptr(input), ptr(expected), B, L, int(self.training), int(record),
-                                            ptr(logits), _stream()), "satrn_model_forward")
+                                            int(teacher_forced), ptr(logits), _stream()), "satrn_model_forward")
         self._last_logits = logits
         self._keep = (input, expected)  # the tape reads them in backward
         return self._gen
@@ -302,12 +302,11 @@ class _SATRNBase(nn.Module):
 
     def forward(self, input, expected, is_train, teacher_forcing_ratio):
         """networks/EfficientSATRN.py:697-706: -> [B, L-1, V] (teacher-forced logits, or greedy-step logits)."""
-        if is_train and random.random() < teacher_forcing_ratio:
+        if is_train:
+            # the reference's coin (Python `random`, :489): teacher forced, or autoregressive WITH gradients (:496-525)
+            tf = random.random() < teacher_forcing_ratio
             self._ensure_bound(input.device)
-            return _TFFunction.apply(self, self._anchor, input, expected, torch.is_grad_enabled())
-        if is_train and torch.is_grad_enabled():
-            raise NotImplementedError("train-time autoregressive branch (networks/EfficientSATRN.py:496-525) needs gradients "
-                                      "through the step loop; not built yet -- use teacher_forcing_ratio=1.0")
+            return _TFFunction.apply(self, self._anchor, input, expected, torch.is_grad_enabled(), tf)
         return self.greedy(input, expected.size(1) - 1)[0]
 
     @torch.no_grad()

@@ -256,3 +256,34 @@ def test_no_cpu_fallback():
     img, expected = O.det_inputs(2, 1, 64, 192, 8)
     with pytest.raises(satrn_amd.SatrnError):
         model(img, expected, True, 1.0)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_train_autoregressive_branch_with_gradients(dtype):
+    """model(input, expected, True, 0.0): the reference's non-teacher-forced training branch
+    (networks/EfficientSATRN.py:496-525) -- step-wise greedy feeding WITH gradients through every step."""
+    cfg = dict(O.CFG_LITE)
+    B, H, W, T = 3, 64, 192, 7
+    model, sd = build(cfg, H, W, dtype, 6)
+    img, expected = O.det_inputs(B, 1, H, W, T, seed=44, pad_tail=2)
+    model.train()
+    logits = model(img.cuda(), expected.cuda(), True, 0.0)   # random.random() < 0.0 never holds -> AR branch
+    loss = model.criterion(logits.transpose(1, 2), expected.cuda()[:, 1:])
+    model.zero_grad()
+    loss.backward()
+    oloss, ologits, ograds, _ = O.forward_backward(img, expected, sd, cfg, teacher_forcing=False)
+    f32 = dtype == "f32"
+    print(f"[ar:{dtype}] loss {loss.item():.6f} oracle {oloss.item():.6f} logits rel err {relerr(logits, ologits):.3e}")
+    assert abs(loss.item() - oloss.item()) < (1e-3 if f32 else 0.1)
+    if f32:
+        assert relerr(logits, ologits) < 1e-3
+        params = dict(model.named_parameters())
+        gl2 = max(g.norm().item() / max(g.numel(), 1) ** 0.5 for g in ograds.values())
+        errs = []
+        for n_, g in ograds.items():
+            d = params[n_].grad.detach().cpu() - g
+            rms = lambda t_: t_.norm().item() / max(t_.numel(), 1) ** 0.5
+            errs.append((rms(d) / max(rms(g), 1e-3 * gl2), n_))
+        worst = sorted(errs, reverse=True)[:4]
+        print(f"[ar:{dtype}] worst grad rel-L2: " + ", ".join(f"{n_}={e_:.2e}" for e_, n_ in worst))
+        assert float(np.median([e_ for e_, _ in errs])) < 1e-3 and worst[0][0] < 3e-2
