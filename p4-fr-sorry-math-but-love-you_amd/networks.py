@@ -397,9 +397,14 @@ class _SATRNBase(nn.Module):
         return json.loads(buf.value.decode())
 
     def flat_grad(self):
+        """the flat fp32 gradient buffer every p.grad is a view of (what the data-parallel all-reduce runs on)."""
+        if self._gflat is None:
+            self._ensure_bound(next(self.parameters()).device)
         return self._gflat
 
     def flat_params(self):
+        if self._gflat is None:
+            self._ensure_bound(next(self.parameters()).device)
         return self._flat[0]
 
     def read_loss(self):
