@@ -28,6 +28,8 @@ void Exec::prof_begin(const char* call) {
   std::string nm = p ? p : call;
   size_t q = nm.find('(');
   if (q != std::string::npos) nm = nm.substr(0, q);
+  static const bool shapes = getenv("SATRN_PROF_SHAPES") != nullptr;  // split families by problem size
+  if (shapes) { char b[64]; snprintf(b, sizeof(b), " B%.0f F%.0f", nbytes, nflops); nm += b; }
   r.name = nm; r.flops = nflops; r.bytes = nbytes;
   (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
   (void)hipEventRecord(r.a, s);
@@ -475,6 +477,9 @@ int model_pack_weights(Model* m, hipStream_t s) {
 namespace {
 struct Geo { int H, W, Ci, OH, OW, KW, stride, pt, pl; };
 
+static inline void used(Tensor* t) { if (t) t->ncons++; }
+static const bool g_fuse_bnb = getenv("SATRN_NO_FUSED_BN_BWD") == nullptr;
+
 static void acc_grad(Exec& e, Tensor* t, const void* src) {
   // first contribution: alias the producer's gradient buffer (it has no reader left once its own backward ran)
   if (!t->g) { t->g = const_cast<void*>(src); t->g_init = true; return; }
@@ -515,11 +520,15 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
   if (geo) { p.H = geo->H; p.W = geo->W; p.Ci = geo->Ci; p.OH = geo->OH; p.OW = geo->OW; p.KW = geo->KW; p.stride = geo->stride; p.pt = geo->pt; p.pl = geo->pl; }
   e.nflops = 2.0 * (double)M * N * w->K; e.nbytes = ((double)x->rows * x->C + (double)M * N + (double)N * w->K) * e.esz();
   LCH(e, launch_gemm(e.dt, geo ? AM_CONV : AM_DENSE, p, e.s));
+  // x is a BatchNorm output and this is its first consumer: our dgrad is the last writer of x's gradient, so its
+  // epilogue can also produce that BatchNorm's backward column sums
+  const bool fuse_bnb = g_fuse_bnb && e.rec && x->bn_y && x->ncons == 0 && (geo ? geo->Ci : w->K) == x->C;
+  used(x);
   if (e.rec) {
     Geo g{};
     if (geo) g = *geo;
     const bool hasgeo = geo != nullptr;
-    e.tape.push_back([&e, x, y, w, bias, act, drop_p, site, seed, g, hasgeo, M, N, B, out_f32]() {
+    e.tape.push_back([&e, x, y, w, bias, act, drop_p, site, seed, g, hasgeo, M, N, B, out_f32, fuse_bnb]() {
       if (!y->g) return;
       const int ldy = out_f32 ? w->ldb : N;
       void* dY = y->g;
@@ -558,6 +567,11 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       GemmP d;
       memset(&d, 0, sizeof(d));
       d.A = dY; d.Bw = w->bwd; d.C = dx; d.beta = beta;
+      if (fuse_bnb) {
+        const int rep = (x->C <= 64 && x->rows >= 65536) ? 16 : ((x->C <= 256 && x->rows >= 16384) ? 4 : 1);
+        x->bn_red = e.zalloc((size_t)rep * 2 * x->C); x->bn_red_rep = rep;
+        d.stats = x->bn_red; d.stats_rep = rep; d.bnb_y = x->bn_y; d.bnb_ss = x->bn_ss; d.bnb_mr = x->bn_mr; d.bnb_act = x->bn_act;
+      }
       if (!hasgeo) {
         d.M = (int)M; d.N = w->K; d.K = w->ldb; d.lda = ldy; d.ldc = x->C;
         e.nflops = 2.0 * (double)d.M * d.N * w->N;
@@ -591,15 +605,20 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res) {
   e.nbytes = (double)M * C * e.esz() * (res ? 3 : 2);
   LCH(e, launch_bn_act(e.dt, y->p, sums, y->stats ? y->stats_rep : 1, bn->w.p, bn->b.p, bn->rm, bn->rv, e.train ? bn->nbt : nullptr, bn->eps, 0.1f, ss, mr,
                        res ? res->p : nullptr, z->p, M, C, act, e.s));
+  used(y); used(res);
   if (e.rec) {
+    if (e.train) { z->bn_y = y->p; z->bn_ss = ss; z->bn_mr = mr; z->bn_act = act; }
     e.tape.push_back([&e, y, z, bn, act, res, ss, mr, M, C]() {
       if (!z->g) return;
-      float* red = e.zalloc(2 * C);
-      e.nbytes = (double)M * C * e.esz() * 2;
-      LCH(e, launch_bn_bwd_reduce(e.dt, z->g, y->p, ss, mr, M, C, act, red, e.s));
+      float* red = z->bn_red;  // already produced by the epilogue of the last kernel that wrote z's gradient?
+      if (!red) {
+        red = e.zalloc(2 * C);
+        e.nbytes = (double)M * C * e.esz() * 2;
+        LCH(e, launch_bn_bwd_reduce(e.dt, z->g, y->p, ss, mr, M, C, act, red, e.s));
+      }
       void* dy = e.grad(y, nullptr);
       e.nbytes = (double)M * C * e.esz() * 3;
-      LCH(e, launch_bn_bwd_apply(e.dt, z->g, y->p, ss, mr, bn->w.p, red, M, C, act, dy, bn->w.g, bn->b.g, e.s));
+      LCH(e, launch_bn_bwd_apply(e.dt, z->g, y->p, ss, mr, bn->w.p, red, M, C, act, dy, bn->w.g, bn->b.g, e.s, z->bn_red ? z->bn_red_rep : 1));
       if (res) acc_grad(e, res, z->g);
     });
   }
@@ -619,6 +638,7 @@ Tensor* op_stem(Exec& e, const float* img, Wt* w, int B, int Cin, int H, int W, 
 }
 
 Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int OW, int pt, int pl, bool want_stats = true) {
+  used(x);
   const int B = x->B, H = x->H, W = x->W, C = x->C;
   Tensor* y = e.newt((long)B * OH * OW, C, B, OH, OW);
   if (want_stats && e.train) y->stats = e.zalloc(2 * C);
@@ -640,6 +660,7 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
 }
 
 Tensor* op_maxpool(Exec& e, Tensor* x) {
+  used(x);
   const int B = x->B, H = x->H, W = x->W, C = x->C;
   Tensor* y = e.newt((long)B * (H / 2) * (W / 2), C, B, H / 2, W / 2);
   LCH(e, launch_maxpool(e.dt, 0, x->p, nullptr, y->p, B, H, W, C, e.s));
@@ -654,6 +675,7 @@ Tensor* op_maxpool(Exec& e, Tensor* x) {
 }
 
 Tensor* op_pool(Exec& e, Tensor* x) {  // mean over HW -> [B][C]
+  used(x);
   const int B = x->B, HW = x->H * x->W, C = x->C;
   Tensor* y = e.newt(B, C);
   LCH(e, launch_pool_hw(e.dt, x->p, y->p, B, HW, C, e.s));
@@ -669,6 +691,7 @@ Tensor* op_pool(Exec& e, Tensor* x) {  // mean over HW -> [B][C]
 }
 
 Tensor* op_act(Exec& e, Tensor* u, int act) {
+  used(u);
   Tensor* z = e.newt(u->rows, u->C);
   LCH(e, launch_act_fwd(e.dt, u->p, z->p, u->rows * u->C, act, e.s));
   if (e.rec)
@@ -681,6 +704,7 @@ Tensor* op_act(Exec& e, Tensor* u, int act) {
 }
 
 Tensor* op_se_scale(Exec& e, Tensor* x, Tensor* gate) {
+  used(x); used(gate);
   const int B = x->B, HW = x->H * x->W, C = x->C;
   Tensor* y = e.newt(x->rows, C, B, x->H, x->W);
   LCH(e, launch_se_scale(e.dt, x->p, gate->p, y->p, B, HW, C, e.s));
@@ -697,6 +721,7 @@ Tensor* op_se_scale(Exec& e, Tensor* x, Tensor* gate) {
 }
 
 Tensor* op_posenc_apply(Exec& e, Tensor* x, Tensor* gate) {
+  used(x); used(gate);
   Model* m = e.m;
   const int B = x->B, H = x->H, W = x->W, C = x->C;
   const float* hpos = (const float*)(m->ws + m->off_hpos);
@@ -714,6 +739,7 @@ Tensor* op_posenc_apply(Exec& e, Tensor* x, Tensor* gate) {
 }
 
 Tensor* op_ln(Exec& e, Tensor* a, Tensor* b, LNp* ln) {
+  used(a); used(b);
   const long R = a->rows;
   const int C = a->C;
   Tensor* y = e.newt(R, C, a->B, a->H, a->W);
@@ -732,6 +758,7 @@ Tensor* op_ln(Exec& e, Tensor* a, Tensor* b, LNp* ln) {
 }
 
 Tensor* op_quirk(Exec& e, Tensor* yv) {  // networks/EfficientSATRN.py:269
+  used(yv);
   const int B = yv->B, HW = yv->H * yv->W, C = yv->C;
   Tensor* z = e.newt(yv->rows, C, B, yv->H, yv->W);
   LCH(e, launch_reshape_quirk(e.dt, 0, yv->p, z->p, B, HW, C, 0, e.s));
@@ -748,6 +775,7 @@ Tensor* op_quirk(Exec& e, Tensor* yv) {  // networks/EfficientSATRN.py:269
 // attention over column slices of projection outputs: Q = qt[:, qoff:qoff+D], K = kvt[:, koff:], V = kvt[:, voff:]
 Tensor* op_attn(Exec& e, Tensor* qt, int qoff, Tensor* kvt, int koff, int voff, int B, int Lq, int Lk, int heads, int D,
                 int causal, const int64_t* text, int ld_text, float drop_p) {
+  used(qt); used(kvt);
   const int hd = D / heads;
   Tensor* o = e.newt((long)B * Lq, D, B);
   float* lse = (float*)e.alloc((size_t)B * heads * Lq * 4);
@@ -851,6 +879,7 @@ Tensor* encoder_layer(Exec& e, Tensor* x, EncLayer* el) {
 
 // squeeze-and-excite: pool + MLP in one kernel, x*gate in a second; backward = dgate reduction, two SE kernels, dx
 Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb) {
+  used(x);
   const int B = x->B, HW = x->H * x->W, C = x->C, S = eb->se;
   float* pooled = (float*)e.alloc((size_t)B * C * 4);
   float* u1 = (float*)e.alloc((size_t)B * S * 4);
@@ -940,6 +969,7 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
 
 // out rows (b, j<n) = src rows (b*sbs + soff + j); backward scatters (accumulating) into src's gradient
 Tensor* op_rows(Exec& e, Tensor* src, int B, int n, long sbs, long soff) {
+  used(src);
   const int C = src->C;
   Tensor* y = e.newt((long)B * n, C, B);
   LCH(e, launch_copy_rows(e.dt, src->p, y->p, B, n, C, sbs, soff, n, 0, 0, e.s));
@@ -956,6 +986,7 @@ Tensor* op_rows(Exec& e, Tensor* src, int B, int n, long sbs, long soff) {
 // dst rows (b*dbs + doff + j) = x rows (b*n + j), in place inside an existing tensor; backward routes dst's gradient
 // rows back to x (x is the only writer of those rows)
 void op_store_rows(Exec& e, Tensor* dst, Tensor* x, int B, int n, long dbs, long doff) {
+  used(dst); used(x);
   const int C = x->C;
   LCH(e, launch_copy_rows(e.dt, x->p, dst->p, B, n, C, n, 0, dbs, doff, 0, e.s));
   if (e.rec)
@@ -968,6 +999,7 @@ void op_store_rows(Exec& e, Tensor* dst, Tensor* x, int B, int n, long dbs, long
 }
 // hist = [F rows (b, 0..t-1) ; x row b]  ->  [B*(t+1)][C]
 Tensor* op_hist(Exec& e, Tensor* F, Tensor* x, int B, int T, int t) {
+  used(F); used(x);
   const int C = x->C;
   Tensor* h = e.newt((long)B * (t + 1), C, B);
   if (t > 0) LCH(e, launch_copy_rows(e.dt, F->p, h->p, B, t, C, T, 0, t + 1, 0, 0, e.s));

@@ -63,6 +63,12 @@ struct Tensor {
   bool f32 = false;  // logits
   int stats_rep = 1;
   float* stats = nullptr;  // [2C] column sum / sum of squares written by the producing kernel (BatchNorm input)
+  // BatchNorm outputs (training): what the LAST gradient contributor needs to also produce the BN backward's column
+  // sums in its own epilogue (bn_red, zeroed, [bn_red_rep][2C]); ncons counts forward consumers so far -- the first
+  // consumer in forward order is the last contributor in backward order
+  int ncons = 0;
+  const void* bn_y = nullptr; const float* bn_ss = nullptr; const float* bn_mr = nullptr; int bn_act = 0;
+  float* bn_red = nullptr; int bn_red_rep = 1;
 };
 
 struct EffBlock { int type, cin, cout, mid, stride, se; bool skip; Wt c0, c1, dw, se_r, se_e; Vec se_rb, se_eb; BNp bn1, bn2, bn3; };

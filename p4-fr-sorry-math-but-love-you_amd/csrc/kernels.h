@@ -18,6 +18,9 @@ struct GemmP {
   const float* ascale; int ascale_hw;  // optional A[m][k] *= ascale[(m/ascale_hw)*K + k]  (SE gate), dense only
   float* stats;  // optional [stats_rep][2N] (zeroed): per-column sum / sum of squares of the output (for the BatchNorm that follows)
   int stats_rep; // replicas (>= 1) the row tiles spread their atomics over; the consumer sums them
+  // optional (dgrad of a BatchNorm output, N == the BN's C): stats become the BN backward's column sums
+  // [sum g, sum g*xhat] with g = dz_total*act'(y*scale+shift), so the separate reduction pass disappears
+  const void* bnb_y; const float* bnb_ss; const float* bnb_mr; int bnb_act;
 };
 void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s);
 
@@ -67,7 +70,7 @@ void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* sc
                           long M, int C, int act, float* red /*[2C] zeroed*/, hipStream_t s);
 void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* scale_shift, const float* mean_rstd,
                          const float* w, const float* red, long M, int C, int act, void* dy, float* dw, float* db,
-                         hipStream_t s);
+                         hipStream_t s, int red_rep = 1);
 void launch_stem_conv(int dt, const float* img, const float* w, void* y, int B, int Cin, int H, int W, int Co, int OH,
                       int OW, int stride, int pad, hipStream_t s);
 void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int B, int Cin, int H, int W, int Co,

@@ -254,14 +254,16 @@ void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* ss
 // dy = A*g + Bc + Cc*y with g = dz*act'(y*scale+shift): per-channel coefficients computed once per thread
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* dz, const T* y, const float* ss, const float* mr, const float* w,
-                                    const float* red, float invM, long nchunks, int C, int act, T* dy, float* dw,
-                                    float* db) {
+                                    const float* red, int red_rep, float invM, long nchunks, int C, int act, T* dy,
+                                    float* dw, float* db) {
   constexpr int CH = TT<T>::CH;
   const int CC = C / CH;
   const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
   if (tid < C && dw) {  // parameter grads (grad buffers are zeroed per step: accumulate)
-    dw[tid] += red[C + tid];
-    db[tid] += red[tid];
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < red_rep; ++r) { a += red[(size_t)r * 2 * C + C + tid]; b += red[(size_t)r * 2 * C + tid]; }
+    dw[tid] += a;
+    db[tid] += b;
   }
   const int c0 = (int)(tid % CC) * CH;
   float sc[CH], sh[CH], A[CH], Bc[CH], Cc[CH];
@@ -269,6 +271,12 @@ __global__ void bn_bwd_apply_kernel(const T* dz, const T* y, const float* ss, co
     float mu[CH], rs[CH], ww[CH], r0[CH], r1[CH];
     ldv(ss + c0, sc, CH); ldv(ss + C + c0, sh, CH); ldv(mr + c0, mu, CH); ldv(mr + C + c0, rs, CH);
     ldv(w + c0, ww, CH); ldv(red + c0, r0, CH); ldv(red + C + c0, r1, CH);
+    for (int r = 1; r < red_rep; ++r) {
+      float t0[CH], t1[CH];
+      ldv(red + (size_t)r * 2 * C + c0, t0, CH); ldv(red + (size_t)r * 2 * C + C + c0, t1, CH);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { r0[j] += t0[j]; r1[j] += t1[j]; }
+    }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       float a = ww[j] * rs[j], m1 = r0[j] * invM, m2 = r1[j] * invM;
@@ -290,13 +298,14 @@ __global__ void bn_bwd_apply_kernel(const T* dz, const T* y, const float* ss, co
   }
 }
 void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* ss, const float* mr, const float* w,
-                         const float* red, long M, int C, int act, void* dy, float* dw, float* db, hipStream_t s) {
+                         const float* red, long M, int C, int act, void* dy, float* dw, float* db, hipStream_t s,
+                         int red_rep) {
   DISPATCH_T(dt, {
     long n = M * C / TT<T>::CH;
     int g = grid_chan(n, C / TT<T>::CH);
     while ((long)g * 256 < C) g *= 2;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g), dim3(256), 0, s, (const T*)dz, (const T*)y, ss, mr, w, red,
-                       1.0f / (float)M, n, C, act, (T*)dy, dw, db);
+                       red_rep < 1 ? 1 : red_rep, 1.0f / (float)M, n, C, act, (T*)dy, dw, db);
   });
 }
 

@@ -167,6 +167,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     const int col = n0 + j * 16 + fr;
     const float bias = (p.bias && col < p.N) ? p.bias[col] : 0.f;
     float s1 = 0.f, s2 = 0.f;
+    float bsc = 0.f, bsh = 0.f, bmu = 0.f, brs = 0.f;
+    if (p.bnb_y && col < p.N) { bsc = p.bnb_ss[col]; bsh = p.bnb_ss[p.N + col]; bmu = p.bnb_mr[col]; brs = p.bnb_mr[p.N + col]; }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -175,14 +177,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         if (row >= p.M || col >= p.N) continue;
         float v = act_fwd(acc[i][j][r] + bias, p.act);
         if (p.drop_p > 0.f) v *= drop_scale(seed, p.site, (uint32_t)(row * p.N + col), p.drop_p);
-        s1 += v; s2 += v * v;
         const long o = (long)row * p.ldc + col;
+        float tot;
         if (p.out_f32) {
           float* c = (float*)p.C;
-          c[o] = p.beta ? c[o] + v : v;
+          tot = p.beta ? c[o] + v : v;
+          c[o] = tot;
         } else {
           T* c = (T*)p.C;
-          c[o] = from_f<T>(p.beta ? to_f(c[o]) + v : v);
+          tot = p.beta ? to_f(c[o]) + v : v;
+          c[o] = from_f<T>(tot);
+        }
+        if (p.bnb_y) {
+          const float yv = to_f(((const T*)p.bnb_y)[(long)row * p.N + col]);
+          const float g = tot * act_bwd(yv * bsc + bsh, p.bnb_act);
+          s1 += g; s2 += g * ((yv - bmu) * brs);
+        } else {
+          s1 += v; s2 += v * v;
         }
       }
     }

@@ -390,7 +390,7 @@ class _SATRNBase(nn.Module):
         expected = expected.contiguous()
         B, L = expected.shape
         self._prepare(input, B, L)
-        buf = ctypes.create_string_buffer(1 << 16)
+        buf = ctypes.create_string_buffer(1 << 18)
         check(self._lib.satrn_model_profile_step(self._h, ptr(input), ptr(expected), B, L, buf, len(buf), _stream()),
               "satrn_model_profile_step")
         self._gen += 1
