@@ -897,8 +897,17 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb) {
       float* dz2 = (float*)e.alloc((size_t)B * C * 4);
       float* du1 = (float*)e.alloc((size_t)B * S * 4);
       LCH(e, launch_se_bwd_gate(e.dt, y->g, x->p, dgate, B, HW, C, e.s));
-      LCH(e, launch_se_bwd(e.dt, dgate, gate->p, u1, s1, pooled, eb->se_r.p, eb->se_e.p, dz2, du1, dpooled, eb->se_r.g, eb->se_rb.g,
-                           eb->se_e.g, eb->se_eb.g, B, C, S, e.s));
+      {
+        // data path on the main chain; the two weight-gradient products only feed the optimizer -> side stream
+        const int dt = e.dt; void* gp = gate->p; float* w1 = eb->se_r.p; float* w2 = eb->se_e.p;
+        float* g1 = eb->se_r.g; float* gb1 = eb->se_rb.g; float* g2 = eb->se_e.g; float* gb2 = eb->se_eb.g;
+        if (e.prof || e.dry) {
+          LCH(e, launch_se_bwd(dt, dgate, gp, u1, s1, pooled, w1, w2, dz2, du1, dpooled, g1, gb1, g2, gb2, B, C, S, e.s, 3));
+        } else {
+          launch_se_bwd(dt, dgate, gp, u1, s1, pooled, w1, w2, dz2, du1, dpooled, g1, gb1, g2, gb2, B, C, S, e.s, 1);
+          e.defer([=](hipStream_t ws) { launch_se_bwd(dt, dgate, gp, u1, s1, pooled, w1, w2, dz2, du1, dpooled, g1, gb1, g2, gb2, B, C, S, ws, 2); });
+        }
+      }
       int beta;
       void* dx = e.grad(x, &beta);
       LCH(e, launch_se_bwd_x(e.dt, y->g, gate->p, dpooled, dx, B, HW, C, beta, e.s));

@@ -144,7 +144,7 @@ void launch_se_fwd(int dt, const void* x, const float* W1, const float* b1, cons
                    float* u1, float* s1, void* gate, int B, int HW, int C, int S, hipStream_t s);
 void launch_se_bwd(int dt, const void* dgate, const void* gate, const float* u1, const float* s1, const float* pooled,
                    const float* W1, const float* W2, float* dz2, float* du1, void* dpooled, float* dW1, float* db1, float* dW2,
-                   float* db2, int B, int C, int S, hipStream_t s);
+                   float* db2, int B, int C, int S, hipStream_t s, int parts = 3 /*1: data path, 2: weight gradients*/);
 
 // persistent greedy decoder (kernels_decode.hip): weights are the packed [N][K] compute copies, biases / LN fp32
 struct DecLayerW {

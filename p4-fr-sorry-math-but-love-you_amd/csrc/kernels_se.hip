@@ -167,13 +167,15 @@ void launch_se_fwd(int dt, const void* x, const float* W1, const float* b1, cons
 }
 void launch_se_bwd(int dt, const void* dgate, const void* gate, const float* u1, const float* s1, const float* pooled,
                    const float* W1, const float* W2, float* dz2, float* du1, void* dpooled, float* dW1, float* db1, float* dW2,
-                   float* db2, int B, int C, int S, hipStream_t s) {
+                   float* db2, int B, int C, int S, hipStream_t s, int parts) {
   size_t sh = (size_t)(C + 17 * S) * sizeof(float);
-  if (dt == DT_BF16)
+  if (!(parts & 1)) {
+  } else if (dt == DT_BF16)
     hipLaunchKernelGGL((se_bwd_a_kernel<bf16_t>), dim3(B), dim3(1024), sh, s, (const bf16_t*)dgate, (const bf16_t*)gate, u1, W1, W2, dz2, du1, (bf16_t*)dpooled, C, S);
   else
     hipLaunchKernelGGL((se_bwd_a_kernel<float>), dim3(B), dim3(1024), sh, s, (const float*)dgate, (const float*)gate, u1, W1, W2, dz2, du1, (float*)dpooled, C, S);
   size_t sh2 = (size_t)2 * B * 8 * sizeof(float);
-  hipLaunchKernelGGL(se_bwd_b_kernel, dim3((C + 255) / 256, (S + 7) / 8), dim3(256), sh2, s, dz2, du1, s1, pooled, dW1, db1, dW2,
+  if (parts & 2)
+    hipLaunchKernelGGL(se_bwd_b_kernel, dim3((C + 255) / 256, (S + 7) / 8), dim3(256), sh2, s, dz2, du1, s1, pooled, dW1, db1, dW2,
                      db2, B, C, S);
 }

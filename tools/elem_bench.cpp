@@ -60,6 +60,16 @@ int main(int argc, char** argv) {
     printf("  se_scale       %7.1f us\n", time_us([&](hipStream_t st) { launch_se_scale(dt, x, z, y, sh.B, sh.H * sh.W, C, st); }, s));
     printf("  se_bwd_gate    %7.1f us\n", time_us([&](hipStream_t st) { launch_se_bwd_gate(dt, dz, x, z, sh.B, sh.H * sh.W, C, st); }, s));
     printf("  se_bwd_x       %7.1f us\n", time_us([&](hipStream_t st) { launch_se_bwd_x(dt, dz, z, z, x, sh.B, sh.H * sh.W, C, 0, st); }, s));
+    {
+      const int S = C / 24;  // EfficientNetV2-S: se_ratio 0.25 of the block input (C/6 or C/4 of the expanded width)
+      float *W1, *W2, *u1;
+      hipMalloc(&W1, (size_t)S * C * 4); hipMalloc(&W2, (size_t)S * C * 4); hipMalloc(&u1, (size_t)4 * sh.B * (S + C) * 4);
+      hipMemset(W1, 0, (size_t)S * C * 4); hipMemset(W2, 0, (size_t)S * C * 4);
+      float* pooled = u1 + 2 * sh.B * S;
+      printf("  se_fwd (S=%d)  %7.1f us\n", S, time_us([&](hipStream_t st) { launch_se_fwd(dt, x, W1, b, W2, b, pooled, u1, u1 + sh.B * S, z, sh.B, sh.H * sh.W, C, S, st); }, s));
+      printf("  se_fwd HW=1    %7.1f us\n", time_us([&](hipStream_t st) { launch_se_fwd(dt, x, W1, b, W2, b, pooled, u1, u1 + sh.B * S, z, sh.B, 1, C, S, st); }, s));
+      hipFree(W1); hipFree(W2); hipFree(u1);
+    }
     printf("  fill(2C f32)   %7.1f us\n", time_us([&](hipStream_t st) { launch_fill(red, 0, (size_t)2 * C * 4, st); }, s));
     hipFree(x); hipFree(y); hipFree(z); hipFree(dz); hipFree(f);
   }
