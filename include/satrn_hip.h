@@ -217,6 +217,14 @@ int satrn_model_encode(satrn_model* m, const float* images, int B, float* src_ou
  * once per (B, steps, buffer addresses) and replays it: the four buffers must then stay at the same addresses. */
 int satrn_model_greedy(satrn_model* m, const float* images, const float* src, int B, int steps, float* logits,
                        int64_t* ids, int use_graph, void* stream);
+/* Step-wise decoding session = EfficientSATRN_decoder.step_forward / reset_status (networks/EfficientSATRN.py:932-952),
+ * the interface the ensemble driver uses (utils/ensemble_utils.py:84-96: softmax-average the models' step logits, pick the
+ * next token outside the model).  begin: src fp32 [B][N][dec_src] (an encoder output, satrn_model_encode) -> cross-
+ * attention K/V of every layer + empty self-attention caches, step index 0.  step: target int64 [B] (this step's input
+ * tokens; <SOS> first) -> logits fp32 [B][V]; at most max_steps (<= 500) steps.  The session lives in the workspace:
+ * any other call on the same model ends it (the next satrn_model_step then fails). */
+int satrn_model_step_begin(satrn_model* m, const float* src, int B, int max_steps, void* stream);
+int satrn_model_step(satrn_model* m, const int64_t* target, float* logits, void* stream);
 /* One EAGER forward + CE + backward with every kernel launch bracketed by HIP events on `stream`; writes a JSON array
  * [{"kernel", "launches", "ms", "flops", "bytes"}...] (per kernel family, algorithmic flops / bytes) to json_out. */
 int satrn_model_profile_step(satrn_model* m, const float* images, const int64_t* expected, int B, int L, char* json_out,

@@ -470,23 +470,50 @@ def decoder_tf_forward(src, text, sd, cfg):
     return F.linear(tgt, sd["decoder.generator.weight"], sd["decoder.generator.bias"])
 
 
+def decoder_step(target, t, feats, src, sd, cfg):
+    """EfficientSATRN_decoder.step_forward (networks/EfficientSATRN.py:932-948) == one trip of the greedy loop (:534-551):
+    target [b] int64, feats = per-layer history (updated in place) -> logits [b, 1, V]."""
+    b = src.size(0)
+    Dd = cfg["dec_hidden"]
+    tgt = text_embedding(target.view(b, 1), sd) + pos_table_1d(Dd)[t].view(1, 1, Dd)
+    for l in range(cfg["dec_layers"]):
+        tgt = decoder_layer(tgt, feats[l], src, None, sd, f"decoder.attention_layers.{l}.", cfg["dec_heads"])
+        feats[l] = tgt if feats[l] is None else torch.cat([feats[l], tgt], 1)
+    return F.linear(tgt, sd["decoder.generator.weight"], sd["decoder.generator.bias"])
+
+
 def decoder_greedy_forward(src, num_steps, sd, cfg):
     """networks/EfficientSATRN.py:528-561 (no DecodingManager).  Returns (logits [b,steps,V], ids [b,steps]).
     argmax ties -> lowest index (torch.argmax)."""
     b = src.size(0)
-    Dd = cfg["dec_hidden"]
-    pe = pos_table_1d(Dd)
     target = torch.full((b,), SOS_ID, dtype=torch.int64)
     feats = [None] * cfg["dec_layers"]
     outs, ids = [], []
     for t in range(num_steps):
-        tgt = text_embedding(target.view(b, 1), sd) + pe[t].view(1, 1, Dd)
-        for l in range(cfg["dec_layers"]):
-            tgt = decoder_layer(tgt, feats[l], src, None, sd, f"decoder.attention_layers.{l}.", cfg["dec_heads"])
-            feats[l] = tgt if feats[l] is None else torch.cat([feats[l], tgt], 1)
-        o = F.linear(tgt, sd["decoder.generator.weight"], sd["decoder.generator.bias"])
+        o = decoder_step(target, t, feats, src, sd, cfg)
         target = torch.argmax(o[:, -1, :], dim=-1)
         outs.append(o[:, 0])
+        ids.append(target)
+    return torch.stack(outs, 1), torch.stack(ids, 1)
+
+
+def ensemble_greedy_forward(srcs, num_steps, sds, cfg):
+    """utils/ensemble_utils.py:70-103 without a DecodingManager: every step, each model's step_forward logits ->
+    softmax, averaged over the models, argmax of the average is every model's next input.
+    Returns (averaged probabilities [b, steps, V], ids [b, steps])."""
+    b = srcs[0].size(0)
+    target = torch.full((b,), SOS_ID, dtype=torch.int64)
+    feats = [[None] * cfg["dec_layers"] for _ in sds]
+    outs, ids = [], []
+    for t in range(num_steps):
+        acc = None
+        for m, sd in enumerate(sds):
+            o = decoder_step(target, t, feats[m], srcs[m], sd, cfg)[:, 0]
+            pr = F.softmax(o, dim=-1)
+            acc = pr if acc is None else acc + pr
+        acc = acc / len(sds)
+        target = torch.argmax(acc, dim=-1)
+        outs.append(acc)
         ids.append(target)
     return torch.stack(outs, 1), torch.stack(ids, 1)
 

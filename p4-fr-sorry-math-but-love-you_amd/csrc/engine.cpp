@@ -1116,6 +1116,7 @@ static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) 
   e.reset(m->ws + m->persist_bytes, m->ws_bytes > m->persist_bytes ? m->ws_bytes - m->persist_bytes : 0,
           m->ws + m->off_zero, m->zero_bytes);
   e.peak = 0;
+  ++m->epoch;  // whatever lived in the arena (e.g. a step-wise decoding session) is gone
   if (!dry) launch_fill(m->ws + m->off_zero, 0, m->zero_bytes, s);
 }
 
@@ -1277,6 +1278,60 @@ int model_encode(Model* m, const float* img, int B, float* src_out, hipStream_t 
   return 0;
 }
 
+// One KV-cached decoder step for all B sequences: ids[b*ld_ids] are the input tokens of step t, logits -> [B][ld_logits].
+static int decode_one_step(Model* m, const int64_t* ids, int ld_ids, int t, int steps, std::vector<Tensor*>& crossKV,
+                           std::vector<Tensor*>& cache, float* logits, int ld_logits) {
+  Exec& e = *m->ex;
+  hipStream_t s = e.s;
+  const SatrnConfig& c = m->cfg;
+  const int Dd = c.dec_hidden, V = c.num_classes, L = (int)m->dec.size();
+  const int B = cache[0]->B;
+  const int Nsrc = (int)(crossKV[0]->rows / B);
+  const size_t es = e.esz();
+  const float inv_temp = 1.0f / sqrtf((float)Dd);
+  Tensor* x = op_embed(e, ids, ld_ids, B, 1, t, 0.f);
+  for (int l = 0; l < L; ++l) {
+    DecLayer& dl = m->dec[l];
+    MHAp& sa = dl.self_att;
+    // q = x Wq ; [k v](x) -> cache slot t
+    Wt wq = sa.qkv; wq.N = Dd;
+    Vec bq = sa.bqkv; bq.n = Dd;
+    Tensor* q = op_gemm(e, x, &wq, &bq, ACT_NONE, 0.f, nullptr);
+    GemmP g;
+    memset(&g, 0, sizeof(g));
+    g.A = x->p; g.Bw = (char*)sa.qkv.fwd + (size_t)Dd * Dd * es; g.bias = sa.bqkv.p + Dd;
+    g.C = (char*)cache[l]->p + (size_t)t * 2 * Dd * es; g.M = B; g.N = 2 * Dd; g.K = Dd; g.lda = Dd; g.ldc = steps * 2 * Dd;
+    launch_gemm(e.dt, AM_DENSE, g, s);
+    Tensor* att = e.newt(B, Dd, B);
+    AttnP p;
+    memset(&p, 0, sizeof(p));
+    p.Q = q->p; p.K = cache[l]->p; p.V = (char*)cache[l]->p + (size_t)Dd * es; p.O = att->p;
+    p.B = B; p.H = c.dec_heads; p.Lq = 1; p.Lk = t + 1; p.hd = Dd / c.dec_heads;
+    p.ldq = Dd; p.ldk = 2 * Dd; p.ldv = 2 * Dd; p.ldo = Dd;
+    p.sq_b = Dd; p.sk_b = (long)steps * 2 * Dd; p.sv_b = p.sk_b; p.so_b = Dd;
+    p.inv_temp = inv_temp; p.pad_id = c.pad_id;
+    if (launch_attn_checked(e.dt, 0, p, s)) { m->err = "attention shape unsupported (Lk > 512?)"; return -4; }
+    Tensor* o = op_gemm(e, att, &sa.out, &sa.bout, ACT_NONE, 0.f, nullptr);
+    Tensor* t1 = op_ln(e, o, x, &dl.ln1);
+    Tensor* q2 = op_gemm(e, t1, &dl.cross_att.qkv, &dl.cross_att.bqkv, ACT_NONE, 0.f, nullptr);
+    Tensor* a2 = op_attn(e, q2, 0, crossKV[l], 0, Dd, B, 1, Nsrc, c.dec_heads, Dd, 0, nullptr, 0, 0.f);
+    Tensor* o2 = op_gemm(e, a2, &dl.cross_att.out, &dl.cross_att.bout, ACT_NONE, 0.f, nullptr);
+    Tensor* t2 = op_ln(e, o2, t1, &dl.ln2);
+    Tensor* f0 = op_gemm(e, t2, &dl.lin0, &dl.b0, ACT_RELU, 0.f, nullptr);
+    Tensor* f1 = op_gemm(e, f0, &dl.lin1, &dl.b1, ACT_RELU, 0.f, nullptr);
+    x = op_ln(e, f1, t2, &dl.ln3);
+    // history entry for the following steps: k/v of this layer's OUTPUT
+    g.A = x->p;
+    launch_gemm(e.dt, AM_DENSE, g, s);
+  }
+  GemmP g;
+  memset(&g, 0, sizeof(g));
+  g.A = x->p; g.Bw = m->gen.fwd; g.bias = m->gen_b.p; g.C = logits; g.M = B; g.N = V; g.K = Dd;
+  g.lda = Dd; g.ldc = ld_logits; g.out_f32 = 1;
+  launch_gemm(e.dt, AM_DENSE, g, s);
+  return 0;
+}
+
 // Greedy decode with the reference's step semantics (networks/EfficientSATRN.py:528-561, :386-396): the
 // self-attention history of a layer is k/v_linear of that layer's previous OUTPUTS plus the current INPUT.
 // KV-cached: slot t first holds k/v(input_t), is attended, then is overwritten with k/v(output_t).
@@ -1328,53 +1383,54 @@ static int greedy_body(Model* m, const float* img, const float* src_in, int B, i
   }
   const size_t mark = e.off;
   const size_t keep = e.tens.size();
-  const float inv_temp = 1.0f / sqrtf((float)Dd);
   for (int t = 0; t < steps; ++t) {
     e.off = mark;  // per-step scratch is reused
-    Tensor* x = op_embed(e, t == 0 ? sos : ids_out + (t - 1), t == 0 ? 1 : steps, B, 1, t, 0.f);
-    for (int l = 0; l < L; ++l) {
-      DecLayer& dl = m->dec[l];
-      MHAp& sa = dl.self_att;
-      // q = x Wq ; [k v](x) -> cache slot t
-      Wt wq = sa.qkv; wq.N = Dd;
-      Vec bq = sa.bqkv; bq.n = Dd;
-      Tensor* q = op_gemm(e, x, &wq, &bq, ACT_NONE, 0.f, nullptr);
-      GemmP g;
-      memset(&g, 0, sizeof(g));
-      g.A = x->p; g.Bw = (char*)sa.qkv.fwd + (size_t)Dd * Dd * es; g.bias = sa.bqkv.p + Dd;
-      g.C = (char*)cache[l]->p + (size_t)t * 2 * Dd * es; g.M = B; g.N = 2 * Dd; g.K = Dd; g.lda = Dd; g.ldc = steps * 2 * Dd;
-      launch_gemm(e.dt, AM_DENSE, g, s);
-      Tensor* att = e.newt(B, Dd, B);
-      AttnP p;
-      memset(&p, 0, sizeof(p));
-      p.Q = q->p; p.K = cache[l]->p; p.V = (char*)cache[l]->p + (size_t)Dd * es; p.O = att->p;
-      p.B = B; p.H = c.dec_heads; p.Lq = 1; p.Lk = t + 1; p.hd = Dd / c.dec_heads;
-      p.ldq = Dd; p.ldk = 2 * Dd; p.ldv = 2 * Dd; p.ldo = Dd;
-      p.sq_b = Dd; p.sk_b = (long)steps * 2 * Dd; p.sv_b = p.sk_b; p.so_b = Dd;
-      p.inv_temp = inv_temp; p.pad_id = c.pad_id;
-      if (launch_attn_checked(e.dt, 0, p, s)) { m->err = "attention shape unsupported (Lk > 512?)"; return -4; }
-      Tensor* o = op_gemm(e, att, &sa.out, &sa.bout, ACT_NONE, 0.f, nullptr);
-      Tensor* t1 = op_ln(e, o, x, &dl.ln1);
-      Tensor* q2 = op_gemm(e, t1, &dl.cross_att.qkv, &dl.cross_att.bqkv, ACT_NONE, 0.f, nullptr);
-      Tensor* a2 = op_attn(e, q2, 0, crossKV[l], 0, Dd, B, 1, Nsrc, c.dec_heads, Dd, 0, nullptr, 0, 0.f);
-      Tensor* o2 = op_gemm(e, a2, &dl.cross_att.out, &dl.cross_att.bout, ACT_NONE, 0.f, nullptr);
-      Tensor* t2 = op_ln(e, o2, t1, &dl.ln2);
-      Tensor* f0 = op_gemm(e, t2, &dl.lin0, &dl.b0, ACT_RELU, 0.f, nullptr);
-      Tensor* f1 = op_gemm(e, f0, &dl.lin1, &dl.b1, ACT_RELU, 0.f, nullptr);
-      x = op_ln(e, f1, t2, &dl.ln3);
-      // history entry for the following steps: k/v of this layer's OUTPUT
-      g.A = x->p;
-      launch_gemm(e.dt, AM_DENSE, g, s);
-    }
-    GemmP g;
-    memset(&g, 0, sizeof(g));
-    g.A = x->p; g.Bw = m->gen.fwd; g.bias = m->gen_b.p; g.C = logits_out + (size_t)t * V; g.M = B; g.N = V; g.K = Dd;
-    g.lda = Dd; g.ldc = steps * V; g.out_f32 = 1;
-    launch_gemm(e.dt, AM_DENSE, g, s);
+    int rc = decode_one_step(m, t == 0 ? sos : ids_out + (t - 1), t == 0 ? 1 : steps, t, steps, crossKV, cache,
+                             logits_out + (size_t)t * V, steps * V);
+    if (rc) return rc;
     launch_argmax(logits_out + (size_t)t * V, ids_out + t, B, V, steps * V, steps, s);
     e.tens.resize(keep);
   }
   if (e.oom) { m->err = "workspace exhausted"; return -2; }
+  return 0;
+}
+
+// ---- step-wise decoding session (the ensemble driver's interface: networks/EfficientSATRN.py:932-952 step_forward /
+// reset_status, called from utils/ensemble_utils.py:84-96).  begin = reset_status + the per-sequence work (cross K/V
+// of src, empty self-attention caches); each step consumes the caller's token ids and returns logits [B][V].  The
+// session lives in the workspace arena, so any other call on the same model ends it.
+int model_step_begin(Model* m, const float* src_in, int B, int max_steps, hipStream_t s) {
+  if (!m->bound || !m->ws_set) { m->err = "bind parameters and set a workspace first"; return -1; }
+  if (max_steps < 1 || max_steps > 500) { m->err = "max 500 decode steps (PositionEncoder1D max_len)"; return -1; }
+  Exec& e = *m->ex;
+  const SatrnConfig& c = m->cfg;
+  exec_begin(m, s, false, false, false);
+  const int N = m->feat_h * m->feat_w;
+  Tensor* src = e.newt((long)B * N, c.dec_src, B);
+  launch_cast(DT_F32, e.dt, src_in, src->p, src->rows * src->C, s);
+  const int L = (int)m->dec.size();
+  m->step_cross.assign(L, nullptr); m->step_cache.assign(L, nullptr);
+  for (int l = 0; l < L; ++l) {
+    m->step_cross[l] = op_gemm(e, src, &m->dec[l].cross_att.kv, &m->dec[l].cross_att.bkv, ACT_NONE, 0.f, nullptr);
+    m->step_cache[l] = e.newt((long)B * max_steps, 2 * c.dec_hidden, B);
+  }
+  if (e.oom) { m->err = "workspace exhausted"; m->step_B = 0; return -2; }
+  m->step_B = B; m->step_max = max_steps; m->step_t = 0; m->step_mark = e.off; m->step_keep = e.tens.size();
+  m->step_epoch = ++m->epoch;
+  return 0;
+}
+
+int model_step(Model* m, const int64_t* target, float* logits_out, hipStream_t s) {
+  Exec& e = *m->ex;
+  if (!m->step_B || m->step_epoch != m->epoch) { m->err = "no live step session (call satrn_model_step_begin; other calls on the model end a session)"; return -1; }
+  if (m->step_t >= m->step_max) { m->err = "step session exhausted (max_steps reached)"; return -1; }
+  e.s = s;
+  e.off = m->step_mark;
+  e.tens.resize(m->step_keep);
+  int rc = decode_one_step(m, target, 1, m->step_t, m->step_max, m->step_cross, m->step_cache, logits_out, m->cfg.num_classes);
+  if (rc) return rc;
+  if (e.oom) { m->err = "workspace exhausted"; return -2; }
+  m->step_t += 1;
   return 0;
 }
 

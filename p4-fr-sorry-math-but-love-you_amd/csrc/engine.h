@@ -109,6 +109,9 @@ struct Model {
   long adam_t = 0;
   hipGraphExec_t decode_graph = nullptr; const void* decode_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float* hy_pinned = nullptr;
+  // step-wise decoding session (satrn_model_step_begin / satrn_model_step)
+  std::vector<struct Tensor*> step_cross, step_cache; int step_B = 0, step_max = 0, step_t = 0; size_t step_mark = 0, step_keep = 0;
+  long epoch = 0, step_epoch = -1;  // every arena reset bumps epoch: a session from an older epoch is dead
   std::string err;
 };
 
@@ -160,5 +163,7 @@ int model_read_loss(Model* m, float* out4, hipStream_t s);
 int model_encode(Model* m, const float* img, int B, float* src_out, hipStream_t s);
 int model_greedy(Model* m, const float* img, const float* src_or_null, int B, int steps, float* logits_out,
                  int64_t* ids_out, int use_graph, hipStream_t s);
+int model_step_begin(Model* m, const float* src, int B, int max_steps, hipStream_t s);
+int model_step(Model* m, const int64_t* target, float* logits_out, hipStream_t s);
 int model_profile_step(Model* m, const float* img, const int64_t* expected, int B, int L, char* out, size_t out_cap,
                        hipStream_t s);

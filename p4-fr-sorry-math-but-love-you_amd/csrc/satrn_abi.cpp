@@ -354,6 +354,14 @@ int satrn_model_greedy(satrn_model* h, const float* img, const float* src, int B
                        int use_graph, void* st) {
   return mret(h, model_greedy(h->m, img, src, B, steps, logits, ids, use_graph, S(st)), "greedy");
 }
+int satrn_model_step_begin(satrn_model* h, const float* src, int B, int max_steps, void* st) {
+  if (!src || B <= 0) return fail(-1, "satrn_model_step_begin: src is null or B <= 0");
+  return mret(h, model_step_begin(h->m, src, B, max_steps, S(st)), "step_begin");
+}
+int satrn_model_step(satrn_model* h, const int64_t* target, float* logits, void* st) {
+  if (!target || !logits) return fail(-1, "satrn_model_step: null pointer");
+  return mret(h, model_step(h->m, target, logits, S(st)), "step");
+}
 int satrn_model_profile_step(satrn_model* h, const float* img, const int64_t* exp, int B, int L, char* json_out,
                              size_t cap, void* st) {
   return mret(h, model_profile_step(h->m, img, exp, B, L, json_out, cap, S(st)), "profile_step");

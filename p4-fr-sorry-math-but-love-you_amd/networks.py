@@ -424,23 +424,73 @@ class LiteSATRN(_SATRNBase):
     _NETWORK = 0
 
 
-class EfficientSATRN_encoder(nn.Module):
+class _Half(nn.Module):
+    """Shared plumbing of the encoder-only / decoder-only wrappers: the engine always holds the whole model (one flat
+    parameter buffer); the wrapper registers only its half in the module tree, so state_dict() has exactly the
+    reference's keys ('encoder.*' or 'decoder.*') and the other half keeps its initial values, unused."""
+
+    def __init__(self, FLAGS, train_dataset, dtype):
+        super().__init__()
+        # not a registered submodule: its parameters must not appear in this wrapper's state_dict
+        object.__setattr__(self, "_full", EfficientSATRN(FLAGS, train_dataset, None, None, dtype))
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        self._full._apply(fn, *a, **k)  # .to(device) / .float() reach the unregistered half as well
+        return self
+
+
+class EfficientSATRN_encoder(_Half):
     """networks/EfficientSATRN.py:870-894: encoder-only wrapper used by the ensemble path; forward(input) -> [B, N, D]."""
 
     def __init__(self, FLAGS, train_dataset, checkpoint=None, dtype=None):
-        super().__init__()
-        self._full = EfficientSATRN(FLAGS, train_dataset, None, None, dtype)
+        super().__init__(FLAGS, train_dataset, dtype)
         self.encoder = self._full.encoder
         if checkpoint:
-            self.load_state_dict(checkpoint, strict=False)
+            self.load_state_dict(checkpoint)
 
     def forward(self, input):
         return self._full.encode(input)
 
 
-class EfficientSATRN_decoder(nn.Module):
-    """networks/EfficientSATRN.py:897-952 (step_forward / reset_status ensemble API) -- not on the built path yet."""
+class EfficientSATRN_decoder(_Half):
+    """networks/EfficientSATRN.py:897-952: decoder-only wrapper with the step-wise ensemble interface.
 
-    def __init__(self, FLAGS, train_dataset, checkpoint=None, dtype=None):
-        super().__init__()
-        raise NotImplementedError("step-wise ensemble decoder API is a 'next' row (SURVEY.md 8f rank 2); not built yet")
+    step_forward(src, target) -> [B, 1, V] consumes one token per sequence and keeps the per-layer history on the device
+    (self-attention K/V cache; the cross-attention K/V of `src` are projected once, at the first step after
+    reset_status() -- the reference re-projects them every step, :386-396).  `src` must be the same encoder output for
+    every step of a sequence, as in utils/ensemble_utils.py:84-96.  max_steps bounds the history (default 256; the
+    reference's drivers use max_sequence + 1 = 231)."""
+
+    def __init__(self, FLAGS, train_dataset, checkpoint=None, dtype=None, max_steps=256):
+        super().__init__(FLAGS, train_dataset, dtype)
+        self.decoder = self._full.decoder
+        self.step_idx = 0
+        self.max_steps = int(max_steps)
+        if checkpoint:
+            self.load_state_dict(checkpoint)
+
+    @torch.no_grad()
+    def step_forward(self, src, target):
+        full = self._full
+        if not src.is_cuda:
+            raise SatrnError("the SATRN engine runs on MI355X only: move src/target to 'cuda' (no CPU fallback)")
+        B = src.size(0)
+        cur = torch.cuda.current_stream()
+        if self.step_idx == 0:
+            src = src.float().contiguous()
+            dummy = torch.empty(B, 1, 1, 1, device=src.device)
+            full._prepare(dummy, B, self.max_steps + 1)
+            check(full._lib.satrn_model_step_begin(full._h, ptr(src), B, self.max_steps, _stream()), "satrn_model_step_begin")
+            self._keep_src = src
+        target = target.reshape(B).to(torch.int64).contiguous()
+        logits = torch.empty(B, 1, full._cfg.num_classes, dtype=torch.float32, device=src.device)
+        check(full._lib.satrn_model_step(full._h, ptr(target), ptr(logits), _stream()), "satrn_model_step")
+        self._keep_tgt = target  # the launch reads it asynchronously
+        self.step_idx += 1
+        return logits
+
+    def reset_status(self):
+        self.step_idx = 0
+
+
