@@ -217,6 +217,19 @@ int satrn_model_encode(satrn_model* m, const float* images, int B, float* src_ou
  * once per (B, steps, buffer addresses) and replays it: the four buffers must then stay at the same addresses. */
 int satrn_model_greedy(satrn_model* m, const float* images, const float* src, int B, int steps, float* logits,
                        int64_t* ids, int use_graph, void* stream);
+/* DecodingManager on the device (postprocessing/postprocessing.py:180-388).  rules: int32 [V + 8] in device memory, the
+ * manager's rule lists compiled by satrn_amd.decoding.compile_rules: per token (flag bits: 1 next must be "_", 2 next must
+ * be "{", 4 next cannot be "_", 8 next cannot be "{", 16 cannot follow <SOS>) | (run-length limit << 8), then the ids of
+ * <SOS>, <EOS>, "", "_", "{", "}" and two reserved words.  state: int32 [B][4] = last token, run length, #"{", #"}".
+ * satrn_sift = DecodingManager.sift (:189-246): probs = softmax(x) with the blacklisted tokens zeroed, targets = argmax,
+ * state advanced (MemoryNode.record, :317-335).  satrn_sift_reset = DecodingManager.reset (:248-255).
+ * satrn_model_greedy_rules = the greedy decode of satrn_model_greedy with the manager inside the decode kernel
+ * (networks/EfficientSATRN.py:536-554): `probs` receives the masked probabilities [B][steps][V], not logits. */
+int satrn_sift(const float* x, int ld, int32_t* state, const int32_t* rules, int B, int V, int64_t* targets, float* probs,
+               int ldp, void* stream);
+int satrn_sift_reset(int32_t* state, int B, int sos_id, void* stream);
+int satrn_model_greedy_rules(satrn_model* m, const float* images, const float* src, int B, int steps, const int32_t* rules,
+                             float* probs, int64_t* ids, void* stream);
 /* Step-wise decoding session = EfficientSATRN_decoder.step_forward / reset_status (networks/EfficientSATRN.py:932-952),
  * the interface the ensemble driver uses (utils/ensemble_utils.py:84-96: softmax-average the models' step logits, pick the
  * next token outside the model).  begin: src fp32 [B][N][dec_src] (an encoder output, satrn_model_encode) -> cross-

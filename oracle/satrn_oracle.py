@@ -21,6 +21,7 @@ All dropout is p=0 here (parity mode); BN runs in batch-stat mode when ``train``
 import math
 from collections import OrderedDict
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -570,3 +571,83 @@ def clip_adamw_step(params, grads, m, v, step, lr, wd=1e-6, max_norm=2.0, b1=0.9
         denom = (v[n].sqrt() / math.sqrt(bc2)).add_(eps)
         p.addcdiv_(m[n], denom, value=-lr / bc1)
     return total
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# DecodingManager (postprocessing/postprocessing.py:180-388) restated over the compiled rule table
+# (table[V + 8] int32: per-token flags | limit << 8, then ids sos, eos, "", "_", "{", "}").
+# ---------------------------------------------------------------------------------------------------------------
+R_NEXT_UNDERBAR, R_NEXT_LBRACKET, R_NOT_UNDERBAR, R_NOT_LBRACKET, R_NOT_INITIAL = 1, 2, 4, 8, 16
+
+
+def sift_blacklist(cur, series, nl, nr, table):
+    """MemoryNode._look_back (:337-388) -> bool [V]: tokens forbidden at the next step."""
+    V = len(table) - 8
+    sos, eos, empty, under, lbr, rbr = (int(v) for v in table[V:V + 6])
+    black = np.zeros(V, dtype=bool)
+    black[sos] = True
+    if empty >= 0:
+        black[empty] = True
+    if nl == nr and rbr >= 0:
+        black[rbr] = True
+    w = int(table[cur])
+    if cur == eos:
+        return black
+    if cur == sos:
+        black |= (np.asarray(table[:V]) & R_NOT_INITIAL) != 0
+        return black
+    if w & R_NEXT_UNDERBAR:
+        black[:] = True
+        black[under] = False
+        return black
+    if w & R_NEXT_LBRACKET:
+        black[:] = True
+        black[lbr] = False
+        return black
+    if w & R_NOT_UNDERBAR:
+        black[under] = True
+    if w & R_NOT_LBRACKET:
+        black[lbr] = True
+    lim = w >> 8
+    if lim > 0 and series >= lim:
+        black[cur] = True
+    return black
+
+
+def sift_new_state(batch, table):
+    V = len(table) - 8
+    return [[int(table[V]), 1, 0, 0] for _ in range(batch)]  # current token <SOS>, run length 1, no brackets (:308-315)
+
+
+def sift(x, state, table):
+    """DecodingManager.sift (:189-246): softmax of the input, blacklisted entries zeroed, argmax, MemoryNode.record
+    (:317-335).  x [B, V] float; state is updated in place.  Returns (targets int64 [B], masked probabilities [B, V])."""
+    V = len(table) - 8
+    lbr, rbr = int(table[V + 4]), int(table[V + 5])
+    probs = F.softmax(x.float(), dim=-1)
+    mask = torch.from_numpy(np.stack([sift_blacklist(*st, table) for st in state]))
+    probs = probs.masked_fill(mask, 0)
+    targets = torch.argmax(probs, dim=-1)
+    for st, t in zip(state, targets.tolist()):
+        st[1] = st[1] + 1 if st[0] == t else 1
+        if t == lbr:
+            st[2] += 1
+        elif t == rbr:
+            st[3] += 1
+        st[0] = t
+    return targets, probs
+
+
+def decoder_greedy_managed(src, num_steps, sd, cfg, table):
+    """networks/EfficientSATRN.py:528-561 WITH a DecodingManager: returns (masked probabilities [b, steps, V], ids)."""
+    b = src.size(0)
+    target = torch.full((b,), SOS_ID, dtype=torch.int64)
+    feats = [None] * cfg["dec_layers"]
+    state = sift_new_state(b, table)
+    outs, ids = [], []
+    for t in range(num_steps):
+        o = decoder_step(target, t, feats, src, sd, cfg)
+        target, pr = sift(o[:, -1, :], state, table)
+        outs.append(pr)
+        ids.append(target)
+    return torch.stack(outs, 1), torch.stack(ids, 1)

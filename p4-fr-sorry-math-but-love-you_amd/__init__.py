@@ -3,6 +3,8 @@ reference's module interface (networks.py, utils.py).  No CPU fallback: every co
 from . import _lib
 from ._lib import SatrnError
 from .networks import EfficientSATRN, LiteSATRN, EfficientSATRN_encoder, EfficientSATRN_decoder, SATRNCrossEntropy
+from . import decoding
+from .decoding import DeviceDecodingManager, compile_rules
 from .utils import get_network, load_vocab, Flags, START, END, PAD, SPECIAL_TOKENS
 
 __all__ = ["EfficientSATRN", "LiteSATRN", "EfficientSATRN_encoder", "EfficientSATRN_decoder", "SATRNCrossEntropy",

@@ -1336,7 +1336,7 @@ static int decode_one_step(Model* m, const int64_t* ids, int ld_ids, int t, int 
 // self-attention history of a layer is k/v_linear of that layer's previous OUTPUTS plus the current INPUT.
 // KV-cached: slot t first holds k/v(input_t), is attended, then is overwritten with k/v(output_t).
 static int greedy_body(Model* m, const float* img, const float* src_in, int B, int steps, float* logits_out, int64_t* ids_out,
-                       hipStream_t s) {
+                       hipStream_t s, const int32_t* rules) {
   Exec& e = *m->ex;
   const SatrnConfig& c = m->cfg;
   const int Dd = c.dec_hidden, V = c.num_classes;
@@ -1375,11 +1375,16 @@ static int greedy_body(Model* m, const float* img, const float* src_in, int B, i
     }
     dp.nlayers = L; dp.embed = m->embed.p; dp.pe = (const float*)(m->ws + m->off_pe1d); dp.wgen = m->gen.fwd; dp.bgen = m->gen_b.p;
     dp.logits = logits_out; dp.ids = ids_out; dp.B = B; dp.steps = steps; dp.D = Dd; dp.F = c.dec_filter; dp.V = V;
-    dp.H = c.dec_heads; dp.Nsrc = Nsrc; dp.sos = c.sos_id;
+    dp.H = c.dec_heads; dp.Nsrc = Nsrc; dp.sos = c.sos_id; dp.rules = rules;
     if (launch_decode_greedy(e.dt, dp, s) == 0) {
       if (e.oom) { m->err = "workspace exhausted"; return -2; }
       return 0;
     }
+  }
+  int32_t* sift_state = nullptr;
+  if (rules) {
+    sift_state = (int32_t*)e.alloc((size_t)B * 16);
+    launch_sift_reset(sift_state, B, c.sos_id, s);
   }
   const size_t mark = e.off;
   const size_t keep = e.tens.size();
@@ -1388,7 +1393,8 @@ static int greedy_body(Model* m, const float* img, const float* src_in, int B, i
     int rc = decode_one_step(m, t == 0 ? sos : ids_out + (t - 1), t == 0 ? 1 : steps, t, steps, crossKV, cache,
                              logits_out + (size_t)t * V, steps * V);
     if (rc) return rc;
-    launch_argmax(logits_out + (size_t)t * V, ids_out + t, B, V, steps * V, steps, s);
+    if (rules) launch_sift_strided(logits_out + (size_t)t * V, steps * V, sift_state, rules, B, V, ids_out + t, steps, s);
+    else launch_argmax(logits_out + (size_t)t * V, ids_out + t, B, V, steps * V, steps, s);
     e.tens.resize(keep);
   }
   if (e.oom) { m->err = "workspace exhausted"; return -2; }
@@ -1476,16 +1482,16 @@ int model_profile_step(Model* m, const float* img, const int64_t* expected, int 
 // Greedy decode entry: eager, or (use_graph) the whole decode -- encoder + every step's ~45 launches -- captured once
 // per (B, steps, buffer addresses) and replayed, which removes the host launch cost of ~10^4 kernels per batch.
 int model_greedy(Model* m, const float* img, const float* src_in, int B, int steps, float* logits_out, int64_t* ids_out,
-                 int use_graph, hipStream_t s) {
+                 int use_graph, hipStream_t s, const int32_t* rules) {
   if (!m->bound || !m->ws_set) { m->err = "bind parameters and set a workspace first"; return -1; }
   if (steps > 500) { m->err = "max 500 decode steps (PositionEncoder1D max_len)"; return -1; }
-  if (!use_graph) return greedy_body(m, img, src_in, B, steps, logits_out, ids_out, s);
+  if (!use_graph || rules) return greedy_body(m, img, src_in, B, steps, logits_out, ids_out, s, rules);
   const void* key[6] = {img, src_in, logits_out, ids_out, (void*)(intptr_t)B, (void*)(intptr_t)steps};
   if (m->decode_graph && memcmp(key, m->decode_key, sizeof(key)) != 0) { (void)hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
   if (!m->decode_graph) {
     hipGraph_t g = nullptr;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) { m->err = "stream capture failed"; return -3; }
-    int rc = greedy_body(m, img, src_in, B, steps, logits_out, ids_out, s);
+    int rc = greedy_body(m, img, src_in, B, steps, logits_out, ids_out, s, nullptr);
     hipError_t er = hipStreamEndCapture(s, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     if (er != hipSuccess || !g) { m->err = "decode graph capture failed"; return -3; }

@@ -160,5 +160,12 @@ struct DecodeP {
   float* logits; int64_t* ids;
   int B, steps, D, F, V, H, Nsrc, sos;
   int dbg;  // timing ablation bits (SATRN_DEC_DBG), 0 in production
+  const int32_t* rules;  // optional compiled DecodingManager rules [V + 8]: outputs become masked probabilities
 };
 int launch_decode_greedy(int dt, const DecodeP& p, hipStream_t s);
+// DecodingManager.sift / reset as launches: x [B][ld] logits (or probabilities), state int32 [B][4], targets int64 [B], probs [B][ldp]
+void launch_sift(const float* x, int ld, int32_t* state, const int32_t* rules, int B, int V, int64_t* targets, float* probs,
+                 int ldp, hipStream_t s);
+void launch_sift_reset(int32_t* state, int B, int sos, hipStream_t s);
+void launch_sift_strided(float* x, int ld, int32_t* state, const int32_t* rules, int B, int V, int64_t* targets, int ldt,
+                         hipStream_t s);

@@ -9,6 +9,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "sift.h"
 
 #define DEC_THREADS 1024
 #define DEC_WAVES (DEC_THREADS / 64)
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
   T* xT = reinterpret_cast<T*>(lg + ((V + 3) & ~3));  // [max(D,F)] current GEMV input in the compute dtype (16-byte aligned)
   __shared__ int s_tok;
   const int b = blockIdx.x, tid = threadIdx.x;
+  SiftState sst{p.sos, 1, 0, 0};  // DecodingManager memory of this sequence (uniform across the workgroup)
   const float inv_temp = rsqrtf((float)D);
   const float emb_scale = sqrtf((float)D);
   int tok = p.sos;
@@ -224,21 +226,31 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
     gemv<T>((const T*)p.wgen, p.bgen, xT, lg, V, D, ACT_NONE);
     __syncthreads();
     float* out = p.logits + ((long)b * p.steps + t) * V;
-    for (int i = tid; i < V; i += DEC_THREADS) out[i] = lg[i];
-    if (tid < 64) {
-      float best = -INFINITY;
-      int bi = 0x7fffffff;
-      for (int c = tid; c < V; c += 64) { float v = lg[c]; if (v > best) { best = v; bi = c; } }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        float ob = __shfl_xor(best, o, 64);
-        int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    if (p.rules) {
+      // DecodingManager.sift (postprocessing.py:189-246): the step's output becomes the masked softmax, the next token
+      // its argmax
+      if (tid < 64) {
+        const int bi = sift_wave(lg, out, V, sst, p.rules, tid);
+        if (tid == 0) { s_tok = bi; p.ids[(long)b * p.steps + t] = bi; }
       }
-      if (tid == 0) { s_tok = bi; p.ids[(long)b * p.steps + t] = bi; }
+    } else {
+      for (int i = tid; i < V; i += DEC_THREADS) out[i] = lg[i];
+      if (tid < 64) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = tid; c < V; c += 64) { float v = lg[c]; if (v > best) { best = v; bi = c; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          float ob = __shfl_xor(best, o, 64);
+          int oi = __shfl_xor(bi, o, 64);
+          if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (tid == 0) { s_tok = bi; p.ids[(long)b * p.steps + t] = bi; }
+      }
     }
     __syncthreads();
     tok = s_tok;
+    if (p.rules) sift_record(sst, tok, p.rules, V);
     __syncthreads();
   }
 }
@@ -262,4 +274,45 @@ int launch_decode_greedy(int dt, const DecodeP& p0, hipStream_t s) {
     hipLaunchKernelGGL((decode_greedy_kernel<float>), dim3(p.B), dim3(DEC_THREADS), sh, s, p);
   }
   return 0;
+}
+
+// ---- DecodingManager as stand-alone launches (ensemble driver / step-wise decode path) --------------------------
+__global__ __launch_bounds__(64) void sift_kernel(const float* x, int ld, int32_t* state, const int32_t* rules, int V,
+                                                  int64_t* targets, float* probs, int ldp) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  SiftState st{state[4 * b], state[4 * b + 1], state[4 * b + 2], state[4 * b + 3]};
+  const int bi = sift_wave(x + (long)b * ld, probs + (long)b * ldp, V, st, rules, lane);
+  if (lane == 0) {
+    sift_record(st, bi, rules, V);
+    state[4 * b] = st.cur; state[4 * b + 1] = st.series; state[4 * b + 2] = st.nl; state[4 * b + 3] = st.nr;
+    targets[b] = bi;
+  }
+}
+// in-place variant for the step-wise decode path: x[b*ld ..] is overwritten by the masked probabilities, the target
+// goes to targets[b*ldt]
+__global__ __launch_bounds__(64) void sift_strided_kernel(float* x, int ld, int32_t* state, const int32_t* rules, int V,
+                                                          int64_t* targets, int ldt) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  SiftState st{state[4 * b], state[4 * b + 1], state[4 * b + 2], state[4 * b + 3]};
+  const int bi = sift_wave(x + (long)b * ld, x + (long)b * ld, V, st, rules, lane);
+  if (lane == 0) {
+    sift_record(st, bi, rules, V);
+    state[4 * b] = st.cur; state[4 * b + 1] = st.series; state[4 * b + 2] = st.nl; state[4 * b + 3] = st.nr;
+    targets[(long)b * ldt] = bi;
+  }
+}
+void launch_sift_strided(float* x, int ld, int32_t* state, const int32_t* rules, int B, int V, int64_t* targets, int ldt,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(sift_strided_kernel, dim3(B), dim3(64), 0, s, x, ld, state, rules, V, targets, ldt);
+}
+__global__ void sift_reset_kernel(int32_t* state, int B, int sos) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) { state[4 * b] = sos; state[4 * b + 1] = 1; state[4 * b + 2] = 0; state[4 * b + 3] = 0; }
+}
+void launch_sift(const float* x, int ld, int32_t* state, const int32_t* rules, int B, int V, int64_t* targets, float* probs,
+                 int ldp, hipStream_t s) {
+  hipLaunchKernelGGL(sift_kernel, dim3(B), dim3(64), 0, s, x, ld, state, rules, V, targets, probs, ldp);
+}
+void launch_sift_reset(int32_t* state, int B, int sos, hipStream_t s) {
+  hipLaunchKernelGGL(sift_reset_kernel, dim3((B + 255) / 256), dim3(256), 0, s, state, B, sos);
 }

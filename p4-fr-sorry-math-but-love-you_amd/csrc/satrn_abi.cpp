@@ -354,6 +354,22 @@ int satrn_model_greedy(satrn_model* h, const float* img, const float* src, int B
                        int use_graph, void* st) {
   return mret(h, model_greedy(h->m, img, src, B, steps, logits, ids, use_graph, S(st)), "greedy");
 }
+int satrn_model_greedy_rules(satrn_model* h, const float* img, const float* src, int B, int steps, const int32_t* rules,
+                             float* probs, int64_t* ids, void* st) {
+  if (!rules) return fail(-1, "satrn_model_greedy_rules: rules is null");
+  return mret(h, model_greedy(h->m, img, src, B, steps, probs, ids, 0, S(st), rules), "greedy_rules");
+}
+int satrn_sift(const float* x, int ld, int32_t* state, const int32_t* rules, int B, int V, int64_t* targets, float* probs,
+               int ldp, void* st) {
+  if (!x || !state || !rules || !targets || !probs || B <= 0 || V <= 0 || ld < V || ldp < V) return fail(-1, "satrn_sift: bad argument");
+  launch_sift(x, ld, state, rules, B, V, targets, probs, ldp, S(st));
+  return 0;
+}
+int satrn_sift_reset(int32_t* state, int B, int sos_id, void* st) {
+  if (!state || B <= 0) return fail(-1, "satrn_sift_reset: bad argument");
+  launch_sift_reset(state, B, sos_id, S(st));
+  return 0;
+}
 int satrn_model_step_begin(satrn_model* h, const float* src, int B, int max_steps, void* st) {
   if (!src || B <= 0) return fail(-1, "satrn_model_step_begin: src is null or B <= 0");
   return mret(h, model_step_begin(h->m, src, B, max_steps, S(st)), "step_begin");

@@ -89,9 +89,6 @@ class _SATRNBase(nn.Module):
 
     def __init__(self, FLAGS, train_dataset, checkpoint=None, decoding_manager=None, dtype=None):
         super().__init__()
-        if decoding_manager is not None:
-            raise NotImplementedError("DecodingManager runs on the host in the reference (postprocessing/postprocessing.py); "
-                                      "it is not part of the accelerated path yet")
         lib = _lib.load()
         self._lib = lib
         dt = _DT[self._DEFAULT_DTYPE if dtype is None else dtype]
@@ -121,6 +118,12 @@ class _SATRNBase(nn.Module):
         self.decoder.num_classes = c.num_classes
         self.decoder.hidden_dim = c.dec_hidden
         self.decoder.filter_dim = c.dec_filter
+        # a reference DecodingManager (anything with .tokens / .rules) is compiled for the device once; like the
+        # reference (SATRNDecoder.manager, networks/EfficientSATRN.py:464) it only acts in the inference decode loop
+        from .decoding import DeviceDecodingManager
+        self.decoder.manager = None if decoding_manager is None else DeviceDecodingManager.wrap(decoding_manager)
+        if self.decoder.manager is not None and self.decoder.manager.vocab_size != c.num_classes:
+            raise SatrnError("decoding_manager vocabulary does not match the dataset's")
         self.criterion = SATRNCrossEntropy(ignore_index=c.pad_id)
         self._anchor = torch.zeros(1, requires_grad=True)
         self._gen = 0
@@ -311,7 +314,8 @@ class _SATRNBase(nn.Module):
 
     @torch.no_grad()
     def greedy(self, input, num_steps, use_graph=False):
-        """networks/EfficientSATRN.py:528-561 (no DecodingManager): -> (logits [B, steps, V], ids [B, steps]).
+        """networks/EfficientSATRN.py:528-561: -> (logits [B, steps, V], ids [B, steps]); with a decoding manager the
+        first tensor holds the masked softmax probabilities instead (:553-554), the rules run inside the decode kernel.
         With use_graph the whole decode (encoder + every step) replays as one hipGraph from persistent staging buffers
         (measured SLOWER than eager launches on ROCm 7.2 for this ~10^4-node graph: 100 ms vs 80 ms per 64x231 batch, so
         it is off by default); the first call of a shape always runs eagerly."""
@@ -329,9 +333,14 @@ class _SATRNBase(nn.Module):
         if self._side is None:
             self._side = torch.cuda.Stream(device=input.device)
         self._side.wait_stream(cur)
+        mgr = self.decoder.manager
         with torch.cuda.stream(self._side):
-            check(self._lib.satrn_model_greedy(self._h, ptr(simg), None, B, num_steps, ptr(slog), ptr(sids),
-                                               int(use_graph and warm[0]), _stream()), "satrn_model_greedy")
+            if mgr is not None:
+                check(self._lib.satrn_model_greedy_rules(self._h, ptr(simg), None, B, num_steps, ptr(mgr.table(input.device)),
+                                                         ptr(slog), ptr(sids), _stream()), "satrn_model_greedy_rules")
+            else:
+                check(self._lib.satrn_model_greedy(self._h, ptr(simg), None, B, num_steps, ptr(slog), ptr(sids),
+                                                   int(use_graph and warm[0]), _stream()), "satrn_model_greedy")
         cur.wait_stream(self._side)
         warm[0] = True
         return slog.clone(), sids.clone()
