@@ -199,6 +199,30 @@ def main():
             dsec = (time.perf_counter() - t1) / reps
             out["greedy_decode"] = dict(value=round(64 * 231 / dsec, 1), unit="tokens/s", batch=64, steps=231,
                                         ms_per_batch=round(dsec * 1e3, 2), includes="encoder + 231 decoder steps")
+            # the same decode with the DecodingManager rules evaluated inside the decode kernel (the reference's default
+            # at inference, inference.py:48); rule table = the reference RULES as compiled into tests/golden/rules.npz
+            rules_npz = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "rules.npz")
+            if os.path.exists(rules_npz):
+                import numpy as np
+                import satrn_amd
+                table = np.load(rules_npz)["table"]
+
+                class _M:
+                    tokens = ["<SOS>", "<EOS>"] + [f"t{i}" for i in range(len(table) - 10)]
+                    rules = {}
+                mgr = satrn_amd.DeviceDecodingManager(_M())
+                mgr._table_host = table.astype(np.int32)
+                model.decoder.manager = mgr
+                model.greedy(dimg, 231)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    model.greedy(dimg, 231)
+                torch.cuda.synchronize()
+                msec = (time.perf_counter() - t1) / reps
+                model.decoder.manager = None
+                out["greedy_decode"]["with_decoding_manager"] = dict(value=round(64 * 231 / msec, 1), unit="tokens/s",
+                                                                     ms_per_batch=round(msec * 1e3, 2))
             model.train()
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline ...")
