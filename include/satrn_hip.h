@@ -153,6 +153,12 @@ int satrn_embedding_bwd(int dtype, const int64_t* ids, int ld_ids, const void* d
 int satrn_cross_entropy(int dtype, const float* logits, const int64_t* targets, int ld, int B, int T, int V, int Vp,
                         int pad_id, float* loss_out, float* lse_ws, void* dlogits, void* stream);
 
+/* Knowledge-distillation loss of train_modules/train_distillation.py:49-55 (loss_fn_kd), forward and gradient in one
+ * pass: student / teacher fp32 logits [B][T][V], labels int64 [B][ld] (NOT ignored when PAD, as in the reference).
+ * loss = alpha*temperature^2 * KLDiv_batchmean(log_softmax(s/temperature), softmax(t/temperature)) + (1-alpha)*CE(s, labels);
+ * loss_out [1], dlogits fp32 [B][T][V] = d loss / d student. */
+int satrn_kd_loss(const float* student, const float* teacher, const int64_t* labels, int ld, int B, int T, int V,
+                  float temperature, float alpha, float* loss_out, float* dlogits, void* stream);
 /* clip_grad_norm_(max_norm) + AdamW.step over flat fp32 buffers: train_modules/train_single_opt.py:95-98.
  * gnorm_sq: device float, ZERO on entry (receives sum of squares, reduced in a fixed order so that data-parallel
  * replicas stay bit-identical); scratch1024: 1024 device floats.  hyper (device, 9 floats):

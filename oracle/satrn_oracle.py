@@ -651,3 +651,11 @@ def decoder_greedy_managed(src, num_steps, sd, cfg, table):
         outs.append(pr)
         ids.append(target)
     return torch.stack(outs, 1), torch.stack(ids, 1)
+
+
+def loss_fn_kd(outputs, labels, teacher_outputs, T=10, alpha=0.1):
+    """train_modules/train_distillation.py:49-55: outputs / teacher_outputs [B, V, T_len] logits, labels [B, T_len].
+    KL(softmax(teacher/T) || softmax(student/T)) summed over everything / B (reduction="batchmean") * alpha*T^2 plus
+    (1-alpha) * cross-entropy over ALL positions (no ignore_index: PAD labels count as an ordinary class)."""
+    kd = F.kl_div(F.log_softmax(outputs / T, dim=1), F.softmax(teacher_outputs / T, dim=1), reduction="batchmean")
+    return kd * (alpha * T * T) + F.cross_entropy(outputs, labels) * (1.0 - alpha)

@@ -2,7 +2,7 @@
 reference's module interface (networks.py, utils.py).  No CPU fallback: every compute path goes through the library."""
 from . import _lib
 from ._lib import SatrnError
-from .networks import EfficientSATRN, LiteSATRN, EfficientSATRN_encoder, EfficientSATRN_decoder, SATRNCrossEntropy
+from .networks import EfficientSATRN, LiteSATRN, EfficientSATRN_encoder, EfficientSATRN_decoder, SATRNCrossEntropy, loss_fn_kd
 from . import decoding
 from .decoding import DeviceDecodingManager, compile_rules
 from .utils import get_network, load_vocab, Flags, START, END, PAD, SPECIAL_TOKENS

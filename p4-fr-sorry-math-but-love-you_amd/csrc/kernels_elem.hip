@@ -1131,6 +1131,50 @@ void launch_ce_full(int dt_out, const float* logits, const int64_t* tgt, int ld_
   else launch_ce_bwd_t<float>(logits, tgt, ld_tgt, tgt_off, B, T_, V, Vp, pad_id, loss_out, lse_ws, dlogits, upstream, s);
 }
 
+// ---- knowledge-distillation loss (train_modules/train_distillation.py:49-55) on fp32 logits [R = B*T][V]: one wave per
+// row.  loss = alpha*Tk^2/B * sum_rows KL(softmax(t/Tk) || softmax(s/Tk)) + (1-alpha)/R * sum_rows CE(s, label)  (the
+// reference's CE here has no ignore_index).  dlogits = d loss / d s, written in the same pass.
+__global__ __launch_bounds__(256) void kd_loss_kernel(const float* st, const float* te, const int64_t* lab, int ld_lab, int T_,
+                                                      int V, long R, float inv_tk, float w_kd, float w_ce, float* out,
+                                                      float* dl) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float lsum = 0.f;
+  for (long r = (long)blockIdx.x * 4 + wv; r < R; r += (long)gridDim.x * 4) {
+    const float* x = st + r * V;
+    const float* y = te + r * V;
+    float mx = -INFINITY, my = -INFINITY;
+    for (int c = lane; c < V; c += 64) { mx = fmaxf(mx, x[c]); my = fmaxf(my, y[c]); }
+    mx = wave_max(mx); my = wave_max(my);
+    float s1 = 0.f, sk = 0.f, tk = 0.f;
+    for (int c = lane; c < V; c += 64) {
+      s1 += expf(x[c] - mx); sk += expf((x[c] - mx) * inv_tk); tk += expf((y[c] - my) * inv_tk);
+    }
+    s1 = wave_sum(s1); sk = wave_sum(sk); tk = wave_sum(tk);
+    const float lse1 = mx + logf(s1), lsek = mx * inv_tk + logf(sk), lset = my * inv_tk + logf(tk);
+    const int64_t t = lab[(r / T_) * ld_lab + (r % T_)];
+    float kl = 0.f;
+    for (int c = lane; c < V; c += 64) {
+      const float lq = x[c] * inv_tk - lsek, lp = y[c] * inv_tk - lset, pp = expf(lp);
+      kl += pp * (lp - lq);
+      dl[r * V + c] = w_kd * inv_tk * (expf(lq) - pp) + w_ce * (expf(x[c] - lse1) - (c == t ? 1.f : 0.f));
+    }
+    kl = wave_sum(kl);
+    if (lane == 0) lsum += w_kd * kl + w_ce * (lse1 - x[t]);
+  }
+  __shared__ float bsum[4];
+  if (lane == 0) bsum[wv] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, bsum[0] + bsum[1] + bsum[2] + bsum[3]);
+}
+void launch_kd_loss(const float* student, const float* teacher, const int64_t* labels, int ld_labels, int B, int T_, int V,
+                    float temperature, float alpha, float* loss_out, float* dlogits, hipStream_t s) {
+  const long R = (long)B * T_;
+  launch_fill(loss_out, 0, sizeof(float), s);
+  hipLaunchKernelGGL(kd_loss_kernel, dim3(grid_for(R, 4, 2048)), dim3(256), 0, s, student, teacher, labels, ld_labels, T_, V, R,
+                     1.0f / temperature, alpha * temperature * temperature / (float)B, (1.0f - alpha) / (float)R, loss_out,
+                     dlogits);
+}
+
 // ---- misc -----------------------------------------------------------------------------------------------
 template <typename TI, typename TO>
 __global__ void cast_kernel(const TI* in, TO* out, long n) {

@@ -285,6 +285,13 @@ int satrn_cross_entropy(int dt, const float* logits, const int64_t* targets, int
   launch_ce_full(dt, logits, targets, ld, 0, B, T, V, Vp, pad_id, loss_out, lse_ws, dlogits, nullptr, S(st));
   return done("cross_entropy");
 }
+int satrn_kd_loss(const float* student, const float* teacher, const int64_t* labels, int ld, int B, int T, int V,
+                  float temperature, float alpha, float* loss_out, float* dlogits, void* st) {
+  if (!student || !teacher || !labels || !loss_out || !dlogits || B <= 0 || T <= 0 || V <= 0 || !(temperature > 0.f))
+    return fail(-1, "satrn_kd_loss: bad argument");
+  launch_kd_loss(student, teacher, labels, ld, B, T, V, temperature, alpha, loss_out, dlogits, S(st));
+  return done("kd_loss");
+}
 int satrn_clip_adamw(float* p, const float* g, float* m, float* v, long n, float* gnorm_sq, float* scratch1024,
                      const float* hyper, void* st) {
   launch_sumsq(g, n, gnorm_sq, scratch1024, S(st));

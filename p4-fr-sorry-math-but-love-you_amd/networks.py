@@ -65,6 +65,35 @@ class _CEFunction(torch.autograd.Function):
         return (dl * g).transpose(1, 2), None, None
 
 
+class _KDFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, outputs, labels, teacher_outputs, T, alpha):
+        lib = _lib.load()
+        if not outputs.is_cuda:
+            raise SatrnError("loss_fn_kd needs CUDA/HIP tensors (no CPU fallback)")
+        s = outputs.transpose(1, 2).contiguous().float()          # [B, T_len, V]
+        t = teacher_outputs.transpose(1, 2).contiguous().float()
+        B, TL, V = s.shape
+        lab = labels if labels.stride(1) == 1 else labels.contiguous()
+        out = torch.empty(1, dtype=torch.float32, device=s.device)
+        dl = torch.empty_like(s)
+        check(lib.satrn_kd_loss(ptr(s), ptr(t), ptr(lab), lab.stride(0), B, TL, V, float(T), float(alpha), ptr(out), ptr(dl),
+                                _stream()), "satrn_kd_loss")
+        ctx.save_for_backward(dl)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return (dl * g).transpose(1, 2), None, None, None, None
+
+
+def loss_fn_kd(outputs, labels, teacher_outputs, T=10, alpha=0.1):
+    """train_modules/train_distillation.py:49-55 with the same call signature: outputs / teacher_outputs [B, V, T_len]
+    (logits.transpose(1, 2)), labels [B, T_len]; one fused kernel computes the loss and d loss / d outputs."""
+    return _KDFunction.apply(outputs, labels, teacher_outputs, T, alpha)
+
+
 class _TFFunction(torch.autograd.Function):
     """Teacher-forced forward of the whole model as ONE autograd node; backward replays the engine's tape."""
 
