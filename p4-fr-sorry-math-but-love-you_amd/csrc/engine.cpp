@@ -1212,7 +1212,10 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
   // hyper-parameters for this step (lr changes every iteration in the reference's scheduler)
   if (phase & 2) m->adam_t += 1;
   if (!m->hy_pinned && hipHostMalloc((void**)&m->hy_pinned, 64 * 16 * sizeof(float), 0) != hipSuccess) { m->err = "hipHostMalloc failed"; return -5; }
-  float* hy = m->hy_pinned + (m->adam_t % 64) * 16;
+  // one pinned slot per CALL: the async copy below reads the slot when the GPU gets there, and the host may be several
+  // calls ahead by then (a slot keyed by the optimizer step was overwritten by the next step's phase-1 call while the
+  // phase-2 copy of the previous step was still queued: wrong grad_scale on whichever rank lost that race)
+  float* hy = m->hy_pinned + (m->hy_seq++ % 64) * 16;
   memcpy(hy, hyper9, 9 * sizeof(float));
   hy[6] = 1.0f - powf(hy[1], (float)m->adam_t);
   hy[7] = 1.0f - powf(hy[2], (float)m->adam_t);

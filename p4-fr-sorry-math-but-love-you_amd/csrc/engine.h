@@ -108,7 +108,7 @@ struct Model {
   hipGraphExec_t graphs[4] = {nullptr, nullptr, nullptr, nullptr}; int graph_B = 0, graph_L = 0;
   long adam_t = 0;
   hipGraphExec_t decode_graph = nullptr; const void* decode_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  float* hy_pinned = nullptr;
+  float* hy_pinned = nullptr; unsigned long hy_seq = 0;
   // step-wise decoding session (satrn_model_step_begin / satrn_model_step)
   std::vector<struct Tensor*> step_cross, step_cache; int step_B = 0, step_max = 0, step_t = 0; size_t step_mark = 0, step_keep = 0;
   long epoch = 0, step_epoch = -1;  // every arena reset bumps epoch: a session from an older epoch is dead
