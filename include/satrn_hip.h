@@ -213,9 +213,14 @@ int satrn_model_loss_backward(satrn_model* m, const int64_t* expected, int B, in
 /* forward + CE + backward + clip + AdamW + re-pack; hyper9 is a HOST array (see satrn_clip_adamw; entries 6,7
  * are filled in by the library).  use_graph != 0 replays one captured hipGraph per (B, L): images / expected must
  * then stay at the same device addresses from call to call.  phase: bit 0 = zero grads + forward + CE + backward,
- * bit 1 = clip + AdamW + re-pack (data-parallel callers all-reduce the flat gradient between the two). */
+ * bit 1 = clip + AdamW + re-pack (data-parallel callers all-reduce the flat gradient between the two).
+ * phase = 16 + k (k = 0..3, in order, eager only): the same work as bit 0 cut into four backward segments -- k = 0 zeroes
+ * the gradients, runs forward + CE and the decoder's backward; 1 = encoder transformer + positional encoding; 2 = last
+ * backbone stage; 3 = the rest.  When call k returns, the flat-gradient range satrn_model_segment_range(k) is final on
+ * `stream`, so its all-reduce can run (on another stream) while the following segments execute. */
 int satrn_model_train_step(satrn_model* m, const float* images, const int64_t* expected, int B, int L,
                            const float* hyper9, int use_graph, int phase, void* stream);
+int satrn_model_segment_range(satrn_model* m, int seg, int64_t* lo, int64_t* hi); /* [lo, hi) in flat fp32 elements */
 int satrn_model_read_loss(satrn_model* m, float* out4_host, void* stream); /* sum, count, mean, gnorm^2; syncs */
 int satrn_model_encode(satrn_model* m, const float* images, int B, float* src_out, void* stream);
 /* KV-cached greedy decode; images may be NULL when src (fp32 [B][N][dec_src]) is given.

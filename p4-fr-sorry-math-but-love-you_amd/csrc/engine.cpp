@@ -193,6 +193,8 @@ const StageDef kEffV2S[6] = {{0, 2, 1, 1, 24, 0.f},   {1, 4, 2, 4, 48, 0.f},   {
                              {2, 6, 2, 4, 128, .25f}, {2, 9, 1, 6, 160, .25f}, {2, 15, 2, 6, 256, .25f}};
 }  // namespace
 
+static void segment_ranges(Model* m);
+
 Model* model_create(const SatrnConfig& cfg) {
   Model* m = new Model();
   m->cfg = cfg;
@@ -356,6 +358,7 @@ Model* model_create(const SatrnConfig& cfg) {
   m->ex = new Exec();
   m->ex->m = m;
   if (!getenv("SATRN_NO_SIDE_STREAM")) (void)hipStreamCreateWithFlags(&m->ex->s2, hipStreamNonBlocking);
+  segment_ranges(m);
   return m;
 }
 
@@ -960,13 +963,18 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
   } else {
     x = op_stem(e, img, &m->stem, B, c.rgb, c.height, c.width, 2, 0);
     x = op_bn_act(e, x, &m->stem_bn, ACT_SILU, nullptr);
-    for (auto& eb : m->blocks) x = eff_block(e, x, &eb);
+    for (size_t bi = 0; bi < m->blocks.size(); ++bi) {
+      if ((int)bi == m->late_block) m->seg_mark[0] = e.tape.size();
+      x = eff_block(e, x, &m->blocks[bi]);
+    }
     int H = x->H, W = x->W;
     x = op_gemm(e, x, &m->conv_last, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
     x->B = B; x->H = H; x->W = W;
     x = op_bn_act(e, x, &m->bn_last, ACT_SILU, nullptr);
   }
   if (x->H != m->feat_h || x->W != m->feat_w) { m->err = "feature map size does not match input_size/32 (or /16)"; e.oom = true; }
+  m->seg_mark[1] = e.tape.size();  // end of the backbone
+  if (c.network == 0) m->seg_mark[0] = 0;
   // adaptive 2D positional encoding (networks/EfficientSATRN.py:135-154)
   Tensor* pooled = op_pool(e, x);
   Tensor* h0 = op_gemm(e, pooled, &m->pe_d0, &m->pe_b0, ACT_RELU, e.drop, nullptr);
@@ -1161,8 +1169,53 @@ int model_forward(Model* m, const float* img, const int64_t* expected, int B, in
   Exec& e = *m->ex;
   exec_begin(m, s, train, record, false);
   e.src = encoder_forward(e, img, B);
+  m->seg_mark[2] = e.tape.size();  // end of the encoder
+  m->seg_next = 0;
   e.logits = teacher_forced ? decoder_tf(e, e.src, expected, B, L, logits_out) : decoder_ar(e, e.src, B, L, logits_out);
   if (e.oom) { if (m->err.empty()) m->err = "workspace exhausted"; return -2; }
+  return 0;
+}
+
+// Backward in four segments (decoder | encoder transformer + positional encoding | late backbone | early backbone): after
+// segment k, the flat-gradient range seg_lo[k]..seg_hi[k] is final on stream s (side-stream weight gradients joined), so
+// a data-parallel caller can start reducing it while the next segments run.
+static void segment_ranges(Model* m) {
+  const int64_t off_dec = m->embed.off, off_pe = m->pe_d0.off;
+  int64_t off_late = 0;
+  m->late_block = 0;
+  if (m->cfg.network != 0 && !m->blocks.empty()) {
+    // last stage of the backbone (15 blocks at 4x12, ~47 % of all parameters) + conv_last
+    size_t k = m->blocks.size();
+    while (k > 0 && m->blocks[k - 1].cout == m->blocks.back().cout) --k;
+    m->late_block = (int)k;
+    off_late = m->blocks[k].c0.off;
+  }
+  m->seg_lo[0] = off_dec;  m->seg_hi[0] = m->n_params;
+  m->seg_lo[1] = off_pe;   m->seg_hi[1] = off_dec;
+  m->seg_lo[2] = off_late; m->seg_hi[2] = off_pe;
+  m->seg_lo[3] = 0;        m->seg_hi[3] = off_late;
+}
+
+int model_backward_segment(Model* m, const int64_t* expected, int B, int L, int seg, hipStream_t s) {
+  Exec& e = *m->ex;
+  if (!e.logits) { m->err = "no forward"; return -1; }
+  if (seg != m->seg_next || seg < 0 || seg > 3) { m->err = "backward segments must run in order 0..3 after a recorded forward"; return -1; }
+  e.s = s;
+  if (seg == 0) {
+    Tensor* lg = e.logits;
+    const int Vp = m->gen.ldb, V = m->cfg.num_classes;
+    float* lse = (float*)e.alloc((size_t)lg->rows * 4);
+    lg->g = e.alloc((size_t)lg->rows * Vp * e.esz());
+    lg->g_init = true;
+    launch_ce_full(e.dt, (const float*)lg->p, expected, L, 1, B, L - 1, V, Vp, m->cfg.pad_id, scal(m) + SC_LOSS, lse, lg->g, nullptr, s);
+  }
+  const size_t hi = seg == 0 ? e.tape.size() : m->seg_mark[3 - seg];
+  const size_t lo = seg == 3 ? 0 : m->seg_mark[2 - seg];
+  for (size_t i = hi; i > lo; --i) e.tape[i - 1]();
+  e.join();
+  m->seg_next = seg + 1;
+  if (seg == 3) e.tape.clear();
+  if (e.oom) { m->err = "workspace exhausted in backward"; return -2; }
   return 0;
 }
 
@@ -1206,6 +1259,17 @@ int model_loss_backward(Model* m, const int64_t* expected, int B, int L, hipStre
 
 int model_train_step(Model* m, const float* img, const int64_t* expected, int B, int L, const float* hyper9,
                      int use_graph, int phase, hipStream_t s) {
+  const int seg = (phase & 16) ? (phase & 3) : -1;  // 16 + k: backward segment k (k == 0 also zeroes grads and runs forward + CE)
+  if (seg >= 0) {
+    if (!m->bound || !m->ws_set || !m->grads) { m->err = "bind parameters/grads and set a workspace first"; return -1; }
+    if (seg == 0) {
+      launch_seed_advance((uint32_t*)(scal(m) + SC_SEED), s);
+      launch_fill(m->grads, 0, (size_t)m->n_params * 4, s);
+      int rc = model_forward(m, img, expected, B, L, true, true, nullptr, s);
+      if (rc) return rc;
+    }
+    return model_backward_segment(m, expected, B, L, seg, s);
+  }
   phase &= 3;
   if (!phase) return 0;
   if (!m->bound || !m->ws_set || !m->grads) { m->err = "bind parameters/grads and set a workspace first"; return -1; }

@@ -111,6 +111,9 @@ struct Model {
   float* hy_pinned = nullptr; unsigned long hy_seq = 0;
   // step-wise decoding session (satrn_model_step_begin / satrn_model_step)
   std::vector<struct Tensor*> step_cross, step_cache; int step_B = 0, step_max = 0, step_t = 0; size_t step_mark = 0, step_keep = 0;
+  // backward segments for overlapping the gradient exchange with the rest of the backward pass: tape marks recorded
+  // in forward (early/late backbone, end of backbone, end of encoder) and the flat-gradient range each segment completes
+  size_t seg_mark[3] = {0, 0, 0}; int64_t seg_lo[4] = {0, 0, 0, 0}, seg_hi[4] = {0, 0, 0, 0}; int late_block = 0; int seg_next = 0;
   long epoch = 0, step_epoch = -1;  // every arena reset bumps epoch: a session from an older epoch is dead
   std::string err;
 };
@@ -163,6 +166,7 @@ int model_read_loss(Model* m, float* out4, hipStream_t s);
 int model_encode(Model* m, const float* img, int B, float* src_out, hipStream_t s);
 int model_greedy(Model* m, const float* img, const float* src_or_null, int B, int steps, float* logits_out,
                  int64_t* ids_out, int use_graph, hipStream_t s, const int32_t* rules = nullptr);
+int model_backward_segment(Model* m, const int64_t* expected, int B, int L, int seg, hipStream_t s);
 int model_step_begin(Model* m, const float* src, int B, int max_steps, hipStream_t s);
 int model_step(Model* m, const int64_t* target, float* logits_out, hipStream_t s);
 int model_profile_step(Model* m, const float* img, const int64_t* expected, int B, int L, char* out, size_t out_cap,

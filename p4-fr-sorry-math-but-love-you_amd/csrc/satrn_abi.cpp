@@ -377,6 +377,11 @@ int satrn_sift_reset(int32_t* state, int B, int sos_id, void* st) {
   launch_sift_reset(state, B, sos_id, S(st));
   return 0;
 }
+int satrn_model_segment_range(satrn_model* h, int seg, int64_t* lo, int64_t* hi) {
+  if (!h || seg < 0 || seg > 3 || !lo || !hi) return fail(-1, "satrn_model_segment_range: bad argument");
+  *lo = h->m->seg_lo[seg]; *hi = h->m->seg_hi[seg];
+  return 0;
+}
 int satrn_model_step_begin(satrn_model* h, const float* src, int B, int max_steps, void* st) {
   if (!src || B <= 0) return fail(-1, "satrn_model_step_begin: src is null or B <= 0");
   return mret(h, model_step_begin(h->m, src, B, max_steps, S(st)), "step_begin");

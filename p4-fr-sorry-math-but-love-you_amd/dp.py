@@ -46,12 +46,26 @@ def shard_batch(n_items, rank, world):
     return s, min(n_items, s + per)
 
 
-def dp_train_step(model, images, expected, lr, **kw):
-    """forward/backward graph -> flat-gradient all-reduce -> clip + AdamW graph (grad_scale = 1/world)."""
+def dp_train_step(model, images, expected, lr, overlap=True, **kw):
+    """One data-parallel step.  overlap=True (eager execution): the backward runs in four segments (decoder | encoder
+    transformer | last backbone stage | rest); as soon as a segment is done, the all-reduce of the flat-gradient range it
+    completed is started asynchronously (RCCL on its own stream) and runs beside the remaining segments.  Otherwise:
+    forward/backward -> one flat all-reduce -> clip + AdamW.  Both end with grad_scale = 1/world inside the optimizer."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
         model.train_step(images, expected, lr, **kw)
         return
-    model.train_step(images, expected, lr, phase=1, **kw)
-    allreduce_flat(model.flat_grad())
+    if overlap and not kw.get("use_graph", False):
+        kw2 = {k: v for k, v in kw.items() if k != "use_graph"}
+        works = []
+        for seg in range(4):
+            model.train_step(images, expected, lr, phase=16 + seg, **kw2)
+            lo, hi = model.segment_range(seg)
+            if hi > lo:
+                works.append(dist.all_reduce(model.flat_grad()[lo:hi], async_op=True))
+        for w in works:
+            w.wait()
+    else:
+        model.train_step(images, expected, lr, phase=1, **kw)
+        allreduce_flat(model.flat_grad())
     model.train_step(images, expected, lr, phase=2, grad_scale=1.0 / world, **kw)

@@ -392,7 +392,8 @@ class _SATRNBase(nn.Module):
         (train_modules/train_single_opt.py:80-98 with teacher forcing).  Default: eager launches on two HIP streams (weight
         gradients run beside the data-gradient chain; measured 15.4 ms vs 17.0 ms for the single-chain hipGraph replay,
         which use_graph=True selects).  phase: 1 = forward/backward only,
-        2 = clip + AdamW only (data-parallel callers all-reduce the flat gradient in between), 3 = both."""
+        2 = clip + AdamW only (data-parallel callers all-reduce the flat gradient in between), 3 = both; 16 + k = backward
+        segment k of phase 1 (k = 0..3 in order; overlapped gradient exchange, see dp.dp_train_step)."""
         input = self._img(input)
         B, L = expected.shape
         self._ensure_bound(input.device)
@@ -401,8 +402,9 @@ class _SATRNBase(nn.Module):
             self._ensure_packed()
         if self._stage is None or self._stage[0].shape != input.shape or self._stage[1].shape != expected.shape:
             self._stage = (torch.empty_like(input), torch.empty_like(expected.contiguous()))
-        self._stage[0].copy_(input, non_blocking=True)
-        self._stage[1].copy_(expected, non_blocking=True)
+        if int(phase) in (1, 3, 16):  # calls that start a step stage its inputs; later segments / phase 2 reuse them
+            self._stage[0].copy_(input, non_blocking=True)
+            self._stage[1].copy_(expected, non_blocking=True)
         hy = (ctypes.c_float * 9)(lr, betas[0], betas[1], eps, weight_decay, max_grad_norm, 0.0, 0.0, grad_scale)
         # graphs are captured on a private stream (the legacy default stream cannot capture); the first step of a shape
         # runs eagerly so that one-time kernel attribute setup never lands inside a capture
@@ -433,6 +435,12 @@ class _SATRNBase(nn.Module):
               "satrn_model_profile_step")
         self._gen += 1
         return json.loads(buf.value.decode())
+
+    def segment_range(self, seg):
+        """[lo, hi) of the flat gradient that train_step(phase=16 + seg) completes (see include/satrn_hip.h)."""
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        check(self._lib.satrn_model_segment_range(self._h, int(seg), ctypes.byref(lo), ctypes.byref(hi)), "segment_range")
+        return lo.value, hi.value
 
     def flat_grad(self):
         """the flat fp32 gradient buffer every p.grad is a view of (what the data-parallel all-reduce runs on)."""

@@ -50,3 +50,58 @@ def test_bucket_bounds_cover_buffer():
     assert b[0][0] == 0 and b[-1][1] == 27221141
     assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
     assert all((e - s) % 4 == 0 for s, e in b[:-1])
+
+
+class _FakeModel:
+    """records the call sequence of dp.dp_train_step and lets 'segments' fill their flat-gradient ranges"""
+
+    def __init__(self, rank):
+        self.g = torch.zeros(1000)
+        self.rank = rank
+        self.calls = []
+        self.ranges = [(700, 1000), (400, 700), (100, 400), (0, 100)]
+
+    def flat_grad(self):
+        return self.g
+
+    def segment_range(self, seg):
+        return self.ranges[seg]
+
+    def train_step(self, images, expected, lr, phase=3, grad_scale=1.0, **kw):
+        self.calls.append((phase, grad_scale))
+        if phase == 1:
+            self.g[:] = float(self.rank + 1)
+        elif phase >= 16:
+            lo, hi = self.ranges[phase - 16]
+            if phase == 16:
+                self.g.zero_()
+            self.g[lo:hi] = float(self.rank + 1)
+
+
+def _overlap_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from satrn_amd import dp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = _FakeModel(rank), _FakeModel(rank)
+    dp.dp_train_step(a, None, None, 1e-3, overlap=True)
+    dp.dp_train_step(b, None, None, 1e-3, overlap=False)
+    ok = bool((a.g == 3.0).all()) and bool((b.g == 3.0).all())  # 1 + 2 summed over the two ranks, every element once
+    ok = ok and [c[0] for c in a.calls] == [16, 17, 18, 19, 2] and [c[0] for c in b.calls] == [1, 2]
+    ok = ok and a.calls[-1][1] == 0.5 and b.calls[-1][1] == 0.5
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_reduces_every_segment_once_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

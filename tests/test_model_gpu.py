@@ -287,3 +287,41 @@ def test_train_autoregressive_branch_with_gradients(dtype):
         worst = sorted(errs, reverse=True)[:4]
         print(f"[ar:{dtype}] worst grad rel-L2: " + ", ".join(f"{n_}={e_:.2e}" for e_, n_ in worst))
         assert float(np.median([e_ for e_, _ in errs])) < 1e-3 and worst[0][0] < 3e-2
+
+
+@pytest.mark.parametrize("name", ["lite_c1_pad", "eff_small"])
+def test_segmented_backward_equals_whole_backward(golden_dir, name):
+    """train_step(phase=16+k), k = 0..3 (the overlapped data-parallel exchange's backward segments) leaves the same flat
+    gradient as phase=1, and the four segment ranges tile the flat buffer in backward order."""
+    z, meta, cfg = load_case(golden_dir, name)
+    B, H, W, T = (int(meta[k]) for k in ("batch", "height", "width", "seq_len"))
+    img, expected = O.det_inputs(B, cfg["rgb"], H, W, T, seed=int(meta["iseed"]), pad_tail=int(meta["pad_tail"]))
+    imgd, expd = img.cuda(), expected.cuda()
+    model, _ = build(cfg, H, W, "f32", int(meta["wseed"]))
+    model.train()
+    model.train_step(imgd, expd, 0.0, phase=1)
+    torch.cuda.synchronize()
+    whole = model.flat_grad().detach().clone()
+    loss1 = model.read_loss()[0]
+    # run-to-run noise of the same computation (float atomics arrive in a different order; tiny BatchNorm batches amplify it)
+    model.train_step(imgd, expd, 0.0, phase=1)
+    torch.cuda.synchronize()
+    gmax = whole.abs().max().item()
+    tol = 10.0 * (model.flat_grad() - whole).abs().max().item() + 1e-4 * gmax
+    n = whole.numel()
+    ranges = [model.segment_range(k) for k in range(4)]
+    assert ranges[0][1] == n and ranges[3][0] == 0 and all(ranges[k][0] == ranges[k + 1][1] for k in range(3))
+    for k in range(4):
+        model.train_step(imgd, expd, 0.0, phase=16 + k)
+        torch.cuda.synchronize()
+        lo, hi = ranges[k]
+        if hi > lo:  # the range a segment completes is final as soon as its call returns
+            d = (model.flat_grad()[lo:hi] - whole[lo:hi]).abs().max().item()
+            assert d <= tol, f"segment {k}: {d} > {tol}"
+    assert abs(model.read_loss()[0] - loss1) < 1e-4
+    d = (model.flat_grad() - whole).abs().max().item()
+    print(f"[segments:{name}] max diff {d:.3e} (tolerance {tol:.3e}, max |g| {gmax:.3e})")
+    assert d <= tol
+    import satrn_amd
+    with pytest.raises(satrn_amd.SatrnError):
+        model.train_step(imgd, expd, 0.0, phase=18)  # out of order
