@@ -227,6 +227,7 @@ static void launch_gemm_t(const GemmP& p, hipStream_t s) {
 #define FORCE_CASE(BM_, BN_, KP_) if (bm == BM_ && bn == BN_ && kp == KP_) { hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, AM, (AM == AM_DENSE && BF) ? KP_ : 1>), dim3(blocks(BM_, BN_)), dim3(256), 0, s, p); return; }
       FORCE_CASE(64, 64, 1) FORCE_CASE(64, 64, 2) FORCE_CASE(64, 64, 4) FORCE_CASE(128, 64, 1) FORCE_CASE(128, 64, 2)
       FORCE_CASE(128, 128, 1) FORCE_CASE(128, 128, 2) FORCE_CASE(256, 32, 1)
+      FORCE_CASE(64, 32, 1) FORCE_CASE(64, 32, 2) FORCE_CASE(64, 32, 4)
 #undef FORCE_CASE
     }
   }
@@ -243,9 +244,16 @@ static void launch_gemm_t(const GemmP& p, hipStream_t s) {
   } else if (p.N > 64 && blocks(128, 128) >= 1024) {
     if (kp >= 2 && BF) hipLaunchKernelGGL((gemm_kernel<T, 128, 128, AM, (D && BF ? 2 : 1)>), dim3(blocks(128, 128)), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<T, 128, 128, AM, 1>), dim3(blocks(128, 128)), dim3(256), 0, s, p);
+  } else if (D && p.N >= 64 && blocks(64, 64) <= 800) {
+    // small grids (late stages: M <= 6144): 64x32 tiles double the number of workgroups; 13-20 % faster on the
+    // M=1536/6144 shapes of tools/gemm_bench.py (SMALLN=1), deep K staged 4 panels per barrier
+    if (nk32 >= 24 && BF) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D && BF ? 4 : 1)>), dim3(blocks(64, 32)), dim3(256), 0, s, p);
+    else if (nk32 >= 4) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D ? 2 : 1)>), dim3(blocks(64, 32)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, 1>), dim3(blocks(64, 32)), dim3(256), 0, s, p);
   } else {
-    if (kp == 4 && BF) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, (D && BF ? 4 : 1)>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
-    else if (kp >= 2) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, (D ? 2 : 1)>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
+    // medium grids: several workgroups per CU, so LDS per workgroup (occupancy) matters more than barriers -- two panels
+    // per barrier only from K = 256 up, never four (M=1536 N=1536 K=512: 17.7 us with KP=4, 12.2 with KP=2)
+    if (kp >= 2 && nk32 >= 8) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, (D ? 2 : 1)>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, 1>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
   }
 }

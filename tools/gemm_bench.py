@@ -16,7 +16,7 @@ def bench(fn, iters=200):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e3  # us
 
-shapes = [(1536, 1536, 256), (1536, 256, 1536), (6144, 960, 160), (6144, 160, 960), (6144, 512, 128), (6144, 128, 512),
+shapes = [(1536, 256, 1536), (1536, 512, 512), (6144, 160, 960), (6144, 128, 512), (1536, 256, 512), (1536, 512, 256)] if os.environ.get('SMALLN') == '1' else [(1536, 1536, 256), (6144, 960, 160), (6144, 512, 128), (1536, 1536, 512), (4096, 1024, 256), (6144, 768, 192)] if os.environ.get('SMALLN') == '2' else [(1536, 1536, 256), (1536, 256, 1536), (6144, 960, 160), (6144, 160, 960), (6144, 512, 128), (6144, 128, 512),
           (4096, 1024, 256), (4096, 256, 1024), (4096, 768, 256), (1536, 512, 512), (98304, 48, 192)]
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 for M, N, K in shapes:
