@@ -224,6 +224,16 @@ def main():
                 model.decoder.manager = None
                 out["greedy_decode"]["with_decoding_manager"] = dict(value=round(64 * 231 / msec, 1), unit="tokens/s",
                                                                      ms_per_batch=round(msec * 1e3, 2))
+            # the decode is one dependent chain per image (one workgroup each): 64 images use 64 of the 256 CUs, so a larger
+            # batch costs almost nothing extra -- reported beside the BASELINE batch, not instead of it
+            dimg4 = torch.cat([dimg] * 4)
+            model.greedy(dimg4, 231)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            model.greedy(dimg4, 231)
+            torch.cuda.synchronize()
+            d4 = time.perf_counter() - t1
+            out["greedy_decode"]["batch_256"] = dict(value=round(256 * 231 / d4, 1), unit="tokens/s", ms_per_batch=round(d4 * 1e3, 2))
             model.train()
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline ...")

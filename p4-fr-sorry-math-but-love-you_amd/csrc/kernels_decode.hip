@@ -31,12 +31,68 @@ template <> DEVI void ld4<bf16_t>(const bf16_t* p, float* o) {
 // reduction happens inside the MFMA -- no cross-lane shuffles, and the unrolled k loop keeps 8+ loads in flight per
 // lane, which is what a latency-bound weight stream needs.  xT: the input vector in the compute dtype (LDS).
 template <typename T>
-DEVI void gemv(const T* __restrict__ W, const float* __restrict__ bias, const T* xT, float* y, int N, int K, int act) {
+DEVI void gemv(const T* __restrict__ W, const float* __restrict__ bias, const T* xT, float* y, int N, int K, int act,
+               float* part = nullptr) {
   constexpr int CH = TT<T>::CH;
   constexpr int GU = 2;  // 16-output groups per wave iteration: 2 x 8 weight loads in flight per lane
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int ng = (N + 15) >> 4;
+  // deep, narrow products (FFN second linear: N = D, K = 4D) leave most waves idle and make the busy ones walk K in
+  // several dependent batches of loads: split K into 256-wide slices spread over the waves (one batch each), partial
+  // sums through LDS (part: [K/256][N] floats), then one pass adds them up
+  if (part && K > 256 && (K & 255) == 0 && ng * (K >> 8) <= 4 * DEC_WAVES * GU) {
+    const int ks = K >> 8, items = ng * ks;
+    for (int it0 = wave * GU; it0 < items; it0 += DEC_WAVES * GU) {
+      const T* wr[GU];
+      const T* xr[GU];
+      f32x4 acc[GU];
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int it = it0 + u < items ? it0 + u : items - 1;
+        const int g = it / ks, sl = it - g * ks;
+        int row = g * 16 + fr;
+        if (row >= N) row = N - 1;
+        wr[u] = W + (long)row * K + sl * 256 + fq * 8;
+        xr[u] = xT + sl * 256 + fq * 8;
+        acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int kk = 0; kk < 256; kk += 32) {
+        Frag<T> a[GU], b[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+          reinterpret_cast<uint4*>(&a[u])[0] = ld16(wr[u] + kk);
+          if (CH == 4) reinterpret_cast<uint4*>(&a[u])[1] = ld16(wr[u] + kk + 4);
+          reinterpret_cast<uint4*>(&b[u])[0] = ld16(xr[u] + kk);
+          if (CH == 4) reinterpret_cast<uint4*>(&b[u])[1] = ld16(xr[u] + kk + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) mma(a[u], b[u], acc[u]);
+      }
+      if (fr == 0) {
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+          const int it = it0 + u;
+          if (it < items) {
+            const int g = it / ks, sl = it - g * ks;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int n = g * 16 + fq * 4 + r;
+              if (n < N) part[sl * N + n] = acc[u][r];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += DEC_THREADS) {
+      float v = bias ? bias[n] : 0.f;
+      for (int sl = 0; sl < ks; ++sl) v += part[sl * N + n];
+      y[n] = act == ACT_RELU ? fmaxf(v, 0.f) : v;
+    }
+    return;
+  }
   const T* xr = xT + fq * 8;
   for (int g0 = wave * GU; g0 < ng; g0 += DEC_WAVES * GU) {
     const T* wr[GU];
@@ -170,7 +226,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
   float* tmp = att + D;          // [D]
   float* ff = tmp + D;           // [F]
   float* sc = ff + F;            // [H][nkP]
-  float* red = sc + (H * nkP > 3 * D ? H * nkP : 3 * D);  // [2*DEC_WAVES]  (sc doubles as a 3D-wide reduction scratch)
+  const int scn = H * nkP > 4 * D ? H * nkP : 4 * D;  // sc doubles as reduction scratch: 3D (attend) / (F/256)*D (split-K gemv)
+  float* red = sc + scn;  // [2*DEC_WAVES]
   float* lg = red + 2 * DEC_WAVES;  // [V] (padded to a multiple of 4)
   T* xT = reinterpret_cast<T*>(lg + ((V + 3) & ~3));  // [max(D,F)] current GEMV input in the compute dtype (16-byte aligned)
   __shared__ int s_tok;
@@ -209,7 +266,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
       if (!(p.dbg & 4)) gemv<T>((const T*)w.w0, w.b0, xT, ff, F, D, ACT_RELU);
       __syncthreads();
       to_t<T>(ff, xT, F);
-      if (!(p.dbg & 4)) gemv<T>((const T*)w.w1, w.b1, xT, tmp, D, F, ACT_RELU);
+      if (!(p.dbg & 4)) gemv<T>((const T*)w.w1, w.b1, xT, tmp, D, F, ACT_RELU, (F >> 8) * D <= scn ? sc : nullptr);
       __syncthreads();
       add_layernorm(tmp, x, w.ln3w, w.ln3b, D, red);           // tmp = t3 (layer output)
       if (tid < D) x[tid] = tmp[tid];
@@ -261,7 +318,7 @@ int launch_decode_greedy(int dt, const DecodeP& p0, hipStream_t s) {
   p.dbg = dbg ? atoi(dbg) : 0;
   if (p.D % 32 || p.F % 32 || p.D > DEC_THREADS || p.nlayers > 4 || (p.D / p.H) % 4) return -1;
   const int nkP = ((p.steps > p.Nsrc ? p.steps : p.Nsrc) + 3) & ~3;
-  const int scn = p.H * nkP > 3 * p.D ? p.H * nkP : 3 * p.D;
+  const int scn = p.H * nkP > 4 * p.D ? p.H * nkP : 4 * p.D;
   size_t sh = (size_t)(6 * p.D + p.F + scn + 2 * DEC_WAVES + ((p.V + 3) & ~3) + (p.F > p.D ? p.F : p.D)) * sizeof(float);
   if (sh > 140 * 1024) return -1;
   if (dt == DT_BF16) {
