@@ -1158,6 +1158,10 @@ size_t model_workspace_bytes(Model* m, int B, int L) {
   size_t es = e.esz();
   size_t dec = (size_t)m->cfg.dec_layers * ((size_t)B * 512 * 2 * m->cfg.dec_hidden * es + (size_t)B * m->feat_h * m->feat_w * 2 * m->cfg.dec_hidden * es) +
                (size_t)64 * B * std::max(m->cfg.dec_filter, 3 * m->cfg.dec_hidden) * 4 + (1u << 20);
+  {  // k-panel-major weight copies of the persistent decoder
+    const size_t D = m->cfg.dec_hidden, F = m->cfg.dec_filter;
+    dec += ((size_t)m->cfg.dec_layers * (6 * D * D + 2 * D * F) + (size_t)m->cfg.num_classes * D) * es + (64u << 10);
+  }
   m->ws = save_ws;
   size_t need = m->persist_bytes + std::max(train_peak, train_peak / 2 + dec) + (16u << 20);
   return need;
@@ -1430,17 +1434,23 @@ static int greedy_body(Model* m, const float* img, const float* src_in, int B, i
   if (!getenv("SATRN_DECODE_STEPWISE") && L <= 4) {
     DecodeP dp;
     memset(&dp, 0, sizeof(dp));
+    // the kernel streams every weight once per step and image: k-panel-major copies (one coalesced load per MFMA operand)
+    auto kp = [&](const void* fwd, int N, int K) -> const void* {
+      void* d = e.alloc((size_t)N * K * es);
+      if (!e.dry && d) launch_repack_kpanel(e.dt, fwd, d, N, K, s);
+      return d;
+    };
     for (int l = 0; l < L; ++l) {
       DecLayer& dl = m->dec[l];
       DecLayerW& w = dp.L[l];
-      w.wqkv = dl.self_att.qkv.fwd; w.bqkv = dl.self_att.bqkv.p; w.wo = dl.self_att.out.fwd; w.bo = dl.self_att.bout.p;
-      w.wq2 = dl.cross_att.qkv.fwd; w.bq2 = dl.cross_att.bqkv.p; w.wo2 = dl.cross_att.out.fwd; w.bo2 = dl.cross_att.bout.p;
-      w.w0 = dl.lin0.fwd; w.b0 = dl.b0.p; w.w1 = dl.lin1.fwd; w.b1 = dl.b1.p;
-      w.wkv = (char*)dl.self_att.qkv.fwd + (size_t)Dd * Dd * es; w.bkv = dl.self_att.bqkv.p + Dd;
+      w.wqkv = kp(dl.self_att.qkv.fwd, 3 * Dd, Dd); w.bqkv = dl.self_att.bqkv.p; w.wo = kp(dl.self_att.out.fwd, Dd, Dd); w.bo = dl.self_att.bout.p;
+      w.wq2 = kp(dl.cross_att.qkv.fwd, Dd, Dd); w.bq2 = dl.cross_att.bqkv.p; w.wo2 = kp(dl.cross_att.out.fwd, Dd, Dd); w.bo2 = dl.cross_att.bout.p;
+      w.w0 = kp(dl.lin0.fwd, c.dec_filter, Dd); w.b0 = dl.b0.p; w.w1 = kp(dl.lin1.fwd, Dd, c.dec_filter); w.b1 = dl.b1.p;
+      w.bkv = dl.self_att.bqkv.p + Dd;
       w.ln1w = dl.ln1.w.p; w.ln1b = dl.ln1.b.p; w.ln2w = dl.ln2.w.p; w.ln2b = dl.ln2.b.p; w.ln3w = dl.ln3.w.p; w.ln3b = dl.ln3.b.p;
       w.crossKV = crossKV[l]->p; w.cache = cache[l]->p;
     }
-    dp.nlayers = L; dp.embed = m->embed.p; dp.pe = (const float*)(m->ws + m->off_pe1d); dp.wgen = m->gen.fwd; dp.bgen = m->gen_b.p;
+    dp.nlayers = L; dp.embed = m->embed.p; dp.pe = (const float*)(m->ws + m->off_pe1d); dp.wgen = kp(m->gen.fwd, V, Dd); dp.bgen = m->gen_b.p;
     dp.logits = logits_out; dp.ids = ids_out; dp.B = B; dp.steps = steps; dp.D = Dd; dp.F = c.dec_filter; dp.V = V;
     dp.H = c.dec_heads; dp.Nsrc = Nsrc; dp.sos = c.sos_id; dp.rules = rules;
     if (launch_decode_greedy(e.dt, dp, s) == 0) {

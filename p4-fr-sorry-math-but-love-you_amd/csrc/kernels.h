@@ -150,7 +150,7 @@ void launch_se_bwd(int dt, const void* dgate, const void* gate, const float* u1,
 
 // persistent greedy decoder (kernels_decode.hip): weights are the packed [N][K] compute copies, biases / LN fp32
 struct DecLayerW {
-  const void *wqkv, *wo, *wq2, *wo2, *w0, *w1, *wkv;
+  const void *wqkv, *wo, *wq2, *wo2, *w0, *w1;  // k-panel-major [K/32][N][32] (launch_repack_kpanel); k|v of the history = rows D..3D of wqkv
   const float *bqkv, *bo, *bq2, *bo2, *b0, *b1, *bkv, *ln1w, *ln1b, *ln2w, *ln2b, *ln3w, *ln3b;
   const void* crossKV;  // [B][Nsrc][2D]
   void* cache;          // [B][steps][2D] scratch
@@ -163,8 +163,10 @@ struct DecodeP {
   int B, steps, D, F, V, H, Nsrc, sos;
   int dbg;  // timing ablation bits (SATRN_DEC_DBG), 0 in production
   const int32_t* rules;  // optional compiled DecodingManager rules [V + 8]: outputs become masked probabilities
+  long long* prof;       // optional [16] cycle counters per phase family (SATRN_DEC_PROF, workgroup 0 only)
 };
-int launch_decode_greedy(int dt, const DecodeP& p, hipStream_t s);
+int launch_decode_greedy(int dt, const DecodeP& p, hipStream_t s);  // weights in DecLayerW / wgen: k-panel-major copies
+void launch_repack_kpanel(int dt, const void* src /*[N][K]*/, void* dst /*[K/32][N][32]*/, int N, int K, hipStream_t s);
 // DecodingManager.sift / reset as launches: x [B][ld] logits (or probabilities), state int32 [B][4], targets int64 [B], probs [B][ldp]
 void launch_sift(const float* x, int ld, int32_t* state, const int32_t* rules, int B, int V, int64_t* targets, float* probs,
                  int ldp, hipStream_t s);

@@ -25,83 +25,33 @@ template <> DEVI void ld4<bf16_t>(const bf16_t* p, float* o) {
   o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
 }
 
-// y[n] = act(bias[n] + sum_k W[n][k] * x[k]) for n in [0,N).  Matrix-vector product on the MFMA: a wave owns 16 outputs
-// at a time, the weight rows are the A operand fetched straight from global memory (16-byte loads, 64 contiguous bytes
-// per row and k-group), the activation vector is the B operand broadcast into all 16 columns from LDS, and the K
-// reduction happens inside the MFMA -- no cross-lane shuffles, and the unrolled k loop keeps 8+ loads in flight per
-// lane, which is what a latency-bound weight stream needs.  xT: the input vector in the compute dtype (LDS).
+// y[n] = act(bias[n] + sum_k W[row0 + n][k] * x[k]) for n in [0,N).  Matrix-vector product on the MFMA: a wave owns 16
+// outputs at a time, the weight rows are the A operand fetched straight from global memory, the activation vector is the B
+// operand broadcast into all 16 columns from LDS, and the K reduction happens inside the MFMA -- no cross-lane shuffles.
+// Weights are in K-PANEL-MAJOR order [K/32][Ntot][32] (launch_repack_kpanel): the 16 rows x 32 k a wave needs for one MFMA
+// are 16 x 64 B (bf16) of CONTIGUOUS memory, one fully coalesced load instruction; with the row-major [N][K] copy the same
+// instruction touched 16 different rows (half a cache line each) and the stream ran at 33 GB/s per CU instead of 58
+// (tools/elem_bench.cpp, gemv_layout_kernel).  xT: the input vector in the compute dtype (LDS).
 template <typename T>
-DEVI void gemv(const T* __restrict__ W, const float* __restrict__ bias, const T* xT, float* y, int N, int K, int act,
-               float* part = nullptr) {
+DEVI const T* kp_addr(const T* W, int Ntot, int row, int kk, int fq) { return W + ((long)(kk >> 5) * Ntot + row) * 32 + fq * 8; }
+
+template <typename T>
+DEVI void gemv(const T* __restrict__ W, int Ntot, int row0, const float* __restrict__ bias, const T* xT, float* y, int N, int K,
+               int act) {
   constexpr int CH = TT<T>::CH;
   constexpr int GU = 2;  // 16-output groups per wave iteration: 2 x 8 weight loads in flight per lane
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int ng = (N + 15) >> 4;
-  // deep, narrow products (FFN second linear: N = D, K = 4D) leave most waves idle and make the busy ones walk K in
-  // several dependent batches of loads: split K into 256-wide slices spread over the waves (one batch each), partial
-  // sums through LDS (part: [K/256][N] floats), then one pass adds them up
-  if (part && K > 256 && (K & 255) == 0 && ng * (K >> 8) <= 4 * DEC_WAVES * GU) {
-    const int ks = K >> 8, items = ng * ks;
-    for (int it0 = wave * GU; it0 < items; it0 += DEC_WAVES * GU) {
-      const T* wr[GU];
-      const T* xr[GU];
-      f32x4 acc[GU];
-#pragma unroll
-      for (int u = 0; u < GU; ++u) {
-        const int it = it0 + u < items ? it0 + u : items - 1;
-        const int g = it / ks, sl = it - g * ks;
-        int row = g * 16 + fr;
-        if (row >= N) row = N - 1;
-        wr[u] = W + (long)row * K + sl * 256 + fq * 8;
-        xr[u] = xT + sl * 256 + fq * 8;
-        acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int kk = 0; kk < 256; kk += 32) {
-        Frag<T> a[GU], b[GU];
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-          reinterpret_cast<uint4*>(&a[u])[0] = ld16(wr[u] + kk);
-          if (CH == 4) reinterpret_cast<uint4*>(&a[u])[1] = ld16(wr[u] + kk + 4);
-          reinterpret_cast<uint4*>(&b[u])[0] = ld16(xr[u] + kk);
-          if (CH == 4) reinterpret_cast<uint4*>(&b[u])[1] = ld16(xr[u] + kk + 4);
-        }
-#pragma unroll
-        for (int u = 0; u < GU; ++u) mma(a[u], b[u], acc[u]);
-      }
-      if (fr == 0) {
-#pragma unroll
-        for (int u = 0; u < GU; ++u) {
-          const int it = it0 + u;
-          if (it < items) {
-            const int g = it / ks, sl = it - g * ks;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int n = g * 16 + fq * 4 + r;
-              if (n < N) part[sl * N + n] = acc[u][r];
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    for (int n = threadIdx.x; n < N; n += DEC_THREADS) {
-      float v = bias ? bias[n] : 0.f;
-      for (int sl = 0; sl < ks; ++sl) v += part[sl * N + n];
-      y[n] = act == ACT_RELU ? fmaxf(v, 0.f) : v;
-    }
-    return;
-  }
   const T* xr = xT + fq * 8;
   for (int g0 = wave * GU; g0 < ng; g0 += DEC_WAVES * GU) {
-    const T* wr[GU];
+    int rowu[GU];
     f32x4 acc[GU];
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
       int row = (g0 + u) * 16 + fr;
       if (row >= N) row = N - 1;
-      wr[u] = W + (long)row * K + fq * 8;
+      rowu[u] = row0 + row;
       acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll 8
@@ -109,8 +59,9 @@ DEVI void gemv(const T* __restrict__ W, const float* __restrict__ bias, const T*
       Frag<T> a[GU], b;
 #pragma unroll
       for (int u = 0; u < GU; ++u) {
-        reinterpret_cast<uint4*>(&a[u])[0] = ld16(wr[u] + kk);
-        if (CH == 4) reinterpret_cast<uint4*>(&a[u])[1] = ld16(wr[u] + kk + 4);
+        const T* wp = kp_addr<T>(W, Ntot, rowu[u], kk, fq);
+        reinterpret_cast<uint4*>(&a[u])[0] = ld16(wp);
+        if (CH == 4) reinterpret_cast<uint4*>(&a[u])[1] = ld16(wp + 4);
       }
       reinterpret_cast<uint4*>(&b)[0] = ld16(xr + kk);
       if (CH == 4) reinterpret_cast<uint4*>(&b)[1] = ld16(xr + kk + 4);
@@ -226,7 +177,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
   float* tmp = att + D;          // [D]
   float* ff = tmp + D;           // [F]
   float* sc = ff + F;            // [H][nkP]
-  const int scn = H * nkP > 4 * D ? H * nkP : 4 * D;  // sc doubles as reduction scratch: 3D (attend) / (F/256)*D (split-K gemv)
+  const int scn = H * nkP > 4 * D ? H * nkP : 4 * D;  // sc doubles as a 3D-wide reduction scratch in attend
   float* red = sc + scn;  // [2*DEC_WAVES]
   float* lg = red + 2 * DEC_WAVES;  // [V] (padded to a multiple of 4)
   T* xT = reinterpret_cast<T*>(lg + ((V + 3) & ~3));  // [max(D,F)] current GEMV input in the compute dtype (16-byte aligned)
@@ -236,6 +187,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
   const float inv_temp = rsqrtf((float)D);
   const float emb_scale = sqrtf((float)D);
   int tok = p.sos;
+  long long tlast = p.prof ? (long long)wall_clock64() : 0;
+#define TICK(k) do { if (p.prof && b == 0 && tid == 0) { long long now_ = (long long)wall_clock64(); p.prof[k] += now_ - tlast; tlast = now_; } } while (0)
   for (int t = 0; t < p.steps; ++t) {
     // ---- embedding * sqrt(D) + PE(t)   (networks/EfficientSATRN.py:480-483, :425)
     if (tid < D) x[tid] = p.embed[(long)tok * D + tid] * emb_scale + p.pe[(long)t * D + tid];
@@ -245,43 +198,65 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
       T* cache = (T*)w.cache + (long)b * p.steps * 2 * D;  // this row's [steps][2D]
       // q | k | v of the layer INPUT
       to_t<T>(x, xT, D);
-      if (!(p.dbg & 8)) gemv<T>((const T*)w.wqkv, w.bqkv, xT, qkv, 3 * D, D, ACT_NONE);
+      TICK(0);
+      if (!(p.dbg & 8)) gemv<T>((const T*)w.wqkv, 3 * D, 0, w.bqkv, xT, qkv, 3 * D, D, ACT_NONE);
       __syncthreads();
+      TICK(1);
       for (int i = tid; i < 2 * D; i += DEC_THREADS) cache[(long)t * 2 * D + i] = from_f<T>(qkv[D + i]);
       __syncthreads();
+      TICK(0);
       attend<T>(qkv, cache, 2 * D, D, (p.dbg & 1) ? 1 : t + 1, H, hd, inv_temp, sc, nkP, att);
+      TICK(2);
       to_t<T>(att, xT, D);
-      gemv<T>((const T*)w.wo, w.bo, xT, tmp, D, D, ACT_NONE);
+      TICK(0);
+      gemv<T>((const T*)w.wo, D, 0, w.bo, xT, tmp, D, D, ACT_NONE);
       __syncthreads();
+      TICK(3);
       add_layernorm(tmp, x, w.ln1w, w.ln1b, D, red);          // tmp = t1
+      TICK(4);
       to_t<T>(tmp, xT, D);
-      gemv<T>((const T*)w.wq2, w.bq2, xT, qkv, D, D, ACT_NONE);
+      TICK(0);
+      gemv<T>((const T*)w.wq2, D, 0, w.bq2, xT, qkv, D, D, ACT_NONE);
       __syncthreads();
+      TICK(3);
       attend<T>(qkv, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D, 2 * D, D, (p.dbg & 2) ? 1 : p.Nsrc, H, hd, inv_temp, sc, nkP, att);
+      TICK(5);
       to_t<T>(att, xT, D);
-      gemv<T>((const T*)w.wo2, w.bo2, xT, x, D, D, ACT_NONE);
+      TICK(0);
+      gemv<T>((const T*)w.wo2, D, 0, w.bo2, xT, x, D, D, ACT_NONE);
       __syncthreads();
+      TICK(3);
       add_layernorm(x, tmp, w.ln2w, w.ln2b, D, red);           // x = t2
+      TICK(4);
       to_t<T>(x, xT, D);
-      if (!(p.dbg & 4)) gemv<T>((const T*)w.w0, w.b0, xT, ff, F, D, ACT_RELU);
+      TICK(0);
+      if (!(p.dbg & 4)) gemv<T>((const T*)w.w0, F, 0, w.b0, xT, ff, F, D, ACT_RELU);
       __syncthreads();
+      TICK(6);
       to_t<T>(ff, xT, F);
-      if (!(p.dbg & 4)) gemv<T>((const T*)w.w1, w.b1, xT, tmp, D, F, ACT_RELU, (F >> 8) * D <= scn ? sc : nullptr);
+      TICK(0);
+      if (!(p.dbg & 4)) gemv<T>((const T*)w.w1, D, 0, w.b1, xT, tmp, D, F, ACT_RELU);
       __syncthreads();
+      TICK(7);
       add_layernorm(tmp, x, w.ln3w, w.ln3b, D, red);           // tmp = t3 (layer output)
+      TICK(4);
       if (tid < D) x[tid] = tmp[tid];
       __syncthreads();
       // history entry for later steps: k/v of the layer OUTPUT
       to_t<T>(x, xT, D);
-      if (!(p.dbg & 16)) gemv<T>((const T*)w.wkv, w.bkv, xT, qkv, 2 * D, D, ACT_NONE);
+      TICK(0);
+      if (!(p.dbg & 16)) gemv<T>((const T*)w.wqkv, 3 * D, D, w.bkv, xT, qkv, 2 * D, D, ACT_NONE);  // rows D..3D of the fused q|k|v weight
       __syncthreads();
+      TICK(8);
       for (int i = tid; i < 2 * D; i += DEC_THREADS) cache[(long)t * 2 * D + i] = from_f<T>(qkv[i]);
       __syncthreads();
     }
     // ---- generator + argmax (lowest index wins ties, like torch.argmax)
     to_t<T>(x, xT, D);
-    gemv<T>((const T*)p.wgen, p.bgen, xT, lg, V, D, ACT_NONE);
+    TICK(0);
+    gemv<T>((const T*)p.wgen, V, 0, p.bgen, xT, lg, V, D, ACT_NONE);
     __syncthreads();
+    TICK(9);
     float* out = p.logits + ((long)b * p.steps + t) * V;
     if (p.rules) {
       // DecodingManager.sift (postprocessing.py:189-246): the step's output becomes the masked softmax, the next token
@@ -309,7 +284,26 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
     tok = s_tok;
     if (p.rules) sift_record(sst, tok, p.rules, V);
     __syncthreads();
+    TICK(10);
   }
+}
+
+// [N][K] row-major -> [K/32][N][32] k-panel-major (K % 32 == 0), 16-byte chunks
+template <typename T>
+__global__ void repack_kpanel_kernel(const T* src, T* dst, int N, int K) {
+  constexpr int CH = TT<T>::CH, CPP = 32 / CH;  // chunks per 32-wide panel row
+  const long nchunks = (long)N * (K / CH);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / (K / CH)), kc = (int)(i - (long)n * (K / CH));
+    st16(dst + ((long)(kc / CPP) * N + n) * 32 + (kc % CPP) * CH, ld16(src + (long)n * K + kc * CH));
+  }
+}
+void launch_repack_kpanel(int dt, const void* src, void* dst, int N, int K, hipStream_t s) {
+  const long n = (long)N * K / (dt == DT_BF16 ? 8 : 4);
+  int g = (int)((n + 255) / 256);
+  if (g > 2048) g = 2048;
+  if (dt == DT_BF16) hipLaunchKernelGGL((repack_kpanel_kernel<bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, N, K);
+  else hipLaunchKernelGGL((repack_kpanel_kernel<float>), dim3(g), dim3(256), 0, s, (const float*)src, (float*)dst, N, K);
 }
 
 int launch_decode_greedy(int dt, const DecodeP& p0, hipStream_t s) {
@@ -317,6 +311,13 @@ int launch_decode_greedy(int dt, const DecodeP& p0, hipStream_t s) {
   static const char* dbg = getenv("SATRN_DEC_DBG");  // timing-only ablations (outputs wrong)
   p.dbg = dbg ? atoi(dbg) : 0;
   if (p.D % 32 || p.F % 32 || p.D > DEC_THREADS || p.nlayers > 4 || (p.D / p.H) % 4) return -1;
+  static const bool want_prof = getenv("SATRN_DEC_PROF") != nullptr;  // debugging aid: per-phase clocks of workgroup 0
+  static long long* prof_buf = nullptr;
+  if (want_prof) {
+    if (!prof_buf) (void)hipMalloc((void**)&prof_buf, 16 * sizeof(long long));
+    (void)hipMemsetAsync(prof_buf, 0, 16 * sizeof(long long), s);
+    p.prof = prof_buf;
+  } else p.prof = nullptr;
   const int nkP = ((p.steps > p.Nsrc ? p.steps : p.Nsrc) + 3) & ~3;
   const int scn = p.H * nkP > 4 * p.D ? p.H * nkP : 4 * p.D;
   size_t sh = (size_t)(6 * p.D + p.F + scn + 2 * DEC_WAVES + ((p.V + 3) & ~3) + (p.F > p.D ? p.F : p.D)) * sizeof(float);
@@ -329,6 +330,16 @@ int launch_decode_greedy(int dt, const DecodeP& p0, hipStream_t s) {
     static bool a = false;
     if (!a) { (void)hipFuncSetAttribute((const void*)decode_greedy_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); a = true; }
     hipLaunchKernelGGL((decode_greedy_kernel<float>), dim3(p.B), dim3(DEC_THREADS), sh, s, p);
+  }
+  if (want_prof) {
+    long long h[16];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, prof_buf, sizeof(h), hipMemcpyDeviceToHost);
+    const char* nm[11] = {"other/convert", "qkv gemv", "self attend", "DxD gemv (wo,q2,wo2)", "layernorm", "cross attend", "ffn w0",
+                          "ffn w1", "wkv gemv", "generator", "argmax/step end"};
+    double tot = 0;
+    for (int i = 0; i < 11; ++i) tot += (double)h[i];
+    for (int i = 0; i < 11; ++i) fprintf(stderr, "[dec prof] %-22s %8.2f ms (%.1f%%)\n", nm[i], h[i] / 1e5, 100.0 * h[i] / tot);
   }
   return 0;
 }

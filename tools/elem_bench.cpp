@@ -27,9 +27,136 @@ __global__ __launch_bounds__(1024) void empty_kernel(float* o) {
   if (threadIdx.x == 0 && o == nullptr) sm[0] = 1.f;
 }
 
+// one workgroup streams `bytes` from global memory `reps` times (16-byte loads, UNR in flight per lane): what a single
+// CU can pull from L2 / Infinity Cache -- the limit of the persistent decoder's weight streaming
+template <int UNR>
+__global__ __launch_bounds__(1024) void stream_kernel(const uint4* p, size_t n16, int reps, float* out) {
+  float acc = 0.f;
+  for (int r = 0; r < reps; ++r) {
+    for (size_t i = threadIdx.x; i + (UNR - 1) * 1024 < n16; i += (size_t)UNR * 1024) {
+      uint4 v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[u] = p[i + (size_t)u * 1024];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc += __uint_as_float(v[u].x ^ v[u].y ^ v[u].z ^ v[u].w);
+    }
+    __syncthreads();
+  }
+  if (acc == 12345.f) out[0] = acc;
+}
+
+// MFMA matrix-vector product as in the persistent decoder, two weight layouts: LAYOUT 0 = [N][K] row-major (a wave load
+// touches 16 rows x 64 B), LAYOUT 1 = [K/32][N][32] k-panel-major (a wave load is 1 KB contiguous)
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
+template <int LAYOUT, int GU = 2, int UNR = 8>
+__global__ __launch_bounds__(1024) void gemv_layout_kernel(const uint4* W, const uint4* x, float* y, int N, int K, int reps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+  const int ng = N / 16;
+  for (int r = 0; r < reps; ++r) {
+    for (int g0 = wave * GU; g0 < ng; g0 += 16 * GU) {
+      f32x4_t acc[GU];
+#pragma unroll
+      for (int u = 0; u < GU; ++u) acc[u] = f32x4_t{0, 0, 0, 0};
+#pragma unroll UNR
+      for (int kk = 0; kk < K; kk += 32) {
+        uint4 a[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+          int row = (g0 + u) * 16 + fr;
+          if (row >= N) row = N - 1;
+          const size_t off = LAYOUT == 0 ? ((size_t)row * K + kk + fq * 8) / 8 : (((size_t)(kk / 32) * N + row) * 32 + fq * 8) / 8;
+          a[u] = W[off];
+        }
+        const uint4 b = x[(kk + fq * 8) / 8];
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[u]), __builtin_bit_cast(bf16x8_t, b), acc[u], 0, 0, 0);
+      }
+      if (fr == 0)
+        for (int u = 0; u < GU; ++u)
+          for (int q = 0; q < 4; ++q) if ((g0 + u) * 16 + fq * 4 + q < N) y[(g0 + u) * 16 + fq * 4 + q] = acc[u][q];
+    }
+    __syncthreads();
+  }
+}
+
+// k-panel-major weights + group-level software pipeline: a wave walks its 16-row groups one after the other and requests
+// the next group's K/32 panels before it multiplies the current one (K == 256: 8 + 8 loads in flight, no drain between groups)
+template <int KS>
+__global__ __launch_bounds__(1024) void gemv_pipe_kernel(const uint4* W, const uint4* x, float* y, int N, int reps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+  const int ng = N / 16;
+  uint4 xb[KS];
+  for (int r = 0; r < reps; ++r) {
+#pragma unroll
+    for (int k = 0; k < KS; ++k) xb[k] = x[(k * 32 + fq * 8) / 8];
+    uint4 cur[KS], nxt[KS];
+    int g = wave;
+    if (g < ng) {
+#pragma unroll
+      for (int k = 0; k < KS; ++k) cur[k] = W[(((size_t)k * N + g * 16 + fr) * 32 + fq * 8) / 8];
+    }
+    for (; g < ng; g += 16) {
+      const int gn = g + 16;
+      if (gn < ng) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) nxt[k] = W[(((size_t)k * N + gn * 16 + fr) * 32 + fq * 8) / 8];
+      }
+      f32x4_t acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < KS; ++k)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, cur[k]), __builtin_bit_cast(bf16x8_t, xb[k]), acc, 0, 0, 0);
+      if (fr == 0)
+        for (int q = 0; q < 4; ++q) y[g * 16 + fq * 4 + q] = acc[q];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) cur[k] = nxt[k];
+    }
+    __syncthreads();
+  }
+}
+
 int main(int argc, char** argv) {
   hipStream_t s;
   hipStreamCreate(&s);
+  {
+    uint4 *W, *x; float* y;
+    hipMalloc(&W, 8 << 20); hipMalloc(&x, 1 << 16); hipMalloc(&y, 1 << 16);
+    hipMemset(W, 0, 8 << 20); hipMemset(x, 0, 1 << 16);
+    struct { int N, K; } sh[] = {{768, 256}, {1024, 256}, {256, 1024}, {256, 256}};
+    for (auto q : sh)
+      for (int nb : {1, 64}) {
+        const int reps = 50;
+        float u0 = time_us([&](hipStream_t st) { hipLaunchKernelGGL(gemv_layout_kernel<0>, dim3(nb), dim3(1024), 0, st, W, x, y, q.N, q.K, reps); }, s, 10);
+        float u1 = time_us([&](hipStream_t st) { hipLaunchKernelGGL(gemv_layout_kernel<1>, dim3(nb), dim3(1024), 0, st, W, x, y, q.N, q.K, reps); }, s, 10);
+        {
+          float a1 = time_us([&](hipStream_t st) { hipLaunchKernelGGL((gemv_layout_kernel<1, 1, 8>), dim3(nb), dim3(1024), 0, st, W, x, y, q.N, q.K, reps); }, s, 10);
+          float a2 = time_us([&](hipStream_t st) { hipLaunchKernelGGL((gemv_layout_kernel<1, 4, 8>), dim3(nb), dim3(1024), 0, st, W, x, y, q.N, q.K, reps); }, s, 10);
+          float a3 = time_us([&](hipStream_t st) { hipLaunchKernelGGL((gemv_layout_kernel<1, 2, 4>), dim3(nb), dim3(1024), 0, st, W, x, y, q.N, q.K, reps); }, s, 10);
+          float a4 = time_us([&](hipStream_t st) { hipLaunchKernelGGL((gemv_layout_kernel<1, 3, 8>), dim3(nb), dim3(1024), 0, st, W, x, y, q.N, q.K, reps); }, s, 10);
+          printf("gemv N=%4d K=%4d blocks=%2d: k-panel GU1/U8 %6.2f  GU4/U8 %6.2f  GU2/U4 %6.2f  GU3/U8 %6.2f us/rep\n", q.N, q.K, nb, a1 / reps, a2 / reps, a3 / reps, a4 / reps);
+        }
+        if (q.K == 256 && false) {
+          float u2 = time_us([&](hipStream_t st) { hipLaunchKernelGGL(gemv_pipe_kernel<8>, dim3(nb), dim3(1024), 0, st, W, x, y, q.N, reps); }, s, 10);
+          printf("gemv N=%4d K=%4d blocks=%2d: pipelined k-panel-major %6.2f us/rep (%5.1f GB/s)\n", q.N, q.K, nb, u2 / reps, q.N * q.K * 2.0 / (u2 / reps) / 1e3);
+        }
+        printf("gemv N=%4d K=%4d blocks=%2d: row-major %6.2f us/rep (%5.1f GB/s)   k-panel-major %6.2f us/rep (%5.1f GB/s)\n", q.N, q.K, nb,
+               u0 / reps, q.N * q.K * 2.0 / (u0 / reps) / 1e3, u1 / reps, q.N * q.K * 2.0 / (u1 / reps) / 1e3);
+      }
+  }
+  {
+    uint4* buf; float* o;
+    hipMalloc(&buf, 8 << 20); hipMalloc(&o, 64); hipMemset(buf, 0, 8 << 20);
+    for (size_t kb : {128, 512, 2048, 6144})
+      for (int nb : {1, 8, 64}) {
+        const int reps = 20;
+        float us4 = time_us([&](hipStream_t st) { hipLaunchKernelGGL(stream_kernel<4>, dim3(nb), dim3(1024), 0, st, buf, kb * 64, reps, o); }, s, 20);
+        float us16 = time_us([&](hipStream_t st) { hipLaunchKernelGGL(stream_kernel<16>, dim3(nb), dim3(1024), 0, st, buf, kb * 64, reps, o); }, s, 20);
+        printf("stream %5zu KB x%d reps, %2d blocks: UNR4 %7.1f us (%.1f GB/s/CU)  UNR16 %7.1f us (%.1f GB/s/CU)\n", kb, reps, nb, us4,
+               kb * 1024.0 * reps / us4 / 1e3, us16, kb * 1024.0 * reps / us16 / 1e3);
+      }
+    hipFree(buf); hipFree(o);
+  }
   const int dt = 1;  // bf16
   struct Shape { int B, H, W, C; };
   std::vector<Shape> shapes = {{32, 8, 24, 512}, {32, 8, 24, 960}, {32, 4, 12, 1536}, {32, 16, 48, 256}, {32, 32, 96, 192}};
