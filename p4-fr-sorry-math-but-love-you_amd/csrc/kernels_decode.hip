@@ -112,21 +112,29 @@ DEVI void add_layernorm(float* v, const float* r, const float* w, const float* b
   __syncthreads();
 }
 
-// o[0..D) = softmax(q K^T / temp) V over `nk` keys; K at kv[j*ld + h*hd], V at kv[j*ld + voff + h*hd]
+// o[0..D) = softmax(q K^T / temp) V over `nk` keys; K at kv[j*ld + h*hd], V at kv[j*ld + voff + h*hd].
+// Every global access is a 16-byte load and a thread's loads are independent, so each of the two passes over the history
+// costs about one memory round trip: scores -- one thread per (key, head), hd/CH chunk loads in flight; PV -- one thread
+// per (key group, 16-byte chunk of the D output dims), partial sums combined by shuffles inside the wave and through
+// wred [DEC_WAVES][D] across waves.  Needs D/CH to be a power of two <= 64.
 template <typename T>
 DEVI void attend(const float* q, const T* kv, long ld, int voff, int nk, int H, int hd, float inv_temp, float* sc /*[H][nkP]*/,
-                 int nkP, float* o) {
+                 int nkP, float* o, float* wred) {
+  constexpr int CH = TT<T>::CH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = H * hd;
+  const int cph = hd / CH;  // chunks per head
   for (int idx = tid; idx < nk * H; idx += DEC_THREADS) {
     const int j = idx / H, h = idx - j * H;
     const T* kp = kv + (long)j * ld + h * hd;
     const float* qp = q + h * hd;
     float acc = 0.f;
-    for (int d = 0; d < hd; d += 4) {
-      float f[4];
-      ld4<T>(kp + d, f);
-      acc += f[0] * qp[d] + f[1] * qp[d + 1] + f[2] * qp[d + 2] + f[3] * qp[d + 3];
+#pragma unroll 4
+    for (int c = 0; c < cph; ++c) {
+      float f[CH];
+      unpack<T>(ld16(kp + c * CH), f);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) acc += f[e] * qp[c * CH + e];
     }
     sc[h * nkP + j] = acc * inv_temp;
   }
@@ -142,26 +150,36 @@ DEVI void attend(const float* q, const T* kv, long ld, int voff, int nk, int H, 
     for (int j = lane; j < nk; j += 64) sc[h * nkP + j] *= inv;
   }
   __syncthreads();
-  // two half-ranges of keys per output element when there are spare threads
-  const int parts = DEC_THREADS / D >= 4 ? 4 : (DEC_THREADS / D > 1 ? 2 : 1);
-  const int d = tid % D, part = tid / D;
-  float acc = 0.f;
-  if (part < parts) {
-    const int h = d / hd;
-    const T* vp = kv + voff + d;
-#pragma unroll 8
-    for (int j = part; j < nk; j += parts) acc += sc[h * nkP + j] * to_f(vp[(long)j * ld]);
+  const int cpr = D / CH;             // 16-byte chunks per V row (power of two <= 64)
+  const int KG = DEC_THREADS / cpr;   // key groups
+  const int dc = tid % cpr, kg = tid / cpr;
+  const int h = (dc * CH) / hd;
+  float acc[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+  const T* vp = kv + voff + dc * CH;
+#pragma unroll 4
+  for (int j = kg; j < nk; j += KG) {
+    float f[CH];
+    unpack<T>(ld16(vp + (long)j * ld), f);
+    const float pj = sc[h * nkP + j];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc[e] += pj * f[e];
   }
-  __syncthreads();  // sc reuse as reduction scratch below
-  if (parts > 1) {
-    if (part > 0 && part < parts) sc[(part - 1) * D + d] = acc;
-    __syncthreads();
-    if (part == 0) {
-      for (int q2 = 1; q2 < parts; ++q2) acc += sc[(q2 - 1) * D + d];
-      o[d] = acc;
-    }
-  } else if (part == 0) {
-    o[d] = acc;
+  for (int o2 = cpr; o2 < 64; o2 <<= 1) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc[e] += __shfl_xor(acc[e], o2, 64);
+  }
+  if (lane < cpr) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) wred[wave * D + dc * CH + e] = acc[e];
+  }
+  __syncthreads();
+  if (tid < D) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < DEC_WAVES; ++w) v += wred[w * D + tid];
+    o[tid] = v;
   }
   __syncthreads();
 }
@@ -180,7 +198,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
   const int scn = H * nkP > 4 * D ? H * nkP : 4 * D;  // sc doubles as a 3D-wide reduction scratch in attend
   float* red = sc + scn;  // [2*DEC_WAVES]
   float* lg = red + 2 * DEC_WAVES;  // [V] (padded to a multiple of 4)
-  T* xT = reinterpret_cast<T*>(lg + ((V + 3) & ~3));  // [max(D,F)] current GEMV input in the compute dtype (16-byte aligned)
+  float* wred = lg + ((V + 3) & ~3);  // [DEC_WAVES][D] per-wave partial attention outputs
+  T* xT = reinterpret_cast<T*>(wred + DEC_WAVES * D);  // [max(D,F)] current GEMV input in the compute dtype (16-byte aligned)
   __shared__ int s_tok;
   const int b = blockIdx.x, tid = threadIdx.x;
   SiftState sst{p.sos, 1, 0, 0};  // DecodingManager memory of this sequence (uniform across the workgroup)
@@ -205,7 +224,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
       for (int i = tid; i < 2 * D; i += DEC_THREADS) cache[(long)t * 2 * D + i] = from_f<T>(qkv[D + i]);
       __syncthreads();
       TICK(0);
-      attend<T>(qkv, cache, 2 * D, D, (p.dbg & 1) ? 1 : t + 1, H, hd, inv_temp, sc, nkP, att);
+      attend<T>(qkv, cache, 2 * D, D, (p.dbg & 1) ? 1 : t + 1, H, hd, inv_temp, sc, nkP, att, wred);
       TICK(2);
       to_t<T>(att, xT, D);
       TICK(0);
@@ -219,7 +238,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
       gemv<T>((const T*)w.wq2, D, 0, w.bq2, xT, qkv, D, D, ACT_NONE);
       __syncthreads();
       TICK(3);
-      attend<T>(qkv, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D, 2 * D, D, (p.dbg & 2) ? 1 : p.Nsrc, H, hd, inv_temp, sc, nkP, att);
+      attend<T>(qkv, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D, 2 * D, D, (p.dbg & 2) ? 1 : p.Nsrc, H, hd, inv_temp, sc, nkP, att, wred);
       TICK(5);
       to_t<T>(att, xT, D);
       TICK(0);
@@ -311,6 +330,10 @@ int launch_decode_greedy(int dt, const DecodeP& p0, hipStream_t s) {
   static const char* dbg = getenv("SATRN_DEC_DBG");  // timing-only ablations (outputs wrong)
   p.dbg = dbg ? atoi(dbg) : 0;
   if (p.D % 32 || p.F % 32 || p.D > DEC_THREADS || p.nlayers > 4 || (p.D / p.H) % 4) return -1;
+  {
+    const int ch = dt == DT_BF16 ? 8 : 4, cpr = p.D / ch;
+    if ((p.D / p.H) % ch || cpr > 64 || (cpr & (cpr - 1))) return -1;  // attend(): 16-byte chunks, shuffle reduction
+  }
   static const bool want_prof = getenv("SATRN_DEC_PROF") != nullptr;  // debugging aid: per-phase clocks of workgroup 0
   static long long* prof_buf = nullptr;
   if (want_prof) {
@@ -320,7 +343,7 @@ int launch_decode_greedy(int dt, const DecodeP& p0, hipStream_t s) {
   } else p.prof = nullptr;
   const int nkP = ((p.steps > p.Nsrc ? p.steps : p.Nsrc) + 3) & ~3;
   const int scn = p.H * nkP > 4 * p.D ? p.H * nkP : 4 * p.D;
-  size_t sh = (size_t)(6 * p.D + p.F + scn + 2 * DEC_WAVES + ((p.V + 3) & ~3) + (p.F > p.D ? p.F : p.D)) * sizeof(float);
+  size_t sh = (size_t)(6 * p.D + p.F + scn + 2 * DEC_WAVES + ((p.V + 3) & ~3) + DEC_WAVES * p.D + (p.F > p.D ? p.F : p.D)) * sizeof(float);
   if (sh > 140 * 1024) return -1;
   if (dt == DT_BF16) {
     static bool a = false;
