@@ -153,6 +153,13 @@ int satrn_embedding_bwd(int dtype, const int64_t* ids, int ld_ids, const void* d
 int satrn_cross_entropy(int dtype, const float* logits, const int64_t* targets, int ld, int B, int T, int V, int Vp,
                         int pad_id, float* loss_out, float* lse_ws, void* dlogits, void* stream);
 
+/* Per-step training metrics without host round trips (train_modules/train_single_opt.py:101-109 = id_to_string(do_eval=1)
+ * of utils/utils.py:134-164 + word_error_rate / sentence_acc of utils/metrics.py:9-34 + the symbol counts), on token ids:
+ * sequence int64 [B][ld_seq] (T predictions per sample), expected int64 [B][ld_exp] (L entries: <SOS> ... <EOS> <PAD>|-1...).
+ * acc double [5] (device) += {sum over samples of Levenshtein/max(len), samples, exactly-equal samples, correct symbols,
+ * non-pad symbols}; empty_id = id of the "" token (or -1).  Sequences up to 512 tokens. */
+int satrn_step_metrics(const int64_t* sequence, int ld_seq, int T, const int64_t* expected, int ld_exp, int L, int B, int pad_id,
+                       int sos_id, int eos_id, int empty_id, double* acc, void* stream);
 /* Knowledge-distillation loss of train_modules/train_distillation.py:49-55 (loss_fn_kd), forward and gradient in one
  * pass: student / teacher fp32 logits [B][T][V], labels int64 [B][ld] (NOT ignored when PAD, as in the reference).
  * loss = alpha*temperature^2 * KLDiv_batchmean(log_softmax(s/temperature), softmax(t/temperature)) + (1-alpha)*CE(s, labels);

@@ -659,3 +659,51 @@ def loss_fn_kd(outputs, labels, teacher_outputs, T=10, alpha=0.1):
     (1-alpha) * cross-entropy over ALL positions (no ignore_index: PAD labels count as an ordinary class)."""
     kd = F.kl_div(F.log_softmax(outputs / T, dim=1), F.softmax(teacher_outputs / T, dim=1), reduction="batchmean")
     return kd * (alpha * T * T) + F.cross_entropy(outputs, labels) * (1.0 - alpha)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Per-step training metrics (train_modules/train_single_opt.py:101-109, utils/utils.py:134-164, utils/metrics.py:9-34)
+# restated over token ids.  id_to_string(do_eval=1) drops <PAD>/<SOS>/-1, stops at <EOS> and joins "tok " pieces, so the
+# string ends in a space and .split(" ") yields the tokens plus one trailing ''; the "" token (last vocabulary entry)
+# is that same empty string.  editdistance (third-party, pinned editdistance==0.5.3, absent here) = Levenshtein distance
+# between the two token lists: UNPINNED against the package, pinned to the published algorithm; the string / sentence /
+# symbol parts are pinned to the reference's own functions (tests/golden/metrics.npz).
+# ---------------------------------------------------------------------------------------------------------------
+def metric_tokens(row, pad_id=PAD_ID, sos_id=SOS_ID, eos_id=1, empty_id=NUM_CLASSES - 1):
+    """ids the reference's string would split into (the '' token and the trailing '' both become -2)."""
+    out = []
+    for t in row:
+        t = int(t)
+        if t in (pad_id, sos_id, eos_id):
+            if t == eos_id:
+                break
+            continue
+        if t != -1:
+            out.append(-2 if t == empty_id else t)
+    out.append(-2)
+    return out
+
+
+def levenshtein(a, b):
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
+def step_metrics(sequence, expected, pad_id=PAD_ID):
+    """-> dict(sum_wer, sentences, correct_sentences, correct_symbols, total_symbols) for one batch: what one trip of the
+    reference's training loop adds to its running sums (wer and sent_acc there are per-batch means: divide by sentences)."""
+    B = sequence.shape[0]
+    sum_wer, ok = 0.0, 0
+    for b in range(B):
+        p, g = metric_tokens(sequence[b].tolist()), metric_tokens(expected[b].tolist())
+        sum_wer += levenshtein(p, g) / max(len(p), len(g))
+        ok += int(p == g)
+    exp = expected[:, 1:].clone()
+    exp[exp == pad_id] = -1
+    return dict(sum_wer=sum_wer, sentences=B, correct_sentences=ok, correct_symbols=int((sequence == exp).sum().item()),
+                total_symbols=int((exp != -1).sum().item()))

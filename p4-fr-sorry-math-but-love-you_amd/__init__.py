@@ -4,6 +4,8 @@ from . import _lib
 from ._lib import SatrnError
 from .networks import EfficientSATRN, LiteSATRN, EfficientSATRN_encoder, EfficientSATRN_decoder, SATRNCrossEntropy, loss_fn_kd
 from . import decoding
+from . import metrics
+from .metrics import StepMetrics
 from .decoding import DeviceDecodingManager, compile_rules
 from .utils import get_network, load_vocab, Flags, START, END, PAD, SPECIAL_TOKENS
 

@@ -113,6 +113,8 @@ void launch_dropout_bwd(int dt, const void* dz, void* du, long M, int N, float d
 void launch_ce_full(int dt_out, const float* logits, const int64_t* tgt, int ld_tgt, int tgt_off, int B, int T, int V,
                     int Vp, int pad_id, float* loss_out, float* lse_ws, void* dlogits, const float* upstream,
                     hipStream_t s);
+void launch_step_metrics(const int64_t* seq, int ld_seq, int T, const int64_t* expected, int ld_exp, int L, int B, int pad_id,
+                         int sos_id, int eos_id, int empty_id, double* acc /*[5] +=*/, hipStream_t s);
 void launch_kd_loss(const float* student, const float* teacher, const int64_t* labels, int ld_labels, int B, int T, int V,
                     float temperature, float alpha, float* loss_out /*[1]*/, float* dlogits /*[B*T][V]*/, hipStream_t s);
 void launch_act_fwd(int dt, const void* u, void* z, long n, int act, hipStream_t s);

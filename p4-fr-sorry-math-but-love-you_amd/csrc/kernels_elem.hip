@@ -1175,6 +1175,91 @@ void launch_kd_loss(const float* student, const float* teacher, const int64_t* l
                      dlogits);
 }
 
+// ---- per-step training metrics on the device (train_modules/train_single_opt.py:101-109; utils/utils.py:134-164
+// id_to_string(do_eval=1); utils/metrics.py:9-34): one wavefront per sample.  Token lists = ids with <PAD>/<SOS>/-1
+// dropped, cut at <EOS>, plus one trailing "empty" element (the '' that .split(" ") leaves; the "" vocabulary entry is
+// the same string).  WER term = Levenshtein(pred, truth) / max(len), sentence = lists equal, symbols = position-wise
+// matches against expected[:, 1:] with <PAD> never matching.  acc (double [5]) += {sum_wer, sentences, correct
+// sentences, correct symbols, total symbols}.
+#define MET_MAXLEN 512
+__global__ __launch_bounds__(64) void step_metrics_kernel(const int64_t* seq, int ld_seq, int T_, const int64_t* exp, int ld_exp,
+                                                          int L, int pad_id, int sos_id, int eos_id, int empty_id, double* acc) {
+  __shared__ int a[MET_MAXLEN + 1], g[MET_MAXLEN + 1];
+  __shared__ int d0[MET_MAXLEN + 2], d1[MET_MAXLEN + 2], d2[MET_MAXLEN + 2];
+  __shared__ int na_s, ng_s;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int64_t* sr = seq + (long)b * ld_seq;
+  const int64_t* er = exp + (long)b * ld_exp;
+  if (lane == 0) {
+    int n = 0;
+    for (int t = 0; t < T_ && n < MET_MAXLEN; ++t) {
+      const int v = (int)sr[t];
+      if (v == eos_id) break;
+      if (v == pad_id || v == sos_id || v == -1) continue;
+      a[n++] = v == empty_id ? -2 : v;
+    }
+    a[n++] = -2;
+    na_s = n;
+    n = 0;
+    for (int t = 0; t < L && n < MET_MAXLEN; ++t) {
+      const int v = (int)er[t];
+      if (v == eos_id) break;
+      if (v == pad_id || v == sos_id || v == -1) continue;
+      g[n++] = v == empty_id ? -2 : v;
+    }
+    g[n++] = -2;
+    ng_s = n;
+  }
+  // position-wise symbol statistics
+  int cs = 0, ts = 0;
+  for (int t = lane; t < T_ && t + 1 < L; t += 64) {
+    const int e = (int)er[t + 1];
+    const bool valid = e != pad_id && e != -1;
+    ts += valid;
+    cs += valid && (int)sr[t] == e;
+  }
+  cs = (int)wave_sum((float)cs);
+  ts = (int)wave_sum((float)ts);
+  __syncthreads();
+  const int na = na_s, ng = ng_s;
+  // Levenshtein over anti-diagonals: cell (i, j), i in 0..na, j = k - i in 0..ng; dX[i] holds diagonal X
+  int* pp = d0; int* p1 = d1; int* cur = d2;  // k-2, k-1, k
+  if (lane == 0) { pp[0] = 0; p1[0] = 1; p1[1] = 1; }  // k = 0: (0,0); k = 1: (0,1) = 1, (1,0) = 1
+  __syncthreads();
+  for (int k = 2; k <= na + ng; ++k) {
+    const int ilo = k - ng > 0 ? k - ng : 0, ihi = k < na ? k : na;
+    for (int i = ilo + lane; i <= ihi; i += 64) {
+      const int j = k - i;
+      int v;
+      if (i == 0) v = j;
+      else if (j == 0) v = i;
+      else {
+        const int sub = pp[i - 1] + (a[i - 1] != g[j - 1]);
+        const int del = p1[i - 1] + 1, ins = p1[i] + 1;
+        v = sub < del ? sub : del;
+        v = v < ins ? v : ins;
+      }
+      cur[i] = v;
+    }
+    __syncthreads();
+    int* t = pp; pp = p1; p1 = cur; cur = t;
+  }
+  if (lane == 0) {
+    const int dist = (na + ng >= 2) ? p1[na] : (na + ng == 1 ? 1 : 0);
+    bool same = na == ng;
+    for (int i = 0; same && i < na; ++i) same = a[i] == g[i];
+    atomicAdd(acc + 0, (double)dist / (double)(na > ng ? na : ng));
+    atomicAdd(acc + 1, 1.0);
+    atomicAdd(acc + 2, same ? 1.0 : 0.0);
+    atomicAdd(acc + 3, (double)cs);
+    atomicAdd(acc + 4, (double)ts);
+  }
+}
+void launch_step_metrics(const int64_t* seq, int ld_seq, int T_, const int64_t* exp, int ld_exp, int L, int B, int pad_id,
+                         int sos_id, int eos_id, int empty_id, double* acc, hipStream_t s) {
+  hipLaunchKernelGGL(step_metrics_kernel, dim3(B), dim3(64), 0, s, seq, ld_seq, T_, exp, ld_exp, L, pad_id, sos_id, eos_id, empty_id, acc);
+}
+
 // ---- misc -----------------------------------------------------------------------------------------------
 template <typename TI, typename TO>
 __global__ void cast_kernel(const TI* in, TO* out, long n) {

@@ -285,6 +285,12 @@ int satrn_cross_entropy(int dt, const float* logits, const int64_t* targets, int
   launch_ce_full(dt, logits, targets, ld, 0, B, T, V, Vp, pad_id, loss_out, lse_ws, dlogits, nullptr, S(st));
   return done("cross_entropy");
 }
+int satrn_step_metrics(const int64_t* sequence, int ld_seq, int T, const int64_t* expected, int ld_exp, int L, int B, int pad_id,
+                       int sos_id, int eos_id, int empty_id, double* acc, void* st) {
+  if (!sequence || !expected || !acc || B <= 0 || T <= 0 || L <= 0 || T > 512 || L > 512) return fail(-1, "satrn_step_metrics: bad argument (sequences up to 512 tokens)");
+  launch_step_metrics(sequence, ld_seq, T, expected, ld_exp, L, B, pad_id, sos_id, eos_id, empty_id, acc, S(st));
+  return done("step_metrics");
+}
 int satrn_kd_loss(const float* student, const float* teacher, const int64_t* labels, int ld, int B, int T, int V,
                   float temperature, float alpha, float* loss_out, float* dlogits, void* st) {
   if (!student || !teacher || !labels || !loss_out || !dlogits || B <= 0 || T <= 0 || V <= 0 || !(temperature > 0.f))
