@@ -464,8 +464,76 @@ __global__ void dwconv_kernel(const T* x, const T* wp, const float* bias, T* y, 
     st16(o, pack<T>(acc));
   }
 }
+// stride-1 SAME specialisation (28 of the 32 depthwise convolutions of the backbone, both encoder ones): one thread
+// produces TWO horizontally adjacent outputs of a channel chunk, so every loaded input chunk and every unpacked weight
+// chunk is used twice (12 loads instead of 18 per pair, half the index arithmetic) -- these kernels are VALU-issue bound.
+// FLIP = data gradient (correlation with the kernel rotated by 180 degrees; identical for stride 1, pad 1).
+template <typename T, bool FLIP>
+__global__ void dwconv_s1_kernel(const T* x, const T* wp, const float* bias, T* y, int B, int H, int W, int C, int beta) {
+  constexpr int CH = TT<T>::CH;
+  const int CC = C / CH, W2 = W >> 1;
+  const long total = (long)B * H * W2 * CC;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % CC);
+    long pix = i / CC;
+    const int ox = (int)(pix % W2) * 2;
+    const int oy = (int)((pix / W2) % H);
+    const int b = (int)(pix / ((long)W2 * H));
+    float a0[CH], a1[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) a0[j] = a1[j] = (bias && !FLIP) ? bias[cc * CH + j] : 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = oy + kh - 1;
+      if (iy < 0 || iy >= H) continue;
+      const T* row = x + (((long)b * H + iy) * W) * C + cc * CH;
+      float in[4][CH];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ix = ox - 1 + t;
+        if (ix >= 0 && ix < W) unpack<T>(ld16(row + (long)ix * C), in[t]);
+        else {
+#pragma unroll
+          for (int j = 0; j < CH; ++j) in[t][j] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        float wv[CH];
+        const int tap = FLIP ? 8 - (kh * 3 + kw) : kh * 3 + kw;
+        unpack<T>(ld16(wp + tap * C + cc * CH), wv);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { a0[j] += in[kw][j] * wv[j]; a1[j] += in[kw + 1][j] * wv[j]; }
+      }
+    }
+    T* o = y + (((long)b * H + oy) * W + ox) * C + cc * CH;
+    if (beta) {
+      float o0[CH], o1[CH];
+      unpack<T>(ld16(o), o0); unpack<T>(ld16(o + C), o1);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { a0[j] += o0[j]; a1[j] += o1[j]; }
+    }
+    st16(o, pack<T>(a0));
+    st16(o + C, pack<T>(a1));
+  }
+}
+
 void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float* bias, void* y, int B, int H, int W,
                    int C, int OH, int OW, int stride, int pt, int pl, int beta, float* stats, hipStream_t s) {
+  static const bool no_s1 = getenv("SATRN_DW_NO_S1") != nullptr;
+  if (!no_s1 && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && (W & 1) == 0) {
+    DISPATCH_T(dt, {
+      long n2 = (long)B * H * (W / 2) * (C / TT<T>::CH);
+      if (mode == 0)
+        hipLaunchKernelGGL((dwconv_s1_kernel<T, false>), dim3(grid_for(n2)), dim3(256), 0, s, (const T*)x, (const T*)wp, bias,
+                           (T*)y, B, H, W, C, beta);
+      else
+        hipLaunchKernelGGL((dwconv_s1_kernel<T, true>), dim3(grid_for(n2)), dim3(256), 0, s, (const T*)x, (const T*)wp, bias,
+                           (T*)y, B, H, W, C, beta);
+      if (stats && mode == 0) launch_colstats(dt, y, (long)B * OH * OW, C, stats, s);
+    });
+    return;
+  }
   DISPATCH_T(dt, {
     long n = (long)B * OH * OW * (C / TT<T>::CH);
     if (mode == 0)

@@ -289,7 +289,7 @@ def test_train_autoregressive_branch_with_gradients(dtype):
         assert float(np.median([e_ for e_, _ in errs])) < 1e-3 and worst[0][0] < 3e-2
 
 
-@pytest.mark.parametrize("name", ["lite_c1_pad", "eff_small"])
+@pytest.mark.parametrize("name", ["lite_c1_pad", "eff_c2_b2"])
 def test_segmented_backward_equals_whole_backward(golden_dir, name):
     """train_step(phase=16+k), k = 0..3 (the overlapped data-parallel exchange's backward segments) leaves the same flat
     gradient as phase=1, and the four segment ranges tile the flat buffer in backward order."""
@@ -303,11 +303,12 @@ def test_segmented_backward_equals_whole_backward(golden_dir, name):
     torch.cuda.synchronize()
     whole = model.flat_grad().detach().clone()
     loss1 = model.read_loss()[0]
-    # run-to-run noise of the same computation (float atomics arrive in a different order; tiny BatchNorm batches amplify it)
-    model.train_step(imgd, expd, 0.0, phase=1)
-    torch.cuda.synchronize()
+    # the same computation differs from run to run: float atomics arrive in a different order, and a last-bit change of a
+    # BatchNorm statistic now and then flips a ReLU / max-pool decision (observed jumps of 3e-4 * max|g|).  The bound only
+    # has to separate this noise from a wrong segmentation, which would lose or double whole gradient blocks (errors of
+    # the order of max |g|)
     gmax = whole.abs().max().item()
-    tol = 10.0 * (model.flat_grad() - whole).abs().max().item() + 1e-4 * gmax
+    tol = 2e-2 * gmax
     n = whole.numel()
     ranges = [model.segment_range(k) for k in range(4)]
     assert ranges[0][1] == n and ranges[3][0] == 0 and all(ranges[k][0] == ranges[k + 1][1] for k in range(3))
