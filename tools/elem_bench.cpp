@@ -3,6 +3,7 @@
 // run (GPU box): LD_LIBRARY_PATH=p4-fr-sorry-math-but-love-you_amd tools/elem_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <functional>
 #include <vector>
@@ -156,6 +157,24 @@ int main(int argc, char** argv) {
                kb * 1024.0 * reps / us4 / 1e3, us16, kb * 1024.0 * reps / us16 / 1e3);
       }
     hipFree(buf); hipFree(o);
+  }
+  {  // GEMM with / without the BatchNorm-statistics epilogue (column sums through float atomics)
+    void *A, *Bw, *Cc; float* st;
+    hipMalloc(&A, 64 << 20); hipMalloc(&Bw, 16 << 20); hipMalloc(&Cc, 64 << 20); hipMalloc(&st, 1 << 20);
+    hipMemset(A, 0, 64 << 20); hipMemset(Bw, 0, 16 << 20); hipMemset(st, 0, 1 << 20);
+    struct { int M, N, K; } gs[] = {{1536, 1536, 256}, {1536, 256, 1536}, {6144, 960, 160}, {6144, 160, 960}, {6144, 512, 128}, {24576, 256, 64}};
+    for (auto g : gs) {
+      GemmP q;
+      memset(&q, 0, sizeof(q));
+      q.A = A; q.Bw = Bw; q.C = Cc; q.M = g.M; q.N = g.N; q.K = g.K; q.lda = g.K; q.ldc = g.N;
+      float t0 = time_us([&](hipStream_t stt) { launch_gemm(1, 0, q, stt); }, s);
+      q.stats = st; q.stats_rep = 1;
+      float t1 = time_us([&](hipStream_t stt) { launch_gemm(1, 0, q, stt); }, s);
+      q.stats_rep = 8;
+      float t8 = time_us([&](hipStream_t stt) { launch_gemm(1, 0, q, stt); }, s);
+      printf("gemm M=%5d N=%4d K=%4d: plain %6.1f us   +stats %6.1f us   +stats rep8 %6.1f us\n", g.M, g.N, g.K, t0, t1, t8);
+    }
+    hipFree(A); hipFree(Bw); hipFree(Cc); hipFree(st);
   }
   const int dt = 1;  // bf16
   struct Shape { int B, H, W, C; };
