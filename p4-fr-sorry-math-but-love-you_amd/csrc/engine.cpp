@@ -390,6 +390,7 @@ int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s) {
   // packed weights carry zero padding (generator: 245 -> 256 columns) that kernels multiply with zero gradients:
   // the padding must be finite, so clear everything once
   (void)hipMemsetAsync(m->ws, 0, bytes, s);
+  m->zero_hwm = 0; m->ex->zoff = 0;  // fresh, all-zero workspace
   (void)hipStreamSynchronize(s);
   for (Wt* w : m->all_w) {
     w->fwd = w->pk_fwd_off >= 0 ? m->ws + w->pk_fwd_off : nullptr;
@@ -1121,11 +1122,13 @@ static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) 
   Exec& e = *m->ex;
   e.s = s; e.dt = m->cfg.dtype; e.train = train; e.rec = rec; e.dry = dry;
   e.drop = train ? m->cfg.dropout : 0.f;
+  if (!e.dry && e.zbase && e.zoff > m->zero_hwm) m->zero_hwm = e.zoff;  // what the previous call dirtied at most
   e.reset(m->ws + m->persist_bytes, m->ws_bytes > m->persist_bytes ? m->ws_bytes - m->persist_bytes : 0,
           m->ws + m->off_zero, m->zero_bytes);
   e.peak = 0;
   ++m->epoch;  // whatever lived in the arena (e.g. a step-wise decoding session) is gone
-  if (!dry) launch_fill(m->ws + m->off_zero, 0, m->zero_bytes, s);
+  // the pool is all-zero after set_workspace and only ever dirtied up to the high-water mark: clear just that much
+  if (!dry && m->zero_hwm) launch_fill(m->ws + m->off_zero, 0, std::min(m->zero_bytes, (m->zero_hwm + 4095) & ~(size_t)4095), s);
 }
 
 size_t model_workspace_bytes(Model* m, int B, int L) {

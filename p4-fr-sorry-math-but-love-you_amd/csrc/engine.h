@@ -97,7 +97,7 @@ struct Model {
   size_t persist_bytes = 0;
   size_t off_packed = 0, off_adam_m = 0, off_adam_v = 0, off_scalars = 0, off_pe1d = 0, off_hpos = 0, off_wpos = 0,
          off_stage_img = 0, off_stage_tgt = 0, off_zero = 0;
-  size_t zero_bytes = 0;
+  size_t zero_bytes = 0, zero_hwm = 0;
   size_t off_sumsq = 0;
   size_t off_packdesc = 0, packdesc_bytes = 0, off_packblk = 0, packblk_bytes = 0; int pack_n = 0; long pack_total = 0; bool pack_dirty = true;
   int stage_B = 0, stage_L = 0;
