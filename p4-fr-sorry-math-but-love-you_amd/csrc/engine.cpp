@@ -579,11 +579,13 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       if (!hasgeo) {
         d.M = (int)M; d.N = w->K; d.K = w->ldb; d.lda = ldy; d.ldc = x->C;
         e.nflops = 2.0 * (double)d.M * d.N * w->N;
+        e.nbytes = ((double)d.M * w->N + (double)d.M * d.N * (beta ? 2 : 1) + (double)w->N * d.N) * e.esz();  // dY + dX (+old dX) + W
         LCH(e, launch_gemm(e.dt, AM_DENSE, d, e.s));
       } else {
         d.M = (int)((long)B * g.H * g.W); d.N = g.Ci; d.K = 9 * w->Co; d.ldc = g.Ci;
         d.H = g.OH; d.W = g.OW; d.Ci = w->Co; d.OH = g.H; d.OW = g.W; d.KW = g.KW; d.stride = g.stride; d.pt = g.pt; d.pl = g.pl;
         e.nflops = 2.0 * (double)M * N * w->K;
+        e.nbytes = ((double)M * N + (double)d.M * d.N * (beta ? 2 : 1) + (double)N * w->K) * e.esz();
         LCH(e, launch_gemm(e.dt, AM_DGRAD, d, e.s));
       }
     });
