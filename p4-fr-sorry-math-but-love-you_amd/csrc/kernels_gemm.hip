@@ -258,8 +258,176 @@ static void launch_gemm_t(const GemmP& p, hipStream_t s) {
   }
 }
 
+// =========================================================================================
+// 3x3 stride-1 SAME convolution with the input patch staged ONCE in LDS (bf16): forward and data gradient.
+// The implicit-GEMM path above gathers every A k-panel from global memory, i.e. each input element is fetched nine
+// times (once per tap) through L2 / Infinity Cache.  Here a workgroup owns an 8 x 16 pixel tile: it loads the
+// (8+2) x (16+2) halo patch with all C input channels into LDS once, and every MFMA A fragment (16 pixels of one tile
+// row x 8 channels of one tap) is a ds_read_b128 at patch[(ty + dy) * 18 + tx + dx][c].  Only the weight k-panels
+// [BN][32] still stream through the register-staged double buffer (one panel per barrier: staging four made it slower).
+//   out[b][y][x][n] = sum_{tap, c} in[b][y + dy(tap)][x + dx(tap)][c] * Wt[n][tap][c]     (flip: dy, dx mirrored = dgrad)
+// =========================================================================================
+#define HC_TH 8
+#define HC_TW 16
+template <int BN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, int Wimg, int C, int flip) {
+  typedef bf16_t T;
+  constexpr int NT = BN / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+  const int CP = C + 8;                                   // padded pixel pitch (elements): staggers banks
+  T* patch = reinterpret_cast<T*>(hsm);                   // [(TH+2)*(TW+2)][CP]
+  T* wpan = patch + (size_t)(HC_TH + 2) * (HC_TW + 2) * CP;  // [2][BN*32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int tiles_x = (Wimg + HC_TW - 1) / HC_TW, tiles_y = (Himg + HC_TH - 1) / HC_TH;
+  const int ntn = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  const int tile_n = bid % ntn; bid /= ntn;
+  const int txi = bid % tiles_x; bid /= tiles_x;
+  const int tyi = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = tyi * HC_TH, x0 = txi * HC_TW, n0 = tile_n * BN;
+  const T* in = (const T*)p.A + (long)b * Himg * Wimg * C;
+  const T* Wt = (const T*)p.Bw;
+  const int K = 9 * C, C8 = C >> 3;
+
+  // ---- halo patch -> LDS (zero outside the image)
+  for (int i = tid; i < (HC_TH + 2) * (HC_TW + 2) * C8; i += 256) {
+    const int c8 = i % C8, pix = i / C8;
+    const int hy = pix / (HC_TW + 2), hx = pix - hy * (HC_TW + 2);
+    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+    uint4 v = zero16();
+    if (gy >= 0 && gy < Himg && gx >= 0 && gx < Wimg) v = ld16(in + ((long)gy * Wimg + gx) * C + c8 * 8);
+    st16(patch + (size_t)pix * CP + c8 * 8, v);
+  }
+  // ---- weight panels: thread (n = tid / 4, chunk = tid % 4) stages one 16-byte chunk per k-step
+  const int wn = tid >> 2, wc = tid & 3;
+  auto load_w = [&](int ks) -> uint4 {
+    const int k0 = ks * 32 + wc * 8;
+    if (wn < BN && n0 + wn < p.N && k0 < K) return ld16(Wt + (long)(n0 + wn) * K + k0);
+    return zero16();
+  };
+  auto store_w = [&](int buf, uint4 v) { if (wn < BN) st16(wpan + buf * BN * 32 + panel_chunk<T>(wn, wc), v); };
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K + 31) / 32;
+  uint4 wreg = load_w(0);
+  store_w(0, wreg);
+  __syncthreads();
+  // per-lane position in the k stream: 8-channel chunk kc = 4 * ks + fq -> (tap, channel chunk)
+  int tap = fq / C8, cch = fq - tap * C8;
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) wreg = load_w(ks + 1);
+    const T* lb = wpan + cur * BN * 32;
+    {
+      // lanes past the end of K (last k-step only) read a valid address and zero the fragment: the MFMAs below must
+      // be executed by the whole wavefront
+      const bool kvalid = tap < 9;
+      const int tp = kvalid ? tap : 8;
+      const int kh = tp / 3, kw = tp - kh * 3;
+      const int dy = flip ? 2 - kh : kh, dx = flip ? 2 - kw : kw;
+      Frag<T> af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ty = wave * 2 + i;  // tile row of this 16-pixel MFMA row block
+        const uint4 v = ld16(patch + (size_t)((ty + dy) * (HC_TW + 2) + fr + dx) * CP + (kvalid ? cch : 0) * 8);
+        af[i].v = kvalid ? v : zero16();
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        Frag<T> bf = load_frag<T>(lb, j * 16 + fr, fq);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) mma(af[i], bf, acc[i][j]);
+      }
+    }
+    cch += 4;
+    while (cch >= C8) { cch -= C8; ++tap; }
+    if (ks + 1 < nk) store_w(cur ^ 1, wreg);
+    __syncthreads();
+  }
+
+  // ---- epilogue (same contract as gemm_kernel: beta, fused BatchNorm statistics / BatchNorm-backward sums)
+  float* sred = reinterpret_cast<float*>(wpan);  // [2][BN]
+  if (p.stats) {
+    for (int i = tid; i < 2 * BN; i += 256) sred[i] = 0.f;
+    __syncthreads();
+  }
+  const int tile_m = (b * tiles_y + tyi) * tiles_x + txi;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + j * 16 + fr;
+    float s1 = 0.f, s2 = 0.f;
+    float bsc = 0.f, bsh = 0.f, bmu = 0.f, brs = 0.f;
+    if (p.bnb_y && col < p.N) { bsc = p.bnb_ss[col]; bsh = p.bnb_ss[p.N + col]; bmu = p.bnb_mr[col]; brs = p.bnb_mr[p.N + col]; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gy = y0 + wave * 2 + i, gx = x0 + fq * 4 + r;
+        if (gy >= Himg || gx >= Wimg || col >= p.N) continue;
+        const long row = ((long)b * Himg + gy) * Wimg + gx;
+        const float v = acc[i][j][r];
+        const long o = row * p.ldc + col;
+        T* c = (T*)p.C;
+        const float tot = p.beta ? to_f(c[o]) + v : v;
+        c[o] = from_f<T>(tot);
+        if (p.bnb_y) {
+          const float yv = to_f(((const T*)p.bnb_y)[row * p.N + col]);
+          const float g = tot * act_bwd(yv * bsc + bsh, p.bnb_act);
+          s1 += g; s2 += g * ((yv - bmu) * brs);
+        } else {
+          s1 += v; s2 += v * v;
+        }
+      }
+    }
+    if (p.stats) {
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (fq == 0) { atomicAdd(&sred[j * 16 + fr], s1); atomicAdd(&sred[BN + j * 16 + fr], s2); }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int cc = i < BN ? i : i - BN, col = n0 + cc;
+      if (col < p.N) atomicAdd(p.stats + (size_t)(tile_m % p.stats_rep) * 2 * p.N + (i < BN ? 0 : p.N) + col, sred[i]);
+    }
+  }
+}
+
+// stride-1 SAME 3x3 (forward or data gradient), bf16, no bias / activation / dropout epilogue, C % 8 == 0
+static bool conv_halo_launch(int amode, const GemmP& p, hipStream_t s) {
+  static const bool off = getenv("SATRN_NO_HALO_CONV") != nullptr;
+  if (off || p.KW != 3 || p.stride != 1 || p.pt != 1 || p.pl != 1 || p.OH != p.H || p.OW != p.W) return false;
+  if (p.bias || p.act || p.drop_p > 0.f || p.out_f32 || p.ascale || (p.Ci & 7) || p.ldc != p.N) return false;
+  const int C = p.Ci, H = p.OH, W = p.OW;
+  const int B = p.M / (H * W);
+  if ((long)B * H * W != p.M) return false;
+  const int BN = p.N <= 32 ? 32 : 64;
+  const size_t sh = (size_t)(HC_TH + 2) * (HC_TW + 2) * (C + 8) * 2 + (size_t)2 * BN * 32 * 2;
+  if (sh > 150 * 1024) return false;
+  const int tiles = B * ((H + HC_TH - 1) / HC_TH) * ((W + HC_TW - 1) / HC_TW) * ((p.N + BN - 1) / BN);
+  const int flip = amode == AM_DGRAD ? 1 : 0;
+  if (BN == 32) {
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a = true; }
+    hipLaunchKernelGGL((conv3x3_halo_kernel<32>), dim3(tiles), dim3(256), sh, s, p, H, W, C, flip);
+  } else {
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a = true; }
+    hipLaunchKernelGGL((conv3x3_halo_kernel<64>), dim3(tiles), dim3(256), sh, s, p, H, W, C, flip);
+  }
+  return true;
+}
+
 void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return;
+  if (dt == DT_BF16 && amode != AM_DENSE && conv_halo_launch(amode, p, s)) return;
   if (dt == DT_BF16) {
     if (amode == AM_DENSE) launch_gemm_t<bf16_t, AM_DENSE>(p, s);
     else if (amode == AM_CONV) launch_gemm_t<bf16_t, AM_CONV>(p, s);
