@@ -638,7 +638,11 @@ Tensor* op_stem(Exec& e, const float* img, Wt* w, int B, int Cin, int H, int W, 
   if (e.rec)
     e.tape.push_back([&e, img, w, y, B, Cin, H, W, OH, OW, stride, pad]() {
       if (!y->g) return;
-      LCH(e, launch_stem_wgrad(e.dt, img, y->g, w->g, B, Cin, H, W, w->Co, OH, OW, stride, pad, e.s));
+      {
+        const int dt = e.dt; void* yg = y->g; float* wg = w->g; const int Co = w->Co;
+        if (e.prof || e.dry) LCH(e, launch_stem_wgrad(dt, img, yg, wg, B, Cin, H, W, Co, OH, OW, stride, pad, e.s));
+        else e.defer([=](hipStream_t ws) { launch_stem_wgrad(dt, img, yg, wg, B, Cin, H, W, Co, OH, OW, stride, pad, ws); });
+      }
     });
   return y;
 }
