@@ -15,7 +15,6 @@ struct GemmP {
   int H, W, Ci, OH, OW, KW, stride, pt, pl;
   int act, beta, out_f32;
   float drop_p; const uint32_t* seed; uint32_t site;
-  const float* ascale; int ascale_hw;  // optional A[m][k] *= ascale[(m/ascale_hw)*K + k]  (SE gate), dense only
   float* stats;  // optional [stats_rep][2N] (zeroed): per-column sum / sum of squares of the output (for the BatchNorm that follows)
   int stats_rep; // replicas (>= 1) the row tiles spread their atomics over; the consumer sums them
   // optional (dgrad of a BatchNorm output, N == the BN's C): stats become the BN backward's column sums
@@ -36,7 +35,6 @@ struct WgradP {
   int nbatch, nb_inner;                    // batched: z -> (z / nb_inner, z % nb_inner)
   long sY_o, sY_i, sA_o, sA_i, sW_o, sW_i;  // element strides per outer/inner batch index
   int ldw;                                 // out_t==1: row stride of dW
-  const float* ascale; int ascale_hw;      // optional A[m][k] *= ascale[(m/ascale_hw)*K + k]
 };
 void launch_wgrad(int dt, const WgradP& p, hipStream_t s);
 void launch_conv_grad_unpack(const float* tmp /*[N][taps][Ci]*/, float* dw /*[N][Ci][taps] +=*/, int N, int Ci, int taps, hipStream_t s);

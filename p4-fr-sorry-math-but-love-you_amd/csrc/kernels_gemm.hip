@@ -72,14 +72,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         if (ri[i].ok && kok) {
           if (AM == AM_DENSE) {
             v = ld16(A + (long)ri[i].img * p.lda + k0);
-            if (p.ascale) {
-              float f[CH];
-              unpack<T>(v, f);
-              const float* gp = p.ascale + (long)(ri[i].img / p.ascale_hw) * p.K + k0;
-#pragma unroll
-              for (int j = 0; j < CH; ++j) f[j] *= gp[j];
-              v = pack<T>(f);
-            }
           } else if (AM == AM_CONV) {
             int sy = ri[i].by + kh, sx = ri[i].bx + kw;
             if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
@@ -404,7 +396,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, in
 static bool conv_halo_launch(int amode, const GemmP& p, hipStream_t s) {
   static const bool off = getenv("SATRN_NO_HALO_CONV") != nullptr;
   if (off || p.KW != 3 || p.stride != 1 || p.pt != 1 || p.pl != 1 || p.OH != p.H || p.OW != p.W) return false;
-  if (p.bias || p.act || p.drop_p > 0.f || p.out_f32 || p.ascale || (p.Ci & 7) || p.ldc != p.N) return false;
+  if (p.bias || p.act || p.drop_p > 0.f || p.out_f32 || (p.Ci & 7) || p.ldc != p.N) return false;
   const int C = p.Ci, H = p.OH, W = p.OW;
   const int B = p.M / (H * W);
   if ((long)B * H * W != p.M) return false;
@@ -523,14 +515,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split
           if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) v = ld16(A + ((long)(b * p.H * p.W + sy * p.W + sx)) * p.Ci + xci);
         } else {
           v = ld16(A + (long)m * p.lda + xcol);
-          if (p.ascale) {
-            float f[CH];
-            unpack<T>(v, f);
-            const float* gp = p.ascale + (long)(m / p.ascale_hw) * p.K + xcol;
-#pragma unroll
-            for (int j = 0; j < CH; ++j) f[j] *= gp[j];
-            v = pack<T>(f);
-          }
         }
       }
       rx[i] = v;
