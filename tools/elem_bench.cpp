@@ -176,6 +176,29 @@ int main(int argc, char** argv) {
     }
     hipFree(A); hipFree(Bw); hipFree(Cc); hipFree(st);
   }
+  {  // 3x3 stride-1 convolutions through launch_gemm (AM_CONV = 1 forward, AM_DGRAD = 2 data gradient): halo kernel vs implicit GEMM
+    void *A, *Bw, *Cc; float* st;
+    hipMalloc(&A, 96 << 20); hipMalloc(&Bw, 16 << 20); hipMalloc(&Cc, 96 << 20); hipMalloc(&st, 1 << 20);
+    hipMemset(A, 0, 96 << 20); hipMemset(Bw, 0, 16 << 20); hipMemset(Cc, 0, 96 << 20); hipMemset(st, 0, 1 << 20);
+    struct { int B, H, W, C, N, mode; const char* nm; } cs[] = {
+        {32, 32, 96, 192, 48, 2, "dgrad st1 b1-3"}, {32, 16, 48, 256, 64, 2, "dgrad st2 b1-3"}, {32, 64, 192, 24, 24, 2, "dgrad st0"},
+        {32, 32, 96, 48, 192, 1, "fwd st1 b1-3"}, {32, 16, 48, 64, 256, 1, "fwd st2 b1-3"}, {32, 64, 192, 24, 24, 1, "fwd st0"}};
+    for (auto c : cs) {
+      GemmP q;
+      memset(&q, 0, sizeof(q));
+      q.A = A; q.Bw = Bw; q.C = Cc; q.M = c.B * c.H * c.W; q.N = c.N; q.K = 9 * c.C; q.ldc = c.N;
+      q.H = c.H; q.W = c.W; q.Ci = c.C; q.OH = c.H; q.OW = c.W; q.KW = 3; q.stride = 1; q.pt = 1; q.pl = 1;
+      float t0 = time_us([&](hipStream_t stt) { launch_gemm(1, c.mode, q, stt); }, s, 30);
+      q.beta = 1;
+      float t1 = time_us([&](hipStream_t stt) { launch_gemm(1, c.mode, q, stt); }, s, 30);
+      q.beta = 0; q.stats = st; q.stats_rep = 4;
+      float t2 = time_us([&](hipStream_t stt) { launch_gemm(1, c.mode, q, stt); }, s, 30);
+      const double gf = 2.0 * q.M * q.N * q.K / 1e9;
+      printf("conv %-16s M=%6d C=%3d N=%3d: plain %6.1f us (%5.0f TF/s)  beta %6.1f  stats %6.1f   [%s]\n", c.nm, q.M, c.C, c.N, t0, gf / t0 * 1e3 / 1e3, t1, t2,
+             getenv("SATRN_NO_HALO_CONV") ? "implicit GEMM" : "halo");
+    }
+    hipFree(A); hipFree(Bw); hipFree(Cc); hipFree(st);
+  }
   const int dt = 1;  // bf16
   struct Shape { int B, H, W, C; };
   std::vector<Shape> shapes = {{32, 8, 24, 512}, {32, 8, 24, 960}, {32, 4, 12, 1536}, {32, 16, 48, 256}, {32, 32, 96, 192}};
