@@ -357,7 +357,14 @@ Model* model_create(const SatrnConfig& cfg) {
   m->persist_bytes = (o + 255) & ~(size_t)255;
   m->ex = new Exec();
   m->ex->m = m;
-  if (!getenv("SATRN_NO_SIDE_STREAM")) (void)hipStreamCreateWithFlags(&m->ex->s2, hipStreamNonBlocking);
+  if (!getenv("SATRN_NO_SIDE_STREAM")) {
+    // optimizer-only work (weight gradients) runs on a LOW-priority stream: whenever both queues have a kernel ready, the
+    // data-gradient chain (the critical path) is dispatched first
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically greatest = lowest priority
+    if (getenv("SATRN_SIDE_PRIO_DEFAULT") || hipStreamCreateWithPriority(&m->ex->s2, hipStreamNonBlocking, lo) != hipSuccess)
+      (void)hipStreamCreateWithFlags(&m->ex->s2, hipStreamNonBlocking);
+  }
   segment_ranges(m);
   return m;
 }

@@ -360,7 +360,7 @@ class _SATRNBase(nn.Module):
         simg.copy_(input)
         cur = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=input.device)
+            self._side = torch.cuda.Stream(device=input.device, priority=-1)  # high priority: the critical chain
         self._side.wait_stream(cur)
         mgr = self.decoder.manager
         with torch.cuda.stream(self._side):
@@ -413,7 +413,7 @@ class _SATRNBase(nn.Module):
         self._warm.add(key)
         cur = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=input.device)
+            self._side = torch.cuda.Stream(device=input.device, priority=-1)  # high priority: the critical chain
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             check(self._lib.satrn_model_train_step(self._h, ptr(self._stage[0]), ptr(self._stage[1]), B, L, hy,
