@@ -627,11 +627,14 @@ void launch_maxpool(int dt, int bwd, const void* x, const void* dy, void* out, i
 
 // ---- per-image reductions over HW: out[b][c (+C)] = sum_hw f(...)  ---------------------------------
 // MODE 0: mean x ; 1: sum a*b ; 2: posenc dgate (sum dout*hpos[h], sum dout*wpos[w] -> out[b][2C])
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void hw_reduce_kernel(const T* a, const T* bb, const float* hpos, const float* wpos,
-                                                        T* out, int HW, int Wd, int C, float scale) {
+// RG row groups of 64 chunk lanes each (block = 64 * RG threads): a thread sweeps HW / RG rows, so the number of
+// dependent load batches -- what these latency-bound reductions cost -- falls with RG
+template <typename T, int MODE, int RG>
+__global__ __launch_bounds__(64 * RG) void hw_reduce_kernel(const T* a, const T* bb, const float* hpos, const float* wpos,
+                                                            T* out, int HW, int Wd, int C, float scale) {
   constexpr int CH = TT<T>::CH;
-  __shared__ float red[2][4][64 * CH];
+  constexpr int NRED = MODE == 2 ? 2 : 1;
+  __shared__ float red[NRED][RG][64 * CH];
   const int CC = C / CH;
   const int b = blockIdx.x;
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(256) void hw_reduce_kernel(const T* a, const T* bb,
   for (int j = 0; j < CH; ++j) s0[j] = s1[j] = 0.f;
   if (c < CC) {
 #pragma unroll 4
-    for (int p = rg; p < HW; p += 4) {
+    for (int p = rg; p < HW; p += RG) {
       float v[CH];
       unpack<T>(ld16(a + ((long)b * HW + p) * C + c * CH), v);
       if (MODE == 0) {
@@ -663,13 +666,16 @@ __global__ __launch_bounds__(256) void hw_reduce_kernel(const T* a, const T* bb,
     }
   }
 #pragma unroll
-  for (int j = 0; j < CH; ++j) { red[0][rg][cl * CH + j] = s0[j]; red[1][rg][cl * CH + j] = s1[j]; }
+  for (int j = 0; j < CH; ++j) { red[0][rg][cl * CH + j] = s0[j]; if (MODE == 2) red[NRED - 1][rg][cl * CH + j] = s1[j]; }
   __syncthreads();
   if (rg == 0 && c < CC) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      s0[j] = (red[0][0][cl * CH + j] + red[0][1][cl * CH + j] + red[0][2][cl * CH + j] + red[0][3][cl * CH + j]) * scale;
-      s1[j] = (red[1][0][cl * CH + j] + red[1][1][cl * CH + j] + red[1][2][cl * CH + j] + red[1][3][cl * CH + j]) * scale;
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int g = 0; g < RG; ++g) { t0 += red[0][g][cl * CH + j]; if (MODE == 2) t1 += red[NRED - 1][g][cl * CH + j]; }
+      s0[j] = t0 * scale;
+      s1[j] = t1 * scale;
     }
     if (MODE == 2) {
       st16(out + (long)b * 2 * C + c * CH, pack<T>(s0));
@@ -682,14 +688,14 @@ __global__ __launch_bounds__(256) void hw_reduce_kernel(const T* a, const T* bb,
 void launch_pool_hw(int dt, const void* x, void* out, int B, int HW, int C, hipStream_t s) {
   DISPATCH_T(dt, {
     int gy = (C / TT<T>::CH + 63) / 64;
-    hipLaunchKernelGGL((hw_reduce_kernel<T, 0>), dim3(B, gy), dim3(256), 0, s, (const T*)x, (const T*)nullptr, nullptr,
+    hipLaunchKernelGGL((hw_reduce_kernel<T, 0, 16>), dim3(B, gy), dim3(1024), 0, s, (const T*)x, (const T*)nullptr, nullptr,
                        nullptr, (T*)out, HW, 1, C, 1.0f / (float)HW);
   });
 }
 void launch_se_bwd_gate(int dt, const void* dout, const void* x, void* dgate, int B, int HW, int C, hipStream_t s) {
   DISPATCH_T(dt, {
     int gy = (C / TT<T>::CH + 63) / 64;
-    hipLaunchKernelGGL((hw_reduce_kernel<T, 1>), dim3(B, gy), dim3(256), 0, s, (const T*)dout, (const T*)x, nullptr,
+    hipLaunchKernelGGL((hw_reduce_kernel<T, 1, 16>), dim3(B, gy), dim3(1024), 0, s, (const T*)dout, (const T*)x, nullptr,
                        nullptr, (T*)dgate, HW, 1, C, 1.0f);
   });
 }
@@ -697,7 +703,7 @@ void launch_posenc2d_bwd(int dt, const void* dout, const float* hpos, const floa
                          int W, int C, hipStream_t s) {
   DISPATCH_T(dt, {
     int gy = (C / TT<T>::CH + 63) / 64;
-    hipLaunchKernelGGL((hw_reduce_kernel<T, 2>), dim3(B, gy), dim3(256), 0, s, (const T*)dout, (const T*)nullptr, hpos,
+    hipLaunchKernelGGL((hw_reduce_kernel<T, 2, 4>), dim3(B, gy), dim3(256), 0, s, (const T*)dout, (const T*)nullptr, hpos,
                        wpos, (T*)dgate, H * W, W, C, 1.0f);
   });
 }
