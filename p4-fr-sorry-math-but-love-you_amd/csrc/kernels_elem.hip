@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int 
 }
 
 template <typename T, int NO, typename F>
-static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain, hipStream_t s, int rows_per_thread = 8) {
+static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain, hipStream_t s, int rows_per_thread = 8,
+                             int target_blocks = 512, int max_blocks = 1024) {
   constexpr int CH = TT<T>::CH;
   int CC = C / CH;
   // at most 32 column chunks per block (>= 8 row lanes), >= 32 rows per thread when M allows: keeps the number of
@@ -86,12 +87,12 @@ static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain
   // ~4 rows per thread, at most ~1024 blocks: these reductions are latency-bound per thread, and the float atomics
   // they end with (NO * TX * CH per block) are cheap next to the streamed bytes
   // rows per thread: as many as keep >= ~512 blocks in flight (these kernels are latency-bound, not byte-bound)
-  long rpt = (M * gy) / ((long)TY * 512);
+  long rpt = (M * gy) / ((long)TY * target_blocks);
   if (rpt < 1) rpt = 1;
   if (rpt > rows_per_thread) rpt = rows_per_thread;
   long rpb = (long)TY * rpt;
   long gx = (M + rpb - 1) / rpb;
-  long cap = 1024 / gy < 1 ? 1 : 1024 / gy;
+  long cap = max_blocks / gy < 1 ? 1 : max_blocks / gy;
   if (gx > cap) { gx = cap; rpb = (M + gx - 1) / gx; rpb = ((rpb + TY - 1) / TY) * TY; gx = (M + rpb - 1) / rpb; }
   hipLaunchKernelGGL((colreduce_kernel<T, NO, F>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1,
                      nmain);
@@ -546,6 +547,9 @@ void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float*
   });
 }
 
+// side-stream kernel (see launch_wgrad_tile): a small grid keeps it out of the data-gradient chain's way
+static const int DWW_BLK = getenv("SATRN_DWW_BLOCKS") ? atoi(getenv("SATRN_DWW_BLOCKS")) : 512;
+static const int DWW_RPT = getenv("SATRN_DWW_RPT") ? atoi(getenv("SATRN_DWW_RPT")) : 8;
 template <typename T> struct DwWgradF {
   const T* x; const T* dy; int H, W, C, OH, OW, stride, pt, pl;
   __device__ void prep(int) {}
@@ -804,10 +808,10 @@ void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw, float
   DISPATCH_T(dt, {
     DwWgradF<T> f{(const T*)x, (const T*)dy, H, W, C, OH, OW, stride, pt, pl};
     if (scratch10C) {
-      launch_colreduce<T, 10>(f, (long)B * OH * OW, C, scratch10C, nullptr, -1, s, 8);
+      launch_colreduce<T, 10>(f, (long)B * OH * OW, C, scratch10C, nullptr, -1, s, DWW_RPT, DWW_BLK, DWW_BLK);
       hipLaunchKernelGGL(dw_wgrad_scatter_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, s, scratch10C, dw, dbias, C);
     } else {
-      launch_colreduce<T, 10>(f, (long)B * OH * OW, C, dw, dbias, 9, s, 16);
+      launch_colreduce<T, 10>(f, (long)B * OH * OW, C, dw, dbias, 9, s, 16, DWW_BLK, DWW_BLK);
     }
   });
 }
