@@ -632,18 +632,19 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res) {
                        res ? res->p : nullptr, z->p, M, C, act, e.s));
   used(y); used(res);
   if (e.rec) {
-    if (e.train) { z->bn_y = y->p; z->bn_ss = ss; z->bn_mr = mr; z->bn_act = act; }
+    if (e.train) { z->bn_y = y->p; z->bn_ss = ss; z->bn_mr = mr; z->bn_act = act; z->bn_has_res = res != nullptr; }
     e.tape.push_back([&e, y, z, bn, act, res, ss, mr, M, C]() {
       if (!z->g) return;
       float* red = z->bn_red;  // already produced by the epilogue of the last kernel that wrote z's gradient?
       if (!red) {
         red = e.zalloc(2 * C);
         e.nbytes = (double)M * C * e.esz() * 2;
-        LCH(e, launch_bn_bwd_reduce(e.dt, z->g, y->p, ss, mr, M, C, act, red, e.s));
+        LCH(e, launch_bn_bwd_reduce(e.dt, z->g, y->p, ss, mr, M, C, act, red, e.s, z->se_gate, z->se_dpool, z->se_hw));
       }
       void* dy = e.grad(y, nullptr);
       e.nbytes = (double)M * C * e.esz() * 3;
-      LCH(e, launch_bn_bwd_apply(e.dt, z->g, y->p, ss, mr, bn->w.p, red, M, C, act, dy, bn->w.g, bn->b.g, e.s, z->bn_red ? z->bn_red_rep : 1));
+      LCH(e, launch_bn_bwd_apply(e.dt, z->g, y->p, ss, mr, bn->w.p, red, M, C, act, dy, bn->w.g, bn->b.g, e.s, z->bn_red ? z->bn_red_rep : 1,
+                                 z->se_gate, z->se_dpool, z->se_hw));
       if (res) acc_grad(e, res, z->g);
     });
   }
@@ -937,9 +938,17 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb) {
           e.defer([=](hipStream_t ws) { launch_se_bwd(dt, dgate, gp, u1, s1, pooled, w1, w2, dz2, du1, dpooled, g1, gb1, g2, gb2, B, C, S, ws, 2); });
         }
       }
-      int beta;
-      void* dx = e.grad(x, &beta);
-      LCH(e, launch_se_bwd_x(e.dt, y->g, gate->p, dpooled, dx, B, HW, C, beta, e.s));
+      static const bool fold = getenv("SATRN_NO_SE_FOLD") == nullptr;
+      if (fold && x->bn_y && !x->bn_has_res && x->ncons == 1 && !x->g) {
+        // x is a BatchNorm output read by this op only: its backward computes y->g*gate + dpooled/HW on the fly, so the
+        // gradient tensor se_bwd_x would write is never materialised
+        x->g = y->g; x->g_init = true;
+        x->se_gate = gate->p; x->se_dpool = dpooled; x->se_hw = HW;
+      } else {
+        int beta;
+        void* dx = e.grad(x, &beta);
+        LCH(e, launch_se_bwd_x(e.dt, y->g, gate->p, dpooled, dx, B, HW, C, beta, e.s));
+      }
     });
   return y;
 }

@@ -69,6 +69,10 @@ struct Tensor {
   int ncons = 0;
   const void* bn_y = nullptr; const float* bn_ss = nullptr; const float* bn_mr = nullptr; int bn_act = 0;
   float* bn_red = nullptr; int bn_red_rep = 1;
+  // squeeze-and-excite backward folded into this BatchNorm output's backward: g holds the SE OUTPUT's gradient and the
+  // true gradient is g*se_gate[b] + se_dpool[b]/se_hw
+  const void* se_gate = nullptr; const void* se_dpool = nullptr; int se_hw = 0;
+  bool bn_has_res = false;  // the BatchNorm that produced this tensor also added a residual (its gradient = this tensor's)
 };
 
 struct EffBlock { int type, cin, cout, mid, stride, se; bool skip; Wt c0, c1, dw, se_r, se_e; Vec se_rb, se_eb; BNp bn1, bn2, bn3; };

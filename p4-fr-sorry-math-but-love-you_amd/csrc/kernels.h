@@ -65,10 +65,13 @@ void launch_bn_act(int dt, const void* y, const float* sums, int sums_rep, const
                    float* rv, int64_t* nbt, float eps, float mom, float* scale_shift, float* mean_rstd, const void* res,
                    void* z, long M, int C, int act, hipStream_t s);
 void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* scale_shift, const float* mean_rstd,
-                          long M, int C, int act, float* red /*[2C] zeroed*/, hipStream_t s);
+                          long M, int C, int act, float* red /*[2C] zeroed*/, hipStream_t s,
+                          const void* se_gate = nullptr /*[B][C] T*/, const void* se_dpool = nullptr /*[B][C] T*/, int se_hw = 0);
 void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* scale_shift, const float* mean_rstd,
                          const float* w, const float* red, long M, int C, int act, void* dy, float* dw, float* db,
-                         hipStream_t s, int red_rep = 1);
+                         hipStream_t s, int red_rep = 1, const void* se_gate = nullptr, const void* se_dpool = nullptr, int se_hw = 0);
+// se_gate/se_dpool/se_hw: the gradient fed to the two BatchNorm-backward passes is dz*gate[b][c] + dpool[b][c]/se_hw (the
+// squeeze-and-excite backward wrt its input, b = row / se_hw) computed on the fly instead of materialised by se_bwd_x
 void launch_stem_conv(int dt, const float* img, const float* w, void* y, int B, int Cin, int H, int W, int Co, int OH,
                       int OW, int stride, int pad, hipStream_t s);
 void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int B, int Cin, int H, int W, int Co,

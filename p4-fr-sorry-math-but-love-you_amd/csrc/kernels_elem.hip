@@ -224,6 +224,9 @@ void launch_bn_act(int dt, const void* y, const float* sums, int sums_rep, const
 
 template <typename T> struct BnBwdRedF {
   const T* dz; const T* y; const float* ss; const float* mr; int C; int act;
+  // optional squeeze-and-excite backward folded in: the gradient of the BN output is dz*gate[b] + dpool[b]*scale
+  // (what se_bwd_x would have materialised), b = row / se_hw
+  const T* se_gate; const T* se_dpool; int se_hw; float se_scale;
   float sc[TT<T>::CH], sh[TT<T>::CH], mu[TT<T>::CH], rs[TT<T>::CH];
   __device__ void prep(int c0) {
     ldv(ss + c0, sc, TT<T>::CH); ldv(ss + C + c0, sh, TT<T>::CH); ldv(mr + c0, mu, TT<T>::CH); ldv(mr + C + c0, rs, TT<T>::CH);
@@ -233,6 +236,14 @@ template <typename T> struct BnBwdRedF {
     float d[CH], v[CH];
     unpack<T>(ld16(dz + r * C + c0), d);
     unpack<T>(ld16(y + r * C + c0), v);
+    if (se_gate) {
+      const long b = r / se_hw;
+      float gt[CH], dp[CH];
+      unpack<T>(ld16(se_gate + b * C + c0), gt);
+      unpack<T>(ld16(se_dpool + b * C + c0), dp);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) d[j] = d[j] * gt[j] + dp[j] * se_scale;
+    }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       float u = v[j] * sc[j] + sh[j];
@@ -244,10 +255,11 @@ template <typename T> struct BnBwdRedF {
   }
 };
 void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* ss, const float* mr, long M, int C,
-                          int act, float* red, hipStream_t s) {
+                          int act, float* red, hipStream_t s, const void* se_gate, const void* se_dpool, int se_hw) {
   DISPATCH_T(dt, {
     BnBwdRedF<T> f;
     f.dz = (const T*)dz; f.y = (const T*)y; f.ss = ss; f.mr = mr; f.C = C; f.act = act;
+    f.se_gate = (const T*)se_gate; f.se_dpool = (const T*)se_dpool; f.se_hw = se_hw > 0 ? se_hw : 1; f.se_scale = se_hw > 0 ? 1.0f / (float)se_hw : 0.f;
     launch_colreduce<T, 2>(f, M, C, red, red + C, 1, s);
   });
 }
@@ -256,7 +268,7 @@ void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* ss
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* dz, const T* y, const float* ss, const float* mr, const float* w,
                                     const float* red, int red_rep, float invM, long nchunks, int C, int act, T* dy,
-                                    float* dw, float* db) {
+                                    float* dw, float* db, const T* se_gate, const T* se_dpool, int se_hw, float se_scale) {
   constexpr int CH = TT<T>::CH;
   const int CC = C / CH;
   const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
@@ -290,6 +302,14 @@ __global__ void bn_bwd_apply_kernel(const T* dz, const T* y, const float* ss, co
     float d[CH], v[CH];
     unpack<T>(ld16(dz + i * CH), d);
     unpack<T>(ld16(y + i * CH), v);
+    if (se_gate) {  // squeeze-and-excite backward folded in (see BnBwdRedF)
+      const long b = (i / CC) / se_hw;
+      float gt[CH], dp[CH];
+      unpack<T>(ld16(se_gate + b * C + c0), gt);
+      unpack<T>(ld16(se_dpool + b * C + c0), dp);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) d[j] = d[j] * gt[j] + dp[j] * se_scale;
+    }
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       float g = d[j] * act_bwd(v[j] * sc[j] + sh[j], act);
@@ -300,13 +320,14 @@ __global__ void bn_bwd_apply_kernel(const T* dz, const T* y, const float* ss, co
 }
 void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* ss, const float* mr, const float* w,
                          const float* red, long M, int C, int act, void* dy, float* dw, float* db, hipStream_t s,
-                         int red_rep) {
+                         int red_rep, const void* se_gate, const void* se_dpool, int se_hw) {
   DISPATCH_T(dt, {
     long n = M * C / TT<T>::CH;
     int g = grid_chan(n, C / TT<T>::CH);
     while ((long)g * 256 < C) g *= 2;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g), dim3(256), 0, s, (const T*)dz, (const T*)y, ss, mr, w, red,
-                       red_rep < 1 ? 1 : red_rep, 1.0f / (float)M, n, C, act, (T*)dy, dw, db);
+                       red_rep < 1 ? 1 : red_rep, 1.0f / (float)M, n, C, act, (T*)dy, dw, db, (const T*)se_gate, (const T*)se_dpool,
+                       se_hw > 0 ? se_hw : 1, se_hw > 0 ? 1.0f / (float)se_hw : 0.f);
   });
 }
 
