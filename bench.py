@@ -183,7 +183,7 @@ def main():
                    scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                    config=dict(workload="EfficientSATRN train step (fwd+CE+bwd+clip+AdamW), bs32/GPU, 1x128x384, teacher-forced T=128, dropout 0.1 (BASELINE configs[1])",
                                global_batch=world * B, seq_len=T, parallelism=f"dp{world}", hipgraph=graph, streams=1 if graph else 2,
-                               exchange=("none" if world == 1 else ("one flat all-reduce" if graph else "4 backward segments, asynchronous per-range RCCL all-reduce"))),
+                               exchange=("none" if world == 1 else ("one flat all-reduce" if graph else "backward cut after the last backbone stage: 74 % of the gradient all-reduced (async RCCL) beside the rest of the backward"))),
                    roofline=roof, final_loss=round(loss, 4), grad_norm=round(gnorm, 4),
                    kernel_breakdown=[dict(kernel=p["kernel"], launches=p["launches"], ms=round(p["ms"], 3)) for p in prof[:12]])
         if world == 1 and not args.no_decode:

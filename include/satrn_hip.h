@@ -224,7 +224,9 @@ int satrn_model_loss_backward(satrn_model* m, const int64_t* expected, int B, in
  * phase = 16 + k (k = 0..3, in order, eager only): the same work as bit 0 cut into four backward segments -- k = 0 zeroes
  * the gradients, runs forward + CE and the decoder's backward; 1 = encoder transformer + positional encoding; 2 = last
  * backbone stage; 3 = the rest.  When call k returns, the flat-gradient range satrn_model_segment_range(k) is final on
- * `stream`, so its all-reduce can run (on another stream) while the following segments execute. */
+ * `stream`, so its all-reduce can run (on another stream) while the following segments execute.  16 + k + 4*k_to runs
+ * segments k..k_to in one call (one side-stream join at the end); the data-parallel driver uses 16 + 0 + 4*2 (segments
+ * 0-2: 74 % of the parameters) followed by 16 + 3. */
 int satrn_model_train_step(satrn_model* m, const float* images, const int64_t* expected, int B, int L,
                            const float* hyper9, int use_graph, int phase, void* stream);
 int satrn_model_segment_range(satrn_model* m, int seg, int64_t* lo, int64_t* hi); /* [lo, hi) in flat fp32 elements */

@@ -1237,10 +1237,12 @@ static void segment_ranges(Model* m) {
   m->seg_lo[3] = 0;        m->seg_hi[3] = off_late;
 }
 
-int model_backward_segment(Model* m, const int64_t* expected, int B, int L, int seg, hipStream_t s) {
+// runs segments seg..seg_to in one go (one side-stream join, at the end)
+int model_backward_segment(Model* m, const int64_t* expected, int B, int L, int seg, hipStream_t s, int seg_to) {
   Exec& e = *m->ex;
   if (!e.logits) { m->err = "no forward"; return -1; }
-  if (seg != m->seg_next || seg < 0 || seg > 3) { m->err = "backward segments must run in order 0..3 after a recorded forward"; return -1; }
+  if (seg_to < seg) seg_to = seg;
+  if (seg != m->seg_next || seg < 0 || seg_to > 3) { m->err = "backward segments must run in order 0..3 after a recorded forward"; return -1; }
   e.s = s;
   if (seg == 0) {
     Tensor* lg = e.logits;
@@ -1251,11 +1253,11 @@ int model_backward_segment(Model* m, const int64_t* expected, int B, int L, int 
     launch_ce_full(e.dt, (const float*)lg->p, expected, L, 1, B, L - 1, V, Vp, m->cfg.pad_id, scal(m) + SC_LOSS, lse, lg->g, nullptr, s);
   }
   const size_t hi = seg == 0 ? e.tape.size() : m->seg_mark[3 - seg];
-  const size_t lo = seg == 3 ? 0 : m->seg_mark[2 - seg];
+  const size_t lo = seg_to == 3 ? 0 : m->seg_mark[2 - seg_to];
   for (size_t i = hi; i > lo; --i) e.tape[i - 1]();
   e.join();
-  m->seg_next = seg + 1;
-  if (seg == 3) e.tape.clear();
+  m->seg_next = seg_to + 1;
+  if (seg_to == 3) e.tape.clear();
   if (e.oom) { m->err = "workspace exhausted in backward"; return -2; }
   return 0;
 }
@@ -1300,7 +1302,9 @@ int model_loss_backward(Model* m, const int64_t* expected, int B, int L, hipStre
 
 int model_train_step(Model* m, const float* img, const int64_t* expected, int B, int L, const float* hyper9,
                      int use_graph, int phase, hipStream_t s) {
-  const int seg = (phase & 16) ? (phase & 3) : -1;  // 16 + k: backward segment k (k == 0 also zeroes grads and runs forward + CE)
+  // 16 + k (+ 4 * k_to): backward segments k..k_to (k == 0 also zeroes the gradients and runs forward + CE)
+  const int seg = (phase & 16) ? (phase & 3) : -1;
+  const int seg_to = (phase >> 2) & 3;
   if (seg >= 0) {
     if (!m->bound || !m->ws_set || !m->grads) { m->err = "bind parameters/grads and set a workspace first"; return -1; }
     if (seg == 0) {
@@ -1309,7 +1313,7 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
       int rc = model_forward(m, img, expected, B, L, true, true, nullptr, s);
       if (rc) return rc;
     }
-    return model_backward_segment(m, expected, B, L, seg, s);
+    return model_backward_segment(m, expected, B, L, seg, s, seg_to);
   }
   phase &= 3;
   if (!phase) return 0;

@@ -402,7 +402,7 @@ class _SATRNBase(nn.Module):
             self._ensure_packed()
         if self._stage is None or self._stage[0].shape != input.shape or self._stage[1].shape != expected.shape:
             self._stage = (torch.empty_like(input), torch.empty_like(expected.contiguous()))
-        if int(phase) in (1, 3, 16):  # calls that start a step stage its inputs; later segments / phase 2 reuse them
+        if int(phase) in (1, 3) or (int(phase) & 16 and int(phase) & 3 == 0):  # calls that start a step stage its inputs
             self._stage[0].copy_(input, non_blocking=True)
             self._stage[1].copy_(expected, non_blocking=True)
         hy = (ctypes.c_float * 9)(lr, betas[0], betas[1], eps, weight_decay, max_grad_norm, 0.0, 0.0, grad_scale)

@@ -72,10 +72,12 @@ class _FakeModel:
         if phase == 1:
             self.g[:] = float(self.rank + 1)
         elif phase >= 16:
-            lo, hi = self.ranges[phase - 16]
-            if phase == 16:
+            k, k_to = phase & 3, max((phase >> 2) & 3, phase & 3)
+            if k == 0:
                 self.g.zero_()
-            self.g[lo:hi] = float(self.rank + 1)
+            for seg in range(k, k_to + 1):
+                lo, hi = self.ranges[seg]
+                self.g[lo:hi] = float(self.rank + 1)
 
 
 def _overlap_worker(rank, world, port, q):
@@ -88,7 +90,7 @@ def _overlap_worker(rank, world, port, q):
     dp.dp_train_step(a, None, None, 1e-3, overlap=True)
     dp.dp_train_step(b, None, None, 1e-3, overlap=False)
     ok = bool((a.g == 3.0).all()) and bool((b.g == 3.0).all())  # 1 + 2 summed over the two ranks, every element once
-    ok = ok and [c[0] for c in a.calls] == [16, 17, 18, 19, 2] and [c[0] for c in b.calls] == [1, 2]
+    ok = ok and [c[0] for c in a.calls] == [24, 19, 2] and [c[0] for c in b.calls] == [1, 2]
     ok = ok and a.calls[-1][1] == 0.5 and b.calls[-1][1] == 0.5
     q.put((rank, ok))
     dist.destroy_process_group()

@@ -323,6 +323,12 @@ def test_segmented_backward_equals_whole_backward(golden_dir, name):
     d = (model.flat_grad() - whole).abs().max().item()
     print(f"[segments:{name}] max diff {d:.3e} (tolerance {tol:.3e}, max |g| {gmax:.3e})")
     assert d <= tol
+    # segments 0-2 in one call, then 3 (what dp.dp_train_step issues)
+    model.train_step(imgd, expd, 0.0, phase=16 + 0 + 4 * 2)
+    model.train_step(imgd, expd, 0.0, phase=16 + 3)
+    torch.cuda.synchronize()
+    d = (model.flat_grad() - whole).abs().max().item()
+    assert d <= tol, d
     import satrn_amd
     with pytest.raises(satrn_amd.SatrnError):
         model.train_step(imgd, expd, 0.0, phase=18)  # out of order

@@ -15,8 +15,8 @@ def whole():
     model.train_step(img, exp, 5e-4)
 
 def segmented():
-    for k in range(4):
-        model.train_step(img, exp, 5e-4, phase=16 + k)
+    model.train_step(img, exp, 5e-4, phase=16 + 0 + 4 * 2)
+    model.train_step(img, exp, 5e-4, phase=16 + 3)
     model.train_step(img, exp, 5e-4, phase=2)
 
 for name, fn in (("whole", whole), ("segmented", segmented), ("whole", whole), ("segmented", segmented)):
