@@ -248,7 +248,6 @@ Model* model_create(const SatrnConfig& cfg) {
           eb.se_rb = b.vec(q + "se.conv_reduce.bias", eb.se, 3, eb.mid);
           eb.se_e = b.dense(q + "se.conv_expand.weight", eb.mid, eb.se, 1, true);
           eb.se_eb = b.vec(q + "se.conv_expand.bias", eb.mid, 3, eb.se);
-          eb.se_r.kind = WK_STEM; eb.se_e.kind = WK_STEM;  // consumed as fp32 masters by the fused SE kernels: no packed copies
           eb.c1 = b.dense(q + "conv_pwl.weight", eb.cout, eb.mid, 1, true);
           eb.bn3 = b.bn(q + "bn3", eb.cout, 1e-3f);
         }
@@ -916,7 +915,7 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb) {
   float* s1 = (float*)e.alloc((size_t)B * S * 4);
   Tensor* gate = e.newt(B, C);
   e.nbytes = (double)x->rows * C * e.esz();
-  LCH(e, launch_se_fwd(e.dt, x->p, eb->se_r.p, eb->se_rb.p, eb->se_e.p, eb->se_eb.p, pooled, u1, s1, gate->p, B, HW, C, S, e.s));
+  LCH(e, launch_se_fwd(e.dt, x->p, eb->se_r.fwd, eb->se_rb.p, eb->se_e.fwd, eb->se_eb.p, pooled, u1, s1, gate->p, B, HW, C, S, e.s));
   Tensor* y = e.newt(x->rows, C, B, x->H, x->W);
   LCH(e, launch_se_scale(e.dt, x->p, gate->p, y->p, B, HW, C, e.s));
   if (e.rec)
@@ -929,7 +928,7 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb) {
       LCH(e, launch_se_bwd_gate(e.dt, y->g, x->p, dgate, B, HW, C, e.s));
       {
         // data path on the main chain; the two weight-gradient products only feed the optimizer -> side stream
-        const int dt = e.dt; void* gp = gate->p; float* w1 = eb->se_r.p; float* w2 = eb->se_e.p;
+        const int dt = e.dt; void* gp = gate->p; const void* w1 = eb->se_r.fwd; const void* w2 = eb->se_e.fwd;
         float* g1 = eb->se_r.g; float* gb1 = eb->se_rb.g; float* g2 = eb->se_e.g; float* gb2 = eb->se_eb.g;
         if (e.prof || e.dry) {
           LCH(e, launch_se_bwd(dt, dgate, gp, u1, s1, pooled, w1, w2, dz2, du1, dpooled, g1, gb1, g2, gb2, B, C, S, e.s, 3));

@@ -145,10 +145,11 @@ void launch_adamw(float* p, const float* g, float* m, float* v, long n, const fl
                   hipStream_t s);
 
 // fused squeeze-and-excite (kernels_se.hip): W1 [S][C], W2 [C][S] are the fp32 masters
-void launch_se_fwd(int dt, const void* x, const float* W1, const float* b1, const float* W2, const float* b2, float* pooled,
+// W1 [S][C], W2 [C][S]: the packed compute-dtype copies (dt)
+void launch_se_fwd(int dt, const void* x, const void* W1, const float* b1, const void* W2, const float* b2, float* pooled,
                    float* u1, float* s1, void* gate, int B, int HW, int C, int S, hipStream_t s);
 void launch_se_bwd(int dt, const void* dgate, const void* gate, const float* u1, const float* s1, const float* pooled,
-                   const float* W1, const float* W2, float* dz2, float* du1, void* dpooled, float* dW1, float* db1, float* dW2,
+                   const void* W1, const void* W2, float* dz2, float* du1, void* dpooled, float* dW1, float* db1, float* dW2,
                    float* db2, int B, int C, int S, hipStream_t s, int parts = 3 /*1: data path, 2: weight gradients*/);
 
 // persistent greedy decoder (kernels_decode.hip): weights are the packed [N][K] compute copies, biases / LN fp32

@@ -8,7 +8,7 @@
 
 // ---- forward: pooled[b][:] (fp32), u1[b][:] (pre-activation), s1[b][:], gate[b][:] (T)
 template <typename T>
-__global__ __launch_bounds__(1024) void se_fwd_kernel(const T* x, const float* W1, const float* b1, const float* W2,
+__global__ __launch_bounds__(1024) void se_fwd_kernel(const T* x, const T* W1, const float* b1, const T* W2,
                                                       const float* b2, float* pooled, float* u1, float* s1, T* gate,
                                                       int HW, int C, int S) {
   constexpr int CH = TT<T>::CH;
@@ -44,33 +44,70 @@ __global__ __launch_bounds__(1024) void se_fwd_kernel(const T* x, const float* W
     pooled[(long)b * C + c] = m;
   }
   __syncthreads();
-  // ---- hidden: one wave per hidden unit (rows of W1 are contiguous in C)
-  for (int j = wave; j < S; j += 16) {
-    const float* w = W1 + (long)j * C;
-    float acc = 0.f;
-#pragma unroll 4
-    for (int c = lane * 4; c < C; c += 256) {
-      float4 wv = *reinterpret_cast<const float4*>(w + c);
-      acc += wv.x * p[c] + wv.y * p[c + 1] + wv.z * p[c + 2] + wv.w * p[c + 3];
+  // ---- hidden: one wave per hidden unit (rows of W1 are contiguous in C).  The weights are the packed compute-dtype
+  // copies: this per-image block is bound by how fast one CU streams the two matrices, so bf16 halves its time
+  // a wave owns up to four hidden units (j0, j0+16, j0+32, j0+48) and requests all their row chunks before using any:
+  // after a kernel boundary every first touch is a far (Infinity Cache / HBM) round trip of ~3 us, so the phase costs
+  // one such trip per DEPENDENT batch of loads -- one batch here instead of four
+  for (int j0 = wave; j0 < S; j0 += 64) {
+    float accu[4] = {0.f, 0.f, 0.f, 0.f};
+    float bj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bj[u] = j0 + 16 * u < S ? b1[j0 + 16 * u] : 0.f;
+    for (int c0 = lane * CH; c0 < C; c0 += 3 * 64 * CH) {
+      uint4 raw[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int c = c0 + q * 64 * CH, j = j0 + 16 * u;
+          raw[u][q] = (c < C && j < S) ? ld16(W1 + (long)j * C + c) : zero16();
+        }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int c = c0 + q * 64 * CH;
+        if (c < C) {
+          float pv[CH];
+#pragma unroll
+          for (int e = 0; e < CH; ++e) pv[e] = p[c + e];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            float wv[CH];
+            unpack<T>(raw[u][q], wv);
+#pragma unroll
+            for (int e = 0; e < CH; ++e) accu[u] += wv[e] * pv[e];
+          }
+        }
+      }
     }
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      float u = acc + b1[j];
-      float sv = u * sigmoidf_(u);
-      h[j] = sv;
-      u1[(long)b * S + j] = u;
-      s1[(long)b * S + j] = sv;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + 16 * u;
+      const float a = wave_sum(accu[u]);
+      if (lane == 0 && j < S) {
+        const float uu = a + bj[u];
+        const float sv = uu * sigmoidf_(uu);
+        h[j] = sv;
+        u1[(long)b * S + j] = uu;
+        s1[(long)b * S + j] = sv;
+      }
     }
   }
   __syncthreads();
   // ---- gate: thread per channel (rows of W2 are contiguous in S)
   for (int c = tid; c < C; c += 1024) {
-    const float* w = W2 + (long)c * S;
+    const T* w = W2 + (long)c * S;
     float acc = b2[c];
+    if ((S % CH) == 0) {
 #pragma unroll 8
-    for (int j = 0; j < S; j += 4) {
-      float4 wv = *reinterpret_cast<const float4*>(w + j);
-      acc += wv.x * h[j] + wv.y * h[j + 1] + wv.z * h[j + 2] + wv.w * h[j + 3];
+      for (int j = 0; j < S; j += CH) {
+        float wv[CH];
+        unpack<T>(ld16(w + j), wv);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc += wv[e] * h[j + e];
+      }
+    } else {
+      for (int j = 0; j < S; ++j) acc += to_f(w[j]) * h[j];
     }
     gate[(long)b * C + c] = from_f<T>(sigmoidf_(acc));
   }
@@ -78,9 +115,9 @@ __global__ __launch_bounds__(1024) void se_fwd_kernel(const T* x, const float* W
 
 // ---- backward A (per image): dz2 = dgate*gate*(1-gate); ds1 = W2^T dz2; du1 = ds1*silu'(u1); dpooled = W1^T du1
 template <typename T>
-__global__ __launch_bounds__(1024) void se_bwd_a_kernel(const T* dgate, const T* gate, const float* u1, const float* W1,
-                                                        const float* W2, float* dz2, float* du1, T* dpooled, int C, int S) {
-  extern __shared__ float sm[];  // dz[C] | part[16][S] | du[S]
+__global__ __launch_bounds__(1024) void se_bwd_a_kernel(const T* dgate, const T* gate, const float* u1, const T* W1,
+                                                        const T* W2, float* dz2, float* du1, T* dpooled, int C, int S) {
+  extern __shared__ float sm[];  // dz[C] | part[16][S] | du[S] | part2[JG][C] (JG*C <= 1024*CH)
   float* dz = sm;
   float* part = sm + C;
   float* du = part + 16 * S;
@@ -92,12 +129,51 @@ __global__ __launch_bounds__(1024) void se_bwd_a_kernel(const T* dgate, const T*
     dz2[(long)b * C + c] = v;
   }
   __syncthreads();
-  // ds1[j] = sum_c W2[c][j] * dz[c]: lane = j (S <= 64), the 16 waves split the channels, 8 loads in flight each
-  {
+  // Both matrix-vector products below read their whole matrix with 16-byte loads, every thread issuing ALL its loads
+  // (<= 16) before using any: after a kernel boundary a first touch is a far round trip, so a phase costs one trip per
+  // dependent batch -- the scalar-load loops this replaces made 12 and 8 of them.
+  constexpr int CH = TT<T>::CH;
+  float* part2 = du + S;  // [JG][C] partial sums of the second product
+  const int SC = S / CH;  // 16-byte chunks per W2 row
+  // ds1[j] = sum_c W2[c][j] * dz[c]
+  int SCP = 1;  // chunks per row rounded up to a power of two (lanes jq >= SC idle): S = 40 -> 5 of 8
+  while (SCP < SC) SCP <<= 1;
+  if ((S % CH) == 0 && SCP <= 8 && C * SCP <= 16 * 1024) {
+    const int jq = tid % SCP, cstep = 1024 / SCP;
+    uint4 raw[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = tid / SCP + q * cstep;
+      raw[q] = (c < C && jq < SC) ? ld16(W2 + (long)c * S + jq * CH) : zero16();
+    }
+    float acc[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = tid / SCP + q * cstep;
+      if (c < C) {
+        float wv[CH];
+        unpack<T>(raw[q], wv);
+        const float d = dz[c];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc[e] += wv[e] * d;
+      }
+    }
+    // lanes of a wave with the same jq: xor over the lane bits above log2(SC)
+    for (int o = SCP; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+    }
+    if (lane < SC) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) part[wave * S + lane * CH + e] = acc[e];
+    }
+  } else {
     float acc = 0.f;
     if (lane < S) {
 #pragma unroll 8
-      for (int c = wave; c < C; c += 16) acc += W2[(long)c * S + lane] * dz[c];
+      for (int c = wave; c < C; c += 16) acc += to_f(W2[(long)c * S + lane]) * dz[c];
       part[wave * S + lane] = acc;
     }
   }
@@ -111,11 +187,48 @@ __global__ __launch_bounds__(1024) void se_bwd_a_kernel(const T* dgate, const T*
     du1[(long)b * S + tid] = v;
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 1024) {
-    float acc = 0.f;
+  // dpooled[c] = sum_j W1[j][c] * du[j]: thread = (16-byte chunk of c, group of hidden units)
+  const int CQ = C / CH;
+  const int JG = CQ <= 1024 ? 1024 / CQ : 0;
+  if (JG >= 1 && (S + JG - 1) / JG <= 16) {
+    const int cq = tid % CQ, jg = tid / CQ;
+    if (jg < JG) {
+      uint4 raw[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int j = jg + q * JG;
+        raw[q] = j < S ? ld16(W1 + (long)j * C + cq * CH) : zero16();
+      }
+      float acc[CH];
+#pragma unroll
+      for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int j = jg + q * JG;
+        if (j < S) {
+          float wv[CH];
+          unpack<T>(raw[q], wv);
+          const float d = du[j];
+#pragma unroll
+          for (int e = 0; e < CH; ++e) acc[e] += wv[e] * d;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < CH; ++e) part2[jg * C + cq * CH + e] = acc[e];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 1024) {
+      float a = 0.f;
+      for (int g = 0; g < JG; ++g) a += part2[g * C + c];
+      dpooled[(long)b * C + c] = from_f<T>(a);
+    }
+  } else {
+    for (int c = tid; c < C; c += 1024) {
+      float acc = 0.f;
 #pragma unroll 8
-    for (int j = 0; j < S; ++j) acc += W1[(long)j * C + c] * du[j];
-    dpooled[(long)b * C + c] = from_f<T>(acc);
+      for (int j = 0; j < S; ++j) acc += to_f(W1[(long)j * C + c]) * du[j];
+      dpooled[(long)b * C + c] = from_f<T>(acc);
+    }
   }
 }
 
@@ -157,23 +270,23 @@ __global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* dz2, const f
   }
 }
 
-void launch_se_fwd(int dt, const void* x, const float* W1, const float* b1, const float* W2, const float* b2, float* pooled,
+void launch_se_fwd(int dt, const void* x, const void* W1, const float* b1, const void* W2, const float* b2, float* pooled,
                    float* u1, float* s1, void* gate, int B, int HW, int C, int S, hipStream_t s) {
   size_t sh = (size_t)(5 * C + S) * sizeof(float);
   if (dt == DT_BF16)
-    hipLaunchKernelGGL((se_fwd_kernel<bf16_t>), dim3(B), dim3(1024), sh, s, (const bf16_t*)x, W1, b1, W2, b2, pooled, u1, s1, (bf16_t*)gate, HW, C, S);
+    hipLaunchKernelGGL((se_fwd_kernel<bf16_t>), dim3(B), dim3(1024), sh, s, (const bf16_t*)x, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, pooled, u1, s1, (bf16_t*)gate, HW, C, S);
   else
-    hipLaunchKernelGGL((se_fwd_kernel<float>), dim3(B), dim3(1024), sh, s, (const float*)x, W1, b1, W2, b2, pooled, u1, s1, (float*)gate, HW, C, S);
+    hipLaunchKernelGGL((se_fwd_kernel<float>), dim3(B), dim3(1024), sh, s, (const float*)x, (const float*)W1, b1, (const float*)W2, b2, pooled, u1, s1, (float*)gate, HW, C, S);
 }
 void launch_se_bwd(int dt, const void* dgate, const void* gate, const float* u1, const float* s1, const float* pooled,
-                   const float* W1, const float* W2, float* dz2, float* du1, void* dpooled, float* dW1, float* db1, float* dW2,
+                   const void* W1, const void* W2, float* dz2, float* du1, void* dpooled, float* dW1, float* db1, float* dW2,
                    float* db2, int B, int C, int S, hipStream_t s, int parts) {
-  size_t sh = (size_t)(C + 17 * S) * sizeof(float);
+  size_t sh = (size_t)(C + 17 * S + 1024 * (dt == DT_BF16 ? 8 : 4)) * sizeof(float);
   if (!(parts & 1)) {
   } else if (dt == DT_BF16)
-    hipLaunchKernelGGL((se_bwd_a_kernel<bf16_t>), dim3(B), dim3(1024), sh, s, (const bf16_t*)dgate, (const bf16_t*)gate, u1, W1, W2, dz2, du1, (bf16_t*)dpooled, C, S);
+    hipLaunchKernelGGL((se_bwd_a_kernel<bf16_t>), dim3(B), dim3(1024), sh, s, (const bf16_t*)dgate, (const bf16_t*)gate, u1, (const bf16_t*)W1, (const bf16_t*)W2, dz2, du1, (bf16_t*)dpooled, C, S);
   else
-    hipLaunchKernelGGL((se_bwd_a_kernel<float>), dim3(B), dim3(1024), sh, s, (const float*)dgate, (const float*)gate, u1, W1, W2, dz2, du1, (float*)dpooled, C, S);
+    hipLaunchKernelGGL((se_bwd_a_kernel<float>), dim3(B), dim3(1024), sh, s, (const float*)dgate, (const float*)gate, u1, (const float*)W1, (const float*)W2, dz2, du1, (float*)dpooled, C, S);
   size_t sh2 = (size_t)2 * B * 8 * sizeof(float);
   if (parts & 2)
     hipLaunchKernelGGL(se_bwd_b_kernel, dim3((C + 255) / 256, (S + 7) / 8), dim3(256), sh2, s, dz2, du1, s1, pooled, dW1, db1, dW2,
