@@ -918,8 +918,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
   for (int k = 0; k < NCH; ++k)
 #pragma unroll
     for (int j = 0; j < CH; ++j) gw[k][j] = gb[k][j] = 0.f;
-  for (long r = (long)blockIdx.x * 4 + wv; r < R; r += (long)gridDim.x * 4) {
-    const float mean = mr[r], rstd = mr[R + r];
+  // a wave walks its rows with the NEXT row's operands (inputs, statistics and, when accumulating, the old gradient
+  // values) already requested: every row would otherwise cost two dependent far round trips (inputs, then the
+  // read-modify-write of da / db after the reduction)
+  struct RowRaw { uint4 xa[NCH], xb[NCH], dd[NCH], oa[NCH], ob[NCH]; float mean, rstd; };
+  auto load_row = [&](long r, RowRaw& q) {
+    q.mean = mr[r]; q.rstd = mr[R + r];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = lane + k * 64;
+      if (c < CC) {
+        q.xa[k] = ld16(a + r * C + c * CH);
+        if (b) q.xb[k] = ld16(b + r * C + c * CH);
+        q.dd[k] = ld16(dout + r * C + c * CH);
+        if (beta_a) q.oa[k] = ld16(da + r * C + c * CH);
+        if (db && beta_b) q.ob[k] = ld16(db + r * C + c * CH);
+      }
+    }
+  };
+  const long rstep = (long)gridDim.x * 4;
+  long r = (long)blockIdx.x * 4 + wv;
+  RowRaw cur, nxt;
+  if (r < R) load_row(r, cur);
+  for (; r < R; r += rstep) {
+    if (r + rstep < R) load_row(r + rstep, nxt);
+    const float mean = cur.mean, rstd = cur.rstd;
     float xh[NCH][CH], g[NCH][CH];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -927,14 +950,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
       int c = lane + k * 64;
       if (c < CC) {
         float d[CH];
-        unpack<T>(ld16(a + r * C + c * CH), xh[k]);
+        unpack<T>(cur.xa[k], xh[k]);
         if (b) {
           float t[CH];
-          unpack<T>(ld16(b + r * C + c * CH), t);
+          unpack<T>(cur.xb[k], t);
 #pragma unroll
           for (int j = 0; j < CH; ++j) xh[k][j] += t[j];
         }
-        unpack<T>(ld16(dout + r * C + c * CH), d);
+        unpack<T>(cur.dd[k], d);
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
           xh[k][j] = (xh[k][j] - mean) * rstd;
@@ -956,7 +979,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
 #pragma unroll
         for (int j = 0; j < CH; ++j) o[j] = rstd * (g[k][j] - s1 - xh[k][j] * s2);
         if (beta_a) {
-          unpack<T>(ld16(da + r * C + c * CH), t);
+          unpack<T>(cur.oa[k], t);
 #pragma unroll
           for (int j = 0; j < CH; ++j) t[j] += o[j];
           st16(da + r * C + c * CH, pack<T>(t));
@@ -965,7 +988,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
         }
         if (db) {
           if (beta_b) {
-            unpack<T>(ld16(db + r * C + c * CH), t);
+            unpack<T>(cur.ob[k], t);
 #pragma unroll
             for (int j = 0; j < CH; ++j) t[j] += o[j];
             st16(db + r * C + c * CH, pack<T>(t));
@@ -975,6 +998,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
         }
       }
     }
+    cur = nxt;
   }
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
