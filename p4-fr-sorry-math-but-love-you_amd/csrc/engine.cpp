@@ -560,6 +560,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       memset(&q, 0, sizeof(q));
       q.dY = dY; q.A = x->p; q.dW = w->g; q.M = (int)M; q.N = N; q.K = w->K; q.ldy = ldy; q.lda = x->C;
       q.nbatch = 1; q.nb_inner = 1;
+      q.full_grid = (e.serial || !e.s2 || e.prof) ? 1 : 0;
       float* tmp = nullptr;
       if (hasgeo) {
         q.conv = 1; q.H = g.H; q.W = g.W; q.Ci = g.Ci; q.OH = g.OH; q.OW = g.OW; q.KW = g.KW; q.stride = g.stride; q.pt = g.pt; q.pl = g.pl;
@@ -1357,7 +1358,14 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
     // the caller must keep img / expected at the same addresses across replays (bench + trainer use staging buffers)
     hipGraph_t g = nullptr;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) { m->err = "stream capture failed"; return -3; }
+    // captured as ONE chain: the replay does not overlap a forked branch well on ROCm 7.2, and without a concurrent chain
+    // the weight-gradient kernels may use chip-filling grids
+    hipStream_t keep_s2 = m->ex->s2;
+    m->ex->s2 = nullptr;
+    m->ex->serial = true;
     int rc = body();
+    m->ex->serial = false;
+    m->ex->s2 = keep_s2;
     hipError_t er = hipStreamEndCapture(s, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     if (er != hipSuccess || !g) { m->err = "graph capture failed"; return -3; }

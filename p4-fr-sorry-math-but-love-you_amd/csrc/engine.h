@@ -134,6 +134,7 @@ struct Exec {
   hipStream_t s = nullptr;
   int dt = 0;
   bool train = false, rec = false, dry = false;
+  bool serial = false;  // no concurrent side stream (hipGraph capture / profiling): side kernels may fill the chip
   float drop = 0.f;
   char* base = nullptr; size_t cap = 0, off = 0, peak = 0;  // bump arena
   char* zbase = nullptr; size_t zcap = 0, zoff = 0;          // zero pool

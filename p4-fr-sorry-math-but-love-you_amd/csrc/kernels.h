@@ -32,6 +32,7 @@ struct WgradP {
   int conv_packed_out;  // conv: write dW as [N][taps][Ci] (contiguous atomics) for launch_conv_grad_unpack
   int out_t;       // 0: fp32 atomicAdd into dW (zeroed by caller); 1: store as T (batched attention use)
   int out_accum;   // out_t == 1: add to the existing values (K/V shared by several attention calls)
+  int full_grid;   // 1: size the grid to fill the chip (no concurrent data-gradient chain to stay out of the way of)
   int nbatch, nb_inner;                    // batched: z -> (z / nb_inner, z % nb_inner)
   long sY_o, sY_i, sA_o, sA_i, sW_o, sW_i;  // element strides per outer/inner batch index
   int ldw;                                 // out_t==1: row stride of dW

@@ -600,7 +600,7 @@ static void launch_wgrad_tile(const WgradP& p, hipStream_t s) {
     // 2 429 img/s, 96 dense / 384 conv 2 535 img/s, 32 dense 2 526, 64 (all) 2 358 (side stream becomes the critical path)
     static const long tgt_d = getenv("SATRN_WGRAD_BLOCKS") ? atol(getenv("SATRN_WGRAD_BLOCKS")) : 96;
     static const long tgt_c = getenv("SATRN_WGRAD_BLOCKS_CONV") ? atol(getenv("SATRN_WGRAD_BLOCKS_CONV")) : 384;
-    const long tgt = p.conv ? tgt_c : tgt_d;
+    const long tgt = p.full_grid ? 768 : (p.conv ? tgt_c : tgt_d);
     splits = (int)((tgt + (long)tiles * nb - 1) / ((long)tiles * nb));
     int maxs = (p.M + 4 * MS - 1) / (4 * MS);
     if (splits > maxs) splits = maxs;
