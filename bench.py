@@ -235,6 +235,19 @@ def main():
             torch.cuda.synchronize()
             d4 = time.perf_counter() - t1
             out["greedy_decode"]["batch_256"] = dict(value=round(256 * 231 / d4, 1), unit="tokens/s", ms_per_batch=round(d4 * 1e3, 2))
+            # best-first beam search of the same 64 images (EfficientSATRN.beam_search, beam 5, max_sequence 230): one launch,
+            # at most 229 decoder-step expansions per image
+            class _Loader:
+                class dataset:
+                    token_to_id = {"<SOS>": 0, "<EOS>": 1, "<PAD>": 2}
+            model.beam_search(dimg, _Loader, beam_width=5, max_sequence=230)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            model.beam_search(dimg, _Loader, beam_width=5, max_sequence=230)
+            torch.cuda.synchronize()
+            db = time.perf_counter() - t1
+            out["greedy_decode"]["beam_search"] = dict(beam_width=5, max_sequence=230, batch=64, ms_per_batch=round(db * 1e3, 2),
+                                                       includes="encoder + up to 229 expansions per image + back-trace + D2H")
             model.train()
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline ...")

@@ -250,6 +250,14 @@ int satrn_sift(const float* x, int ld, int32_t* state, const int32_t* rules, int
 int satrn_sift_reset(int32_t* state, int B, int sos_id, void* stream);
 int satrn_model_greedy_rules(satrn_model* m, const float* images, const float* src, int B, int steps, const int32_t* rules,
                              float* probs, int64_t* ids, void* stream);
+/* EfficientSATRN.beam_search (networks/EfficientSATRN.py:708-867; caller postprocessing/decoding.py:42-48) for topk = 1:
+ * per image a best-first search over a priority queue of (score = -sum(log p)/len, node), stopping at the first popped
+ * <EOS> node or after max_sequence-1 expansions of beam_width children each; the whole search of every image runs in one
+ * launch (priority queue, decoder steps with the ancestors' KV rows, log-softmax, top-k, back-trace; no host sync).
+ * sequences: int64 [B][max_sequence] in device memory -- the utterance INCLUDING <SOS> (as the reference returns it),
+ * padded with pad_id.  beam_width 1..16, max_sequence 1..500. */
+int satrn_model_beam_search(satrn_model* m, const float* images, int B, int beam_width, int max_sequence, int eos_id, int pad_id,
+                            int64_t* sequences, void* stream);
 /* Step-wise decoding session = EfficientSATRN_decoder.step_forward / reset_status (networks/EfficientSATRN.py:932-952),
  * the interface the ensemble driver uses (utils/ensemble_utils.py:84-96: softmax-average the models' step logits, pick the
  * next token outside the model).  begin: src fp32 [B][N][dec_src] (an encoder output, satrn_model_encode) -> cross-

@@ -653,6 +653,66 @@ def decoder_greedy_managed(src, num_steps, sd, cfg, table):
     return torch.stack(outs, 1), torch.stack(ids, 1)
 
 
+def beam_search(src, sd, cfg, beam_width=5, max_sequence=230, trace=None):
+    """EfficientSATRN.beam_search (networks/EfficientSATRN.py:708-867; LiteSATRN's is the same text) for topk=1, the only
+    value the reference's own output packing (:857-865) accepts.  Per image a BEST-FIRST search over a priority queue
+    (not a level-synchronous beam): pop the node with the lowest score = -(sum of log-probs)/len
+    (postprocessing/decoding.py:80; ties: the shorter node first, :83-84), stop at the first popped <EOS> node (:764-767) or
+    after max_sequence-1 expansions (:754, num_steps += beam_width per expansion); an expansion runs one decoder step
+    whose self-attention history is the layer OUTPUTS of the node's ancestors (:785-800), takes log_softmax and pushes
+    the beam_width best continuations (:806-829).  No <EOS> popped -> the best node left in the queue (:834-835).  The
+    utterance is read root-first INCLUDING <SOS> (:842-848), padded with <PAD> / cut to max_sequence (:857-864).
+    Log-probabilities accumulate in float64 as in the reference (.item() -> Python float, :815,821).
+    Returns int64 [b, max_sequence]; trace (optional list) receives per image the popped node tokens in order."""
+    b = src.size(0)
+    Dd = cfg["dec_hidden"]
+    L = cfg["dec_layers"]
+    pe = pos_table_1d(Dd)
+    gw, gb = sd["decoder.generator.weight"], sd["decoder.generator.bias"]
+    rows = []
+    for i in range(b):
+        cur_src = src[i:i + 1]
+        # node = [parent, token, logp (float64), len, per-layer history of OUTPUTS or None]
+        nodes = [[-1, SOS_ID, 0.0, 1, [None] * L]]
+        alive = {0}
+        n_exp, end = 0, -1
+        popped = []
+        while True:
+            if n_exp * beam_width >= (max_sequence - 1) * beam_width:
+                break
+            n = min(alive, key=lambda k: (-(nodes[k][2] / float(nodes[k][3])), nodes[k][3], k))
+            alive.discard(n)
+            parent, tok, logp, ln, hist = nodes[n]
+            popped.append(tok)
+            if tok == EOS_ID and parent != -1:
+                end = n
+                break
+            tgt = text_embedding(torch.tensor([[tok]], dtype=torch.int64), sd) + pe[ln - 1].view(1, 1, Dd)
+            hist = list(hist)
+            for l in range(L):
+                tgt = decoder_layer(tgt, hist[l], cur_src, None, sd, f"decoder.attention_layers.{l}.", cfg["dec_heads"])
+                hist[l] = tgt if hist[l] is None else torch.cat([hist[l], tgt], 1)
+            lp = F.log_softmax(F.linear(tgt, gw, gb), dim=-1)
+            vals, idx = torch.topk(lp, beam_width)
+            for k in range(beam_width):
+                nodes.append([n, int(idx[0, 0, k]), logp + vals[0, 0, k].item(), ln + 1, hist])
+                alive.add(len(nodes) - 1)
+            n_exp += 1
+        if end < 0:
+            end = min(alive, key=lambda k: (-(nodes[k][2] / float(nodes[k][3])), nodes[k][3], k))
+        utt = []
+        k = end
+        while k != -1:
+            utt.append(nodes[k][1])
+            k = nodes[k][0]
+        utt = utt[::-1]
+        utt = (utt + [PAD_ID] * max(0, max_sequence - len(utt)))[:max_sequence]
+        rows.append(utt)
+        if trace is not None:
+            trace.append(popped)
+    return torch.tensor(rows, dtype=torch.int64)
+
+
 def loss_fn_kd(outputs, labels, teacher_outputs, T=10, alpha=0.1):
     """train_modules/train_distillation.py:49-55: outputs / teacher_outputs [B, V, T_len] logits, labels [B, T_len].
     KL(softmax(teacher/T) || softmax(student/T)) summed over everything / B (reduction="batchmean") * alpha*T^2 plus

@@ -6,7 +6,7 @@ from .networks import EfficientSATRN, LiteSATRN, EfficientSATRN_encoder, Efficie
 from . import decoding
 from . import metrics
 from .metrics import StepMetrics
-from .decoding import DeviceDecodingManager, compile_rules
+from .decoding import DeviceDecodingManager, compile_rules, decode
 from .utils import get_network, load_vocab, Flags, START, END, PAD, SPECIAL_TOKENS
 
 __all__ = ["EfficientSATRN", "LiteSATRN", "EfficientSATRN_encoder", "EfficientSATRN_decoder", "SATRNCrossEntropy",

@@ -1199,6 +1199,8 @@ size_t model_workspace_bytes(Model* m, int B, int L) {
     const size_t D = m->cfg.dec_hidden, F = m->cfg.dec_filter;
     dec += ((size_t)m->cfg.dec_layers * (6 * D * D + 2 * D * F) + (size_t)m->cfg.num_classes * D) * es + (64u << 10);
   }
+  // beam search: node tables (1 + 16*499 nodes x 32 B) and ancestor-row lists (499 x 504 x 2 B) per image
+  dec += (size_t)B * ((size_t)(1 + 16 * 499) * 32 + (size_t)499 * 504 * 2) + (64u << 10);
   m->ws = save_ws;
   size_t need = m->persist_bytes + std::max(train_peak, train_peak / 2 + dec) + (16u << 20);
   return need;
@@ -1451,6 +1453,36 @@ static int decode_one_step(Model* m, const int64_t* ids, int ld_ids, int t, int 
   return 0;
 }
 
+// Parameter block of the persistent decode kernels (greedy / beam search): k-panel-major weight copies in the arena,
+// per-layer cross K/V and self-attention caches ([B][steps][2D]).
+static void fill_decode_params(Model* m, DecodeP& dp, const std::vector<Tensor*>& crossKV, const std::vector<Tensor*>& cache, int B,
+                               int steps, int Nsrc, hipStream_t s) {
+  Exec& e = *m->ex;
+  const SatrnConfig& c = m->cfg;
+  const int Dd = c.dec_hidden, V = c.num_classes, L = (int)m->dec.size();
+  const size_t es = e.esz();
+  memset(&dp, 0, sizeof(dp));
+  // the kernel streams every weight once per step and image: k-panel-major copies (one coalesced load per MFMA operand)
+  auto kp = [&](const void* fwd, int N, int K) -> const void* {
+    void* d = e.alloc((size_t)N * K * es);
+    if (!e.dry && d) launch_repack_kpanel(e.dt, fwd, d, N, K, s);
+    return d;
+  };
+  for (int l = 0; l < L; ++l) {
+    DecLayer& dl = m->dec[l];
+    DecLayerW& w = dp.L[l];
+    w.wqkv = kp(dl.self_att.qkv.fwd, 3 * Dd, Dd); w.bqkv = dl.self_att.bqkv.p; w.wo = kp(dl.self_att.out.fwd, Dd, Dd); w.bo = dl.self_att.bout.p;
+    w.wq2 = kp(dl.cross_att.qkv.fwd, Dd, Dd); w.bq2 = dl.cross_att.bqkv.p; w.wo2 = kp(dl.cross_att.out.fwd, Dd, Dd); w.bo2 = dl.cross_att.bout.p;
+    w.w0 = kp(dl.lin0.fwd, c.dec_filter, Dd); w.b0 = dl.b0.p; w.w1 = kp(dl.lin1.fwd, Dd, c.dec_filter); w.b1 = dl.b1.p;
+    w.bkv = dl.self_att.bqkv.p + Dd;
+    w.ln1w = dl.ln1.w.p; w.ln1b = dl.ln1.b.p; w.ln2w = dl.ln2.w.p; w.ln2b = dl.ln2.b.p; w.ln3w = dl.ln3.w.p; w.ln3b = dl.ln3.b.p;
+    w.crossKV = crossKV[l]->p; w.cache = cache[l]->p;
+  }
+  dp.nlayers = L; dp.embed = m->embed.p; dp.pe = (const float*)(m->ws + m->off_pe1d); dp.wgen = kp(m->gen.fwd, V, Dd); dp.bgen = m->gen_b.p;
+  dp.B = B; dp.steps = steps; dp.D = Dd; dp.F = c.dec_filter; dp.V = V;
+  dp.H = c.dec_heads; dp.Nsrc = Nsrc; dp.sos = c.sos_id;
+}
+
 // Greedy decode with the reference's step semantics (networks/EfficientSATRN.py:528-561, :386-396): the
 // self-attention history of a layer is k/v_linear of that layer's previous OUTPUTS plus the current INPUT.
 // KV-cached: slot t first holds k/v(input_t), is attended, then is overwritten with k/v(output_t).
@@ -1481,26 +1513,8 @@ static int greedy_body(Model* m, const float* img, const float* src_in, int B, i
   // ---- fast path: the persistent one-launch decoder (one workgroup per image for the whole decode)
   if (!getenv("SATRN_DECODE_STEPWISE") && L <= 4) {
     DecodeP dp;
-    memset(&dp, 0, sizeof(dp));
-    // the kernel streams every weight once per step and image: k-panel-major copies (one coalesced load per MFMA operand)
-    auto kp = [&](const void* fwd, int N, int K) -> const void* {
-      void* d = e.alloc((size_t)N * K * es);
-      if (!e.dry && d) launch_repack_kpanel(e.dt, fwd, d, N, K, s);
-      return d;
-    };
-    for (int l = 0; l < L; ++l) {
-      DecLayer& dl = m->dec[l];
-      DecLayerW& w = dp.L[l];
-      w.wqkv = kp(dl.self_att.qkv.fwd, 3 * Dd, Dd); w.bqkv = dl.self_att.bqkv.p; w.wo = kp(dl.self_att.out.fwd, Dd, Dd); w.bo = dl.self_att.bout.p;
-      w.wq2 = kp(dl.cross_att.qkv.fwd, Dd, Dd); w.bq2 = dl.cross_att.bqkv.p; w.wo2 = kp(dl.cross_att.out.fwd, Dd, Dd); w.bo2 = dl.cross_att.bout.p;
-      w.w0 = kp(dl.lin0.fwd, c.dec_filter, Dd); w.b0 = dl.b0.p; w.w1 = kp(dl.lin1.fwd, Dd, c.dec_filter); w.b1 = dl.b1.p;
-      w.bkv = dl.self_att.bqkv.p + Dd;
-      w.ln1w = dl.ln1.w.p; w.ln1b = dl.ln1.b.p; w.ln2w = dl.ln2.w.p; w.ln2b = dl.ln2.b.p; w.ln3w = dl.ln3.w.p; w.ln3b = dl.ln3.b.p;
-      w.crossKV = crossKV[l]->p; w.cache = cache[l]->p;
-    }
-    dp.nlayers = L; dp.embed = m->embed.p; dp.pe = (const float*)(m->ws + m->off_pe1d); dp.wgen = kp(m->gen.fwd, V, Dd); dp.bgen = m->gen_b.p;
-    dp.logits = logits_out; dp.ids = ids_out; dp.B = B; dp.steps = steps; dp.D = Dd; dp.F = c.dec_filter; dp.V = V;
-    dp.H = c.dec_heads; dp.Nsrc = Nsrc; dp.sos = c.sos_id; dp.rules = rules;
+    fill_decode_params(m, dp, crossKV, cache, B, steps, Nsrc, s);
+    dp.logits = logits_out; dp.ids = ids_out; dp.rules = rules;
     if (launch_decode_greedy(e.dt, dp, s) == 0) {
       if (e.oom) { m->err = "workspace exhausted"; return -2; }
       return 0;
@@ -1523,6 +1537,43 @@ static int greedy_body(Model* m, const float* img, const float* src_in, int B, i
     e.tens.resize(keep);
   }
   if (e.oom) { m->err = "workspace exhausted"; return -2; }
+  return 0;
+}
+
+// Best-first beam search (EfficientSATRN.beam_search, networks/EfficientSATRN.py:708-867, topk = 1): encoder, cross K/V,
+// then ONE launch that runs every image's whole search (kernels_decode.hip).  sequences: int64 [B][max_sequence] (device).
+int model_beam_search(Model* m, const float* img, int B, int beam_width, int max_sequence, int eos_id, int pad_id,
+                      int64_t* sequences, hipStream_t s) {
+  if (!m->bound || !m->ws_set) { m->err = "bind parameters and set a workspace first"; return -1; }
+  if (beam_width < 1 || beam_width > 16) { m->err = "beam_width must be in 1..16"; return -1; }
+  if (max_sequence < 1 || max_sequence > 500) { m->err = "max_sequence must be in 1..500 (PositionEncoder1D max_len)"; return -1; }
+  Exec& e = *m->ex;
+  const SatrnConfig& c = m->cfg;
+  const int L = (int)m->dec.size();
+  if (L > 4) { m->err = "beam search: at most 4 decoder layers"; return -1; }
+  exec_begin(m, s, false, false, false);
+  Tensor* src = encoder_forward(e, img, B);
+  const int Nsrc = (int)(src->rows / B);
+  const int E = max_sequence - 1;  // expansions per image at most (:754)
+  std::vector<Tensor*> crossKV(L), cache(L);
+  for (int l = 0; l < L; ++l) {
+    crossKV[l] = op_gemm(e, src, &m->dec[l].cross_att.kv, &m->dec[l].cross_att.bkv, ACT_NONE, 0.f, nullptr);
+    cache[l] = e.newt((long)B * std::max(E, 1), 2 * c.dec_hidden, B);
+  }
+  DecodeP dp;
+  fill_decode_params(m, dp, crossKV, cache, B, E, Nsrc, s);
+  BeamP q;
+  memset(&q, 0, sizeof(q));
+  q.bw = beam_width; q.max_seq = max_sequence; q.eos = eos_id; q.pad = pad_id;
+  q.NN = 1 + beam_width * E;
+  q.pstride = (E + 7) & ~7;
+  const size_t nn = (size_t)B * q.NN;
+  q.logp = (double*)e.alloc(nn * 8); q.score = (double*)e.alloc(nn * 8);
+  q.parent = (int32_t*)e.alloc(nn * 4); q.tok = (int32_t*)e.alloc(nn * 4); q.len = (int32_t*)e.alloc(nn * 4); q.slot = (int32_t*)e.alloc(nn * 4);
+  q.path = (uint16_t*)e.alloc((size_t)B * std::max(E, 1) * std::max(q.pstride, 8) * 2);
+  q.out = sequences;
+  if (e.oom) { m->err = "workspace exhausted"; return -2; }
+  if (launch_beam_search(e.dt, dp, q, s) != 0) { m->err = "beam search: unsupported decoder shape for the persistent kernel"; return -1; }
   return 0;
 }
 

@@ -171,6 +171,8 @@ int model_read_loss(Model* m, float* out4, hipStream_t s);
 int model_encode(Model* m, const float* img, int B, float* src_out, hipStream_t s);
 int model_greedy(Model* m, const float* img, const float* src_or_null, int B, int steps, float* logits_out,
                  int64_t* ids_out, int use_graph, hipStream_t s, const int32_t* rules = nullptr);
+int model_beam_search(Model* m, const float* img, int B, int beam_width, int max_sequence, int eos_id, int pad_id,
+                      int64_t* sequences, hipStream_t s);
 int model_backward_segment(Model* m, const int64_t* expected, int B, int L, int seg, hipStream_t s, int seg_to = -1);
 int model_step_begin(Model* m, const float* src, int B, int max_steps, hipStream_t s);
 int model_step(Model* m, const int64_t* target, float* logits_out, hipStream_t s);

@@ -171,6 +171,16 @@ struct DecodeP {
   long long* prof;       // optional [16] cycle counters per phase family (SATRN_DEC_PROF, workgroup 0 only)
 };
 int launch_decode_greedy(int dt, const DecodeP& p, hipStream_t s);  // weights in DecLayerW / wgen: k-panel-major copies
+// best-first beam search (networks/EfficientSATRN.py:708-867): DecodeP.steps = max_sequence - 1 expansions (= cache rows per
+// image); node tables are per image [NN], NN >= 1 + bw*steps; path [steps][pstride] uint16; out int64 [B][max_seq]
+struct BeamP {
+  int bw, max_seq, eos, pad, NN, pstride;
+  int32_t *parent, *tok, *len, *slot;
+  double *logp, *score;
+  uint16_t* path;
+  int64_t* out;
+};
+int launch_beam_search(int dt, const DecodeP& p, const BeamP& q, hipStream_t s);
 void launch_repack_kpanel(int dt, const void* src /*[N][K]*/, void* dst /*[K/32][N][32]*/, int N, int K, hipStream_t s);
 // DecodingManager.sift / reset as launches: x [B][ld] logits (or probabilities), state int32 [B][4], targets int64 [B], probs [B][ldp]
 void launch_sift(const float* x, int ld, int32_t* state, const int32_t* rules, int B, int V, int64_t* targets, float* probs,

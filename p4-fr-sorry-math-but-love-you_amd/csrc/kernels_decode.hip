@@ -117,16 +117,18 @@ DEVI void add_layernorm(float* v, const float* r, const float* w, const float* b
 // costs about one memory round trip: scores -- one thread per (key, head), hd/CH chunk loads in flight; PV -- one thread
 // per (key group, 16-byte chunk of the D output dims), partial sums combined by shuffles inside the wave and through
 // wred [DEC_WAVES][D] across waves.  Needs D/CH to be a power of two <= 64.
-template <typename T>
+// IDX: key j lives in cache row krow[j] (LDS) instead of row j -- the best-first beam search attends over the slots of a
+// node's ancestors.
+template <typename T, bool IDX = false>
 DEVI void attend(const float* q, const T* kv, long ld, int voff, int nk, int H, int hd, float inv_temp, float* sc /*[H][nkP]*/,
-                 int nkP, float* o, float* wred) {
+                 int nkP, float* o, float* wred, const int* krow = nullptr) {
   constexpr int CH = TT<T>::CH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = H * hd;
   const int cph = hd / CH;  // chunks per head
   for (int idx = tid; idx < nk * H; idx += DEC_THREADS) {
     const int j = idx / H, h = idx - j * H;
-    const T* kp = kv + (long)j * ld + h * hd;
+    const T* kp = kv + (long)(IDX ? krow[j] : j) * ld + h * hd;
     const float* qp = q + h * hd;
     float acc = 0.f;
 #pragma unroll 4
@@ -161,7 +163,7 @@ DEVI void attend(const float* q, const T* kv, long ld, int voff, int nk, int H, 
 #pragma unroll 4
   for (int j = kg; j < nk; j += KG) {
     float f[CH];
-    unpack<T>(ld16(vp + (long)j * ld), f);
+    unpack<T>(ld16(vp + (long)(IDX ? krow[j] : j) * ld), f);
     const float pj = sc[h * nkP + j];
 #pragma unroll
     for (int e = 0; e < CH; ++e) acc[e] += pj * f[e];
@@ -184,98 +186,133 @@ DEVI void attend(const float* q, const T* kv, long ld, int voff, int nk, int H, 
   __syncthreads();
 }
 
+// LDS carve-up shared by the greedy and the beam-search kernels
+template <typename T> struct DecSm {
+  float *x, *qkv, *att, *tmp, *ff, *sc, *red, *lg, *wred;
+  T* xT;
+  int nkP;
+  float* end;
+};
+template <typename T> DEVI DecSm<T> dec_carve(float* sm, const DecodeP& p) {
+  DecSm<T> S;
+  const int D = p.D, F = p.F, V = p.V, H = p.H;
+  S.nkP = ((p.steps > p.Nsrc ? p.steps : p.Nsrc) + 3) & ~3;
+  S.x = sm;                 // [D] layer input / running activation
+  S.qkv = S.x + D;          // [3D]
+  S.att = S.qkv + 3 * D;    // [D]
+  S.tmp = S.att + D;        // [D]
+  S.ff = S.tmp + D;         // [F]
+  S.sc = S.ff + F;          // [H][nkP]
+  const int scn = H * S.nkP > 4 * D ? H * S.nkP : 4 * D;  // sc doubles as a 3D-wide reduction scratch in attend
+  S.red = S.sc + scn;       // [2*DEC_WAVES]
+  S.lg = S.red + 2 * DEC_WAVES;       // [V] (padded to a multiple of 4)
+  S.wred = S.lg + ((V + 3) & ~3);     // [DEC_WAVES][D] per-wave partial attention outputs
+  S.xT = reinterpret_cast<T*>(S.wred + DEC_WAVES * D);  // [max(D,F)] current GEMV input in the compute dtype (16-byte aligned)
+  S.end = S.wred + DEC_WAVES * D + (F > D ? F : D);     // (an f32 slot per element: more than T needs)
+  return S;
+}
+static size_t dec_lds_floats(const DecodeP& p) {
+  const int nkP = ((p.steps > p.Nsrc ? p.steps : p.Nsrc) + 3) & ~3;
+  const int scn = p.H * nkP > 4 * p.D ? p.H * nkP : 4 * p.D;
+  return (size_t)(6 * p.D + p.F + scn + 2 * DEC_WAVES + ((p.V + 3) & ~3) + DEC_WAVES * p.D + (p.F > p.D ? p.F : p.D));
+}
+
+#define TICK(k) do { if (p.prof && b == 0 && tid == 0) { long long now_ = (long long)wall_clock64(); p.prof[k] += now_ - tlast; tlast = now_; } } while (0)
+
+// One decoder step for workgroup b: S.x holds embedding + PE on entry; on exit S.lg holds the generator's logits.  The
+// step's k/v go to cache row `slot`; self-attention looks at nk keys (rows 0..nk-1, or rows idx[0..nk-1] when IDX; the
+// last one is `slot`).  Reference: TransformerDecoderLayer.forward step mode (networks/EfficientSATRN.py:374-397).
+template <typename T, bool IDX>
+DEVI void dec_step(const DecodeP& p, const DecSm<T>& S, int b, int slot, int nk, const int* idx, long long& tlast) {
+  const int D = p.D, F = p.F, V = p.V, H = p.H, hd = D / H, tid = threadIdx.x;
+  const float inv_temp = rsqrtf((float)D);
+  float *x = S.x, *qkv = S.qkv, *att = S.att, *tmp = S.tmp, *ff = S.ff, *sc = S.sc, *red = S.red, *wred = S.wred;
+  T* xT = S.xT;
+  const int nkP = S.nkP;
+  for (int l = 0; l < p.nlayers; ++l) {
+    const DecLayerW& w = p.L[l];
+    T* cache = (T*)w.cache + (long)b * p.steps * 2 * D;  // this row's [steps][2D]
+    // q | k | v of the layer INPUT
+    to_t<T>(x, xT, D);
+    TICK(0);
+    if (!(p.dbg & 8)) gemv<T>((const T*)w.wqkv, 3 * D, 0, w.bqkv, xT, qkv, 3 * D, D, ACT_NONE);
+    __syncthreads();
+    TICK(1);
+    for (int i = tid; i < 2 * D; i += DEC_THREADS) cache[(long)slot * 2 * D + i] = from_f<T>(qkv[D + i]);
+    __syncthreads();
+    TICK(0);
+    attend<T, IDX>(qkv, cache, 2 * D, D, (p.dbg & 1) ? 1 : nk, H, hd, inv_temp, sc, nkP, att, wred, idx);
+    TICK(2);
+    to_t<T>(att, xT, D);
+    TICK(0);
+    gemv<T>((const T*)w.wo, D, 0, w.bo, xT, tmp, D, D, ACT_NONE);
+    __syncthreads();
+    TICK(3);
+    add_layernorm(tmp, x, w.ln1w, w.ln1b, D, red);          // tmp = t1
+    TICK(4);
+    to_t<T>(tmp, xT, D);
+    TICK(0);
+    gemv<T>((const T*)w.wq2, D, 0, w.bq2, xT, qkv, D, D, ACT_NONE);
+    __syncthreads();
+    TICK(3);
+    attend<T, false>(qkv, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D, 2 * D, D, (p.dbg & 2) ? 1 : p.Nsrc, H, hd, inv_temp, sc, nkP, att, wred);
+    TICK(5);
+    to_t<T>(att, xT, D);
+    TICK(0);
+    gemv<T>((const T*)w.wo2, D, 0, w.bo2, xT, x, D, D, ACT_NONE);
+    __syncthreads();
+    TICK(3);
+    add_layernorm(x, tmp, w.ln2w, w.ln2b, D, red);           // x = t2
+    TICK(4);
+    to_t<T>(x, xT, D);
+    TICK(0);
+    if (!(p.dbg & 4)) gemv<T>((const T*)w.w0, F, 0, w.b0, xT, ff, F, D, ACT_RELU);
+    __syncthreads();
+    TICK(6);
+    to_t<T>(ff, xT, F);
+    TICK(0);
+    if (!(p.dbg & 4)) gemv<T>((const T*)w.w1, D, 0, w.b1, xT, tmp, D, F, ACT_RELU);
+    __syncthreads();
+    TICK(7);
+    add_layernorm(tmp, x, w.ln3w, w.ln3b, D, red);           // tmp = t3 (layer output)
+    TICK(4);
+    if (tid < D) x[tid] = tmp[tid];
+    __syncthreads();
+    // history entry for later steps: k/v of the layer OUTPUT
+    to_t<T>(x, xT, D);
+    TICK(0);
+    if (!(p.dbg & 16)) gemv<T>((const T*)w.wqkv, 3 * D, D, w.bkv, xT, qkv, 2 * D, D, ACT_NONE);  // rows D..3D of the fused q|k|v weight
+    __syncthreads();
+    TICK(8);
+    for (int i = tid; i < 2 * D; i += DEC_THREADS) cache[(long)slot * 2 * D + i] = from_f<T>(qkv[i]);
+    __syncthreads();
+  }
+  to_t<T>(x, xT, D);
+  TICK(0);
+  gemv<T>((const T*)p.wgen, V, 0, p.bgen, xT, S.lg, V, D, ACT_NONE);
+  __syncthreads();
+  TICK(9);
+}
+
 template <typename T>
 __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
   extern __shared__ float sm[];
-  const int D = p.D, F = p.F, V = p.V, H = p.H, hd = D / H;
-  const int nkP = ((p.steps > p.Nsrc ? p.steps : p.Nsrc) + 3) & ~3;
-  float* x = sm;                 // [D] layer input / running activation
-  float* qkv = x + D;            // [3D]
-  float* att = qkv + 3 * D;      // [D]
-  float* tmp = att + D;          // [D]
-  float* ff = tmp + D;           // [F]
-  float* sc = ff + F;            // [H][nkP]
-  const int scn = H * nkP > 4 * D ? H * nkP : 4 * D;  // sc doubles as a 3D-wide reduction scratch in attend
-  float* red = sc + scn;  // [2*DEC_WAVES]
-  float* lg = red + 2 * DEC_WAVES;  // [V] (padded to a multiple of 4)
-  float* wred = lg + ((V + 3) & ~3);  // [DEC_WAVES][D] per-wave partial attention outputs
-  T* xT = reinterpret_cast<T*>(wred + DEC_WAVES * D);  // [max(D,F)] current GEMV input in the compute dtype (16-byte aligned)
+  const DecSm<T> S = dec_carve<T>(sm, p);
+  const int D = p.D, V = p.V;
+  float* x = S.x;
+  float* lg = S.lg;
   __shared__ int s_tok;
   const int b = blockIdx.x, tid = threadIdx.x;
   SiftState sst{p.sos, 1, 0, 0};  // DecodingManager memory of this sequence (uniform across the workgroup)
-  const float inv_temp = rsqrtf((float)D);
   const float emb_scale = sqrtf((float)D);
   int tok = p.sos;
   long long tlast = p.prof ? (long long)wall_clock64() : 0;
-#define TICK(k) do { if (p.prof && b == 0 && tid == 0) { long long now_ = (long long)wall_clock64(); p.prof[k] += now_ - tlast; tlast = now_; } } while (0)
   for (int t = 0; t < p.steps; ++t) {
     // ---- embedding * sqrt(D) + PE(t)   (networks/EfficientSATRN.py:480-483, :425)
     if (tid < D) x[tid] = p.embed[(long)tok * D + tid] * emb_scale + p.pe[(long)t * D + tid];
     __syncthreads();
-    for (int l = 0; l < p.nlayers; ++l) {
-      const DecLayerW& w = p.L[l];
-      T* cache = (T*)w.cache + (long)b * p.steps * 2 * D;  // this row's [steps][2D]
-      // q | k | v of the layer INPUT
-      to_t<T>(x, xT, D);
-      TICK(0);
-      if (!(p.dbg & 8)) gemv<T>((const T*)w.wqkv, 3 * D, 0, w.bqkv, xT, qkv, 3 * D, D, ACT_NONE);
-      __syncthreads();
-      TICK(1);
-      for (int i = tid; i < 2 * D; i += DEC_THREADS) cache[(long)t * 2 * D + i] = from_f<T>(qkv[D + i]);
-      __syncthreads();
-      TICK(0);
-      attend<T>(qkv, cache, 2 * D, D, (p.dbg & 1) ? 1 : t + 1, H, hd, inv_temp, sc, nkP, att, wred);
-      TICK(2);
-      to_t<T>(att, xT, D);
-      TICK(0);
-      gemv<T>((const T*)w.wo, D, 0, w.bo, xT, tmp, D, D, ACT_NONE);
-      __syncthreads();
-      TICK(3);
-      add_layernorm(tmp, x, w.ln1w, w.ln1b, D, red);          // tmp = t1
-      TICK(4);
-      to_t<T>(tmp, xT, D);
-      TICK(0);
-      gemv<T>((const T*)w.wq2, D, 0, w.bq2, xT, qkv, D, D, ACT_NONE);
-      __syncthreads();
-      TICK(3);
-      attend<T>(qkv, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D, 2 * D, D, (p.dbg & 2) ? 1 : p.Nsrc, H, hd, inv_temp, sc, nkP, att, wred);
-      TICK(5);
-      to_t<T>(att, xT, D);
-      TICK(0);
-      gemv<T>((const T*)w.wo2, D, 0, w.bo2, xT, x, D, D, ACT_NONE);
-      __syncthreads();
-      TICK(3);
-      add_layernorm(x, tmp, w.ln2w, w.ln2b, D, red);           // x = t2
-      TICK(4);
-      to_t<T>(x, xT, D);
-      TICK(0);
-      if (!(p.dbg & 4)) gemv<T>((const T*)w.w0, F, 0, w.b0, xT, ff, F, D, ACT_RELU);
-      __syncthreads();
-      TICK(6);
-      to_t<T>(ff, xT, F);
-      TICK(0);
-      if (!(p.dbg & 4)) gemv<T>((const T*)w.w1, D, 0, w.b1, xT, tmp, D, F, ACT_RELU);
-      __syncthreads();
-      TICK(7);
-      add_layernorm(tmp, x, w.ln3w, w.ln3b, D, red);           // tmp = t3 (layer output)
-      TICK(4);
-      if (tid < D) x[tid] = tmp[tid];
-      __syncthreads();
-      // history entry for later steps: k/v of the layer OUTPUT
-      to_t<T>(x, xT, D);
-      TICK(0);
-      if (!(p.dbg & 16)) gemv<T>((const T*)w.wqkv, 3 * D, D, w.bkv, xT, qkv, 2 * D, D, ACT_NONE);  // rows D..3D of the fused q|k|v weight
-      __syncthreads();
-      TICK(8);
-      for (int i = tid; i < 2 * D; i += DEC_THREADS) cache[(long)t * 2 * D + i] = from_f<T>(qkv[i]);
-      __syncthreads();
-    }
-    // ---- generator + argmax (lowest index wins ties, like torch.argmax)
-    to_t<T>(x, xT, D);
-    TICK(0);
-    gemv<T>((const T*)p.wgen, V, 0, p.bgen, xT, lg, V, D, ACT_NONE);
-    __syncthreads();
-    TICK(9);
+    dec_step<T, false>(p, S, b, t, t + 1, nullptr, tlast);
+    // ---- argmax (lowest index wins ties, like torch.argmax)
     float* out = p.logits + ((long)b * p.steps + t) * V;
     if (p.rules) {
       // DecodingManager.sift (postprocessing.py:189-246): the step's output becomes the masked softmax, the next token
@@ -304,6 +341,126 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
     if (p.rules) sift_record(sst, tok, p.rules, V);
     __syncthreads();
     TICK(10);
+  }
+}
+
+// =========================================================================================
+// Best-first beam search (EfficientSATRN.beam_search, networks/EfficientSATRN.py:708-867, topk = 1): ONE workgroup runs
+// the whole search of one image -- priority queue, decoder steps, log-softmax, top-k and the final back-trace -- with
+// no host round trip (the reference pops one node at a time on the host with .item() syncs).
+//   node table (global, per image): parent, token, len, logp (f64, as the reference accumulates Python floats), score =
+//     -logp/len (+inf once popped); node 0 is <SOS>; expansion e creates nodes 1 + e*bw .. e*bw + bw.
+//   pop = argmin over live nodes of (score, len, index)  (decoding.py:80,83-84; equal score and len: unspecified there).
+//   An expanded node owns cache row e (its k/v per layer, the greedy kernel's slot semantics) and path[e] = the rows of
+//   its expanded ancestors followed by e: the self-attention key list of the step.
+// =========================================================================================
+template <typename T>
+__global__ __launch_bounds__(DEC_THREADS) void beam_search_kernel(DecodeP p, BeamP q) {
+  extern __shared__ float sm[];
+  const DecSm<T> S = dec_carve<T>(sm, p);
+  int* idx = reinterpret_cast<int*>(S.end);  // [nkP] key rows of the current expansion
+  const int D = p.D, V = p.V, E = p.steps, bw = q.bw;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ double s_ws[DEC_WAVES];
+  __shared__ int s_wl[DEC_WAVES], s_wi[DEC_WAVES];
+  __shared__ int s_pop, s_ctok[16];
+  __shared__ float s_clp[16];
+  int32_t* parent = q.parent + (long)b * q.NN;
+  int32_t* ntok = q.tok + (long)b * q.NN;
+  int32_t* nlen = q.len + (long)b * q.NN;
+  int32_t* nslot = q.slot + (long)b * q.NN;
+  double* nlogp = q.logp + (long)b * q.NN;
+  double* nscore = q.score + (long)b * q.NN;
+  uint16_t* path = q.path + (long)b * (E > 0 ? E : 1) * q.pstride;
+  int64_t* out = q.out + (long)b * q.max_seq;
+  const float emb_scale = sqrtf((float)D);
+  long long tlast = 0;
+  if (tid == 0) { parent[0] = -1; ntok[0] = p.sos; nlen[0] = 1; nslot[0] = -1; nlogp[0] = 0.0; nscore[0] = 0.0; }
+  __syncthreads();
+  int nn = 1, end = -1;
+  // lowest (score, len, index) among the live nodes -> s_pop
+  auto pop = [&]() {
+    double bs = INFINITY; int bl = 0x7fffffff, bi = 0x7fffffff;
+    for (int k = tid; k < nn; k += DEC_THREADS) {
+      const double sc = nscore[k];
+      const int ln = nlen[k];
+      if (sc < bs || (sc == bs && (ln < bl || (ln == bl && k < bi)))) { bs = sc; bl = ln; bi = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double os = __shfl_xor(bs, o, 64);
+      const int ol = __shfl_xor(bl, o, 64), oi = __shfl_xor(bi, o, 64);
+      if (os < bs || (os == bs && (ol < bl || (ol == bl && oi < bi)))) { bs = os; bl = ol; bi = oi; }
+    }
+    if (lane == 0) { s_ws[wave] = bs; s_wl[wave] = bl; s_wi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < DEC_WAVES; ++w)
+        if (s_ws[w] < bs || (s_ws[w] == bs && (s_wl[w] < bl || (s_wl[w] == bl && s_wi[w] < bi)))) { bs = s_ws[w]; bl = s_wl[w]; bi = s_wi[w]; }
+      s_pop = bi;
+      nscore[bi] = INFINITY;  // leaves the queue
+    }
+    __syncthreads();
+    return s_pop;
+  };
+  for (int e = 0; e < E; ++e) {      // :754 -- num_steps grows by beam_width per expansion, limit (max_sequence-1)*beam_width
+    const int n = pop();
+    const int tok = ntok[n], d = nlen[n], par = parent[n];
+    if (tok == q.eos && par != -1) { end = n; break; }   // :764-767 (topk = 1: the first <EOS> ends the search)
+    // key rows: the expanded ancestors' rows, then this expansion's own row
+    uint16_t* prow = path + (long)e * q.pstride;
+    if (par >= 0) {
+      const uint16_t* pp = path + (long)nslot[par] * q.pstride;
+      for (int i = tid; i < d - 1; i += DEC_THREADS) { const int r = pp[i]; prow[i] = (uint16_t)r; idx[i] = r; }
+    }
+    if (tid == 0) { prow[d - 1] = (uint16_t)e; idx[d - 1] = e; nslot[n] = e; }
+    // embedding * sqrt(D) + PE(len - 1)   (:773-778)
+    if (tid < D) S.x[tid] = p.embed[(long)tok * D + tid] * emb_scale + p.pe[(long)(d - 1) * D + tid];
+    __syncthreads();
+    dec_step<T, true>(p, S, b, e, d, idx, tlast);
+    // log_softmax + top-bw (:806-809), children (:813-829)
+    if (tid < 64) {
+      float m = -INFINITY;
+      for (int c = tid; c < V; c += 64) m = fmaxf(m, S.lg[c]);
+      m = wave_max(m);
+      float sum = 0.f;
+      for (int c = tid; c < V; c += 64) sum += expf(S.lg[c] - m);
+      sum = wave_sum(sum);
+      const float lse = logf(sum);
+      for (int k = 0; k < bw; ++k) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = tid; c < V; c += 64) { const float v = S.lg[c]; if (v > best) { best = v; bi = c; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ob = __shfl_xor(best, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (tid == 0) { s_ctok[k] = bi; s_clp[k] = (best - m) - lse; }
+        if (tid == (bi & 63)) S.lg[bi] = -INFINITY;
+      }
+    }
+    __syncthreads();
+    if (tid < bw) {
+      const int c = nn + tid;
+      const double lp = nlogp[n] + (double)s_clp[tid];
+      parent[c] = n; ntok[c] = s_ctok[tid]; nlen[c] = d + 1; nslot[c] = -1; nlogp[c] = lp;
+      nscore[c] = -(lp / (double)(d + 1));
+    }
+    nn += bw;
+    __syncthreads();
+  }
+  if (end < 0) end = pop();   // :834-835 no <EOS> popped: the best node left in the queue
+  // utterance root-first INCLUDING <SOS> (:842-848), padded with <PAD> / cut at max_sequence (:857-864)
+  const int ln = nlen[end];
+  for (int i = ln + tid; i < q.max_seq; i += DEC_THREADS) out[i] = q.pad;
+  if (tid == 0) {
+    int k = end;
+    for (int i = ln - 1; k >= 0; --i) {
+      if (i < q.max_seq) out[i] = ntok[k];
+      k = parent[k];
+    }
   }
 }
 
@@ -341,9 +498,7 @@ int launch_decode_greedy(int dt, const DecodeP& p0, hipStream_t s) {
     (void)hipMemsetAsync(prof_buf, 0, 16 * sizeof(long long), s);
     p.prof = prof_buf;
   } else p.prof = nullptr;
-  const int nkP = ((p.steps > p.Nsrc ? p.steps : p.Nsrc) + 3) & ~3;
-  const int scn = p.H * nkP > 4 * p.D ? p.H * nkP : 4 * p.D;
-  size_t sh = (size_t)(6 * p.D + p.F + scn + 2 * DEC_WAVES + ((p.V + 3) & ~3) + DEC_WAVES * p.D + (p.F > p.D ? p.F : p.D)) * sizeof(float);
+  size_t sh = dec_lds_floats(p) * sizeof(float);
   if (sh > 140 * 1024) return -1;
   if (dt == DT_BF16) {
     static bool a = false;
@@ -363,6 +518,30 @@ int launch_decode_greedy(int dt, const DecodeP& p0, hipStream_t s) {
     double tot = 0;
     for (int i = 0; i < 11; ++i) tot += (double)h[i];
     for (int i = 0; i < 11; ++i) fprintf(stderr, "[dec prof] %-22s %8.2f ms (%.1f%%)\n", nm[i], h[i] / 1e5, 100.0 * h[i] / tot);
+  }
+  return 0;
+}
+
+int launch_beam_search(int dt, const DecodeP& p0, const BeamP& q, hipStream_t s) {
+  DecodeP p = p0;
+  p.dbg = 0; p.prof = nullptr; p.rules = nullptr;
+  if (p.D % 32 || p.F % 32 || p.D > DEC_THREADS || p.nlayers > 4 || (p.D / p.H) % 4) return -1;
+  {
+    const int ch = dt == DT_BF16 ? 8 : 4, cpr = p.D / ch;
+    if ((p.D / p.H) % ch || cpr > 64 || (cpr & (cpr - 1))) return -1;
+  }
+  if (q.bw < 1 || q.bw > 16 || p.steps < 0 || p.steps > 65535 || q.NN < 1 + q.bw * p.steps || q.pstride < p.steps) return -1;
+  const int nkP = ((p.steps > p.Nsrc ? p.steps : p.Nsrc) + 3) & ~3;
+  size_t sh = (dec_lds_floats(p) + nkP) * sizeof(float);
+  if (sh > 140 * 1024) return -1;
+  if (dt == DT_BF16) {
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute((const void*)beam_search_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); a = true; }
+    hipLaunchKernelGGL((beam_search_kernel<bf16_t>), dim3(p.B), dim3(DEC_THREADS), sh, s, p, q);
+  } else {
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute((const void*)beam_search_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); a = true; }
+    hipLaunchKernelGGL((beam_search_kernel<float>), dim3(p.B), dim3(DEC_THREADS), sh, s, p, q);
   }
   return 0;
 }

@@ -372,6 +372,11 @@ int satrn_model_greedy_rules(satrn_model* h, const float* img, const float* src,
   if (!rules) return fail(-1, "satrn_model_greedy_rules: rules is null");
   return mret(h, model_greedy(h->m, img, src, B, steps, probs, ids, 0, S(st), rules), "greedy_rules");
 }
+int satrn_model_beam_search(satrn_model* h, const float* img, int B, int beam_width, int max_sequence, int eos_id, int pad_id,
+                            int64_t* sequences, void* st) {
+  if (!img || !sequences || B <= 0) return fail(-1, "satrn_model_beam_search: bad argument");
+  return mret(h, model_beam_search(h->m, img, B, beam_width, max_sequence, eos_id, pad_id, sequences, S(st)), "beam_search");
+}
 int satrn_sift(const float* x, int ld, int32_t* state, const int32_t* rules, int B, int V, int64_t* targets, float* probs,
                int ldp, void* st) {
   if (!x || !state || !rules || !targets || !probs || B <= 0 || V <= 0 || ld < V || ldp < V) return fail(-1, "satrn_sift: bad argument");

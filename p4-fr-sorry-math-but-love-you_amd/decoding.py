@@ -121,3 +121,17 @@ class DeviceDecodingManager:
                                    stream), "satrn_sift")
         self._keep = x
         return targets, (probs.unsqueeze(1) if three_d else probs)
+
+
+def decode(model, input, data_loader=None, expected=None, method="greedy", beam_width=3):
+    """postprocessing/decoding.py:6-53: the inference / validation decoding switch.
+    greedy -> ids int64 [B, L-1] (argmax of model(input, expected, False, 0.0), computed inside the decode kernel);
+    beam -> model.beam_search(...) with max_sequence = expected.size(-1) - 1, int64 [B, max_sequence] on the CPU."""
+    if method == "greedy":
+        # the reference takes topk(1) of the returned step outputs; the decode kernel already produced that argmax
+        # (logits, or the DecodingManager's masked probabilities -- the same winner either way)
+        return model.greedy(input, expected.size(1) - 1)[1]
+    if method == "beam":
+        return model.beam_search(input=input, data_loader=data_loader, beam_width=beam_width,
+                                 max_sequence=expected.size(-1) - 1)
+    raise NotImplementedError(f"There's no '{method}' type yet.")

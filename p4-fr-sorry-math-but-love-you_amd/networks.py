@@ -464,6 +464,27 @@ class EfficientSATRN(_SATRNBase):
     """Drop-in for networks/EfficientSATRN.py:664 (EfficientNetV2-S backbone, /32)."""
     _NETWORK = 1
 
+    @torch.no_grad()
+    def beam_search(self, input, data_loader, topk=1, beam_width=5, max_sequence=230):
+        """networks/EfficientSATRN.py:708-867 -> int64 [B, max_sequence] on the CPU (what id_to_string consumes): per image
+        a best-first search (priority queue on -sum(log p)/len) that ends at the first popped <EOS> or after
+        max_sequence-1 expansions; rows start with <SOS> and are padded with <PAD>, as the reference returns them.  The whole
+        batch runs in one launch, one workgroup per image (satrn_model_beam_search).  Only topk=1: the reference's own
+        packing of the result (:857-865) cannot represent more than one utterance per image."""
+        if topk != 1:
+            raise NotImplementedError("beam_search: topk must be 1 (the reference's output packing accepts nothing else)")
+        t2i = data_loader.dataset.token_to_id
+        eos, pad = int(t2i["<EOS>"]), int(t2i["<PAD>"])
+        if int(t2i["<SOS>"]) != self._cfg.sos_id:
+            raise ValueError("data_loader's <SOS> id differs from the model's")
+        input = self._img(input)
+        B = input.size(0)
+        self._prepare(input, B, 2)
+        seq = torch.empty(B, int(max_sequence), dtype=torch.int64, device=input.device)
+        check(self._lib.satrn_model_beam_search(self._h, ptr(input), B, int(beam_width), int(max_sequence), eos, pad, ptr(seq),
+                                                _stream()), "satrn_model_beam_search")
+        return seq.cpu()
+
 
 class LiteSATRN(_SATRNBase):
     """Drop-in for networks/LiteSATRN.py:548 (ShallowCNN backbone, /16)."""
