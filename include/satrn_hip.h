@@ -229,6 +229,13 @@ int satrn_model_loss_backward(satrn_model* m, const int64_t* expected, int B, in
  * 0-2: 74 % of the parameters) followed by 16 + 3. */
 int satrn_model_train_step(satrn_model* m, const float* images, const int64_t* expected, int B, int L,
                            const float* hyper9, int use_graph, int phase, void* stream);
+/* The dual-optimizer iteration of train_modules/train_dual_opt.py:87-113: as satrn_model_train_step (eager), but phase
+ * bit 1 clips the encoder.* and the decoder.* gradients SEPARATELY (two clip_grad_norm_ calls there) and steps each group
+ * with its own hyper9 (own learning rate / weight decay; Adam == entry 4 set to 0).  The two squared gradient norms are
+ * readable with satrn_model_read_grad_norms (host float[2]: encoder, decoder; synchronises). */
+int satrn_model_train_step_dual(satrn_model* m, const float* images, const int64_t* expected, int B, int L,
+                                const float* hyper9_enc, const float* hyper9_dec, int phase, void* stream);
+int satrn_model_read_grad_norms(satrn_model* m, float* out2_host, void* stream);
 int satrn_model_segment_range(satrn_model* m, int seg, int64_t* lo, int64_t* hi); /* [lo, hi) in flat fp32 elements */
 int satrn_model_read_loss(satrn_model* m, float* out4_host, void* stream); /* sum, count, mean, gnorm^2; syncs */
 int satrn_model_encode(satrn_model* m, const float* images, int B, float* src_out, void* stream);

@@ -1303,7 +1303,10 @@ int model_loss_backward(Model* m, const int64_t* expected, int B, int L, hipStre
 
 
 int model_train_step(Model* m, const float* img, const int64_t* expected, int B, int L, const float* hyper9,
-                     int use_graph, int phase, hipStream_t s) {
+                     int use_graph, int phase, hipStream_t s, const float* hyper9_dec) {
+  // hyper9_dec != null: the reference's dual-optimizer iteration (train_modules/train_dual_opt.py:87-113) -- encoder and
+  // decoder parameters are clipped SEPARATELY (clip_grad_norm_ per group) and stepped with their own learning rates
+  if (hyper9_dec && use_graph) { m->err = "the dual-optimizer step runs eagerly (use_graph must be 0)"; return -1; }
   // 16 + k (+ 4 * k_to): backward segments k..k_to (k == 0 also zeroes the gradients and runs forward + CE)
   const int seg = (phase & 16) ? (phase & 3) : -1;
   const int seg_to = (phase >> 2) & 3;
@@ -1331,6 +1334,13 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
   hy[6] = 1.0f - powf(hy[1], (float)m->adam_t);
   hy[7] = 1.0f - powf(hy[2], (float)m->adam_t);
   (void)hipMemcpyAsync(scal(m) + SC_HYPER, hy, 9 * sizeof(float), hipMemcpyHostToDevice, s);
+  if (hyper9_dec) {
+    float* hd = m->hy_pinned + (m->hy_seq++ % 64) * 16;
+    memcpy(hd, hyper9_dec, 9 * sizeof(float));
+    hd[6] = 1.0f - powf(hd[1], (float)m->adam_t);
+    hd[7] = 1.0f - powf(hd[2], (float)m->adam_t);
+    (void)hipMemcpyAsync(scal(m) + SC_HYPER2, hd, 9 * sizeof(float), hipMemcpyHostToDevice, s);
+  }
   auto body = [&]() -> int {
     if (phase & 1) {
       launch_seed_advance((uint32_t*)(scal(m) + SC_SEED), s);
@@ -1341,10 +1351,20 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
       if (rc) return rc;
     }
     if (phase & 2) {
-      launch_fill(scal(m) + SC_GNORM, 0, 4, s);
-      launch_sumsq(m->grads, m->n_params, scal(m) + SC_GNORM, (float*)(m->ws + m->off_sumsq), s);
-      launch_adamw(m->params, m->grads, (float*)(m->ws + m->off_adam_m), (float*)(m->ws + m->off_adam_v), m->n_params,
-                   scal(m) + SC_GNORM, scal(m) + SC_HYPER, s);
+      float* am = (float*)(m->ws + m->off_adam_m);
+      float* av = (float*)(m->ws + m->off_adam_v);
+      launch_fill(scal(m) + SC_GNORM, 0, 8, s);  // both norm slots
+      if (!hyper9_dec) {
+        launch_sumsq(m->grads, m->n_params, scal(m) + SC_GNORM, (float*)(m->ws + m->off_sumsq), s);
+        launch_adamw(m->params, m->grads, am, av, m->n_params, scal(m) + SC_GNORM, scal(m) + SC_HYPER, s);
+      } else {
+        // flat order: encoder.* first, decoder.* from the embedding on (model.encoder.parameters() / model.decoder.parameters())
+        const int64_t ne = m->embed.off, nd = m->n_params - ne;
+        launch_sumsq(m->grads, ne, scal(m) + SC_GNORM, (float*)(m->ws + m->off_sumsq), s);
+        launch_sumsq(m->grads + ne, nd, scal(m) + SC_GNORM2, (float*)(m->ws + m->off_sumsq), s);
+        launch_adamw(m->params, m->grads, am, av, ne, scal(m) + SC_GNORM, scal(m) + SC_HYPER, s);
+        launch_adamw(m->params + ne, m->grads + ne, am + ne, av + ne, nd, scal(m) + SC_GNORM2, scal(m) + SC_HYPER2, s);
+      }
       return model_pack_weights(m, s);
     }
     return 0;
@@ -1385,6 +1405,12 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
 int model_read_loss(Model* m, float* out4, hipStream_t s) {
   (void)hipMemcpyAsync(out4, scal(m) + SC_LOSS, 16, hipMemcpyDeviceToHost, s);
   (void)hipMemcpyAsync(out4 + 3, scal(m) + SC_GNORM, 4, hipMemcpyDeviceToHost, s);
+  (void)hipStreamSynchronize(s);
+  return 0;
+}
+
+int model_read_grad_norms(Model* m, float* out2, hipStream_t s) {
+  (void)hipMemcpyAsync(out2, scal(m) + SC_GNORM, 8, hipMemcpyDeviceToHost, s);
   (void)hipStreamSynchronize(s);
   return 0;
 }

@@ -123,7 +123,8 @@ struct Model {
 };
 
 // scalars block (floats unless noted), all in device memory inside the persistent region
-enum { SC_SEED = 0 /*uint32*/, SC_GNORM = 1, SC_LOSS = 4 /*4 floats*/, SC_HYPER = 8 /*9 floats*/, SC_ONE = 20, SC_COUNT = 32 };
+enum { SC_SEED = 0 /*uint32*/, SC_GNORM = 1, SC_GNORM2 = 2 /*decoder group, dual-optimizer step*/, SC_LOSS = 4 /*4 floats*/, SC_HYPER = 8 /*9 floats*/, SC_ONE = 20,
+       SC_HYPER2 = 21 /*9 floats: decoder group*/, SC_COUNT = 32 };
 
 struct ProfRec { std::string name; double flops = 0, bytes = 0; hipEvent_t a = nullptr, b = nullptr; };
 
@@ -166,7 +167,8 @@ int model_forward(Model* m, const float* img, const int64_t* expected, int B, in
 int model_backward(Model* m, const float* dlogits, hipStream_t s);
 int model_loss_backward(Model* m, const int64_t* expected, int B, int L, hipStream_t s);
 int model_train_step(Model* m, const float* img, const int64_t* expected, int B, int L, const float* hyper9,
-                     int use_graph, int phase, hipStream_t s);
+                     int use_graph, int phase, hipStream_t s, const float* hyper9_dec = nullptr);
+int model_read_grad_norms(Model* m, float* out2, hipStream_t s);
 int model_read_loss(Model* m, float* out4, hipStream_t s);
 int model_encode(Model* m, const float* img, int B, float* src_out, hipStream_t s);
 int model_greedy(Model* m, const float* img, const float* src_or_null, int B, int steps, float* logits_out,

@@ -361,6 +361,15 @@ int satrn_model_train_step(satrn_model* h, const float* img, const int64_t* exp,
                            int use_graph, int phase, void* st) {
   return mret(h, model_train_step(h->m, img, exp, B, L, hyper9, use_graph, phase, S(st)), "train_step");
 }
+int satrn_model_train_step_dual(satrn_model* h, const float* img, const int64_t* exp, int B, int L, const float* hyper9_enc,
+                                const float* hyper9_dec, int phase, void* st) {
+  if (!hyper9_enc || !hyper9_dec) return fail(-1, "satrn_model_train_step_dual: both hyper-parameter arrays are required");
+  return mret(h, model_train_step(h->m, img, exp, B, L, hyper9_enc, 0, phase, S(st), hyper9_dec), "train_step_dual");
+}
+int satrn_model_read_grad_norms(satrn_model* h, float* out2, void* st) {
+  if (!out2) return fail(-1, "satrn_model_read_grad_norms: out2 is null");
+  return mret(h, model_read_grad_norms(h->m, out2, S(st)), "read_grad_norms");
+}
 int satrn_model_read_loss(satrn_model* h, float* out4, void* st) { return mret(h, model_read_loss(h->m, out4, S(st)), "read_loss"); }
 int satrn_model_encode(satrn_model* h, const float* img, int B, float* src, void* st) { return mret(h, model_encode(h->m, img, B, src, S(st)), "encode"); }
 int satrn_model_greedy(satrn_model* h, const float* img, const float* src, int B, int steps, float* logits, int64_t* ids,

@@ -390,10 +390,19 @@ class _SATRNBase(nn.Module):
                    grad_scale=1.0, use_graph=False, phase=3):
         """forward + CE + backward + clip_grad_norm_ + AdamW + weight re-pack in ONE library call
         (train_modules/train_single_opt.py:80-98 with teacher forcing).  Default: eager launches on two HIP streams (weight
-        gradients run beside the data-gradient chain; measured 15.4 ms vs 17.0 ms for the single-chain hipGraph replay,
+        gradients run beside the data-gradient chain; measured 12.5 ms vs 15.2 ms for the single-chain hipGraph replay,
         which use_graph=True selects).  phase: 1 = forward/backward only,
         2 = clip + AdamW only (data-parallel callers all-reduce the flat gradient in between), 3 = both; 16 + k = backward
-        segment k of phase 1 (k = 0..3 in order; overlapped gradient exchange, see dp.dp_train_step)."""
+        segment k of phase 1 (k = 0..3 in order; overlapped gradient exchange, see dp.dp_train_step).
+        lr = (encoder_lr, decoder_lr) and/or weight_decay = (encoder_wd, decoder_wd) select the reference's DUAL-optimizer
+        iteration (train_modules/train_dual_opt.py:87-113): encoder.* and decoder.* gradients are clipped separately and
+        stepped with their own learning rates (eager only; plain Adam = weight_decay 0, what that trainer uses)."""
+        dual = isinstance(lr, (tuple, list)) or isinstance(weight_decay, (tuple, list))
+        if dual:
+            lr = tuple(lr) if isinstance(lr, (tuple, list)) else (lr, lr)
+            weight_decay = tuple(weight_decay) if isinstance(weight_decay, (tuple, list)) else (weight_decay, weight_decay)
+            if use_graph:
+                raise ValueError("the dual-optimizer step runs eagerly (use_graph=False)")
         input = self._img(input)
         B, L = expected.shape
         self._ensure_bound(input.device)
@@ -405,7 +414,11 @@ class _SATRNBase(nn.Module):
         if int(phase) in (1, 3) or (int(phase) & 16 and int(phase) & 3 == 0):  # calls that start a step stage its inputs
             self._stage[0].copy_(input, non_blocking=True)
             self._stage[1].copy_(expected, non_blocking=True)
-        hy = (ctypes.c_float * 9)(lr, betas[0], betas[1], eps, weight_decay, max_grad_norm, 0.0, 0.0, grad_scale)
+        if dual:
+            hy = (ctypes.c_float * 9)(lr[0], betas[0], betas[1], eps, weight_decay[0], max_grad_norm, 0.0, 0.0, grad_scale)
+            hy2 = (ctypes.c_float * 9)(lr[1], betas[0], betas[1], eps, weight_decay[1], max_grad_norm, 0.0, 0.0, grad_scale)
+        else:
+            hy = (ctypes.c_float * 9)(lr, betas[0], betas[1], eps, weight_decay, max_grad_norm, 0.0, 0.0, grad_scale)
         # graphs are captured on a private stream (the legacy default stream cannot capture); the first step of a shape
         # runs eagerly so that one-time kernel attribute setup never lands inside a capture
         key = (B, L, int(phase))
@@ -416,8 +429,12 @@ class _SATRNBase(nn.Module):
             self._side = torch.cuda.Stream(device=input.device, priority=-1)  # high priority: the critical chain
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
-            check(self._lib.satrn_model_train_step(self._h, ptr(self._stage[0]), ptr(self._stage[1]), B, L, hy,
-                                                   int(use_graph and warm), int(phase), _stream()), "satrn_model_train_step")
+            if dual:
+                check(self._lib.satrn_model_train_step_dual(self._h, ptr(self._stage[0]), ptr(self._stage[1]), B, L, hy, hy2,
+                                                            int(phase), _stream()), "satrn_model_train_step_dual")
+            else:
+                check(self._lib.satrn_model_train_step(self._h, ptr(self._stage[0]), ptr(self._stage[1]), B, L, hy,
+                                                       int(use_graph and warm), int(phase), _stream()), "satrn_model_train_step")
         cur.wait_stream(self._side)
         self._gen += 1
         self._packed_version = -2  # parameters were updated and re-packed inside the step
@@ -458,6 +475,12 @@ class _SATRNBase(nn.Module):
         out = (ctypes.c_float * 4)()
         check(self._lib.satrn_model_read_loss(self._h, out, _stream()), "read_loss")
         return float(out[2]), float(out[1]), math.sqrt(max(float(out[3]), 0.0))
+
+    def read_grad_norms(self):
+        """-> (encoder grad-norm, decoder grad-norm) of the last dual-optimizer train_step (train_dual_opt.py:101-109)."""
+        out = (ctypes.c_float * 2)()
+        check(self._lib.satrn_model_read_grad_norms(self._h, out, _stream()), "read_grad_norms")
+        return math.sqrt(max(float(out[0]), 0.0)), math.sqrt(max(float(out[1]), 0.0))
 
 
 class EfficientSATRN(_SATRNBase):

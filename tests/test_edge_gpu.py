@@ -115,6 +115,40 @@ def test_torch_optimizer_on_flat_parameter_views_matches_fused_step():
     assert upd < 2e-6  # steps are ~5e-4
 
 
+def test_dual_optimizer_step_matches_two_torch_optimizers():
+    """train_modules/train_dual_opt.py:87-113: clip_grad_norm_ per group (encoder / decoder) and two Adam optimizers with
+    their own learning rates == the fused dual step fed the same gradients."""
+    cfg = dict(O.CFG_LITE)
+    img, expected = O.det_inputs(2, 1, 64, 192, 6, seed=57)
+    imgd, expd = img.cuda(), expected.cuda()
+    a, _ = build(cfg, 64, 192, "f32", 13)
+    b, _ = build(cfg, 64, 192, "f32", 13)
+    a.train(); b.train()
+    enc_p, dec_p = list(a.encoder.parameters()), list(a.decoder.parameters())
+    enc_opt, dec_opt = torch.optim.Adam(enc_p, lr=1e-4), torch.optim.Adam(dec_p, lr=5e-4)
+    for it in range(3):
+        logits = a(imgd, expd, True, 1.0)
+        loss = a.criterion(logits.transpose(1, 2), expd[:, 1:])
+        enc_opt.zero_grad(); dec_opt.zero_grad()
+        loss.backward()
+        b.flat_grad().copy_(a.flat_grad())
+        torch.cuda.synchronize()
+        # a clip value that bites for one group only on some iterations
+        mg = 0.05 if it == 1 else 2.0
+        en = torch.nn.utils.clip_grad_norm_(enc_p, mg)
+        dn = torch.nn.utils.clip_grad_norm_(dec_p, mg)
+        enc_opt.step(); dec_opt.step()
+        b.train_step(imgd, expd, (1e-4, 5e-4), weight_decay=0.0, max_grad_norm=mg, phase=2)
+        ge, gd = b.read_grad_norms()
+        assert abs(ge - en.item()) < 1e-4 * max(1.0, en.item()) and abs(gd - dn.item()) < 1e-4 * max(1.0, dn.item())
+    pa, pb = a.flat_params().detach().cpu(), b.flat_params().detach().cpu()
+    upd = (pa - pb).abs().max().item()
+    print("max param diff after 3 dual steps:", upd)
+    assert upd < 2e-6
+    with pytest.raises(ValueError):
+        b.train_step(imgd, expd, (1e-4, 5e-4), use_graph=True)
+
+
 def test_state_dict_roundtrip_on_device(tmp_path):
     cfg = dict(O.CFG_LITE)
     a, sd = build(cfg, 64, 192, "bf16", 12)
