@@ -236,6 +236,10 @@ int satrn_model_train_step(satrn_model* m, const float* images, const int64_t* e
 int satrn_model_train_step_dual(satrn_model* m, const float* images, const int64_t* expected, int B, int L,
                                 const float* hyper9_enc, const float* hyper9_dec, int phase, void* stream);
 int satrn_model_read_grad_norms(satrn_model* m, float* out2_host, void* stream);
+/* argmax over the vocabulary of the last forward's / train step's logits -> ids int64 [B][L-1] (device): the `sequence`
+ * of train_modules/train_single_opt.py:82-84 for the per-step metrics, without materialising logits for the caller.
+ * Valid until the next call that runs the model (any forward, decode or train step). */
+int satrn_model_last_sequence(satrn_model* m, int64_t* ids, int B, int L, void* stream);
 int satrn_model_segment_range(satrn_model* m, int seg, int64_t* lo, int64_t* hi); /* [lo, hi) in flat fp32 elements */
 int satrn_model_read_loss(satrn_model* m, float* out4_host, void* stream); /* sum, count, mean, gnorm^2; syncs */
 int satrn_model_encode(satrn_model* m, const float* images, int B, float* src_out, void* stream);

@@ -1215,6 +1215,7 @@ int model_forward(Model* m, const float* img, const int64_t* expected, int B, in
   m->seg_mark[2] = e.tape.size();  // end of the encoder
   m->seg_next = 0;
   e.logits = teacher_forced ? decoder_tf(e, e.src, expected, B, L, logits_out) : decoder_ar(e, e.src, B, L, logits_out);
+  m->logits_epoch = m->epoch;
   if (e.oom) { if (m->err.empty()) m->err = "workspace exhausted"; return -2; }
   return 0;
 }
@@ -1406,6 +1407,16 @@ int model_read_loss(Model* m, float* out4, hipStream_t s) {
   (void)hipMemcpyAsync(out4, scal(m) + SC_LOSS, 16, hipMemcpyDeviceToHost, s);
   (void)hipMemcpyAsync(out4 + 3, scal(m) + SC_GNORM, 4, hipMemcpyDeviceToHost, s);
   (void)hipStreamSynchronize(s);
+  return 0;
+}
+
+// argmax over the vocabulary of the LAST forward's logits -> ids [B][L-1]: the `sequence` the reference's training loop
+// derives from the model output for its per-step metrics (train_modules/train_single_opt.py:82-84)
+int model_last_sequence(Model* m, int64_t* ids_out, int B, int L, hipStream_t s) {
+  Exec& e = *m->ex;
+  if (!e.logits || m->logits_epoch != m->epoch) { m->err = "no live forward (the last call on this model was not a forward / train step)"; return -1; }
+  if ((long)B * (L - 1) != e.logits->rows) { m->err = "last_sequence: B, L differ from the last forward"; return -1; }
+  launch_argmax((const float*)e.logits->p, ids_out, (int)e.logits->rows, m->cfg.num_classes, m->cfg.num_classes, 1, s);
   return 0;
 }
 

@@ -118,6 +118,7 @@ struct Model {
   // backward segments for overlapping the gradient exchange with the rest of the backward pass: tape marks recorded
   // in forward (early/late backbone, end of backbone, end of encoder) and the flat-gradient range each segment completes
   size_t seg_mark[3] = {0, 0, 0}; int64_t seg_lo[4] = {0, 0, 0, 0}, seg_hi[4] = {0, 0, 0, 0}; int late_block = 0; int seg_next = 0;
+  long logits_epoch = -1;  // epoch of the arena that holds the last forward's logits
   long epoch = 0, step_epoch = -1;  // every arena reset bumps epoch: a session from an older epoch is dead
   std::string err;
 };
@@ -169,6 +170,7 @@ int model_loss_backward(Model* m, const int64_t* expected, int B, int L, hipStre
 int model_train_step(Model* m, const float* img, const int64_t* expected, int B, int L, const float* hyper9,
                      int use_graph, int phase, hipStream_t s, const float* hyper9_dec = nullptr);
 int model_read_grad_norms(Model* m, float* out2, hipStream_t s);
+int model_last_sequence(Model* m, int64_t* ids_out, int B, int L, hipStream_t s);
 int model_read_loss(Model* m, float* out4, hipStream_t s);
 int model_encode(Model* m, const float* img, int B, float* src_out, hipStream_t s);
 int model_greedy(Model* m, const float* img, const float* src_or_null, int B, int steps, float* logits_out,

@@ -366,6 +366,10 @@ int satrn_model_train_step_dual(satrn_model* h, const float* img, const int64_t*
   if (!hyper9_enc || !hyper9_dec) return fail(-1, "satrn_model_train_step_dual: both hyper-parameter arrays are required");
   return mret(h, model_train_step(h->m, img, exp, B, L, hyper9_enc, 0, phase, S(st), hyper9_dec), "train_step_dual");
 }
+int satrn_model_last_sequence(satrn_model* h, int64_t* ids, int B, int L, void* st) {
+  if (!ids || B <= 0 || L < 2) return fail(-1, "satrn_model_last_sequence: bad argument");
+  return mret(h, model_last_sequence(h->m, ids, B, L, S(st)), "last_sequence");
+}
 int satrn_model_read_grad_norms(satrn_model* h, float* out2, void* st) {
   if (!out2) return fail(-1, "satrn_model_read_grad_norms: out2 is null");
   return mret(h, model_read_grad_norms(h->m, out2, S(st)), "read_grad_norms");

@@ -476,6 +476,13 @@ class _SATRNBase(nn.Module):
         check(self._lib.satrn_model_read_loss(self._h, out, _stream()), "read_loss")
         return float(out[2]), float(out[1]), math.sqrt(max(float(out[3]), 0.0))
 
+    def last_sequence(self, B, L):
+        """-> int64 [B, L-1]: argmax of the last forward's / train_step's logits (the `sequence` of
+        train_modules/train_single_opt.py:82-84, what StepMetrics.update takes).  Valid until the model runs again."""
+        ids = torch.empty(B, L - 1, dtype=torch.int64, device=self._bound)
+        check(self._lib.satrn_model_last_sequence(self._h, ptr(ids), int(B), int(L), _stream()), "satrn_model_last_sequence")
+        return ids
+
     def read_grad_norms(self):
         """-> (encoder grad-norm, decoder grad-norm) of the last dual-optimizer train_step (train_dual_opt.py:101-109)."""
         out = (ctypes.c_float * 2)()

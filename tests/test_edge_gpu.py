@@ -149,6 +149,28 @@ def test_dual_optimizer_step_matches_two_torch_optimizers():
         b.train_step(imgd, expd, (1e-4, 5e-4), use_graph=True)
 
 
+def test_last_sequence_is_the_argmax_of_the_training_logits():
+    """train_modules/train_single_opt.py:80-84: `sequence` for the per-step metrics, after a fused step, without logits."""
+    import satrn_amd
+    cfg = dict(O.CFG_LITE)
+    img, expected = O.det_inputs(3, 1, 64, 192, 9, seed=58, pad_tail=2)
+    imgd, expd = img.cuda(), expected.cuda()
+    a, _ = build(cfg, 64, 192, "f32", 14)
+    a.train()
+    logits = a(imgd, expd, True, 1.0).detach()
+    B, L = expd.shape
+    seq = a.last_sequence(B, L)                       # after a module-API forward
+    assert seq.shape == (B, L - 1) and (seq == logits.argmax(-1)).all()
+    a.train_step(imgd, expd, 5e-4, phase=1)           # same weights, same batch statistics, dropout 0 -> same logits
+    seq2 = a.last_sequence(B, L)
+    assert (seq2 == seq).all()
+    a.train_step(imgd, expd, 5e-4)                    # a full fused step keeps the step's logits readable
+    assert (a.last_sequence(B, L) == seq).all()
+    a.greedy(imgd, 4)                                 # any other run of the model ends that
+    with pytest.raises(satrn_amd.SatrnError):
+        a.last_sequence(B, L)
+
+
 def test_state_dict_roundtrip_on_device(tmp_path):
     cfg = dict(O.CFG_LITE)
     a, sd = build(cfg, 64, 192, "bf16", 12)
