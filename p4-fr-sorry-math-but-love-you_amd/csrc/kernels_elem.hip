@@ -29,7 +29,9 @@ static inline int grid_for(long work, int per_block = 256, int cap = 4096) {
 // block = TX column-chunk threads x TY row threads; partials go through LDS atomics, then one global
 // atomicAdd per column per block.  F::operator()(row, col0, float out[NO][CH]) adds the row's terms.
 // =============================================================================================
-template <typename T, int NO, typename F>
+// UNR: rows a thread requests together.  It must DIVIDE the per-thread trip count: an unrolled loop whose trip count is
+// smaller than its unroll factor runs only the sequential remainder loop -- one dependent memory round trip per row.
+template <typename T, int NO, typename F, int UNR = 4>
 __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int rows_per_block, int tx_log2,
                                                         float* o0, float* o1, int nmain) {
   constexpr int CH = TT<T>::CH;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int 
   if (r1 > M) r1 = M;
   if (c < CC) {
     f.prep(c * CH);
-#pragma unroll 4
+#pragma unroll UNR
     for (long r = r0 + ty; r < r1; r += TY) f(r, c * CH, acc);
   }
 #pragma unroll
@@ -90,12 +92,25 @@ static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain
   long rpt = (M * gy) / ((long)TY * target_blocks);
   if (rpt < 1) rpt = 1;
   if (rpt > rows_per_thread) rpt = rows_per_thread;
+  static const int force_rpt = getenv("SATRN_COLRED_RPT") ? atoi(getenv("SATRN_COLRED_RPT")) : 0;  // tuning hook
+  if (force_rpt > 0 && NO <= 2) rpt = force_rpt;
   long rpb = (long)TY * rpt;
   long gx = (M + rpb - 1) / rpb;
   long cap = max_blocks / gy < 1 ? 1 : max_blocks / gy;
-  if (gx > cap) { gx = cap; rpb = (M + gx - 1) / gx; rpb = ((rpb + TY - 1) / TY) * TY; gx = (M + rpb - 1) / rpb; }
-  hipLaunchKernelGGL((colreduce_kernel<T, NO, F>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1,
-                     nmain);
+  if (gx > cap) {
+    gx = cap;
+    rpt = ((M + gx - 1) / gx + TY - 1) / TY;
+    rpb = rpt * TY;
+    gx = (M + rpb - 1) / rpb;
+  }
+  // the row loop is unrolled by the largest of 4 / 2 / 1 that DIVIDES the rows per thread (see colreduce_kernel)
+  static const bool unr4 = getenv("SATRN_COLRED_UNR4") != nullptr;  // A/B switch: the old fixed unroll factor
+  if (!unr4 && NO <= 2 && rpt % 4 != 0 && rpt % 2 == 0)
+    hipLaunchKernelGGL((colreduce_kernel<T, NO, F, (NO <= 2 ? 2 : 4)>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1, nmain);
+  else if (!unr4 && NO <= 2 && rpt % 2 != 0 && rpt < 4)
+    hipLaunchKernelGGL((colreduce_kernel<T, NO, F, (NO <= 2 ? 1 : 4)>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1, nmain);
+  else
+    hipLaunchKernelGGL((colreduce_kernel<T, NO, F, 4>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1, nmain);
 }
 
 // ---- BN batch statistics ------------------------------------------------------------------
@@ -260,7 +275,8 @@ void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* ss
     BnBwdRedF<T> f;
     f.dz = (const T*)dz; f.y = (const T*)y; f.ss = ss; f.mr = mr; f.C = C; f.act = act;
     f.se_gate = (const T*)se_gate; f.se_dpool = (const T*)se_dpool; f.se_hw = se_hw > 0 ? se_hw : 1; f.se_scale = se_hw > 0 ? 1.0f / (float)se_hw : 0.f;
-    launch_colreduce<T, 2>(f, M, C, red, red + C, 1, s);
+    static const int tb = getenv("SATRN_BNRED_BLOCKS") ? atoi(getenv("SATRN_BNRED_BLOCKS")) : 512;
+    launch_colreduce<T, 2>(f, M, C, red, red + C, 1, s, 8, tb, 1024);
   });
 }
 
@@ -668,24 +684,41 @@ __global__ __launch_bounds__(64 * RG) void hw_reduce_kernel(const T* a, const T*
 #pragma unroll
   for (int j = 0; j < CH; ++j) s0[j] = s1[j] = 0.f;
   if (c < CC) {
-#pragma unroll 4
-    for (int p = rg; p < HW; p += RG) {
-      float v[CH];
-      unpack<T>(ld16(a + ((long)b * HW + p) * C + c * CH), v);
-      if (MODE == 0) {
+    // rows in batches of four whose loads are all in flight together; the last, partial batch re-reads a valid row with
+    // weight 0 instead of branching (a partially unrolled loop would run its remainder one dependent round trip at a time:
+    // HW = 48 with RG = 16 is three rows per thread, i.e. remainder only)
+    for (int p0 = rg; p0 < HW; p0 += 4 * RG) {
+      uint4 ra[4], rb[4];
+      float m[4];
+      int pp[4];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) s0[j] += v[j];
-      } else if (MODE == 1) {
-        float w[CH];
-        unpack<T>(ld16(bb + ((long)b * HW + p) * C + c * CH), w);
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + u * RG;
+        m[u] = p < HW ? 1.f : 0.f;
+        pp[u] = p < HW ? p : p0;
+        ra[u] = ld16(a + ((long)b * HW + pp[u]) * C + c * CH);
+        if (MODE == 1) rb[u] = ld16(bb + ((long)b * HW + pp[u]) * C + c * CH);
+      }
 #pragma unroll
-        for (int j = 0; j < CH; ++j) s0[j] += v[j] * w[j];
-      } else {
-        int h = p / Wd, w_ = p - h * Wd;
+      for (int u = 0; u < 4; ++u) {
+        float v[CH];
+        unpack<T>(ra[u], v);
+        if (MODE == 0) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          s0[j] += v[j] * hpos[h * C + c * CH + j];
-          s1[j] += v[j] * wpos[w_ * C + c * CH + j];
+          for (int j = 0; j < CH; ++j) s0[j] += m[u] * v[j];
+        } else if (MODE == 1) {
+          float w[CH];
+          unpack<T>(rb[u], w);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) s0[j] += m[u] * v[j] * w[j];
+        } else {
+          int h = pp[u] / Wd, w_ = pp[u] - h * Wd;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            const float mv = m[u] * v[j];
+            s0[j] += mv * hpos[h * C + c * CH + j];
+            s1[j] += mv * wpos[w_ * C + c * CH + j];
+          }
         }
       }
     }

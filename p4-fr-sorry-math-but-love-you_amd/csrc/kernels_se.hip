@@ -98,7 +98,22 @@ __global__ __launch_bounds__(1024) void se_fwd_kernel(const T* x, const T* W1, c
   for (int c = tid; c < C; c += 1024) {
     const T* w = W2 + (long)c * S;
     float acc = b2[c];
-    if ((S % CH) == 0) {
+    if ((S % CH) == 0 && S <= 8 * CH) {
+      // all chunks of the row requested at once (a partially unrolled loop with S/CH < 8 trips would fetch them one
+      // dependent round trip at a time); chunks beyond S re-read the last one and are not used
+      uint4 raw[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) raw[u] = ld16(w + (u * CH < S ? u * CH : S - CH));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u * CH < S) {
+          float wv[CH];
+          unpack<T>(raw[u], wv);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) acc += wv[e] * h[u * CH + e];
+        }
+      }
+    } else if ((S % CH) == 0) {
 #pragma unroll 8
       for (int j = 0; j < S; j += CH) {
         float wv[CH];
