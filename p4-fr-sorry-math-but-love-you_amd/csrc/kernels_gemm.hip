@@ -417,9 +417,105 @@ static bool conv_halo_launch(int amode, const GemmP& p, hipStream_t s) {
   return true;
 }
 
+
+// =========================================================================================
+// Skinny dense GEMM (M <= 64 rows: the per-step products of the step-wise decoder, the train-time autoregressive branch and
+// their data gradients, the positional-encoding gate).  The tiled kernel above needs one load -> LDS -> MFMA round trip per
+// k-panel pair even when a whole operand is a few KB; here a workgroup owns 16 output columns, its four waves split K, and
+// every wave fetches ALL of its A and W fragments straight from global memory into registers before the first MFMA: one
+// memory round trip per launch (7.7 -> ~4 us), no LDS staging, one LDS reduction of the four partial tiles at the end.
+//   lane l: A fragment = A[m0 + (l & 15)][k0 + 8 * (l >> 4) ..+8], B fragment = W[n0 + (l & 15)][same k]  (common.h mma())
+// Requires K % 32 == 0 and K <= 4 * 32 * STEPS.  Same epilogue as gemm_kernel minus the BatchNorm statistics.
+// =========================================================================================
+template <typename T> DEVI Frag<T> load_frag_g(const T* p);
+template <> DEVI Frag<bf16_t> load_frag_g<bf16_t>(const bf16_t* p) { Frag<bf16_t> f; f.v = ld16(p); return f; }
+template <> DEVI Frag<float> load_frag_g<float>(const float* p) { Frag<float> f; f.v0 = ld16(p); f.v1 = ld16(p + 4); return f; }
+template <typename T> DEVI void zero_frag(Frag<T>& f);
+template <> DEVI void zero_frag<bf16_t>(Frag<bf16_t>& f) { f.v = zero16(); }
+template <> DEVI void zero_frag<float>(Frag<float>& f) { f.v0 = zero16(); f.v1 = zero16(); }
+
+template <typename T, int MT, int STEPS>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
+  __shared__ float red[4][MT][64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const T* A = (const T*)p.A;
+  const T* Bw = (const T*)p.Bw;
+  const int nk32 = p.K >> 5;
+  int ncol = n0 + fr;
+  if (ncol >= p.N) ncol = p.N - 1;
+  const T* wrow = Bw + (long)ncol * p.K + fq * 8;
+  const T* arow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    int m = i * 16 + fr;
+    if (m >= p.M) m = p.M - 1;
+    arow[i] = A + (long)m * p.lda + fq * 8;
+  }
+  // this wave's k-steps: wave, wave + 4, ... (interleaved so that the four waves read neighbouring 64-byte pieces)
+  Frag<T> fa[STEPS][MT], fb[STEPS];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const int ks = wave + 4 * s;
+    const bool ok = ks < nk32;
+    const int kk = (ok ? ks : 0) * 32;
+    fb[s] = load_frag_g<T>(wrow + kk);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[s][i] = load_frag_g<T>(arow[i] + kk);
+    if (!ok) zero_frag<T>(fb[s]);
+  }
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) mma(fa[s][i], fb[s], acc[i]);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][i][lane][r] = acc[i][r];
+  __syncthreads();
+  const uint32_t seed = (p.drop_p > 0.f) ? *p.seed : 0u;
+  // 256 threads finish MT * 256 outputs: item -> (row tile i, lane l, reg r); col = l & 15, row = i*16 + (l >> 4)*4 + r
+  for (int it = tid; it < MT * 256; it += 256) {
+    const int i = it >> 8, l = (it >> 2) & 63, r = it & 3;
+    const int row = i * 16 + (l >> 4) * 4 + r, col = n0 + (l & 15);
+    if (row >= p.M || col >= p.N) continue;
+    float v = red[0][i][l][r] + red[1][i][l][r] + red[2][i][l][r] + red[3][i][l][r];
+    v = act_fwd(v + (p.bias ? p.bias[col] : 0.f), p.act);
+    if (p.drop_p > 0.f) v *= drop_scale(seed, p.site, (uint32_t)(row * p.N + col), p.drop_p);
+    const long o = (long)row * p.ldc + col;
+    if (p.out_f32) {
+      float* c = (float*)p.C;
+      c[o] = p.beta ? c[o] + v : v;
+    } else {
+      T* c = (T*)p.C;
+      c[o] = from_f<T>(p.beta ? to_f(c[o]) + v : v);
+    }
+  }
+}
+
+template <typename T>
+static bool gemm_skinny_launch(const GemmP& p, hipStream_t s) {
+  static const bool off = getenv("SATRN_NO_SKINNY_GEMM") != nullptr;
+  if (off || p.M > 64 || (p.K & 31) || p.K > 1024 || p.stats || p.bnb_y || (p.lda & 7)) return false;
+  const int mt = (p.M + 15) / 16;
+  const int steps = ((p.K >> 5) + 3) / 4;  // k-steps per wave
+  const dim3 g((p.N + 15) / 16), b(256);
+#define SK_CASE(MT_, ST_) hipLaunchKernelGGL((gemm_skinny_kernel<T, MT_, ST_>), g, b, 0, s, p)
+#define SK_ROW(MT_) do { if (steps <= 2) SK_CASE(MT_, 2); else if (steps <= 4) SK_CASE(MT_, 4); else SK_CASE(MT_, 8); } while (0)
+  if (mt == 1) SK_ROW(1); else if (mt == 2) SK_ROW(2); else if (mt == 3) SK_ROW(3); else SK_ROW(4);
+#undef SK_ROW
+#undef SK_CASE
+  return true;
+}
+
 void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return;
   if (dt == DT_BF16 && amode != AM_DENSE && conv_halo_launch(amode, p, s)) return;
+  if (amode == AM_DENSE && (dt == DT_BF16 ? gemm_skinny_launch<bf16_t>(p, s) : gemm_skinny_launch<float>(p, s))) return;
   if (dt == DT_BF16) {
     if (amode == AM_DENSE) launch_gemm_t<bf16_t, AM_DENSE>(p, s);
     else if (amode == AM_CONV) launch_gemm_t<bf16_t, AM_CONV>(p, s);

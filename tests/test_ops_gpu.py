@@ -98,7 +98,10 @@ def pack_dense(lib, w, dt, ldb=None):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K,act", [(100, 64, 64, 0), (300, 24, 216, 1), (257, 245, 256, 0), (4096, 1024, 256, 1),
-                                       (64, 768, 256, 3), (1536, 512, 512, 0), (33, 40, 960, 0)])
+                                       (64, 768, 256, 3), (1536, 512, 512, 0), (33, 40, 960, 0),
+                                       # M <= 64: the skinny kernel (register-resident operands, K split over the four waves)
+                                       (32, 256, 1024, 1), (7, 245, 256, 0), (1, 64, 64, 0), (48, 1024, 256, 1), (32, 256, 256, 0),
+                                       (17, 40, 1056, 0)])
 def test_linear(lib, dt, M, N, K, act):
     x, w, b = q(rnd(M, K, seed=1), dt), q(rnd(N, K, seed=2, scale=1 / math.sqrt(K)), dt), rnd(N, seed=3, scale=0.1)
     fwd, bwd, ldb = pack_dense(lib, w, dt)
