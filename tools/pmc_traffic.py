@@ -12,7 +12,7 @@ import json
 import sys
 from collections import defaultdict
 
-FAMILIES = [("gemm_kernel", "launch_gemm"), ("conv3x3_halo_kernel", "launch_gemm"), ("wgrad_kernel", "launch_wgrad"), ("bn_act_kernel", "launch_bn_act"),
+FAMILIES = [("gemm_kernel", "launch_gemm"), ("conv3x3_halo_kernel", "launch_gemm"), ("gemm_skinny_kernel", "launch_gemm"), ("wgrad_kernel", "launch_wgrad"), ("bn_act_kernel", "launch_bn_act"),
             ("bn_bwd_apply_kernel", "launch_bn_bwd_apply"), ("BnBwdRedF", "launch_bn_bwd_reduce"), ("StatsF", "launch_colstats"),
             ("DwWgradF", "launch_dwconv_wgrad"), ("dwconv", "launch_dwconv"), ("se_fwd_kernel", "launch_se_fwd"),
             ("se_bwd_a_kernel", "launch_se_bwd"), ("se_bwd_b_kernel", "launch_se_bwd_weights"), ("attn_kernel", "launch_attn"),
