@@ -362,6 +362,12 @@ Model* model_create(const SatrnConfig& cfg) {
     m->packblk_bytes = nb * 2 * sizeof(int);
     m->off_packblk = take(m->packblk_bytes);
   }
+  {  // eval-mode BatchNorm scale/shift table + its descriptor array (one prepare launch per inference forward)
+    size_t tot = 0;
+    for (BNp* b : m->all_bn) { b->eval_off = tot; tot += (size_t)2 * b->C; }
+    m->off_bn_eval = take(tot * 4);
+    m->off_bn_desc = take(m->all_bn.size() * sizeof(BnEvalDesc) + 16);
+  }
   m->zero_bytes = 40u << 20;
   m->off_zero = take(m->zero_bytes);
   m->persist_bytes = (o + 255) & ~(size_t)255;
@@ -394,6 +400,7 @@ int model_bind(Model* m, float* params, float* grads, float* buf_f32, int64_t* b
   for (BNp* b : m->all_bn) { b->rm = buf_f32 + b->rm_off; b->rv = buf_f32 + b->rv_off; b->nbt = buf_i64 ? buf_i64 + b->nbt_off : nullptr; }
   m->bound = true;
   m->pack_dirty = true;
+  m->bn_desc_dirty = true;
   for (int i = 0; i < 4; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
   if (m->decode_graph) { (void)hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
   return 0;
@@ -408,6 +415,7 @@ int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s) {
   // the padding must be finite, so clear everything once
   (void)hipMemsetAsync(m->ws, 0, bytes, s);
   m->zero_hwm = 0; m->ex->zoff = 0;  // fresh, all-zero workspace
+  m->bn_desc_dirty = true;
   (void)hipStreamSynchronize(s);
   for (Wt* w : m->all_w) {
     w->fwd = w->pk_fwd_off >= 0 ? m->ws + w->pk_fwd_off : nullptr;
@@ -500,6 +508,7 @@ struct Geo { int H, W, Ci, OH, OW, KW, stride, pt, pl; };
 
 static inline void used(Tensor* t) { if (t) t->ncons++; }
 static const bool g_fuse_bnb = getenv("SATRN_NO_FUSED_BN_BWD") == nullptr;
+static const bool g_fuse_bn_eval = getenv("SATRN_NO_FUSED_BN_EVAL") == nullptr;
 
 static void acc_grad(Exec& e, Tensor* t, const void* src) {
   // first contribution: alias the producer's gradient buffer (it has no reader left once its own backward ran)
@@ -540,6 +549,12 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
   }
   if (geo) { p.H = geo->H; p.W = geo->W; p.Ci = geo->Ci; p.OH = geo->OH; p.OW = geo->OW; p.KW = geo->KW; p.stride = geo->stride; p.pt = geo->pt; p.pl = geo->pl; }
   e.nflops = 2.0 * (double)M * N * w->K; e.nbytes = ((double)x->rows * x->C + (double)M * N + (double)N * w->K) * e.esz();
+  if (want_stats && !e.train && !e.rec && g_fuse_bn_eval && !bias && act == ACT_NONE && !out_f32 && !out_ptr) {
+    // inference: the BatchNorm that follows (eval statistics) runs in this product's epilogue -- op_bn_act launches it
+    y->pend = std::make_shared<GemmP>(p); y->pend_mode = geo ? AM_CONV : AM_DENSE;
+    used(x);
+    return y;
+  }
   LCH(e, launch_gemm(e.dt, geo ? AM_CONV : AM_DENSE, p, e.s));
   // x is a BatchNorm output and this is its first consumer: our dgrad is the last writer of x's gradient, so its
   // epilogue can also produce that BatchNorm's backward column sums
@@ -615,6 +630,29 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
 Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res) {
   const int C = bn->C;
   const long M = y->rows;
+  if (y->pend) {
+    Tensor* z = e.newt(M, C, y->B, y->H, y->W);
+    GemmP p = *y->pend;
+    const float* ev = (const float*)(e.m->ws + e.m->off_bn_eval) + bn->eval_off;
+    p.C = z->p; p.ldc = C; p.escale = ev; p.eshift = ev + C; p.act = act; p.eres = res ? res->p : nullptr;
+    e.nflops = 2.0 * (double)p.M * p.N * p.K; e.nbytes = ((double)M * C * (res ? 2 : 1) + (double)p.N * p.K) * e.esz();
+    LCH(e, launch_gemm(e.dt, y->pend_mode, p, e.s));
+    y->pend.reset();
+    used(res);
+    return z;
+  }
+  if (y->pend_dw) {
+    auto fn = y->pend_dw;
+    y->pend_dw = nullptr;
+    if (!res) {
+      Tensor* z = e.newt(M, C, y->B, y->H, y->W);
+      const float* ev = (const float*)(e.m->ws + e.m->off_bn_eval) + bn->eval_off;
+      e.nbytes = (double)M * C * e.esz() * 2;
+      fn(ev, ev + C, act, z->p);
+      return z;
+    }
+    fn(nullptr, nullptr, 0, y->p);  // a residual is added by the separate pass below: run the plain convolution first
+  }
   float* ss = (float*)e.alloc((size_t)2 * C * 4);
   float* mr = (float*)e.alloc((size_t)2 * C * 4);
   float* sums = nullptr;
@@ -672,6 +710,15 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
   const int B = x->B, H = x->H, W = x->W, C = x->C;
   Tensor* y = e.newt((long)B * OH * OW, C, B, OH, OW);
   if (want_stats && e.train) y->stats = e.zalloc(2 * C);
+  if (want_stats && !e.train && !e.rec && g_fuse_bn_eval) {
+    // inference: the BatchNorm that follows runs in this kernel's epilogue (launched by op_bn_act)
+    Exec* ep = &e;
+    const void* xp = x->p; const void* wf = w->fwd; const float* bp = bias ? bias->p : nullptr;
+    y->pend_dw = [=](const float* esc, const float* esh, int act, void* out) {
+      LCH((*ep), launch_dwconv(ep->dt, 0, xp, wf, bp, out, B, H, W, C, OH, OW, stride, pt, pl, 0, nullptr, ep->s, esc, esh, act));
+    };
+    return y;
+  }
   LCH(e, launch_dwconv(e.dt, 0, x->p, w->fwd, bias ? bias->p : nullptr, y->p, B, H, W, C, OH, OW, stride, pt, pl, 0, y->stats, e.s));
   if (e.rec)
     e.tape.push_back([&e, x, y, w, bias, B, H, W, C, OH, OW, stride, pt, pl]() {
@@ -980,7 +1027,24 @@ Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
   return op_bn_act(e, y3, &eb->bn3, ACT_NONE, skip);
 }
 
+// eval-mode scale/shift of every BatchNorm (running statistics may have changed since the last call: one launch)
+static void bn_eval_prepare(Exec& e) {
+  Model* m = e.m;
+  if (e.dry || !g_fuse_bn_eval) return;
+  BnEvalDesc* dev = (BnEvalDesc*)(m->ws + m->off_bn_desc);
+  if (m->bn_desc_dirty) {
+    m->bn_desc_host.clear();
+    float* tab = (float*)(m->ws + m->off_bn_eval);
+    for (BNp* b : m->all_bn) m->bn_desc_host.push_back(BnEvalDesc{b->w.p, b->b.p, b->rm, b->rv, tab + b->eval_off, b->eps, b->C});
+    // the host vector is a member: it outlives the asynchronous copy
+    (void)hipMemcpyAsync(dev, m->bn_desc_host.data(), m->bn_desc_host.size() * sizeof(BnEvalDesc), hipMemcpyHostToDevice, e.s);
+    m->bn_desc_dirty = false;
+  }
+  launch_bn_eval_prepare(dev, (int)m->all_bn.size(), e.s);
+}
+
 Tensor* encoder_forward(Exec& e, const float* img, int B) {
+  if (!e.train && !e.rec) bn_eval_prepare(e);
   Model* m = e.m;
   const SatrnConfig& c = m->cfg;
   Tensor* x;

@@ -48,7 +48,8 @@ struct Wt {
   void* fwd = nullptr; void* bwd = nullptr;  // packed compute copies
   int64_t pk_fwd_off = -1, pk_bwd_off = -1;  // byte offsets inside the persistent region
 };
-struct BNp { Vec w, b; int64_t rm_off = -1, rv_off = -1, nbt_off = -1; float* rm = nullptr; float* rv = nullptr; int64_t* nbt = nullptr; int C = 0; float eps = 1e-5f; };
+struct BNp { Vec w, b; int64_t rm_off = -1, rv_off = -1, nbt_off = -1; float* rm = nullptr; float* rv = nullptr; int64_t* nbt = nullptr; int C = 0; float eps = 1e-5f;
+             size_t eval_off = 0; /* floats into the eval scale/shift table [2C] */ };
 struct LNp { Vec w, b; int C = 0; };
 struct MHAp { Wt qkv;   /* fused [3D][K] when q and kv share the input width, else q only */
               Wt kv;    /* cross attention: [2D][Ksrc] */
@@ -73,6 +74,10 @@ struct Tensor {
   // true gradient is g*se_gate[b] + se_dpool[b]/se_hw
   const void* se_gate = nullptr; const void* se_dpool = nullptr; int se_hw = 0;
   bool bn_has_res = false;  // the BatchNorm that produced this tensor also added a residual (its gradient = this tensor's)
+  // inference: a product whose launch is postponed until the BatchNorm that consumes it is known, so that BatchNorm (eval
+  // statistics) + activation + residual run in its epilogue and the raw output is never written (op_gemm -> op_bn_act)
+  std::shared_ptr<GemmP> pend; int pend_mode = 0;
+  std::function<void(const float* escale, const float* eshift, int act, void* out)> pend_dw;  // same for a depthwise conv
 };
 
 struct EffBlock { int type, cin, cout, mid, stride, se; bool skip; Wt c0, c1, dw, se_r, se_e; Vec se_rb, se_eb; BNp bn1, bn2, bn3; };
@@ -103,6 +108,7 @@ struct Model {
          off_stage_img = 0, off_stage_tgt = 0, off_zero = 0;
   size_t zero_bytes = 0, zero_hwm = 0;
   size_t off_sumsq = 0;
+  size_t off_bn_eval = 0, off_bn_desc = 0; std::vector<BnEvalDesc> bn_desc_host; bool bn_desc_dirty = true;
   size_t off_packdesc = 0, packdesc_bytes = 0, off_packblk = 0, packblk_bytes = 0; int pack_n = 0; long pack_total = 0; bool pack_dirty = true;
   int stage_B = 0, stage_L = 0;
   int feat_h = 0, feat_w = 0;

@@ -20,7 +20,14 @@ struct GemmP {
   // optional (dgrad of a BatchNorm output, N == the BN's C): stats become the BN backward's column sums
   // [sum g, sum g*xhat] with g = dz_total*act'(y*scale+shift), so the separate reduction pass disappears
   const void* bnb_y; const float* bnb_ss; const float* bnb_mr; int bnb_act;
+  // optional inference epilogue (eval-mode BatchNorm folded in): out = act(acc * escale[col] + eshift[col]) + eres[row][col]
+  // (eres: residual in the compute dtype with row stride ldc, may be null)
+  const float* escale; const float* eshift; const void* eres;
 };
+// eval-mode BatchNorm scale / shift of every BatchNorm of a model in ONE launch: out[0..C) = w * rsqrt(rv + eps),
+// out[C..2C) = b - rm * scale
+struct BnEvalDesc { const float* w; const float* b; const float* rm; const float* rv; float* out; float eps; int C; };
+void launch_bn_eval_prepare(const BnEvalDesc* descs_dev, int n, hipStream_t s);
 void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s);
 
 // dW[n][k] (+)= sum_m dY[m][n] * gatherA[m][k]
@@ -79,7 +86,8 @@ void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int 
                        int OH, int OW, int stride, int pad, hipStream_t s);
 void launch_dwconv(int dt, int mode /*0 fwd,1 dgrad*/, const void* x, const void* wp /*[9][C] as T*/, const float* bias,
                    void* y, int B, int H, int W, int C, int OH, int OW, int stride, int pt, int pl, int beta,
-                   float* stats /*optional [2C] zeroed: column sums of y (mode 0)*/, hipStream_t s);
+                   float* stats /*optional [2C] zeroed: column sums of y (mode 0)*/, hipStream_t s,
+                   const float* escale = nullptr, const float* eshift = nullptr, int eact = 0 /*inference (mode 0): y = act(conv*escale[c] + eshift[c])*/);
 void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw /*[C][9] torch layout*/, float* dbias,
                          float* scratch10C /*optional zeroed [10][C]: contiguous atomics + scatter*/, int B, int H, int W,
                          int C, int OH, int OW, int stride, int pt, int pl, hipStream_t s);

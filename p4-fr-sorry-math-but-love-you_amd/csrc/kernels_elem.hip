@@ -158,6 +158,18 @@ void launch_bn_finalize(const float* sums, long M, int C, const float* w, const 
                      rm, rv, nbt, eps, mom, train, ss, mr);
 }
 
+__global__ void bn_eval_prepare_kernel(const BnEvalDesc* descs) {
+  const BnEvalDesc d = descs[blockIdx.x];
+  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+    const float sc = d.w[c] * rsqrtf(d.rv[c] + d.eps);
+    d.out[c] = sc;
+    d.out[d.C + c] = d.b[c] - d.rm[c] * sc;
+  }
+}
+void launch_bn_eval_prepare(const BnEvalDesc* descs_dev, int n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(n), dim3(256), 0, s, descs_dev);
+}
+
 // grid for streaming kernels with per-channel parameters: total threads is a multiple of the chunk count CC, so a
 // thread always meets the same channel chunk and keeps its parameters in registers
 static inline int grid_chan(long nchunks, int CC) {
@@ -488,7 +500,7 @@ void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int 
 // ---- depthwise 3x3 (forward gather / transposed gather for the data gradient) -----------------------
 template <typename T, int MODE>
 __global__ void dwconv_kernel(const T* x, const T* wp, const float* bias, T* y, int B, int H, int W, int C, int OH,
-                              int OW, int stride, int pt, int pl, int beta) {
+                              int OW, int stride, int pt, int pl, int beta, const float* esc, const float* esh, int eact) {
   // MODE 0: x = input [B,H,W,C], y = output [B,OH,OW,C].  MODE 1: x = dY [B,H,W,C] (H,W = conv OUTPUT dims),
   // y = dX [B,OH,OW,C] (OH,OW = conv INPUT dims).  One thread per output chunk: these tensors are small and
   // L2-resident, so occupancy (not instruction count) is what hides the nine gathers.
@@ -528,6 +540,12 @@ __global__ void dwconv_kernel(const T* x, const T* wp, const float* bias, T* y, 
       }
     }
     T* o = y + pix * C + cc * CH;
+    if (esc) {  // inference: eval-mode BatchNorm + activation folded in
+      float sc[CH], sh[CH];
+      ldv(esc + cc * CH, sc, CH); ldv(esh + cc * CH, sh, CH);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[j] = act_fwd(acc[j] * sc[j] + sh[j], eact);
+    }
     if (beta) {
       float old[CH];
       unpack<T>(ld16(o), old);
@@ -542,7 +560,8 @@ __global__ void dwconv_kernel(const T* x, const T* wp, const float* bias, T* y, 
 // chunk is used twice (12 loads instead of 18 per pair, half the index arithmetic) -- these kernels are VALU-issue bound.
 // FLIP = data gradient (correlation with the kernel rotated by 180 degrees; identical for stride 1, pad 1).
 template <typename T, bool FLIP>
-__global__ void dwconv_s1_kernel(const T* x, const T* wp, const float* bias, T* y, int B, int H, int W, int C, int beta) {
+__global__ void dwconv_s1_kernel(const T* x, const T* wp, const float* bias, T* y, int B, int H, int W, int C, int beta,
+                                 const float* esc, const float* esh, int eact) {
   constexpr int CH = TT<T>::CH;
   const int CC = C / CH, W2 = W >> 1;
   const long total = (long)B * H * W2 * CC;
@@ -580,6 +599,12 @@ __global__ void dwconv_s1_kernel(const T* x, const T* wp, const float* bias, T* 
       }
     }
     T* o = y + (((long)b * H + oy) * W + ox) * C + cc * CH;
+    if (esc) {  // inference: eval-mode BatchNorm + activation folded in
+      float sc[CH], sh[CH];
+      ldv(esc + cc * CH, sc, CH); ldv(esh + cc * CH, sh, CH);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { a0[j] = act_fwd(a0[j] * sc[j] + sh[j], eact); a1[j] = act_fwd(a1[j] * sc[j] + sh[j], eact); }
+    }
     if (beta) {
       float o0[CH], o1[CH];
       unpack<T>(ld16(o), o0); unpack<T>(ld16(o + C), o1);
@@ -592,17 +617,18 @@ __global__ void dwconv_s1_kernel(const T* x, const T* wp, const float* bias, T* 
 }
 
 void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float* bias, void* y, int B, int H, int W,
-                   int C, int OH, int OW, int stride, int pt, int pl, int beta, float* stats, hipStream_t s) {
+                   int C, int OH, int OW, int stride, int pt, int pl, int beta, float* stats, hipStream_t s,
+                   const float* esc, const float* esh, int eact) {
   static const bool no_s1 = getenv("SATRN_DW_NO_S1") != nullptr;
   if (!no_s1 && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && (W & 1) == 0) {
     DISPATCH_T(dt, {
       long n2 = (long)B * H * (W / 2) * (C / TT<T>::CH);
       if (mode == 0)
         hipLaunchKernelGGL((dwconv_s1_kernel<T, false>), dim3(grid_for(n2)), dim3(256), 0, s, (const T*)x, (const T*)wp, bias,
-                           (T*)y, B, H, W, C, beta);
+                           (T*)y, B, H, W, C, beta, esc, esh, eact);
       else
         hipLaunchKernelGGL((dwconv_s1_kernel<T, true>), dim3(grid_for(n2)), dim3(256), 0, s, (const T*)x, (const T*)wp, bias,
-                           (T*)y, B, H, W, C, beta);
+                           (T*)y, B, H, W, C, beta, esc, esh, eact);
       if (stats && mode == 0) launch_colstats(dt, y, (long)B * OH * OW, C, stats, s);
     });
     return;
@@ -611,10 +637,10 @@ void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float*
     long n = (long)B * OH * OW * (C / TT<T>::CH);
     if (mode == 0)
       hipLaunchKernelGGL((dwconv_kernel<T, 0>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)wp, bias,
-                         (T*)y, B, H, W, C, OH, OW, stride, pt, pl, beta);
+                         (T*)y, B, H, W, C, OH, OW, stride, pt, pl, beta, esc, esh, eact);
     else
       hipLaunchKernelGGL((dwconv_kernel<T, 1>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)x, (const T*)wp, bias,
-                         (T*)y, B, H, W, C, OH, OW, stride, pt, pl, beta);
+                         (T*)y, B, H, W, C, OH, OW, stride, pt, pl, beta, esc, esh, eact);
     if (stats && mode == 0) launch_colstats(dt, y, (long)B * OH * OW, C, stats, s);
   });
 }

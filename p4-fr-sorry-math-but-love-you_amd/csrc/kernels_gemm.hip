@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + j * 16 + fr;
     const float bias = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+    const float esc = (p.escale && col < p.N) ? p.escale[col] : 1.f, esh = (p.escale && col < p.N) ? p.eshift[col] : 0.f;
     float s1 = 0.f, s2 = 0.f;
     float bsc = 0.f, bsh = 0.f, bmu = 0.f, brs = 0.f;
     if (p.bnb_y && col < p.N) { bsc = p.bnb_ss[col]; bsh = p.bnb_ss[p.N + col]; bmu = p.bnb_mr[col]; brs = p.bnb_mr[p.N + col]; }
@@ -167,9 +168,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wave * (BM / 4) + i * 16 + fq * 4 + r;
         if (row >= p.M || col >= p.N) continue;
-        float v = act_fwd(acc[i][j][r] + bias, p.act);
+        float v = act_fwd(acc[i][j][r] * esc + esh + bias, p.act);
         if (p.drop_p > 0.f) v *= drop_scale(seed, p.site, (uint32_t)(row * p.N + col), p.drop_p);
         const long o = (long)row * p.ldc + col;
+        if (p.eres) v += to_f(((const T*)p.eres)[o]);
         float tot;
         if (p.out_f32) {
           float* c = (float*)p.C;
@@ -356,6 +358,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, in
     float s1 = 0.f, s2 = 0.f;
     float bsc = 0.f, bsh = 0.f, bmu = 0.f, brs = 0.f;
     if (p.bnb_y && col < p.N) { bsc = p.bnb_ss[col]; bsh = p.bnb_ss[p.N + col]; bmu = p.bnb_mr[col]; brs = p.bnb_mr[p.N + col]; }
+    const float esc = (p.escale && col < p.N) ? p.escale[col] : 1.f, esh = (p.escale && col < p.N) ? p.eshift[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -363,8 +366,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, in
         const int gy = y0 + wave * 2 + i, gx = x0 + fq * 4 + r;
         if (gy >= Himg || gx >= Wimg || col >= p.N) continue;
         const long row = ((long)b * Himg + gy) * Wimg + gx;
-        const float v = acc[i][j][r];
         const long o = row * p.ldc + col;
+        float v = acc[i][j][r];
+        if (p.escale) {  // inference: eval-mode BatchNorm + activation (+ residual) folded in
+          v = act_fwd(v * esc + esh, p.act);
+          if (p.eres) v += to_f(((const bf16_t*)p.eres)[o]);
+        }
         T* c = (T*)p.C;
         const float tot = p.beta ? to_f(c[o]) + v : v;
         c[o] = from_f<T>(tot);
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, in
 static bool conv_halo_launch(int amode, const GemmP& p, hipStream_t s) {
   static const bool off = getenv("SATRN_NO_HALO_CONV") != nullptr;
   if (off || p.KW != 3 || p.stride != 1 || p.pt != 1 || p.pl != 1 || p.OH != p.H || p.OW != p.W) return false;
-  if (p.bias || p.act || p.drop_p > 0.f || p.out_f32 || (p.Ci & 7) || p.ldc != p.N) return false;
+  if (p.bias || (p.act && !p.escale) || p.drop_p > 0.f || p.out_f32 || (p.Ci & 7) || p.ldc != p.N) return false;
   const int C = p.Ci, H = p.OH, W = p.OW;
   const int B = p.M / (H * W);
   if ((long)B * H * W != p.M) return false;
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
 template <typename T>
 static bool gemm_skinny_launch(const GemmP& p, hipStream_t s) {
   static const bool off = getenv("SATRN_NO_SKINNY_GEMM") != nullptr;
-  if (off || p.M > 64 || (p.K & 31) || p.K > 1024 || p.stats || p.bnb_y || (p.lda & 7)) return false;
+  if (off || p.M > 64 || (p.K & 31) || p.K > 1024 || p.stats || p.bnb_y || p.escale || (p.lda & 7)) return false;
   const int mt = (p.M + 15) / 16;
   const int steps = ((p.K >> 5) + 3) / 4;  // k-steps per wave
   const dim3 g((p.N + 15) / 16), b(256);
