@@ -37,7 +37,7 @@ DEVI const T* kp_addr(const T* W, int Ntot, int row, int kk, int fq) { return W 
 
 template <typename T>
 DEVI void gemv(const T* __restrict__ W, int Ntot, int row0, const float* __restrict__ bias, const T* xT, float* y, int N, int K,
-               int act) {
+               int act, T* yT = nullptr /*optional: the output also in the compute dtype (the next product's input)*/) {
   constexpr int CH = TT<T>::CH;
   constexpr int GU = 2;  // 16-output groups per wave iteration: 2 x 8 weight loads in flight per lane
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -76,20 +76,17 @@ DEVI void gemv(const T* __restrict__ W, int Ntot, int row0, const float* __restr
           const int n = (g0 + u) * 16 + fq * 4 + r;
           if (n < N) {
             float v = acc[u][r] + (bias ? bias[n] : 0.f);
-            y[n] = act == ACT_RELU ? fmaxf(v, 0.f) : v;
+            v = act == ACT_RELU ? fmaxf(v, 0.f) : v;
+            y[n] = v;
+            if (yT) yT[n] = from_f<T>(v);
           }
         }
     }
   }
 }
-// f32 vector -> compute dtype (LDS to LDS)
-template <typename T> DEVI void to_t(const float* src, T* dst, int n) {
-  for (int i = threadIdx.x; i < n; i += DEC_THREADS) dst[i] = from_f<T>(src[i]);
-  __syncthreads();
-}
-
-// v[0..D) <- LayerNorm(v + r) * w + b   (in place; red = LDS scratch of 2*DEC_WAVES floats)
-DEVI void add_layernorm(float* v, const float* r, const float* w, const float* b, int D, float* red) {
+// v[0..D) <- LayerNorm(v + r) * w + b   (in place; red = LDS scratch of 2*DEC_WAVES floats); vT (and v2) receive copies
+template <typename T>
+DEVI void add_layernorm(float* v, const float* r, const float* w, const float* b, int D, float* red, T* vT, float* v2 = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float x = 0.f;
   if (tid < D) x = v[tid] + r[tid];
@@ -108,7 +105,12 @@ DEVI void add_layernorm(float* v, const float* r, const float* w, const float* b
 #pragma unroll
   for (int i = 0; i < DEC_WAVES; ++i) var += red[DEC_WAVES + i];
   float rstd = rsqrtf(var / (float)D + 1e-5f);
-  if (tid < D) v[tid] = d * rstd * w[tid] + b[tid];
+  if (tid < D) {
+    const float o = d * rstd * w[tid] + b[tid];
+    v[tid] = o;
+    if (v2) v2[tid] = o;
+    vT[tid] = from_f<T>(o);  // the next product's input: no separate conversion pass
+  }
   __syncthreads();
 }
 
@@ -121,7 +123,7 @@ DEVI void add_layernorm(float* v, const float* r, const float* w, const float* b
 // node's ancestors.
 template <typename T, bool IDX = false>
 DEVI void attend(const float* q, const T* kv, long ld, int voff, int nk, int H, int hd, float inv_temp, float* sc /*[H][nkP]*/,
-                 int nkP, float* o, float* wred, const int* krow = nullptr) {
+                 int nkP, float* o, float* wred, T* oT, const int* krow = nullptr) {
   constexpr int CH = TT<T>::CH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = H * hd;
@@ -182,6 +184,7 @@ DEVI void attend(const float* q, const T* kv, long ld, int voff, int nk, int H, 
 #pragma unroll
     for (int w = 0; w < DEC_WAVES; ++w) v += wred[w * D + tid];
     o[tid] = v;
+    oT[tid] = from_f<T>(v);
   }
   __syncthreads();
 }
@@ -207,14 +210,14 @@ template <typename T> DEVI DecSm<T> dec_carve(float* sm, const DecodeP& p) {
   S.red = S.sc + scn;       // [2*DEC_WAVES]
   S.lg = S.red + 2 * DEC_WAVES;       // [V] (padded to a multiple of 4)
   S.wred = S.lg + ((V + 3) & ~3);     // [DEC_WAVES][D] per-wave partial attention outputs
-  S.xT = reinterpret_cast<T*>(S.wred + DEC_WAVES * D);  // [max(D,F)] current GEMV input in the compute dtype (16-byte aligned)
-  S.end = S.wred + DEC_WAVES * D + (F > D ? F : D);     // (an f32 slot per element: more than T needs)
+  S.xT = reinterpret_cast<T*>(S.wred + DEC_WAVES * D);  // [D + F] product inputs in the compute dtype: [0,D) the running vector, [D,D+F) the FFN hidden
+  S.end = S.wred + DEC_WAVES * D + (D + F);             // (an f32 slot per element: more than T needs)
   return S;
 }
 static size_t dec_lds_floats(const DecodeP& p) {
   const int nkP = ((p.steps > p.Nsrc ? p.steps : p.Nsrc) + 3) & ~3;
   const int scn = p.H * nkP > 4 * p.D ? p.H * nkP : 4 * p.D;
-  return (size_t)(6 * p.D + p.F + scn + 2 * DEC_WAVES + ((p.V + 3) & ~3) + DEC_WAVES * p.D + (p.F > p.D ? p.F : p.D));
+  return (size_t)(6 * p.D + p.F + scn + 2 * DEC_WAVES + ((p.V + 3) & ~3) + DEC_WAVES * p.D + (p.D + p.F));
 }
 
 #define TICK(k) do { if (p.prof && b == 0 && tid == 0) { long long now_ = (long long)wall_clock64(); p.prof[k] += now_ - tlast; tlast = now_; } } while (0)
@@ -229,66 +232,52 @@ DEVI void dec_step(const DecodeP& p, const DecSm<T>& S, int b, int slot, int nk,
   float *x = S.x, *qkv = S.qkv, *att = S.att, *tmp = S.tmp, *ff = S.ff, *sc = S.sc, *red = S.red, *wred = S.wred;
   T* xT = S.xT;
   const int nkP = S.nkP;
+  // S.xT holds the compute-dtype copy of S.x on entry (written with the embedding) and of every later product input:
+  // each producer (LayerNorm, attention, the FFN's first product) writes it next to its f32 output
   for (int l = 0; l < p.nlayers; ++l) {
     const DecLayerW& w = p.L[l];
     T* cache = (T*)w.cache + (long)b * p.steps * 2 * D;  // this row's [steps][2D]
     // q | k | v of the layer INPUT
-    to_t<T>(x, xT, D);
-    TICK(0);
     if (!(p.dbg & 8)) gemv<T>((const T*)w.wqkv, 3 * D, 0, w.bqkv, xT, qkv, 3 * D, D, ACT_NONE);
     __syncthreads();
     TICK(1);
     for (int i = tid; i < 2 * D; i += DEC_THREADS) cache[(long)slot * 2 * D + i] = from_f<T>(qkv[D + i]);
     __syncthreads();
     TICK(0);
-    attend<T, IDX>(qkv, cache, 2 * D, D, (p.dbg & 1) ? 1 : nk, H, hd, inv_temp, sc, nkP, att, wred, idx);
+    attend<T, IDX>(qkv, cache, 2 * D, D, (p.dbg & 1) ? 1 : nk, H, hd, inv_temp, sc, nkP, att, wred, xT, idx);
     TICK(2);
-    to_t<T>(att, xT, D);
-    TICK(0);
     gemv<T>((const T*)w.wo, D, 0, w.bo, xT, tmp, D, D, ACT_NONE);
     __syncthreads();
     TICK(3);
-    add_layernorm(tmp, x, w.ln1w, w.ln1b, D, red);          // tmp = t1
+    add_layernorm<T>(tmp, x, w.ln1w, w.ln1b, D, red, xT);          // tmp = t1
     TICK(4);
-    to_t<T>(tmp, xT, D);
-    TICK(0);
     gemv<T>((const T*)w.wq2, D, 0, w.bq2, xT, qkv, D, D, ACT_NONE);
     __syncthreads();
     TICK(3);
-    attend<T, false>(qkv, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D, 2 * D, D, (p.dbg & 2) ? 1 : p.Nsrc, H, hd, inv_temp, sc, nkP, att, wred);
+    attend<T, false>(qkv, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D, 2 * D, D, (p.dbg & 2) ? 1 : p.Nsrc, H, hd, inv_temp, sc, nkP, att, wred, xT);
     TICK(5);
-    to_t<T>(att, xT, D);
-    TICK(0);
     gemv<T>((const T*)w.wo2, D, 0, w.bo2, xT, x, D, D, ACT_NONE);
     __syncthreads();
     TICK(3);
-    add_layernorm(x, tmp, w.ln2w, w.ln2b, D, red);           // x = t2
+    add_layernorm<T>(x, tmp, w.ln2w, w.ln2b, D, red, xT);           // x = t2
     TICK(4);
-    to_t<T>(x, xT, D);
-    TICK(0);
-    if (!(p.dbg & 4)) gemv<T>((const T*)w.w0, F, 0, w.b0, xT, ff, F, D, ACT_RELU);
+    // the second FFN product reads xT while the first one is still writing it: its input goes to a separate region
+    T* ffT = xT + D;
+    if (!(p.dbg & 4)) gemv<T>((const T*)w.w0, F, 0, w.b0, xT, ff, F, D, ACT_RELU, ffT);
     __syncthreads();
     TICK(6);
-    to_t<T>(ff, xT, F);
-    TICK(0);
-    if (!(p.dbg & 4)) gemv<T>((const T*)w.w1, D, 0, w.b1, xT, tmp, D, F, ACT_RELU);
+    if (!(p.dbg & 4)) gemv<T>((const T*)w.w1, D, 0, w.b1, ffT, tmp, D, F, ACT_RELU);
     __syncthreads();
     TICK(7);
-    add_layernorm(tmp, x, w.ln3w, w.ln3b, D, red);           // tmp = t3 (layer output)
+    add_layernorm<T>(tmp, x, w.ln3w, w.ln3b, D, red, xT, x);        // x = tmp = t3 (layer output)
     TICK(4);
-    if (tid < D) x[tid] = tmp[tid];
-    __syncthreads();
     // history entry for later steps: k/v of the layer OUTPUT
-    to_t<T>(x, xT, D);
-    TICK(0);
     if (!(p.dbg & 16)) gemv<T>((const T*)w.wqkv, 3 * D, D, w.bkv, xT, qkv, 2 * D, D, ACT_NONE);  // rows D..3D of the fused q|k|v weight
     __syncthreads();
     TICK(8);
     for (int i = tid; i < 2 * D; i += DEC_THREADS) cache[(long)slot * 2 * D + i] = from_f<T>(qkv[i]);
     __syncthreads();
   }
-  to_t<T>(x, xT, D);
-  TICK(0);
   gemv<T>((const T*)p.wgen, V, 0, p.bgen, xT, S.lg, V, D, ACT_NONE);
   __syncthreads();
   TICK(9);
@@ -309,7 +298,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
   long long tlast = p.prof ? (long long)wall_clock64() : 0;
   for (int t = 0; t < p.steps; ++t) {
     // ---- embedding * sqrt(D) + PE(t)   (networks/EfficientSATRN.py:480-483, :425)
-    if (tid < D) x[tid] = p.embed[(long)tok * D + tid] * emb_scale + p.pe[(long)t * D + tid];
+    if (tid < D) { const float v0 = p.embed[(long)tok * D + tid] * emb_scale + p.pe[(long)t * D + tid]; x[tid] = v0; S.xT[tid] = from_f<T>(v0); }
     __syncthreads();
     dec_step<T, false>(p, S, b, t, t + 1, nullptr, tlast);
     // ---- argmax (lowest index wins ties, like torch.argmax)
@@ -415,7 +404,7 @@ __global__ __launch_bounds__(DEC_THREADS) void beam_search_kernel(DecodeP p, Bea
     }
     if (tid == 0) { prow[d - 1] = (uint16_t)e; idx[d - 1] = e; nslot[n] = e; }
     // embedding * sqrt(D) + PE(len - 1)   (:773-778)
-    if (tid < D) S.x[tid] = p.embed[(long)tok * D + tid] * emb_scale + p.pe[(long)(d - 1) * D + tid];
+    if (tid < D) { const float v0 = p.embed[(long)tok * D + tid] * emb_scale + p.pe[(long)(d - 1) * D + tid]; S.x[tid] = v0; S.xT[tid] = from_f<T>(v0); }
     __syncthreads();
     dec_step<T, true>(p, S, b, e, d, idx, tlast);
     // log_softmax + top-bw (:806-809), children (:813-829)
