@@ -1080,6 +1080,9 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
   Tensor* gate = op_gemm(e, h0, &m->pe_d1, &m->pe_b1, ACT_SIGMOID, 0.f, nullptr);
   x = op_posenc_apply(e, x, gate);
   for (auto& el : m->enc) x = encoder_layer(e, x, &el);
+  // inference postpones products until their BatchNorm is known (op_gemm / op_dwconv -> op_bn_act): none may be left over
+  for (auto& t : e.tens)
+    if (t->pend || t->pend_dw) { m->err = "internal: a postponed product was never launched"; e.oom = true; }
   return x;  // [B*HW][D] == [b, hw, c]
 }
 
