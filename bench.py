@@ -201,6 +201,20 @@ def main():
             dsec = (time.perf_counter() - t1) / reps
             out["greedy_decode"] = dict(value=round(64 * 231 / dsec, 1), unit="tokens/s", batch=64, steps=231,
                                         ms_per_batch=round(dsec * 1e3, 2), includes="encoder + 231 decoder steps")
+            # HBM roofline of the decode (38 MB of weights + mean KV history per 64-image step, bf16), with the
+            # encoder pass timed on its own and taken out
+            model.encode(dimg)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                model.encode(dimg)
+            torch.cuda.synchronize()
+            esec = (time.perf_counter() - t1) / reps
+            step_us = max(dsec - esec, 1e-9) / 231 * 1e6
+            out["greedy_decode"]["roofline"] = dict(bound="hbm", algorithmic_bytes_per_step=38.0e6, us_per_step=round(step_us, 1),
+                                                    achieved=round(38.0e6 / step_us / 1e3, 1), peak=8000.0, unit="GB/s",
+                                                    frac=round(38.0e6 / step_us / 1e3 / 8000.0, 4), encoder_ms=round(esec * 1e3, 2),
+                                                    note="one dependent chain per image: ~31 weight-streaming phases per step, each bound by a memory round trip and one CU's L2 bandwidth, not by HBM")
             # the same decode with the DecodingManager rules evaluated inside the decode kernel (the reference's default
             # at inference, inference.py:48); rule table = the reference RULES as compiled into tests/golden/rules.npz
             rules_npz = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "rules.npz")
