@@ -71,3 +71,29 @@ def get_network(model_type, FLAGS, model_checkpoint, device, dataset, decoding_m
     else:
         raise NotImplementedError
     return model
+
+
+def id_to_string(tokens, data_loader, do_eval=0):
+    """utils/utils.py:134-164: token ids [B, T] -> list of space-joined token strings (each token followed by a space).
+    do_eval: <PAD>/<SOS> skipped, decoding of a row stops at its first <EOS>; -1 entries are always skipped.
+    The reference calls .item() per token (B*T host syncs on a device tensor); here the ids cross to the host ONCE."""
+    rows = tokens.detach().cpu().tolist() if hasattr(tokens, "detach") else [list(r) for r in tokens]
+    id_to_token = data_loader.dataset.id_to_token
+    result = []
+    if do_eval:
+        t2i = data_loader.dataset.token_to_id
+        eos_id = t2i["<EOS>"]
+        special = {t2i["<PAD>"], t2i["<SOS>"], eos_id}
+    for example in rows:
+        parts = []
+        for token in example:
+            if do_eval:
+                if token not in special:
+                    if token != -1:
+                        parts.append(id_to_token[token])
+                elif token == eos_id:
+                    break
+            elif token != -1:
+                parts.append(id_to_token[token])
+        result.append("".join(p + " " for p in parts))
+    return result

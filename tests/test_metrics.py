@@ -74,3 +74,41 @@ def test_device_step_metrics_match_oracle():
     assert (r["sentences"], r["correct_sentences"], r["correct_symbols"], r["total_symbols"]) == (
         m["sentences"], m["correct_sentences"], m["correct_symbols"], m["total_symbols"])
     assert r["sum_wer"] == pytest.approx(m["sum_wer"], rel=1e-12)
+
+
+def test_id_to_string_follows_the_reference_loop():
+    """utils/utils.py:134-164 restated literally (per-token loop) against the one-transfer version."""
+    import satrn_amd
+
+    class DS:
+        token_to_id = {"<SOS>": 0, "<EOS>": 1, "<PAD>": 2}
+        id_to_token = {i: f"t{i}" for i in range(245)}
+    DS.id_to_token[244] = ""
+
+    class DL:
+        dataset = DS()
+
+    def ref(tokens, do_eval):
+        out = []
+        special = {2, 0, 1}
+        for ex in tokens:
+            s = ""
+            for tok in ex:
+                tok = tok.item()
+                if do_eval:
+                    if tok not in special:
+                        if tok != -1:
+                            s += DS.id_to_token[tok] + " "
+                    elif tok == 1:
+                        break
+                elif tok != -1:
+                    s += DS.id_to_token[tok] + " "
+            out.append(s)
+        return out
+
+    g = torch.Generator().manual_seed(3)
+    toks = torch.randint(-1, 245, (6, 17), generator=g)
+    toks[0, 5] = 1; toks[1, 0] = 1; toks[2, :] = 2; toks[3, 3] = 0; toks[4, 7] = 244
+    for do_eval in (0, 1):
+        assert satrn_amd.id_to_string(toks, DL, do_eval) == ref(toks, do_eval)
+    assert satrn_amd.id_to_string(toks[:0], DL, 1) == []
