@@ -169,13 +169,21 @@ DEVI void attend(const float* q, const T* kv, long ld, int voff, int nk, int H, 
 #pragma unroll
   for (int e = 0; e < CH; ++e) acc[e] = 0.f;
   const T* vp = kv + voff + dc * CH;
-#pragma unroll 4
-  for (int j = kg; j < nk; j += KG) {
+  // two keys per trip with both loads in flight (the partially unrolled form is not unrolled by the compiler: one dependent
+  // round trip per key); a key past the end re-reads key 0 with weight 0
+  for (int j = kg; j < nk; j += 2 * KG) {
+    const int j1 = j + KG;
+    const int j1c = j1 < nk ? j1 : 0;
+    const uint4 r0 = ld16(vp + (long)(IDX ? krow[j] : j) * ld);
+    const uint4 r1 = ld16(vp + (long)(IDX ? krow[j1c] : j1c) * ld);
+    const float p0 = sc[h * nkP + j], p1 = j1 < nk ? sc[h * nkP + j1c] : 0.f;
     float f[CH];
-    unpack<T>(ld16(vp + (long)(IDX ? krow[j] : j) * ld), f);
-    const float pj = sc[h * nkP + j];
+    unpack<T>(r0, f);
 #pragma unroll
-    for (int e = 0; e < CH; ++e) acc[e] += pj * f[e];
+    for (int e = 0; e < CH; ++e) acc[e] += p0 * f[e];
+    unpack<T>(r1, f);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc[e] += p1 * f[e];
   }
   for (int o2 = cpr; o2 < 64; o2 <<= 1) {
 #pragma unroll
