@@ -63,8 +63,7 @@ DEVI void gemv(const T* __restrict__ W, int Ntot, int row0, const float* __restr
         const int n = (g0 + u) * 16 + fq * 4 + r;
         bl[u][r] = (bias && n < N) ? bias[n] : 0.f;
       }
-#pragma unroll 8
-    for (int kk = 0; kk < K; kk += 32) {
+    auto kstep = [&](int kk) {
       Frag<T> a[GU], b;
 #pragma unroll
       for (int u = 0; u < GU; ++u) {
@@ -76,7 +75,16 @@ DEVI void gemv(const T* __restrict__ W, int Ntot, int row0, const float* __restr
       if (CH == 4) reinterpret_cast<uint4*>(&b)[1] = ld16(xr + kk + 4);
 #pragma unroll
       for (int u = 0; u < GU; ++u) mma(a[u], b, acc[u]);
+    };
+    // K in chunks of 8 k-steps with a CONSTANT trip count: `#pragma unroll 8` on the runtime loop is refused (the MFMA is a
+    // convergent operation, so no remainder loop may be generated) and the loop then runs one k-step -- one dependent memory
+    // round trip -- at a time; the constant inner loop is unrolled and its 8 x GU weight loads are all in flight together
+    int kk = 0;
+    for (; kk + 256 <= K; kk += 256) {
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) kstep(kk + s8 * 32);
     }
+    for (; kk < K; kk += 32) kstep(kk);
     if (fr == 0) {
 #pragma unroll
       for (int u = 0; u < GU; ++u)
