@@ -87,6 +87,42 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    as a child, pass its stderr through, print the ONE JSON line rank 0 produced and check it really came from N ranks."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()  # counting devices does not initialise the GPU in this process
+    if have < n:
+        log(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible")
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            log(ln)
+    if proc.returncode != 0 or line is None:
+        log(f"bench.py: the {n}-rank job failed (exit code {proc.returncode}, JSON line {'found' if line else 'missing'})")
+        return proc.returncode or 3
+    got = json.loads(line)
+    if got.get("n_gpus") != n or got.get("rccl_ranks") != n:
+        log(f"bench.py: asked for {n} ranks, the line reports n_gpus={got.get('n_gpus')} rccl_ranks={got.get('rccl_ranks')}")
+        return 4
+    print(line, flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,9 +135,16 @@ def main():
     ap.add_argument("--no-decode", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched bare (no torchrun): start the N ranks ourselves as CHILD processes -- before this process touches the
+        # GPU -- relay rank 0's JSON line and leave with the launcher's exit code (never exec-replace: see the round notes)
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -179,7 +222,7 @@ def main():
         roof["share_of_step_kernel_time"] = round(dom["ms"] / max(tot_ms, 1e-9), 4)
         roof["whole_step_mfma_frac"] = round(FLOP_PER_IMG_TRAIN * B / (ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 5)
         out = dict(metric="train images/sec (whole node) EfficientSATRN bs32/GPU 128x384", value=round(value, 2), unit="images/s",
-                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True,
+                   n_gpus=world, rccl_ranks=(dist.get_world_size() if dist is not None else 1), steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                    config=dict(workload="EfficientSATRN train step (fwd+CE+bwd+clip+AdamW), bs32/GPU, 1x128x384, teacher-forced T=128, dropout 0.1 (BASELINE configs[1])",
                                global_batch=world * B, seq_len=T, parallelism=f"dp{world}", hipgraph=graph, streams=1 if graph else 2,

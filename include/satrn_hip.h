@@ -226,7 +226,10 @@ int satrn_model_loss_backward(satrn_model* m, const int64_t* expected, int B, in
  * backbone stage; 3 = the rest.  When call k returns, the flat-gradient range satrn_model_segment_range(k) is final on
  * `stream`, so its all-reduce can run (on another stream) while the following segments execute.  16 + k + 4*k_to runs
  * segments k..k_to in one call (one side-stream join at the end); the data-parallel driver uses 16 + 0 + 4*2 (segments
- * 0-2: 74 % of the parameters) followed by 16 + 3. */
+ * 0-2: 74 % of the parameters) followed by 16 + 3.
+ * + 32 (any of the above, eager): module.eval() semantics WITH gradients -- BatchNorm uses (and does not update) its running
+ * statistics, dropout is off; every sample is then independent of the rest of the batch, which is the mode the data-parallel
+ * equivalence test runs in (N ranks' averaged gradient == one rank's gradient on the concatenated batch). */
 int satrn_model_train_step(satrn_model* m, const float* images, const int64_t* expected, int B, int L,
                            const float* hyper9, int use_graph, int phase, void* stream);
 /* The dual-optimizer iteration of train_modules/train_dual_opt.py:87-113: as satrn_model_train_step (eager), but phase
@@ -281,9 +284,23 @@ int satrn_model_step(satrn_model* m, const int64_t* target, float* logits, void*
  * [{"kernel", "launches", "ms", "flops", "bytes"}...] (per kernel family, algorithmic flops / bytes) to json_out. */
 int satrn_model_profile_step(satrn_model* m, const float* images, const int64_t* expected, int B, int L, char* json_out,
                              size_t cap, void* stream);
-/* adam state access for checkpointing / tests (device pointers inside the workspace) */
+/* Optimizer state of the fused step (torch.optim.AdamW's exp_avg / exp_avg_sq / step, which the reference checkpoints:
+ * train_modules/train_single_opt.py:497-512 `optimizer.state_dict()`).  exp_avg / exp_avg_sq are caller-owned flat fp32
+ * DEVICE buffers of satrn_model_flat_size(m, 0) elements, borrowed until the next bind / destroy -- they are NOT part of the
+ * workspace, so replacing the workspace (satrn_model_set_workspace with a larger one for a longer batch) neither clears
+ * the moments nor restarts the bias correction; it also carries the dropout RNG state over from the old workspace, which
+ * must stay allocated until that call returns.  satrn_model_rng_state reads (set == 0) or writes the RNG word. */
+int satrn_model_bind_optimizer(satrn_model* m, float* exp_avg, float* exp_avg_sq);
+/* Device error word (read and cleared; synchronises `stream`): bit 0 = a decoder-input token id outside the embedding table,
+ * bit 1 = a loss target outside [0, V) other than ignore_index.  nn.Embedding / nn.CrossEntropyLoss raise on such input
+ * (the reference's loader pads `expected` with -1, data/loader.py:12-16, rewritten to <PAD> at
+ * train_modules/train_single_opt.py:78); the kernels skip the element and set the bit instead of reading out of bounds.
+ * satrn_model_read_loss checks the word too and fails with -6. */
+int satrn_device_error(void* stream);
 float* satrn_model_adam_state(satrn_model* m, int which /*0 exp_avg, 1 exp_avg_sq*/);
 int satrn_model_set_step(satrn_model* m, long t);
+long satrn_model_get_step(satrn_model* m);
+int satrn_model_rng_state(satrn_model* m, uint32_t* seed_io_host, int set, void* stream);
 
 #ifdef __cplusplus
 }

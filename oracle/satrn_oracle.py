@@ -536,7 +536,7 @@ def trainable_names(cfg):
     return [k for k, (_, kind) in param_specs(cfg).items() if not kind.startswith("bn_r") and kind != "bn_nbt"]
 
 
-def forward_backward(img, expected, sd, cfg, dtype=None, teacher_forcing=True):
+def forward_backward(img, expected, sd, cfg, dtype=None, teacher_forcing=True, bn_train=True):
     """One teacher-forced training forward + CE + backward on the oracle.
     Returns (loss, logits, grads{name}, bn_updates{name}).  dtype=torch.bfloat16 runs the same graph with every tensor
     in bf16 (PyTorch's own bf16 kernels): the yardstick for how much gradient noise bf16 storage costs."""
@@ -550,7 +550,13 @@ def forward_backward(img, expected, sd, cfg, dtype=None, teacher_forcing=True):
     st = _BNState()
     # teacher_forcing=False: the train-time autoregressive branch with gradients (networks/EfficientSATRN.py:496-525);
     # same arithmetic as the greedy loop, run under autograd with BN in batch-stat mode
-    logits = model_forward(img, expected, sd, cfg, True, teacher_forcing, st)
+    if bn_train:
+        logits = model_forward(img, expected, sd, cfg, True, teacher_forcing, st)
+    else:
+        # module.eval() with gradients (BatchNorm on its running statistics; the oracle has no dropout): what
+        # `model.eval(); model.decoder(model.encoder(x), text, True, L, 1.0)` computes in the reference
+        src = encoder_forward(img, sd, cfg, False, st)
+        logits = decoder_tf_forward(src, expected[:, :-1], sd, cfg)
     loss = loss_fn(logits.float(), expected)
     grads = torch.autograd.grad(loss, [sd[n] for n in names], allow_unused=True)
     g = OrderedDict((n, (gi if gi is not None else torch.zeros_like(sd[n])).float()) for n, gi in zip(names, grads))

@@ -345,8 +345,6 @@ Model* model_create(const SatrnConfig& cfg) {
     }
   }
   m->off_packed = 0;
-  m->off_adam_m = take((size_t)m->n_params * 4);
-  m->off_adam_v = take((size_t)m->n_params * 4);
   m->off_scalars = take(SC_COUNT * 4);
   m->off_sumsq = take(1024 * 4);
   m->off_pe1d = take((size_t)500 * Dd * 4);
@@ -367,6 +365,12 @@ Model* model_create(const SatrnConfig& cfg) {
     for (BNp* b : m->all_bn) { b->eval_off = tot; tot += (size_t)2 * b->C; }
     m->off_bn_eval = take(tot * 4);
     m->off_bn_desc = take(m->all_bn.size() * sizeof(BnEvalDesc) + 16);
+  }
+  // f32 is the parity mode: cross-workgroup float reductions go through fixed-order partial slabs instead of atomics
+  // (SATRN_DETERMINISTIC=1 forces it for bf16 too, SATRN_NONDET=1 switches it off)
+  if ((cfg.dtype == DT_F32 || getenv("SATRN_DETERMINISTIC")) && !getenv("SATRN_NONDET")) {
+    m->det_floats = (size_t)8 << 20;
+    m->off_det = take(2 * m->det_floats * sizeof(float));
   }
   m->zero_bytes = 40u << 20;
   m->off_zero = take(m->zero_bytes);
@@ -408,8 +412,31 @@ int model_bind(Model* m, float* params, float* grads, float* buf_f32, int64_t* b
 
 static float* scal(Model* m) { return (float*)(m->ws + m->off_scalars); }
 
+int model_bind_optimizer(Model* m, float* exp_avg, float* exp_avg_sq) {
+  m->adam_m = exp_avg; m->adam_v = exp_avg_sq;
+  for (int i = 0; i < 4; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
+  return 0;
+}
+
+// dropout RNG state (one uint32 on the device, advanced once per training step): read (set == 0) or written
+int model_rng_state(Model* m, uint32_t* seed_io, int set, hipStream_t s) {
+  if (!m->ws_set) { m->err = "set a workspace first"; return -1; }
+  if (set) (void)hipMemcpyAsync(m->ws + m->off_scalars + SC_SEED * 4, seed_io, 4, hipMemcpyHostToDevice, s);
+  else (void)hipMemcpyAsync(seed_io, m->ws + m->off_scalars + SC_SEED * 4, 4, hipMemcpyDeviceToHost, s);
+  (void)hipStreamSynchronize(s);
+  return 0;
+}
+
 int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s) {
   if (bytes < m->persist_bytes + (1u << 20)) { m->err = "workspace too small"; return -2; }
+  // a REPLACEMENT workspace (grown for a larger batch / longer sequence) continues the run: the dropout seed is carried
+  // over from the old one (the caller keeps it alive until this call returns); Adam's moments and step count are not in
+  // the workspace at all
+  uint32_t seed0 = 0x1234567u;
+  if (m->ws_set && m->ws && m->ws != (char*)ws) {
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(&seed0, m->ws + m->off_scalars + SC_SEED * 4, 4, hipMemcpyDeviceToHost);
+  }
   m->ws = (char*)ws; m->ws_bytes = bytes;
   // packed weights carry zero padding (generator: 245 -> 256 columns) that kernels multiply with zero gradients:
   // the padding must be finite, so clear everything once
@@ -450,17 +477,13 @@ int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s) {
   (void)hipStreamSynchronize(s);
   tab2d(m->feat_h, m->off_hpos);
   tab2d(m->feat_w, m->off_wpos);
-  (void)hipMemsetAsync(m->ws + m->off_adam_m, 0, (size_t)m->n_params * 4, s);
-  (void)hipMemsetAsync(m->ws + m->off_adam_v, 0, (size_t)m->n_params * 4, s);
   (void)hipMemsetAsync(m->ws + m->off_scalars, 0, SC_COUNT * 4, s);
   float one = 1.0f;
-  uint32_t seed0 = 0x1234567u;
   (void)hipMemcpyAsync(scal(m) + SC_ONE, &one, 4, hipMemcpyHostToDevice, s);
   (void)hipMemcpyAsync(scal(m) + SC_SEED, &seed0, 4, hipMemcpyHostToDevice, s);
   (void)hipStreamSynchronize(s);
   m->ws_set = true;
   m->pack_dirty = true;
-  m->adam_t = 0;
   return 0;
 }
 
@@ -544,7 +567,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
   p.act = act; p.out_f32 = out_f32 ? 1 : 0; p.drop_p = drop_p; p.seed = seed; p.site = site;
   if (want_stats && e.train) {
     // tall, narrow outputs (early backbone stages): many row tiles hit the same 2N addresses -> spread over replicas
-    const int rep = (N <= 64 && M >= 65536) ? 16 : ((N <= 256 && M >= 16384) ? 4 : 1);
+    const int rep = g_det.on ? 1 : ((N <= 64 && M >= 65536) ? 16 : ((N <= 256 && M >= 16384) ? 4 : 1));  // deterministic mode folds into ONE [2N]
     y->stats = e.zalloc((size_t)rep * 2 * N); y->stats_rep = rep; p.stats = y->stats; p.stats_rep = rep;
   }
   if (geo) { p.H = geo->H; p.W = geo->W; p.Ci = geo->Ci; p.OH = geo->OH; p.OW = geo->OW; p.KW = geo->KW; p.stride = geo->stride; p.pt = geo->pt; p.pl = geo->pl; }
@@ -606,7 +629,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       memset(&d, 0, sizeof(d));
       d.A = dY; d.Bw = w->bwd; d.C = dx; d.beta = beta;
       if (fuse_bnb) {
-        const int rep = (x->C <= 64 && x->rows >= 65536) ? 16 : ((x->C <= 256 && x->rows >= 16384) ? 4 : 1);
+        const int rep = g_det.on ? 1 : ((x->C <= 64 && x->rows >= 65536) ? 16 : ((x->C <= 256 && x->rows >= 16384) ? 4 : 1));
         x->bn_red = e.zalloc((size_t)rep * 2 * x->C); x->bn_red_rep = rep;
         d.stats = x->bn_red; d.stats_rep = rep; d.bnb_y = x->bn_y; d.bnb_ss = x->bn_ss; d.bnb_mr = x->bn_mr; d.bnb_act = x->bn_act;
       }
@@ -671,7 +694,8 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res) {
   used(y); used(res);
   if (e.rec) {
     if (e.train) { z->bn_y = y->p; z->bn_ss = ss; z->bn_mr = mr; z->bn_act = act; z->bn_has_res = res != nullptr; }
-    e.tape.push_back([&e, y, z, bn, act, res, ss, mr, M, C]() {
+    const int eval_stats = e.train ? 0 : 1;  // recorded forward with running statistics: dy = dz * act' * w * rstd, no batch terms
+    e.tape.push_back([&e, y, z, bn, act, res, ss, mr, M, C, eval_stats]() {
       if (!z->g) return;
       float* red = z->bn_red;  // already produced by the epilogue of the last kernel that wrote z's gradient?
       if (!red) {
@@ -682,7 +706,7 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res) {
       void* dy = e.grad(y, nullptr);
       e.nbytes = (double)M * C * e.esz() * 3;
       LCH(e, launch_bn_bwd_apply(e.dt, z->g, y->p, ss, mr, bn->w.p, red, M, C, act, dy, bn->w.g, bn->b.g, e.s, z->bn_red ? z->bn_red_rep : 1,
-                                 z->se_gate, z->se_dpool, z->se_hw));
+                                 z->se_gate, z->se_dpool, z->se_hw, eval_stats));
       if (res) acc_grad(e, res, z->g);
     });
   }
@@ -908,11 +932,11 @@ Tensor* op_embed(Exec& e, const int64_t* ids, int ld_ids, int B, int L, int pos0
   const uint32_t site = drop_p > 0.f ? e.site++ : 0;
   const uint32_t* seed = (const uint32_t*)(scal(m) + SC_SEED);
   const float* pe = (const float*)(m->ws + m->off_pe1d);
-  LCH(e, launch_embed(e.dt, ids, m->embed.p, pe, y->p, B, L, ld_ids, D, pos0, drop_p, seed, site, e.s));
+  LCH(e, launch_embed(e.dt, ids, m->embed.p, pe, y->p, B, L, ld_ids, D, pos0, drop_p, seed, site, e.s, m->embed.N));
   if (e.rec)
     e.tape.push_back([&e, m, ids, ld_ids, y, B, L, D, drop_p, seed, site]() {
       if (!y->g) return;
-      LCH(e, launch_embed_bwd(e.dt, ids, y->g, m->embed.g, B, L, ld_ids, D, drop_p, seed, site, e.s));
+      LCH(e, launch_embed_bwd(e.dt, ids, y->g, m->embed.g, B, L, ld_ids, D, drop_p, seed, site, e.s, m->embed.N));
     });
   return y;
 }
@@ -1219,8 +1243,19 @@ Tensor* decoder_tf(Exec& e, Tensor* src, const int64_t* expected, int B, int L, 
 // =====================================================================================================
 // model-level entry points
 // =====================================================================================================
+// the reduction mode is process-global state of the kernel launchers: every engine entry point that launches work selects
+// its own model's mode first
+static void det_activate(Model* m) {
+  g_det.on = (m->det_floats && m->ws) ? 1 : 0;
+  g_det.cap = m->det_floats;
+  g_det.scratch[0] = g_det.on ? (float*)(m->ws + m->off_det) : nullptr;
+  g_det.scratch[1] = g_det.on ? (float*)(m->ws + m->off_det) + m->det_floats : nullptr;
+  g_det.side = m->ex ? m->ex->s2 : nullptr;
+}
+
 static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) {
   Exec& e = *m->ex;
+  det_activate(m);
   e.s = s; e.dt = m->cfg.dtype; e.train = train; e.rec = rec; e.dry = dry;
   e.drop = train ? m->cfg.dropout : 0.f;
   if (!e.dry && e.zbase && e.zoff > m->zero_hwm) m->zero_hwm = e.zoff;  // what the previous call dirtied at most
@@ -1310,6 +1345,7 @@ static void segment_ranges(Model* m) {
 // runs segments seg..seg_to in one go (one side-stream join, at the end)
 int model_backward_segment(Model* m, const int64_t* expected, int B, int L, int seg, hipStream_t s, int seg_to) {
   Exec& e = *m->ex;
+  det_activate(m);
   if (!e.logits) { m->err = "no forward"; return -1; }
   if (seg_to < seg) seg_to = seg;
   if (seg != m->seg_next || seg < 0 || seg_to > 3) { m->err = "backward segments must run in order 0..3 after a recorded forward"; return -1; }
@@ -1340,6 +1376,7 @@ static void run_tape(Exec& e) {
 
 int model_backward(Model* m, const float* dlogits, hipStream_t s) {
   Exec& e = *m->ex;
+  det_activate(m);
   if (!e.logits || e.tape.empty()) { m->err = "no recorded forward"; return -1; }
   e.s = s;
   Tensor* lg = e.logits;
@@ -1354,6 +1391,7 @@ int model_backward(Model* m, const float* dlogits, hipStream_t s) {
 
 int model_loss_backward(Model* m, const int64_t* expected, int B, int L, hipStream_t s) {
   Exec& e = *m->ex;
+  det_activate(m);
   if (!e.logits) { m->err = "no forward"; return -1; }
   e.s = s;
   Tensor* lg = e.logits;
@@ -1376,6 +1414,9 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
   // decoder parameters are clipped SEPARATELY (clip_grad_norm_ per group) and stepped with their own learning rates
   if (hyper9_dec && use_graph) { m->err = "the dual-optimizer step runs eagerly (use_graph must be 0)"; return -1; }
   // 16 + k (+ 4 * k_to): backward segments k..k_to (k == 0 also zeroes the gradients and runs forward + CE)
+  // + 32: forward with BatchNorm RUNNING statistics and no dropout (module.eval() semantics) but gradients recorded -- the
+  // per-sample-independent mode in which N ranks' averaged gradients equal one rank's on the concatenated batch
+  const bool train_mode = !(phase & 32);
   const int seg = (phase & 16) ? (phase & 3) : -1;
   const int seg_to = (phase >> 2) & 3;
   if (seg >= 0) {
@@ -1383,7 +1424,7 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
     if (seg == 0) {
       launch_seed_advance((uint32_t*)(scal(m) + SC_SEED), s);
       launch_fill(m->grads, 0, (size_t)m->n_params * 4, s);
-      int rc = model_forward(m, img, expected, B, L, true, true, nullptr, s);
+      int rc = model_forward(m, img, expected, B, L, train_mode, true, nullptr, s);
       if (rc) return rc;
     }
     return model_backward_segment(m, expected, B, L, seg, s, seg_to);
@@ -1391,6 +1432,8 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
   phase &= 3;
   if (!phase) return 0;
   if (!m->bound || !m->ws_set || !m->grads) { m->err = "bind parameters/grads and set a workspace first"; return -1; }
+  if ((phase & 2) && (!m->adam_m || !m->adam_v)) { m->err = "bind the optimizer state first (satrn_model_bind_optimizer)"; return -1; }
+  if (!train_mode) use_graph = 0;  // the captured graphs are the training-mode step
   // hyper-parameters for this step (lr changes every iteration in the reference's scheduler)
   if (phase & 2) m->adam_t += 1;
   if (!m->hy_pinned && hipHostMalloc((void**)&m->hy_pinned, 64 * 16 * sizeof(float), 0) != hipSuccess) { m->err = "hipHostMalloc failed"; return -5; }
@@ -1413,14 +1456,14 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
     if (phase & 1) {
       launch_seed_advance((uint32_t*)(scal(m) + SC_SEED), s);
       launch_fill(m->grads, 0, (size_t)m->n_params * 4, s);
-      int rc = model_forward(m, img, expected, B, L, true, true, nullptr, s);
+      int rc = model_forward(m, img, expected, B, L, train_mode, true, nullptr, s);
       if (rc) return rc;
       rc = model_loss_backward(m, expected, B, L, s);
       if (rc) return rc;
     }
     if (phase & 2) {
-      float* am = (float*)(m->ws + m->off_adam_m);
-      float* av = (float*)(m->ws + m->off_adam_v);
+      float* am = m->adam_m;
+      float* av = m->adam_v;
       launch_fill(scal(m) + SC_GNORM, 0, 8, s);  // both norm slots
       if (!hyper9_dec) {
         launch_sumsq(m->grads, m->n_params, scal(m) + SC_GNORM, (float*)(m->ws + m->off_sumsq), s);
@@ -1474,6 +1517,11 @@ int model_read_loss(Model* m, float* out4, hipStream_t s) {
   (void)hipMemcpyAsync(out4, scal(m) + SC_LOSS, 16, hipMemcpyDeviceToHost, s);
   (void)hipMemcpyAsync(out4 + 3, scal(m) + SC_GNORM, 4, hipMemcpyDeviceToHost, s);
   (void)hipStreamSynchronize(s);
+  if (unsigned ef = device_error_read_clear(s)) {
+    m->err = std::string("token ids out of range reached the model (") + ((ef & 1) ? "decoder input outside the embedding table; " : "") +
+             ((ef & 2) ? "loss target outside the vocabulary; " : "") + "rewrite the loader's -1 padding to <PAD> first, train_modules/train_single_opt.py:78)";
+    return -6;
+  }
   return 0;
 }
 
@@ -1708,6 +1756,7 @@ int model_step_begin(Model* m, const float* src_in, int B, int max_steps, hipStr
 
 int model_step(Model* m, const int64_t* target, float* logits_out, hipStream_t s) {
   Exec& e = *m->ex;
+  det_activate(m);
   if (!m->step_B || m->step_epoch != m->epoch) { m->err = "no live step session (call satrn_model_step_begin; other calls on the model end a session)"; return -1; }
   if (m->step_t >= m->step_max) { m->err = "step session exhausted (max_steps reached)"; return -1; }
   e.s = s;

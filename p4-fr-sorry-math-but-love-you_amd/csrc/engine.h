@@ -104,10 +104,11 @@ struct Model {
   char* ws = nullptr; size_t ws_bytes = 0;
   // persistent region layout (byte offsets inside ws)
   size_t persist_bytes = 0;
-  size_t off_packed = 0, off_adam_m = 0, off_adam_v = 0, off_scalars = 0, off_pe1d = 0, off_hpos = 0, off_wpos = 0,
+  size_t off_packed = 0, off_scalars = 0, off_pe1d = 0, off_hpos = 0, off_wpos = 0,
          off_stage_img = 0, off_stage_tgt = 0, off_zero = 0;
   size_t zero_bytes = 0, zero_hwm = 0;
   size_t off_sumsq = 0;
+  size_t off_det = 0, det_floats = 0;  // two scratch slabs of the deterministic reductions (f32 parity mode), 0 = atomics
   size_t off_bn_eval = 0, off_bn_desc = 0; std::vector<BnEvalDesc> bn_desc_host; bool bn_desc_dirty = true;
   size_t off_packdesc = 0, packdesc_bytes = 0, off_packblk = 0, packblk_bytes = 0; int pack_n = 0; long pack_total = 0; bool pack_dirty = true;
   int stage_B = 0, stage_L = 0;
@@ -117,6 +118,9 @@ struct Model {
   struct Exec* ex = nullptr;
   hipGraphExec_t graphs[4] = {nullptr, nullptr, nullptr, nullptr}; int graph_B = 0, graph_L = 0;
   long adam_t = 0;
+  // optimizer state lives OUTSIDE the resizable workspace (caller-owned flat fp32 buffers, one element per parameter):
+  // a workspace regrown for a longer batch must not restart Adam
+  float* adam_m = nullptr; float* adam_v = nullptr;
   hipGraphExec_t decode_graph = nullptr; const void* decode_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float* hy_pinned = nullptr; unsigned long hy_seq = 0;
   // step-wise decoding session (satrn_model_step_begin / satrn_model_step)
@@ -167,6 +171,8 @@ Model* model_create(const SatrnConfig& cfg);
 void model_destroy(Model* m);
 size_t model_workspace_bytes(Model* m, int B, int L);
 int model_bind(Model* m, float* params, float* grads, float* buf_f32, int64_t* buf_i64);
+int model_bind_optimizer(Model* m, float* exp_avg, float* exp_avg_sq);
+int model_rng_state(Model* m, uint32_t* seed_io, int set, hipStream_t s);
 int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s);
 int model_pack_weights(Model* m, hipStream_t s);
 int model_forward(Model* m, const float* img, const int64_t* expected, int B, int L, bool train, bool record,

@@ -4,6 +4,23 @@
 #include <stdint.h>
 
 enum { DT_F32 = 0, DT_BF16 = 1 };
+
+// Deterministic reductions (the f32 parity mode): every cross-workgroup float reduction that normally ends in global float
+// atomics (BatchNorm statistics in GEMM epilogues, column reductions, split-M weight gradients, bias / LayerNorm / embedding
+// gradients, the loss sum) instead stores per-workgroup partials into a scratch slab and a second small launch folds them in
+// a FIXED order.  Results are then bit-identical from run to run and independent of how the backward is cut into
+// segments / streams.  The engine owns two slabs (main chain, weight-gradient side stream) and switches the mode on for
+// dtype f32; operator-level C-ABI calls without an engine keep the atomic forms.
+struct DetCtx { int on = 0; float* scratch[2] = {nullptr, nullptr}; size_t cap = 0 /*floats per slab*/; hipStream_t side = nullptr; };
+extern DetCtx g_det;
+void det_overflow_warn(size_t need_floats);
+static inline float* det_scratch(hipStream_t s, size_t need_floats) {
+  if (!g_det.on) return nullptr;
+  if (need_floats > g_det.cap) { det_overflow_warn(need_floats); return nullptr; }
+  return g_det.scratch[(g_det.side && s == g_det.side) ? 1 : 0];
+}
+// out[i] += sum_{r < nrep} part[r * stride + i]  (r ascending), i < n
+void launch_fold(const float* part, int nrep, long stride, long n, float* out, hipStream_t s);
 enum { AM_DENSE = 0, AM_CONV = 1, AM_DGRAD = 2 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3 };
 
@@ -15,6 +32,7 @@ struct GemmP {
   int H, W, Ci, OH, OW, KW, stride, pt, pl;
   int act, beta, out_f32;
   float drop_p; const uint32_t* seed; uint32_t site;
+  float* stats_part;  // deterministic mode (set by launch_gemm): per-row-tile partial sums [slot][2][N], folded into stats afterwards
   float* stats;  // optional [stats_rep][2N] (zeroed): per-column sum / sum of squares of the output (for the BatchNorm that follows)
   int stats_rep; // replicas (>= 1) the row tiles spread their atomics over; the consumer sums them
   // optional (dgrad of a BatchNorm output, N == the BN's C): stats become the BN backward's column sums
@@ -43,6 +61,7 @@ struct WgradP {
   int nbatch, nb_inner;                    // batched: z -> (z / nb_inner, z % nb_inner)
   long sY_o, sY_i, sA_o, sA_i, sW_o, sW_i;  // element strides per outer/inner batch index
   int ldw;                                 // out_t==1: row stride of dW
+  float* det_part;                         // deterministic mode (set by launch_wgrad): [split][N][K] partial slabs
 };
 void launch_wgrad(int dt, const WgradP& p, hipStream_t s);
 void launch_conv_grad_unpack(const float* tmp /*[N][taps][Ci]*/, float* dw /*[N][Ci][taps] +=*/, int N, int Ci, int taps, hipStream_t s);
@@ -77,7 +96,8 @@ void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* sc
                           const void* se_gate = nullptr /*[B][C] T*/, const void* se_dpool = nullptr /*[B][C] T*/, int se_hw = 0);
 void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* scale_shift, const float* mean_rstd,
                          const float* w, const float* red, long M, int C, int act, void* dy, float* dw, float* db,
-                         hipStream_t s, int red_rep = 1, const void* se_gate = nullptr, const void* se_dpool = nullptr, int se_hw = 0);
+                         hipStream_t s, int red_rep = 1, const void* se_gate = nullptr, const void* se_dpool = nullptr, int se_hw = 0,
+                         int eval_stats = 0 /*1: the forward used running statistics: no batch-mean terms in dy*/);
 // se_gate/se_dpool/se_hw: the gradient fed to the two BatchNorm-backward passes is dz*gate[b][c] + dpool[b][c]/se_hw (the
 // squeeze-and-excite backward wrt its input, b = row / se_hw) computed on the fly instead of materialised by se_bwd_x
 void launch_stem_conv(int dt, const float* img, const float* w, void* y, int B, int Cin, int H, int W, int Co, int OH,
@@ -112,9 +132,11 @@ void launch_layernorm_bwd(int dt, const void* dout, const void* a, const void* b
                           float* dbias, long R, int C, float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s);
 void launch_reshape_quirk(int dt, int inverse, const void* in, void* out, int B, int HW, int C, int beta, hipStream_t s);
 void launch_embed(int dt, const int64_t* ids, const float* table, const float* pe, void* out, int B, int L, int ld_ids,
-                  int D, int pos0, float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s);
+                  int D, int pos0, float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s, int nrows = 0);
 void launch_embed_bwd(int dt, const int64_t* ids, const void* dout, float* dtable, int B, int L, int ld_ids, int D,
-                      float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s);
+                      float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s, int nrows = 0);
+// nrows > 0: ids outside [0, nrows) are skipped and flagged in the device error word instead of followed
+unsigned device_error_read_clear(hipStream_t s);  // bit 0: embedding id out of range, bit 1: CE target out of range; synchronises
 void launch_colsum(int dt, const void* x, long M, int C, int ld, float* out /*[C] +=*/, hipStream_t s);
 void launch_act_bwd(int dt, const void* dz, const void* z_post, void* du, long n, int act, float drop_p, hipStream_t s);
 void launch_dropout_bwd(int dt, const void* dz, void* du, long M, int N, float drop_p, const uint32_t* seed, uint32_t site,

@@ -17,6 +17,25 @@ DEVI void ldv(const float* p, float* o, int n) {  // n (multiple of 4) floats th
   }
 }
 
+DetCtx g_det;
+void det_overflow_warn(size_t need_floats) {
+  static bool once = false;
+  if (!once) { once = true; fprintf(stderr, "[satrn] deterministic-reduction scratch too small (%zu floats needed, %zu available): this reduction falls back to float atomics\n", need_floats, g_det.cap); }
+}
+__global__ void fold_kernel(const float* part, int nrep, long stride, long n, float* out) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float a = 0.f;
+    for (int r = 0; r < nrep; ++r) a += part[(size_t)r * stride + i];
+    out[i] += a;
+  }
+}
+void launch_fold(const float* part, int nrep, long stride, long n, float* out, hipStream_t s) {
+  if (n <= 0 || nrep <= 0) return;
+  long g = (n + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(fold_kernel, dim3((int)g), dim3(256), 0, s, part, nrep, stride, n, out);
+}
+
 static inline int grid_for(long work, int per_block = 256, int cap = 4096) {
   long g = (work + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -33,7 +52,7 @@ static inline int grid_for(long work, int per_block = 256, int cap = 4096) {
 // smaller than its unroll factor runs only the sequential remainder loop -- one dependent memory round trip per row.
 template <typename T, int NO, typename F, int UNR = 4>
 __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int rows_per_block, int tx_log2,
-                                                        float* o0, float* o1, int nmain) {
+                                                        float* o0, float* o1, int nmain, float* part) {
   constexpr int CH = TT<T>::CH;
   __shared__ float red[256 * CH];  // [TY][TX*CH]
   const int TX = 1 << tx_log2, TY = 256 >> tx_log2;
@@ -64,6 +83,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int 
       for (int y = 0; y < TY; ++y) sum += red[y * TX * CH + i];
       int col = cbase * CH + i;
       if (col < C) {
+        // deterministic mode: this row block's partial goes to its own slot [blockIdx.x][k][col]; colreduce_fold_kernel
+        // adds the row blocks in ascending order
+        if (part) { part[((size_t)blockIdx.x * NO + k) * C + col] = sum; continue; }
         // nmain < 0: k-major o0[k*C + col] (contiguous atomics).  Else sums k < nmain go to o0[col*nmain + k] and the
         // remaining one to o1[col]
         if (nmain < 0) atomicAdd(o0 + (long)k * C + col, sum);
@@ -72,6 +94,18 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int 
       }
     }
     __syncthreads();
+  }
+}
+
+__global__ void colreduce_fold_kernel(const float* part, int gx, int NO, int C, float* o0, float* o1, int nmain) {
+  const long n = (long)NO * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i / C), col = (int)(i - (long)k * C);
+    float a = 0.f;
+    for (int r = 0; r < gx; ++r) a += part[(size_t)r * n + i];
+    if (nmain < 0) o0[(long)k * C + col] += a;
+    else if (k < nmain) o0[(long)col * nmain + k] += a;
+    else if (o1) o1[col] += a;
   }
 }
 
@@ -105,12 +139,17 @@ static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain
   }
   // the row loop is unrolled by the largest of 4 / 2 / 1 that DIVIDES the rows per thread (see colreduce_kernel)
   static const bool unr4 = getenv("SATRN_COLRED_UNR4") != nullptr;  // A/B switch: the old fixed unroll factor
+  float* part = det_scratch(s, (size_t)gx * NO * C);
   if (!unr4 && NO <= 2 && rpt % 4 != 0 && rpt % 2 == 0)
-    hipLaunchKernelGGL((colreduce_kernel<T, NO, F, (NO <= 2 ? 2 : 4)>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1, nmain);
+    hipLaunchKernelGGL((colreduce_kernel<T, NO, F, (NO <= 2 ? 2 : 4)>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1, nmain, part);
   else if (!unr4 && NO <= 2 && rpt % 2 != 0 && rpt < 4)
-    hipLaunchKernelGGL((colreduce_kernel<T, NO, F, (NO <= 2 ? 1 : 4)>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1, nmain);
+    hipLaunchKernelGGL((colreduce_kernel<T, NO, F, (NO <= 2 ? 1 : 4)>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1, nmain, part);
   else
-    hipLaunchKernelGGL((colreduce_kernel<T, NO, F, 4>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1, nmain);
+    hipLaunchKernelGGL((colreduce_kernel<T, NO, F, 4>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1, nmain, part);
+  if (part) {
+    long n = (long)NO * C;
+    hipLaunchKernelGGL(colreduce_fold_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, part, (int)gx, NO, C, o0, o1, nmain);
+  }
 }
 
 // ---- BN batch statistics ------------------------------------------------------------------
@@ -383,13 +422,14 @@ __global__ void bn_bwd_apply_kernel(const T* dz, const T* y, const float* ss, co
 }
 void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* ss, const float* mr, const float* w,
                          const float* red, long M, int C, int act, void* dy, float* dw, float* db, hipStream_t s,
-                         int red_rep, const void* se_gate, const void* se_dpool, int se_hw) {
+                         int red_rep, const void* se_gate, const void* se_dpool, int se_hw, int eval_stats) {
   DISPATCH_T(dt, {
     long n = M * C / TT<T>::CH;
     int g = grid_chan(n, C / TT<T>::CH);
     while ((long)g * 256 < C) g *= 2;
+    // eval statistics: invM = 0 removes the batch-mean / batch-variance terms (Bc = Cc = 0), dw / db stay sum(g*xhat) / sum(g)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g), dim3(256), 0, s, (const T*)dz, (const T*)y, ss, mr, w, red,
-                       red_rep < 1 ? 1 : red_rep, 1.0f / (float)M, n, C, act, (T*)dy, dw, db, (const T*)se_gate, (const T*)se_dpool,
+                       red_rep < 1 ? 1 : red_rep, eval_stats ? 0.0f : 1.0f / (float)M, n, C, act, (T*)dy, dw, db, (const T*)se_gate, (const T*)se_dpool,
                        se_hw > 0 ? se_hw : 1, se_hw > 0 ? 1.0f / (float)se_hw : 0.f);
   });
 }
@@ -434,16 +474,16 @@ void launch_stem_conv(int dt, const float* img, const float* w, void* y, int B, 
   });
 }
 
-// dW[co][ci][kh][kw] += sum_pix dy[pix][co] * img[b][ci][sy][sx]; LDS accumulation then global atomics
+// dW[co][ci][kh][kw] += sum_pix dy[pix][co] * img[b][ci][sy][sx].  Per input channel every thread's partial goes to its own
+// LDS slot and the pixel lanes are summed in a fixed order (deterministic inside the block); the block's result is added
+// with one global atomic per weight, or -- deterministic mode -- stored as a per-block partial and folded afterwards.
 template <typename T>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* img, const T* dy, float* dw, int B, int Cin,
                                                          int H, int W, int Co, int OH, int OW, int stride, int pad,
-                                                         int pix_per_block) {
+                                                         int pix_per_block, float* part) {
   constexpr int CH = TT<T>::CH;
-  extern __shared__ float red[];  // [Co*Cin*9]
-  const int nW = Co * Cin * 9;
-  for (int i = threadIdx.x; i < nW; i += 256) red[i] = 0.f;
-  __syncthreads();
+  extern __shared__ float red[];  // [np][Co*9]
+  const int nW = Co * Cin * 9, nC = Co * 9;
   const int CC = Co / CH;
   long p0 = (long)blockIdx.x * pix_per_block;
   long p1 = p0 + pix_per_block;
@@ -452,8 +492,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* img, const
   // thread -> channel chunk (fixed) and a strided set of pixels
   int cc = threadIdx.x % CC;
   int lane_p = threadIdx.x / CC, np = 256 / CC;
-  if (lane_p < np) {
-    for (int ci = 0; ci < Cin; ++ci) {
+  for (int ci = 0; ci < Cin; ++ci) {
+    if (lane_p < np) {
       float acc[9][CH];
 #pragma unroll
       for (int t = 0; t < 9; ++t)
@@ -480,11 +520,19 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* img, const
 #pragma unroll
       for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < CH; ++j) atomicAdd(&red[((cc * CH + j) * Cin + ci) * 9 + t], acc[t][j]);
+        for (int j = 0; j < CH; ++j) red[(size_t)lane_p * nC + (cc * CH + j) * 9 + t] = acc[t][j];
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nC; i += 256) {
+      float a = 0.f;
+      for (int q = 0; q < np; ++q) a += red[(size_t)q * nC + i];
+      const int co = i / 9, t = i - co * 9;
+      const long dst = ((long)co * Cin + ci) * 9 + t;
+      if (part) part[(size_t)blockIdx.x * nW + dst] = a;
+      else atomicAdd(dw + dst, a);
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < nW; i += 256) atomicAdd(dw + i, red[i]);
 }
 void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int B, int Cin, int H, int W, int Co,
                        int OH, int OW, int stride, int pad, hipStream_t s) {
@@ -492,8 +540,12 @@ void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int 
     long NP = (long)B * OH * OW;
     int ppb = 2048;
     int g = (int)((NP + ppb - 1) / ppb);
-    hipLaunchKernelGGL((stem_wgrad_kernel<T>), dim3(g), dim3(256), (size_t)Co * Cin * 9 * sizeof(float), s, img,
-                       (const T*)dy, dw, B, Cin, H, W, Co, OH, OW, stride, pad, ppb);
+    const int np = 256 / (Co / TT<T>::CH);
+    const int nW = Co * Cin * 9;
+    float* part = det_scratch(s, (size_t)g * nW);
+    hipLaunchKernelGGL((stem_wgrad_kernel<T>), dim3(g), dim3(256), (size_t)np * Co * 9 * sizeof(float), s, img,
+                       (const T*)dy, dw, B, Cin, H, W, Co, OH, OW, stride, pad, ppb, part);
+    if (part) launch_fold(part, g, nW, nW, dw, s);
   });
 }
 
@@ -1000,13 +1052,11 @@ void launch_layernorm(int dt, const void* a, const void* b, const float* w, cons
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const T* a, const T* b, const float* w,
                                                             const float* mr, T* da, T* db, int beta_a, int beta_b,
-                                                            float* dw, float* dbias, long R, int C) {
+                                                            float* dw, float* dbias, long R, int C, float* part) {
   constexpr int CH = TT<T>::CH;
-  extern __shared__ float red[];  // [2][C]
+  extern __shared__ float red[];  // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int CC = C / CH;
-  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
-  __syncthreads();
   float gw[NCH][CH], gb[NCH][CH];
 #pragma unroll
   for (int k = 0; k < NCH; ++k)
@@ -1094,21 +1144,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
     }
     cur = nxt;
   }
+  // the four waves' partials go to their own LDS slots and are added in a fixed order
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     int c = lane + k * 64;
     if (c < CC) {
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
-        atomicAdd(&red[c * CH + j], gw[k][j]);
-        atomicAdd(&red[C + c * CH + j], gb[k][j]);
+        red[wv * 2 * C + c * CH + j] = gw[k][j];
+        red[wv * 2 * C + C + c * CH + j] = gb[k][j];
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) {
-    atomicAdd(dw + i, red[i]);
-    atomicAdd(dbias + i, red[C + i]);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const float a = ((red[i] + red[2 * C + i]) + red[4 * C + i]) + red[6 * C + i];
+    if (part) part[(size_t)blockIdx.x * 2 * C + i] = a;   // deterministic mode: folded afterwards
+    else atomicAdd((i < C ? dw : dbias - C) + i, a);
   }
 }
 void launch_layernorm_bwd(int dt, const void* dout, const void* a, const void* b, const float* w, const float* mr,
@@ -1117,16 +1169,18 @@ void launch_layernorm_bwd(int dt, const void* dout, const void* a, const void* b
   DISPATCH_T(dt, {
     int cc = C / TT<T>::CH;
     int g = grid_for(R, 16, 512);
-    size_t sh = (size_t)2 * C * sizeof(float);
+    size_t sh = (size_t)8 * C * sizeof(float);
+    float* part = det_scratch(s, (size_t)g * 2 * C);
     if (cc <= 64)
       hipLaunchKernelGGL((layernorm_bwd_kernel<T, 1>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a,
-                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C);
+                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part);
     else if (cc <= 128)
       hipLaunchKernelGGL((layernorm_bwd_kernel<T, 2>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a,
-                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C);
+                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part);
     else
       hipLaunchKernelGGL((layernorm_bwd_kernel<T, 4>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a,
-                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C);
+                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part);
+    if (part) { launch_fold(part, g, 2L * C, C, dw, s); launch_fold(part + C, g, 2L * C, C, dbias, s); }
   });
 }
 
@@ -1155,10 +1209,23 @@ void launch_reshape_quirk(int dt, int inverse, const void* in, void* out, int B,
   });
 }
 
+// ---- device error word: set by kernels that meet an index they must not follow (a token id outside the embedding table /
+// the vocabulary, e.g. the loader's -1 padding reaching the model before the -1 -> <PAD> rewrite of
+// train_modules/train_single_opt.py:78); nn.Embedding / CrossEntropyLoss raise there, these kernels skip the element and
+// flag it, and the next satrn_model_read_loss / satrn_device_error call reports it
+__device__ unsigned g_satrn_errflag = 0;
+unsigned device_error_read_clear(hipStream_t s) {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(g_satrn_errflag), sizeof(v), 0, hipMemcpyDeviceToHost, s) != hipSuccess) return 0;
+  (void)hipStreamSynchronize(s);
+  if (v) { unsigned z = 0; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_satrn_errflag), &z, sizeof(z), 0, hipMemcpyHostToDevice, s); (void)hipStreamSynchronize(s); }
+  return v;
+}
+
 // ---- embedding * sqrt(D) + 1-D positional encoding (+dropout) ----------------------------------------
 template <typename T>
 __global__ void embed_kernel(const int64_t* ids, const float* table, const float* pe, T* out, int L, int ld_ids, int D,
-                             int pos0, long total, float drop_p, const uint32_t* seedp, uint32_t site) {
+                             int pos0, long total, float drop_p, const uint32_t* seedp, uint32_t site, int nrows) {
   const float sc = sqrtf((float)D);
   const uint32_t seed = drop_p > 0.f ? *seedp : 0u;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -1167,22 +1234,25 @@ __global__ void embed_kernel(const int64_t* ids, const float* table, const float
     int t = (int)(bt % L);
     long b = bt / L;
     int64_t id = ids[b * ld_ids + t];
-    float v = table[id * D + d] * sc + pe[(long)(pos0 + t) * D + d];
+    float tv = 0.f;
+    if (nrows > 0 && (id < 0 || id >= nrows)) { if (d == 0) atomicOr(&g_satrn_errflag, 1u); }
+    else tv = table[id * D + d];
+    float v = tv * sc + pe[(long)(pos0 + t) * D + d];
     if (drop_p > 0.f) v *= drop_scale(seed, site, (uint32_t)i, drop_p);
     out[i] = from_f<T>(v);
   }
 }
 void launch_embed(int dt, const int64_t* ids, const float* table, const float* pe, void* out, int B, int L, int ld_ids,
-                  int D, int pos0, float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s) {
+                  int D, int pos0, float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s, int nrows) {
   DISPATCH_T(dt, {
     long n = (long)B * L * D;
     hipLaunchKernelGGL((embed_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, ids, table, pe, (T*)out, L, ld_ids, D,
-                       pos0, n, drop_p, seed, site);
+                       pos0, n, drop_p, seed, site, nrows);
   });
 }
 template <typename T>
 __global__ void embed_bwd_kernel(const int64_t* ids, const T* dout, float* dtable, int L, int ld_ids, int D, long total,
-                                 float drop_p, const uint32_t* seedp, uint32_t site) {
+                                 float drop_p, const uint32_t* seedp, uint32_t site, int nrows) {
   const float sc = sqrtf((float)D);
   const uint32_t seed = drop_p > 0.f ? *seedp : 0u;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -1191,23 +1261,49 @@ __global__ void embed_bwd_kernel(const int64_t* ids, const T* dout, float* dtabl
     int t = (int)(bt % L);
     long b = bt / L;
     int64_t id = ids[b * ld_ids + t];
+    if (nrows > 0 && (id < 0 || id >= nrows)) continue;  // flagged by the forward kernel
     float g = to_f(dout[i]) * sc;
     if (drop_p > 0.f) g *= drop_scale(seed, site, (uint32_t)i, drop_p);
     atomicAdd(dtable + id * D + d, g);
   }
 }
+// deterministic mode: one workgroup per table row walks all tokens in order (the table has 246 rows, a batch a few thousand tokens)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_det_kernel(const int64_t* ids, const T* dout, float* dtable, int B, int L, int ld_ids,
+                                                            int D, float drop_p, const uint32_t* seedp, uint32_t site) {
+  const float sc = sqrtf((float)D);
+  const uint32_t seed = drop_p > 0.f ? *seedp : 0u;
+  const int64_t row = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float a = 0.f;
+    bool any = false;
+    for (long bt = 0; bt < (long)B * L; ++bt) {
+      if (ids[(bt / L) * ld_ids + (bt % L)] != row) continue;
+      const long i = bt * D + d;
+      float g = to_f(dout[i]) * sc;
+      if (drop_p > 0.f) g *= drop_scale(seed, site, (uint32_t)i, drop_p);
+      a += g; any = true;
+    }
+    if (any) dtable[row * D + d] += a;
+  }
+}
 void launch_embed_bwd(int dt, const int64_t* ids, const void* dout, float* dtable, int B, int L, int ld_ids, int D,
-                      float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s) {
+                      float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s, int nrows) {
+  if (g_det.on && nrows > 0) {
+    DISPATCH_T(dt, { hipLaunchKernelGGL((embed_bwd_det_kernel<T>), dim3(nrows), dim3(256), 0, s, ids, (const T*)dout, dtable, B, L,
+                                        ld_ids, D, drop_p, seed, site); });
+    return;
+  }
   DISPATCH_T(dt, {
     long n = (long)B * L * D;
     hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, ids, (const T*)dout, dtable, L,
-                       ld_ids, D, n, drop_p, seed, site);
+                       ld_ids, D, n, drop_p, seed, site, nrows);
   });
 }
 
 // ---- bias gradients: out[c] += sum_rows x[row*ld + c] --------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long M, int C, int ld, float* out, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, long M, int C, int ld, float* out, int rows_per_block, float* part) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + cl;
@@ -1218,7 +1314,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, long M, int C, 
     for (long r = r0 + rg; r < r1; r += 4) sum += to_f(x[r * ld + c]);
   red[rg][cl] = sum;
   __syncthreads();
-  if (rg == 0 && c < C) atomicAdd(out + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+  if (rg == 0 && c < C) {
+    const float a = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (part) part[(size_t)blockIdx.x * C + c] = a;  // deterministic mode: folded afterwards
+    else atomicAdd(out + c, a);
+  }
 }
 void launch_colsum(int dt, const void* x, long M, int C, int ld, float* out, hipStream_t s) {
   DISPATCH_T(dt, {
@@ -1228,7 +1328,9 @@ void launch_colsum(int dt, const void* x, long M, int C, int ld, float* out, hip
     long rpb = (M + want - 1) / want;
     if (rpb < 32) rpb = 32;
     int gx = (int)((M + rpb - 1) / rpb);
-    hipLaunchKernelGGL((colsum_kernel<T>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, M, C, ld, out, (int)rpb);
+    float* part = det_scratch(s, (size_t)gx * C);
+    hipLaunchKernelGGL((colsum_kernel<T>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, M, C, ld, out, (int)rpb, part);
+    if (part) launch_fold(part, gx, C, C, out, s);
   });
 }
 
@@ -1278,7 +1380,7 @@ void launch_dropout_bwd(int dt, const void* dz, void* du, long M, int N, float p
 
 // ---- cross-entropy (ignore_index) on fp32 logits [R][V]: one wave per row ---------------------------------
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const int64_t* tgt, int ld_tgt, int tgt_off,
-                                                     int T_, int V, int pad_id, long R, float* out, float* lse_ws) {
+                                                     int T_, int V, int pad_id, long R, float* out, float* lse_ws, float* part) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float lsum = 0.f, lcnt = 0.f;
   for (long r = (long)blockIdx.x * 4 + wv; r < R; r += (long)gridDim.x * 4) {
@@ -1293,7 +1395,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const 
     if (lane == 0) {
       lse_ws[r] = lse;
       int64_t t = tgt[(r / T_) * ld_tgt + tgt_off + (r % T_)];
-      if (t != pad_id) { lsum += lse - x[t]; lcnt += 1.f; }
+      if (t != pad_id && (t < 0 || t >= V)) atomicOr(&g_satrn_errflag, 2u);  // torch raises here; flagged and ignored
+      else if (t != pad_id) { lsum += lse - x[t]; lcnt += 1.f; }
     }
   }
   // one pair of atomics per BLOCK (thousands of same-address float atomics serialise at ~20 ns each)
@@ -1302,7 +1405,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* logits, const 
   __syncthreads();
   if (threadIdx.x == 0) {
     float a = bsum[0][0] + bsum[0][1] + bsum[0][2] + bsum[0][3], b = bsum[1][0] + bsum[1][1] + bsum[1][2] + bsum[1][3];
-    if (b > 0.f) { atomicAdd(out, a); atomicAdd(out + 1, b); }
+    if (part) { part[blockIdx.x * 2] = a; part[blockIdx.x * 2 + 1] = b; }  // deterministic mode: folded afterwards
+    else if (b > 0.f) { atomicAdd(out, a); atomicAdd(out + 1, b); }
   }
 }
 template <typename TO>
@@ -1317,7 +1421,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, const 
     const float* x = logits + r * V;
     int64_t t = tgt[(r / T_) * ld_tgt + tgt_off + (r % T_)];
     const float lse = lse_ws[r];
-    const bool valid = t != pad_id;
+    const bool valid = t != pad_id && t >= 0 && t < V;
     for (int c = lane; c < Vp; c += 64) {
       float g = 0.f;
       if (valid && c < V) g = (__expf(x[c] - lse) - (c == t ? 1.f : 0.f)) * sc;
@@ -1342,8 +1446,11 @@ void launch_ce_full(int dt_out, const float* logits, const int64_t* tgt, int ld_
                     const float* upstream, hipStream_t s) {
   long R = (long)B * T_;
   launch_fill(loss_out, 0, 4 * sizeof(float), s);
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid_for(R, 16, 256)), dim3(256), 0, s, logits, tgt, ld_tgt, tgt_off, T_, V,
-                     pad_id, R, loss_out, lse_ws);
+  const int gce = grid_for(R, 16, 256);
+  float* part = det_scratch(s, (size_t)gce * 2);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(gce), dim3(256), 0, s, logits, tgt, ld_tgt, tgt_off, T_, V,
+                     pad_id, R, loss_out, lse_ws, part);
+  if (part) launch_fold(part, gce, 2, 2, loss_out, s);
   if (dt_out == DT_BF16) launch_ce_bwd_t<bf16_t>(logits, tgt, ld_tgt, tgt_off, B, T_, V, Vp, pad_id, loss_out, lse_ws, dlogits, upstream, s);
   else launch_ce_bwd_t<float>(logits, tgt, ld_tgt, tgt_off, B, T_, V, Vp, pad_id, loss_out, lse_ws, dlogits, upstream, s);
 }

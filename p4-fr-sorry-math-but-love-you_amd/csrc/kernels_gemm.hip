@@ -149,11 +149,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
   // ---- epilogue: C layout col = lane&15, row = (lane>>4)*4 + reg
   const uint32_t seed = (p.drop_p > 0.f) ? *p.seed : 0u;
-  float* sred = reinterpret_cast<float*>(lds);  // [2][BN] column sums for the BatchNorm that follows (LDS is free now)
-  if (p.stats) {
-    for (int i = tid; i < 2 * BN; i += 256) sred[i] = 0.f;
-    __syncthreads();
-  }
+  // [4 waves][2][BN] column sums for the BatchNorm that follows (LDS is free now).  Every (wave, column) slot has exactly one
+  // writer and the four row groups are summed in a fixed order: the in-block part of the statistics is deterministic
+  float* sred = reinterpret_cast<float*>(lds);
+  if (p.stats) __syncthreads();  // all waves are done reading the last k-panel
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + j * 16 + fr;
@@ -194,15 +193,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     if (p.stats) {
       s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (fq == 0) { atomicAdd(&sred[j * 16 + fr], s1); atomicAdd(&sred[BN + j * 16 + fr], s2); }
+      if (fq == 0) { sred[wave * 2 * BN + j * 16 + fr] = s1; sred[wave * 2 * BN + BN + j * 16 + fr] = s2; }
     }
   }
   if (p.stats) {
     __syncthreads();
     for (int i = tid; i < 2 * BN; i += 256) {
       int c = i < BN ? i : i - BN, col = n0 + c;
-      // narrow outputs with a tall grid: spread the same-address atomics over stats_rep replicas of [2N]
-      if (col < p.N) atomicAdd(p.stats + (size_t)(tile_m % p.stats_rep) * 2 * p.N + (i < BN ? 0 : p.N) + col, sred[i]);
+      if (col >= p.N) continue;
+      const float tot = ((sred[i] + sred[2 * BN + i]) + sred[4 * BN + i]) + sred[6 * BN + i];
+      if (p.stats_part) {
+        // deterministic mode: a tile owns BM/64 slots of 64 rows (its sums in the first, zeros in the rest), so the fold
+        // over ceil(M/64) slots does not need to know which tile height ran
+#pragma unroll
+        for (int q = 0; q < BM / 64; ++q)
+          p.stats_part[((size_t)(tile_m * (BM / 64) + q) * 2 + (i < BN ? 0 : 1)) * p.N + col] = q == 0 ? tot : 0.f;
+      } else {
+        // narrow outputs with a tall grid: spread the same-address atomics over stats_rep replicas of [2N]
+        atomicAdd(p.stats + (size_t)(tile_m % p.stats_rep) * 2 * p.N + (i < BN ? 0 : p.N) + col, tot);
+      }
     }
   }
 }
@@ -519,9 +528,13 @@ static bool gemm_skinny_launch(const GemmP& p, hipStream_t s) {
   return true;
 }
 
-void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s) {
-  if (p.M <= 0 || p.N <= 0) return;
-  if (dt == DT_BF16 && amode != AM_DENSE && conv_halo_launch(amode, p, s)) return;
+void launch_gemm(int dt, int amode, const GemmP& p0, hipStream_t s) {
+  if (p0.M <= 0 || p0.N <= 0) return;
+  GemmP p = p0;
+  p.stats_part = nullptr;
+  const int nslots = (p.M + 63) / 64;
+  if (p.stats) p.stats_part = det_scratch(s, (size_t)(nslots + 4) * 2 * p.N);  // null unless the deterministic mode is on
+  if (!p.stats_part && dt == DT_BF16 && amode != AM_DENSE && conv_halo_launch(amode, p, s)) return;
   if (amode == AM_DENSE && (dt == DT_BF16 ? gemm_skinny_launch<bf16_t>(p, s) : gemm_skinny_launch<float>(p, s))) return;
   if (dt == DT_BF16) {
     if (amode == AM_DENSE) launch_gemm_t<bf16_t, AM_DENSE>(p, s);
@@ -532,6 +545,7 @@ void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s) {
     else if (amode == AM_CONV) launch_gemm_t<float, AM_CONV>(p, s);
     else launch_gemm_t<float, AM_DGRAD>(p, s);
   }
+  if (p.stats_part) launch_fold(p.stats_part, nslots, 2L * p.N, 2L * p.N, p.stats, s);
 }
 
 // =========================================================================================
@@ -682,12 +696,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split
           *op = from_f<T>(p.out_accum ? to_f(*op) + acc[i][j][r] : acc[i][j][r]);
         } else {
           long dst;
+          if (p.det_part) { p.det_part[((size_t)blockIdx.y * p.N + n) * p.K + k] = acc[i][j][r]; continue; }  // folded afterwards
           if (CONV && !p.conv_packed_out) { int tp = k / p.Ci, c = k - tp * p.Ci; dst = ((long)n * p.Ci + c) * taps + tp; }
           else dst = (long)n * p.K + k;
           atomicAdd((float*)p.dW + dst, acc[i][j][r]);
         }
       }
     }
+  }
+}
+
+// deterministic mode: dW[dst(n, k)] += sum over the M splits (ascending) of the partial slabs
+__global__ void wgrad_fold_kernel(const float* part, int splits, int N, int K, int Ci_torch, int taps, float* dW) {
+  const long n_ = (long)N * K;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_; i += (long)gridDim.x * blockDim.x) {
+    float a = 0.f;
+    for (int r = 0; r < splits; ++r) a += part[(size_t)r * n_ + i];
+    long dst = i;
+    if (Ci_torch) { const int n = (int)(i / K), k = (int)(i - (long)n * K); const int tp = k / Ci_torch, c = k - tp * Ci_torch; dst = ((long)n * Ci_torch + c) * taps + tp; }
+    dW[dst] += a;
   }
 }
 
@@ -703,20 +730,35 @@ static void launch_wgrad_tile(const WgradP& p, hipStream_t s) {
     // 2 429 img/s, 96 dense / 384 conv 2 535 img/s, 32 dense 2 526, 64 (all) 2 358 (side stream becomes the critical path)
     static const long tgt_d = getenv("SATRN_WGRAD_BLOCKS") ? atol(getenv("SATRN_WGRAD_BLOCKS")) : 96;
     static const long tgt_c = getenv("SATRN_WGRAD_BLOCKS_CONV") ? atol(getenv("SATRN_WGRAD_BLOCKS_CONV")) : 384;
-    const long tgt = p.full_grid ? 768 : (p.conv ? tgt_c : tgt_d);
+    // deterministic mode: the split count (= the summation grouping) must not depend on which stream / graph mode runs the kernel
+    const long tgt = g_det.on ? 256 : (p.full_grid ? 768 : (p.conv ? tgt_c : tgt_d));
     splits = (int)((tgt + (long)tiles * nb - 1) / ((long)tiles * nb));
     int maxs = (p.M + 4 * MS - 1) / (4 * MS);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
   }
+  const bool det = !p.out_t && g_det.on;
+  if (det) {  // the partial slabs [splits][N][K] must fit the scratch slab
+    const size_t per = (size_t)p.N * p.K;
+    const long fit = (long)(g_det.cap / (per ? per : 1));
+    if (splits > fit) splits = (int)(fit < 1 ? 1 : fit);
+  }
   int rps = (p.M + splits - 1) / splits;
   rps = ((rps + MS - 1) / MS) * MS;
   splits = (p.M + rps - 1) / rps;
   WgradP q = p;
+  q.det_part = det ? det_scratch(s, (size_t)splits * p.N * p.K) : nullptr;
   if (q.nb_inner <= 0) q.nb_inner = 1;
   dim3 grid(tiles, splits, nb);
   if (p.conv) hipLaunchKernelGGL((wgrad_kernel<T, BNW, BKW, 1>), grid, dim3(256), 0, s, q, rps);
   else hipLaunchKernelGGL((wgrad_kernel<T, BNW, BKW, 0>), grid, dim3(256), 0, s, q, rps);
+  if (q.det_part) {
+    const long n = (long)p.N * p.K;
+    int g = (int)((n + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(wgrad_fold_kernel, dim3(g), dim3(256), 0, s, q.det_part, splits, p.N, p.K,
+                       (p.conv && !p.conv_packed_out) ? p.Ci : 0, p.conv ? p.KW * p.KW : 1, (float*)p.dW);
+  }
 }
 
 void launch_wgrad(int dt, const WgradP& p, hipStream_t s) {

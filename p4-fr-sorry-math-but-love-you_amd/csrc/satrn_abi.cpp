@@ -16,7 +16,8 @@ static int done(const char* what) {
   return 0;
 }
 #define S(x) ((hipStream_t)(x))
-#define CHK_DT(dt) do { if ((dt) != 0 && (dt) != 1) return fail(-1, "dtype must be 0 (f32) or 1 (bf16)"); } while (0)
+// operator-level calls have no engine workspace behind them: they always use the atomic reduction forms
+#define CHK_DT(dt) do { g_det.on = 0; if ((dt) != 0 && (dt) != 1) return fail(-1, "dtype must be 0 (f32) or 1 (bf16)"); } while (0)
 static int chk_c(int dt, int c, const char* what) {
   int ch = dt == DT_BF16 ? 8 : 4;
   if (c <= 0 || c % ch) return fail(-1, std::string(what) + " must be a positive multiple of " + std::to_string(ch));
@@ -420,9 +421,12 @@ int satrn_model_profile_step(satrn_model* h, const float* img, const int64_t* ex
 }
 float* satrn_model_adam_state(satrn_model* h, int which) {
   Model* m = h->m;
-  if (!m->ws) return nullptr;
-  return (float*)(m->ws + (which == 0 ? m->off_adam_m : m->off_adam_v));
+  return which == 0 ? m->adam_m : m->adam_v;
 }
+int satrn_device_error(void* st) { return (int)device_error_read_clear(S(st)); }
+int satrn_model_bind_optimizer(satrn_model* h, float* exp_avg, float* exp_avg_sq) { return mret(h, model_bind_optimizer(h->m, exp_avg, exp_avg_sq), "bind_optimizer"); }
+long satrn_model_get_step(satrn_model* h) { return h->m->adam_t; }
+int satrn_model_rng_state(satrn_model* h, uint32_t* seed_io_host, int set, void* st) { return mret(h, model_rng_state(h->m, seed_io_host, set, S(st)), "rng_state"); }
 int satrn_model_set_step(satrn_model* h, long t) { h->m->adam_t = t; return 0; }
 
 }  // extern "C"

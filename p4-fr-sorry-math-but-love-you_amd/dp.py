@@ -46,13 +46,15 @@ def shard_batch(n_items, rank, world):
     return s, min(n_items, s + per)
 
 
-def dp_train_step(model, images, expected, lr, overlap=True, **kw):
+def dp_train_step(model, images, expected, lr, overlap=True, force_exchange=False, **kw):
     """One data-parallel step.  overlap=True (eager execution): the backward is cut after the last backbone stage; the all-reduce
     of everything finished by then (74 % of the flat gradient) is started asynchronously (RCCL on its own stream) and runs
     beside the backward of the early backbone, whose range is reduced at the end.  Otherwise:
-    forward/backward -> one flat all-reduce -> clip + AdamW.  Both end with grad_scale = 1/world inside the optimizer."""
+    forward/backward -> one flat all-reduce -> clip + AdamW.  Both end with grad_scale = 1/world inside the optimizer.
+    force_exchange: take the split-phase path and issue the collectives even when the group has ONE rank (how the one-GPU
+    test box executes the RCCL calls and the stream hand-offs of the real path)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_exchange and dist.is_initialized()):
         model.train_step(images, expected, lr, **kw)
         return
     if overlap and not kw.get("use_graph", False):

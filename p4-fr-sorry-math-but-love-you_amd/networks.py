@@ -254,6 +254,13 @@ class _SATRNBase(nn.Module):
         self._gflat = torch.zeros_like(flats[0])
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
         check(self._lib.satrn_model_bind(self._h, ptr(flats[0]), ptr(self._gflat), ptr(flats[1]), ptr(flats[2])), "bind")
+        # AdamW moments of the fused step: own flat tensors (NOT in the resizable workspace), moved with the model
+        old = getattr(self, "_adam", None)
+        self._adam = (torch.zeros_like(flats[0]), torch.zeros_like(flats[0]))
+        if old is not None and old[0].numel() == flats[0].numel():
+            self._adam[0].copy_(old[0])
+            self._adam[1].copy_(old[1])
+        check(self._lib.satrn_model_bind_optimizer(self._h, ptr(self._adam[0]), ptr(self._adam[1])), "bind_optimizer")
         self._bound = device
         self._packed_version = -1
         if self._ws is not None and self._ws.device != device:
@@ -265,9 +272,14 @@ class _SATRNBase(nn.Module):
             return
         B2, L2 = max(B, self._ws_key[0]), max(L, self._ws_key[1])
         need = self._lib.satrn_model_workspace_bytes(self._h, B2, L2)
-        self._ws = None
-        self._ws = torch.empty(need, dtype=torch.uint8, device=device)
-        check(self._lib.satrn_model_set_workspace(self._h, ptr(self._ws), need, _stream()), "set_workspace")
+        # the old workspace stays allocated until set_workspace returns: the engine carries the dropout RNG word over from
+        # it.  Nothing else that must survive lives there (Adam's moments / step count are bound separately), so a batch
+        # that is longer than every earlier one only costs a re-pack of the compute weights
+        old_ws = self._ws
+        new_ws = torch.empty(need, dtype=torch.uint8, device=device)
+        check(self._lib.satrn_model_set_workspace(self._h, ptr(new_ws), need, _stream()), "set_workspace")
+        self._ws = new_ws
+        del old_ws
         self._ws_key = (B2, L2)
         self._packed_version = -1
         self._stage = None
@@ -275,10 +287,12 @@ class _SATRNBase(nn.Module):
         self._warm = set()
 
     def _param_version(self):
+        ps = getattr(self, "_ptensors", None)
+        if ps is None:  # the Parameter objects are created once (re-binding only swaps their .data)
+            ps = self._ptensors = [self._tensor_of(e) for e in self._entries if e[1] == 0]
         v = 0
-        for e in self._entries:
-            if e[1] == 0:
-                v += self._tensor_of(e)._version
+        for t in ps:
+            v += t._version
         return v
 
     def _ensure_packed(self):
@@ -292,11 +306,52 @@ class _SATRNBase(nn.Module):
         self._ensure_ws(B, L, input.device)
         self._ensure_packed()
 
-    @staticmethod
-    def _img(input):
+    def _img(self, input):
+        c = self._cfg
+        if input.dim() != 4 or tuple(input.shape[1:]) != (c.rgb, c.height, c.width):
+            # the engine takes the geometry from the configuration: another shape would be read out of bounds
+            raise SatrnError(f"input must be [B, {c.rgb}, {c.height}, {c.width}] (FLAGS.data.rgb / FLAGS.input_size), got {tuple(input.shape)}")
         if input.dtype != torch.float32 or not input.is_contiguous():
             input = input.float().contiguous()
         return input
+
+    def reserve(self, B, L, device=None):
+        """Size the workspace for batches up to B samples x L tokens now (data-parallel runs call this with the global
+        maxima so that no rank re-allocates mid-run; growing later is safe, it only re-packs the compute weights)."""
+        device = torch.device(device) if device is not None else (self._bound or next(self.parameters()).device)
+        self._ensure_bound(device)
+        self._ensure_ws(int(B), int(L), device)
+
+    def optimizer_state_dict(self):
+        """State of the fused AdamW (what torch.optim.AdamW.state_dict() holds per parameter, flat here) + the dropout RNG
+        word; the reference checkpoints its optimizer the same way (train_modules/train_single_opt.py:497-512)."""
+        if self._bound is None:
+            raise SatrnError("optimizer_state_dict: the model has not run on a device yet")
+        seed = ctypes.c_uint32(0)
+        if self._ws is not None:
+            check(self._lib.satrn_model_rng_state(self._h, ctypes.byref(seed), 0, _stream()), "rng_state")
+        return {"exp_avg": self._adam[0].detach().clone(), "exp_avg_sq": self._adam[1].detach().clone(),
+                "step": int(self._lib.satrn_model_get_step(self._h)), "rng": int(seed.value)}
+
+    def load_optimizer_state_dict(self, sd):
+        if self._bound is None:
+            raise SatrnError("load_optimizer_state_dict: move the model to its device and run reserve() first")
+        with torch.no_grad():
+            self._adam[0].copy_(sd["exp_avg"])
+            self._adam[1].copy_(sd["exp_avg_sq"])
+        check(self._lib.satrn_model_set_step(self._h, int(sd["step"])), "set_step")
+        if self._ws is not None and "rng" in sd:
+            seed = ctypes.c_uint32(int(sd["rng"]))
+            check(self._lib.satrn_model_rng_state(self._h, ctypes.byref(seed), 1, _stream()), "rng_state")
+
+    def check_device_error(self):
+        """raise if a kernel met token ids outside the embedding table / vocabulary since the last check (synchronises)"""
+        bits = self._lib.satrn_device_error(_stream())
+        if bits:
+            raise SatrnError("token ids out of range reached the model ("
+                             + ("decoder input outside the embedding table; " if bits & 1 else "")
+                             + ("loss target outside the vocabulary; " if bits & 2 else "")
+                             + "rewrite the loader's -1 padding to <PAD> before the forward, as train_single_opt.py:78 does)")
 
     # ------------------------------------------------------------------ engine calls
     def _run_forward(self, input, expected, record, teacher_forced=True):
@@ -387,7 +442,7 @@ class _SATRNBase(nn.Module):
 
     # ------------------------------------------------------------------ fused training step (bench / trainer fast path)
     def train_step(self, input, expected, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6, max_grad_norm=2.0,
-                   grad_scale=1.0, use_graph=False, phase=3):
+                   grad_scale=1.0, use_graph=False, phase=3, bn_eval=False):
         """forward + CE + backward + clip_grad_norm_ + AdamW + weight re-pack in ONE library call
         (train_modules/train_single_opt.py:80-98 with teacher forcing).  Default: eager launches on two HIP streams (weight
         gradients run beside the data-gradient chain; measured 12.5 ms vs 15.2 ms for the single-chain hipGraph replay,
@@ -396,7 +451,12 @@ class _SATRNBase(nn.Module):
         segment k of phase 1 (k = 0..3 in order; overlapped gradient exchange, see dp.dp_train_step).
         lr = (encoder_lr, decoder_lr) and/or weight_decay = (encoder_wd, decoder_wd) select the reference's DUAL-optimizer
         iteration (train_modules/train_dual_opt.py:87-113): encoder.* and decoder.* gradients are clipped separately and
-        stepped with their own learning rates (eager only; plain Adam = weight_decay 0, what that trainer uses)."""
+        stepped with their own learning rates (eager only; plain Adam = weight_decay 0, what that trainer uses).
+        bn_eval=True: module.eval() semantics with gradients (BatchNorm running statistics, no dropout; eager) -- every
+        sample independent of its batch, the mode of the data-parallel equivalence test."""
+        if bn_eval:
+            phase = int(phase) | 32
+            use_graph = False
         dual = isinstance(lr, (tuple, list)) or isinstance(weight_decay, (tuple, list))
         if dual:
             lr = tuple(lr) if isinstance(lr, (tuple, list)) else (lr, lr)
@@ -407,11 +467,13 @@ class _SATRNBase(nn.Module):
         B, L = expected.shape
         self._ensure_bound(input.device)
         self._ensure_ws(B, L, input.device)
-        if self._packed_version == -1:
+        # the in-step AdamW re-packs the compute copies itself and does not bump torch's tensor versions: a version that
+        # moved since the last step means load_state_dict / an EMA / a manual edit touched the masters -> pack again
+        if self._packed_version != self._param_version():
             self._ensure_packed()
         if self._stage is None or self._stage[0].shape != input.shape or self._stage[1].shape != expected.shape:
             self._stage = (torch.empty_like(input), torch.empty_like(expected.contiguous()))
-        if int(phase) in (1, 3) or (int(phase) & 16 and int(phase) & 3 == 0):  # calls that start a step stage its inputs
+        if (int(phase) & 31) in (1, 3) or (int(phase) & 16 and int(phase) & 3 == 0):  # calls that start a step stage its inputs
             self._stage[0].copy_(input, non_blocking=True)
             self._stage[1].copy_(expected, non_blocking=True)
         if dual:
@@ -437,7 +499,7 @@ class _SATRNBase(nn.Module):
                                                        int(use_graph and warm), int(phase), _stream()), "satrn_model_train_step")
         cur.wait_stream(self._side)
         self._gen += 1
-        self._packed_version = -2  # parameters were updated and re-packed inside the step
+        self._packed_version = self._param_version()  # parameters were updated and re-packed inside the step
 
     def profile_step(self, input, expected):
         """One eager forward + CE + backward with HIP events around every launch -> list of per-kernel-family dicts
@@ -473,7 +535,7 @@ class _SATRNBase(nn.Module):
     def read_loss(self):
         """-> (mean loss, valid-token count, grad-norm) of the last train_step / loss pass (synchronises)."""
         out = (ctypes.c_float * 4)()
-        check(self._lib.satrn_model_read_loss(self._h, out, _stream()), "read_loss")
+        check(self._lib.satrn_model_read_loss(self._h, out, _stream()), "read_loss")  # fails on flagged out-of-range token ids
         return float(out[2]), float(out[1]), math.sqrt(max(float(out[3]), 0.0))
 
     def last_sequence(self, B, L):

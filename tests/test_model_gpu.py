@@ -116,10 +116,14 @@ def test_train_forward_backward_vs_golden_and_oracle(golden_dir, name, dtype):
         # per-tensor bounds are loose on purpose: ONE ReLU / max-pool decision flipping at |u| ~ 1e-7 (forward agrees to
         # 1e-6) moves a whole element of a small late-stage tensor and everything upstream of it; the median is tight
         med = float(np.median([e[0] for e in errs.values()]))
-        print(f"[{name}:{dtype}] median rel-L2 grad err {med:.3e}")
-        assert med < (5e-2 if tiny else 1e-2)
+        wl2, wmx = max(e[0] for e in errs.values()), max(e[1] for e in errs.values())
+        print(f"[{name}:{dtype}] median rel-L2 grad err {med:.3e}; worst rel-L2 {wl2:.3e}, worst rel-max {wmx:.3e}")
+        # the engine's f32 step is deterministic (fixed-order reductions), so these are fixed numbers, not noise bounds:
+        # measured medians 1.4e-6 .. 2.0e-4, worst tensor 8.4e-3 (lite_c1_pad: one ReLU / max-pool decision that the CPU
+        # oracle's different summation order takes the other way moves a late-stage element and everything upstream)
+        assert med < 1e-3
         for n_, (l2, mx) in errs.items():
-            assert l2 < (1e-1 if tiny else 2e-2) and mx < (3e-1 if tiny else 1.5e-1), f"grad {n_}: rel L2 {l2} max {mx}"
+            assert l2 < 1.5e-2 and mx < 1e-1, f"grad {n_}: rel L2 {l2} max {mx}"
     else:
         # yardstick: the oracle graph run by PyTorch itself with every tensor in bf16 (CPU bf16 kernels)
         _, tlogits, tgrads, _ = O.forward_backward(img, expected, sd, cfg, dtype=torch.bfloat16)
@@ -303,12 +307,16 @@ def test_segmented_backward_equals_whole_backward(golden_dir, name):
     torch.cuda.synchronize()
     whole = model.flat_grad().detach().clone()
     loss1 = model.read_loss()[0]
-    # the same computation differs from run to run: float atomics arrive in a different order, and a last-bit change of a
-    # BatchNorm statistic now and then flips a ReLU / max-pool decision (observed jumps of 3e-4 * max|g|).  The bound only
-    # has to separate this noise from a wrong segmentation, which would lose or double whole gradient blocks (errors of
-    # the order of max |g|)
+    # f32 is the deterministic mode: every cross-workgroup reduction (BatchNorm statistics, split weight gradients, bias /
+    # LayerNorm / embedding gradients, the loss sum) folds per-workgroup partials in a fixed order, so the same step gives the
+    # same BITS however the backward is cut into segments and whichever stream a kernel ran on.  (Round 1 used float atomics:
+    # a last-bit change of a BatchNorm statistic flipped ReLU / max-pool decisions and moved gradients by 3e-4 of their
+    # maximum -- tools/grad_paths.py shows the discrete states -- and this test had a 2e-2 tolerance.)
+    model.train_step(imgd, expd, 0.0, phase=1)
+    torch.cuda.synchronize()
+    assert torch.equal(model.flat_grad(), whole), "the f32 step is not reproducible from run to run"
     gmax = whole.abs().max().item()
-    tol = 2e-2 * gmax
+    tol = 0.0
     n = whole.numel()
     ranges = [model.segment_range(k) for k in range(4)]
     assert ranges[0][1] == n and ranges[3][0] == 0 and all(ranges[k][0] == ranges[k + 1][1] for k in range(3))
@@ -329,6 +337,13 @@ def test_segmented_backward_equals_whole_backward(golden_dir, name):
     torch.cuda.synchronize()
     d = (model.flat_grad() - whole).abs().max().item()
     assert d <= tol, d
+    # the single-chain hipGraph replay of the same step (other grids for the weight gradients, one stream): same bits
+    model.train_step(imgd, expd, 0.0, phase=1, use_graph=True)   # first call of the shape runs eagerly
+    model.train_step(imgd, expd, 0.0, phase=1, use_graph=True)   # replay
+    torch.cuda.synchronize()
+    dg = (model.flat_grad() - whole).abs().max().item()
+    print(f"[segments:{name}] graph replay vs eager: max diff {dg:.3e}")
+    assert dg == 0.0   # deterministic mode sizes every split independently of the stream / graph mode
     import satrn_amd
     with pytest.raises(satrn_amd.SatrnError):
         model.train_step(imgd, expd, 0.0, phase=18)  # out of order
