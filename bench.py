@@ -78,9 +78,87 @@ def cpu_baseline(B, H, W, T, budget_s=15.0, max_steps=48):
         if time.time() - t_all > budget_s:
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
-    return dict(value=round(B / best, 3), unit="images/s", cores=torch.get_num_threads(), kind="port",
+    med = sorted(times[1:])[len(times[1:]) // 2] if len(times) > 1 else times[0]
+    return dict(value=round(B / med, 3), unit="images/s", cores=torch.get_num_threads(), cpu=_cpu_model(), kind="port", best=round(B / best, 3),
                 sample=f"oracle fp32 train step (fwd+CE+bwd+clip+AdamW), batch {B} of the same 1x{H}x{W}/T={T} workload, "
-                       f"best of {len(times)} steps in {time.time() - t_all:.1f} s of CPU time")
+                       f"median of {len(times)} steps in {time.time() - t_all:.1f} s of CPU time")
+
+
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_decode_baseline(H, W, B=8, steps=231):
+    """second half of the metric on the host cores: the oracle's reference-semantics greedy decode (like the reference it
+    re-projects the whole output history every step, oracle.decoder_greedy_forward) for a bounded sample."""
+    from oracle import satrn_oracle as O
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, ncpu)))
+    cfg = dict(O.CFG_EFF)
+    sd = O.det_state_dict(cfg, 0)
+    img, _ = O.det_inputs(B, 1, H, W, 4, seed=5)
+    t0 = time.time()
+    with torch.no_grad():
+        src = O.encoder_forward(img, sd, cfg, False)
+        t1 = time.time()
+        O.decoder_greedy_forward(src, steps, sd, cfg)
+    t2 = time.time()
+    return dict(value=round(B * steps / (t2 - t0), 1), unit="tokens/s", cores=torch.get_num_threads(), cpu=_cpu_model(), kind="port",
+                sample=f"oracle fp32 greedy decode, batch {B} x {steps} steps of the same 1x{H}x{W} workload: encoder {t1 - t0:.2f} s + decoder {t2 - t1:.2f} s")
+
+
+def precision_report(H, W, T, B, dev):
+    """(a) what bf16 storage costs on the benchmarked configuration: the same weights and batch through the f32 engine (the
+    parity mode: exact-f32 MFMA, <= 1e-3 of the reference's CPU path) and the bf16 engine, dropout off -- relative error of the
+    logits, the loss and the flat gradient; (b) the f32 engine's own step time on the benchmark workload."""
+    img, exp = synth(B, H, W, T, 21, dev)
+    outs = {}
+    f32 = None
+    for dt in ("f32", "bf16"):
+        torch.manual_seed(21)
+        m = make_model(dt, H, W, 0.0).to(dev)
+        m.train()
+        logits = m(img, exp, True, 1.0)
+        loss = m.criterion(logits.transpose(1, 2), exp[:, 1:])
+        m.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        outs[dt] = (logits.detach().float().clone(), float(loss.item()), m.flat_grad().detach().clone())
+        del m, logits, loss
+        if dt == "f32":
+            torch.manual_seed(21)
+            m2 = make_model("f32", H, W, 0.1).to(dev)
+            m2.train()
+            for _ in range(3):
+                m2.train_step(img, exp, 5e-4)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 6
+            for _ in range(n):
+                m2.train_step(img, exp, 5e-4)
+            torch.cuda.synchronize()
+            fms = (time.perf_counter() - t0) / n * 1e3
+            f32 = dict(ms_per_step=round(fms, 3), images_per_s=round(B / fms * 1e3, 1), steps=n,
+                       mfma_frac=round(FLOP_PER_IMG_TRAIN * B / (fms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4), peak_tflops=PEAK_F32_TFLOPS,
+                       note="dtype f32: v_mfma_f32_16x16x4_f32 (exact f32), deterministic fixed-order reductions; the mode that carries the 1e-3 parity claim")
+            del m2
+    lf, lb = outs["f32"][0], outs["bf16"][0]
+    gf, gb = outs["f32"][2], outs["bf16"][2]
+    res = dict(logits_max_abs_err=round((lb - lf).abs().max().item(), 5), logits_rel_err=round(((lb - lf).abs().max() / lf.abs().max()).item(), 5),
+               loss_f32=round(outs["f32"][1], 5), loss_bf16=round(outs["bf16"][1], 5),
+               grad_rel_l2_err=round(((gb - gf).norm() / gf.norm()).item(), 5),
+               grad_cosine=round((torch.dot(gb, gf) / (gb.norm() * gf.norm())).item(), 6),
+               config="same weights / batch as the benchmark (B=32, 1x128x384, T=128), dropout off, one training forward + backward")
+    return res, f32
 
 
 def log(*a):
@@ -133,6 +211,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (single chain) instead of eager two-stream launches")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bf16-vs-f32 error figures and the f32-mode timing")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -178,9 +257,14 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # one event per step on the stream the step is issued on (the engine's streams are joined to it at the end of every step):
+    # per-step GPU times for the median without a host sync inside the timed region
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -197,32 +281,57 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        ms_median = per_step[len(per_step) // 2]
         # ---- roofline of the dominant kernel family: live HIP-event timing of every launch of one eager step
         prof = model.profile_step(img, exp)
         log("profile:", json.dumps(prof))
         tot_ms = sum(p["ms"] for p in prof)
         dom = prof[0]
-        if dom["flops"] > 0:
-            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            roof = dict(bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 5), traffic=None)
+        # the dominant family is priced against BOTH limits; the binding one is the one it sits closer to (for this network's
+        # GEMMs -- small K, small N, huge M in the early stages; tiny everywhere else -- that is HBM, not the matrix pipe)
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        ach_f = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        ach_b = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        if ach_f / peak >= ach_b / PEAK_HBM_GBS:
+            roof = dict(bound="mfma", achieved=round(ach_f, 3), peak=peak, unit="TFLOP/s", frac=round(ach_f / peak, 5), traffic=None)
         else:
-            ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-            roof = dict(bound="hbm", achieved=round(ach, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 5), traffic=None)
+            roof = dict(bound="hbm", achieved=round(ach_b, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach_b / PEAK_HBM_GBS, 5), traffic=None)
+        roof["mfma_frac"] = round(ach_f / peak, 5)
+        roof["hbm_frac"] = round(ach_b / PEAK_HBM_GBS, 5)
         roof["kernel"] = dom["kernel"]
-        try:  # HBM bytes per launch of this kernel family from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["families"].get(dom["kernel"])
-            if pmc:
-                roof["traffic"] = pmc["hbm_bytes_per_launch"]
-                roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(dom["launches"], 1))
-        except Exception:
-            pass
+        pmc_all = {}
+        for pf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:  # HBM bytes per launch of every kernel family from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+                pmc_all = json.load(open(os.path.join(ROOT, "profiles", pf)))["families"]
+                roof["traffic_source"] = f"profiles/{pf} (rocprofv3 --pmc passes of this command, collected with tools/round_profile.sh; NOT measured in this run)"
+                break
+            except Exception:
+                continue
+        if dom["kernel"] in pmc_all:
+            roof["traffic"] = pmc_all[dom["kernel"]]["hbm_bytes_per_launch"]
+        roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(dom["launches"], 1))
+        # every kernel family of the step against the roofline that bounds it (flops -> MFMA peak of the dtype, bytes -> HBM):
+        # frac = the larger of the two fractions, i.e. how close the family runs to whichever limit it is nearer to
+        fams = []
+        peak_fl = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        for p_ in prof:
+            sec = max(p_["ms"], 1e-6) * 1e-3
+            ff, fb = p_["flops"] / sec / 1e12 / peak_fl, p_["bytes"] / sec / 1e9 / PEAK_HBM_GBS
+            fams.append(dict(kernel=p_["kernel"], launches=p_["launches"], ms=round(p_["ms"], 3), gflop=round(p_["flops"] / 1e9, 2),
+                             mbytes=round(p_["bytes"] / 1e6, 1), mfma_frac=round(ff, 4), hbm_frac=round(fb, 4),
+                             bound="mfma" if ff >= fb else "hbm", frac=round(max(ff, fb), 4),
+                             pmc_hbm_mbytes_per_launch=(round(pmc_all[p_["kernel"]]["hbm_bytes_per_launch"] / 1e6, 2) if p_["kernel"] in pmc_all else None)))
+        roof["families"] = fams
+        roof["step_algorithmic_mbytes"] = round(sum(p_["bytes"] for p_ in prof) / 1e6, 1)
+        roof["step_hbm_bound_ms"] = round(sum(p_["bytes"] for p_ in prof) / (PEAK_HBM_GBS * 1e9) * 1e3, 3)
+        roof["step_mfma_bound_ms"] = round(FLOP_PER_IMG_TRAIN * B / (peak_fl * 1e12) * 1e3, 3)
         roof["launches_per_step"] = dom["launches"]
         roof["avg_launch_us"] = round(dom["ms"] * 1e3 / max(dom["launches"], 1), 3)
         roof["share_of_step_kernel_time"] = round(dom["ms"] / max(tot_ms, 1e-9), 4)
         roof["whole_step_mfma_frac"] = round(FLOP_PER_IMG_TRAIN * B / (ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 5)
         out = dict(metric="train images/sec (whole node) EfficientSATRN bs32/GPU 128x384", value=round(value, 2), unit="images/s",
-                   n_gpus=world, rccl_ranks=(dist.get_world_size() if dist is not None else 1), steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True,
+                   n_gpus=world, rccl_ranks=(dist.get_world_size() if dist is not None else 1), steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), ms_per_step_median=round(ms_median, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                    config=dict(workload="EfficientSATRN train step (fwd+CE+bwd+clip+AdamW), bs32/GPU, 1x128x384, teacher-forced T=128, dropout 0.1 (BASELINE configs[1])",
                                global_batch=world * B, seq_len=T, parallelism=f"dp{world}", hipgraph=graph, streams=1 if graph else 2,
@@ -313,6 +422,19 @@ def main():
                 traceback.print_exc()
                 out.setdefault("greedy_decode", {})["error"] = repr(ex)
                 model.train()
+        if world == 1 and not args.no_extras:
+            try:
+                out["accuracy_bf16_vs_f32"], out["f32_mode"] = precision_report(H, W, T, B, dev)
+            except Exception as ex:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                out["accuracy_bf16_vs_f32"] = dict(error=repr(ex))
+        if not args.no_cpu_baseline and world == 1 and not args.no_decode:
+            log("cpu decode baseline ...")
+            try:
+                out.setdefault("greedy_decode", {})["cpu_baseline"] = cpu_decode_baseline(H, W)
+            except Exception as ex:  # noqa: BLE001
+                out.setdefault("greedy_decode", {})["cpu_baseline"] = dict(error=repr(ex))
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline ...")
             try:

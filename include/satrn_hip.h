@@ -284,6 +284,14 @@ int satrn_model_step(satrn_model* m, const int64_t* target, float* logits, void*
  * [{"kernel", "launches", "ms", "flops", "bytes"}...] (per kernel family, algorithmic flops / bytes) to json_out. */
 int satrn_model_profile_step(satrn_model* m, const float* images, const int64_t* expected, int B, int L, char* json_out,
                              size_t cap, void* stream);
+/* Evaluation-time image transform for a batch of variable-size images in one launch (image half):
+ * data/dataset.py:76-81 ([h / w > 2: rotate(90, expand=True)]) + data/augmentations.py:28-44 (A.Resize(H, W) = cv2 INTER_LINEAR
+ * on uint8, A.Normalize(mean, std, max_pixel_value = 255), ToTensorV2).  descs: DEVICE array of B records
+ * { const uint8_t* pixels (device, HWC, C interleaved); int32 h, w, stride_bytes, pad } (24 bytes each); out fp32 [B][C][H][W];
+ * mean3 / std3: HOST float[3] (the first C entries are used).  C is 1 or 3. */
+int satrn_image_preprocess(const void* descs, int B, int C, int H, int W, float* out, const float* mean3, const float* std3,
+                           void* stream);
+
 /* Optimizer state of the fused step (torch.optim.AdamW's exp_avg / exp_avg_sq / step, which the reference checkpoints:
  * train_modules/train_single_opt.py:497-512 `optimizer.state_dict()`).  exp_avg / exp_avg_sq are caller-owned flat fp32
  * DEVICE buffers of satrn_model_flat_size(m, 0) elements, borrowed until the next bind / destroy -- they are NOT part of the

@@ -7,7 +7,8 @@ from . import decoding
 from . import metrics
 from .metrics import StepMetrics
 from .decoding import DeviceDecodingManager, compile_rules, decode
+from .preprocess import preprocess_images
 from .utils import get_network, load_vocab, Flags, id_to_string, START, END, PAD, SPECIAL_TOKENS
 
 __all__ = ["EfficientSATRN", "LiteSATRN", "EfficientSATRN_encoder", "EfficientSATRN_decoder", "SATRNCrossEntropy",
-           "get_network", "load_vocab", "Flags", "id_to_string", "decode", "StepMetrics", "DeviceDecodingManager", "loss_fn_kd", "SatrnError", "START", "END", "PAD", "SPECIAL_TOKENS"]
+           "get_network", "load_vocab", "Flags", "id_to_string", "decode", "StepMetrics", "DeviceDecodingManager", "loss_fn_kd", "preprocess_images", "SatrnError", "START", "END", "PAD", "SPECIAL_TOKENS"]

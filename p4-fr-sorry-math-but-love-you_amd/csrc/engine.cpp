@@ -19,6 +19,10 @@ void launch_act_fwd(int dt, const void* u, void* z, long n, int act, hipStream_t
 // engine's stream and attributed to a kernel family (the launcher's name) with its algorithmic flops / bytes.
 #define LCH(e, call) do { if (!(e).dry) { if ((e).prof) (e).prof_begin(#call); call; if ((e).prof) (e).prof_end(); } (e).nflops = 0; (e).nbytes = 0; } while (0)
 
+// algorithmic work of the next launch, attributed by the profiler (satrn_model_profile_step): bytes = every operand read
+// once + every result written once in its storage dtype, flops = 2 x multiply-accumulates
+#define WORK(e, fl, by) do { (e).nflops = (double)(fl); (e).nbytes = (double)(by); } while (0)
+
 // =====================================================================================================
 // Exec: arena + tape
 // =====================================================================================================
@@ -82,6 +86,26 @@ void Exec::join() {
   forked = false;
 }
 
+static const bool g_stage_prof = getenv("SATRN_STAGE_PROF") != nullptr;
+void Exec::mark(const char* name) {
+  if (!g_stage_prof || dry) return;
+  hipEvent_t ev; (void)hipEventCreate(&ev);
+  (void)hipEventRecord(ev, s);
+  marks.emplace_back(name, ev);
+}
+void Exec::mark_report() {
+  if (marks.size() < 2) { marks.clear(); return; }
+  (void)hipEventSynchronize(marks.back().second);
+  std::string out = "[stage]";
+  float tot = 0.f;
+  for (size_t i = 1; i < marks.size(); ++i) {
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, marks[i - 1].second, marks[i].second);
+    char b[96]; snprintf(b, sizeof(b), " %s=%.3f", marks[i].first.c_str(), ms); out += b; tot += ms;
+  }
+  fprintf(stderr, "%s total=%.3f\n", out.c_str(), tot);
+  for (auto& m_ : marks) (void)hipEventDestroy(m_.second);
+  marks.clear();
+}
 void Exec::reset(char* b, size_t c, char* zb, size_t zc) {
   base = b; cap = c; off = 0; zbase = zb; zcap = zc; zoff = 0; site = 1;
   tape.clear(); tens.clear(); logits = nullptr; src = nullptr; oom = false; nfork = 0; forked = false;
@@ -591,6 +615,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       if (!y->g) return;
       const int ldy = out_f32 ? w->ldb : N;
       void* dY = y->g;
+      WORK(e, 0, (double)M * N * e.esz() * (act == ACT_NONE ? 2 : 3));
       if (act == ACT_RELU) LCH(e, launch_act_bwd(e.dt, dY, y->p, dY, M * N, ACT_RELU, drop_p, e.s));
       else if (act == ACT_SIGMOID) LCH(e, launch_act_bwd(e.dt, dY, y->p, dY, M * N, ACT_SIGMOID, 0.f, e.s));
       else if (drop_p > 0.f) LCH(e, launch_dropout_bwd(e.dt, dY, dY, M, N, drop_p, seed, site, e.s));
@@ -610,10 +635,11 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
         const int dt = e.dt; const bool dry = e.dry;
         float* bg = bias ? bias->g : nullptr; float* wg = w->g; const int Ci = g.Ci;
         if (e.prof || dry) {
+          WORK(e, 0, (double)M * N * e.esz());
           if (bias) LCH(e, launch_colsum(dt, dY, M, N, ldy, bg, e.s));
-          e.nflops = 2.0 * (double)M * N * w->K;
+          WORK(e, 2.0 * (double)M * N * w->K, ((double)M * N + (double)x->rows * x->C) * e.esz() + (double)N * w->K * 4);
           LCH(e, launch_wgrad(dt, q, e.s));
-          if (tmp) LCH(e, launch_conv_grad_unpack(tmp, wg, N, Ci, 9, e.s));
+          if (tmp) { WORK(e, 0, (double)N * w->K * 12); LCH(e, launch_conv_grad_unpack(tmp, wg, N, Ci, 9, e.s)); }
         } else {
           e.defer([=](hipStream_t ws) {
             if (bg) launch_colsum(dt, dY, M, N, ldy, bg, ws);
@@ -716,12 +742,14 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res) {
 Tensor* op_stem(Exec& e, const float* img, Wt* w, int B, int Cin, int H, int W, int stride, int pad) {
   const int OH = (H + 2 * pad - 3) / stride + 1, OW = (W + 2 * pad - 3) / stride + 1;
   Tensor* y = e.newt((long)B * OH * OW, w->Co, B, OH, OW);
+  WORK(e, 2.0 * (double)B * OH * OW * w->Co * 9 * Cin, (double)B * Cin * H * W * 4 + (double)B * OH * OW * w->Co * e.esz());
   LCH(e, launch_stem_conv(e.dt, img, w->p, y->p, B, Cin, H, W, w->Co, OH, OW, stride, pad, e.s));
   if (e.rec)
     e.tape.push_back([&e, img, w, y, B, Cin, H, W, OH, OW, stride, pad]() {
       if (!y->g) return;
       {
         const int dt = e.dt; void* yg = y->g; float* wg = w->g; const int Co = w->Co;
+        WORK(e, 2.0 * (double)B * OH * OW * Co * 9 * Cin, (double)B * Cin * H * W * 4 + (double)B * OH * OW * Co * e.esz());
         if (e.prof || e.dry) LCH(e, launch_stem_wgrad(dt, img, yg, wg, B, Cin, H, W, Co, OH, OW, stride, pad, e.s));
         else e.defer([=](hipStream_t ws) { launch_stem_wgrad(dt, img, yg, wg, B, Cin, H, W, Co, OH, OW, stride, pad, ws); });
       }
@@ -739,10 +767,13 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
     Exec* ep = &e;
     const void* xp = x->p; const void* wf = w->fwd; const float* bp = bias ? bias->p : nullptr;
     y->pend_dw = [=](const float* esc, const float* esh, int act, void* out) {
+      WORK((*ep), 18.0 * (double)B * OH * OW * C, ((double)B * H * W + (double)B * OH * OW) * C * ep->esz());
       LCH((*ep), launch_dwconv(ep->dt, 0, xp, wf, bp, out, B, H, W, C, OH, OW, stride, pt, pl, 0, nullptr, ep->s, esc, esh, act));
     };
     return y;
   }
+  // the statistics pass behind it reads y once more
+  WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * H * W + (double)B * OH * OW * (y->stats ? 2 : 1)) * C * e.esz());
   LCH(e, launch_dwconv(e.dt, 0, x->p, w->fwd, bias ? bias->p : nullptr, y->p, B, H, W, C, OH, OW, stride, pt, pl, 0, y->stats, e.s));
   if (e.rec)
     e.tape.push_back([&e, x, y, w, bias, B, H, W, C, OH, OW, stride, pt, pl]() {
@@ -750,11 +781,13 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
       float* scr = e.zalloc((size_t)10 * C);
       {
         const int dt = e.dt; void* xp = x->p; void* yg = y->g; float* wg = w->g; float* bg = bias ? bias->g : nullptr;
+        WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * H * W + (double)B * OH * OW) * C * e.esz());
         if (e.prof || e.dry) LCH(e, launch_dwconv_wgrad(dt, xp, yg, wg, bg, scr, B, H, W, C, OH, OW, stride, pt, pl, e.s));
         else e.defer([=](hipStream_t ws) { launch_dwconv_wgrad(dt, xp, yg, wg, bg, scr, B, H, W, C, OH, OW, stride, pt, pl, ws); });
       }
       int beta;
       void* dx = e.grad(x, &beta);
+      WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * OH * OW + (double)B * H * W * (beta ? 2 : 1)) * C * e.esz());
       LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, nullptr, e.s));
     });
   return y;
@@ -764,12 +797,14 @@ Tensor* op_maxpool(Exec& e, Tensor* x) {
   used(x);
   const int B = x->B, H = x->H, W = x->W, C = x->C;
   Tensor* y = e.newt((long)B * (H / 2) * (W / 2), C, B, H / 2, W / 2);
+  WORK(e, 0, (double)(x->rows + y->rows) * C * e.esz());
   LCH(e, launch_maxpool(e.dt, 0, x->p, nullptr, y->p, B, H, W, C, e.s));
   if (e.rec)
     e.tape.push_back([&e, x, y, B, H, W, C]() {
       if (!y->g) return;
       void* dx = e.grad(x, nullptr);
       if ((H & 1) || (W & 1)) LCH(e, launch_fill(dx, 0, (size_t)x->rows * C * e.esz(), e.s));
+      WORK(e, 0, (double)(2 * x->rows + y->rows) * C * e.esz());
       LCH(e, launch_maxpool(e.dt, 1, x->p, y->g, dx, B, H, W, C, e.s));
     });
   return y;
@@ -779,6 +814,7 @@ Tensor* op_pool(Exec& e, Tensor* x) {  // mean over HW -> [B][C]
   used(x);
   const int B = x->B, HW = x->H * x->W, C = x->C;
   Tensor* y = e.newt(B, C);
+  WORK(e, 0, (double)x->rows * C * e.esz());
   LCH(e, launch_pool_hw(e.dt, x->p, y->p, B, HW, C, e.s));
   if (e.rec)
     e.tape.push_back([&e, x, y, B, HW, C]() {
@@ -786,6 +822,7 @@ Tensor* op_pool(Exec& e, Tensor* x) {  // mean over HW -> [B][C]
       int beta;
       void* dx = e.grad(x, &beta);
       if (!beta) LCH(e, launch_fill(dx, 0, (size_t)x->rows * C * e.esz(), e.s));
+      WORK(e, 0, (double)x->rows * C * e.esz() * 2);
       LCH(e, launch_bcast_add_hw(e.dt, y->g, dx, B, HW, C, 1.0f / (float)HW, e.s));
     });
   return y;
@@ -794,11 +831,13 @@ Tensor* op_pool(Exec& e, Tensor* x) {  // mean over HW -> [B][C]
 Tensor* op_act(Exec& e, Tensor* u, int act) {
   used(u);
   Tensor* z = e.newt(u->rows, u->C);
+  WORK(e, 0, (double)u->rows * u->C * e.esz() * 2);
   LCH(e, launch_act_fwd(e.dt, u->p, z->p, u->rows * u->C, act, e.s));
   if (e.rec)
     e.tape.push_back([&e, u, z, act]() {
       if (!z->g) return;
       void* du = e.grad(u, nullptr);
+      WORK(e, 0, (double)u->rows * u->C * e.esz() * 3);
       LCH(e, launch_act_bwd(e.dt, z->g, u->p, du, u->rows * u->C, act, 0.f, e.s));
     });
   return z;
@@ -808,14 +847,17 @@ Tensor* op_se_scale(Exec& e, Tensor* x, Tensor* gate) {
   used(x); used(gate);
   const int B = x->B, HW = x->H * x->W, C = x->C;
   Tensor* y = e.newt(x->rows, C, B, x->H, x->W);
+  WORK(e, 0, (double)x->rows * C * e.esz() * 2);
   LCH(e, launch_se_scale(e.dt, x->p, gate->p, y->p, B, HW, C, e.s));
   if (e.rec)
     e.tape.push_back([&e, x, gate, y, B, HW, C]() {
       if (!y->g) return;
       void* dg = e.grad(gate, nullptr);
+      WORK(e, 0, (double)x->rows * C * e.esz() * 2);
       LCH(e, launch_se_bwd_gate(e.dt, y->g, x->p, dg, B, HW, C, e.s));
       int beta;
       void* dx = e.grad(x, &beta);
+      WORK(e, 0, (double)x->rows * C * e.esz() * (beta ? 3 : 2));
       LCH(e, launch_se_bwd_x(e.dt, y->g, gate->p, nullptr, dx, B, HW, C, beta, e.s));
     });
   return y;
@@ -828,11 +870,13 @@ Tensor* op_posenc_apply(Exec& e, Tensor* x, Tensor* gate) {
   const float* hpos = (const float*)(m->ws + m->off_hpos);
   const float* wpos = (const float*)(m->ws + m->off_wpos);
   Tensor* y = e.newt(x->rows, C, B, H, W);
+  WORK(e, 0, (double)x->rows * C * e.esz() * 2);
   LCH(e, launch_posenc2d(e.dt, x->p, gate->p, hpos, wpos, y->p, B, H, W, C, e.s));
   if (e.rec)
     e.tape.push_back([&e, x, gate, y, hpos, wpos, B, H, W, C]() {
       if (!y->g) return;
       void* dg = e.grad(gate, nullptr);
+      WORK(e, 0, (double)x->rows * C * e.esz());
       LCH(e, launch_posenc2d_bwd(e.dt, y->g, hpos, wpos, dg, B, H, W, C, e.s));
       acc_grad(e, x, y->g);
     });
@@ -845,6 +889,7 @@ Tensor* op_ln(Exec& e, Tensor* a, Tensor* b, LNp* ln) {
   const int C = a->C;
   Tensor* y = e.newt(R, C, a->B, a->H, a->W);
   float* mr = (float*)e.alloc((size_t)2 * R * 4);
+  WORK(e, 0, (double)R * C * e.esz() * (b ? 3 : 2));
   LCH(e, launch_layernorm(e.dt, a->p, b ? b->p : nullptr, ln->w.p, ln->b.p, y->p, mr, R, C, 1e-5f, 0.f, nullptr, 0, e.s));
   if (e.rec)
     e.tape.push_back([&e, a, b, y, ln, mr, R, C]() {
@@ -852,6 +897,7 @@ Tensor* op_ln(Exec& e, Tensor* a, Tensor* b, LNp* ln) {
       int ba = 0, bb = 0;
       void* da = e.grad(a, &ba);
       void* db = b ? e.grad(b, &bb) : nullptr;
+      WORK(e, 0, (double)R * C * e.esz() * ((b ? 5 : 3) + ba + (b ? bb : 0)));
       LCH(e, launch_layernorm_bwd(e.dt, y->g, a->p, b ? b->p : nullptr, ln->w.p, mr, da, db, ba, bb, ln->w.g, ln->b.g, R, C,
                                   0.f, nullptr, 0, e.s));
     });
@@ -862,12 +908,14 @@ Tensor* op_quirk(Exec& e, Tensor* yv) {  // networks/EfficientSATRN.py:269
   used(yv);
   const int B = yv->B, HW = yv->H * yv->W, C = yv->C;
   Tensor* z = e.newt(yv->rows, C, B, yv->H, yv->W);
+  WORK(e, 0, (double)yv->rows * C * e.esz() * 2);
   LCH(e, launch_reshape_quirk(e.dt, 0, yv->p, z->p, B, HW, C, 0, e.s));
   if (e.rec)
     e.tape.push_back([&e, yv, z, B, HW, C]() {
       if (!z->g) return;
       int beta;
       void* dy = e.grad(yv, &beta);
+      WORK(e, 0, (double)yv->rows * C * e.esz() * (beta ? 3 : 2));
       LCH(e, launch_reshape_quirk(e.dt, 1, z->g, dy, B, HW, C, beta, e.s));
     });
   return z;
@@ -891,7 +939,7 @@ Tensor* op_attn(Exec& e, Tensor* qt, int qoff, Tensor* kvt, int koff, int voff, 
   p.ldq = qt->C; p.ldk = kvt->C; p.ldv = kvt->C; p.ldo = D;
   p.sq_b = (long)Lq * qt->C; p.sk_b = (long)Lk * kvt->C; p.sv_b = (long)Lk * kvt->C; p.so_b = (long)Lq * D;
   p.causal = causal; p.pad_id = e.m->cfg.pad_id; p.inv_temp = 1.0f / sqrtf((float)D); p.drop_p = drop_p; p.seed = seed; p.site = site;
-  e.nflops = 4.0 * (double)B * heads * Lq * Lk * hd;
+  WORK(e, 4.0 * (double)B * heads * Lq * Lk * hd, ((double)B * Lq * D * 2 + (double)B * Lk * D * 2) * e.esz());
   LCH(e, launch_attn(e.dt, 0, p, e.s));
   if (e.rec)
     e.tape.push_back([&e, qt, qoff, kvt, koff, voff, o, p, B, Lq, Lk, heads, hd, D, es]() {
@@ -905,7 +953,8 @@ Tensor* op_attn(Exec& e, Tensor* qt, int qoff, Tensor* kvt, int koff, int voff, 
       (void)bq;
       AttnP q = p;
       q.dO = o->g; q.dQ = (char*)dq + qoff * es; q.dS = dS; q.Pd = Pd;
-      e.nflops = 6.0 * (double)B * heads * Lq * Lk * hd;
+      // reads q, k, v, o, dO; writes dQ and the two [B, heads, Lq, LkP] probability / score-gradient tensors
+      WORK(e, 6.0 * (double)B * heads * Lq * Lk * hd, ((double)B * Lq * D * 4 + (double)B * Lk * D * 2 + 2.0 * B * heads * Lq * LkP) * es);
       LCH(e, launch_attn(e.dt, 1, q, e.s));
       WgradP w;
       memset(&w, 0, sizeof(w));
@@ -913,11 +962,11 @@ Tensor* op_attn(Exec& e, Tensor* qt, int qoff, Tensor* kvt, int koff, int voff, 
       w.sY_o = (long)heads * Lq * LkP; w.sY_i = (long)Lq * LkP;
       w.sW_o = (long)Lk * kvt->C; w.sW_i = hd; w.ldw = kvt->C;
       // dV = Pd^T dO
-      e.nflops = 2.0 * (double)B * heads * Lq * Lk * hd;
+      WORK(e, 2.0 * (double)B * heads * Lq * Lk * hd, ((double)B * heads * Lq * LkP + (double)B * Lq * D + (double)B * Lk * D) * es);
       w.dY = Pd; w.A = o->g; w.lda = D; w.sA_o = (long)Lq * D; w.sA_i = hd; w.dW = (char*)dkv + voff * es;
       LCH(e, launch_wgrad(e.dt, w, e.s));
       // dK = dS^T Q
-      e.nflops = 2.0 * (double)B * heads * Lq * Lk * hd;
+      WORK(e, 2.0 * (double)B * heads * Lq * Lk * hd, ((double)B * heads * Lq * LkP + (double)B * Lq * D + (double)B * Lk * D) * es);
       w.dY = dS; w.A = (char*)qt->p + qoff * es; w.lda = qt->C; w.sA_o = (long)Lq * qt->C; w.sA_i = hd; w.dW = (char*)dkv + koff * es;
       LCH(e, launch_wgrad(e.dt, w, e.s));
     });
@@ -932,10 +981,12 @@ Tensor* op_embed(Exec& e, const int64_t* ids, int ld_ids, int B, int L, int pos0
   const uint32_t site = drop_p > 0.f ? e.site++ : 0;
   const uint32_t* seed = (const uint32_t*)(scal(m) + SC_SEED);
   const float* pe = (const float*)(m->ws + m->off_pe1d);
+  WORK(e, 0, (double)B * L * D * (4 + e.esz()));
   LCH(e, launch_embed(e.dt, ids, m->embed.p, pe, y->p, B, L, ld_ids, D, pos0, drop_p, seed, site, e.s, m->embed.N));
   if (e.rec)
     e.tape.push_back([&e, m, ids, ld_ids, y, B, L, D, drop_p, seed, site]() {
       if (!y->g) return;
+      WORK(e, 0, (double)B * L * D * (4 + e.esz()));
       LCH(e, launch_embed_bwd(e.dt, ids, y->g, m->embed.g, B, L, ld_ids, D, drop_p, seed, site, e.s, m->embed.N));
     });
   return y;
@@ -986,9 +1037,10 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb) {
   float* u1 = (float*)e.alloc((size_t)B * S * 4);
   float* s1 = (float*)e.alloc((size_t)B * S * 4);
   Tensor* gate = e.newt(B, C);
-  e.nbytes = (double)x->rows * C * e.esz();
+  WORK(e, 4.0 * (double)B * C * S, (double)x->rows * C * e.esz() + (double)C * S * e.esz() * 2);
   LCH(e, launch_se_fwd(e.dt, x->p, eb->se_r.fwd, eb->se_rb.p, eb->se_e.fwd, eb->se_eb.p, pooled, u1, s1, gate->p, B, HW, C, S, e.s));
   Tensor* y = e.newt(x->rows, C, B, x->H, x->W);
+  WORK(e, 0, (double)x->rows * C * e.esz() * 2);
   LCH(e, launch_se_scale(e.dt, x->p, gate->p, y->p, B, HW, C, e.s));
   if (e.rec)
     e.tape.push_back([&e, x, y, gate, eb, pooled, u1, s1, B, HW, C, S]() {
@@ -997,12 +1049,14 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb) {
       void* dpooled = e.alloc((size_t)B * C * e.esz());
       float* dz2 = (float*)e.alloc((size_t)B * C * 4);
       float* du1 = (float*)e.alloc((size_t)B * S * 4);
+      WORK(e, 0, (double)x->rows * C * e.esz() * 2);
       LCH(e, launch_se_bwd_gate(e.dt, y->g, x->p, dgate, B, HW, C, e.s));
       {
         // data path on the main chain; the two weight-gradient products only feed the optimizer -> side stream
         const int dt = e.dt; void* gp = gate->p; const void* w1 = eb->se_r.fwd; const void* w2 = eb->se_e.fwd;
         float* g1 = eb->se_r.g; float* gb1 = eb->se_rb.g; float* g2 = eb->se_e.g; float* gb2 = eb->se_eb.g;
         if (e.prof || e.dry) {
+          WORK(e, 8.0 * (double)B * C * S, (double)C * S * e.esz() * 2 + (double)B * C * 16);
           LCH(e, launch_se_bwd(dt, dgate, gp, u1, s1, pooled, w1, w2, dz2, du1, dpooled, g1, gb1, g2, gb2, B, C, S, e.s, 3));
         } else {
           launch_se_bwd(dt, dgate, gp, u1, s1, pooled, w1, w2, dz2, du1, dpooled, g1, gb1, g2, gb2, B, C, S, e.s, 1);
@@ -1018,6 +1072,7 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb) {
       } else {
         int beta;
         void* dx = e.grad(x, &beta);
+        WORK(e, 0, (double)x->rows * C * e.esz() * (beta ? 3 : 2));
         LCH(e, launch_se_bwd_x(e.dt, y->g, gate->p, dpooled, dx, B, HW, C, beta, e.s));
       }
     });
@@ -1084,11 +1139,19 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
       x = op_maxpool(e, x);
     }
   } else {
+    auto stage_mark = [&e](const std::string& nm) {  // forward mark now, backward mark when the tape reaches this point
+      if (!g_stage_prof || e.dry) return;
+      e.mark(("f:" + nm).c_str());
+      if (e.rec) { Exec* ep = &e; e.tape.push_back([ep, nm]() { ep->mark(("b:" + nm).c_str()); }); }
+    };
+    stage_mark("begin");
     x = op_stem(e, img, &m->stem, B, c.rgb, c.height, c.width, 2, 0);
     x = op_bn_act(e, x, &m->stem_bn, ACT_SILU, nullptr);
+    stage_mark("stem");
     for (size_t bi = 0; bi < m->blocks.size(); ++bi) {
       if ((int)bi == m->late_block) m->seg_mark[0] = e.tape.size();
       x = eff_block(e, x, &m->blocks[bi]);
+      if (bi + 1 == m->blocks.size() || m->blocks[bi + 1].cout != m->blocks[bi].cout) stage_mark("cout" + std::to_string(m->blocks[bi].cout));
     }
     int H = x->H, W = x->W;
     x = op_gemm(e, x, &m->conv_last, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
@@ -1103,7 +1166,9 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
   Tensor* h0 = op_gemm(e, pooled, &m->pe_d0, &m->pe_b0, ACT_RELU, e.drop, nullptr);
   Tensor* gate = op_gemm(e, h0, &m->pe_d1, &m->pe_b1, ACT_SIGMOID, 0.f, nullptr);
   x = op_posenc_apply(e, x, gate);
+  if (g_stage_prof && !e.dry) { e.mark("f:posenc"); if (e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->mark("b:enc_layers"); }); } }
   for (auto& el : m->enc) x = encoder_layer(e, x, &el);
+  if (g_stage_prof && !e.dry) { e.mark("f:enc_layers"); if (e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->mark("b:decoder"); }); } }
   // inference postpones products until their BatchNorm is known (op_gemm / op_dwconv -> op_bn_act): none may be left over
   for (auto& t : e.tens)
     if (t->pend || t->pend_dw) { m->err = "internal: a postponed product was never launched"; e.oom = true; }
@@ -1454,12 +1519,29 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
   }
   auto body = [&]() -> int {
     if (phase & 1) {
+      if (g_stage_prof) { m->ex->s = s; m->ex->mark_report(); m->ex->mark("start"); }
       launch_seed_advance((uint32_t*)(scal(m) + SC_SEED), s);
-      launch_fill(m->grads, 0, (size_t)m->n_params * 4, s);
+      // clearing the 109 MB gradient buffer is not on the forward's path: eager two-stream steps do it on the side stream
+      // (behind everything the previous step queued on `s`, i.e. its optimizer), beside the forward; the backward waits for it
+      Exec& ex = *m->ex;
+      const bool side_zero = ex.s2 && !ex.serial && !use_graph && !getenv("SATRN_ZERO_ON_CHAIN");
+      static hipEvent_t evz0 = nullptr, evz1 = nullptr;
+      if (side_zero) {
+        if (!evz0) { (void)hipEventCreateWithFlags(&evz0, hipEventDisableTiming); (void)hipEventCreateWithFlags(&evz1, hipEventDisableTiming); }
+        (void)hipEventRecord(evz0, s);
+        (void)hipStreamWaitEvent(ex.s2, evz0, 0);
+        launch_fill(m->grads, 0, (size_t)m->n_params * 4, ex.s2);
+        (void)hipEventRecord(evz1, ex.s2);
+      } else {
+        launch_fill(m->grads, 0, (size_t)m->n_params * 4, s);
+      }
       int rc = model_forward(m, img, expected, B, L, train_mode, true, nullptr, s);
       if (rc) return rc;
+      if (side_zero) (void)hipStreamWaitEvent(s, evz1, 0);
+      if (g_stage_prof) m->ex->mark("f:decoder");
       rc = model_loss_backward(m, expected, B, L, s);
       if (rc) return rc;
+      if (g_stage_prof) m->ex->mark("b:join");
     }
     if (phase & 2) {
       float* am = m->adam_m;
@@ -1476,7 +1558,9 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
         launch_adamw(m->params, m->grads, am, av, ne, scal(m) + SC_GNORM, scal(m) + SC_HYPER, s);
         launch_adamw(m->params + ne, m->grads + ne, am + ne, av + ne, nd, scal(m) + SC_GNORM2, scal(m) + SC_HYPER2, s);
       }
-      return model_pack_weights(m, s);
+      int rc = model_pack_weights(m, s);
+      if (g_stage_prof) m->ex->mark("opt+pack");
+      return rc;
     }
     return 0;
   };

@@ -159,6 +159,9 @@ struct Exec {
   hipStream_t side(); void join();
   std::vector<std::function<void(hipStream_t)>> pending; void defer(std::function<void(hipStream_t)> fn); void flush_side();
 
+  // SATRN_STAGE_PROF=1: events on the main stream at stage boundaries of an ordinary eager step (forward and, through tape
+  // closures, backward) -> per-stage wall time of the critical chain, printed by the next step
+  std::vector<std::pair<std::string, hipEvent_t>> marks; void mark(const char* name); void mark_report();
   void* alloc(size_t bytes);
   float* zalloc(size_t nfloats);
   Tensor* newt(long rows, int C, int B = 0, int H = 0, int W = 0, bool f32 = false);

@@ -218,3 +218,8 @@ void launch_sift(const float* x, int ld, int32_t* state, const int32_t* rules, i
 void launch_sift_reset(int32_t* state, int B, int sos, hipStream_t s);
 void launch_sift_strided(float* x, int ld, int32_t* state, const int32_t* rules, int B, int V, int64_t* targets, int ldt,
                          hipStream_t s);
+
+// ---- evaluation-time image transform (kernels_image.hip): one descriptor per image (device pointer to uint8 HWC pixels, row stride in bytes)
+struct ImageDesc { const unsigned char* data; int h, w, stride, pad_; };
+void launch_image_preprocess(const ImageDesc* descs_dev, int B, int C, int H, int W, float* out /*[B][C][H][W]*/, const float* mean3,
+                             const float* std3, hipStream_t s);

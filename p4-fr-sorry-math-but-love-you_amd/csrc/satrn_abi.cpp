@@ -423,6 +423,11 @@ float* satrn_model_adam_state(satrn_model* h, int which) {
   Model* m = h->m;
   return which == 0 ? m->adam_m : m->adam_v;
 }
+int satrn_image_preprocess(const void* descs, int B, int C, int H, int W, float* out, const float* mean3, const float* std3, void* st) {
+  if (!descs || !out || !mean3 || !std3 || B <= 0 || (C != 1 && C != 3) || H <= 0 || W <= 0) return fail(-1, "satrn_image_preprocess: bad argument (C must be 1 or 3)");
+  launch_image_preprocess((const ImageDesc*)descs, B, C, H, W, out, mean3, std3, S(st));
+  return done("image_preprocess");
+}
 int satrn_device_error(void* st) { return (int)device_error_read_clear(S(st)); }
 int satrn_model_bind_optimizer(satrn_model* h, float* exp_avg, float* exp_avg_sq) { return mret(h, model_bind_optimizer(h->m, exp_avg, exp_avg_sq), "bind_optimizer"); }
 long satrn_model_get_step(satrn_model* h) { return h->m->adam_t; }
