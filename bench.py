@@ -161,6 +161,47 @@ def precision_report(H, W, T, B, dev):
     return res, f32
 
 
+def swin_report(dev, B=16, T=128):
+    """BASELINE configs[3]: SwinTRN (networks/SWIN.py: Swin-B/384 encoder + SWIN.yaml decoder) training step, bf16, batch 16.
+    The reference cannot run 256x256 (PatchEmbed asserts 384, 64 patches % window 12 != 0: SURVEY section 2 row 3), so this is
+    the reference's own 384x384 geometry."""
+    import satrn_amd
+    flags = satrn_amd.Flags(dict(network="SWIN", input_size=dict(height=384, width=384),
+                                 SATRN=dict(encoder=dict(hidden_dim=300, filter_dim=600, layer_num=6, head_num=8),
+                                            decoder=dict(src_dim=1024, hidden_dim=512, filter_dim=512, layer_num=4, head_num=8)),
+                                 data=dict(rgb=3), dropout_rate=0.1)).get()
+    torch.manual_seed(21)
+    m = satrn_amd.SWIN(flags, _DS(), True, dtype="bf16").to(dev)
+    m.train()
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(B, 3, 384, 384, generator=g).to(dev)
+    exp = torch.randint(3, 245, (B, T + 1), generator=g)
+    exp[:, 0] = 0
+    exp[:, -1] = 1
+    exp = exp.to(dev)
+    for _ in range(3):
+        m.train_step(img, exp, 5e-4)
+    torch.cuda.synchronize()
+    n = 8
+    t0 = time.perf_counter()
+    for _ in range(n):
+        m.train_step(img, exp, 5e-4)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    loss = m.read_loss()[0]
+    prof = m.profile_step(img, exp)
+    fl = sum(p_["flops"] for p_ in prof)
+    by = sum(p_["bytes"] for p_ in prof)
+    top = [dict(kernel=p_["kernel"], launches=p_["launches"], ms=round(p_["ms"], 3), gflop=round(p_["flops"] / 1e9, 1),
+                mfma_frac=round(p_["flops"] / max(p_["ms"], 1e-6) / 1e9 / PEAK_BF16_TFLOPS, 4)) for p_ in prof[:6]]
+    del m
+    return dict(workload="SwinTRN train step (fwd+CE+bwd+clip+AdamW), bs16, 3x384x384, teacher-forced T=128, dropout 0.1, drop_path 0.5 (BASELINE configs[3] at the reference's 384 geometry)",
+                ms_per_step=round(ms, 3), images_per_s=round(B / ms * 1e3, 1), steps=n, dtype="bf16", final_loss=round(loss, 4),
+                step_gflop=round(fl / 1e9, 1), step_algorithmic_mbytes=round(by / 1e6, 1),
+                mfma_frac=round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), hbm_frac=round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                launches=sum(p_["launches"] for p_ in prof), top_families=top)
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -429,6 +470,14 @@ def main():
                 import traceback
                 traceback.print_exc()
                 out["accuracy_bf16_vs_f32"] = dict(error=repr(ex))
+        if world == 1 and not args.no_extras:
+            log("swin ...")
+            try:
+                out["swin_trn"] = swin_report(dev)
+            except Exception as ex:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                out["swin_trn"] = dict(error=repr(ex))
         if not args.no_cpu_baseline and world == 1 and not args.no_decode:
             log("cpu decode baseline ...")
             try:

@@ -182,7 +182,7 @@ int satrn_clip_adamw(float* params, const float* grads, float* exp_avg, float* e
 typedef struct satrn_model satrn_model;
 
 typedef struct satrn_config {
-  int network; /* 0 LiteSATRN, 1 EfficientSATRN */
+  int network; /* 0 LiteSATRN, 1 EfficientSATRN, 2 SwinTRN */
   int rgb;     /* FLAGS.data.rgb */
   int height, width;
   int enc_hidden, enc_filter, enc_heads, enc_layers;
@@ -191,6 +191,10 @@ typedef struct satrn_config {
   int pad_id, sos_id;
   float dropout; /* FLAGS.dropout_rate */
   int dtype;
+  /* network == 2, SwinTRN (networks/SWIN.py:1024-1031; the reference hard-codes img 384, patch 4, embed 128, depths 2/2/18/2,
+   * heads 4/8/16/32, window 12, drop_path 0.5, 21841 head classes; dec_src = enc_hidden = 8 * embed).  Ignored otherwise. */
+  int swin_embed, swin_depths[4], swin_heads[4], swin_window, swin_patch, swin_head_classes;
+  float swin_drop_path;
 } satrn_config;
 
 satrn_model* satrn_model_create(const satrn_config* cfg);

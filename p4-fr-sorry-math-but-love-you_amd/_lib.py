@@ -20,7 +20,9 @@ class satrn_config(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in
                 ("network", "rgb", "height", "width", "enc_hidden", "enc_filter", "enc_heads", "enc_layers", "dec_src",
                  "dec_hidden", "dec_filter", "dec_heads", "dec_layers", "num_classes", "pad_id", "sos_id")] + \
-               [("dropout", ctypes.c_float), ("dtype", ctypes.c_int)]
+               [("dropout", ctypes.c_float), ("dtype", ctypes.c_int), ("swin_embed", ctypes.c_int), ("swin_depths", ctypes.c_int * 4),
+                ("swin_heads", ctypes.c_int * 4), ("swin_window", ctypes.c_int), ("swin_patch", ctypes.c_int),
+                ("swin_head_classes", ctypes.c_int), ("swin_drop_path", ctypes.c_float)]
 
 
 def parse_header(path=HEADER):

@@ -66,6 +66,7 @@ DEVI float act_fwd(float u, int act) {
   if (act == ACT_RELU) return u > 0.f ? u : 0.f;
   if (act == ACT_SILU) return u * sigmoidf_(u);
   if (act == ACT_SIGMOID) return sigmoidf_(u);
+  if (act == ACT_GELU) return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));
   return u;
 }
 // derivative of act at pre-activation u
@@ -73,6 +74,7 @@ DEVI float act_bwd(float u, int act) {
   if (act == ACT_RELU) return u > 0.f ? 1.f : 0.f;
   if (act == ACT_SILU) { float s = sigmoidf_(u); return s * (1.f + u * (1.f - s)); }
   if (act == ACT_SIGMOID) { float s = sigmoidf_(u); return s * (1.f - s); }
+  if (act == ACT_GELU) return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
   return 1.f;
 }
 

@@ -143,6 +143,7 @@ void* Exec::grad(Tensor* t, int* beta) {
 namespace {
 struct Builder {
   Model* m;
+  int winit = 0;  // attention / feed-forward Linear weights: 0 xavier_normal_ (SATRN, networks/EfficientSATRN.py:193-196,336-337), 2 torch default (SWIN.py:776-793)
   int64_t addp(const std::string& name, std::vector<int64_t> shape, int init, int fan_in, int fan_out) {
     StateEntry e;
     e.name = name; e.shape = shape; e.kind = ST_PARAM; e.offset = m->n_params; e.init = init;
@@ -201,9 +202,9 @@ struct Builder {
   // flat order: q.w k.w v.w q.b k.b v.b out.w out.b  (so [q;k;v] and [k;v] are contiguous fused operands)
   MHAp mha(const std::string& name, int D, int Ksrc, int heads) {
     MHAp a; a.D = D; a.heads = heads; a.cross = (Ksrc != D);
-    int64_t qo = addp(name + ".q_linear.weight", {D, D}, 0, D, D);
-    int64_t ko = addp(name + ".k_linear.weight", {D, Ksrc}, 0, Ksrc, D);
-    addp(name + ".v_linear.weight", {D, Ksrc}, 0, Ksrc, D);
+    int64_t qo = addp(name + ".q_linear.weight", {D, D}, winit, D, D);
+    int64_t ko = addp(name + ".k_linear.weight", {D, Ksrc}, winit, Ksrc, D);
+    addp(name + ".v_linear.weight", {D, Ksrc}, winit, Ksrc, D);
     int64_t qb = addp(name + ".q_linear.bias", {D}, 3, D, 0);
     int64_t kb = addp(name + ".k_linear.bias", {D}, 3, Ksrc, 0);
     addp(name + ".v_linear.bias", {D}, 3, Ksrc, 0);
@@ -216,7 +217,7 @@ struct Builder {
     // q-only view (the step decoder projects the single query row separately from the history's K/V)
     a.qonly.kind = WK_DENSE; a.qonly.off = qo; a.qonly.K = D; a.qonly.N = D; a.qonly.ldb = D; a.qonly.Co = D; a.qonly.Ci = D;
     a.bq.off = qb; a.bq.n = D;
-    a.out = dense(name + ".out_linear.weight", D, D, 0);
+    a.out = dense(name + ".out_linear.weight", D, D, winit);
     a.bout = vec(name + ".out_linear.bias", D, 3, D);
     return a;
   }
@@ -235,7 +236,9 @@ Model* model_create(const SatrnConfig& cfg) {
   m->cfg = cfg;
   Builder b{m};
   const int D = cfg.enc_hidden;
-  if (cfg.network == 0) {
+  if (cfg.network == 2) {
+    // built below (after the shared decoder dims are known)
+  } else if (cfg.network == 0) {
     int ch[5] = {cfg.rgb, D / 2, D, D, D};
     for (int i = 0; i < 4; ++i) {
       std::string n = "encoder.shallow_cnn.conv" + std::to_string(i) + ".weight";
@@ -282,12 +285,67 @@ Model* model_create(const SatrnConfig& cfg) {
     m->conv_last = b.dense(p + "conv_last.weight", D, 256, 1, true);
     m->bn_last = b.bn(p + "bn2", D, 1e-5f);
   }
+  if (cfg.network == 2) {
+    // SwinTransformer (networks/SWIN.py:590-755) in torch's state_dict order: a module's own parameters, then its buffers,
+    // then its children.  init 9 = trunc_normal_(std 0.02) (every nn.Linear weight, the bias tables, the position embedding:
+    // :137,:665,:707-710), 7 / 8 = the relative_position_index / attn_mask buffers (filled by the host mirror; the kernels
+    // derive both from the geometry)
+    const std::string p = "encoder.";
+    const int E = cfg.swin_embed, P = cfg.swin_patch, Cin = cfg.rgb, R0 = cfg.height / P;
+    auto lin = [&](const std::string& n, int N, int K, bool bias, Wt* w, Vec* bv) {
+      *w = b.dense(n + ".weight", N, K, 9);
+      if (bias) *bv = b.vec(n + ".bias", N, 5);
+    };
+    m->sw_patch.kind = WK_DENSE; m->sw_patch.N = E; m->sw_patch.K = Cin * P * P; m->sw_patch.Co = E; m->sw_patch.Ci = m->sw_patch.K; m->sw_patch.taps = 1; m->sw_patch.ldb = (E + 7) & ~7;
+    m->sw_patch.off = b.addp(p + "patch_embed.proj.weight", {E, Cin, P, P}, 1, Cin * P * P, E);
+    m->sw_patch_b = b.vec(p + "patch_embed.proj.bias", E, 3, Cin * P * P);
+    m->sw_patch_norm = b.ln(p + "patch_embed.norm", E);
+    m->sw_ape.n = R0 * R0 * E; m->sw_ape.off = b.addp(p + "absolute_pos_embed", {1, R0 * R0, E}, 9, 0, 0);
+    int total_blocks = 0, bi = 0;
+    for (int i = 0; i < 4; ++i) total_blocks += cfg.swin_depths[i];
+    for (int i = 0; i < 4; ++i) {
+      SwinStage st;
+      st.dim = E << i; st.res = R0 >> i; st.down = i < 3;
+      for (int j = 0; j < cfg.swin_depths[i]; ++j, ++bi) {
+        SwinBlock sb;
+        sb.dim = st.dim; sb.heads = cfg.swin_heads[i]; sb.res = st.res;
+        sb.ws = cfg.swin_window; sb.shift = (j % 2 == 0) ? 0 : cfg.swin_window / 2;
+        if (st.res <= sb.ws) { sb.ws = st.res; sb.shift = 0; }  // :253-256
+        sb.drop_path = total_blocks > 1 ? cfg.swin_drop_path * (float)bi / (float)(total_blocks - 1) : 0.f;  // torch.linspace (:669-671)
+        const std::string q = p + "layers." + std::to_string(i) + ".blocks." + std::to_string(j) + ".";
+        const int N = sb.ws * sb.ws, C = sb.dim;
+        if (sb.shift > 0) b.addb(q + "attn_mask", {(st.res / sb.ws) * (st.res / sb.ws), N, N}, ST_BUF_F32, 8);
+        sb.n1 = b.ln(q + "norm1", C);
+        sb.rpb.n = (2 * sb.ws - 1) * (2 * sb.ws - 1) * sb.heads;
+        sb.rpb.off = b.addp(q + "attn.relative_position_bias_table", {(2 * sb.ws - 1) * (2 * sb.ws - 1), sb.heads}, 9, 0, 0);
+        b.addb(q + "attn.relative_position_index", {N, N}, ST_BUF_I64, 7);
+        lin(q + "attn.qkv", 3 * C, C, true, &sb.qkv, &sb.bqkv);
+        lin(q + "attn.proj", C, C, true, &sb.proj, &sb.bproj);
+        sb.n2 = b.ln(q + "norm2", C);
+        lin(q + "mlp.fc1", 4 * C, C, true, &sb.fc1, &sb.b1);
+        lin(q + "mlp.fc2", C, 4 * C, true, &sb.fc2, &sb.b2);
+        st.blocks.push_back(sb);
+      }
+      if (st.down) {
+        const std::string q = p + "layers." + std::to_string(i) + ".downsample.";
+        Vec none;
+        lin(q + "reduction", 2 * st.dim, 4 * st.dim, false, &st.dred, &none);
+        st.dnorm = b.ln(q + "norm", 4 * st.dim);
+      }
+      m->swin.push_back(st);
+    }
+    m->sw_norm = b.ln(p + "norm", E << 3);
+    lin(p + "head", cfg.swin_head_classes, E << 3, true, &m->sw_head, &m->sw_head_b);
+    m->sw_head.kind = WK_STEM;  // the classification head is never applied (:732-739): a parameter for state_dict parity only, not packed
+  }
+  if (cfg.network != 2) {
   m->pe_d0 = b.dense("encoder.positional_encoding.dense0.weight", D / 2, D, 0);
   m->pe_b0 = b.vec("encoder.positional_encoding.dense0.bias", D / 2, 3, D);
   m->pe_d1 = b.dense("encoder.positional_encoding.dense1.weight", 2 * D, D / 2, 0);
   m->pe_b1 = b.vec("encoder.positional_encoding.dense1.bias", 2 * D, 3, D / 2);
+  }
   const int Fe = cfg.enc_filter;
-  for (int l = 0; l < cfg.enc_layers; ++l) {
+  for (int l = 0; l < (cfg.network == 2 ? 0 : cfg.enc_layers); ++l) {
     std::string q = "encoder.attention_layers." + std::to_string(l) + ".";
     EncLayer el;
     el.norm = b.ln(q + "norm", D);
@@ -302,6 +360,7 @@ Model* model_create(const SatrnConfig& cfg) {
     m->enc.push_back(el);
   }
   const int Dd = cfg.dec_hidden, Ds = cfg.dec_src, Ff = cfg.dec_filter, V = cfg.num_classes;
+  if (cfg.network == 2) b.winit = 2;
   m->embed.kind = WK_STEM; m->embed.N = V + 1; m->embed.K = Dd;
   m->embed.off = b.addp("decoder.embedding.weight", {V + 1, Dd}, 6, 0, 0);
   for (int l = 0; l < cfg.dec_layers; ++l) {
@@ -313,10 +372,13 @@ Model* model_create(const SatrnConfig& cfg) {
     dl.cross_att.cross = true;
     dl.cross_att.qkv.N = Dd; dl.cross_att.qkv.ldb = Dd; dl.cross_att.qkv.Co = Dd; dl.cross_att.bqkv.n = Dd;
     dl.ln2 = b.ln(q + "attention_norm", Dd);
-    dl.lin0 = b.dense(q + "feedforward_layer.linear0.weight", Ff, Dd, 0);
-    dl.b0 = b.vec(q + "feedforward_layer.linear0.bias", Ff, 3, Dd);
-    dl.lin1 = b.dense(q + "feedforward_layer.linear1.weight", Dd, Ff, 0);
-    dl.b1 = b.vec(q + "feedforward_layer.linear1.bias", Dd, 3, Ff);
+    // SWIN.py's Feedforward is an nn.Sequential (:826-838): state_dict names layers.0 / layers.3 instead of linear0 / linear1
+    const std::string f0 = cfg.network == 2 ? "feedforward_layer.layers.0" : "feedforward_layer.linear0";
+    const std::string f1 = cfg.network == 2 ? "feedforward_layer.layers.3" : "feedforward_layer.linear1";
+    dl.lin0 = b.dense(q + f0 + ".weight", Ff, Dd, b.winit);
+    dl.b0 = b.vec(q + f0 + ".bias", Ff, 3, Dd);
+    dl.lin1 = b.dense(q + f1 + ".weight", Dd, Ff, b.winit);
+    dl.b1 = b.vec(q + f1 + ".bias", Dd, 3, Ff);
     dl.ln3 = b.ln(q + "feedforward_norm", Dd);
     m->dec.push_back(dl);
   }
@@ -329,7 +391,17 @@ Model* model_create(const SatrnConfig& cfg) {
   auto regbn = [&](BNp& x) { m->all_bn.push_back(&x); regv(x.w); regv(x.b); };
   auto regln = [&](LNp& x) { regv(x.w); regv(x.b); };
   auto regmha = [&](MHAp& a) { regw(a.qkv); regw(a.kv); regw(a.qonly); regv(a.bqkv); regv(a.bkv); regv(a.bq); regw(a.out); regv(a.bout); };
-  if (cfg.network == 0) {
+  if (cfg.network == 2) {
+    regw(m->sw_patch); regv(m->sw_patch_b); regln(m->sw_patch_norm); regv(m->sw_ape);
+    for (auto& st : m->swin) {
+      for (auto& sb : st.blocks) {
+        regln(sb.n1); regln(sb.n2); regv(sb.rpb); regw(sb.qkv); regv(sb.bqkv); regw(sb.proj); regv(sb.bproj);
+        regw(sb.fc1); regv(sb.b1); regw(sb.fc2); regv(sb.b2);
+      }
+      if (st.down) { regw(st.dred); regln(st.dnorm); }
+    }
+    regln(m->sw_norm); regw(m->sw_head); regv(m->sw_head_b);
+  } else if (cfg.network == 0) {
     for (auto& w : m->lite_conv) regw(w);
     for (auto& x : m->lite_bn) regbn(x);
   } else {
@@ -341,7 +413,7 @@ Model* model_create(const SatrnConfig& cfg) {
     }
     regw(m->conv_last); regbn(m->bn_last);
   }
-  regw(m->pe_d0); regw(m->pe_d1); regv(m->pe_b0); regv(m->pe_b1);
+  if (cfg.network != 2) { regw(m->pe_d0); regw(m->pe_d1); regv(m->pe_b0); regv(m->pe_b1); }
   for (auto& el : m->enc) {
     regln(el.norm); regmha(el.att); regw(el.conv0); regw(el.conv1); regw(el.dw); regv(el.dwb);
     regbn(el.norm0); regbn(el.dwnorm); regbn(el.norm1);
@@ -373,7 +445,19 @@ Model* model_create(const SatrnConfig& cfg) {
   m->off_sumsq = take(1024 * 4);
   m->off_pe1d = take((size_t)500 * Dd * 4);
   if (cfg.network == 0) { m->feat_h = cfg.height / 16; m->feat_w = cfg.width / 16; }
+  else if (cfg.network == 2) { m->feat_h = m->feat_w = (cfg.height / cfg.swin_patch) >> 3; }
   else { m->feat_h = cfg.height / 32; m->feat_w = cfg.width / 32; }
+  for (auto& st : m->swin)
+    for (auto& sb : st.blocks) {
+      if (sb.shift <= 0) continue;
+      for (size_t g = 0; g < m->sw_geo.size(); ++g)
+        if (m->sw_geo[g].res == sb.res && m->sw_geo[g].ws == sb.ws && m->sw_geo[g].shift == sb.shift) sb.geo = (int)g;
+      if (sb.geo < 0) {
+        const size_t nW = (size_t)(sb.res / sb.ws) * (sb.res / sb.ws), N = (size_t)sb.ws * sb.ws;
+        m->sw_geo.push_back({sb.res, sb.ws, sb.shift, take(nW * N * N * 4)});
+        sb.geo = (int)m->sw_geo.size() - 1;
+      }
+    }
   m->off_hpos = take((size_t)std::max(m->feat_h, 1) * D * 4);
   m->off_wpos = take((size_t)std::max(m->feat_w, 1) * D * 4);
   m->packdesc_bytes = (m->all_w.size() + 8) * sizeof(PackDesc);
@@ -501,6 +585,23 @@ int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s) {
   (void)hipStreamSynchronize(s);
   tab2d(m->feat_h, m->off_hpos);
   tab2d(m->feat_w, m->off_wpos);
+  for (auto& g : m->sw_geo) {
+    // networks/SWIN.py:288-309: region ids 0..8 of the SHIFTED map (h / w slices [0, -ws), [-ws, -shift), [-shift, end)),
+    // window-partitioned; mask[w][i][j] = -100 where the two tokens come from different regions
+    const int nWw = g.res / g.ws, N = g.ws * g.ws;
+    std::vector<float> mk((size_t)nWw * nWw * N * N);
+    auto region = [&](int v) { return v < g.res - g.ws ? 0 : (v < g.res - g.shift ? 1 : 2); };
+    for (int wy = 0; wy < nWw; ++wy)
+      for (int wx = 0; wx < nWw; ++wx)
+        for (int i = 0; i < N; ++i)
+          for (int j = 0; j < N; ++j) {
+            const int idi = 3 * region(wy * g.ws + i / g.ws) + region(wx * g.ws + i % g.ws);
+            const int idj = 3 * region(wy * g.ws + j / g.ws) + region(wx * g.ws + j % g.ws);
+            mk[(((size_t)wy * nWw + wx) * N + i) * N + j] = idi != idj ? -100.0f : 0.0f;
+          }
+    (void)hipMemcpyAsync(m->ws + g.off, mk.data(), mk.size() * 4, hipMemcpyHostToDevice, s);
+    (void)hipStreamSynchronize(s);
+  }
   (void)hipMemsetAsync(m->ws + m->off_scalars, 0, SC_COUNT * 4, s);
   float one = 1.0f;
   (void)hipMemcpyAsync(scal(m) + SC_ONE, &one, 4, hipMemcpyHostToDevice, s);
@@ -992,6 +1093,196 @@ Tensor* op_embed(Exec& e, const int64_t* ids, int ld_ids, int B, int L, int pos0
   return y;
 }
 
+// ---- SwinTRN ops (networks/SWIN.py) ---------------------------------------------------------------------
+// rows permutation: cyclic shift + window partition (reverse = window_reverse + roll back); backward = the inverse permutation
+Tensor* op_window_perm(Exec& e, Tensor* x, int B, int H, int W, int ws, int shift, int reverse) {
+  used(x);
+  const int C = x->C;
+  Tensor* y = e.newt(x->rows, C, B, H, W);
+  WORK(e, 0, (double)x->rows * C * e.esz() * 2);
+  LCH(e, launch_window_perm(e.dt, x->p, y->p, B, H, W, C, ws, shift, reverse, 0, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, x, y, B, H, W, C, ws, shift, reverse]() {
+      if (!y->g) return;
+      int beta;
+      void* dx = e.grad(x, &beta);
+      WORK(e, 0, (double)x->rows * C * e.esz() * (beta ? 3 : 2));
+      LCH(e, launch_window_perm(e.dt, y->g, dx, B, H, W, C, ws, shift, !reverse, beta, e.s));
+    });
+  return y;
+}
+
+Tensor* op_patch_merge(Exec& e, Tensor* x, int B, int H, int W) {
+  used(x);
+  const int C = x->C;
+  Tensor* y = e.newt(x->rows / 4, 4 * C, B, H / 2, W / 2);
+  WORK(e, 0, (double)x->rows * C * e.esz() * 2);
+  LCH(e, launch_patch_merge(e.dt, x->p, y->p, B, H, W, C, 0, 0, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, x, y, B, H, W, C]() {
+      if (!y->g) return;
+      int beta;
+      void* dx = e.grad(x, &beta);
+      WORK(e, 0, (double)x->rows * C * e.esz() * (beta ? 3 : 2));
+      LCH(e, launch_patch_merge(e.dt, y->g, dx, B, H, W, C, 1, beta, e.s));
+    });
+  return y;
+}
+
+// out = shortcut + DropPath(branch): per-sample keep mask, scale 1/(1-p) (timm DropPath; identity in eval)
+Tensor* op_droppath_add(Exec& e, Tensor* shortcut, Tensor* branch, int B, float p) {
+  used(shortcut); used(branch);
+  if (!e.train) p = 0.f;
+  const uint32_t site = p > 0.f ? e.site++ : 0;
+  const uint32_t* seed = (const uint32_t*)(scal(e.m) + SC_SEED);
+  const int C = branch->C;
+  const long per = branch->rows / B * C;
+  Tensor* y = e.newt(branch->rows, C, B, shortcut->H, shortcut->W);
+  WORK(e, 0, (double)branch->rows * C * e.esz() * 3);
+  LCH(e, launch_droppath(e.dt, 0, shortcut->p, branch->p, y->p, B, per, p, seed, site, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, shortcut, branch, y, B, per, C, p, seed, site]() {
+      if (!y->g) return;
+      int beta;
+      void* db = e.grad(branch, &beta);
+      if (beta) { e.m->err = "internal: drop-path branch has two consumers"; e.oom = true; return; }
+      WORK(e, 0, (double)branch->rows * C * e.esz() * 2);
+      LCH(e, launch_droppath(e.dt, 1, y->g, nullptr, db, B, per, p, seed, site, e.s));
+      acc_grad(e, shortcut, y->g);
+    });
+  return y;
+}
+
+// x [B][L][C] + table [L][C] (absolute position embedding, fp32 parameter); d table = sum over the batch
+Tensor* op_add_table(Exec& e, Tensor* x, Vec* table, int B) {
+  used(x);
+  const int C = x->C;
+  const long LC = x->rows / B * C;
+  Tensor* y = e.newt(x->rows, C, B, x->H, x->W);
+  WORK(e, 0, (double)x->rows * C * e.esz() * 2);
+  LCH(e, launch_add_rows_table(e.dt, x->p, table->p, y->p, B, LC, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, x, y, table, B, LC]() {
+      if (!y->g) return;
+      const int dt = e.dt; void* yg = y->g; float* tg = table->g;
+      if (e.prof || e.dry) { WORK(e, 0, (double)B * LC * e.esz()); LCH(e, launch_colsum(dt, yg, B, (int)LC, (int)LC, tg, e.s)); }
+      else e.defer([=](hipStream_t ws) { launch_colsum(dt, yg, B, (int)LC, (int)LC, tg, ws); });
+      acc_grad(e, x, y->g);
+    });
+  return y;
+}
+
+// window attention over a fused qkv tensor [B_*N][3C] (q | k | v, head h at columns h*hd): softmax(q k^T * hd^-0.5 + bias[h] +
+// mask[window]) v  (networks/SWIN.py:152-190); the relative-position-bias table is gathered to [heads][N][N] per call
+Tensor* op_window_attn(Exec& e, Tensor* qkv, SwinBlock* sb, int B_, const float* wmask, int nW) {
+  used(qkv);
+  const int N = sb->ws * sb->ws, C = sb->dim, heads = sb->heads, hd = C / heads;
+  Tensor* o = e.newt((long)B_ * N, C, B_);
+  float* lse = (float*)e.alloc((size_t)B_ * heads * N * 4);
+  float* bias = (float*)e.alloc((size_t)heads * N * N * 4);
+  LCH(e, launch_relpos_bias(sb->rpb.p, bias, sb->ws, heads, e.s));
+  const size_t es = e.esz();
+  AttnP p;
+  memset(&p, 0, sizeof(p));
+  p.Q = qkv->p; p.K = (char*)qkv->p + (size_t)C * es; p.V = (char*)qkv->p + (size_t)2 * C * es; p.O = o->p; p.lse = lse;
+  p.B = B_; p.H = heads; p.Lq = N; p.Lk = N; p.hd = hd;
+  p.ldq = p.ldk = p.ldv = 3 * C; p.ldo = C;
+  p.sq_b = p.sk_b = p.sv_b = (long)N * 3 * C; p.so_b = (long)N * C;
+  p.inv_temp = 1.0f / sqrtf((float)hd); p.pad_id = e.m->cfg.pad_id;
+  p.bias = bias; p.wmask = wmask; p.nW = nW > 0 ? nW : 1;
+  WORK(e, 4.0 * (double)B_ * heads * N * N * hd, (double)B_ * N * C * 4 * es);
+  LCH(e, launch_attn(e.dt, 0, p, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, qkv, o, sb, p, B_, N, C, heads, hd, es]() {
+      if (!o->g) return;
+      const size_t LkP = attn_lkp(N);
+      void* dS = e.alloc((size_t)B_ * heads * N * LkP * es);
+      void* Pd = e.alloc((size_t)B_ * heads * N * LkP * es);
+      int bq = 0;
+      void* dq = e.grad(qkv, &bq);
+      if (bq) { e.m->err = "internal: qkv tensor has two consumers"; e.oom = true; return; }
+      AttnP q = p;
+      q.dO = o->g; q.dQ = dq; q.dS = dS; q.Pd = Pd;
+      WORK(e, 6.0 * (double)B_ * heads * N * N * hd, ((double)B_ * N * C * 6 + 2.0 * B_ * heads * N * LkP) * es);
+      LCH(e, launch_attn(e.dt, 1, q, e.s));
+      WgradP w;
+      memset(&w, 0, sizeof(w));
+      w.M = N; w.N = N; w.K = hd; w.ldy = (int)LkP; w.out_t = 1; w.out_accum = 0; w.nbatch = B_ * heads; w.nb_inner = heads;
+      w.sY_o = (long)heads * N * LkP; w.sY_i = (long)N * LkP;
+      w.sW_o = (long)N * 3 * C; w.sW_i = hd; w.ldw = 3 * C;
+      WORK(e, 2.0 * (double)B_ * heads * N * N * hd, ((double)B_ * heads * N * LkP + 2.0 * B_ * N * C) * es);
+      w.dY = Pd; w.A = o->g; w.lda = C; w.sA_o = (long)N * C; w.sA_i = hd; w.dW = (char*)dq + (size_t)2 * C * es;  // dV = Pd^T dO
+      LCH(e, launch_wgrad(e.dt, w, e.s));
+      WORK(e, 2.0 * (double)B_ * heads * N * N * hd, ((double)B_ * heads * N * LkP + 2.0 * B_ * N * C) * es);
+      w.dY = dS; w.A = qkv->p; w.lda = 3 * C; w.sA_o = (long)N * 3 * C; w.sA_i = hd; w.dW = (char*)dq + (size_t)C * es;    // dK = dS^T Q
+      LCH(e, launch_wgrad(e.dt, w, e.s));
+      // d table: dS (gradient of the raw q k^T product) summed over the windows = inv_temp * d bias; optimizer-only -> side stream
+      float* dbias = e.zalloc((size_t)heads * N * LkP);
+      {
+        const int dt = e.dt, ws_ = sb->ws, ld = (int)LkP, ncol = (int)(heads * N * LkP);
+        float* tg = sb->rpb.g; const float sc = sqrtf((float)hd);
+        if (e.prof || e.dry) {
+          WORK(e, 0, (double)B_ * ncol * es);
+          LCH(e, launch_colsum(dt, dS, B_, ncol, ncol, dbias, e.s));
+          LCH(e, launch_relpos_bias_bwd(dbias, tg, ws_, heads, ld, sc, e.s));
+        } else {
+          e.defer([=](hipStream_t s2) { launch_colsum(dt, dS, B_, ncol, ncol, dbias, s2); launch_relpos_bias_bwd(dbias, tg, ws_, heads, ld, sc, s2); });
+        }
+      }
+    });
+  return o;
+}
+
+Tensor* swin_block(Exec& e, Tensor* x, SwinBlock* sb, int B) {
+  Model* m = e.m;
+  const int R = sb->res, nWw = R / sb->ws, nW = nWw * nWw;
+  Tensor* y = op_ln(e, x, nullptr, &sb->n1);
+  Tensor* yw = (nW > 1 || sb->shift) ? op_window_perm(e, y, B, R, R, sb->ws, sb->shift, 0) : y;
+  Tensor* qkv = op_gemm(e, yw, &sb->qkv, &sb->bqkv, ACT_NONE, 0.f, nullptr);
+  const float* mask = sb->geo >= 0 ? (const float*)(m->ws + m->sw_geo[sb->geo].off) : nullptr;
+  Tensor* att = op_window_attn(e, qkv, sb, B * nW, mask, nW);
+  Tensor* pr = op_gemm(e, att, &sb->proj, &sb->bproj, ACT_NONE, 0.f, nullptr);
+  Tensor* prt = (nW > 1 || sb->shift) ? op_window_perm(e, pr, B, R, R, sb->ws, sb->shift, 1) : pr;
+  Tensor* x1 = op_droppath_add(e, x, prt, B, sb->drop_path);
+  x1->B = B; x1->H = R; x1->W = R;
+  Tensor* y2 = op_ln(e, x1, nullptr, &sb->n2);
+  Tensor* h = op_gemm(e, y2, &sb->fc1, &sb->b1, ACT_NONE, 0.f, nullptr);
+  Tensor* g = op_act(e, h, ACT_GELU);
+  Tensor* o = op_gemm(e, g, &sb->fc2, &sb->b2, ACT_NONE, 0.f, nullptr);
+  Tensor* x2 = op_droppath_add(e, x1, o, B, sb->drop_path);
+  x2->B = B; x2->H = R; x2->W = R;
+  return x2;
+}
+
+// SwinTransformer.forward_features (networks/SWIN.py:722-735): patch embedding (4x4 stride-4 conv = GEMM over extracted patches) +
+// LayerNorm + absolute position embedding, four stages of (shifted-)window blocks with patch merging between them, final LayerNorm
+Tensor* swin_encoder_forward(Exec& e, const float* img, int B) {
+  Model* m = e.m;
+  const SatrnConfig& c = m->cfg;
+  const int P = c.swin_patch, R0 = c.height / P, E = c.swin_embed;
+  Tensor* pt = e.newt((long)B * R0 * R0, c.rgb * P * P, B, R0, R0);
+  WORK(e, 0, (double)B * c.rgb * c.height * c.width * 4 + (double)pt->rows * pt->C * e.esz());
+  LCH(e, launch_patchify(e.dt, img, pt->p, B, c.rgb, c.height, c.width, P, e.s));
+  Tensor* x = op_gemm(e, pt, &m->sw_patch, &m->sw_patch_b, ACT_NONE, 0.f, nullptr);
+  x->B = B; x->H = R0; x->W = R0;
+  x = op_ln(e, x, nullptr, &m->sw_patch_norm);
+  x = op_add_table(e, x, &m->sw_ape, B);
+  (void)E;
+  for (auto& st : m->swin) {
+    for (auto& sb : st.blocks) x = swin_block(e, x, &sb, B);
+    if (st.down) {
+      Tensor* mg = op_patch_merge(e, x, B, st.res, st.res);
+      Tensor* mn = op_ln(e, mg, nullptr, &st.dnorm);
+      x = op_gemm(e, mn, &st.dred, nullptr, ACT_NONE, 0.f, nullptr);
+      x->B = B; x->H = st.res / 2; x->W = st.res / 2;
+    }
+  }
+  x = op_ln(e, x, nullptr, &m->sw_norm);
+  m->seg_mark[0] = 0; m->seg_mark[1] = e.tape.size();
+  if (x->H != m->feat_h || x->W != m->feat_w) { m->err = "SwinTRN: final resolution does not match the configuration"; e.oom = true; }
+  return x;  // [B * 144][8E]
+}
+
 // ---- composite blocks ---------------------------------------------------------------------------------
 static void same_geo(int H, int W, int Ci, int stride, Geo* g) {
   g->H = H; g->W = W; g->Ci = Ci; g->KW = 3; g->stride = stride;
@@ -1122,7 +1413,9 @@ static void bn_eval_prepare(Exec& e) {
   launch_bn_eval_prepare(dev, (int)m->all_bn.size(), e.s);
 }
 
+Tensor* swin_encoder_forward(Exec& e, const float* img, int B);
 Tensor* encoder_forward(Exec& e, const float* img, int B) {
+  if (e.m->cfg.network == 2) return swin_encoder_forward(e, img, B);
   if (!e.train && !e.rec) bn_eval_prepare(e);
   Model* m = e.m;
   const SatrnConfig& c = m->cfg;
@@ -1377,6 +1670,9 @@ int model_forward(Model* m, const float* img, const int64_t* expected, int B, in
                   float* logits_out, hipStream_t s, bool teacher_forced) {
   if (!m->bound || !m->ws_set) { m->err = "bind parameters and set a workspace first"; return -1; }
   Exec& e = *m->ex;
+  // every TRAINING forward draws fresh dropout / stochastic-depth masks (its backward reads the same RNG word); the module-API
+  // path (model(...) + loss.backward(), the reference's loop) advances here just like the fused train_step
+  if (train) launch_seed_advance((uint32_t*)(scal(m) + SC_SEED), s);
   exec_begin(m, s, train, record, false);
   e.src = encoder_forward(e, img, B);
   m->seg_mark[2] = e.tape.size();  // end of the encoder
@@ -1391,10 +1687,13 @@ int model_forward(Model* m, const float* img, const int64_t* expected, int B, in
 // segment k, the flat-gradient range seg_lo[k]..seg_hi[k] is final on stream s (side-stream weight gradients joined), so
 // a data-parallel caller can start reducing it while the next segments run.
 static void segment_ranges(Model* m) {
-  const int64_t off_dec = m->embed.off, off_pe = m->pe_d0.off;
+  const int64_t off_dec = m->embed.off, off_pe = m->cfg.network == 2 ? m->embed.off : m->pe_d0.off;
   int64_t off_late = 0;
   m->late_block = 0;
-  if (m->cfg.network != 0 && !m->blocks.empty()) {
+  if (m->cfg.network == 2 && m->swin.size() == 4 && !m->swin[2].blocks.empty()) {
+    // SwinTRN: the deep third stage onwards (18 of 24 blocks, ~85 % of the encoder parameters) is the "late" part
+    off_late = m->swin[2].blocks[0].n1.w.off;
+  } else if (m->cfg.network != 0 && !m->blocks.empty()) {
     // last stage of the backbone (15 blocks at 4x12, ~47 % of all parameters) + conv_last
     size_t k = m->blocks.size();
     while (k > 0 && m->blocks[k - 1].cout == m->blocks.back().cout) --k;
@@ -1487,7 +1786,6 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
   if (seg >= 0) {
     if (!m->bound || !m->ws_set || !m->grads) { m->err = "bind parameters/grads and set a workspace first"; return -1; }
     if (seg == 0) {
-      launch_seed_advance((uint32_t*)(scal(m) + SC_SEED), s);
       launch_fill(m->grads, 0, (size_t)m->n_params * 4, s);
       int rc = model_forward(m, img, expected, B, L, train_mode, true, nullptr, s);
       if (rc) return rc;
@@ -1520,7 +1818,6 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
   auto body = [&]() -> int {
     if (phase & 1) {
       if (g_stage_prof) { m->ex->s = s; m->ex->mark_report(); m->ex->mark("start"); }
-      launch_seed_advance((uint32_t*)(scal(m) + SC_SEED), s);
       // clearing the 109 MB gradient buffer is not on the forward's path: eager two-stream steps do it on the side stream
       // (behind everything the previous step queued on `s`, i.e. its optimizer), beside the forward; the backward waits for it
       Exec& ex = *m->ex;

@@ -23,6 +23,10 @@ struct SatrnConfig {
   int pad_id, sos_id;
   float dropout;
   int dtype;  // DT_F32 / DT_BF16
+  // network == 2 (SwinTRN, networks/SWIN.py:1024-1031): the reference hard-codes 384 / patch 4 / 128 / [2,2,18,2] / [4,8,16,32] /
+  // window 12 / drop_path 0.5 / ape / 21841 head classes; smaller values only serve the parity tests
+  int swin_embed = 0, swin_depths[4] = {0, 0, 0, 0}, swin_heads[4] = {0, 0, 0, 0}, swin_window = 0, swin_patch = 0, swin_head_classes = 0;
+  float swin_drop_path = 0.f;
 };
 
 enum { ST_PARAM = 0, ST_BUF_F32 = 1, ST_BUF_I64 = 2 };
@@ -80,6 +84,8 @@ struct Tensor {
   std::function<void(const float* escale, const float* eshift, int act, void* out)> pend_dw;  // same for a depthwise conv
 };
 
+struct SwinBlock { LNp n1, n2; Wt qkv, proj, fc1, fc2; Vec bqkv, bproj, b1, b2, rpb; int dim = 0, heads = 0, res = 0, ws = 0, shift = 0; float drop_path = 0.f; int geo = -1; };
+struct SwinStage { std::vector<SwinBlock> blocks; bool down = false; LNp dnorm; Wt dred; int dim = 0, res = 0; };
 struct EffBlock { int type, cin, cout, mid, stride, se; bool skip; Wt c0, c1, dw, se_r, se_e; Vec se_rb, se_eb; BNp bn1, bn2, bn3; };
 struct EncLayer { LNp norm; MHAp att; Wt conv0, conv1, dw; Vec dwb; BNp norm0, dwnorm, norm1; };
 struct DecLayer { MHAp self_att, cross_att; LNp ln1, ln2, ln3; Wt lin0, lin1; Vec b0, b1; };
@@ -93,6 +99,9 @@ struct Model {
   std::vector<Wt> lite_conv; std::vector<BNp> lite_bn;
   std::vector<EffBlock> blocks;
   Wt conv_last; BNp bn_last;
+  // SwinTRN encoder
+  Wt sw_patch; Vec sw_patch_b, sw_ape; LNp sw_patch_norm, sw_norm; std::vector<SwinStage> swin; Wt sw_head; Vec sw_head_b;
+  struct SwinGeo { int res, ws, shift; size_t off; }; std::vector<SwinGeo> sw_geo;  // shifted-window mask tables in the persistent region
   Wt pe_d0, pe_d1; Vec pe_b0, pe_b1;
   std::vector<EncLayer> enc;
   Wt embed;  // [V+1][Dd] (gathered directly from the fp32 master)

@@ -22,7 +22,7 @@ static inline float* det_scratch(hipStream_t s, size_t need_floats) {
 // out[i] += sum_{r < nrep} part[r * stride + i]  (r ascending), i < n
 void launch_fold(const float* part, int nrep, long stride, long n, float* out, hipStream_t s);
 enum { AM_DENSE = 0, AM_CONV = 1, AM_DGRAD = 2 };
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3, ACT_GELU = 4 /*exact erf form, nn.GELU (networks/SWIN.py:29)*/ };
 
 // C[M,N] = act(gatherA[M,K] * Bw[N,K]^T + bias) (+dropout) (+= if beta)
 struct GemmP {
@@ -75,6 +75,9 @@ struct AttnP {
   int ldq, ldk, ldv, ldo;  // row strides (elements)
   int causal, pad_id;
   float inv_temp, drop_p; const uint32_t* seed; uint32_t site;
+  // window attention (networks/SWIN.py:163-183): scores += bias[h][i][j] (relative position bias, shared by all windows) and
+  // += wmask[b % nW][i][j] (0 / -100 shifted-window mask); both fp32 with row stride Lk, either may be null
+  const float* bias; const float* wmask; int nW;
   int q_pos0;              // step mode: absolute position of query row 0 (causal uses q_pos0 + i)
   long sq_b, sk_b, sv_b, so_b;  // batch strides (elements) of Q / K / V / O(dO,dQ use sq_b/so_b)
 };
@@ -223,3 +226,13 @@ void launch_sift_strided(float* x, int ld, int32_t* state, const int32_t* rules,
 struct ImageDesc { const unsigned char* data; int h, w, stride, pad_; };
 void launch_image_preprocess(const ImageDesc* descs_dev, int B, int C, int H, int W, float* out /*[B][C][H][W]*/, const float* mean3,
                              const float* std3, hipStream_t s);
+
+// ---- SwinTRN-specific data movement (kernels_swin.hip) ----------------------------------------------------------------
+void launch_patchify(int dt, const float* img, void* out /*[B*(H/P)*(W/P)][Cin*P*P]*/, int B, int Cin, int H, int W, int P, hipStream_t s);
+void launch_add_rows_table(int dt, const void* x, const float* table /*[LC] fp32*/, void* out, int B, long LC, hipStream_t s);
+void launch_window_perm(int dt, const void* in, void* out, int B, int H, int W, int C, int ws, int shift, int reverse, int beta, hipStream_t s);
+void launch_patch_merge(int dt, const void* in, void* out, int B, int H, int W, int C /*input channels*/, int reverse, int beta, hipStream_t s);
+void launch_relpos_bias(const float* table /*[(2ws-1)^2][heads]*/, float* bias /*[heads][N][N]*/, int ws, int heads, hipStream_t s);
+void launch_relpos_bias_bwd(const float* dbias /*[heads][N][ld]*/, float* dtable, int ws, int heads, int ld, float scale, hipStream_t s);
+void launch_droppath(int dt, int mode, const void* a, const void* b, void* out, int B, long per_sample, float p, const uint32_t* seed,
+                     uint32_t site, hipStream_t s);

@@ -103,7 +103,12 @@ __global__ __launch_bounds__(QT * 4) void attn_kernel(AttnP p) {
       for (int r = 0; r < 4; ++r) {
         const int qi = q0 + r0 + fq * 4 + r;
         bool m = km || (p.causal && key > p.q_pos0 + qi);
-        s[kt][r] = m ? -INFINITY : s[kt][r] * p.inv_temp;
+        float sv = s[kt][r] * p.inv_temp;
+        if ((p.bias || p.wmask) && !km && qi < p.Lq) {
+          if (p.bias) sv += p.bias[((long)h * p.Lq + qi) * p.Lk + key];
+          if (p.wmask) sv += p.wmask[((long)(b % p.nW) * p.Lq + qi) * p.Lk + key];
+        }
+        s[kt][r] = m ? -INFINITY : sv;
       }
     }
   }

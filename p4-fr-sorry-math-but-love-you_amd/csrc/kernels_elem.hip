@@ -1043,8 +1043,11 @@ void launch_layernorm(int dt, const void* a, const void* b, const float* w, cons
     else if (cc <= 128)
       hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(g), dim3(256), 0, s, (const T*)a, (const T*)b, w, bias, (T*)out,
                          mr, R, C, eps);
-    else
+    else if (cc <= 256)
       hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(g), dim3(256), 0, s, (const T*)a, (const T*)b, w, bias, (T*)out,
+                         mr, R, C, eps);
+    else  // up to 512 chunks per row (SwinTRN patch merging normalises 4*512 channels: 512 chunks in f32)
+      hipLaunchKernelGGL((layernorm_kernel<T, 8>), dim3(g), dim3(256), 0, s, (const T*)a, (const T*)b, w, bias, (T*)out,
                          mr, R, C, eps);
   });
 }
@@ -1177,8 +1180,11 @@ void launch_layernorm_bwd(int dt, const void* dout, const void* a, const void* b
     else if (cc <= 128)
       hipLaunchKernelGGL((layernorm_bwd_kernel<T, 2>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a,
                          (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part);
-    else
+    else if (cc <= 256)
       hipLaunchKernelGGL((layernorm_bwd_kernel<T, 4>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a,
+                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part);
+    else
+      hipLaunchKernelGGL((layernorm_bwd_kernel<T, 8>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a,
                          (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part);
     if (part) { launch_fold(part, g, 2L * C, C, dw, s); launch_fold(part + C, g, 2L * C, C, dbias, s); }
   });
@@ -1342,7 +1348,7 @@ __global__ void act_bwd_kernel(const T* dz, const T* zu, T* du, long n, int act,
     float d = to_f(dz[i]), z = to_f(zu[i]), r;
     if (act == ACT_RELU) r = z > 0.f ? d * keep_inv : 0.f;
     else if (act == ACT_SIGMOID) r = d * z * (1.f - z);
-    else if (act == ACT_SILU) r = d * act_bwd(z, ACT_SILU);
+    else if (act == ACT_SILU || act == ACT_GELU) r = d * act_bwd(z, act);   // zu holds the PRE-activation
     else r = d;
     du[i] = from_f<T>(r);
   }

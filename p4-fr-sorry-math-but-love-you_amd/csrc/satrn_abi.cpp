@@ -324,6 +324,22 @@ satrn_model* satrn_model_create(const satrn_config* c) {
   k.dec_src = c->dec_src; k.dec_hidden = c->dec_hidden; k.dec_filter = c->dec_filter; k.dec_heads = c->dec_heads;
   k.dec_layers = c->dec_layers; k.num_classes = c->num_classes; k.pad_id = c->pad_id; k.sos_id = c->sos_id;
   k.dropout = c->dropout; k.dtype = c->dtype;
+  if (c->network == 2) {
+    k.swin_embed = c->swin_embed; k.swin_window = c->swin_window; k.swin_patch = c->swin_patch; k.swin_head_classes = c->swin_head_classes;
+    k.swin_drop_path = c->swin_drop_path;
+    for (int i = 0; i < 4; ++i) { k.swin_depths[i] = c->swin_depths[i]; k.swin_heads[i] = c->swin_heads[i]; }
+    // networks/SWIN.py:559-572 (square image, whole patches), :59 (windows tile every stage), head_dim as the attention kernel takes it
+    if (c->height != c->width || c->swin_patch <= 0 || c->height % c->swin_patch) { g_err = "SwinTRN: square input, side a multiple of the patch size"; return nullptr; }
+    if (c->swin_embed <= 0 || c->swin_embed % 32 || c->dec_src != c->swin_embed * 8) { g_err = "SwinTRN: embed_dim a multiple of 32 and dec_src == 8 * embed_dim"; return nullptr; }
+    if ((c->rgb * c->swin_patch * c->swin_patch) % ch) { g_err = "SwinTRN: rgb * patch^2 must be a multiple of 8"; return nullptr; }
+    int res = c->height / c->swin_patch;
+    for (int i = 0; i < 4; ++i, res /= 2) {
+      const int dim = c->swin_embed << i, ws = res <= c->swin_window ? res : c->swin_window;
+      if (c->swin_depths[i] <= 0 || c->swin_heads[i] <= 0 || dim % c->swin_heads[i] || (dim / c->swin_heads[i]) % ch || dim / c->swin_heads[i] > 64) { g_err = "SwinTRN: bad depth / head count (head_dim <= 64, multiple of 8)"; return nullptr; }
+      if (res < 1 || res % ws || (i < 3 && res % 2) || ws * ws > 256) { g_err = "SwinTRN: the window must tile every stage's resolution (and ws*ws <= 256 keys)"; return nullptr; }
+    }
+    if (c->swin_head_classes <= 0) { g_err = "SwinTRN: head classes"; return nullptr; }
+  } else if (c->network != 0 && c->network != 1) { g_err = "network must be 0 (LiteSATRN), 1 (EfficientSATRN) or 2 (SwinTRN)"; return nullptr; }
   satrn_model* h = new satrn_model();
   h->m = model_create(k);
   return h;

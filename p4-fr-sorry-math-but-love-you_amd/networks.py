@@ -116,6 +116,11 @@ class _SATRNBase(nn.Module):
     _NETWORK = 1
     _DEFAULT_DTYPE = "bf16"
 
+    def _configure(self, c, FLAGS):
+        """network-specific part of the configuration (the SATRN models read the encoder block of the YAML)"""
+        e = FLAGS.SATRN.encoder
+        c.enc_hidden, c.enc_filter, c.enc_heads, c.enc_layers = int(e.hidden_dim), int(e.filter_dim), int(e.head_num), int(e.layer_num)
+
     def __init__(self, FLAGS, train_dataset, checkpoint=None, decoding_manager=None, dtype=None):
         super().__init__()
         lib = _lib.load()
@@ -125,10 +130,10 @@ class _SATRNBase(nn.Module):
         c.network = self._NETWORK
         c.rgb = int(FLAGS.data.rgb)
         c.height, c.width = int(FLAGS.input_size.height), int(FLAGS.input_size.width)
-        e, d = FLAGS.SATRN.encoder, FLAGS.SATRN.decoder
-        c.enc_hidden, c.enc_filter, c.enc_heads, c.enc_layers = int(e.hidden_dim), int(e.filter_dim), int(e.head_num), int(e.layer_num)
+        d = FLAGS.SATRN.decoder
         c.dec_src, c.dec_hidden, c.dec_filter = int(d.src_dim), int(d.hidden_dim), int(d.filter_dim)
         c.dec_heads, c.dec_layers = int(d.head_num), int(d.layer_num)
+        self._configure(c, FLAGS)
         c.num_classes = len(train_dataset.id_to_token)
         c.pad_id, c.sos_id = int(train_dataset.token_to_id[PAD]), int(train_dataset.token_to_id[START])
         c.dropout = float(FLAGS.dropout_rate)
@@ -166,7 +171,7 @@ class _SATRNBase(nn.Module):
         self._dstage = None
         self._side = None
         self._warm = set()
-        if checkpoint:
+        if checkpoint and checkpoint is not True:   # networks/SWIN.py:1025 has `checkpoint=True` as its default
             self.load_state_dict(checkpoint)
 
     def __del__(self):
@@ -228,6 +233,29 @@ class _SATRNBase(nn.Module):
                 t.zero_()
             elif init == 6:
                 t.normal_(0.0, 1.0)
+            elif init == 9:   # timm trunc_normal_(std=0.02): N(0, 0.02) cut at +-2 (a = -2, b = 2 are ~100 sigma: no-op bounds)
+                t.normal_(0.0, 0.02).clamp_(-2.0, 2.0)
+            elif init == 7:   # WindowAttention.relative_position_index (networks/SWIN.py:120-135)
+                ws = int(round(math.sqrt(t.shape[0])))
+                co = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+                rel = (co[:, :, None] - co[:, None, :]).permute(1, 2, 0).contiguous()
+                rel[:, :, 0] += ws - 1
+                rel[:, :, 1] += ws - 1
+                rel[:, :, 0] *= 2 * ws - 1
+                t.copy_(rel.sum(-1))
+            elif init == 8:   # SwinTransformerBlock.attn_mask (networks/SWIN.py:288-309): 0 / -100 between the shifted regions
+                nW, N = t.shape[0], t.shape[1]
+                ws = int(round(math.sqrt(N)))
+                res, shift = ws * int(round(math.sqrt(nW))), ws // 2
+                img = torch.zeros(res, res)
+                cnt = 0
+                for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                    for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                        img[hs, wsl] = cnt
+                        cnt += 1
+                mw = img.view(res // ws, ws, res // ws, ws).permute(0, 2, 1, 3).reshape(-1, N)
+                am = mw[:, None, :] - mw[:, :, None]
+                t.copy_(torch.where(am != 0, torch.full_like(am, -100.0), torch.zeros_like(am)))
 
     def _tensor_of(self, entry):
         return getattr(entry[5], entry[6])
@@ -429,13 +457,20 @@ class _SATRNBase(nn.Module):
         warm[0] = True
         return slog.clone(), sids.clone()
 
+    def _feat_tokens(self):
+        c = self._cfg
+        if self._NETWORK == 2:
+            return ((c.height // c.swin_patch) >> 3) ** 2
+        f = 32 if self._NETWORK == 1 else 16
+        return (c.height // f) * (c.width // f)
+
     @torch.no_grad()
     def encode(self, input):
         """SATRNEncoder.forward (networks/EfficientSATRN.py:311-323) in eval mode -> [B, hw, c] fp32."""
         input = self._img(input)
         B = input.size(0)
         self._prepare(input, B, 2)
-        n = (self._cfg.height // (32 if self._NETWORK == 1 else 16)) * (self._cfg.width // (32 if self._NETWORK == 1 else 16))
+        n = self._feat_tokens()
         src = torch.empty(B, n, self._cfg.enc_hidden, dtype=torch.float32, device=input.device)
         check(self._lib.satrn_model_encode(self._h, ptr(input), B, ptr(src), _stream()), "satrn_model_encode")
         return src
@@ -581,6 +616,34 @@ class EfficientSATRN(_SATRNBase):
 class LiteSATRN(_SATRNBase):
     """Drop-in for networks/LiteSATRN.py:548 (ShallowCNN backbone, /16)."""
     _NETWORK = 0
+
+
+class SWIN(_SATRNBase):
+    """Drop-in for networks/SWIN.py:1024 (BASELINE configs[3], SwinTRN): Swin-B/384 encoder (patch 4, embed 128, depths
+    2/2/18/2, heads 4/8/16/32, window 12, shifted windows with the 0 / -100 mask, relative position bias, absolute position
+    embedding, stochastic depth up to 0.5, exact-erf GELU MLP, patch merging, final LayerNorm -> [B, 144, 1024]) + the
+    transformer decoder of the SATRN models with the YAML's decoder dims (configs/SWIN.yaml:11-16).  The reference hard-codes
+    the encoder geometry and downloads ImageNet-22k weights at construction (:1028-1034; no network here: random init, load a
+    checkpoint instead); `swin=dict(embed_dim=, depths=, num_heads=, window_size=, patch_size=, drop_path_rate=, head_classes=)`
+    overrides the geometry for tests.  state_dict keys == the reference module's (encoder.* incl. the unused head and the
+    relative_position_index / attn_mask buffers, decoder.*)."""
+    _NETWORK = 2
+    _SWIN_DEFAULT = dict(embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32), window_size=12, patch_size=4, drop_path_rate=0.5,
+                         head_classes=21841)
+
+    def __init__(self, FLAGS, train_dataset, checkpoint=True, decoding_manager=None, dtype=None, swin=None):
+        self._swin = dict(self._SWIN_DEFAULT, **(swin or {}))
+        super().__init__(FLAGS, train_dataset, checkpoint, decoding_manager, dtype)
+
+    def _configure(self, c, FLAGS):
+        g = self._swin
+        c.swin_embed, c.swin_window, c.swin_patch = int(g["embed_dim"]), int(g["window_size"]), int(g["patch_size"])
+        c.swin_head_classes, c.swin_drop_path = int(g["head_classes"]), float(g["drop_path_rate"])
+        for i in range(4):
+            c.swin_depths[i], c.swin_heads[i] = int(g["depths"][i]), int(g["num_heads"][i])
+        # the encoder block of SWIN.yaml is unused by the reference (networks/SWIN.py:1028-1031); the engine's generic checks
+        # want a consistent width
+        c.enc_hidden, c.enc_filter, c.enc_heads, c.enc_layers = c.dec_src, c.dec_src, 1, 0
 
 
 class _Half(nn.Module):

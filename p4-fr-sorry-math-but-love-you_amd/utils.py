@@ -68,6 +68,8 @@ def get_network(model_type, FLAGS, model_checkpoint, device, dataset, decoding_m
         model = networks.EfficientSATRN_encoder(FLAGS, dataset, model_checkpoint, **kw).to(device)
     elif model_type in ("EfficientSATRN_decoder", "MySATRN_decoder"):
         model = networks.EfficientSATRN_decoder(FLAGS, dataset, model_checkpoint, **kw).to(device)
+    elif model_type == "SWIN":
+        model = networks.SWIN(FLAGS, dataset, model_checkpoint or True, decoding_manager, **kw).to(device)
     else:
         raise NotImplementedError
     return model
