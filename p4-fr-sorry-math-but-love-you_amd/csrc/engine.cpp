@@ -52,6 +52,8 @@ hipStream_t Exec::side() {
 // Side launches are queued (they only need their inputs, which the main stream has already been asked to produce) and
 // flushed a few closures later behind ONE event: keeps the host cost of forking at ~1/8 of an event pair per launch.
 void Exec::defer(std::function<void(hipStream_t)> fn) {
+  static const bool skip = getenv("SATRN_TIMING_SKIP_WGRAD") != nullptr;  // timing experiment only (wrong gradients): the chain alone
+  if (skip && !dry) return;
   if (!s2 || dry) { fn(s); return; }
   pending.push_back(std::move(fn));
   // hand the batch to the side stream every 4 launches: with 8 the main chain waited 0.39 ms at the final join for the

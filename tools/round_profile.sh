@@ -1,26 +1,37 @@
 #!/bin/bash
-# Round-end evidence, run ON the GPU box from the repo root (gpurun -- 'bash tools/round_profile.sh r01_v13'):
+# Round-end evidence, run ON the GPU box from the repo root (gpurun -- 'bash tools/round_profile.sh r02'):
 #   1. rocprofv3 --kernel-trace --stats of the bench command  -> profiles/<tag>_bench_kernel_stats.csv + _bench_line.log
-#   2. two PMC passes (FETCH_SIZE / WRITE_SIZE, kernel-trace only) -> profiles/r01_pmc_traffic.json (read by bench.py)
-#   3. the default bench line                                      -> profiles/<tag>_bench_default.json
+#   2. two PMC passes (FETCH_SIZE / WRITE_SIZE, kernel-trace only) -> profiles/<tag>_pmc_traffic.json (read by bench.py)
+#   3. MFMA-busy PMC pass of the whole step and of the encoder self-attention region alone -> profiles/<tag>_mfma_busy*.json
+#   4. the default bench line                                      -> profiles/<tag>_bench_default.json
+# Every rocprofv3 command has the program itself after `--` and never mixes --pmc with the trace domains gpurun refuses.
 set -e -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
-rm -rf "$OUT" gpurun_out/pmc_fetch gpurun_out/pmc_write
+rm -rf "$OUT" gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma gpurun_out/pmc_region
 mkdir -p "$OUT" profiles
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 bench.py --steps 10 --warmup 4 --no-decode --no-cpu-baseline > "$OUT/bench_line.log" 2>&1
+BENCH="bench.py --steps 10 --warmup 4 --no-decode --no-cpu-baseline --no-extras"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 $BENCH > "$OUT/bench_line.log" 2>&1
 cp "$(ls "$OUT"/*/*kernel_stats.csv | head -1)" "profiles/${TAG}_bench_kernel_stats.csv"
 grep '^{' "$OUT/bench_line.log" > "profiles/${TAG}_bench_line.log"
 echo "stats done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 2 --no-decode --no-cpu-baseline > gpurun_out/pmc_fetch.log 2>&1
+SHORT="bench.py --steps 2 --warmup 2 --no-decode --no-cpu-baseline --no-extras"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 $SHORT > gpurun_out/pmc_fetch.log 2>&1
 echo "pmc fetch done"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 2 --no-decode --no-cpu-baseline > gpurun_out/pmc_write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 $SHORT > gpurun_out/pmc_write.log 2>&1
 echo "pmc write done"
-python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
-cp profiles/r01_pmc_traffic.json gpurun_out/
+python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write "profiles/${TAG}_pmc_traffic.json"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_mfma -- python3 $SHORT > gpurun_out/pmc_mfma.log 2>&1
+python3 tools/pmc_mfma.py gpurun_out/pmc_mfma "profiles/${TAG}_mfma_busy_step.json" "whole training step ($SHORT), bf16 B=32"
+echo "pmc mfma (step) done"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_region -- python3 tools/enc_attn_region.py --iters 20 > gpurun_out/pmc_region.log 2>&1
+python3 tools/pmc_mfma.py gpurun_out/pmc_region "profiles/${TAG}_mfma_busy.json" "encoder self-attention region alone (tools/enc_attn_region.py --iters 20: LN -> QKV -> attention -> out-proj, fwd + bwd), bf16 B=32"
+python3 tools/enc_attn_region.py > "profiles/${TAG}_enc_attn_region.json" 2> /dev/null
+python3 tools/enc_attn_region.py --batch 1024 --iters 50 > "profiles/${TAG}_enc_attn_region_b1024.json" 2> /dev/null
+echo "pmc mfma (region) done"
 python3 bench.py > "$OUT/default.log" 2>&1
 grep '^{' "$OUT/default.log" > "profiles/${TAG}_bench_default.json"
-cp profiles/${TAG}_* gpurun_out/
-rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write "$OUT"/*/  # raw traces are large; the summaries are what is kept
+mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma gpurun_out/pmc_region "$OUT"/*/  # raw traces are large; the summaries are what is kept
 echo "round profile done"
