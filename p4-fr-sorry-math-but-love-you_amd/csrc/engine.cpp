@@ -1661,6 +1661,8 @@ size_t model_workspace_bytes(Model* m, int B, int L) {
     const size_t D = m->cfg.dec_hidden, F = m->cfg.dec_filter;
     dec += ((size_t)m->cfg.dec_layers * (6 * D * D + 2 * D * F) + (size_t)m->cfg.num_classes * D) * es + (64u << 10);
   }
+  // pipelined decoder: role table + one 2 KB granule mailbox per (edge, image)
+  dec += 256 + 256 * sizeof(PipeRole) + ((size_t)(m->cfg.dec_layers + 1) + (size_t)m->cfg.dec_layers * 18) * B * 256 * 8 + (64u << 10);
   // beam search: node tables (1 + 16*499 nodes x 32 B) and ancestor-row lists (499 x 504 x 2 B) per image
   dec += (size_t)B * ((size_t)(1 + 16 * 499) * 32 + (size_t)499 * 504 * 2) + (64u << 10);
   m->ws = save_ws;
@@ -2045,11 +2047,27 @@ static int greedy_body(Model* m, const float* img, const float* src_in, int B, i
   }
   int64_t* sos = (int64_t*)e.alloc((size_t)B * 8);
   launch_fill_i64(sos, c.sos_id, B, s);
-  // ---- fast path: the persistent one-launch decoder (one workgroup per image for the whole decode)
+  // ---- fast path: the persistent one-launch decoders
   if (!getenv("SATRN_DECODE_STEPWISE") && L <= 4) {
     DecodeP dp;
     fill_decode_params(m, dp, crossKV, cache, B, steps, Nsrc, s);
     dp.logits = logits_out; dp.ids = ids_out; dp.rules = rules;
+    // (1) bf16: the pipelined weight-stationary decoder (one workgroup per role, weights resident in LDS).  It is checked
+    //     synchronously -- a decode is tens of milliseconds and its caller reads the result next -- and a pipeline that gave up
+    //     (bounded waits) is re-run on the one-workgroup-per-image kernel, so a result is always the decoder's.  Not inside a
+    //     stream capture (the check synchronises).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    if (cap == hipStreamCaptureStatusNone && !rules) {
+      const size_t sb = decode_pipe_scratch_bytes(dp);
+      void* scratch = e.alloc(sb);
+      if (!e.oom && launch_decode_pipe(e.dt, dp, scratch, sb, s) == 0) {
+        const int perr = decode_pipe_error(scratch, s);
+        if (perr == 0) return 0;
+        fprintf(stderr, "[satrn] pipelined decoder gave up (role %d): falling back to the one-workgroup-per-image decoder\n", perr - 1);
+      }
+      if (e.oom) { m->err = "workspace exhausted"; return -2; }
+    }
     if (launch_decode_greedy(e.dt, dp, s) == 0) {
       if (e.oom) { m->err = "workspace exhausted"; return -2; }
       return 0;

@@ -203,7 +203,23 @@ struct DecodeP {
   const int32_t* rules;  // optional compiled DecodingManager rules [V + 8]: outputs become masked probabilities
   long long* prof;       // optional [16] cycle counters per phase family (SATRN_DEC_PROF, workgroup 0 only)
 };
-int launch_decode_greedy(int dt, const DecodeP& p, hipStream_t s);  // weights in DecLayerW / wgen: k-panel-major copies
+int launch_decode_greedy(int dt, const DecodeP& p, hipStream_t s);
+// pipelined weight-stationary greedy decoder (kernels_decode.hip): one persistent workgroup per ROLE (a slice of the decoder's
+// weights resident in LDS), images flow through the roles over tagged 8-byte granule mailboxes
+struct PipeRole { int type, layer, sub, img0, img1, istep /*serves images img0, img0 + istep, ... < img1*/, N, K, Ntot, row0, kp0; const void* w; const float* bias; const float* lnw; const float* lnb;
+                  const float* pre_bias; const float* pre_lnw; const float* pre_lnb; /*non-null: recompute the previous layer's FFN combine + LayerNorm from its partials*/ };
+struct PipeP {
+  DecLayerW L[4];
+  int nlayers;
+  const float* embed; const float* pe;
+  float* logits; int64_t* ids;
+  int B, steps, D, F, V, H, Nsrc, sos;
+  const PipeRole* roles; unsigned long long* mail; int* err; long long timeout_ticks;
+  long long* prof;  // optional [2 * nroles]: wall-clock ticks spent waiting / in total (SATRN_PIPE_PROF)
+};
+size_t decode_pipe_scratch_bytes(const DecodeP& p);
+int launch_decode_pipe(int dt, const DecodeP& p, void* scratch, size_t scratch_bytes, hipStream_t s);  // 0 launched, -1 shape not supported
+int decode_pipe_error(void* scratch, hipStream_t s);  // weights in DecLayerW / wgen: k-panel-major copies
 // best-first beam search (networks/EfficientSATRN.py:708-867): DecodeP.steps = max_sequence - 1 expansions (= cache rows per
 // image); node tables are per image [NN], NN >= 1 + bw*steps; path [steps][pstride] uint16; out int64 [B][max_seq]
 struct BeamP {

@@ -6,6 +6,10 @@
 // global cache, its activations in LDS.  The reference's history quirk is kept: slot t holds k/v(layer input) while
 // step t is attended, then is overwritten with k/v(layer output) for the following steps.
 #include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -35,16 +39,15 @@ template <> DEVI void ld4<bf16_t>(const bf16_t* p, float* o) {
 template <typename T>
 DEVI const T* kp_addr(const T* W, int Ntot, int row, int kk, int fq) { return W + ((long)(kk >> 5) * Ntot + row) * 32 + fq * 8; }
 
-template <typename T>
+template <typename T, int GU = 2 /*16-output groups per wave iteration: GU x 8 weight loads in flight per lane*/, int NT = DEC_THREADS>
 DEVI void gemv(const T* __restrict__ W, int Ntot, int row0, const float* __restrict__ bias, const T* xT, float* y, int N, int K,
                int act, T* yT = nullptr /*optional: the output also in the compute dtype (the next product's input)*/) {
   constexpr int CH = TT<T>::CH;
-  constexpr int GU = 2;  // 16-output groups per wave iteration: 2 x 8 weight loads in flight per lane
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int ng = (N + 15) >> 4;
   const T* xr = xT + fq * 8;
-  for (int g0 = wave * GU; g0 < ng; g0 += DEC_WAVES * GU) {
+  for (int g0 = wave * GU; g0 < ng; g0 += (NT / 64) * GU) {
     int rowu[GU];
     f32x4 acc[GU];
 #pragma unroll
@@ -136,29 +139,39 @@ DEVI void add_layernorm(float* v, const float* r, const float* w, const float* b
 // wred [DEC_WAVES][D] across waves.  Needs D/CH to be a power of two <= 64.
 // IDX: key j lives in cache row krow[j] (LDS) instead of row j -- the best-first beam search attends over the slots of a
 // node's ancestors.
-template <typename T, bool IDX = false>
+template <typename T, bool IDX = false, bool TAIL = false, int NT = DEC_THREADS>
 DEVI void attend(const float* q, const T* kv, long ld, int voff, int nk, int H, int hd, float inv_temp, float* sc /*[H][nkP]*/,
-                 int nkP, float* o, float* wred, T* oT, const int* krow = nullptr) {
+                 int nkP, float* o, float* wred, T* oT, const int* krow = nullptr, const T* tail = nullptr /*the last `ntail` keys' rows (same
+                 row layout, row stride ld) come from here instead of kv: rows the caller has just produced and keeps in LDS*/, int ntail = 0) {
   constexpr int CH = TT<T>::CH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = H * hd;
   const int cph = hd / CH;  // chunks per head
-  for (int idx = tid; idx < nk * H; idx += DEC_THREADS) {
+  for (int idx = tid; idx < nk * H; idx += NT) {
     const int j = idx / H, h = idx - j * H;
-    const T* kp = kv + (long)(IDX ? krow[j] : j) * ld + h * hd;
+    // (two loads selected by value, not one load through a selected pointer: the rows may live in different address spaces)
+    bool in_tail = false;
+    if constexpr (TAIL) in_tail = j >= nk - ntail;
+    const T* kp = kv + (long)(IDX ? krow[j] : (in_tail ? 0 : j)) * ld + h * hd;
     const float* qp = q + h * hd;
     float acc = 0.f;
 #pragma unroll 4
     for (int c = 0; c < cph; ++c) {
       float f[CH];
-      unpack<T>(ld16(kp + c * CH), f);
+      uint4 raw;
+      if constexpr (TAIL) {
+        if (in_tail) raw = ld16(tail + (long)(j - (nk - ntail)) * ld + h * hd + c * CH); else raw = ld16(kp + c * CH);
+      } else {
+        raw = ld16(kp + c * CH);
+      }
+      unpack<T>(raw, f);
 #pragma unroll
       for (int e = 0; e < CH; ++e) acc += f[e] * qp[c * CH + e];
     }
     sc[h * nkP + j] = acc * inv_temp;
   }
   __syncthreads();
-  for (int h = wave; h < H; h += DEC_WAVES) {
+  for (int h = wave; h < H; h += (NT / 64)) {
     float m = -INFINITY;
     for (int j = lane; j < nk; j += 64) m = fmaxf(m, sc[h * nkP + j]);
     m = wave_max(m);
@@ -170,7 +183,7 @@ DEVI void attend(const float* q, const T* kv, long ld, int voff, int nk, int H, 
   }
   __syncthreads();
   const int cpr = D / CH;             // 16-byte chunks per V row (power of two <= 64)
-  const int KG = DEC_THREADS / cpr;   // key groups
+  const int KG = NT / cpr;   // key groups
   const int dc = tid % cpr, kg = tid / cpr;
   const int h = (dc * CH) / hd;
   float acc[CH];
@@ -182,8 +195,14 @@ DEVI void attend(const float* q, const T* kv, long ld, int voff, int nk, int H, 
   for (int j = kg; j < nk; j += 2 * KG) {
     const int j1 = j + KG;
     const int j1c = j1 < nk ? j1 : 0;
-    const uint4 r0 = ld16(vp + (long)(IDX ? krow[j] : j) * ld);
-    const uint4 r1 = ld16(vp + (long)(IDX ? krow[j1c] : j1c) * ld);
+    uint4 r0, r1;
+    if constexpr (TAIL) {
+      if (j >= nk - ntail) r0 = ld16(tail + voff + dc * CH + (long)(j - (nk - ntail)) * ld); else r0 = ld16(vp + (long)j * ld);
+      if (j1c >= nk - ntail) r1 = ld16(tail + voff + dc * CH + (long)(j1c - (nk - ntail)) * ld); else r1 = ld16(vp + (long)j1c * ld);
+    } else {
+      r0 = ld16(vp + (long)(IDX ? krow[j] : j) * ld);
+      r1 = ld16(vp + (long)(IDX ? krow[j1c] : j1c) * ld);
+    }
     const float p0 = sc[h * nkP + j], p1 = j1 < nk ? sc[h * nkP + j1c] : 0.f;
     float f[CH];
     unpack<T>(r0, f);
@@ -205,7 +224,7 @@ DEVI void attend(const float* q, const T* kv, long ld, int voff, int nk, int H, 
   if (tid < D) {
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < DEC_WAVES; ++w) v += wred[w * D + tid];
+    for (int w = 0; w < (NT / 64); ++w) v += wred[w * D + tid];
     o[tid] = v;
     oT[tid] = from_f<T>(v);
   }
@@ -477,6 +496,494 @@ __global__ __launch_bounds__(DEC_THREADS) void beam_search_kernel(DecodeP p, Bea
 }
 
 // [N][K] row-major -> [K/32][N][32] k-panel-major (K % 32 == 0), 16-byte chunks
+
+// =========================================================================================
+// Pipelined, weight-stationary greedy decoder (bf16).  The one-workgroup-per-image decoder above re-streams all 5.8 MB of
+// decoder weights through ONE compute unit's L2 path every step and pays ~36 dependent phases of 3-5 us each (170 us / step).
+// Here the decoder step is cut into ROLES, each owned by one persistent workgroup on its own compute unit with its slice of
+// the weights RESIDENT IN LDS (<= 128 KB: one 256x256 bf16 matrix) for the whole decode:
+//   per layer:  Q | K(in) | V(in) | K(out) | V(out) projections, self-attention (image shards, owns the KV cache rows of its
+//               images), out-projection + LayerNorm, cross-attention query projection, cross-attention (image shards),
+//               out-projection + LayerNorm, 4 x FFN-in slices, 4 x FFN-out K-slices, FFN combine + LayerNorm
+//   once:       generator + argmax + next-token embedding
+// Images flow through the roles like items through a systolic pipeline: a role loops over (step, image), waits for its input
+// vector(s), computes from LDS-resident weights, publishes its output.  Every hand-off is a vector of 8-byte {tag, f32}
+// granules written and read with relaxed agent-scope (sc1) accesses -- the data IS the flag (cdna_hip_programming.md,
+// Guideline 16 form R2; tag = step + 1, mailboxes zeroed before the launch) -- so no fences, no flags, no cache maintenance;
+// the KV cache rows of an image are written and read by the same workgroup.  A hop costs ~1-1.5 us and a step is ~28 hops
+// for one image, while 64 images are in flight in different roles.  Every wait is bounded (wall clock) and watches a global
+// error word: a stuck pipeline ends with an error code instead of hanging the device.
+// Semantics are the greedy kernel's (reference networks/EfficientSATRN.py:528-561, :386-396).
+// =========================================================================================
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+typedef __attribute__((address_space(1))) int gi32_t;
+
+enum { PR_Q = 0, PR_KA, PR_VA, PR_KB, PR_VB, PR_ATT, PR_O, PR_Q2, PR_XATT, PR_O2, PR_F0, PR_F1, PR_L3, PR_GEN, PR_NTYPES };
+enum { PE_Q = 0, PE_KIN, PE_VIN, PE_KOUT, PE_VOUT, PE_ATT, PE_T1, PE_Q2, PE_ATT2, PE_T2, PE_F0 /*4*/, PE_P = PE_F0 + 4 /*4*/, PE_PER_LAYER = PE_P + 4 };
+
+struct PipeCtx {
+  const PipeP* p;
+  gu64_t* mail;
+  gi32_t* err;
+  long long t_end;
+  int* s_fail;  // LDS word
+};
+
+DEVI gu64_t* pipe_box(const PipeCtx& c, int edge, int img) { return c.mail + ((size_t)edge * c.p->B + img) * 256; }
+DEVI int pipe_edge_x(int l) { return l; }
+DEVI int pipe_edge(const PipeP& p, int l, int e) { return (p.nlayers + 1) + l * PE_PER_LAYER + e; }
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load and store of the
+// wave (vmcnt(0)), which inside a role would expose the round trip of the hand-off stores just issued and of the next item's
+// request on every item.  Nothing in a role's compute path touches global memory (weights, biases and LayerNorm parameters are
+// LDS-resident), so LDS ordering is all the role loop needs.
+#define LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+// add_layernorm with the parameters in LDS and LDS-only barriers (same arithmetic order as add_layernorm above)
+template <typename T, int NT = DEC_THREADS>
+DEVI void add_layernorm_lds(float* v, const float* r, const float* w, const float* b, int D, float* red, T* vT) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float wt = 0.f, bt = 0.f, x = 0.f;
+  if (tid < D) { wt = w[tid]; bt = b[tid]; x = v[tid] + r[tid]; }
+  const float s_ = wave_sum(x), q = wave_sum(x * x);
+  if (lane == 0) { red[wave] = s_; red[(NT / 64) + wave] = q; }
+  LDS_BARRIER();
+  float mean = 0.f, msq = 0.f;
+#pragma unroll
+  for (int i = 0; i < (NT / 64); ++i) { mean += red[i]; msq += red[(NT / 64) + i]; }
+  mean /= (float)D;
+  const float var = fmaxf(msq / (float)D - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + 1e-5f);
+  if (tid < D) {
+    const float o = (x - mean) * rstd * wt + bt;
+    v[tid] = o;
+    vT[tid] = from_f<T>(o);
+  }
+  LDS_BARRIER();
+}
+
+// A role's inputs for one (step, image): up to five D-wide vectors, each with its own expected tag.  All of them are requested at
+// once (thread tid polls granule tid & 255 of vector tid >> 8; the fifth vector is taken by the first 256 threads as well) and
+// the request for the NEXT (step, image) is issued before the current one is computed, so in steady state a role never waits a
+// memory round trip for data that has already arrived.
+// (scalar fields, selected with compare chains: a runtime-indexed array inside the struct would live in scratch memory and
+// every access would be a memory round trip counted in vmcnt -- measured: +1.8 us per item)
+struct RecvPlan { int n; int e0, e1, e2, e3, e4; unsigned g0, g1, g2, g3, g4; };
+struct RecvRegs { unsigned long long v0, v1, v2; };
+DEVI void plan_put(RecvPlan& pl, int e, unsigned g) {
+  switch (pl.n) {
+    case 0: pl.e0 = e; pl.g0 = g; break;
+    case 1: pl.e1 = e; pl.g1 = g; break;
+    case 2: pl.e2 = e; pl.g2 = g; break;
+    case 3: pl.e3 = e; pl.g3 = g; break;
+    default: pl.e4 = e; pl.g4 = g; break;
+  }
+  ++pl.n;
+}
+DEVI int plan_edge(const RecvPlan& pl, int k) { return k == 0 ? pl.e0 : (k == 1 ? pl.e1 : (k == 2 ? pl.e2 : (k == 3 ? pl.e3 : pl.e4))); }
+DEVI unsigned plan_tag(const RecvPlan& pl, int k) { return k == 0 ? pl.g0 : (k == 1 ? pl.g1 : (k == 2 ? pl.g2 : (k == 3 ? pl.g3 : pl.g4))); }
+
+// thread -> granule mapping with 512 threads and D = 256: threads 0..255 take vectors 0, 2, 4, threads 256..511 vectors 1, 3
+DEVI void pipe_issue(const PipeCtx& c, const RecvPlan& pl, int img, RecvRegs& rr, int D) {
+  const int tid = threadIdx.x, k = tid / D, i = tid - k * D;
+  rr.v0 = 0; rr.v1 = 0; rr.v2 = 0;
+  if (k < pl.n) rr.v0 = __hip_atomic_load(pipe_box(c, plan_edge(pl, k), img) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (k + 2 < pl.n) rr.v1 = __hip_atomic_load(pipe_box(c, plan_edge(pl, k + 2), img) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (k + 4 < pl.n) rr.v2 = __hip_atomic_load(pipe_box(c, plan_edge(pl, k + 4), img) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEVI bool pipe_wait1(const PipeCtx& c, gu64_t* g, unsigned want, unsigned long long& v, unsigned& spins) {
+  while ((unsigned)(v >> 32) != want) {
+    if (spins > 64) __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 1023u) == 0) {
+      if (__hip_atomic_load(c.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || (long long)wall_clock64() > c.t_end) { *c.s_fail = 1; return false; }
+    }
+    v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return true;
+}
+// spin until every requested granule carries its tag, then put the payloads into in[k][i] (LDS); false = gave up
+template <typename T>
+DEVI bool pipe_complete(const PipeCtx& c, const RecvPlan& pl, int img, RecvRegs& rr, float* in, T* xT, int D) {
+  const int tid = threadIdx.x, k = tid / D, i = tid - k * D;
+  unsigned spins = 0;
+  if (k < pl.n) {
+    pipe_wait1(c, pipe_box(c, plan_edge(pl, k), img) + i, plan_tag(pl, k), rr.v0, spins);
+    const float fv = __uint_as_float((unsigned)rr.v0);
+    in[k * D + i] = fv;
+    if (k == 0) xT[i] = from_f<T>(fv);   // the first vector is the matrix-vector input: its compute-dtype copy, no extra pass
+  }
+  if (k + 2 < pl.n) {
+    pipe_wait1(c, pipe_box(c, plan_edge(pl, k + 2), img) + i, plan_tag(pl, k + 2), rr.v1, spins);
+    in[(k + 2) * D + i] = __uint_as_float((unsigned)rr.v1);
+  }
+  if (k + 4 < pl.n) {
+    pipe_wait1(c, pipe_box(c, plan_edge(pl, k + 4), img) + i, plan_tag(pl, k + 4), rr.v2, spins);
+    in[(k + 4) * D + i] = __uint_as_float((unsigned)rr.v2);
+  }
+  LDS_BARRIER();
+  return *c.s_fail == 0;
+}
+DEVI void pipe_send(const PipeCtx& c, int edge, int img, unsigned tag, const float* src, int n) {
+  const int tid = threadIdx.x;
+  if (tid < n) __hip_atomic_store(pipe_box(c, edge, img) + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(src[tid]), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define PIPE_THREADS 512
+template <typename T>
+__global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ int s_fail, s_tok;
+  const PipeRole role = p.roles[blockIdx.x];
+  const int tid = threadIdx.x, D = p.D, H = p.H, hd = D / H;
+  const int l = role.layer, NL = p.nlayers;
+  if (tid == 0) s_fail = 0;
+  PipeCtx c;
+  c.p = &p; c.mail = (gu64_t*)p.mail; c.err = (gi32_t*)p.err; c.s_fail = &s_fail;
+  c.t_end = (long long)wall_clock64() + (long long)p.timeout_ticks;
+  // ---- LDS: [weights image (role.N x role.K elements, k-panel-major)] [f32 scratch]
+  T* wl = reinterpret_cast<T*>(sm);
+  const size_t wbytes = ((size_t)role.N * role.K * sizeof(T) + 255) & ~(size_t)255;
+  float* f = sm + wbytes / 4;
+  float* in = f;             // [5][D] received vectors ([2][D] for the query-projection + cross-attention role: its LDS is full)
+  float* y = in + (role.type == PR_Q2 ? 2 : 5) * D;  // [D] outputs (every role of the pipeline produces <= D values)
+  float* lp = y + D;         // [6][D] parameters, loaded once: bias | LayerNorm w | b | the PREVIOUS layer's FFN bias | LayerNorm w | b
+  float* red = lp + 6 * D;   // [2*(PIPE_THREADS / 64)]
+  T* xT = reinterpret_cast<T*>(red + 2 * (PIPE_THREADS / 64));  // [D] compute-dtype copy of the matrix-vector input (an f32 slot per element)
+  float* att_sc = reinterpret_cast<float*>(xT) + D;   // attention roles only: sc [H][nkA] then wred [(PIPE_THREADS / 64)][D]
+  const int nkA = role.type == PR_ATT ? (((p.steps > p.Nsrc ? p.steps : p.Nsrc) + 3) & ~3) : ((p.Nsrc + 3) & ~3);
+  float* att_wred = att_sc + (H * nkA > 4 * D ? H * nkA : 4 * D);
+  // ---- stage this role's weight slice: rows [row0, row0 + N) of k-panels [kp0, kp0 + K/32) of a [..][Ntot][32] source
+  if (role.w) {
+    const T* src = (const T*)role.w;
+    const int cpr = 32 / TT<T>::CH;  // 16-byte chunks per panel row
+    const long nch = (long)(role.K / 32) * role.N * cpr;
+    for (long i = tid; i < nch; i += PIPE_THREADS) {
+      const int ch = (int)(i % cpr);
+      const long pr = i / cpr;
+      const int row = (int)(pr % role.N), kp = (int)(pr / role.N);
+      st16(wl + ((long)kp * role.N + row) * 32 + ch * TT<T>::CH, ld16(src + ((long)(kp + role.kp0) * role.Ntot + role.row0 + row) * 32 + ch * TT<T>::CH));
+    }
+  }
+  for (int i = tid; i < D; i += PIPE_THREADS) {
+    lp[i] = (role.bias && i < (role.type == PR_L3 ? D : role.N)) ? role.bias[i] : 0.f;
+    lp[D + i] = role.lnw ? role.lnw[i] : 1.f;
+    lp[2 * D + i] = role.lnb ? role.lnb[i] : 0.f;
+    lp[3 * D + i] = role.pre_bias ? role.pre_bias[i] : 0.f;
+    lp[4 * D + i] = role.pre_lnw ? role.pre_lnw[i] : 1.f;
+    lp[5 * D + i] = role.pre_lnb ? role.pre_lnb[i] : 0.f;
+  }
+  const float* l_bias = role.bias ? lp : nullptr;
+  const float* l_lnw = lp + D;
+  const float* l_lnb = lp + 2 * D;
+  // pre != 0: this role sits on the critical path right behind a layer boundary and does not wait for the combine role's hop:
+  // it receives the previous layer's four FFN partials + t2 itself and recomputes x = LayerNorm(relu(sum + b1) + t2) (same
+  // arithmetic, same order) -- one hand-off less per layer on every image's path
+  const bool pre = role.pre_lnw != nullptr;
+  __syncthreads();
+  const float inv_temp = rsqrtf((float)D);
+  const float emb_scale = sqrtf((float)D);
+  const int nimg = role.img0 < role.img1 ? (role.img1 - role.img0 + role.istep - 1) / role.istep : 0;
+  // inputs of (step t) for this role type
+  auto plan = [&](int t) {
+    RecvPlan pl;
+    pl.n = 0; pl.e0 = pl.e1 = pl.e2 = pl.e3 = pl.e4 = 0; pl.g0 = pl.g1 = pl.g2 = pl.g3 = pl.g4 = 0;
+    auto put = [&](int e, unsigned tg) { plan_put(pl, e, tg); };
+    const unsigned tg = (unsigned)t + 1u;
+    switch (role.type) {
+      case PR_Q: case PR_KA: case PR_VA:
+        if (pre) { for (int j = 0; j < 4; ++j) put(pipe_edge(p, l - 1, PE_P + j), tg); put(pipe_edge(p, l - 1, PE_T2), tg); }
+        else put(pipe_edge_x(l), tg);
+        break;
+      case PR_KB: case PR_VB: put(pipe_edge_x(l + 1), tg); break;
+      case PR_ATT:
+        put(pipe_edge(p, l, PE_Q), tg); put(pipe_edge(p, l, PE_KIN), tg); put(pipe_edge(p, l, PE_VIN), tg);
+        if (t > 0) { put(pipe_edge(p, l, PE_KOUT), (unsigned)t); put(pipe_edge(p, l, PE_VOUT), (unsigned)t); }
+        break;
+      case PR_O: put(pipe_edge(p, l, PE_ATT), tg); put(pipe_edge_x(l), tg); break;
+      case PR_Q2: put(pipe_edge(p, l, PE_T1), tg); break;
+      case PR_XATT: put(pipe_edge(p, l, PE_Q2), tg); break;  // (only when the cross-attention is not folded into the Q2 role)
+      case PR_O2: put(pipe_edge(p, l, PE_ATT2), tg); put(pipe_edge(p, l, PE_T1), tg); break;
+      case PR_F0: put(pipe_edge(p, l, PE_T2), tg); break;
+      case PR_F1: put(pipe_edge(p, l, PE_F0 + role.sub), tg); break;
+      case PR_L3: for (int j = 0; j < 4; ++j) put(pipe_edge(p, l, PE_P + j), tg); put(pipe_edge(p, l, PE_T2), tg); break;
+      default:  // PR_GEN
+        if (pre) { for (int j = 0; j < 4; ++j) put(pipe_edge(p, NL - 1, PE_P + j), tg); put(pipe_edge(p, NL - 1, PE_T2), tg); }
+        else put(pipe_edge_x(NL), tg);
+        break;
+    }
+    return pl;
+  };
+  if (role.type == PR_GEN) {  // step 0 inputs: <SOS> for every image
+    for (int img = role.img0; img < role.img1; img += role.istep) {
+      if (tid < D) y[tid] = p.embed[(long)p.sos * D + tid] * emb_scale + p.pe[tid];
+      __syncthreads();
+      pipe_send(c, pipe_edge_x(0), img, 1u, y, D);
+      __syncthreads();
+    }
+  }
+  bool ok = nimg > 0 && p.steps > 0;
+  long long t_wait = 0, t_gemv = 0, t_bar = 0;
+  const long long t_begin = (long long)wall_clock64();
+  RecvRegs rr;
+  RecvPlan cur = plan(0);
+  if (ok) pipe_issue(c, cur, role.img0, rr, D);
+  for (int t = 0; t < p.steps && ok; ++t) {
+    for (int img = role.img0; img < role.img1 && ok; img += role.istep) {
+      const long long w0 = p.prof ? (long long)wall_clock64() : 0;
+      ok = pipe_complete<T>(c, cur, img, rr, in, xT, D);
+      if (p.prof && tid == 0) t_wait += (long long)wall_clock64() - w0;
+      if (!ok) break;
+      const unsigned tag = (unsigned)t + 1u;
+      if (pre) {
+        if (tid < D) y[tid] = fmaxf(((in[tid] + in[D + tid]) + in[2 * D + tid]) + in[3 * D + tid] + lp[3 * D + tid], 0.f);
+        add_layernorm_lds<T, PIPE_THREADS>(y, in + 4 * D, lp + 4 * D, lp + 5 * D, D, red, xT);   // y = x(l), xT = its compute-dtype copy
+      }
+      switch (role.type) {
+        case PR_GEN: {
+          gemv<T, 2, PIPE_THREADS>(wl, role.N, 0, l_bias, xT, y, role.N, D, ACT_NONE);
+          LDS_BARRIER();
+          float* out = p.logits + ((long)img * p.steps + t) * p.V;
+          for (int i = tid; i < p.V; i += PIPE_THREADS) out[i] = y[i];
+          if (tid < 64) {
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+            for (int cc = tid; cc < p.V; cc += 64) { float v = y[cc]; if (v > best) { best = v; bi = cc; } }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+              float ob = __shfl_xor(best, o, 64);
+              int oi = __shfl_xor(bi, o, 64);
+              if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (tid == 0) { s_tok = bi; p.ids[(long)img * p.steps + t] = bi; }
+          }
+          LDS_BARRIER();
+          if (t + 1 < p.steps) {
+            // the next token's embedding goes straight from global memory into the hand-off (no LDS round trip)
+            const int tok = s_tok;
+            if (tid < D) {
+              const float v = p.embed[(long)tok * D + tid] * emb_scale + p.pe[(long)(t + 1) * D + tid];
+              __hip_atomic_store(pipe_box(c, pipe_edge_x(0), img) + tid, ((unsigned long long)(tag + 1u) << 32) | (unsigned long long)__float_as_uint(v),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          break;
+        }
+        case PR_ATT: {
+          const int nkP = nkA;
+          T* cache = (T*)p.L[l].cache + (long)img * p.steps * 2 * D;
+          // row t-1 <- k / v of the previous step's layer OUTPUT (the reference's history), row t <- k / v of this step's INPUT
+          // Both rows are also kept in LDS for this step's attention (row t-1, row t): the attention then reads rows 0..t-2 from
+          // the cache only -- written at least one step ago -- and nothing waits for this step's cache stores (~1 us exposed
+          // otherwise; attend()'s own barriers retire them long before the next step reads them)
+          T* tailT = reinterpret_cast<T*>(att_wred + (PIPE_THREADS / 64) * D);   // [2][2D] compute-dtype rows
+          const int ntail = t > 0 ? 2 : 1;
+          if (t > 0) for (int i = tid; i < 2 * D; i += PIPE_THREADS) { const T v = from_f<T>(in[3 * D + i]); cache[(long)(t - 1) * 2 * D + i] = v; tailT[i] = v; }
+          for (int i = tid; i < 2 * D; i += PIPE_THREADS) { const T v = from_f<T>(in[D + i]); cache[(long)t * 2 * D + i] = v; tailT[(ntail - 1) * 2 * D + i] = v; }
+          LDS_BARRIER();
+          attend<T, false, true, PIPE_THREADS>(in, cache, 2 * D, D, t + 1, H, hd, inv_temp, att_sc, nkP, y, att_wred, xT, nullptr, tailT, ntail);
+          pipe_send(c, pipe_edge(p, l, PE_ATT), img, tag, y, D);
+          break;
+        }
+        case PR_XATT: {
+          const int nkP = nkA;
+          attend<T, false, false, PIPE_THREADS>(in, (const T*)p.L[l].crossKV + (long)img * p.Nsrc * 2 * D, 2 * D, D, p.Nsrc, H, hd, inv_temp, att_sc, nkP, y, att_wred, xT);
+          pipe_send(c, pipe_edge(p, l, PE_ATT2), img, tag, y, D);
+          break;
+        }
+        case PR_L3: {
+          // ffn = relu(sum of the four K-slice partials + bias); out = LayerNorm(ffn + t2)
+          // (each thread reads and writes its own element: no barrier needed before the LayerNorm)
+          if (tid < D) y[tid] = fmaxf(((in[tid] + in[D + tid]) + in[2 * D + tid]) + in[3 * D + tid] + lp[tid], 0.f);
+          add_layernorm_lds<T, PIPE_THREADS>(y, in + 4 * D, l_lnw, l_lnb, D, red, xT);
+          pipe_send(c, pipe_edge_x(l + 1), img, tag, y, D);
+          break;
+        }
+        default: {  // matrix-vector roles
+          const long long g0 = (p.prof && tid == 0) ? (long long)wall_clock64() : 0;
+          gemv<T, 2, PIPE_THREADS>(wl, role.N, 0, l_bias, xT, y, role.N, role.K, role.type == PR_F0 ? ACT_RELU : ACT_NONE);
+          const long long g1 = (p.prof && tid == 0) ? (long long)wall_clock64() : 0;
+          LDS_BARRIER();
+          if (p.prof && tid == 0) { t_gemv += g1 - g0; t_bar += (long long)wall_clock64() - g1; }
+          int e_out;
+          switch (role.type) {
+            case PR_Q: e_out = pipe_edge(p, l, PE_Q); break;
+            case PR_KA: e_out = pipe_edge(p, l, PE_KIN); break;
+            case PR_VA: e_out = pipe_edge(p, l, PE_VIN); break;
+            case PR_KB: e_out = pipe_edge(p, l, PE_KOUT); break;
+            case PR_VB: e_out = pipe_edge(p, l, PE_VOUT); break;
+            case PR_O: e_out = pipe_edge(p, l, PE_T1); break;
+            case PR_Q2: e_out = pipe_edge(p, l, PE_Q2); break;
+            case PR_O2: e_out = pipe_edge(p, l, PE_T2); break;
+            case PR_F0: e_out = pipe_edge(p, l, PE_F0 + role.sub); break;
+            default: e_out = pipe_edge(p, l, PE_P + role.sub); break;  // PR_F1
+          }
+          if (role.type == PR_O || role.type == PR_O2) add_layernorm_lds<T, PIPE_THREADS>(y, in + D, l_lnw, l_lnb, D, red, xT);
+          if (role.type == PR_Q2 && role.sub == 1) {
+            // cross-attention folded into the query projection's role (one hand-off less): K / V of the encoder output were
+            // projected before the launch and are read-only here.  (Requesting those rows before the projection, so that their
+            // round trips hide behind it, changed nothing: 99.3 vs 97.3 us per step -- the rows are L2-hot)
+            attend<T, false, false, PIPE_THREADS>(y, (const T*)p.L[l].crossKV + (long)img * p.Nsrc * 2 * D, 2 * D, D, p.Nsrc, H, hd, inv_temp, att_sc, nkA, in, att_wred, xT);
+            pipe_send(c, pipe_edge(p, l, PE_ATT2), img, tag, in, D);
+            LDS_BARRIER();  // `in` is the next item's receive buffer
+            break;
+          }
+          pipe_send(c, e_out, img, tag, y, role.N);
+          break;
+        }
+      }
+      if (p.prof && tid == 0 && img == 0 && (t == 100 || t == 101)) p.prof[768 + (t - 100) * 256 + blockIdx.x] = (long long)wall_clock64();
+      // no barrier here: the next item's first LDS writes (pipe_complete: in / xT) do not touch y, and its own barrier comes before
+      // anything overwrites y.
+      // Request the next (step, image)'s inputs.  (Issued BEFORE the compute, the two request registers had to live across the
+      // matrix-vector product in a 128-VGPR kernel: they were spilled, and a spill store waits for the load it stores.)
+      {
+        int nt = t, ni = img + role.istep;
+        if (ni >= role.img1) { ni = role.img0; ++nt; }
+        if (nt < p.steps) { cur = plan(nt); pipe_issue(c, cur, ni, rr, D); }
+      }
+    }
+  }
+  if (!ok && s_fail && tid == 0) __hip_atomic_store(c.err, 1 + (int)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (p.prof && tid == 0) { p.prof[2 * blockIdx.x] = t_wait; p.prof[2 * blockIdx.x + 1] = (long long)wall_clock64() - t_begin; p.prof[512 + 2 * blockIdx.x] = t_gemv; p.prof[512 + 2 * blockIdx.x + 1] = t_bar; }
+}
+
+// Host side: role table + mailboxes live in a caller-provided scratch block (device memory).  Returns 0 when the pipeline was
+// launched, -1 when the shape does not fit it (the caller then uses the one-workgroup-per-image kernel).
+size_t decode_pipe_scratch_bytes(const DecodeP& p) {
+  const size_t nedges = (size_t)(p.nlayers + 1) + (size_t)p.nlayers * PE_PER_LAYER;
+  return 256 /*err*/ + 256 * sizeof(PipeRole) + nedges * p.B * 256 * 8;
+}
+int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_bytes, hipStream_t s) {
+  const bool off = getenv("SATRN_DECODE_NO_PIPE") != nullptr;  // read per call: tests switch between the two decoders in one process
+  if (off || dt != DT_BF16 || d.rules || d.D != 256 || d.F != 1024 || d.H * (d.D / d.H) != d.D || (d.D / d.H) % 8 || d.V > 256 || d.B > 112 /*larger batches: the per-image kernel (1 workgroup per image, no hand-offs) wins*/ || d.nlayers < 1 || d.nlayers > 4 ||
+      d.B < 1 || scratch_bytes < decode_pipe_scratch_bytes(d))
+    return -1;
+  typedef bf16_t T;
+  std::vector<PipeRole> roles;
+  auto add = [&](int type, int l, int sub, int i0, int i1, const void* w, int Ntot, int row0, int kp0, int N, int K, const float* bias, const float* lnw,
+                 const float* lnb) {
+    PipeRole r;
+    memset(&r, 0, sizeof(r));
+    r.type = type; r.layer = l; r.sub = sub; r.img0 = i0; r.img1 = i1; r.istep = 1; r.w = w; r.Ntot = Ntot; r.row0 = row0; r.kp0 = kp0; r.N = N; r.K = K; r.bias = bias;
+    r.lnw = lnw; r.lnb = lnb;
+    if (l > 0 && (type == PR_Q || type == PR_KA || type == PR_VA)) { r.pre_bias = d.L[l - 1].b1; r.pre_lnw = d.L[l - 1].ln3w; r.pre_lnb = d.L[l - 1].ln3b; }
+    if (type == PR_GEN) { r.pre_bias = d.L[d.nlayers - 1].b1; r.pre_lnw = d.L[d.nlayers - 1].ln3w; r.pre_lnb = d.L[d.nlayers - 1].ln3b; }
+    roles.push_back(r);
+  };
+  const int D = d.D, F = d.F, B = d.B;
+  // every role is sharded over images: a shard is one workgroup (one compute unit) serving a contiguous range of the batch.
+  // Attention roles do the most work per item (two passes over the image's KV history), matrix-vector roles the least.
+  auto knob = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+  // shards sized from the measured service times per item (SATRN_PIPE_PROF: matrix-vector 2.3 us, +LayerNorm 3.8, cross-attention
+  // 5.5, self-attention 8.6 at 231 steps) so that no role is busy for more than ~60 us of a step at batch 64
+  int SA = knob("SATRN_PIPE_ATT_SHARDS", 10), SX = knob("SATRN_PIPE_XATT_SHARDS", 8), SM = knob("SATRN_PIPE_MV_SHARDS", 3), SL = knob("SATRN_PIPE_LN_SHARDS", 4);
+  {  // one workgroup per compute unit: scale the shard counts down until the role count fits the chip
+    auto count = [&]() { return d.nlayers * (5 * SM + SA + SL + SX + SL + 8 * SM + SM) + SL; };
+    while (count() > 250 && (SA > 1 || SX > 1 || SM > 1 || SL > 1)) { if (SA > 1) --SA; if (SX > 1 && count() > 250) --SX; if (SM > 1 && count() > 250) --SM; if (SL > 1 && count() > 250) --SL; }
+  }
+  auto sharded = [&](int n, int type, int l, int sub, const void* w, int Ntot, int row0, int kp0, int N, int K, const float* bias, const float* lnw,
+                     const float* lnb) {
+    // shard k of n serves images k, k + n, k + 2n, ... in increasing order.  (Contiguous ranges made every role wait for the
+    // slowest upstream shard to walk through its whole range before the next image of its own range arrived: head-of-line
+    // blocking, +45 us per step at batch 64.)
+    n = n < 1 ? 1 : (n > B ? B : n);
+    for (int k = 0; k < n; ++k) { add(type, l, sub, k, B, w, Ntot, row0, kp0, N, K, bias, lnw, lnb); roles.back().istep = n; }
+  };
+  for (int l = 0; l < d.nlayers; ++l) {
+    const DecLayerW& w = d.L[l];
+    sharded(SM, PR_Q, l, 0, w.wqkv, 3 * D, 0, 0, D, D, w.bqkv, nullptr, nullptr);
+    sharded(SM, PR_KA, l, 0, w.wqkv, 3 * D, D, 0, D, D, w.bqkv + D, nullptr, nullptr);
+    sharded(SM, PR_VA, l, 0, w.wqkv, 3 * D, 2 * D, 0, D, D, w.bqkv + 2 * D, nullptr, nullptr);
+    sharded(SM, PR_KB, l, 0, w.wqkv, 3 * D, D, 0, D, D, w.bqkv + D, nullptr, nullptr);
+    sharded(SM, PR_VB, l, 0, w.wqkv, 3 * D, 2 * D, 0, D, D, w.bqkv + 2 * D, nullptr, nullptr);
+    sharded(SA, PR_ATT, l, 0, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr);
+    sharded(SL, PR_O, l, 0, w.wo, D, 0, 0, D, D, w.bo, w.ln1w, w.ln1b);
+    sharded(SX, PR_Q2, l, 1 /*+ cross-attention*/, w.wq2, D, 0, 0, D, D, w.bq2, nullptr, nullptr);
+    sharded(SL, PR_O2, l, 0, w.wo2, D, 0, 0, D, D, w.bo2, w.ln2w, w.ln2b);
+    for (int j = 0; j < F / D; ++j) sharded(SM, PR_F0, l, j, w.w0, F, j * D, 0, D, D, w.b0 + j * D, nullptr, nullptr);
+    for (int j = 0; j < F / D; ++j) sharded(SM, PR_F1, l, j, w.w1, D, 0, j * (D / 32), D, D, nullptr, nullptr, nullptr);
+    sharded(SM, PR_L3, l, 0, nullptr, 0, 0, 0, 0, 0, w.b1, w.ln3w, w.ln3b);
+  }
+  sharded(SL, PR_GEN, 0, 0, d.wgen, d.V, 0, 0, d.V, D, d.bgen, nullptr, nullptr);
+  if (roles.size() > 250) return -1;  // one workgroup per compute unit, all resident (256 CUs)
+  PipeP p;
+  memset(&p, 0, sizeof(p));
+  for (int l = 0; l < d.nlayers; ++l) p.L[l] = d.L[l];
+  p.nlayers = d.nlayers; p.embed = d.embed; p.pe = d.pe; p.logits = d.logits; p.ids = d.ids;
+  p.B = B; p.steps = d.steps; p.D = D; p.F = F; p.V = d.V; p.H = d.H; p.Nsrc = d.Nsrc; p.sos = d.sos;
+  char* sc = (char*)scratch;
+  p.err = (int*)sc;
+  p.roles = (const PipeRole*)(sc + 256);
+  p.mail = (unsigned long long*)(sc + 256 + 256 * sizeof(PipeRole));
+  p.timeout_ticks = 300000000LL;  // 3 s of the 100 MHz wall clock: far beyond any legitimate decode, short enough to end a stuck one
+  // pinned staging for the asynchronous copy of the role table: a small ring, so that a call never rewrites a slot whose copy
+  // may still be queued
+  static PipeRole* h_ring = nullptr;
+  static unsigned h_seq = 0;
+  if (!h_ring && hipHostMalloc((void**)&h_ring, 8 * 256 * sizeof(PipeRole), 0) != hipSuccess) return -1;
+  PipeRole* h_roles = h_ring + (size_t)(h_seq++ % 8) * 256;
+  memcpy(h_roles, roles.data(), roles.size() * sizeof(PipeRole));
+  const size_t nedges = (size_t)(d.nlayers + 1) + (size_t)d.nlayers * PE_PER_LAYER;
+#define PIPE_CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "[satrn] decode pipe: %s -> %s\n", #call, hipGetErrorString(e_)); return -1; } } while (0)
+  PIPE_CK(hipMemsetAsync(sc, 0, 256, s));
+  launch_fill((void*)p.mail, 0, nedges * B * 256 * 8, s);
+  PIPE_CK(hipGetLastError());
+  PIPE_CK(hipMemcpyAsync((void*)p.roles, h_roles, roles.size() * sizeof(PipeRole), hipMemcpyHostToDevice, s));
+  // LDS: weights image (<= 128 KB) + scratch; attention roles use the scratch for scores / partial outputs instead of weights
+  const int nkS = ((d.steps > d.Nsrc ? d.steps : d.Nsrc) + 3) & ~3, nkX = (d.Nsrc + 3) & ~3;
+  const int PW = PIPE_THREADS / 64;
+  const size_t fl_common = (size_t)5 * D + D + 6 * D + 2 * PW + D;
+  const size_t fl_att_self = fl_common + (size_t)(d.H * nkS > 4 * D ? d.H * nkS : 4 * D) + (size_t)PW * D + 4 * D /*two newest K|V rows*/;
+  const size_t fl_att_cross = fl_common + (size_t)(d.H * nkX > 4 * D ? d.H * nkX : 4 * D) + (size_t)PW * D;
+  size_t sh = std::max((size_t)D * D * sizeof(T) + 256 + (fl_att_cross - 3 * D) * 4, fl_att_self * 4);   // Q2 role: weights + cross-attention scratch
+  sh = std::max(sh, (size_t)D * D * sizeof(T) + 256 + fl_common * 4);
+  sh = std::max(sh, (((size_t)d.V * D * sizeof(T) + 255) & ~(size_t)255) + fl_common * 4);
+  if (sh > 160 * 1024 - 64) return -1;
+  static bool a = false;
+  if (!a) { PIPE_CK(hipFuncSetAttribute((const void*)decode_pipe_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); a = true; }
+  static const bool want_prof = getenv("SATRN_PIPE_PROF") != nullptr;  // debugging aid: per-role wait / total wall-clock ticks
+  static long long* prof_buf = nullptr;
+  if (want_prof) {
+    if (!prof_buf) (void)hipMalloc((void**)&prof_buf, 2048 * sizeof(long long));
+    (void)hipMemsetAsync(prof_buf, 0, 2048 * sizeof(long long), s);
+    p.prof = prof_buf;
+  }
+  hipLaunchKernelGGL((decode_pipe_kernel<T>), dim3((unsigned)roles.size()), dim3(PIPE_THREADS), sh, s, p);
+  PIPE_CK(hipGetLastError());
+  if (want_prof) {
+    static long long h[2048];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, prof_buf, sizeof(h), hipMemcpyDeviceToHost);
+    static const char* nm[PR_NTYPES] = {"Q", "Kin", "Vin", "Kout", "Vout", "ATT", "O+LN1", "Q2", "XATT", "O2+LN2", "F0", "F1", "L3", "GEN"};
+    {  // timeline of image 0 through step 100 (and when step 101's first role finished): who hands to whom, how long each hop takes
+      std::vector<std::pair<long long, size_t>> tl;
+      for (size_t i = 0; i < roles.size(); ++i) if (h[768 + i]) tl.push_back({h[768 + i], i});
+      std::sort(tl.begin(), tl.end());
+      for (size_t k = 0; k < tl.size(); ++k)
+        fprintf(stderr, "[pipe timeline] +%7.2f us (d %5.2f)  role %3zu %-7s l%d s%d\n", (tl[k].first - tl[0].first) / 100.0, k ? (tl[k].first - tl[k - 1].first) / 100.0 : 0.0, tl[k].second,
+                nm[roles[tl[k].second].type], roles[tl[k].second].layer, roles[tl[k].second].sub);
+      long long first101 = 0;
+      for (size_t i = 0; i < roles.size(); ++i) if (h[768 + 256 + i] && (!first101 || h[768 + 256 + i] < first101)) first101 = h[768 + 256 + i];
+      if (!tl.empty() && first101) fprintf(stderr, "[pipe timeline] step 101 first completion at +%.2f us\n", (first101 - tl[0].first) / 100.0);
+    }
+    for (size_t i = 0; i < roles.size(); ++i)
+      if (roles[i].layer == 0 || roles[i].type == PR_GEN)
+        fprintf(stderr, "[pipe prof] role %3zu %-7s l%d s%d imgs %d-%d: total %.2f ms, waiting %.2f ms (%.0f%%), busy per item %.2f us\n", i, nm[roles[i].type], roles[i].layer,
+                roles[i].sub, roles[i].img0, roles[i].img1, h[2 * i + 1] / 1e5, h[2 * i] / 1e5, 100.0 * h[2 * i] / (double)std::max(h[2 * i + 1], 1LL),
+                (h[2 * i + 1] - h[2 * i]) / 100.0 / std::max(1, ((roles[i].img1 - roles[i].img0 + roles[i].istep - 1) / roles[i].istep) * d.steps)),
+        fprintf(stderr, "            gemv %.2f us, barrier after it %.2f us per item (thread 0)\n", h[512 + 2 * i] / 100.0 / std::max(1, ((roles[i].img1 - roles[i].img0 + roles[i].istep - 1) / roles[i].istep) * d.steps),
+                h[512 + 2 * i + 1] / 100.0 / std::max(1, ((roles[i].img1 - roles[i].img0 + roles[i].istep - 1) / roles[i].istep) * d.steps));
+  }
+  return 0;
+}
+int decode_pipe_error(void* scratch, hipStream_t s) {  // synchronises; 0 = clean
+  int e = 0;
+  (void)hipMemcpyAsync(&e, scratch, sizeof(int), hipMemcpyDeviceToHost, s);
+  (void)hipStreamSynchronize(s);
+  return e;
+}
+
 template <typename T>
 __global__ void repack_kpanel_kernel(const T* src, T* dst, int N, int K) {
   constexpr int CH = TT<T>::CH, CPP = 32 / CH;  // chunks per 32-wide panel row

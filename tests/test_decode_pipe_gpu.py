@@ -1,0 +1,73 @@
+"""GPU: the pipelined weight-stationary greedy decoder (bf16; one persistent workgroup per decoder ROLE with its weight slice
+resident in LDS, images flowing through tagged-granule mailboxes) against the one-workgroup-per-image decoder it replaces and
+against the CPU oracle.  The two kernels differ only in summation grouping (four FFN K-slices, attention partial sums), so logits
+agree to bf16 noise and ids wherever the top-1 / top-2 margin is clear."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import satrn_oracle as O
+from tests.test_model_gpu import build
+
+pytestmark = pytest.mark.gpu
+
+
+def _greedy(model, img, steps, pipe):
+    if pipe:
+        os.environ.pop("SATRN_DECODE_NO_PIPE", None)
+    else:
+        os.environ["SATRN_DECODE_NO_PIPE"] = "1"
+    try:
+        lg, ids = model.greedy(img, steps)
+        torch.cuda.synchronize()
+        return lg.clone(), ids.clone()
+    finally:
+        os.environ.pop("SATRN_DECODE_NO_PIPE", None)
+
+
+@pytest.mark.parametrize("B,steps", [(2, 7), (5, 33), (64, 231)])
+def test_pipelined_decoder_matches_per_image_decoder(B, steps):
+    cfg = dict(O.CFG_EFF)
+    model, sd = build(cfg, 128, 384, "bf16", 6)
+    model.eval()
+    img, _ = O.det_inputs(B, 1, 128, 384, 4, seed=90 + B)
+    imgd = img.cuda()
+    lg0, ids0 = _greedy(model, imgd, steps, pipe=False)
+    lg1, ids1 = _greedy(model, imgd, steps, pipe=True)
+    assert torch.isfinite(lg1).all()
+    # step 0 sees identical inputs in both kernels
+    d0 = (lg1[:, 0] - lg0[:, 0]).abs().max().item()
+    print(f"[pipe B={B} T={steps}] step-0 logits max diff {d0:.3e}")
+    assert d0 < 2e-2 * max(1.0, lg0[:, 0].abs().max().item())
+    # follow the sequences while they agree: a differing token (an argmax decided inside bf16 noise) legitimately changes
+    # everything after it for that image
+    top2 = torch.topk(lg0, 2, dim=-1).values
+    margin = (top2[..., 0] - top2[..., 1])
+    agree = 0
+    for b in range(B):
+        same = (ids0[b] == ids1[b]).int()
+        first_diff = int(same.argmin().item()) if same.min().item() == 0 else steps
+        agree += first_diff
+        if first_diff < steps:
+            assert margin[b, first_diff].item() < 0.1, f"image {b} step {first_diff}: ids differ at a clear margin {margin[b, first_diff].item():.3f}"
+        if first_diff > 0:
+            assert (lg1[b, :first_diff] - lg0[b, :first_diff]).abs().max().item() < 0.08 * max(1.0, lg0[b].abs().max().item())
+    print(f"[pipe B={B} T={steps}] identical prefix: {agree} of {B * steps} tokens")
+    # random-init weights give many near-ties: over 231 steps most images meet one inside bf16 noise and their continuations
+    # then differ legitimately (each first difference was checked against its margin above); short decodes agree entirely
+    assert agree >= (0.9 if steps <= 40 else 0.25) * B * steps
+
+
+def test_pipelined_decoder_second_call_and_growing_batch():
+    """mailboxes are re-zeroed per call; a second decode of another batch size reuses the model"""
+    cfg = dict(O.CFG_EFF)
+    model, sd = build(cfg, 128, 384, "bf16", 7)
+    model.eval()
+    for B, steps in ((3, 9), (8, 12), (3, 9)):
+        img, _ = O.det_inputs(B, 1, 128, 384, 4, seed=70 + B)
+        lg0, ids0 = _greedy(model, img.cuda(), steps, pipe=False)
+        lg1, ids1 = _greedy(model, img.cuda(), steps, pipe=True)
+        assert (ids0[:, 0] == ids1[:, 0]).all() or (lg1[:, 0] - lg0[:, 0]).abs().max().item() < 0.05
+        assert torch.isfinite(lg1).all()
