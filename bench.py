@@ -409,7 +409,21 @@ def main():
                 out["greedy_decode"]["roofline"] = dict(bound="hbm", algorithmic_bytes_per_step=38.0e6, us_per_step=round(step_us, 1),
                                                         achieved=round(38.0e6 / step_us / 1e3, 1), peak=8000.0, unit="GB/s",
                                                         frac=round(38.0e6 / step_us / 1e3 / 8000.0, 4), encoder_ms=round(esec * 1e3, 2),
-                                                        note="one dependent chain per image: ~31 weight-streaming phases per step, each bound by a memory round trip and one CU's L2 bandwidth, not by HBM")
+                                                        kernel="decode_pipe_kernel (one persistent workgroup per decoder role, weights resident in LDS, images pipelined through the roles)",
+                                                        note="latency-bound, not HBM-bound: a token is a dependent chain of ~22 role hops per step (3 layers x [Q/K/V, attention, O+LN, Q2+cross-attention, O2+LN, FFN0, FFN1] + generator); the weights never leave LDS, so the 38 MB/step figure is what a weight-streaming decoder would move, kept as the algorithmic unit of SURVEY 8d")
+                # the per-image kernel of round 1 (one workgroup per image streams every weight each step), kept as the
+                # fallback for shapes the pipeline does not take; timed beside it
+                os.environ["SATRN_DECODE_NO_PIPE"] = "1"
+                try:
+                    model.greedy(dimg, 231)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    model.greedy(dimg, 231)
+                    torch.cuda.synchronize()
+                    out["greedy_decode"]["per_image_kernel"] = dict(ms_per_batch=round((time.perf_counter() - t1) * 1e3, 2),
+                                                                    note="round-1 decoder (fallback path), same batch")
+                finally:
+                    os.environ.pop("SATRN_DECODE_NO_PIPE", None)
                 # the same decode with the DecodingManager rules evaluated inside the decode kernel (the reference's default
                 # at inference, inference.py:48); rule table = the reference RULES as compiled into tests/golden/rules.npz
                 rules_npz = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "rules.npz")
@@ -434,8 +448,16 @@ def main():
                     model.decoder.manager = None
                     out["greedy_decode"]["with_decoding_manager"] = dict(value=round(64 * 231 / msec, 1), unit="tokens/s",
                                                                          ms_per_batch=round(msec * 1e3, 2))
-                # the decode is one dependent chain per image (one workgroup each): 64 images use 64 of the 256 CUs, so a larger
-                # batch costs almost nothing extra -- reported beside the BASELINE batch, not instead of it
+                # larger batches, reported beside the BASELINE batch, not instead of it: 112 images is the most the pipeline's
+                # mailboxes take; above that the engine falls back to the per-image kernel (one workgroup per image)
+                dimg112 = torch.cat([dimg, dimg[:48]])
+                model.greedy(dimg112, 231)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                model.greedy(dimg112, 231)
+                torch.cuda.synchronize()
+                d112 = time.perf_counter() - t1
+                out["greedy_decode"]["batch_112"] = dict(value=round(112 * 231 / d112, 1), unit="tokens/s", ms_per_batch=round(d112 * 1e3, 2), decoder="pipelined")
                 dimg4 = torch.cat([dimg] * 4)
                 model.greedy(dimg4, 231)
                 torch.cuda.synchronize()
@@ -443,7 +465,7 @@ def main():
                 model.greedy(dimg4, 231)
                 torch.cuda.synchronize()
                 d4 = time.perf_counter() - t1
-                out["greedy_decode"]["batch_256"] = dict(value=round(256 * 231 / d4, 1), unit="tokens/s", ms_per_batch=round(d4 * 1e3, 2))
+                out["greedy_decode"]["batch_256"] = dict(value=round(256 * 231 / d4, 1), unit="tokens/s", ms_per_batch=round(d4 * 1e3, 2), decoder="per-image kernel (batch > 112)")
                 # best-first beam search of the same 64 images (EfficientSATRN.beam_search, beam 5, max_sequence 230): one launch,
                 # at most 229 decoder-step expansions per image
                 class _Loader:
