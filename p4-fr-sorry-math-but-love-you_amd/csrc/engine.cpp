@@ -5,6 +5,7 @@
 //   :400-426 (PositionEncoder1D), :429-566 (SATRNDecoder), networks/LiteSATRN.py:21-70 (ShallowCNN),
 //   train_modules/train_single_opt.py:80-98 (loss, backward, clip, AdamW).
 #include "engine.h"
+#include <chrono>
 
 #include <math.h>
 #include <stdio.h>
@@ -56,14 +57,16 @@ void Exec::defer(std::function<void(hipStream_t)> fn) {
   if (skip && !dry) return;
   if (!s2 || dry) { fn(s); return; }
   pending.push_back(std::move(fn));
-  // hand the batch to the side stream every 4 launches: with 8 the main chain waited 0.39 ms at the final join for the
-  // tail of the side stream, with 4 it waits 0.19 ms; 2 and 1 cost more in events than they save
-  static const int thr = getenv("SATRN_FLUSH") ? atoi(getenv("SATRN_FLUSH")) : 4;
+  // hand the batch to the side stream every 8 launches (round 2, tools/ab_flush.sh: 4 -> 12.35, 8 -> 12.14, 16 -> 12.15,
+  // never -> 14.6 ms/step): every hand-over is an event record on the chain's queue, which stalls it for >= 7 us
+  static const int thr = getenv("SATRN_FLUSH") ? atoi(getenv("SATRN_FLUSH")) : 8;
   if ((int)pending.size() >= thr) flush_side();
 }
 void Exec::flush_side() {
   if (pending.empty()) return;
-  if (nfork >= (int)evs.size()) { hipEvent_t ev; (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming); evs.push_back(ev); }
+  // fork events order device work only (nobody on the host reads them): no system-scope fence at the record
+  static const unsigned evflags = getenv("SATRN_EV_FLAGS") ? (unsigned)strtoul(getenv("SATRN_EV_FLAGS"), nullptr, 0) : (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+  if (nfork >= (int)evs.size()) { hipEvent_t ev; (void)hipEventCreateWithFlags(&ev, evflags); evs.push_back(ev); }
   hipEvent_t ev = evs[nfork++];
   (void)hipEventRecord(ev, s);
   (void)hipStreamWaitEvent(s2, ev, 0);
@@ -1819,7 +1822,13 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
     hd[7] = 1.0f - powf(hd[2], (float)m->adam_t);
     (void)hipMemcpyAsync(scal(m) + SC_HYPER2, hd, 9 * sizeof(float), hipMemcpyHostToDevice, s);
   }
+  static const bool host_prof = getenv("SATRN_HOST_PROF") != nullptr;  // host time spent ISSUING the forward / backward / optimizer
+  auto hnow = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto body = [&]() -> int {
+    const double h0 = host_prof ? hnow() : 0.0;
+    double h1 = h0, h2 = h0;
+    struct HostRep { const bool on; const double& a; const double& b; const double& c; decltype(hnow)& now;
+                     ~HostRep() { if (on) { double d = now(); fprintf(stderr, "[host] issue: forward %.0f us, loss+backward %.0f us, optimizer %.0f us\n", b - a, c - b, d - c); } } } rep{host_prof, h0, h1, h2, hnow};
     if (phase & 1) {
       if (g_stage_prof) { m->ex->s = s; m->ex->mark_report(); m->ex->mark("start"); }
       // clearing the 109 MB gradient buffer is not on the forward's path: eager two-stream steps do it on the side stream
@@ -1840,10 +1849,12 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
       if (rc) return rc;
       if (side_zero) (void)hipStreamWaitEvent(s, evz1, 0);
       if (g_stage_prof) m->ex->mark("f:decoder");
+      if (host_prof) h1 = hnow();
       rc = model_loss_backward(m, expected, B, L, s);
       if (rc) return rc;
       if (g_stage_prof) m->ex->mark("b:join");
     }
+    if (host_prof) { h2 = hnow(); if (!(phase & 1)) h1 = h2; }
     if (phase & 2) {
       float* am = m->adam_m;
       float* av = m->adam_v;

@@ -221,19 +221,31 @@ static inline int grid_chan(long nchunks, int CC) {
 
 #define BN_REP_MAXC 512  // widest output that uses replicated statistics is 256 channels
 template <typename T>
-__global__ void bn_act_kernel(const T* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv,
+__global__ void bn_act_kernel(const T* __restrict__ y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv,
                               int64_t* nbt, float eps, float mom, float invM, float unbias, float* ss, float* mr,
-                              const T* res, T* z, long nchunks, int C, int act) {
+                              const T* __restrict__ res, T* __restrict__ z, long nchunks, int C, int act) {
   constexpr int CH = TT<T>::CH;
   __shared__ float s_rep[2 * BN_REP_MAXC];
   const int CC = C / CH;
   const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
   const int c0 = (int)(tid % CC) * CH;
+  // the first chunk of the stream is requested BEFORE the statistics: in the late stages a thread has exactly one chunk, and
+  // a request issued behind the finalize (whose stores it may not overtake) made the kernel two far round trips instead of one
+  uint4 yv = zero16(), rv4 = zero16();
+  if (tid < nchunks) {
+    yv = ld16(y + tid * CH);
+    if (res) rv4 = ld16(res + tid * CH);
+  }
+  // the publishing threads also fetch the running statistics now: the read-modify-write at the end is then stores only
+  float rm0[CH], rv0[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) rm0[j] = rv0[j] = 0.f;
+  if (tid < CC && sums) { ldv(rm + c0, rm0, CH); ldv(rv + c0, rv0, CH); }
   // BatchNorm finalize, redone by every thread for its own channel chunk (a handful of loads); the first CC threads
-  // also publish scale/shift + mean/rstd for the backward and update the running statistics
-  float sc[CH], sh[CH];
+  // also publish scale/shift + mean/rstd for the backward and update the running statistics (after the stream)
+  float sc[CH], sh[CH], mean[CH], var[CH];
   {
-    float mean[CH], var[CH], ww[CH], bb[CH];
+    float ww[CH], bb[CH];
     if (sums) {
       if (sums_rep > 1 && C <= BN_REP_MAXC) {
         // replicated statistics (tall narrow outputs): the BLOCK sums the replicas once into LDS.  Every thread doing it for
@@ -263,33 +275,42 @@ __global__ void bn_act_kernel(const T* y, const float* sums, int sums_rep, const
       ldv(rm + c0, mean, CH); ldv(rv + c0, var, CH);
     }
     ldv(w + c0, ww, CH); ldv(b + c0, bb, CH);
-    const bool pub = tid < CC;
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       float rstd = rsqrtf(var[j] + eps);
       sc[j] = ww[j] * rstd;
       sh[j] = bb[j] - mean[j] * sc[j];
-      if (pub) {
-        ss[c0 + j] = sc[j]; ss[C + c0 + j] = sh[j]; mr[c0 + j] = mean[j]; mr[C + c0 + j] = rstd;
-        if (sums) {
-          rm[c0 + j] = (1.f - mom) * rm[c0 + j] + mom * mean[j];
-          rv[c0 + j] = (1.f - mom) * rv[c0 + j] + mom * var[j] * unbias;
-        }
-      }
     }
-    if (tid == 0 && sums && nbt) *nbt += 1;
   }
   for (long i = tid; i < nchunks; i += nth) {
+    const long nx = i + nth;
+    uint4 yn = zero16(), rn = zero16();
+    if (nx < nchunks) {  // next chunk in flight while this one is computed
+      yn = ld16(y + nx * CH);
+      if (res) rn = ld16(res + nx * CH);
+    }
     float v[CH], r[CH];
-    unpack<T>(ld16(y + i * CH), v);
-    if (res) unpack<T>(ld16(res + i * CH), r);
+    unpack<T>(yv, v);
+    if (res) unpack<T>(rv4, r);
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
       float u = act_fwd(v[j] * sc[j] + sh[j], act);
       v[j] = res ? u + r[j] : u;
     }
     st16(z + i * CH, pack<T>(v));
+    yv = yn; rv4 = rn;
   }
+  if (tid < CC) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      ss[c0 + j] = sc[j]; ss[C + c0 + j] = sh[j]; mr[c0 + j] = mean[j]; mr[C + c0 + j] = rsqrtf(var[j] + eps);
+      if (sums) {
+        rm[c0 + j] = (1.f - mom) * rm0[j] + mom * mean[j];
+        rv[c0 + j] = (1.f - mom) * rv0[j] + mom * var[j] * unbias;
+      }
+    }
+  }
+  if (tid == 0 && sums && nbt) *nbt += 1;
 }
 void launch_bn_act(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm,
                    float* rv, int64_t* nbt, float eps, float mom, float* ss, float* mr, const void* res, void* z, long M,
@@ -298,7 +319,8 @@ void launch_bn_act(int dt, const void* y, const float* sums, int sums_rep, const
   DISPATCH_T(dt, {
     long n = M * C / TT<T>::CH;
     int CC = C / TT<T>::CH;
-    int g = grid_chan(n, CC);
+    static const int gdiv = getenv("SATRN_BN_GRIDDIV") ? atoi(getenv("SATRN_BN_GRIDDIV")) : 1;  // tuning hook: chunks per thread
+    int g = grid_chan((n + gdiv - 1) / gdiv, CC);
     while ((long)g * 256 < CC) g *= 2;
     hipLaunchKernelGGL((bn_act_kernel<T>), dim3(g), dim3(256), 0, s, (const T*)y, sums, sums_rep < 1 ? 1 : sums_rep, w, b, rm, rv, nbt, eps, mom,
                        1.0f / (float)M, unbias, ss, mr, (const T*)res, (T*)z, n, C, act);
@@ -350,12 +372,26 @@ void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* ss
 
 // dy = A*g + Bc + Cc*y with g = dz*act'(y*scale+shift): per-channel coefficients computed once per thread
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* dz, const T* y, const float* ss, const float* mr, const float* w,
-                                    const float* red, int red_rep, float invM, long nchunks, int C, int act, T* dy,
-                                    float* dw, float* db, const T* se_gate, const T* se_dpool, int se_hw, float se_scale) {
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* ss, const float* mr, const float* w,
+                                    const float* red, int red_rep, float invM, long nchunks, int C, int act, T* __restrict__ dy,
+                                    float* dw, float* db, const T* __restrict__ se_gate, const T* __restrict__ se_dpool, int se_hw, float se_scale) {
   constexpr int CH = TT<T>::CH;
   const int CC = C / CH;
   const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+  const int c0 = (int)(tid % CC) * CH;
+  // first chunk of the stream requested before the coefficients (see bn_act_kernel): one far round trip instead of two
+  uint4 dzv = zero16(), yv = zero16(), gtv = zero16(), dpv = zero16();
+  if (tid < nchunks) {
+    dzv = ld16(dz + tid * CH);
+    yv = ld16(y + tid * CH);
+    if (se_gate) {
+      const long b = (tid / CC) / se_hw;
+      gtv = ld16(se_gate + b * C + c0);
+      dpv = ld16(se_dpool + b * C + c0);
+    }
+  }
+  float dw0 = 0.f, db0 = 0.f;  // parameter-gradient accumulators fetched now, stored after the stream
+  if (tid < C && dw) { dw0 = dw[tid]; db0 = db[tid]; }
   __shared__ float s_rep[2 * BN_REP_MAXC];
   const bool lds_rep = red_rep > 1 && C <= BN_REP_MAXC;
   if (lds_rep) {  // the block sums the replicas once (see bn_act_kernel)
@@ -367,14 +403,6 @@ __global__ void bn_bwd_apply_kernel(const T* dz, const T* y, const float* ss, co
     }
     __syncthreads();
   }
-  if (tid < C && dw) {  // parameter grads (grad buffers are zeroed per step: accumulate)
-    float a = 0.f, b = 0.f;
-    if (lds_rep) { a = s_rep[C + tid]; b = s_rep[tid]; }
-    else for (int r = 0; r < red_rep; ++r) { a += red[(size_t)r * 2 * C + C + tid]; b += red[(size_t)r * 2 * C + tid]; }
-    dw[tid] += a;
-    db[tid] += b;
-  }
-  const int c0 = (int)(tid % CC) * CH;
   float sc[CH], sh[CH], A[CH], Bc[CH], Cc[CH];
   {
     float mu[CH], rs[CH], ww[CH], r0[CH], r1[CH];
@@ -401,14 +429,24 @@ __global__ void bn_bwd_apply_kernel(const T* dz, const T* y, const float* ss, co
     }
   }
   for (long i = tid; i < nchunks; i += nth) {
+    const long nx = i + nth;
+    uint4 dzn = zero16(), yn = zero16(), gtn = zero16(), dpn = zero16();
+    if (nx < nchunks) {  // next chunk in flight while this one is computed
+      dzn = ld16(dz + nx * CH);
+      yn = ld16(y + nx * CH);
+      if (se_gate) {
+        const long b = (nx / CC) / se_hw;
+        gtn = ld16(se_gate + b * C + c0);
+        dpn = ld16(se_dpool + b * C + c0);
+      }
+    }
     float d[CH], v[CH];
-    unpack<T>(ld16(dz + i * CH), d);
-    unpack<T>(ld16(y + i * CH), v);
+    unpack<T>(dzv, d);
+    unpack<T>(yv, v);
     if (se_gate) {  // squeeze-and-excite backward folded in (see BnBwdRedF)
-      const long b = (i / CC) / se_hw;
       float gt[CH], dp[CH];
-      unpack<T>(ld16(se_gate + b * C + c0), gt);
-      unpack<T>(ld16(se_dpool + b * C + c0), dp);
+      unpack<T>(gtv, gt);
+      unpack<T>(dpv, dp);
 #pragma unroll
       for (int j = 0; j < CH; ++j) d[j] = d[j] * gt[j] + dp[j] * se_scale;
     }
@@ -418,6 +456,14 @@ __global__ void bn_bwd_apply_kernel(const T* dz, const T* y, const float* ss, co
       d[j] = A[j] * g + Bc[j] + Cc[j] * v[j];
     }
     st16(dy + i * CH, pack<T>(d));
+    dzv = dzn; yv = yn; gtv = gtn; dpv = dpn;
+  }
+  if (tid < C && dw) {  // parameter grads (grad buffers are zeroed per step: accumulate); after the stream: nothing waits for them
+    float a = 0.f, b = 0.f;
+    if (lds_rep) { a = s_rep[C + tid]; b = s_rep[tid]; }
+    else for (int r = 0; r < red_rep; ++r) { a += red[(size_t)r * 2 * C + C + tid]; b += red[(size_t)r * 2 * C + tid]; }
+    dw[tid] = dw0 + a;
+    db[tid] = db0 + b;
   }
 }
 void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* ss, const float* mr, const float* w,
@@ -425,7 +471,8 @@ void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* ss,
                          int red_rep, const void* se_gate, const void* se_dpool, int se_hw, int eval_stats) {
   DISPATCH_T(dt, {
     long n = M * C / TT<T>::CH;
-    int g = grid_chan(n, C / TT<T>::CH);
+    static const int gdiv = getenv("SATRN_BN_GRIDDIV") ? atoi(getenv("SATRN_BN_GRIDDIV")) : 1;  // tuning hook: chunks per thread
+    int g = grid_chan((n + gdiv - 1) / gdiv, C / TT<T>::CH);
     while ((long)g * 256 < C) g *= 2;
     // eval statistics: invM = 0 removes the batch-mean / batch-variance terms (Bc = Cc = 0), dw / db stay sum(g*xhat) / sum(g)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(g), dim3(256), 0, s, (const T*)dz, (const T*)y, ss, mr, w, red,

@@ -13,6 +13,22 @@
 
 template <int AM> struct RowInfo { int by, bx, img; bool ok; };
 
+template <int V> struct IC { static constexpr int value = V; };
+
+// Loads the compiler does not count: issued as inline asm, so its s_waitcnt insertion (which falls back to vmcnt(0) in a loop
+// with two register sets in flight) leaves them alone; the kernel waits for them itself with vm_wait<N>() -- N = loads issued
+// AFTER the ones needed, since they return in order -- and vm_tie() makes the compiler order every later use behind that wait.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+DEVI u32x4 gload16_async(const void* ptr) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+  return v;
+}
+template <int N> DEVI void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+DEVI void vm_tie(u32x4& v) { asm volatile("" : "+v"(v)); }
+DEVI uint4 as_uint4(u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); }
+DEVI u32x4 as_u32x4(uint4 v) { u32x4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+
 template <typename T, int BM, int BN, int AM, int KP>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   // KP = 32-deep k-panels staged per barrier: latency-bound small-grid GEMMs (late 1x1 convs, decoder linears) take
@@ -53,8 +69,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     }
   }
 
-  uint4 ra[KP][NA], rb[KP][NB];
-  auto load_tiles = [&](int kt) {
+  // PF register sets: small tiles (the latency-bound late-stage products: 192-1152 workgroups, one or two per CU) keep TWO
+  // k-stages of global loads in flight -- with one, every k iteration cost a full far round trip (M=1536 N=256 K=1536:
+  // 12 iterations, 16-22 us)
+  constexpr int PF = (BM * BN <= 64 * 64 && AM == AM_DENSE) ? 2 : 1;
+  u32x4 ra[PF][KP][NA], rb[PF][KP][NB];
+  auto load_tiles = [&](int kt, auto SET) {
+    constexpr int S = decltype(SET)::value;
 #pragma unroll
     for (int pp = 0; pp < KP; ++pp) {
       const int k0 = (kt * KP + pp) * 32 + cc * CH;
@@ -69,7 +90,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         uint4 v = zero16();
-        if (ri[i].ok && kok) {
+        if constexpr (AM == AM_DENSE) {
+          // branch-free: an always-valid address + a select.  A load under a branch makes the compiler wait for ALL
+          // outstanding loads at every use (vmcnt(0)), which defeats the two-stage prefetch below
+          // (the select itself happens in store_tiles, after the wait: a select right here would be a use of the load)
+          const bool ok = ri[i].ok && kok;
+          const T* src = A + (ok ? (long)ri[i].img * p.lda + k0 : 0L);
+          if constexpr (PF == 2) { ra[S][pp][i] = gload16_async(src); continue; }
+          v = ld16(src);
+        } else if (ri[i].ok && kok) {
           if (AM == AM_DENSE) {
             v = ld16(A + (long)ri[i].img * p.lda + k0);
           } else if (AM == AM_CONV) {
@@ -85,32 +114,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             }
           }
         }
-        ra[pp][i] = v;
+        ra[S][pp][i] = as_u32x4(v);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         int idx = tid + i * 256;
         int row = idx / CPR, n = n0 + row;
         uint4 v = zero16();
-        if (idx < BN * CPR && n < p.N && kok) v = ld16(Bw + (long)n * p.K + k0);
-        rb[pp][i] = v;
+        const bool ok = idx < BN * CPR && n < p.N && kok;
+        if constexpr (AM == AM_DENSE) {
+          const T* src = Bw + (ok ? (long)n * p.K + k0 : 0L);
+          if constexpr (PF == 2) { rb[S][pp][i] = gload16_async(src); continue; }
+          v = ld16(src);
+        } else if (ok) {
+          v = ld16(Bw + (long)n * p.K + k0);
+        }
+        rb[S][pp][i] = as_u32x4(v);
       }
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, auto SET, int kt) {
+    constexpr int S = decltype(SET)::value;
+    if constexpr (PF == 2) {
+#pragma unroll
+      for (int pp = 0; pp < KP; ++pp) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) vm_tie(ra[S][pp][i]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) vm_tie(rb[S][pp][i]);
+      }
+    }
 #pragma unroll
     for (int pp = 0; pp < KP; ++pp) {
       T* la = lds + buf * STAGE + pp * (BM + BN) * 32;
       T* lb = la + BM * 32;
+      const bool kok = (kt * KP + pp) * 32 + cc * CH < p.K;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         int idx = tid + i * 256;
-        if (idx < BM * CPR) st16(la + panel_chunk<T>(idx / CPR, cc), ra[pp][i]);
+        uint4 v = as_uint4(ra[S][pp][i]);
+        if constexpr (AM == AM_DENSE) { if (!(ri[i].ok && kok)) v = zero16(); }  // dense loads are unconditional (see load_tiles)
+        if (idx < BM * CPR) st16(la + panel_chunk<T>(idx / CPR, cc), v);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         int idx = tid + i * 256;
-        if (idx < BN * CPR) st16(lb + panel_chunk<T>(idx / CPR, cc), rb[pp][i]);
+        uint4 v = as_uint4(rb[S][pp][i]);
+        if constexpr (AM == AM_DENSE) { if (!(n0 + idx / CPR < p.N && kok)) v = zero16(); }
+        if (idx < BN * CPR) st16(lb + panel_chunk<T>(idx / CPR, cc), v);
       }
     }
   };
@@ -122,13 +173,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + 32 * KP - 1) / (32 * KP);
-  load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tiles(kt + 1);
+  auto compute = [&](int cur) {
 #pragma unroll
     for (int pp = 0; pp < KP; ++pp) {
       const T* la = lds + cur * STAGE + pp * (BM + BN) * 32;
@@ -143,8 +189,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         for (int i = 0; i < MT; ++i) mma(af[i], bf, acc[i][j]);
       }
     }
-    if (kt + 1 < nk) store_tiles(cur ^ 1);
+  };
+  if constexpr (PF == 1) {
+    load_tiles(0, IC<0>{});
+    store_tiles(0, IC<0>{}, 0);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) load_tiles(kt + 1, IC<0>{});
+      compute(cur);
+      if (kt + 1 < nk) store_tiles(cur ^ 1, IC<0>{}, kt + 1);
+      __syncthreads();
+    }
+  } else {
+    // stage kt+1 is in flight in register set (kt+1)&1 while stage kt is computed; stage kt+2 is requested into the other set
+    // before the compute, so two far round trips overlap
+    constexpr int NL = KP * (NA + NB);  // loads one stage issues per thread
+    load_tiles(0, IC<0>{});
+    if (nk > 1) { load_tiles(1, IC<1>{}); vm_wait<NL>(); } else { vm_wait<0>(); }
+    store_tiles(0, IC<0>{}, 0);
+    __syncthreads();
+    auto step = [&](int kt, auto PAR) {
+      constexpr int P = decltype(PAR)::value;  // == kt & 1
+      const bool more = kt + 2 < nk;
+      if (more) load_tiles(kt + 2, IC<P>{});
+      compute(P);
+      if (kt + 1 < nk) {
+        if (more) vm_wait<NL>(); else vm_wait<0>();  // stage kt+1 has landed; stage kt+2 may still be in flight
+        store_tiles(P ^ 1, IC<(P ^ 1)>{}, kt + 1);
+      }
+      __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      step(kt, IC<0>{});
+      if (kt + 1 < nk) step(kt + 1, IC<1>{});
+    }
   }
 
   // ---- epilogue: C layout col = lane&15, row = (lane>>4)*4 + reg
