@@ -864,6 +864,8 @@ Tensor* op_stem(Exec& e, const float* img, Wt* w, int B, int Cin, int H, int W, 
 }
 
 Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int OW, int pt, int pl, bool want_stats = true) {
+  // first consumer of a BatchNorm output == last writer of its gradient (see op_gemm): its data gradient can also reduce
+  const bool fuse_bnb = g_fuse_bnb && e.rec && e.train && x->bn_y && x->ncons == 0 && !x->bn_has_res && dwconv_fuses_bnb(x->H, x->W, OH, OW, stride, pt, pl);
   used(x);
   const int B = x->B, H = x->H, W = x->W, C = x->C;
   Tensor* y = e.newt((long)B * OH * OW, C, B, OH, OW);
@@ -882,7 +884,7 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
   WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * H * W + (double)B * OH * OW * (y->stats ? 2 : 1)) * C * e.esz());
   LCH(e, launch_dwconv(e.dt, 0, x->p, w->fwd, bias ? bias->p : nullptr, y->p, B, H, W, C, OH, OW, stride, pt, pl, 0, y->stats, e.s));
   if (e.rec)
-    e.tape.push_back([&e, x, y, w, bias, B, H, W, C, OH, OW, stride, pt, pl]() {
+    e.tape.push_back([&e, x, y, w, bias, B, H, W, C, OH, OW, stride, pt, pl, fuse_bnb]() {
       if (!y->g) return;
       float* scr = e.zalloc((size_t)10 * C);
       {
@@ -894,7 +896,12 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
       int beta;
       void* dx = e.grad(x, &beta);
       WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * OH * OW + (double)B * H * W * (beta ? 2 : 1)) * C * e.esz());
-      LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, nullptr, e.s));
+      DwBnb fb{};
+      if (fuse_bnb) {  // x is a BatchNorm output and this is the last writer of its gradient: also produce that BatchNorm's backward sums
+        x->bn_red = e.zalloc((size_t)2 * C); x->bn_red_rep = 1;
+        fb.bn_y = x->bn_y; fb.ss = x->bn_ss; fb.mr = x->bn_mr; fb.act = x->bn_act; fb.red = x->bn_red;
+      }
+      LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, nullptr, e.s, nullptr, nullptr, 0, fuse_bnb ? &fb : nullptr));
     });
   return y;
 }

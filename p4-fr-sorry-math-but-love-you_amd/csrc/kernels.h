@@ -110,7 +110,13 @@ void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int 
 void launch_dwconv(int dt, int mode /*0 fwd,1 dgrad*/, const void* x, const void* wp /*[9][C] as T*/, const float* bias,
                    void* y, int B, int H, int W, int C, int OH, int OW, int stride, int pt, int pl, int beta,
                    float* stats /*optional [2C] zeroed: column sums of y (mode 0)*/, hipStream_t s,
-                   const float* escale = nullptr, const float* eshift = nullptr, int eact = 0 /*inference (mode 0): y = act(conv*escale[c] + eshift[c])*/);
+                   const float* escale = nullptr, const float* eshift = nullptr, int eact = 0 /*inference (mode 0): y = act(conv*escale[c] + eshift[c])*/,
+                   const struct DwBnb* bnb = nullptr /*mode 1: also produce the BatchNorm-backward sums of the BN whose OUTPUT is dx*/);
+// optional for the data gradient of a depthwise convolution whose input was a BatchNorm(+activation) output: the kernel also
+// accumulates red[0..C) += sum g, red[C..2C) += sum g*xhat with g = dx_total * act'(bn_y*scale+shift) (what launch_bn_bwd_reduce
+// computes in a pass of its own).  Only honoured on the stride-1 SAME path outside the deterministic mode: ask dwconv_fuses_bnb().
+struct DwBnb { const void* bn_y; const float* ss; const float* mr; int act; float* red; };
+bool dwconv_fuses_bnb(int H, int W, int OH, int OW, int stride, int pt, int pl);
 void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw /*[C][9] torch layout*/, float* dbias,
                          float* scratch10C /*optional zeroed [10][C]: contiguous atomics + scatter*/, int B, int H, int W,
                          int C, int OH, int OW, int stride, int pt, int pl, hipStream_t s);

@@ -715,11 +715,132 @@ __global__ void dwconv_s1_kernel(const T* x, const T* wp, const float* bias, T* 
   }
 }
 
+// The same stride-1 convolution as a (32 channel chunks x 8 pixel-pair lanes) tile with a column reduction behind it, so the
+// pass that used to follow it on the dependent chain disappears (each such pass is >= 4.5 us of kernel boundary + one far
+// round trip, 30 of each per training step):
+//   RED = 1 (forward):  stats[0..C) += sum y, stats[C..2C) += sum y*y            (was launch_colstats)
+//   RED = 2 (data gradient of a BatchNorm output): red += [sum g, sum g*xhat], g = dx_total * act'(bn_y*scale+shift)
+//                                                                                  (was launch_bn_bwd_reduce)
+template <typename T, bool FLIP, int RED>
+__global__ __launch_bounds__(256) void dwconv_s1_red_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float* bias, T* y, int B, int H,
+                                                            int W, int C, int beta, int ppt, float* red, const T* __restrict__ bn_y,
+                                                            const float* bn_ss, const float* bn_mr, int bn_act) {
+  constexpr int CH = TT<T>::CH;
+  __shared__ float sred[2][8][32 * CH];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int CC = C / CH, W2 = W >> 1;
+  const int cc = blockIdx.y * 32 + tx;
+  const long P = (long)B * H * W2;
+  float s1[CH], s2[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) s1[j] = s2[j] = 0.f;
+  if (cc < CC) {
+    float bsc[CH], bsh[CH], bmu[CH], brs[CH];
+    if (RED == 2) { ldv(bn_ss + cc * CH, bsc, CH); ldv(bn_ss + C + cc * CH, bsh, CH); ldv(bn_mr + cc * CH, bmu, CH); ldv(bn_mr + C + cc * CH, brs, CH); }
+    for (int k = 0; k < ppt; ++k) {
+      const long pix = ((long)blockIdx.x * ppt + k) * 8 + ty;
+      if (pix >= P) break;
+      const int ox = (int)(pix % W2) * 2;
+      const int oy = (int)((pix / W2) % H);
+      const int b = (int)(pix / ((long)W2 * H));
+      const long orow = ((long)b * H + oy) * W + ox;
+      uint4 yq0 = zero16(), yq1 = zero16(), oq0 = zero16(), oq1 = zero16();
+      if (RED == 2) { yq0 = ld16(bn_y + orow * C + cc * CH); yq1 = ld16(bn_y + (orow + 1) * C + cc * CH); }
+      T* o = y + orow * C + cc * CH;
+      if (beta) { oq0 = ld16(o); oq1 = ld16(o + C); }
+      float a0[CH], a1[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) a0[j] = a1[j] = (bias && !FLIP) ? bias[cc * CH + j] : 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int iy = oy + kh - 1;
+        if (iy < 0 || iy >= H) continue;
+        const T* row = x + (((long)b * H + iy) * W) * C + cc * CH;
+        float in[4][CH];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int ix = ox - 1 + t;
+          if (ix >= 0 && ix < W) unpack<T>(ld16(row + (long)ix * C), in[t]);
+          else {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) in[t][j] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          float wv[CH];
+          const int tap = FLIP ? 8 - (kh * 3 + kw) : kh * 3 + kw;
+          unpack<T>(ld16(wp + tap * C + cc * CH), wv);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) { a0[j] += in[kw][j] * wv[j]; a1[j] += in[kw + 1][j] * wv[j]; }
+        }
+      }
+      if (beta) {
+        float o0[CH], o1[CH];
+        unpack<T>(oq0, o0); unpack<T>(oq1, o1);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { a0[j] += o0[j]; a1[j] += o1[j]; }
+      }
+      st16(o, pack<T>(a0));
+      st16(o + C, pack<T>(a1));
+      if (RED == 1) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { s1[j] += a0[j] + a1[j]; s2[j] += a0[j] * a0[j] + a1[j] * a1[j]; }
+      } else {
+        float v0[CH], v1[CH];
+        unpack<T>(yq0, v0); unpack<T>(yq1, v1);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const float g0 = a0[j] * act_bwd(v0[j] * bsc[j] + bsh[j], bn_act), g1 = a1[j] * act_bwd(v1[j] * bsc[j] + bsh[j], bn_act);
+          s1[j] += g0 + g1;
+          s2[j] += g0 * ((v0[j] - bmu[j]) * brs[j]) + g1 * ((v1[j] - bmu[j]) * brs[j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { sred[0][ty][tx * CH + j] = s1[j]; sred[1][ty][tx * CH + j] = s2[j]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * 32 * CH; i += 256) {
+    const int k = i / (32 * CH), c = i - k * 32 * CH;
+    const int col = blockIdx.y * 32 * CH + c;
+    if (col >= C) continue;
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) sum += sred[k][t][c];
+    atomicAdd(red + (long)k * C + col, sum);
+  }
+}
+
+bool dwconv_fuses_bnb(int H, int W, int OH, int OW, int stride, int pt, int pl) {
+  static const bool off = getenv("SATRN_DW_NO_FUSED_RED") != nullptr;
+  return !off && !g_det.on && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && (W & 1) == 0;
+}
+
 void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float* bias, void* y, int B, int H, int W,
                    int C, int OH, int OW, int stride, int pt, int pl, int beta, float* stats, hipStream_t s,
-                   const float* esc, const float* esh, int eact) {
+                   const float* esc, const float* esh, int eact, const DwBnb* bnb) {
   static const bool no_s1 = getenv("SATRN_DW_NO_S1") != nullptr;
   if (!no_s1 && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && (W & 1) == 0) {
+    const bool red_fwd = mode == 0 && stats && !esc && dwconv_fuses_bnb(H, W, OH, OW, stride, pt, pl);
+    const bool red_bwd = mode == 1 && bnb && dwconv_fuses_bnb(H, W, OH, OW, stride, pt, pl);
+    if (red_fwd || red_bwd) {
+      DISPATCH_T(dt, {
+        const int CC = C / TT<T>::CH, gy = (CC + 31) / 32;
+        const long P = (long)B * H * (W / 2);
+        // pixel pairs per thread: as many (<= 8) as still leave ~512 workgroups
+        long ppt = (P * gy) / (8L * 512);
+        ppt = ppt >= 8 ? 8 : (ppt >= 4 ? 4 : (ppt >= 2 ? 2 : 1));
+        const int gx = (int)((P + 8 * ppt - 1) / (8 * ppt));
+        if (red_fwd)
+          hipLaunchKernelGGL((dwconv_s1_red_kernel<T, false, 1>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, (const T*)wp, bias, (T*)y, B, H, W, C,
+                             beta, (int)ppt, stats, (const T*)nullptr, nullptr, nullptr, 0);
+        else
+          hipLaunchKernelGGL((dwconv_s1_red_kernel<T, true, 2>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, (const T*)wp, bias, (T*)y, B, H, W, C,
+                             beta, (int)ppt, bnb->red, (const T*)bnb->bn_y, bnb->ss, bnb->mr, bnb->act);
+      });
+      return;
+    }
     DISPATCH_T(dt, {
       long n2 = (long)B * H * (W / 2) * (C / TT<T>::CH);
       if (mode == 0)
