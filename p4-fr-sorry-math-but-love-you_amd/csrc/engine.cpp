@@ -782,7 +782,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
   return y;
 }
 
-Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res) {
+Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** pool_out = nullptr) {
   const int C = bn->C;
   const long M = y->rows;
   if (y->pend) {
@@ -821,6 +821,12 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res) {
   }
   Tensor* z = e.newt(M, C, y->B, y->H, y->W);
   e.nbytes = (double)M * C * e.esz() * (res ? 3 : 2);
+  if (pool_out && e.train && !res && sums && y->B > 0 && bn_act_pool_ok(M, C, y->H * y->W)) {
+    // a squeeze-and-excite block follows: its average pool is accumulated here (zeroed [B][C] sums)
+    *pool_out = e.zalloc((size_t)y->B * C);
+    LCH(e, launch_bn_act_pool(e.dt, y->p, sums, y->stats ? y->stats_rep : 1, bn->w.p, bn->b.p, bn->rm, bn->rv, bn->nbt, bn->eps, 0.1f, ss, mr, z->p,
+                              *pool_out, M, C, y->H * y->W, act, e.s));
+  } else
   LCH(e, launch_bn_act(e.dt, y->p, sums, y->stats ? y->stats_rep : 1, bn->w.p, bn->b.p, bn->rm, bn->rv, e.train ? bn->nbt : nullptr, bn->eps, 0.1f, ss, mr,
                        res ? res->p : nullptr, z->p, M, C, act, e.s));
   used(y); used(res);
@@ -864,8 +870,6 @@ Tensor* op_stem(Exec& e, const float* img, Wt* w, int B, int Cin, int H, int W, 
 }
 
 Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int OW, int pt, int pl, bool want_stats = true) {
-  // first consumer of a BatchNorm output == last writer of its gradient (see op_gemm): its data gradient can also reduce
-  const bool fuse_bnb = g_fuse_bnb && e.rec && e.train && x->bn_y && x->ncons == 0 && !x->bn_has_res && dwconv_fuses_bnb(x->H, x->W, OH, OW, stride, pt, pl);
   used(x);
   const int B = x->B, H = x->H, W = x->W, C = x->C;
   Tensor* y = e.newt((long)B * OH * OW, C, B, OH, OW);
@@ -884,7 +888,7 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
   WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * H * W + (double)B * OH * OW * (y->stats ? 2 : 1)) * C * e.esz());
   LCH(e, launch_dwconv(e.dt, 0, x->p, w->fwd, bias ? bias->p : nullptr, y->p, B, H, W, C, OH, OW, stride, pt, pl, 0, y->stats, e.s));
   if (e.rec)
-    e.tape.push_back([&e, x, y, w, bias, B, H, W, C, OH, OW, stride, pt, pl, fuse_bnb]() {
+    e.tape.push_back([&e, x, y, w, bias, B, H, W, C, OH, OW, stride, pt, pl]() {
       if (!y->g) return;
       float* scr = e.zalloc((size_t)10 * C);
       {
@@ -896,12 +900,7 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
       int beta;
       void* dx = e.grad(x, &beta);
       WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * OH * OW + (double)B * H * W * (beta ? 2 : 1)) * C * e.esz());
-      DwBnb fb{};
-      if (fuse_bnb) {  // x is a BatchNorm output and this is the last writer of its gradient: also produce that BatchNorm's backward sums
-        x->bn_red = e.zalloc((size_t)2 * C); x->bn_red_rep = 1;
-        fb.bn_y = x->bn_y; fb.ss = x->bn_ss; fb.mr = x->bn_mr; fb.act = x->bn_act; fb.red = x->bn_red;
-      }
-      LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, nullptr, e.s, nullptr, nullptr, 0, fuse_bnb ? &fb : nullptr));
+      LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, nullptr, e.s));
     });
   return y;
 }
@@ -1333,18 +1332,26 @@ Tensor* encoder_layer(Exec& e, Tensor* x, EncLayer* el) {
 }
 
 // squeeze-and-excite: pool + MLP in one kernel, x*gate in a second; backward = dgate reduction, two SE kernels, dx
-Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb) {
+Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr) {
   used(x);
   const int B = x->B, HW = x->H * x->W, C = x->C, S = eb->se;
   float* pooled = (float*)e.alloc((size_t)B * C * 4);
   float* u1 = (float*)e.alloc((size_t)B * S * 4);
   float* s1 = (float*)e.alloc((size_t)B * S * 4);
   Tensor* gate = e.newt(B, C);
-  WORK(e, 4.0 * (double)B * C * S, (double)x->rows * C * e.esz() + (double)C * S * e.esz() * 2);
-  LCH(e, launch_se_fwd(e.dt, x->p, eb->se_r.fwd, eb->se_rb.p, eb->se_e.fwd, eb->se_eb.p, pooled, u1, s1, gate->p, B, HW, C, S, e.s));
   Tensor* y = e.newt(x->rows, C, B, x->H, x->W);
-  WORK(e, 0, (double)x->rows * C * e.esz() * 2);
-  LCH(e, launch_se_scale(e.dt, x->p, gate->p, y->p, B, HW, C, e.s));
+  bool fused = false;
+  if (poolsum) {  // the pool was accumulated by the BatchNorm pass in front: MLP + x*gate in one launch
+    WORK(e, 4.0 * (double)B * C * S, (double)x->rows * C * e.esz() * 2 + (double)C * S * e.esz() * 2);
+    LCH(e, fused = launch_se_mlp_scale(e.dt, x->p, poolsum, eb->se_r.fwd, eb->se_rb.p, eb->se_e.fwd, eb->se_eb.p, pooled, u1, s1, gate->p, y->p, B, HW, C, S, e.s));
+    if (e.dry) fused = e.dt == DT_BF16 && S <= 64 && (S % 8) == 0 && C <= 1536 && (C % 8) == 0;
+  }
+  if (!fused) {
+    WORK(e, 4.0 * (double)B * C * S, (double)x->rows * C * e.esz() + (double)C * S * e.esz() * 2);
+    LCH(e, launch_se_fwd(e.dt, x->p, eb->se_r.fwd, eb->se_rb.p, eb->se_e.fwd, eb->se_eb.p, pooled, u1, s1, gate->p, B, HW, C, S, e.s));
+    WORK(e, 0, (double)x->rows * C * e.esz() * 2);
+    LCH(e, launch_se_scale(e.dt, x->p, gate->p, y->p, B, HW, C, e.s));
+  }
   if (e.rec)
     e.tape.push_back([&e, x, y, gate, eb, pooled, u1, s1, B, HW, C, S]() {
       if (!y->g) return;
@@ -1402,8 +1409,9 @@ Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
   y->B = B; y->H = H; y->W = W;
   Tensor* z = op_bn_act(e, y, &eb->bn1, ACT_SILU, nullptr);
   Tensor* y2 = op_dwconv(e, z, &eb->dw, nullptr, eb->stride, g.OH, g.OW, g.pt, g.pl);
-  Tensor* z2 = op_bn_act(e, y2, &eb->bn2, ACT_SILU, nullptr);
-  Tensor* z3 = op_se(e, z2, eb);
+  float* poolsum = nullptr;
+  Tensor* z2 = op_bn_act(e, y2, &eb->bn2, ACT_SILU, nullptr, &poolsum);
+  Tensor* z3 = op_se(e, z2, eb, poolsum);
   Tensor* y3 = op_gemm(e, z3, &eb->c1, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   y3->B = B; y3->H = g.OH; y3->W = g.OW;
   return op_bn_act(e, y3, &eb->bn3, ACT_NONE, skip);

@@ -110,19 +110,19 @@ void launch_stem_wgrad(int dt, const float* img, const void* dy, float* dw, int 
 void launch_dwconv(int dt, int mode /*0 fwd,1 dgrad*/, const void* x, const void* wp /*[9][C] as T*/, const float* bias,
                    void* y, int B, int H, int W, int C, int OH, int OW, int stride, int pt, int pl, int beta,
                    float* stats /*optional [2C] zeroed: column sums of y (mode 0)*/, hipStream_t s,
-                   const float* escale = nullptr, const float* eshift = nullptr, int eact = 0 /*inference (mode 0): y = act(conv*escale[c] + eshift[c])*/,
-                   const struct DwBnb* bnb = nullptr /*mode 1: also produce the BatchNorm-backward sums of the BN whose OUTPUT is dx*/);
-// optional for the data gradient of a depthwise convolution whose input was a BatchNorm(+activation) output: the kernel also
-// accumulates red[0..C) += sum g, red[C..2C) += sum g*xhat with g = dx_total * act'(bn_y*scale+shift) (what launch_bn_bwd_reduce
-// computes in a pass of its own).  Only honoured on the stride-1 SAME path outside the deterministic mode: ask dwconv_fuses_bnb().
-struct DwBnb { const void* bn_y; const float* ss; const float* mr; int act; float* red; };
-bool dwconv_fuses_bnb(int H, int W, int OH, int OW, int stride, int pt, int pl);
+                   const float* escale = nullptr, const float* eshift = nullptr, int eact = 0 /*inference (mode 0): y = act(conv*escale[c] + eshift[c])*/);
 void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw /*[C][9] torch layout*/, float* dbias,
                          float* scratch10C /*optional zeroed [10][C]: contiguous atomics + scatter*/, int B, int H, int W,
                          int C, int OH, int OW, int stride, int pt, int pl, hipStream_t s);
 void launch_maxpool(int dt, int bwd, const void* x, const void* dy_or_null, void* out, int B, int H, int W, int C,
                     hipStream_t s);
 void launch_pool_hw(int dt, const void* x, void* out /*[B,C] as T*/, int B, int HW, int C, hipStream_t s);
+// BatchNorm(batch statistics)+activation that also accumulates poolsum[b][c] += sum_hw z (zeroed [B][C]); bn_act_pool_ok() says
+// whether the shape / mode takes it (HW % 48 == 0, not the deterministic mode)
+bool bn_act_pool_ok(long M, int C, int HW);
+void launch_bn_act_pool(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv,
+                        int64_t* nbt, float eps, float mom, float* ss, float* mr, void* z, float* poolsum, long M, int C, int HW, int act,
+                        hipStream_t s);
 void launch_se_scale(int dt, const void* x, const void* gate /*[B,C] T*/, void* out, int B, int HW, int C, hipStream_t s);
 // dx (+)= dout*gate + dpool[b,c]/HW ; dgate[b,c] = sum_hw dout*x   (two kernels)
 void launch_se_bwd_gate(int dt, const void* dout, const void* x, void* dgate /*[B,C] T*/, int B, int HW, int C, hipStream_t s);
@@ -186,6 +186,10 @@ void launch_adamw(float* p, const float* g, float* m, float* v, long n, const fl
 
 // fused squeeze-and-excite (kernels_se.hip): W1 [S][C], W2 [C][S] are the fp32 masters
 // W1 [S][C], W2 [C][S]: the packed compute-dtype copies (dt)
+// squeeze-and-excite MLP + x*gate from pool SUMS (launch_bn_act_pool): grid (B, 4 channel groups); false = shape / dtype not
+// taken (the caller then runs launch_se_fwd + launch_se_scale)
+bool launch_se_mlp_scale(int dt, const void* x, const float* poolsum, const void* W1, const float* b1, const void* W2, const float* b2,
+                         float* pooled, float* u1, float* s1, void* gate, void* y, int B, int HW, int C, int S, hipStream_t s);
 void launch_se_fwd(int dt, const void* x, const void* W1, const float* b1, const void* W2, const float* b2, float* pooled,
                    float* u1, float* s1, void* gate, int B, int HW, int C, int S, hipStream_t s);
 void launch_se_bwd(int dt, const void* dgate, const void* gate, const float* u1, const float* s1, const float* pooled,

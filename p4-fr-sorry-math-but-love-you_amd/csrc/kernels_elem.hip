@@ -327,6 +327,102 @@ void launch_bn_act(int dt, const void* y, const float* sums, int sums_rep, const
   });
 }
 
+// BatchNorm(batch statistics) + activation with the squeeze-and-excite average pool of the RESULT accumulated on the way:
+// poolsum[b][c] += sum over the block's rows of z.  Tile form (32 channel chunks x 8 row lanes, 48 rows per workgroup; HW % 48
+// == 0 so a workgroup never straddles two images).  The pool used to be the first phase of the per-image SE kernel, where ONE
+// workgroup pulled a whole image (up to 368 KB) through one CU: 5-8 us of the 17 that kernel took on the dependent chain.
+#define BNP_ROWS 48
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ y, const float* sums, int sums_rep, const float* w, const float* b,
+                                                          float* rm, float* rv, int64_t* nbt, float eps, float mom, float invM, float unbias,
+                                                          float* ss, float* mr, T* __restrict__ z, float* poolsum, int C, int HW, int act) {
+  constexpr int CH = TT<T>::CH;
+  constexpr int RPT = BNP_ROWS / 8;
+  __shared__ float sred[8][32 * CH];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int CC = C / CH, cc = blockIdx.y * 32 + tx, c0 = cc * CH;
+  const long r0 = (long)blockIdx.x * BNP_ROWS;
+  const int img = (int)(r0 / HW);
+  const bool cok = cc < CC;
+  uint4 yv[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) yv[k] = cok ? ld16(y + (r0 + ty + 8 * k) * C + c0) : zero16();
+  const bool pub = blockIdx.x == 0 && ty == 0 && cok;
+  float rm0[CH], rv0[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) rm0[j] = rv0[j] = 0.f;
+  if (pub) { ldv(rm + c0, rm0, CH); ldv(rv + c0, rv0, CH); }
+  float sc[CH], sh[CH], mean[CH], var[CH], acc[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { sc[j] = sh[j] = mean[j] = var[j] = acc[j] = 0.f; }
+  if (cok) {
+    float ww[CH], bb[CH];
+    ldv(sums + c0, mean, CH); ldv(sums + C + c0, var, CH);
+    for (int rp = 1; rp < sums_rep; ++rp) {
+      float t0[CH], t1[CH];
+      ldv(sums + (size_t)rp * 2 * C + c0, t0, CH); ldv(sums + (size_t)rp * 2 * C + C + c0, t1, CH);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { mean[j] += t0[j]; var[j] += t1[j]; }
+    }
+    ldv(w + c0, ww, CH); ldv(b + c0, bb, CH);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      mean[j] *= invM; var[j] = fmaxf(var[j] * invM - mean[j] * mean[j], 0.f);
+      const float rstd = rsqrtf(var[j] + eps);
+      sc[j] = ww[j] * rstd;
+      sh[j] = bb[j] - mean[j] * sc[j];
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      float v[CH];
+      unpack<T>(yv[k], v);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) v[j] = act_fwd(v[j] * sc[j] + sh[j], act);
+      const uint4 o = pack<T>(v);
+      st16(z + (r0 + ty + 8 * k) * C + c0, o);
+      float r[CH];
+      unpack<T>(o, r);  // the pool averages the STORED values (what the separate pooling pass read)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[j] += r[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) sred[ty][tx * CH + j] = acc[j];
+  __syncthreads();
+  {
+    const int c = threadIdx.x, col = blockIdx.y * 32 * CH + c;
+    if (c < 32 * CH && col < C) {
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) sum += sred[t][c];
+      atomicAdd(poolsum + (long)img * C + col, sum);
+    }
+  }
+  if (pub) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      ss[c0 + j] = sc[j]; ss[C + c0 + j] = sh[j]; mr[c0 + j] = mean[j]; mr[C + c0 + j] = rsqrtf(var[j] + eps);
+      rm[c0 + j] = (1.f - mom) * rm0[j] + mom * mean[j];
+      rv[c0 + j] = (1.f - mom) * rv0[j] + mom * var[j] * unbias;
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+}
+bool bn_act_pool_ok(long M, int C, int HW) {
+  static const bool off = getenv("SATRN_NO_FUSED_POOL") != nullptr;
+  return !off && !g_det.on && HW > 0 && (HW % BNP_ROWS) == 0 && (M % HW) == 0;
+}
+void launch_bn_act_pool(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv,
+                        int64_t* nbt, float eps, float mom, float* ss, float* mr, void* z, float* poolsum, long M, int C, int HW, int act,
+                        hipStream_t s) {
+  float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
+  DISPATCH_T(dt, {
+    const int CC = C / TT<T>::CH;
+    hipLaunchKernelGGL((bn_act_pool_kernel<T>), dim3((int)(M / BNP_ROWS), (CC + 31) / 32), dim3(256), 0, s, (const T*)y, sums, sums_rep < 1 ? 1 : sums_rep,
+                       w, b, rm, rv, nbt, eps, mom, 1.0f / (float)M, unbias, ss, mr, (T*)z, poolsum, C, HW, act);
+  });
+}
+
 template <typename T> struct BnBwdRedF {
   const T* dz; const T* y; const float* ss; const float* mr; int C; int act;
   // optional squeeze-and-excite backward folded in: the gradient of the BN output is dz*gate[b] + dpool[b]*scale
@@ -718,13 +814,13 @@ __global__ void dwconv_s1_kernel(const T* x, const T* wp, const float* bias, T* 
 // The same stride-1 convolution as a (32 channel chunks x 8 pixel-pair lanes) tile with a column reduction behind it, so the
 // pass that used to follow it on the dependent chain disappears (each such pass is >= 4.5 us of kernel boundary + one far
 // round trip, 30 of each per training step):
-//   RED = 1 (forward):  stats[0..C) += sum y, stats[C..2C) += sum y*y            (was launch_colstats)
-//   RED = 2 (data gradient of a BatchNorm output): red += [sum g, sum g*xhat], g = dx_total * act'(bn_y*scale+shift)
-//                                                                                  (was launch_bn_bwd_reduce)
-template <typename T, bool FLIP, int RED>
+//   stats[0..C) += sum y, stats[C..2C) += sum y*y            (was launch_colstats behind the convolution)
+// (The same treatment of the data gradient -- the BatchNorm-backward sums of its input reduced in the epilogue -- was built and
+// measured in round 2: 206 VGPRs, two waves per SIMD, 20 / 37 us against 19 / 30 for the two separate kernels.  Not kept.)
+template <typename T>
 __global__ __launch_bounds__(256) void dwconv_s1_red_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float* bias, T* y, int B, int H,
-                                                            int W, int C, int beta, int ppt, float* red, const T* __restrict__ bn_y,
-                                                            const float* bn_ss, const float* bn_mr, int bn_act) {
+                                                            int W, int C, int beta, int ppt, float* red) {
+  constexpr bool FLIP = false;
   constexpr int CH = TT<T>::CH;
   __shared__ float sred[2][8][32 * CH];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -735,8 +831,6 @@ __global__ __launch_bounds__(256) void dwconv_s1_red_kernel(const T* __restrict_
 #pragma unroll
   for (int j = 0; j < CH; ++j) s1[j] = s2[j] = 0.f;
   if (cc < CC) {
-    float bsc[CH], bsh[CH], bmu[CH], brs[CH];
-    if (RED == 2) { ldv(bn_ss + cc * CH, bsc, CH); ldv(bn_ss + C + cc * CH, bsh, CH); ldv(bn_mr + cc * CH, bmu, CH); ldv(bn_mr + C + cc * CH, brs, CH); }
     for (int k = 0; k < ppt; ++k) {
       const long pix = ((long)blockIdx.x * ppt + k) * 8 + ty;
       if (pix >= P) break;
@@ -744,8 +838,7 @@ __global__ __launch_bounds__(256) void dwconv_s1_red_kernel(const T* __restrict_
       const int oy = (int)((pix / W2) % H);
       const int b = (int)(pix / ((long)W2 * H));
       const long orow = ((long)b * H + oy) * W + ox;
-      uint4 yq0 = zero16(), yq1 = zero16(), oq0 = zero16(), oq1 = zero16();
-      if (RED == 2) { yq0 = ld16(bn_y + orow * C + cc * CH); yq1 = ld16(bn_y + (orow + 1) * C + cc * CH); }
+      uint4 oq0 = zero16(), oq1 = zero16();
       T* o = y + orow * C + cc * CH;
       if (beta) { oq0 = ld16(o); oq1 = ld16(o + C); }
       float a0[CH], a1[CH];
@@ -783,19 +876,8 @@ __global__ __launch_bounds__(256) void dwconv_s1_red_kernel(const T* __restrict_
       }
       st16(o, pack<T>(a0));
       st16(o + C, pack<T>(a1));
-      if (RED == 1) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) { s1[j] += a0[j] + a1[j]; s2[j] += a0[j] * a0[j] + a1[j] * a1[j]; }
-      } else {
-        float v0[CH], v1[CH];
-        unpack<T>(yq0, v0); unpack<T>(yq1, v1);
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-          const float g0 = a0[j] * act_bwd(v0[j] * bsc[j] + bsh[j], bn_act), g1 = a1[j] * act_bwd(v1[j] * bsc[j] + bsh[j], bn_act);
-          s1[j] += g0 + g1;
-          s2[j] += g0 * ((v0[j] - bmu[j]) * brs[j]) + g1 * ((v1[j] - bmu[j]) * brs[j]);
-        }
-      }
+      for (int j = 0; j < CH; ++j) { s1[j] += a0[j] + a1[j]; s2[j] += a0[j] * a0[j] + a1[j] * a1[j]; }
     }
   }
 #pragma unroll
@@ -812,19 +894,17 @@ __global__ __launch_bounds__(256) void dwconv_s1_red_kernel(const T* __restrict_
   }
 }
 
-bool dwconv_fuses_bnb(int H, int W, int OH, int OW, int stride, int pt, int pl) {
+static bool dwconv_fuses_stats(int H, int W, int OH, int OW, int stride, int pt, int pl) {
   static const bool off = getenv("SATRN_DW_NO_FUSED_RED") != nullptr;
   return !off && !g_det.on && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && (W & 1) == 0;
 }
 
 void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float* bias, void* y, int B, int H, int W,
                    int C, int OH, int OW, int stride, int pt, int pl, int beta, float* stats, hipStream_t s,
-                   const float* esc, const float* esh, int eact, const DwBnb* bnb) {
+                   const float* esc, const float* esh, int eact) {
   static const bool no_s1 = getenv("SATRN_DW_NO_S1") != nullptr;
   if (!no_s1 && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && (W & 1) == 0) {
-    const bool red_fwd = mode == 0 && stats && !esc && dwconv_fuses_bnb(H, W, OH, OW, stride, pt, pl);
-    const bool red_bwd = mode == 1 && bnb && dwconv_fuses_bnb(H, W, OH, OW, stride, pt, pl);
-    if (red_fwd || red_bwd) {
+    if (mode == 0 && stats && !esc && dwconv_fuses_stats(H, W, OH, OW, stride, pt, pl)) {
       DISPATCH_T(dt, {
         const int CC = C / TT<T>::CH, gy = (CC + 31) / 32;
         const long P = (long)B * H * (W / 2);
@@ -832,12 +912,8 @@ void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float*
         long ppt = (P * gy) / (8L * 512);
         ppt = ppt >= 8 ? 8 : (ppt >= 4 ? 4 : (ppt >= 2 ? 2 : 1));
         const int gx = (int)((P + 8 * ppt - 1) / (8 * ppt));
-        if (red_fwd)
-          hipLaunchKernelGGL((dwconv_s1_red_kernel<T, false, 1>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, (const T*)wp, bias, (T*)y, B, H, W, C,
-                             beta, (int)ppt, stats, (const T*)nullptr, nullptr, nullptr, 0);
-        else
-          hipLaunchKernelGGL((dwconv_s1_red_kernel<T, true, 2>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, (const T*)wp, bias, (T*)y, B, H, W, C,
-                             beta, (int)ppt, bnb->red, (const T*)bnb->bn_y, bnb->ss, bnb->mr, bnb->act);
+        hipLaunchKernelGGL((dwconv_s1_red_kernel<T>), dim3(gx, gy), dim3(256), 0, s, (const T*)x, (const T*)wp, bias, (T*)y, B, H, W, C, beta, (int)ppt,
+                           stats);
       });
       return;
     }

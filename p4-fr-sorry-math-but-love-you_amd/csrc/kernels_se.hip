@@ -128,6 +128,115 @@ __global__ __launch_bounds__(1024) void se_fwd_kernel(const T* x, const T* W1, c
   }
 }
 
+// ---- forward from pool sums (bf16, S <= 64, C <= 1536): grid (B, SE_G).  Every workgroup computes the whole hidden layer of
+// its image (the reduce matrix is requested into registers at the start: 12 x 16 bytes per thread) and then the gate and
+// x*gate of ITS quarter of the channels, so the image is scaled by four CUs and never pooled by one.
+#define SE_G 4
+__global__ __launch_bounds__(1024) void se_mlp_scale_kernel(const bf16_t* __restrict__ x, const float* __restrict__ poolsum, const bf16_t* __restrict__ W1,
+                                                            const float* b1, const bf16_t* __restrict__ W2, const float* b2, float* pooled, float* u1,
+                                                            float* s1, bf16_t* gate, bf16_t* __restrict__ y, int HW, int C, int S) {
+  constexpr int CH = 8;
+  extern __shared__ float sm[];  // p[C] | h[64] | g[C / SE_G (+pad)]
+  float* p = sm;
+  float* h = sm + C;
+  float* g = h + 64;
+  const int b = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int CC = C / CH;
+  const int cs = ((CC + SE_G - 1) / SE_G) * CH;  // channels per group (multiple of 8)
+  const int cbeg = grp * cs, cend = min(C, cbeg + cs);
+  uint4 raw[4][3];
+  float bj[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int j = wave + 16 * u;
+    bj[u] = j < S ? b1[j] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int c = (lane + q * 64) * CH;
+      raw[u][q] = (c < C && j < S) ? ld16(W1 + (long)j * C + c) : zero16();
+    }
+  }
+  // expand rows of this thread's channel of the group
+  uint4 raw2[8];
+  {
+    const int c = cbeg + tid < cend ? cbeg + tid : cbeg;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) raw2[u] = ld16(W2 + (long)c * S + (u * CH < S ? u * CH : 0));
+  }
+  const float inv = 1.0f / (float)HW;
+  for (int c = tid; c < C; c += 1024) {
+    const float m = poolsum[(long)b * C + c] * inv;
+    p[c] = m;
+    if (grp == 0) pooled[(long)b * C + c] = m;
+  }
+  __syncthreads();
+  {
+    float accu[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int c = (lane + q * 64) * CH;
+      if (c < C) {
+        float pv[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) pv[e] = p[c + e];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float wv[CH];
+          unpack<bf16_t>(raw[u][q], wv);
+#pragma unroll
+          for (int e = 0; e < CH; ++e) accu[u] += wv[e] * pv[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = wave + 16 * u;
+      const float a = wave_sum(accu[u]);
+      if (lane == 0 && j < S) {
+        const float uu = a + bj[u];
+        const float sv = uu * sigmoidf_(uu);
+        h[j] = sv;
+        if (grp == 0) { u1[(long)b * S + j] = uu; s1[(long)b * S + j] = sv; }
+      }
+    }
+  }
+  __syncthreads();
+  if (cbeg + tid < cend) {
+    const int c = cbeg + tid;
+    float acc = b2[c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u * CH < S) {
+        float wv[CH];
+        unpack<bf16_t>(raw2[u], wv);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc += wv[e] * h[u * CH + e];
+      }
+    }
+    const bf16_t gb = from_f<bf16_t>(sigmoidf_(acc));
+    gate[(long)b * C + c] = gb;
+    g[tid] = to_f(gb);  // the product uses the stored (rounded) gate, like the separate x*gate pass
+  }
+  __syncthreads();
+  {
+    const int ncc = (cend - cbeg) / CH;  // chunks per row in this group
+    if (ncc > 0) {
+      const bf16_t* xb = x + (long)b * HW * C + cbeg;
+      bf16_t* yb = y + (long)b * HW * C + cbeg;
+      const int n = HW * ncc;
+#pragma unroll 4
+      for (int i = tid; i < n; i += 1024) {
+        const int r = i / ncc, c = (i - r * ncc) * CH;
+        float v[CH];
+        unpack<bf16_t>(ld16(xb + (long)r * C + c), v);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) v[e] *= g[c + e];
+        st16(yb + (long)r * C + c, pack<bf16_t>(v));
+      }
+    }
+  }
+}
+
 // ---- backward A (per image): dz2 = dgate*gate*(1-gate); ds1 = W2^T dz2; du1 = ds1*silu'(u1); dpooled = W1^T du1
 template <typename T>
 __global__ __launch_bounds__(1024) void se_bwd_a_kernel(const T* dgate, const T* gate, const float* u1, const T* W1,
@@ -292,6 +401,16 @@ void launch_se_fwd(int dt, const void* x, const void* W1, const float* b1, const
     hipLaunchKernelGGL((se_fwd_kernel<bf16_t>), dim3(B), dim3(1024), sh, s, (const bf16_t*)x, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, pooled, u1, s1, (bf16_t*)gate, HW, C, S);
   else
     hipLaunchKernelGGL((se_fwd_kernel<float>), dim3(B), dim3(1024), sh, s, (const float*)x, (const float*)W1, b1, (const float*)W2, b2, pooled, u1, s1, (float*)gate, HW, C, S);
+}
+bool launch_se_mlp_scale(int dt, const void* x, const float* poolsum, const void* W1, const float* b1, const void* W2, const float* b2,
+                         float* pooled, float* u1, float* s1, void* gate, void* y, int B, int HW, int C, int S, hipStream_t s) {
+  // a group's channels must fit one thread each (<= 1024) and the reduce matrix 12 chunks per thread (C <= 1536)
+  if (dt != DT_BF16 || S > 64 || (S % 8) != 0 || C > 1536 || (C % 8) != 0) return false;
+  const int cs = (((C / 8) + SE_G - 1) / SE_G) * 8;
+  size_t sh = (size_t)(C + 64 + cs) * sizeof(float);
+  hipLaunchKernelGGL(se_mlp_scale_kernel, dim3(B, SE_G), dim3(1024), sh, s, (const bf16_t*)x, poolsum, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2,
+                     pooled, u1, s1, (bf16_t*)gate, (bf16_t*)y, HW, C, S);
+  return true;
 }
 void launch_se_bwd(int dt, const void* dgate, const void* gate, const float* u1, const float* s1, const float* pooled,
                    const void* W1, const void* W2, float* dz2, float* du1, void* dpooled, float* dW1, float* db1, float* dW2,
