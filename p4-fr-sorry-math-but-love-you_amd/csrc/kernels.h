@@ -217,6 +217,7 @@ int launch_decode_greedy(int dt, const DecodeP& p, hipStream_t s);
 // pipelined weight-stationary greedy decoder (kernels_decode.hip): one persistent workgroup per ROLE (a slice of the decoder's
 // weights resident in LDS), images flow through the roles over tagged 8-byte granule mailboxes
 struct PipeRole { int type, layer, sub, img0, img1, istep /*serves images img0, img0 + istep, ... < img1*/, N, K, Ntot, row0, kp0; const void* w; const float* bias; const float* lnw; const float* lnb;
+                  const void* w2; int N2, K2, Ntot2, row02, kp02; /*second LDS-resident matrix (feed-forward role: the K-slab of the output projection)*/
                   const float* pre_bias; const float* pre_lnw; const float* pre_lnb; /*non-null: recompute the previous layer's FFN combine + LayerNorm from its partials*/ };
 struct PipeP {
   DecLayerW L[4];

@@ -518,8 +518,11 @@ __global__ __launch_bounds__(DEC_THREADS) void beam_search_kernel(DecodeP p, Bea
 typedef __attribute__((address_space(1))) unsigned long long gu64_t;
 typedef __attribute__((address_space(1))) int gi32_t;
 
-enum { PR_Q = 0, PR_KA, PR_VA, PR_KB, PR_VB, PR_ATT, PR_O, PR_Q2, PR_XATT, PR_O2, PR_F0, PR_F1, PR_L3, PR_GEN, PR_NTYPES };
-enum { PE_Q = 0, PE_KIN, PE_VIN, PE_KOUT, PE_VOUT, PE_ATT, PE_T1, PE_Q2, PE_ATT2, PE_T2, PE_F0 /*4*/, PE_P = PE_F0 + 4 /*4*/, PE_PER_LAYER = PE_P + 4 };
+enum { PR_Q = 0, PR_KA, PR_VA, PR_KB, PR_VB, PR_ATT, PR_O, PR_Q2, PR_XATT, PR_O2, PR_FF, PR_L3, PR_GEN, PR_NTYPES };
+// edges of one layer.  Roles that receive several vectors receive runs of CONSECUTIVE edges (see RecvPlan): Q|KIN|VIN, KOUT|VOUT,
+// T2|P0..P7
+#define PIPE_NFF 8   // feed-forward slabs: F / PIPE_NFF hidden units each
+enum { PE_Q = 0, PE_KIN, PE_VIN, PE_KOUT, PE_VOUT, PE_ATT, PE_T1, PE_Q2, PE_ATT2, PE_T2, PE_P /*PIPE_NFF partial sums*/, PE_PER_LAYER = PE_P + PIPE_NFF };
 
 struct PipeCtx {
   const PipeP* p;
@@ -562,34 +565,29 @@ DEVI void add_layernorm_lds(float* v, const float* r, const float* w, const floa
   LDS_BARRIER();
 }
 
-// A role's inputs for one (step, image): up to five D-wide vectors, each with its own expected tag.  All of them are requested at
-// once (thread tid polls granule tid & 255 of vector tid >> 8; the fifth vector is taken by the first 256 threads as well) and
-// the request for the NEXT (step, image) is issued before the current one is computed, so in steady state a role never waits a
-// memory round trip for data that has already arrived.
-// (scalar fields, selected with compare chains: a runtime-indexed array inside the struct would live in scratch memory and
-// every access would be a memory round trip counted in vmcnt -- measured: +1.8 us per item)
-struct RecvPlan { int n; int e0, e1, e2, e3, e4; unsigned g0, g1, g2, g3, g4; };
-struct RecvRegs { unsigned long long v0, v1, v2; };
-DEVI void plan_put(RecvPlan& pl, int e, unsigned g) {
-  switch (pl.n) {
-    case 0: pl.e0 = e; pl.g0 = g; break;
-    case 1: pl.e1 = e; pl.g1 = g; break;
-    case 2: pl.e2 = e; pl.g2 = g; break;
-    case 3: pl.e3 = e; pl.g3 = g; break;
-    default: pl.e4 = e; pl.g4 = g; break;
-  }
-  ++pl.n;
+// A role's inputs for one (step, image): up to ten D-wide vectors in at most two runs of consecutive edges, each run with its
+// own expected tag.  All of them are requested at once (thread tid polls granule tid & 255 of vectors tid >> 8, +2, +4, ...) and the
+// request for the NEXT (step, image) is issued right after the current one is computed, so in steady state a role never waits
+// a memory round trip for data that has already arrived.
+// (scalar fields only: a runtime-indexed array inside the struct would live in scratch memory and every access would be a memory
+// round trip counted in vmcnt -- measured: +1.8 us per item)
+struct RecvPlan { int n0, b0, n1, b1; unsigned g0, g1; };
+struct RecvRegs { unsigned long long v[5]; };  // indexed with compile-time constants only
+DEVI void plan_put(RecvPlan& pl, int e, unsigned g, int cnt = 1) {
+  if (pl.n0 == 0) { pl.b0 = e; pl.n0 = cnt; pl.g0 = g; }
+  else { pl.b1 = e; pl.n1 = cnt; pl.g1 = g; }
 }
-DEVI int plan_edge(const RecvPlan& pl, int k) { return k == 0 ? pl.e0 : (k == 1 ? pl.e1 : (k == 2 ? pl.e2 : (k == 3 ? pl.e3 : pl.e4))); }
-DEVI unsigned plan_tag(const RecvPlan& pl, int k) { return k == 0 ? pl.g0 : (k == 1 ? pl.g1 : (k == 2 ? pl.g2 : (k == 3 ? pl.g3 : pl.g4))); }
+DEVI int plan_edge(const RecvPlan& pl, int k) { return k < pl.n0 ? pl.b0 + k : pl.b1 + (k - pl.n0); }
+DEVI unsigned plan_tag(const RecvPlan& pl, int k) { return k < pl.n0 ? pl.g0 : pl.g1; }
 
-// thread -> granule mapping with 512 threads and D = 256: threads 0..255 take vectors 0, 2, 4, threads 256..511 vectors 1, 3
+// thread -> granule mapping with 512 threads and D = 256: threads 0..255 take vectors 0, 2, 4, .., threads 256..511 vectors 1, 3, ..
 DEVI void pipe_issue(const PipeCtx& c, const RecvPlan& pl, int img, RecvRegs& rr, int D) {
-  const int tid = threadIdx.x, k = tid / D, i = tid - k * D;
-  rr.v0 = 0; rr.v1 = 0; rr.v2 = 0;
-  if (k < pl.n) rr.v0 = __hip_atomic_load(pipe_box(c, plan_edge(pl, k), img) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (k + 2 < pl.n) rr.v1 = __hip_atomic_load(pipe_box(c, plan_edge(pl, k + 2), img) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (k + 4 < pl.n) rr.v2 = __hip_atomic_load(pipe_box(c, plan_edge(pl, k + 4), img) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int tid = threadIdx.x, k = tid / D, i = tid - k * D, n = pl.n0 + pl.n1;
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    rr.v[m] = 0;
+    if (k + 2 * m < n) rr.v[m] = __hip_atomic_load(pipe_box(c, plan_edge(pl, k + 2 * m), img) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 DEVI bool pipe_wait1(const PipeCtx& c, gu64_t* g, unsigned want, unsigned long long& v, unsigned& spins) {
   while ((unsigned)(v >> 32) != want) {
@@ -604,28 +602,25 @@ DEVI bool pipe_wait1(const PipeCtx& c, gu64_t* g, unsigned want, unsigned long l
 // spin until every requested granule carries its tag, then put the payloads into in[k][i] (LDS); false = gave up
 template <typename T>
 DEVI bool pipe_complete(const PipeCtx& c, const RecvPlan& pl, int img, RecvRegs& rr, float* in, T* xT, int D) {
-  const int tid = threadIdx.x, k = tid / D, i = tid - k * D;
+  const int tid = threadIdx.x, k = tid / D, i = tid - k * D, n = pl.n0 + pl.n1;
   unsigned spins = 0;
-  if (k < pl.n) {
-    pipe_wait1(c, pipe_box(c, plan_edge(pl, k), img) + i, plan_tag(pl, k), rr.v0, spins);
-    const float fv = __uint_as_float((unsigned)rr.v0);
-    in[k * D + i] = fv;
-    if (k == 0) xT[i] = from_f<T>(fv);   // the first vector is the matrix-vector input: its compute-dtype copy, no extra pass
-  }
-  if (k + 2 < pl.n) {
-    pipe_wait1(c, pipe_box(c, plan_edge(pl, k + 2), img) + i, plan_tag(pl, k + 2), rr.v1, spins);
-    in[(k + 2) * D + i] = __uint_as_float((unsigned)rr.v1);
-  }
-  if (k + 4 < pl.n) {
-    pipe_wait1(c, pipe_box(c, plan_edge(pl, k + 4), img) + i, plan_tag(pl, k + 4), rr.v2, spins);
-    in[(k + 4) * D + i] = __uint_as_float((unsigned)rr.v2);
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const int v = k + 2 * m;
+    if (v < n) {
+      pipe_wait1(c, pipe_box(c, plan_edge(pl, v), img) + i, plan_tag(pl, v), rr.v[m], spins);
+      const float fv = __uint_as_float((unsigned)rr.v[m]);
+      in[v * D + i] = fv;
+      if (v == 0) xT[i] = from_f<T>(fv);   // the first vector is the matrix-vector input: its compute-dtype copy, no extra pass
+    }
   }
   LDS_BARRIER();
   return *c.s_fail == 0;
 }
-DEVI void pipe_send(const PipeCtx& c, int edge, int img, unsigned tag, const float* src, int n) {
+// (off: first granule written -- the two half-head attention roles of an image fill the two halves of ONE mailbox vector)
+DEVI void pipe_send(const PipeCtx& c, int edge, int img, unsigned tag, const float* src, int n, int off = 0) {
   const int tid = threadIdx.x;
-  if (tid < n) __hip_atomic_store(pipe_box(c, edge, img) + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(src[tid]), __ATOMIC_RELAXED,
+  if (tid < n) __hip_atomic_store(pipe_box(c, edge, img) + off + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(src[tid]), __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -643,10 +638,12 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
   c.t_end = (long long)wall_clock64() + (long long)p.timeout_ticks;
   // ---- LDS: [weights image (role.N x role.K elements, k-panel-major)] [f32 scratch]
   T* wl = reinterpret_cast<T*>(sm);
-  const size_t wbytes = ((size_t)role.N * role.K * sizeof(T) + 255) & ~(size_t)255;
+  const size_t w1bytes = ((size_t)role.N * role.K * sizeof(T) + 255) & ~(size_t)255;
+  T* wl2 = reinterpret_cast<T*>(sm + w1bytes / 4);   // second matrix (feed-forward role)
+  const size_t wbytes = w1bytes + (((size_t)role.N2 * role.K2 * sizeof(T) + 255) & ~(size_t)255);
   float* f = sm + wbytes / 4;
-  float* in = f;             // [5][D] received vectors ([2][D] for the query-projection + cross-attention role: its LDS is full)
-  float* y = in + (role.type == PR_Q2 ? 2 : 5) * D;  // [D] outputs (every role of the pipeline produces <= D values)
+  float* in = f;             // [10][D] received vectors ([2][D] for the query-projection + cross-attention role)
+  float* y = in + (role.type == PR_Q2 ? 2 : 10) * D;  // [D] outputs (every role of the pipeline produces <= D values)
   float* lp = y + D;         // [6][D] parameters, loaded once: bias | LayerNorm w | b | the PREVIOUS layer's FFN bias | LayerNorm w | b
   float* red = lp + 6 * D;   // [2*(PIPE_THREADS / 64)]
   T* xT = reinterpret_cast<T*>(red + 2 * (PIPE_THREADS / 64));  // [D] compute-dtype copy of the matrix-vector input (an f32 slot per element)
@@ -663,6 +660,17 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
       const long pr = i / cpr;
       const int row = (int)(pr % role.N), kp = (int)(pr / role.N);
       st16(wl + ((long)kp * role.N + row) * 32 + ch * TT<T>::CH, ld16(src + ((long)(kp + role.kp0) * role.Ntot + role.row0 + row) * 32 + ch * TT<T>::CH));
+    }
+  }
+  if (role.w2) {
+    const T* src = (const T*)role.w2;
+    const int cpr = 32 / TT<T>::CH;
+    const long nch = (long)(role.K2 / 32) * role.N2 * cpr;
+    for (long i = tid; i < nch; i += PIPE_THREADS) {
+      const int ch = (int)(i % cpr);
+      const long pr = i / cpr;
+      const int row = (int)(pr % role.N2), kp = (int)(pr / role.N2);
+      st16(wl2 + ((long)kp * role.N2 + row) * 32 + ch * TT<T>::CH, ld16(src + ((long)(kp + role.kp02) * role.Ntot2 + role.row02 + row) * 32 + ch * TT<T>::CH));
     }
   }
   for (int i = tid; i < D; i += PIPE_THREADS) {
@@ -687,29 +695,27 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
   // inputs of (step t) for this role type
   auto plan = [&](int t) {
     RecvPlan pl;
-    pl.n = 0; pl.e0 = pl.e1 = pl.e2 = pl.e3 = pl.e4 = 0; pl.g0 = pl.g1 = pl.g2 = pl.g3 = pl.g4 = 0;
-    auto put = [&](int e, unsigned tg) { plan_put(pl, e, tg); };
+    pl.n0 = pl.n1 = pl.b0 = pl.b1 = 0; pl.g0 = pl.g1 = 0;
     const unsigned tg = (unsigned)t + 1u;
     switch (role.type) {
       case PR_Q: case PR_KA: case PR_VA:
-        if (pre) { for (int j = 0; j < 4; ++j) put(pipe_edge(p, l - 1, PE_P + j), tg); put(pipe_edge(p, l - 1, PE_T2), tg); }
-        else put(pipe_edge_x(l), tg);
+        if (pre) plan_put(pl, pipe_edge(p, l - 1, PE_T2), tg, 1 + PIPE_NFF);   // t2 | the feed-forward partial sums
+        else plan_put(pl, pipe_edge_x(l), tg);
         break;
-      case PR_KB: case PR_VB: put(pipe_edge_x(l + 1), tg); break;
+      case PR_KB: case PR_VB: plan_put(pl, pipe_edge_x(l + 1), tg); break;
       case PR_ATT:
-        put(pipe_edge(p, l, PE_Q), tg); put(pipe_edge(p, l, PE_KIN), tg); put(pipe_edge(p, l, PE_VIN), tg);
-        if (t > 0) { put(pipe_edge(p, l, PE_KOUT), (unsigned)t); put(pipe_edge(p, l, PE_VOUT), (unsigned)t); }
+        plan_put(pl, pipe_edge(p, l, PE_Q), tg, 3);                              // q | k(in) | v(in)
+        if (t > 0) plan_put(pl, pipe_edge(p, l, PE_KOUT), (unsigned)t, 2);      // k(out) | v(out) of the previous step
         break;
-      case PR_O: put(pipe_edge(p, l, PE_ATT), tg); put(pipe_edge_x(l), tg); break;
-      case PR_Q2: put(pipe_edge(p, l, PE_T1), tg); break;
-      case PR_XATT: put(pipe_edge(p, l, PE_Q2), tg); break;  // (only when the cross-attention is not folded into the Q2 role)
-      case PR_O2: put(pipe_edge(p, l, PE_ATT2), tg); put(pipe_edge(p, l, PE_T1), tg); break;
-      case PR_F0: put(pipe_edge(p, l, PE_T2), tg); break;
-      case PR_F1: put(pipe_edge(p, l, PE_F0 + role.sub), tg); break;
-      case PR_L3: for (int j = 0; j < 4; ++j) put(pipe_edge(p, l, PE_P + j), tg); put(pipe_edge(p, l, PE_T2), tg); break;
+      case PR_O: plan_put(pl, pipe_edge(p, l, PE_ATT), tg); plan_put(pl, pipe_edge_x(l), tg); break;
+      case PR_Q2: plan_put(pl, pipe_edge(p, l, PE_T1), tg); break;
+      case PR_XATT: plan_put(pl, pipe_edge(p, l, PE_Q2), tg); break;  // (only when the cross-attention is not folded into the Q2 role)
+      case PR_O2: plan_put(pl, pipe_edge(p, l, PE_ATT2), tg); plan_put(pl, pipe_edge(p, l, PE_T1), tg); break;
+      case PR_FF: plan_put(pl, pipe_edge(p, l, PE_T2), tg); break;
+      case PR_L3: plan_put(pl, pipe_edge(p, l, PE_T2), tg, 1 + PIPE_NFF); break;
       default:  // PR_GEN
-        if (pre) { for (int j = 0; j < 4; ++j) put(pipe_edge(p, NL - 1, PE_P + j), tg); put(pipe_edge(p, NL - 1, PE_T2), tg); }
-        else put(pipe_edge_x(NL), tg);
+        if (pre) plan_put(pl, pipe_edge(p, NL - 1, PE_T2), tg, 1 + PIPE_NFF);
+        else plan_put(pl, pipe_edge_x(NL), tg);
         break;
     }
     return pl;
@@ -735,9 +741,14 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
       if (p.prof && tid == 0) t_wait += (long long)wall_clock64() - w0;
       if (!ok) break;
       const unsigned tag = (unsigned)t + 1u;
-      if (pre) {
-        if (tid < D) y[tid] = fmaxf(((in[tid] + in[D + tid]) + in[2 * D + tid]) + in[3 * D + tid] + lp[3 * D + tid], 0.f);
-        add_layernorm_lds<T, PIPE_THREADS>(y, in + 4 * D, lp + 4 * D, lp + 5 * D, D, red, xT);   // y = x(l), xT = its compute-dtype copy
+      if (pre) {   // in[0] = t2, in[1..PIPE_NFF] = the slabs' partial sums (added in slab order)
+        if (tid < D) {
+          float a = in[D + tid];
+#pragma unroll
+          for (int j = 1; j < PIPE_NFF; ++j) a += in[(1 + j) * D + tid];
+          y[tid] = fmaxf(a + lp[3 * D + tid], 0.f);
+        }
+        add_layernorm_lds<T, PIPE_THREADS>(y, in, lp + 4 * D, lp + 5 * D, D, red, xT);   // y = x(l), xT = its compute-dtype copy
       }
       switch (role.type) {
         case PR_GEN: {
@@ -771,6 +782,10 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
         }
         case PR_ATT: {
           const int nkP = nkA;
+          // role.sub = which half of the heads this workgroup attends with (two workgroups per image shard: half the keys x heads
+          // and half the value bytes each, the same number of dependent passes -> the hop is ~40 % shorter).  A half owns its
+          // heads' COLUMNS of the image's K|V cache rows and of the hand-off vector.
+          const int Dh = D / 2, h0 = role.sub * Dh;
           T* cache = (T*)p.L[l].cache + (long)img * p.steps * 2 * D;
           // row t-1 <- k / v of the previous step's layer OUTPUT (the reference's history), row t <- k / v of this step's INPUT
           // Both rows are also kept in LDS for this step's attention (row t-1, row t): the attention then reads rows 0..t-2 from
@@ -778,11 +793,16 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
           // otherwise; attend()'s own barriers retire them long before the next step reads them)
           T* tailT = reinterpret_cast<T*>(att_wred + (PIPE_THREADS / 64) * D);   // [2][2D] compute-dtype rows
           const int ntail = t > 0 ? 2 : 1;
-          if (t > 0) for (int i = tid; i < 2 * D; i += PIPE_THREADS) { const T v = from_f<T>(in[3 * D + i]); cache[(long)(t - 1) * 2 * D + i] = v; tailT[i] = v; }
-          for (int i = tid; i < 2 * D; i += PIPE_THREADS) { const T v = from_f<T>(in[D + i]); cache[(long)t * 2 * D + i] = v; tailT[(ntail - 1) * 2 * D + i] = v; }
+          for (int i = tid; i < D; i += PIPE_THREADS) {   // D = Dh columns of K + Dh columns of V
+            const int col = i < Dh ? h0 + i : D + h0 + (i - Dh);
+            if (t > 0) { const T v = from_f<T>(in[3 * D + col]); cache[(long)(t - 1) * 2 * D + col] = v; tailT[col] = v; }
+            const T v = from_f<T>(in[D + col]);
+            cache[(long)t * 2 * D + col] = v;
+            tailT[(ntail - 1) * 2 * D + col] = v;
+          }
           LDS_BARRIER();
-          attend<T, false, true, PIPE_THREADS>(in, cache, 2 * D, D, t + 1, H, hd, inv_temp, att_sc, nkP, y, att_wred, xT, nullptr, tailT, ntail);
-          pipe_send(c, pipe_edge(p, l, PE_ATT), img, tag, y, D);
+          attend<T, false, true, PIPE_THREADS>(in + h0, cache + h0, 2 * D, D, t + 1, H / 2, hd, inv_temp, att_sc, nkP, y, att_wred, xT, nullptr, tailT + h0, ntail);
+          pipe_send(c, pipe_edge(p, l, PE_ATT), img, tag, y, Dh, h0);
           break;
         }
         case PR_XATT: {
@@ -792,16 +812,33 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
           break;
         }
         case PR_L3: {
-          // ffn = relu(sum of the four K-slice partials + bias); out = LayerNorm(ffn + t2)
+          // ffn = relu(sum of the slabs' partial sums + bias); out = LayerNorm(ffn + t2)
           // (each thread reads and writes its own element: no barrier needed before the LayerNorm)
-          if (tid < D) y[tid] = fmaxf(((in[tid] + in[D + tid]) + in[2 * D + tid]) + in[3 * D + tid] + lp[tid], 0.f);
-          add_layernorm_lds<T, PIPE_THREADS>(y, in + 4 * D, l_lnw, l_lnb, D, red, xT);
+          if (tid < D) {
+            float a = in[D + tid];
+#pragma unroll
+            for (int j = 1; j < PIPE_NFF; ++j) a += in[(1 + j) * D + tid];
+            y[tid] = fmaxf(a + lp[tid], 0.f);
+          }
+          add_layernorm_lds<T, PIPE_THREADS>(y, in, l_lnw, l_lnb, D, red, xT);
           pipe_send(c, pipe_edge_x(l + 1), img, tag, y, D);
+          break;
+        }
+        case PR_FF: {
+          // hidden slab = relu(W0[slab] x + b0[slab]) (N = F / PIPE_NFF), then this slab's contribution to the output projection
+          // W1[:, slab] hidden (N2 = D): both matrices live in this workgroup's LDS, so the feed-forward is ONE hop on an image's path
+          T* hT = reinterpret_cast<T*>(in + D);
+          float* y2 = in + 2 * D;
+          gemv<T, 2, PIPE_THREADS>(wl, role.N, 0, l_bias, xT, y, role.N, role.K, ACT_RELU, hT);
+          LDS_BARRIER();
+          gemv<T, 2, PIPE_THREADS>(wl2, role.N2, 0, nullptr, hT, y2, role.N2, role.K2, ACT_NONE);
+          LDS_BARRIER();
+          pipe_send(c, pipe_edge(p, l, PE_P + role.sub), img, tag, y2, role.N2);
           break;
         }
         default: {  // matrix-vector roles
           const long long g0 = (p.prof && tid == 0) ? (long long)wall_clock64() : 0;
-          gemv<T, 2, PIPE_THREADS>(wl, role.N, 0, l_bias, xT, y, role.N, role.K, role.type == PR_F0 ? ACT_RELU : ACT_NONE);
+          gemv<T, 2, PIPE_THREADS>(wl, role.N, 0, l_bias, xT, y, role.N, role.K, ACT_NONE);
           const long long g1 = (p.prof && tid == 0) ? (long long)wall_clock64() : 0;
           LDS_BARRIER();
           if (p.prof && tid == 0) { t_gemv += g1 - g0; t_bar += (long long)wall_clock64() - g1; }
@@ -814,17 +851,18 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
             case PR_VB: e_out = pipe_edge(p, l, PE_VOUT); break;
             case PR_O: e_out = pipe_edge(p, l, PE_T1); break;
             case PR_Q2: e_out = pipe_edge(p, l, PE_Q2); break;
-            case PR_O2: e_out = pipe_edge(p, l, PE_T2); break;
-            case PR_F0: e_out = pipe_edge(p, l, PE_F0 + role.sub); break;
-            default: e_out = pipe_edge(p, l, PE_P + role.sub); break;  // PR_F1
+            default: e_out = pipe_edge(p, l, PE_T2); break;  // PR_O2
           }
           if (role.type == PR_O || role.type == PR_O2) add_layernorm_lds<T, PIPE_THREADS>(y, in + D, l_lnw, l_lnb, D, red, xT);
-          if (role.type == PR_Q2 && role.sub == 1) {
+          if (role.type == PR_Q2 && role.sub >= 1) {
             // cross-attention folded into the query projection's role (one hand-off less): K / V of the encoder output were
             // projected before the launch and are read-only here.  (Requesting those rows before the projection, so that their
             // round trips hide behind it, changed nothing: 99.3 vs 97.3 us per step -- the rows are L2-hot)
-            attend<T, false, false, PIPE_THREADS>(y, (const T*)p.L[l].crossKV + (long)img * p.Nsrc * 2 * D, 2 * D, D, p.Nsrc, H, hd, inv_temp, att_sc, nkA, in, att_wred, xT);
-            pipe_send(c, pipe_edge(p, l, PE_ATT2), img, tag, in, D);
+            // sub 1: all heads; sub 2 / 3: this workgroup projects and attends with the first / second half of the heads only
+            // (role.N = D/2 rows of the projection) and fills its half of the hand-off vector
+            const int nh = role.sub == 1 ? H : H / 2, h0 = role.sub == 3 ? D / 2 : 0;
+            attend<T, false, false, PIPE_THREADS>(y, (const T*)p.L[l].crossKV + (long)img * p.Nsrc * 2 * D + h0, 2 * D, D, p.Nsrc, nh, hd, inv_temp, att_sc, nkA, in, att_wred, xT);
+            pipe_send(c, pipe_edge(p, l, PE_ATT2), img, tag, in, nh * hd, h0);
             LDS_BARRIER();  // `in` is the next item's receive buffer
             break;
           }
@@ -832,7 +870,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
           break;
         }
       }
-      if (p.prof && tid == 0 && img == 0 && (t == 100 || t == 101)) p.prof[768 + (t - 100) * 256 + blockIdx.x] = (long long)wall_clock64();
+      if (p.prof && tid == 0 && img == 0 && (t == 100 || t == 101)) p.prof[1024 + (t - 100) * 256 + blockIdx.x] = (long long)wall_clock64();
       // no barrier here: the next item's first LDS writes (pipe_complete: in / xT) do not touch y, and its own barrier comes before
       // anything overwrites y.
       // Request the next (step, image)'s inputs.  (Issued BEFORE the compute, the two request registers had to live across the
@@ -856,7 +894,7 @@ size_t decode_pipe_scratch_bytes(const DecodeP& p) {
 }
 int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_bytes, hipStream_t s) {
   const bool off = getenv("SATRN_DECODE_NO_PIPE") != nullptr;  // read per call: tests switch between the two decoders in one process
-  if (off || dt != DT_BF16 || d.rules || d.D != 256 || d.F != 1024 || d.H * (d.D / d.H) != d.D || (d.D / d.H) % 8 || d.V > 256 || d.B > 112 /*larger batches: the per-image kernel (1 workgroup per image, no hand-offs) wins*/ || d.nlayers < 1 || d.nlayers > 4 ||
+  if (off || dt != DT_BF16 || d.rules || d.D != 256 || d.F != 1024 || d.H * (d.D / d.H) != d.D || (d.D / d.H) % 8 || (d.H & 1) || d.V > 256 || d.B > 112 /*larger batches: the per-image kernel (1 workgroup per image, no hand-offs) wins*/ || d.nlayers < 1 || d.nlayers > 4 ||
       d.B < 1 || scratch_bytes < decode_pipe_scratch_bytes(d))
     return -1;
   typedef bf16_t T;
@@ -877,10 +915,20 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
   auto knob = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
   // shards sized from the measured service times per item (SATRN_PIPE_PROF: matrix-vector 2.3 us, +LayerNorm 3.8, cross-attention
   // 5.5, self-attention 8.6 at 231 steps) so that no role is busy for more than ~60 us of a step at batch 64
-  int SA = knob("SATRN_PIPE_ATT_SHARDS", 10), SX = knob("SATRN_PIPE_XATT_SHARDS", 8), SM = knob("SATRN_PIPE_MV_SHARDS", 3), SL = knob("SATRN_PIPE_LN_SHARDS", 4);
+  int SA = knob("SATRN_PIPE_ATT_SHARDS", 10), SX = knob("SATRN_PIPE_XATT_SHARDS", 5), SM = knob("SATRN_PIPE_MV_SHARDS", 3), SL = knob("SATRN_PIPE_LN_SHARDS", 4);
+  // SQ: q / k(in) / v(in) projections (on every image's path, with the LayerNorm recompute); SH: the history projections and the
+  // combine role (off the path: throughput only); SM: feed-forward slabs
+  int SQ = knob("SATRN_PIPE_QKV_SHARDS", 4), SH = knob("SATRN_PIPE_HIST_SHARDS", 2);
   {  // one workgroup per compute unit: scale the shard counts down until the role count fits the chip
-    auto count = [&]() { return d.nlayers * (5 * SM + SA + SL + SX + SL + 8 * SM + SM) + SL; };
-    while (count() > 250 && (SA > 1 || SX > 1 || SM > 1 || SL > 1)) { if (SA > 1) --SA; if (SX > 1 && count() > 250) --SX; if (SM > 1 && count() > 250) --SM; if (SL > 1 && count() > 250) --SL; }
+    auto count = [&]() { return d.nlayers * (3 * SQ + 3 * SH + 2 * SA + SL + 2 * SX + SL + PIPE_NFF * SM) + SL; };
+    while (count() > 250 && (SA > 1 || SX > 1 || SM > 1 || SL > 1 || SQ > 1 || SH > 1)) {
+      if (SA > 1) --SA;
+      if (SX > 1 && count() > 250) --SX;
+      if (SM > 1 && count() > 250) --SM;
+      if (SL > 1 && count() > 250) --SL;
+      if (SQ > 1 && count() > 250) --SQ;
+      if (SH > 1 && count() > 250) --SH;
+    }
   }
   auto sharded = [&](int n, int type, int l, int sub, const void* w, int Ntot, int row0, int kp0, int N, int K, const float* bias, const float* lnw,
                      const float* lnb) {
@@ -892,18 +940,22 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
   };
   for (int l = 0; l < d.nlayers; ++l) {
     const DecLayerW& w = d.L[l];
-    sharded(SM, PR_Q, l, 0, w.wqkv, 3 * D, 0, 0, D, D, w.bqkv, nullptr, nullptr);
-    sharded(SM, PR_KA, l, 0, w.wqkv, 3 * D, D, 0, D, D, w.bqkv + D, nullptr, nullptr);
-    sharded(SM, PR_VA, l, 0, w.wqkv, 3 * D, 2 * D, 0, D, D, w.bqkv + 2 * D, nullptr, nullptr);
-    sharded(SM, PR_KB, l, 0, w.wqkv, 3 * D, D, 0, D, D, w.bqkv + D, nullptr, nullptr);
-    sharded(SM, PR_VB, l, 0, w.wqkv, 3 * D, 2 * D, 0, D, D, w.bqkv + 2 * D, nullptr, nullptr);
-    sharded(SA, PR_ATT, l, 0, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr);
+    sharded(SQ, PR_Q, l, 0, w.wqkv, 3 * D, 0, 0, D, D, w.bqkv, nullptr, nullptr);
+    sharded(SQ, PR_KA, l, 0, w.wqkv, 3 * D, D, 0, D, D, w.bqkv + D, nullptr, nullptr);
+    sharded(SQ, PR_VA, l, 0, w.wqkv, 3 * D, 2 * D, 0, D, D, w.bqkv + 2 * D, nullptr, nullptr);
+    sharded(SH, PR_KB, l, 0, w.wqkv, 3 * D, D, 0, D, D, w.bqkv + D, nullptr, nullptr);
+    sharded(SH, PR_VB, l, 0, w.wqkv, 3 * D, 2 * D, 0, D, D, w.bqkv + 2 * D, nullptr, nullptr);
+    for (int hf = 0; hf < 2; ++hf) sharded(SA, PR_ATT, l, hf, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr);
     sharded(SL, PR_O, l, 0, w.wo, D, 0, 0, D, D, w.bo, w.ln1w, w.ln1b);
-    sharded(SX, PR_Q2, l, 1 /*+ cross-attention*/, w.wq2, D, 0, 0, D, D, w.bq2, nullptr, nullptr);
+    for (int hf = 0; hf < 2; ++hf) sharded(SX, PR_Q2, l, 2 + hf /*+ cross-attention, half of the heads*/, w.wq2, D, hf * (D / 2), 0, D / 2, D, w.bq2 + hf * (D / 2), nullptr, nullptr);
     sharded(SL, PR_O2, l, 0, w.wo2, D, 0, 0, D, D, w.bo2, w.ln2w, w.ln2b);
-    for (int j = 0; j < F / D; ++j) sharded(SM, PR_F0, l, j, w.w0, F, j * D, 0, D, D, w.b0 + j * D, nullptr, nullptr);
-    for (int j = 0; j < F / D; ++j) sharded(SM, PR_F1, l, j, w.w1, D, 0, j * (D / 32), D, D, nullptr, nullptr, nullptr);
-    sharded(SM, PR_L3, l, 0, nullptr, 0, 0, 0, 0, 0, w.b1, w.ln3w, w.ln3b);
+    for (int j = 0; j < PIPE_NFF; ++j) {
+      const int FS = F / PIPE_NFF;   // hidden units per slab
+      const size_t first = roles.size();
+      sharded(SM, PR_FF, l, j, w.w0, F, j * FS, 0, FS, D, w.b0 + j * FS, nullptr, nullptr);
+      for (size_t r = first; r < roles.size(); ++r) { roles[r].w2 = w.w1; roles[r].Ntot2 = D; roles[r].row02 = 0; roles[r].kp02 = j * (FS / 32); roles[r].N2 = D; roles[r].K2 = FS; }
+    }
+    sharded(SH, PR_L3, l, 0, nullptr, 0, 0, 0, 0, 0, w.b1, w.ln3w, w.ln3b);
   }
   sharded(SL, PR_GEN, 0, 0, d.wgen, d.V, 0, 0, d.V, D, d.bgen, nullptr, nullptr);
   if (roles.size() > 250) return -1;  // one workgroup per compute unit, all resident (256 CUs)
@@ -933,10 +985,10 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
   // LDS: weights image (<= 128 KB) + scratch; attention roles use the scratch for scores / partial outputs instead of weights
   const int nkS = ((d.steps > d.Nsrc ? d.steps : d.Nsrc) + 3) & ~3, nkX = (d.Nsrc + 3) & ~3;
   const int PW = PIPE_THREADS / 64;
-  const size_t fl_common = (size_t)5 * D + D + 6 * D + 2 * PW + D;
+  const size_t fl_common = (size_t)10 * D + D + 6 * D + 2 * PW + D;
   const size_t fl_att_self = fl_common + (size_t)(d.H * nkS > 4 * D ? d.H * nkS : 4 * D) + (size_t)PW * D + 4 * D /*two newest K|V rows*/;
   const size_t fl_att_cross = fl_common + (size_t)(d.H * nkX > 4 * D ? d.H * nkX : 4 * D) + (size_t)PW * D;
-  size_t sh = std::max((size_t)D * D * sizeof(T) + 256 + (fl_att_cross - 3 * D) * 4, fl_att_self * 4);   // Q2 role: weights + cross-attention scratch
+  size_t sh = std::max((size_t)D * D * sizeof(T) + 256 + (fl_att_cross - 8 * D) * 4, fl_att_self * 4);   // Q2 role: weights + cross-attention scratch
   sh = std::max(sh, (size_t)D * D * sizeof(T) + 256 + fl_common * 4);
   sh = std::max(sh, (((size_t)d.V * D * sizeof(T) + 255) & ~(size_t)255) + fl_common * 4);
   if (sh > 160 * 1024 - 64) return -1;
@@ -955,16 +1007,16 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
     static long long h[2048];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, prof_buf, sizeof(h), hipMemcpyDeviceToHost);
-    static const char* nm[PR_NTYPES] = {"Q", "Kin", "Vin", "Kout", "Vout", "ATT", "O+LN1", "Q2", "XATT", "O2+LN2", "F0", "F1", "L3", "GEN"};
+    static const char* nm[PR_NTYPES] = {"Q", "Kin", "Vin", "Kout", "Vout", "ATT", "O+LN1", "Q2", "XATT", "O2+LN2", "FF", "L3", "GEN"};
     {  // timeline of image 0 through step 100 (and when step 101's first role finished): who hands to whom, how long each hop takes
       std::vector<std::pair<long long, size_t>> tl;
-      for (size_t i = 0; i < roles.size(); ++i) if (h[768 + i]) tl.push_back({h[768 + i], i});
+      for (size_t i = 0; i < roles.size(); ++i) if (h[1024 + i]) tl.push_back({h[1024 + i], i});
       std::sort(tl.begin(), tl.end());
       for (size_t k = 0; k < tl.size(); ++k)
         fprintf(stderr, "[pipe timeline] +%7.2f us (d %5.2f)  role %3zu %-7s l%d s%d\n", (tl[k].first - tl[0].first) / 100.0, k ? (tl[k].first - tl[k - 1].first) / 100.0 : 0.0, tl[k].second,
                 nm[roles[tl[k].second].type], roles[tl[k].second].layer, roles[tl[k].second].sub);
       long long first101 = 0;
-      for (size_t i = 0; i < roles.size(); ++i) if (h[768 + 256 + i] && (!first101 || h[768 + 256 + i] < first101)) first101 = h[768 + 256 + i];
+      for (size_t i = 0; i < roles.size(); ++i) if (h[1280 + i] && (!first101 || h[1280 + i] < first101)) first101 = h[1280 + i];
       if (!tl.empty() && first101) fprintf(stderr, "[pipe timeline] step 101 first completion at +%.2f us\n", (first101 - tl[0].first) / 100.0);
     }
     for (size_t i = 0; i < roles.size(); ++i)
