@@ -518,11 +518,12 @@ __global__ __launch_bounds__(DEC_THREADS) void beam_search_kernel(DecodeP p, Bea
 typedef __attribute__((address_space(1))) unsigned long long gu64_t;
 typedef __attribute__((address_space(1))) int gi32_t;
 
-enum { PR_Q = 0, PR_KA, PR_VA, PR_KB, PR_VB, PR_ATT, PR_O, PR_Q2, PR_XATT, PR_O2, PR_FF, PR_L3, PR_GEN, PR_NTYPES };
+enum { PR_Q = 0, PR_KA, PR_VA, PR_KB, PR_VB, PR_ATT, PR_T1, PR_Q2, PR_T2, PR_FF, PR_L3, PR_GEN, PR_NTYPES };
 // edges of one layer.  Roles that receive several vectors receive runs of CONSECUTIVE edges (see RecvPlan): Q|KIN|VIN, KOUT|VOUT,
-// T2|P0..P7
+// OP0|OP1 (+ the layer input), T1|O2P0|O2P1, T2|P0..P7
 #define PIPE_NFF 8   // feed-forward slabs: F / PIPE_NFF hidden units each
-enum { PE_Q = 0, PE_KIN, PE_VIN, PE_KOUT, PE_VOUT, PE_ATT, PE_T1, PE_Q2, PE_ATT2, PE_T2, PE_P /*PIPE_NFF partial sums*/, PE_PER_LAYER = PE_P + PIPE_NFF };
+enum { PE_Q = 0, PE_KIN, PE_VIN, PE_KOUT, PE_VOUT, PE_OP /*2: the head halves' partial self-attention output projections*/, PE_T1 = PE_OP + 2,
+       PE_O2P /*2: partial cross-attention output projections*/, PE_T2 = PE_O2P + 2, PE_P /*PIPE_NFF partial sums*/, PE_PER_LAYER = PE_P + PIPE_NFF };
 
 struct PipeCtx {
   const PipeP* p;
@@ -642,8 +643,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
   T* wl2 = reinterpret_cast<T*>(sm + w1bytes / 4);   // second matrix (feed-forward role)
   const size_t wbytes = w1bytes + (((size_t)role.N2 * role.K2 * sizeof(T) + 255) & ~(size_t)255);
   float* f = sm + wbytes / 4;
-  float* in = f;             // [10][D] received vectors ([2][D] for the query-projection + cross-attention role)
-  float* y = in + (role.type == PR_Q2 ? 2 : 10) * D;  // [D] outputs (every role of the pipeline produces <= D values)
+  float* in = f;             // [10][D] received vectors ([3][D] for the query-projection + cross-attention role)
+  float* y = in + (role.type == PR_Q2 ? 3 : 10) * D;  // [D] outputs (every role of the pipeline produces <= D values)
   float* lp = y + D;         // [6][D] parameters, loaded once: bias | LayerNorm w | b | the PREVIOUS layer's FFN bias | LayerNorm w | b
   float* red = lp + 6 * D;   // [2*(PIPE_THREADS / 64)]
   T* xT = reinterpret_cast<T*>(red + 2 * (PIPE_THREADS / 64));  // [D] compute-dtype copy of the matrix-vector input (an f32 slot per element)
@@ -707,11 +708,8 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
         plan_put(pl, pipe_edge(p, l, PE_Q), tg, 3);                              // q | k(in) | v(in)
         if (t > 0) plan_put(pl, pipe_edge(p, l, PE_KOUT), (unsigned)t, 2);      // k(out) | v(out) of the previous step
         break;
-      case PR_O: plan_put(pl, pipe_edge(p, l, PE_ATT), tg); plan_put(pl, pipe_edge_x(l), tg); break;
-      case PR_Q2: plan_put(pl, pipe_edge(p, l, PE_T1), tg); break;
-      case PR_XATT: plan_put(pl, pipe_edge(p, l, PE_Q2), tg); break;  // (only when the cross-attention is not folded into the Q2 role)
-      case PR_O2: plan_put(pl, pipe_edge(p, l, PE_ATT2), tg); plan_put(pl, pipe_edge(p, l, PE_T1), tg); break;
-      case PR_FF: plan_put(pl, pipe_edge(p, l, PE_T2), tg); break;
+      case PR_T1: case PR_Q2: plan_put(pl, pipe_edge(p, l, PE_OP), tg, 2); plan_put(pl, pipe_edge_x(l), tg); break;   // o partials | layer input
+      case PR_T2: case PR_FF: plan_put(pl, pipe_edge(p, l, PE_T1), tg, 3); break;                                      // t1 | o2 partials
       case PR_L3: plan_put(pl, pipe_edge(p, l, PE_T2), tg, 1 + PIPE_NFF); break;
       default:  // PR_GEN
         if (pre) plan_put(pl, pipe_edge(p, NL - 1, PE_T2), tg, 1 + PIPE_NFF);
@@ -802,13 +800,41 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
           }
           LDS_BARRIER();
           attend<T, false, true, PIPE_THREADS>(in + h0, cache + h0, 2 * D, D, t + 1, H / 2, hd, inv_temp, att_sc, nkP, y, att_wred, xT, nullptr, tailT + h0, ntail);
-          pipe_send(c, pipe_edge(p, l, PE_ATT), img, tag, y, Dh, h0);
+          // this half's share of the output projection: Wo[:, these heads' columns] x attention (LDS-resident K-slab; the first
+          // half adds the bias).  The two partial vectors are summed by whoever applies LayerNorm 1 -- the out-projection +
+          // LayerNorm role of the first version, a whole hop of 3 us on every image's path, is gone.
+          float* y2 = in + 6 * D;
+          gemv<T, 2, PIPE_THREADS>(wl, role.N, 0, l_bias, xT, y2, role.N, role.K, ACT_NONE);
+          LDS_BARRIER();
+          pipe_send(c, pipe_edge(p, l, PE_OP + role.sub), img, tag, y2, D);
           break;
         }
-        case PR_XATT: {
-          const int nkP = nkA;
-          attend<T, false, false, PIPE_THREADS>(in, (const T*)p.L[l].crossKV + (long)img * p.Nsrc * 2 * D, 2 * D, D, p.Nsrc, H, hd, inv_temp, att_sc, nkP, y, att_wred, xT);
-          pipe_send(c, pipe_edge(p, l, PE_ATT2), img, tag, y, D);
+        case PR_T1: case PR_T2: {
+          // t = LayerNorm(partial 0 + partial 1 + residual), published for the roles that need it LATER as a residual (the
+          // roles that need it NOW recompute it themselves from the same three vectors): off every image's critical path
+          const float* p0 = role.type == PR_T1 ? in : in + D;
+          const float* p1 = role.type == PR_T1 ? in + D : in + 2 * D;
+          const float* rs = role.type == PR_T1 ? in + 2 * D : in;
+          if (tid < D) y[tid] = p0[tid] + p1[tid];
+          add_layernorm_lds<T, PIPE_THREADS>(y, rs, l_lnw, l_lnb, D, red, xT);
+          pipe_send(c, pipe_edge(p, l, role.type == PR_T1 ? PE_T1 : PE_T2), img, tag, y, D);
+          break;
+        }
+        case PR_Q2: {
+          // t1 = LayerNorm1(o partials + layer input), recomputed here; q2 = Wq2[these heads] t1; cross-attention over the
+          // encoder memory with this half of the heads (K / V projected before the launch, read-only); then this half's share of
+          // the cross-attention output projection
+          const int Dh = D / 2, h0 = role.sub * Dh;
+          if (tid < D) y[tid] = in[tid] + in[D + tid];
+          add_layernorm_lds<T, PIPE_THREADS>(y, in + 2 * D, l_lnw, l_lnb, D, red, xT);
+          gemv<T, 2, PIPE_THREADS>(wl, role.N, 0, l_bias, xT, y, role.N, role.K, ACT_NONE);   // y[0..Dh) = this half's query
+          LDS_BARRIER();
+          attend<T, false, false, PIPE_THREADS>(y, (const T*)p.L[l].crossKV + (long)img * p.Nsrc * 2 * D + h0, 2 * D, D, p.Nsrc, H / 2, hd, inv_temp, att_sc, nkA, in, att_wred, xT);
+          float* y2 = in + D;
+          gemv<T, 2, PIPE_THREADS>(wl2, role.N2, 0, role.sub == 0 ? lp + 3 * D : nullptr, xT, y2, role.N2, role.K2, ACT_NONE);
+          LDS_BARRIER();
+          pipe_send(c, pipe_edge(p, l, PE_O2P + role.sub), img, tag, y2, D);
+          LDS_BARRIER();  // `in` is the next item's receive buffer
           break;
         }
         case PR_L3: {
@@ -827,8 +853,12 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
         case PR_FF: {
           // hidden slab = relu(W0[slab] x + b0[slab]) (N = F / PIPE_NFF), then this slab's contribution to the output projection
           // W1[:, slab] hidden (N2 = D): both matrices live in this workgroup's LDS, so the feed-forward is ONE hop on an image's path
-          T* hT = reinterpret_cast<T*>(in + D);
-          float* y2 = in + 2 * D;
+          // its input t2 = LayerNorm2(o2 partials + t1) is recomputed here from the three vectors (in[0] = t1)
+          // (taking t2 from the LayerNorm-2 publisher instead -- one more hop, no recompute in eight roles -- measured 22.4 vs 22.2 ms)
+          if (tid < D) y[tid] = in[D + tid] + in[2 * D + tid];
+          add_layernorm_lds<T, PIPE_THREADS>(y, in, l_lnw, l_lnb, D, red, xT);
+          T* hT = reinterpret_cast<T*>(in + 3 * D);
+          float* y2 = in + 4 * D;
           gemv<T, 2, PIPE_THREADS>(wl, role.N, 0, l_bias, xT, y, role.N, role.K, ACT_RELU, hT);
           LDS_BARRIER();
           gemv<T, 2, PIPE_THREADS>(wl2, role.N2, 0, nullptr, hT, y2, role.N2, role.K2, ACT_NONE);
@@ -848,23 +878,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
             case PR_KA: e_out = pipe_edge(p, l, PE_KIN); break;
             case PR_VA: e_out = pipe_edge(p, l, PE_VIN); break;
             case PR_KB: e_out = pipe_edge(p, l, PE_KOUT); break;
-            case PR_VB: e_out = pipe_edge(p, l, PE_VOUT); break;
-            case PR_O: e_out = pipe_edge(p, l, PE_T1); break;
-            case PR_Q2: e_out = pipe_edge(p, l, PE_Q2); break;
-            default: e_out = pipe_edge(p, l, PE_T2); break;  // PR_O2
-          }
-          if (role.type == PR_O || role.type == PR_O2) add_layernorm_lds<T, PIPE_THREADS>(y, in + D, l_lnw, l_lnb, D, red, xT);
-          if (role.type == PR_Q2 && role.sub >= 1) {
-            // cross-attention folded into the query projection's role (one hand-off less): K / V of the encoder output were
-            // projected before the launch and are read-only here.  (Requesting those rows before the projection, so that their
-            // round trips hide behind it, changed nothing: 99.3 vs 97.3 us per step -- the rows are L2-hot)
-            // sub 1: all heads; sub 2 / 3: this workgroup projects and attends with the first / second half of the heads only
-            // (role.N = D/2 rows of the projection) and fills its half of the hand-off vector
-            const int nh = role.sub == 1 ? H : H / 2, h0 = role.sub == 3 ? D / 2 : 0;
-            attend<T, false, false, PIPE_THREADS>(y, (const T*)p.L[l].crossKV + (long)img * p.Nsrc * 2 * D + h0, 2 * D, D, p.Nsrc, nh, hd, inv_temp, att_sc, nkA, in, att_wred, xT);
-            pipe_send(c, pipe_edge(p, l, PE_ATT2), img, tag, in, nh * hd, h0);
-            LDS_BARRIER();  // `in` is the next item's receive buffer
-            break;
+            default: e_out = pipe_edge(p, l, PE_VOUT); break;  // PR_VB
           }
           pipe_send(c, e_out, img, tag, y, role.N);
           break;
@@ -915,17 +929,17 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
   auto knob = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
   // shards sized from the measured service times per item (SATRN_PIPE_PROF: matrix-vector 2.3 us, +LayerNorm 3.8, cross-attention
   // 5.5, self-attention 8.6 at 231 steps) so that no role is busy for more than ~60 us of a step at batch 64
-  int SA = knob("SATRN_PIPE_ATT_SHARDS", 10), SX = knob("SATRN_PIPE_XATT_SHARDS", 5), SM = knob("SATRN_PIPE_MV_SHARDS", 3), SL = knob("SATRN_PIPE_LN_SHARDS", 4);
+  int SA = knob("SATRN_PIPE_ATT_SHARDS", 8), SX = knob("SATRN_PIPE_XATT_SHARDS", 6), SM = knob("SATRN_PIPE_MV_SHARDS", 4);
   // SQ: q / k(in) / v(in) projections (on every image's path, with the LayerNorm recompute); SH: the history projections and the
-  // combine role (off the path: throughput only); SM: feed-forward slabs
-  int SQ = knob("SATRN_PIPE_QKV_SHARDS", 4), SH = knob("SATRN_PIPE_HIST_SHARDS", 2);
+  // combine role (off the path: throughput only); SM: feed-forward slabs; ST: the two LayerNorm publishers (off the path)
+  int SQ = knob("SATRN_PIPE_QKV_SHARDS", 4), SH = knob("SATRN_PIPE_HIST_SHARDS", 2), ST = knob("SATRN_PIPE_LN_SHARDS", 2), SG = knob("SATRN_PIPE_GEN_SHARDS", 4);
   {  // one workgroup per compute unit: scale the shard counts down until the role count fits the chip
-    auto count = [&]() { return d.nlayers * (3 * SQ + 3 * SH + 2 * SA + SL + 2 * SX + SL + PIPE_NFF * SM) + SL; };
-    while (count() > 250 && (SA > 1 || SX > 1 || SM > 1 || SL > 1 || SQ > 1 || SH > 1)) {
+    auto count = [&]() { return d.nlayers * (3 * SQ + 3 * SH + 2 * SA + 2 * ST + 2 * SX + PIPE_NFF * SM) + SG; };
+    while (count() > 250 && (SA > 1 || SX > 1 || SM > 1 || ST > 1 || SQ > 1 || SH > 1)) {
       if (SA > 1) --SA;
       if (SX > 1 && count() > 250) --SX;
       if (SM > 1 && count() > 250) --SM;
-      if (SL > 1 && count() > 250) --SL;
+      if (ST > 1 && count() > 250) --ST;
       if (SQ > 1 && count() > 250) --SQ;
       if (SH > 1 && count() > 250) --SH;
     }
@@ -945,19 +959,28 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
     sharded(SQ, PR_VA, l, 0, w.wqkv, 3 * D, 2 * D, 0, D, D, w.bqkv + 2 * D, nullptr, nullptr);
     sharded(SH, PR_KB, l, 0, w.wqkv, 3 * D, D, 0, D, D, w.bqkv + D, nullptr, nullptr);
     sharded(SH, PR_VB, l, 0, w.wqkv, 3 * D, 2 * D, 0, D, D, w.bqkv + 2 * D, nullptr, nullptr);
-    for (int hf = 0; hf < 2; ++hf) sharded(SA, PR_ATT, l, hf, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr);
-    sharded(SL, PR_O, l, 0, w.wo, D, 0, 0, D, D, w.bo, w.ln1w, w.ln1b);
-    for (int hf = 0; hf < 2; ++hf) sharded(SX, PR_Q2, l, 2 + hf /*+ cross-attention, half of the heads*/, w.wq2, D, hf * (D / 2), 0, D / 2, D, w.bq2 + hf * (D / 2), nullptr, nullptr);
-    sharded(SL, PR_O2, l, 0, w.wo2, D, 0, 0, D, D, w.bo2, w.ln2w, w.ln2b);
+    // self-attention, two workgroups per image shard (half of the heads each) + that half's K-slab of the output projection
+    for (int hf = 0; hf < 2; ++hf) sharded(SA, PR_ATT, l, hf, w.wo, D, 0, hf * (D / 64), D, D / 2, hf == 0 ? w.bo : nullptr, nullptr, nullptr);
+    sharded(ST, PR_T1, l, 0, nullptr, 0, 0, 0, 0, 0, nullptr, w.ln1w, w.ln1b);
+    // LayerNorm 1 + query projection + cross-attention (half of the heads) + that half's K-slab of its output projection
+    for (int hf = 0; hf < 2; ++hf) {
+      const size_t first = roles.size();
+      sharded(SX, PR_Q2, l, hf, w.wq2, D, hf * (D / 2), 0, D / 2, D, w.bq2 + hf * (D / 2), w.ln1w, w.ln1b);
+      for (size_t r = first; r < roles.size(); ++r) {
+        roles[r].w2 = w.wo2; roles[r].Ntot2 = D; roles[r].row02 = 0; roles[r].kp02 = hf * (D / 64); roles[r].N2 = D; roles[r].K2 = D / 2;
+        roles[r].pre_bias = hf == 0 ? w.bo2 : nullptr;   // (bias slot of the second product; pre_lnw stays null)
+      }
+    }
+    sharded(ST, PR_T2, l, 0, nullptr, 0, 0, 0, 0, 0, nullptr, w.ln2w, w.ln2b);
     for (int j = 0; j < PIPE_NFF; ++j) {
       const int FS = F / PIPE_NFF;   // hidden units per slab
       const size_t first = roles.size();
-      sharded(SM, PR_FF, l, j, w.w0, F, j * FS, 0, FS, D, w.b0 + j * FS, nullptr, nullptr);
+      sharded(SM, PR_FF, l, j, w.w0, F, j * FS, 0, FS, D, w.b0 + j * FS, w.ln2w, w.ln2b);
       for (size_t r = first; r < roles.size(); ++r) { roles[r].w2 = w.w1; roles[r].Ntot2 = D; roles[r].row02 = 0; roles[r].kp02 = j * (FS / 32); roles[r].N2 = D; roles[r].K2 = FS; }
     }
     sharded(SH, PR_L3, l, 0, nullptr, 0, 0, 0, 0, 0, w.b1, w.ln3w, w.ln3b);
   }
-  sharded(SL, PR_GEN, 0, 0, d.wgen, d.V, 0, 0, d.V, D, d.bgen, nullptr, nullptr);
+  sharded(SG, PR_GEN, 0, 0, d.wgen, d.V, 0, 0, d.V, D, d.bgen, nullptr, nullptr);
   if (roles.size() > 250) return -1;  // one workgroup per compute unit, all resident (256 CUs)
   PipeP p;
   memset(&p, 0, sizeof(p));
@@ -986,9 +1009,10 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
   const int nkS = ((d.steps > d.Nsrc ? d.steps : d.Nsrc) + 3) & ~3, nkX = (d.Nsrc + 3) & ~3;
   const int PW = PIPE_THREADS / 64;
   const size_t fl_common = (size_t)10 * D + D + 6 * D + 2 * PW + D;
+  const size_t half_w = (size_t)D * (D / 2) * sizeof(T) + 256;   // one K-slab / row-half of a D x D matrix
   const size_t fl_att_self = fl_common + (size_t)(d.H * nkS > 4 * D ? d.H * nkS : 4 * D) + (size_t)PW * D + 4 * D /*two newest K|V rows*/;
-  const size_t fl_att_cross = fl_common + (size_t)(d.H * nkX > 4 * D ? d.H * nkX : 4 * D) + (size_t)PW * D;
-  size_t sh = std::max((size_t)D * D * sizeof(T) + 256 + (fl_att_cross - 8 * D) * 4, fl_att_self * 4);   // Q2 role: weights + cross-attention scratch
+  const size_t fl_att_cross = (fl_common - 7 * D) + (size_t)(d.H * nkX > 4 * D ? d.H * nkX : 4 * D) + (size_t)PW * D;
+  size_t sh = std::max(2 * half_w + fl_att_cross * 4, half_w + fl_att_self * 4);   // query + cross-attention role | self-attention role
   sh = std::max(sh, (size_t)D * D * sizeof(T) + 256 + fl_common * 4);
   sh = std::max(sh, (((size_t)d.V * D * sizeof(T) + 255) & ~(size_t)255) + fl_common * 4);
   if (sh > 160 * 1024 - 64) return -1;
@@ -1007,7 +1031,7 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
     static long long h[2048];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(h, prof_buf, sizeof(h), hipMemcpyDeviceToHost);
-    static const char* nm[PR_NTYPES] = {"Q", "Kin", "Vin", "Kout", "Vout", "ATT", "O+LN1", "Q2", "XATT", "O2+LN2", "FF", "L3", "GEN"};
+    static const char* nm[PR_NTYPES] = {"Q", "Kin", "Vin", "Kout", "Vout", "ATT+O", "T1", "LN1+Q2+X+O2", "T2", "LN2+FF", "L3", "GEN"};
     {  // timeline of image 0 through step 100 (and when step 101's first role finished): who hands to whom, how long each hop takes
       std::vector<std::pair<long long, size_t>> tl;
       for (size_t i = 0; i < roles.size(); ++i) if (h[1024 + i]) tl.push_back({h[1024 + i], i});

@@ -1,6 +1,7 @@
 """GPU: size-independent properties at BASELINE.json's FULL sizes (configs[1]: EfficientSATRN, 32 x 1x128x384, T=128 for
 training; config 5: 64 images x 231 greedy steps for decoding), where the CPU oracle would take minutes.  The oracle /
 golden parity tests (tests/test_model_gpu.py) run the same code paths at sizes the oracle finishes in seconds."""
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -96,10 +97,22 @@ def test_full_size_decode_rows_are_independent_and_beam1_is_greedy():
         dataset = _DS()
     seq = model.beam_search(img, L, beam_width=1, max_sequence=231).cuda()
     assert (seq[:, 0] == O.SOS_ID).all()
+    # the search kernel runs the per-image decoder step: it must walk the per-image greedy kernel's chain EXACTLY, and the
+    # pipelined greedy decoder's chain (same mathematics, partial sums added in another order) up to its first near-tie
+    os.environ["SATRN_DECODE_NO_PIPE"] = "1"
+    try:
+        _, ids_pi = model.greedy(img, 231)
+    finally:
+        os.environ.pop("SATRN_DECODE_NO_PIPE", None)
+    margin = logits.topk(2, -1).values
+    sure_all = ((margin[..., 0] - margin[..., 1]) > 5e-2).cpu()
     for b in range(64):
-        row = ids[b]
+        row = ids_pi[b]
         eos = (row == O.EOS_ID).nonzero()
         n = int(eos[0]) + 1 if len(eos) else 230      # the search stops at the first <EOS>; 230 expansions at most
         n = min(n, 230)
         assert (seq[b, 1:1 + n] == row[:n]).all(), b
         assert (seq[b, 1 + n:] == O.PAD_ID).all(), b
+        first_unsure = int((~sure_all[b]).nonzero()[0]) if (~sure_all[b]).any() else 231
+        m = min(n, first_unsure)
+        assert (seq[b, 1:1 + m] == ids[b, :m]).all(), b
