@@ -411,7 +411,7 @@ def main():
                                                         achieved=round(38.0e6 / step_us / 1e3, 1), peak=8000.0, unit="GB/s",
                                                         frac=round(38.0e6 / step_us / 1e3 / 8000.0, 4), encoder_ms=round(esec * 1e3, 2),
                                                         kernel="decode_pipe_kernel (one persistent workgroup per decoder role, weights resident in LDS, images pipelined through the roles)",
-                                                        note="latency-bound, not HBM-bound: a token is a dependent chain of ~22 role hops per step (3 layers x [Q/K/V, attention, O+LN, Q2+cross-attention, O2+LN, FFN0, FFN1] + generator); the weights never leave LDS, so the 38 MB/step figure is what a weight-streaming decoder would move, kept as the algorithmic unit of SURVEY 8d")
+                                                        note="latency-bound, not HBM-bound: a token is a dependent chain of 13 role hops per step (3 layers x [Q/K/V, self-attention + out-projection, LayerNorm + cross-attention, LayerNorm + feed-forward] + generator), and at batch 64 the 244 role workgroups are ~80 % busy; the weights never leave LDS, so the 38 MB/step figure is what a weight-streaming decoder would move, kept as the algorithmic unit of SURVEY 8d")
                 # the per-image kernel of round 1 (one workgroup per image streams every weight each step), kept as the
                 # fallback for shapes the pipeline does not take; timed beside it
                 os.environ["SATRN_DECODE_NO_PIPE"] = "1"
