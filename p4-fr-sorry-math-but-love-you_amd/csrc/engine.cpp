@@ -58,7 +58,9 @@ void Exec::defer(std::function<void(hipStream_t)> fn) {
   if (!s2 || dry) { fn(s); return; }
   pending.push_back(std::move(fn));
   // hand the batch to the side stream every 8 launches (round 2, tools/ab_flush.sh: 4 -> 12.35, 8 -> 12.14, 16 -> 12.15,
-  // never -> 14.6 ms/step): every hand-over is an event record on the chain's queue, which stalls it for >= 7 us
+  // never -> 14.6 ms/step): every hand-over costs the chain 11-15 us (tools/micro/fork_cost.hip: an event record on the
+  // chain's queue + a wait on the side queue; the record alone is 2 us).  Larger batches early in the backward and small
+  // ones near the join were tried as well (32 / 8): no change -- what the fewer forks save, the later start of the side work costs
   static const int thr = getenv("SATRN_FLUSH") ? atoi(getenv("SATRN_FLUSH")) : 8;
   if ((int)pending.size() >= thr) flush_side();
 }
