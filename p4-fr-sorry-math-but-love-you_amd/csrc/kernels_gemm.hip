@@ -29,8 +29,13 @@ DEVI void vm_tie(u32x4& v) { asm volatile("" : "+v"(v)); }
 DEVI uint4 as_uint4(u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); }
 DEVI u32x4 as_u32x4(uint4 v) { u32x4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
 
-template <typename T, int BM, int BN, int AM, int KP>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+template <typename T, int BM, int BN, int AM, int KP, int G = 1>
+__global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
+  // G = 2: two groups of four waves share one output tile; group g stages and multiplies the k-panels pp = g, g + 2, .. of
+  // every stage, and the two accumulators are added through LDS before the epilogue.  For the deep-K, small-grid products
+  // of the last backbone stages (M = 1536, N = 256, K = 1536: 192 workgroups = one per CU, one wave per SIMD) a workgroup is
+  // a single instruction stream per SIMD -- address arithmetic, LDS round trips, MFMAs and the barrier run one after the other,
+  // ~1 us per k-stage; the second group overlaps them.
   // KP = 32-deep k-panels staged per barrier: latency-bound small-grid GEMMs (late 1x1 convs, decoder linears) take
   // KP = 2/4 so that one global round trip feeds 64/128 of K
   constexpr int CH = TT<T>::CH, CPR = TT<T>::CPR;
@@ -39,7 +44,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   constexpr int STAGE = KP * (BM + BN) * 32;
   __shared__ __attribute__((aligned(16))) T lds[2 * STAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(G == 1 || (KP % G) == 0, "k-panels per stage must divide among the groups");
+  const int grp = G == 1 ? 0 : (int)(threadIdx.x >> 8);   // 0 .. G-1
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // position inside the group
   const int ntn = (p.N + BN - 1) / BN;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = wg % ntn, tile_m = wg / ntn;
@@ -73,11 +80,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   // k-stages of global loads in flight -- with one, every k iteration cost a full far round trip (M=1536 N=256 K=1536:
   // 12 iterations, 16-22 us)
   constexpr int PF = (BM * BN <= 64 * 64 && AM == AM_DENSE) ? 2 : 1;
-  u32x4 ra[PF][KP][NA], rb[PF][KP][NB];
+  u32x4 ra[PF][KP / G][NA], rb[PF][KP / G][NB];
   auto load_tiles = [&](int kt, auto SET) {
     constexpr int S = decltype(SET)::value;
 #pragma unroll
-    for (int pp = 0; pp < KP; ++pp) {
+    for (int pj = 0; pj < KP / G; ++pj) {
+      const int pp = grp + pj * G;   // this group's panels (register slot pj)
       const int k0 = (kt * KP + pp) * 32 + cc * CH;
       const bool kok = k0 < p.K;
       int kh = 0, kw = 0, ci = 0;
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
           // (the select itself happens in store_tiles, after the wait: a select right here would be a use of the load)
           const bool ok = ri[i].ok && kok;
           const T* src = A + (ok ? (long)ri[i].img * p.lda + k0 : 0L);
-          if constexpr (PF == 2) { ra[S][pp][i] = gload16_async(src); continue; }
+          if constexpr (PF == 2) { ra[S][pj][i] = gload16_async(src); continue; }
           v = ld16(src);
         } else if (ri[i].ok && kok) {
           if (AM == AM_DENSE) {
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
             }
           }
         }
-        ra[S][pp][i] = as_u32x4(v);
+        ra[S][pj][i] = as_u32x4(v);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -124,12 +132,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         const bool ok = idx < BN * CPR && n < p.N && kok;
         if constexpr (AM == AM_DENSE) {
           const T* src = Bw + (ok ? (long)n * p.K + k0 : 0L);
-          if constexpr (PF == 2) { rb[S][pp][i] = gload16_async(src); continue; }
+          if constexpr (PF == 2) { rb[S][pj][i] = gload16_async(src); continue; }
           v = ld16(src);
         } else if (ok) {
           v = ld16(Bw + (long)n * p.K + k0);
         }
-        rb[S][pp][i] = as_u32x4(v);
+        rb[S][pj][i] = as_u32x4(v);
       }
     }
   };
@@ -137,29 +145,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     constexpr int S = decltype(SET)::value;
     if constexpr (PF == 2) {
 #pragma unroll
-      for (int pp = 0; pp < KP; ++pp) {
+      for (int pj = 0; pj < KP / G; ++pj) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) vm_tie(ra[S][pp][i]);
+        for (int i = 0; i < NA; ++i) vm_tie(ra[S][pj][i]);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) vm_tie(rb[S][pp][i]);
+        for (int i = 0; i < NB; ++i) vm_tie(rb[S][pj][i]);
       }
     }
 #pragma unroll
-    for (int pp = 0; pp < KP; ++pp) {
+    for (int pj = 0; pj < KP / G; ++pj) {
+      const int pp = grp + pj * G;
       T* la = lds + buf * STAGE + pp * (BM + BN) * 32;
       T* lb = la + BM * 32;
       const bool kok = (kt * KP + pp) * 32 + cc * CH < p.K;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         int idx = tid + i * 256;
-        uint4 v = as_uint4(ra[S][pp][i]);
+        uint4 v = as_uint4(ra[S][pj][i]);
         if constexpr (AM == AM_DENSE) { if (!(ri[i].ok && kok)) v = zero16(); }  // dense loads are unconditional (see load_tiles)
         if (idx < BM * CPR) st16(la + panel_chunk<T>(idx / CPR, cc), v);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         int idx = tid + i * 256;
-        uint4 v = as_uint4(rb[S][pp][i]);
+        uint4 v = as_uint4(rb[S][pj][i]);
         if constexpr (AM == AM_DENSE) { if (!(n0 + idx / CPR < p.N && kok)) v = zero16(); }
         if (idx < BN * CPR) st16(lb + panel_chunk<T>(idx / CPR, cc), v);
       }
@@ -176,7 +185,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const int fr = lane & 15, fq = lane >> 4;
   auto compute = [&](int cur) {
 #pragma unroll
-    for (int pp = 0; pp < KP; ++pp) {
+    for (int pj = 0; pj < KP / G; ++pj) {
+      const int pp = grp + pj * G;
       const T* la = lds + cur * STAGE + pp * (BM + BN) * 32;
       const T* lb = la + BM * 32;
       Frag<T> af[MT];
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   } else {
     // stage kt+1 is in flight in register set (kt+1)&1 while stage kt is computed; stage kt+2 is requested into the other set
     // before the compute, so two far round trips overlap
-    constexpr int NL = KP * (NA + NB);  // loads one stage issues per thread
+    constexpr int NL = (KP / G) * (NA + NB);  // loads one stage issues per thread
     load_tiles(0, IC<0>{});
     if (nk > 1) { load_tiles(1, IC<1>{}); vm_wait<NL>(); } else { vm_wait<0>(); }
     store_tiles(0, IC<0>{}, 0);
@@ -226,6 +236,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     }
   }
 
+  // ---- G > 1: the other groups' accumulators go through LDS (free now) into the first group's; the first group alone
+  // writes the tile and contributes to the column sums (the others keep taking part in the barriers)
+  const bool writer = grp == 0;
+  if constexpr (G > 1) {
+    float* xch = reinterpret_cast<float*>(lds);   // [G - 1][MT][NT][256][4]
+    if (grp > 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(xch + ((((grp - 1) * MT + i) * NT + j) * 256 + tid) * 4) = acc[i][j];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int g2 = 0; g2 < G - 1; ++g2)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(xch + (((g2 * MT + i) * NT + j) * 256 + tid) * 4);
+            acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+          }
+    }
+    __syncthreads();
+  }
   // ---- epilogue: C layout col = lane&15, row = (lane>>4)*4 + reg
   const uint32_t seed = (p.drop_p > 0.f) ? *p.seed : 0u;
   // [4 waves][2][BN] column sums for the BatchNorm that follows (LDS is free now).  Every (wave, column) slot has exactly one
@@ -245,7 +280,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wave * (BM / 4) + i * 16 + fq * 4 + r;
-        if (row >= p.M || col >= p.N) continue;
+        if (row >= p.M || col >= p.N || !writer) continue;
         float v = act_fwd(acc[i][j][r] * esc + esh + bias, p.act);
         if (p.drop_p > 0.f) v *= drop_scale(seed, p.site, (uint32_t)(row * p.N + col), p.drop_p);
         const long o = (long)row * p.ldc + col;
@@ -272,14 +307,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     if (p.stats) {
       s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (fq == 0) { sred[wave * 2 * BN + j * 16 + fr] = s1; sred[wave * 2 * BN + BN + j * 16 + fr] = s2; }
+      if (fq == 0 && writer) { sred[wave * 2 * BN + j * 16 + fr] = s1; sred[wave * 2 * BN + BN + j * 16 + fr] = s2; }
     }
   }
   if (p.stats) {
     __syncthreads();
     for (int i = tid; i < 2 * BN; i += 256) {
       int c = i < BN ? i : i - BN, col = n0 + c;
-      if (col >= p.N) continue;
+      if (col >= p.N || !writer) continue;
       const float tot = ((sred[i] + sred[2 * BN + i]) + sred[4 * BN + i]) + sred[6 * BN + i];
       if (p.stats_part) {
         // deterministic mode: a tile owns BM/64 slots of 64 rows (its sums in the first, zeros in the rest), so the fold
@@ -329,7 +364,11 @@ static void launch_gemm_t(const GemmP& p, hipStream_t s) {
   } else if (D && p.N >= 64 && blocks(64, 64) <= 800) {
     // small grids (late stages: M <= 6144): 64x32 tiles double the number of workgroups; 13-20 % faster on the
     // M=1536/6144 shapes of tools/gemm_bench.py (SMALLN=1), deep K staged 4 panels per barrier
-    if (nk32 >= 24 && BF) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D && BF ? 4 : 1)>), dim3(blocks(64, 32)), dim3(256), 0, s, p);
+    static const bool no_g2 = getenv("SATRN_GEMM_NO_G2") != nullptr;   // A/B switch
+    static const bool g4 = getenv("SATRN_GEMM_G4") != nullptr;
+    if (nk32 >= 24 && BF && !no_g2 && g4 && blocks(64, 32) <= 512) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D && BF ? 4 : 1), (D && BF ? 4 : 1)>), dim3(blocks(64, 32)), dim3(D && BF ? 1024 : 256), 0, s, p);
+    else if (nk32 >= 24 && BF && !no_g2 && blocks(64, 32) <= 512) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D && BF ? 4 : 1), (D && BF ? 2 : 1)>), dim3(blocks(64, 32)), dim3(D && BF ? 512 : 256), 0, s, p);
+    else if (nk32 >= 24 && BF) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D && BF ? 4 : 1)>), dim3(blocks(64, 32)), dim3(256), 0, s, p);
     else if (nk32 >= 4) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D ? 2 : 1)>), dim3(blocks(64, 32)), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, 1>), dim3(blocks(64, 32)), dim3(256), 0, s, p);
   } else {
