@@ -1361,12 +1361,21 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr) {
       void* dpooled = e.alloc((size_t)B * C * e.esz());
       float* dz2 = (float*)e.alloc((size_t)B * C * 4);
       float* du1 = (float*)e.alloc((size_t)B * S * 4);
-      WORK(e, 0, (double)x->rows * C * e.esz() * 2);
-      LCH(e, launch_se_bwd_gate(e.dt, y->g, x->p, dgate, B, HW, C, e.s));
-      {
+      const int dt = e.dt; void* gp = gate->p; const void* w1 = eb->se_r.fwd; const void* w2 = eb->se_e.fwd;
+      float* g1 = eb->se_r.g; float* gb1 = eb->se_rb.g; float* g2 = eb->se_e.g; float* gb2 = eb->se_eb.g;
+      float* ds1 = e.zalloc((size_t)B * S);
+      bool wide = false;
+      WORK(e, 8.0 * (double)B * C * S, (double)x->rows * C * e.esz() * 2 + (double)C * S * e.esz() * 2);
+      LCH(e, wide = launch_se_bwd_wide(dt, y->g, x->p, gp, u1, w1, w2, dz2, du1, ds1, dpooled, B, HW, C, S, e.s));
+      if (e.dry) wide = true;   // planning pass: same allocations either way
+      if (wide) {
+        // weight gradients of the two SE matrices: optimizer-only -> side stream
+        if (e.prof) { WORK(e, 8.0 * (double)B * C * S, (double)C * S * 8 + (double)B * C * 8); LCH(e, launch_se_bwd(dt, dgate, gp, u1, s1, pooled, w1, w2, dz2, du1, dpooled, g1, gb1, g2, gb2, B, C, S, e.s, 2)); }
+        else if (!e.dry) e.defer([=](hipStream_t ws) { launch_se_bwd(dt, dgate, gp, u1, s1, pooled, w1, w2, dz2, du1, dpooled, g1, gb1, g2, gb2, B, C, S, ws, 2); });
+      } else {
+        WORK(e, 0, (double)x->rows * C * e.esz() * 2);
+        LCH(e, launch_se_bwd_gate(e.dt, y->g, x->p, dgate, B, HW, C, e.s));
         // data path on the main chain; the two weight-gradient products only feed the optimizer -> side stream
-        const int dt = e.dt; void* gp = gate->p; const void* w1 = eb->se_r.fwd; const void* w2 = eb->se_e.fwd;
-        float* g1 = eb->se_r.g; float* gb1 = eb->se_rb.g; float* g2 = eb->se_e.g; float* gb2 = eb->se_eb.g;
         if (e.prof || e.dry) {
           WORK(e, 8.0 * (double)B * C * S, (double)C * S * e.esz() * 2 + (double)B * C * 16);
           LCH(e, launch_se_bwd(dt, dgate, gp, u1, s1, pooled, w1, w2, dz2, du1, dpooled, g1, gb1, g2, gb2, B, C, S, e.s, 3));

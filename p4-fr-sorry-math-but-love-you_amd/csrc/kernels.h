@@ -125,6 +125,9 @@ void launch_bn_act_pool(int dt, const void* y, const float* sums, int sums_rep, 
                         hipStream_t s);
 void launch_se_scale(int dt, const void* x, const void* gate /*[B,C] T*/, void* out, int B, int HW, int C, hipStream_t s);
 // dx (+)= dout*gate + dpool[b,c]/HW ; dgate[b,c] = sum_hw dout*x   (two kernels)
+// data path of the squeeze-and-excite backward in two wide launches (dgate + dz2 + ds1 | du1 + dpooled); false = not taken
+bool launch_se_bwd_wide(int dt, const void* dy, const void* x, const void* gate, const float* u1, const void* W1, const void* W2, float* dz2,
+                        float* du1, float* ds1_zeroed /*[B][S]*/, void* dpooled, int B, int HW, int C, int S, hipStream_t s);
 void launch_se_bwd_gate(int dt, const void* dout, const void* x, void* dgate /*[B,C] T*/, int B, int HW, int C, hipStream_t s);
 void launch_se_bwd_x(int dt, const void* dout, const void* gate, const void* dpool /*[B,C] T or null*/, void* dx, int B,
                      int HW, int C, int beta, hipStream_t s);

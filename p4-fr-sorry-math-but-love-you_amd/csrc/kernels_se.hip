@@ -356,6 +356,153 @@ __global__ __launch_bounds__(1024) void se_bwd_a_kernel(const T* dgate, const T*
   }
 }
 
+// ---- backward of the data path as two WIDE launches (grid B x SEB_G channel groups) instead of a chip-wide gate reduction +
+// one workgroup per image that pulled both matrices (392 KB) through one CU (5.5 + 14 us on the dependent chain):
+//   kernel 1, workgroup (b, g):  dgate = sum_hw dy*x over its channels; dz2 = dgate*gate*(1-gate) (stored for the weight
+//                                gradients); its channels' contribution to ds1 = W2^T dz2 -> atomicAdd into ds1[b][:] (zeroed)
+//   kernel 2, workgroup (b, g):  du1 = ds1 * silu'(u1) (group 0 stores it); dpooled = W1^T du1 for its channels
+// (not in the deterministic mode: the S atomics per workgroup add in arrival order)
+#define SEB_G 8
+// bf16 only (f32 is the deterministic mode, which does not come here); S = 64 hidden units at most, <= 32 chunks per group
+__global__ __launch_bounds__(256) void se_bwd_gate_ds_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate,
+                                                             const bf16_t* __restrict__ W2, float* dz2, float* ds1, int HW, int C, int S) {
+  typedef bf16_t T;
+  constexpr int CH = 8;
+  __shared__ float part[256 * CH];   // [row lane][chunk lane * CH]
+  __shared__ float dz[32 * CH];
+  __shared__ float red[4][64];
+  const int b = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int CC = C / CH, ncg = (CC + SEB_G - 1) / SEB_G;   // chunks per group (<= 32)
+  const int cbeg = grp * ncg, nch = min(ncg, CC - cbeg);     // this group's chunks [cbeg, cbeg + nch)
+  const int cs = nch > 0 ? nch * CH : 0;                     // its channels
+  // expand-matrix rows of this group (cs x S): thread = (16-byte chunk q of a row, channel lane), all requested now
+  const int SQ = S / CH;                 // chunks per row (<= 8)
+  const int q = tid & 7, cl = tid >> 3;  // 8 chunk slots x 32 channel lanes
+  uint4 wraw[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int c = cl + 32 * k;
+    wraw[k] = (c < cs && q < SQ) ? ld16(W2 + (long)(cbeg * CH + c) * S + q * CH) : zero16();
+  }
+  // dgate = sum_hw dy * x: TX chunk lanes (power of two >= nch) x TY row lanes
+  int txl = 0;
+  while ((1 << txl) < nch) ++txl;
+  const int TX = 1 << txl, TY = 256 >> txl;
+  const int tx = tid & (TX - 1), ty = tid >> txl;
+  float a[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) a[j] = 0.f;
+  if (tx < nch) {
+    const long base = (long)b * HW * C + (long)(cbeg + tx) * CH;
+#pragma unroll 4
+    for (int r = ty; r < HW; r += TY) {
+      float d[CH], v[CH];
+      unpack<T>(ld16(dy + base + (long)r * C), d);
+      unpack<T>(ld16(x + base + (long)r * C), v);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) a[j] += d[j] * v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) part[(ty * TX + tx) * CH + j] = a[j];
+  __syncthreads();
+  for (int c = tid; c < cs; c += 256) {
+    const int cx = c / CH, cj = c - cx * CH;
+    float dg = 0.f;
+    for (int y2 = 0; y2 < TY; ++y2) dg += part[(y2 * TX + cx) * CH + cj];
+    const float g = to_f(gate[(long)b * C + cbeg * CH + c]);
+    const float v = dg * g * (1.f - g);
+    dz[c] = v;
+    dz2[(long)b * C + cbeg * CH + c] = v;
+  }
+  __syncthreads();
+  // ds1[j] += sum_c W2[c][j] * dz[c] over this group's channels
+  float acc[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int c = cl + 32 * k;
+    if (c < cs) {
+      float wv[CH];
+      unpack<T>(wraw[k], wv);
+      const float d = dz[c];
+#pragma unroll
+      for (int e = 0; e < CH; ++e) acc[e] += wv[e] * d;
+    }
+  }
+  // lanes of a wave with the same q: xor over lane bits 3..5; then the four waves through LDS
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) red[wave][lane * CH + e] = acc[e];
+  }
+  __syncthreads();
+  if (tid < S) atomicAdd(ds1 + (long)b * S + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+}
+__global__ __launch_bounds__(256) void se_bwd_pool_kernel(const float* __restrict__ ds1, const float* __restrict__ u1, const bf16_t* __restrict__ W1,
+                                                          float* du1, bf16_t* dpooled, int C, int S) {
+  typedef bf16_t T;
+  constexpr int CH = 8;
+  __shared__ float du[64];
+  __shared__ float part[8][32 * CH];
+  const int b = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x;
+  const int CC = C / CH, ncg = (CC + SEB_G - 1) / SEB_G;
+  const int cbeg = grp * ncg, nch = min(ncg, CC - cbeg);
+  const int tx = tid & 31, jg = tid >> 5;   // chunk lane, group of 8 hidden units
+  // the matrix rows of this thread are requested before the hidden-layer gradient they are multiplied with
+  uint4 raw[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int j = jg * 8 + k;
+    raw[k] = (tx < nch && j < S) ? ld16(W1 + (long)j * C + (long)(cbeg + tx) * CH) : zero16();
+  }
+  if (tid < 64) {
+    float v = 0.f;
+    if (tid < S) {
+      v = ds1[(long)b * S + tid] * act_bwd(u1[(long)b * S + tid], ACT_SILU);
+      if (grp == 0) du1[(long)b * S + tid] = v;
+    }
+    du[tid] = v;
+  }
+  __syncthreads();
+  float acc[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float wv[CH];
+    unpack<T>(raw[k], wv);
+    const float d = du[jg * 8 + k];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc[e] += wv[e] * d;
+  }
+#pragma unroll
+  for (int e = 0; e < CH; ++e) part[jg][tx * CH + e] = acc[e];
+  __syncthreads();
+  const int cs = nch > 0 ? nch * CH : 0;
+  for (int c = tid; c < cs; c += 256) {
+    float v = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 8; ++g2) v += part[g2][c];
+    dpooled[(long)b * C + cbeg * CH + c] = from_f<T>(v);
+  }
+}
+// false = shape / mode not taken (the caller runs launch_se_bwd_gate + launch_se_bwd)
+bool launch_se_bwd_wide(int dt, const void* dy, const void* x, const void* gate, const float* u1, const void* W1, const void* W2, float* dz2,
+                        float* du1, float* ds1_zeroed, void* dpooled, int B, int HW, int C, int S, hipStream_t s) {
+  static const bool off = getenv("SATRN_SE_NO_WIDE_BWD") != nullptr;
+  if (off || g_det.on || dt != DT_BF16 || S > 64 || (S % 8) != 0 || (C % 8) != 0 || ((C / 8 + SEB_G - 1) / SEB_G) > 32) return false;
+  hipLaunchKernelGGL(se_bwd_gate_ds_kernel, dim3(B, SEB_G), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gate, (const bf16_t*)W2, dz2, ds1_zeroed,
+                     HW, C, S);
+  hipLaunchKernelGGL(se_bwd_pool_kernel, dim3(B, SEB_G), dim3(256), 0, s, ds1_zeroed, u1, (const bf16_t*)W1, du1, (bf16_t*)dpooled, C, S);
+  return true;
+}
+
 // ---- backward B: weight gradients dW2[c][j] = sum_b dz2[b][c]*s1[b][j], dW1[j][c] = sum_b du1[b][j]*pooled[b][c].
 // thread = (channel c, group of 8 hidden units): no atomics (each thread owns its outputs), 16 accumulators
 __global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* dz2, const float* du1, const float* s1,
