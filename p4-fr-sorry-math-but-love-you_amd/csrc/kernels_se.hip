@@ -131,7 +131,7 @@ __global__ __launch_bounds__(1024) void se_fwd_kernel(const T* x, const T* W1, c
 // ---- forward from pool sums (bf16, S <= 64, C <= 1536): grid (B, SE_G).  Every workgroup computes the whole hidden layer of
 // its image (the reduce matrix is requested into registers at the start: 12 x 16 bytes per thread) and then the gate and
 // x*gate of ITS quarter of the channels, so the image is scaled by four CUs and never pooled by one.
-#define SE_G 4
+#define SE_G 8
 __global__ __launch_bounds__(1024) void se_mlp_scale_kernel(const bf16_t* __restrict__ x, const float* __restrict__ poolsum, const bf16_t* __restrict__ W1,
                                                             const float* b1, const bf16_t* __restrict__ W2, const float* b2, float* pooled, float* u1,
                                                             float* s1, bf16_t* gate, bf16_t* __restrict__ y, int HW, int C, int S) {
