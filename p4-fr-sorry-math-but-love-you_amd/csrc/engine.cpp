@@ -2095,7 +2095,7 @@ static int greedy_body(Model* m, const float* img, const float* src_in, int B, i
     //     stream capture (the check synchronises).
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
-    if (cap == hipStreamCaptureStatusNone && !rules) {
+    if (cap == hipStreamCaptureStatusNone) {
       const size_t sb = decode_pipe_scratch_bytes(dp);
       void* scratch = e.alloc(sb);
       if (!e.oom && launch_decode_pipe(e.dt, dp, scratch, sb, s) == 0) {

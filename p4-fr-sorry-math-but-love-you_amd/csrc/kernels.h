@@ -229,6 +229,7 @@ struct PipeP {
   float* logits; int64_t* ids;
   int B, steps, D, F, V, H, Nsrc, sos;
   const PipeRole* roles; unsigned long long* mail; int* err; long long timeout_ticks;
+  const int32_t* rules;  // optional DecodingManager table (sift.h): applied by the generator role, which keeps each of its images' memory
   long long* prof;  // optional [2 * nroles]: wall-clock ticks spent waiting / in total (SATRN_PIPE_PROF)
 };
 size_t decode_pipe_scratch_bytes(const DecodeP& p);

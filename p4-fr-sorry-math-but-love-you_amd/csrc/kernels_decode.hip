@@ -630,10 +630,12 @@ template <typename T>
 __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ int s_fail, s_tok;
+  __shared__ SiftState s_sift[128];   // generator role: DecodingManager memory of each image it serves
   const PipeRole role = p.roles[blockIdx.x];
   const int tid = threadIdx.x, D = p.D, H = p.H, hd = D / H;
   const int l = role.layer, NL = p.nlayers;
   if (tid == 0) s_fail = 0;
+  if (tid < 128) s_sift[tid] = SiftState{p.sos, 1, 0, 0};
   PipeCtx c;
   c.p = &p; c.mail = (gu64_t*)p.mail; c.err = (gi32_t*)p.err; c.s_fail = &s_fail;
   c.t_end = (long long)wall_clock64() + (long long)p.timeout_ticks;
@@ -753,6 +755,18 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
           gemv<T, 2, PIPE_THREADS>(wl, role.N, 0, l_bias, xT, y, role.N, D, ACT_NONE);
           LDS_BARRIER();
           float* out = p.logits + ((long)img * p.steps + t) * p.V;
+          if (p.rules) {
+            // DecodingManager.sift (postprocessing.py:189-246) as in the per-image kernel: the step's output is the masked
+            // softmax, the next token its argmax; the sequence's memory lives in this role's LDS (an image always comes to
+            // the same shard)
+            SiftState& st = s_sift[(img - role.img0) / role.istep];
+            if (tid < 64) {
+              const int bi = sift_wave(y, out, p.V, st, p.rules, tid);
+              if (tid == 0) { s_tok = bi; p.ids[(long)img * p.steps + t] = bi; }
+            }
+            LDS_BARRIER();
+            if (tid == 0) sift_record(st, s_tok, p.rules, p.V);
+          } else {
           for (int i = tid; i < p.V; i += PIPE_THREADS) out[i] = y[i];
           if (tid < 64) {
             float best = -INFINITY;
@@ -765,6 +779,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
               if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
             }
             if (tid == 0) { s_tok = bi; p.ids[(long)img * p.steps + t] = bi; }
+          }
           }
           LDS_BARRIER();
           if (t + 1 < p.steps) {
@@ -908,7 +923,7 @@ size_t decode_pipe_scratch_bytes(const DecodeP& p) {
 }
 int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_bytes, hipStream_t s) {
   const bool off = getenv("SATRN_DECODE_NO_PIPE") != nullptr;  // read per call: tests switch between the two decoders in one process
-  if (off || dt != DT_BF16 || d.rules || d.D != 256 || d.F != 1024 || d.H * (d.D / d.H) != d.D || (d.D / d.H) % 8 || (d.H & 1) || d.V > 256 || d.B > 112 /*larger batches: the per-image kernel (1 workgroup per image, no hand-offs) wins*/ || d.nlayers < 1 || d.nlayers > 4 ||
+  if (off || dt != DT_BF16 || d.D != 256 || d.F != 1024 || d.H * (d.D / d.H) != d.D || (d.D / d.H) % 8 || (d.H & 1) || d.V > 256 || d.B > 112 /*larger batches: the per-image kernel (1 workgroup per image, no hand-offs) wins*/ || d.nlayers < 1 || d.nlayers > 4 ||
       d.B < 1 || scratch_bytes < decode_pipe_scratch_bytes(d))
     return -1;
   typedef bf16_t T;
@@ -986,6 +1001,7 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
   memset(&p, 0, sizeof(p));
   for (int l = 0; l < d.nlayers; ++l) p.L[l] = d.L[l];
   p.nlayers = d.nlayers; p.embed = d.embed; p.pe = d.pe; p.logits = d.logits; p.ids = d.ids;
+  p.rules = d.rules;
   p.B = B; p.steps = d.steps; p.D = D; p.F = F; p.V = d.V; p.H = d.H; p.Nsrc = d.Nsrc; p.sos = d.sos;
   char* sc = (char*)scratch;
   p.err = (int*)sc;
@@ -1015,9 +1031,10 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
   size_t sh = std::max(2 * half_w + fl_att_cross * 4, half_w + fl_att_self * 4);   // query + cross-attention role | self-attention role
   sh = std::max(sh, (size_t)D * D * sizeof(T) + 256 + fl_common * 4);
   sh = std::max(sh, (((size_t)d.V * D * sizeof(T) + 255) & ~(size_t)255) + fl_common * 4);
-  if (sh > 160 * 1024 - 64) return -1;
+  const size_t lds_dyn_max = 160 * 1024 - 4096;   // the kernel's static LDS (flags, the generator's DecodingManager memories) is ~2.1 KB
+  if (sh > lds_dyn_max) return -1;
   static bool a = false;
-  if (!a) { PIPE_CK(hipFuncSetAttribute((const void*)decode_pipe_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); a = true; }
+  if (!a) { PIPE_CK(hipFuncSetAttribute((const void*)decode_pipe_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn_max)); a = true; }
   static const bool want_prof = getenv("SATRN_PIPE_PROF") != nullptr;  // debugging aid: per-role wait / total wall-clock ticks
   static long long* prof_buf = nullptr;
   if (want_prof) {

@@ -71,3 +71,38 @@ def test_pipelined_decoder_second_call_and_growing_batch():
         lg1, ids1 = _greedy(model, img.cuda(), steps, pipe=True)
         assert (ids0[:, 0] == ids1[:, 0]).all() or (lg1[:, 0] - lg0[:, 0]).abs().max().item() < 0.05
         assert torch.isfinite(lg1).all()
+
+
+def test_pipelined_decoder_with_decoding_manager_rules():
+    """DecodingManager rules inside the pipeline's generator role (the reference's default at inference, inference.py:48):
+    same masked probabilities / ids as the per-image kernel's sift wherever the masked top-1 / top-2 margin is clear, and the
+    SAME entries are exactly zero (the blacklist depends on the ids only)."""
+    from tests.test_rules_gpu import _manager, GOLD
+    table = np.load(GOLD)["table"]
+    cfg = dict(O.CFG_EFF)
+    V = len(table) - 8
+    cfg["num_classes"] = V
+    model, sd = build(cfg, 128, 384, "bf16", 8)
+    model.eval()
+    model.decoder.manager = _manager(table)
+    B, steps = 12, 40
+    img, _ = O.det_inputs(B, 1, 128, 384, 4, seed=55)
+    pr0, ids0 = _greedy(model, img.cuda(), steps, pipe=False)
+    pr1, ids1 = _greedy(model, img.cuda(), steps, pipe=True)
+    assert torch.isfinite(pr1).all()
+    assert (pr1.sum(-1) <= 1.0 + 1e-3).all() and (pr1 >= 0).all()
+    top2 = torch.topk(pr0, 2, dim=-1).values
+    margin = top2[..., 0] - top2[..., 1]
+    agree = 0
+    for b in range(B):
+        same = (ids0[b] == ids1[b]).int()
+        first_diff = int(same.argmin().item()) if same.min().item() == 0 else steps
+        agree += first_diff
+        if first_diff < steps:
+            assert margin[b, first_diff].item() < 2e-2, f"image {b} step {first_diff}: ids differ at a clear margin"
+        n = min(first_diff + 1, steps)   # the blacklist of step t depends on the ids before t
+        assert ((pr0[b, :n] == 0) == (pr1[b, :n] == 0)).all(), f"image {b}: different entries blacklisted"
+        if first_diff > 0:
+            assert (pr1[b, :first_diff] - pr0[b, :first_diff]).abs().max().item() < 2e-2
+    print(f"[pipe + rules] identical prefix: {agree} of {B * steps} tokens")
+    assert agree >= 0.5 * B * steps
