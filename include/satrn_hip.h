@@ -111,6 +111,22 @@ int satrn_layernorm_bwd(int dtype, const void* dout, const void* a, const void* 
                         const float* mean_rstd, void* da, void* db, int acc_a, int acc_b, float* dweight, float* dbias,
                         long R, int C, void* stream);
 
+/* Squeeze-and-excite of the EfficientNetV2-S MBConv blocks (timm SqueezeExcite behind networks/EfficientSATRN.py:74,84):
+ * gate[b] = sigmoid(W2 * silu(W1 * mean_hw(x[b]) + b1) + b2), y = x * gate.  x, y: [B][HW][C]; W1 [S][C] and W2 [C][S] in the
+ * compute dtype (the packed copies); pooled [B][C], u1 / s1 [B][S] fp32 (saved for the backward); gate [B][C].
+ * pool_sums: optional [B][C] fp32 sums over HW of x (what the BatchNorm pass in front accumulates in the training step); when
+ * given (bf16, S <= 64, C <= 1536) the MLP + scale run as one launch over B x 8 channel groups, otherwise pool + MLP per image
+ * and the scale as a second launch.
+ * backward (data path): dz2 [B][C], du1 [B][S] fp32 (inputs of the weight-gradient products), dpooled [B][C] in the compute
+ * dtype; the gradient wrt x is dy*gate + dpooled/HW (folded into the BatchNorm backward that follows in the engine).
+ * ds1_zeroed: [B][S] fp32 zeros (scratch of the two-launch wide form; NULL: the per-image form is used, which needs
+ * dgate_scratch [B][C] in the compute dtype instead). */
+int satrn_se_fwd(int dtype, const void* x, const void* W1, const float* b1, const void* W2, const float* b2, const float* pool_sums,
+                 float* pooled, float* u1, float* s1, void* gate, void* y, int B, int HW, int C, int S, void* stream);
+int satrn_se_bwd(int dtype, const void* dy, const void* x, const void* gate, const float* u1, const void* W1, const void* W2,
+                 float* dz2, float* du1, float* ds1_zeroed, void* dgate_scratch, void* dpooled, int B, int HW, int C, int S,
+                 void* stream);
+
 /* Adaptive 2D positional encoding, networks/EfficientSATRN.py:135-154: out = x + g0*hpos[h] + g1*wpos[w]
  * with gate [B][2C] = sigmoid(dense1(relu(dense0(mean_hw x)))) computed by satrn_pool_hw + satrn_linear_fwd. */
 int satrn_pool_hw(int dtype, const void* x, void* out, int B, int HW, int C, void* stream);

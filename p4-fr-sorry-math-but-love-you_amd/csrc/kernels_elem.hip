@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ 
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
 }
 bool bn_act_pool_ok(long M, int C, int HW) {
-  static const bool off = getenv("SATRN_NO_FUSED_POOL") != nullptr;
+  const bool off = getenv("SATRN_NO_FUSED_POOL") != nullptr;   // read per call: tests compare the fused and the plain forms in one process
   return !off && !g_det.on && HW > 0 && (HW % BNP_ROWS) == 0 && (M % HW) == 0;
 }
 void launch_bn_act_pool(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv,
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(256) void dwconv_s1_red_kernel(const T* __restrict_
 }
 
 static bool dwconv_fuses_stats(int H, int W, int OH, int OW, int stride, int pt, int pl) {
-  static const bool off = getenv("SATRN_DW_NO_FUSED_RED") != nullptr;
+  const bool off = getenv("SATRN_DW_NO_FUSED_RED") != nullptr;   // read per call (tests)
   return !off && !g_det.on && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && (W & 1) == 0;
 }
 

@@ -364,7 +364,7 @@ static void launch_gemm_t(const GemmP& p, hipStream_t s) {
   } else if (D && p.N >= 64 && blocks(64, 64) <= 800) {
     // small grids (late stages: M <= 6144): 64x32 tiles double the number of workgroups; 13-20 % faster on the
     // M=1536/6144 shapes of tools/gemm_bench.py (SMALLN=1), deep K staged 4 panels per barrier
-    static const bool no_g2 = getenv("SATRN_GEMM_NO_G2") != nullptr;   // A/B switch
+    const bool no_g2 = getenv("SATRN_GEMM_NO_G2") != nullptr;   // A/B switch, read per call (tests)
     static const bool g4 = getenv("SATRN_GEMM_G4") != nullptr;
     if (nk32 >= 24 && BF && !no_g2 && g4 && blocks(64, 32) <= 512) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D && BF ? 4 : 1), (D && BF ? 4 : 1)>), dim3(blocks(64, 32)), dim3(D && BF ? 1024 : 256), 0, s, p);
     else if (nk32 >= 24 && BF && !no_g2 && blocks(64, 32) <= 512) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D && BF ? 4 : 1), (D && BF ? 2 : 1)>), dim3(blocks(64, 32)), dim3(D && BF ? 512 : 256), 0, s, p);

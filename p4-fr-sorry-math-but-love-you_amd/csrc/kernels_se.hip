@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void se_bwd_pool_kernel(const float* __restric
 // false = shape / mode not taken (the caller runs launch_se_bwd_gate + launch_se_bwd)
 bool launch_se_bwd_wide(int dt, const void* dy, const void* x, const void* gate, const float* u1, const void* W1, const void* W2, float* dz2,
                         float* du1, float* ds1_zeroed, void* dpooled, int B, int HW, int C, int S, hipStream_t s) {
-  static const bool off = getenv("SATRN_SE_NO_WIDE_BWD") != nullptr;
+  const bool off = getenv("SATRN_SE_NO_WIDE_BWD") != nullptr;   // read per call (tests)
   if (off || g_det.on || dt != DT_BF16 || S > 64 || (S % 8) != 0 || (C % 8) != 0 || ((C / 8 + SEB_G - 1) / SEB_G) > 32) return false;
   hipLaunchKernelGGL(se_bwd_gate_ds_kernel, dim3(B, SEB_G), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gate, (const bf16_t*)W2, dz2, ds1_zeroed,
                      HW, C, S);

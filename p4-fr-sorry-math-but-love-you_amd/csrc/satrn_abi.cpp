@@ -201,6 +201,27 @@ int satrn_layernorm_bwd(int dt, const void* dout, const void* a, const void* b, 
   return done("layernorm_bwd");
 }
 
+int satrn_se_fwd(int dt, const void* x, const void* W1, const float* b1, const void* W2, const float* b2, const float* pool_sums,
+                 float* pooled, float* u1, float* s1, void* gate, void* y, int B, int HW, int C, int S, void* st) {
+  CHK_DT(dt);
+  if (B <= 0 || HW <= 0 || C <= 0 || S <= 0 || (C % 8) != 0) return fail(-1, "satrn_se_fwd: bad shape");
+  if (!(pool_sums && launch_se_mlp_scale(dt, x, pool_sums, W1, b1, W2, b2, pooled, u1, s1, gate, y, B, HW, C, S, S(st)))) {
+    launch_se_fwd(dt, x, W1, b1, W2, b2, pooled, u1, s1, gate, B, HW, C, S, S(st));
+    launch_se_scale(dt, x, gate, y, B, HW, C, S(st));
+  }
+  return done("se_fwd");
+}
+int satrn_se_bwd(int dt, const void* dy, const void* x, const void* gate, const float* u1, const void* W1, const void* W2,
+                 float* dz2, float* du1, float* ds1_zeroed, void* dgate_scratch, void* dpooled, int B, int HW, int C, int S, void* st) {
+  CHK_DT(dt);
+  if (B <= 0 || HW <= 0 || C <= 0 || S <= 0 || (C % 8) != 0) return fail(-1, "satrn_se_bwd: bad shape");
+  if (!(ds1_zeroed && launch_se_bwd_wide(dt, dy, x, gate, u1, W1, W2, dz2, du1, ds1_zeroed, dpooled, B, HW, C, S, S(st)))) {
+    if (!dgate_scratch) return fail(-1, "satrn_se_bwd: the per-image form needs dgate_scratch [B][C]");
+    launch_se_bwd_gate(dt, dy, x, dgate_scratch, B, HW, C, S(st));
+    launch_se_bwd(dt, dgate_scratch, gate, u1, nullptr, nullptr, W1, W2, dz2, du1, dpooled, nullptr, nullptr, nullptr, nullptr, B, C, S, S(st), 1);
+  }
+  return done("se_bwd");
+}
 int satrn_pool_hw(int dt, const void* x, void* out, int B, int HW, int C, void* st) {
   CHK_DT(dt);
   if (chk_c(dt, C, "C")) return -1;

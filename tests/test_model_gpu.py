@@ -384,3 +384,46 @@ def test_segmented_backward_equals_whole_backward(golden_dir, name):
     import satrn_amd
     with pytest.raises(satrn_amd.SatrnError):
         model.train_step(imgd, expd, 0.0, phase=18)  # out of order
+
+
+_FUSED_SWITCHES = ("SATRN_NO_FUSED_POOL", "SATRN_DW_NO_FUSED_RED", "SATRN_GEMM_NO_G2", "SATRN_SE_NO_WIDE_BWD")
+
+
+def test_fused_chain_kernels_equal_their_plain_forms(golden_dir, monkeypatch):
+    """Round-2 chain kernels (BatchNorm + SE pool, depthwise conv + statistics, SE MLP + scale, wide SE backward, two-group
+    small-tile GEMM) against the kernels they replaced: same bf16 model and inputs in one process (the switches are read per
+    call).  bf16 training with atomic reductions is noisy from run to run (a BatchNorm statistic moving in its last bit flips
+    ReLU / max-pool decisions), so the yardstick is that noise itself, measured here by running the PLAIN kernels twice: the
+    fused kernels must not be further from the plain ones than the plain ones are from themselves (x2 + a floor)."""
+    _, meta, cfg = load_case(golden_dir, "eff_c2_b2")
+    H, W, T = (int(meta[k]) for k in ("height", "width", "seq_len"))
+    B = 16   # BatchNorm statistics over >= 768 samples in every layer: less flip noise than the 2-image golden case
+    img, expected = O.det_inputs(B, cfg["rgb"], H, W, T, seed=77, pad_tail=0)
+    imgd, expd = img.cuda(), expected.cuda()
+
+    def run(plain):
+        for k in _FUSED_SWITCHES:
+            if plain:
+                monkeypatch.setenv(k, "1")
+            else:
+                monkeypatch.delenv(k, raising=False)
+        model, _ = build(cfg, H, W, "bf16", int(meta["wseed"]))
+        model.train()
+        logits = model(imgd, expd, True, 1.0)
+        loss = model.criterion(logits.transpose(1, 2), expd[:, 1:])
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        g = torch.cat([p.grad.detach().float().flatten() for p in model.parameters()])
+        return logits.detach().float().clone(), g.clone()
+
+    def dist(a, b):
+        (la, ga), (lb, gb) = a, b
+        return relerr(lb, la), (gb - ga).norm().item() / ga.norm().item()
+
+    p0, p1, f0 = run(True), run(True), run(False)
+    nl, ng = dist(p0, p1)
+    fl, fg = dist(p0, f0)
+    print(f"[plain vs plain] logits rel err {nl:.3e}, gradient rel-L2 {ng:.3e}   [fused vs plain] {fl:.3e}, {fg:.3e}")
+    assert fl < 2.0 * nl + 5e-3
+    assert fg < 2.0 * ng + 5e-2

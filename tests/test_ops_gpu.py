@@ -99,6 +99,8 @@ def pack_dense(lib, w, dt, ldb=None):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K,act", [(100, 64, 64, 0), (300, 24, 216, 1), (257, 245, 256, 0), (4096, 1024, 256, 1),
                                        (64, 768, 256, 3), (1536, 512, 512, 0), (33, 40, 960, 0),
+                                       # deep K on a small grid: two wave groups per tile split the k-panels (bf16)
+                                       (1536, 256, 1536, 0), (6144, 160, 960, 1), (200, 72, 800, 0),
                                        # M <= 64: the skinny kernel (register-resident operands, K split over the four waves)
                                        (32, 256, 1024, 1), (7, 245, 256, 0), (1, 64, 64, 0), (48, 1024, 256, 1), (32, 256, 256, 0),
                                        (17, 40, 1056, 0)])
@@ -444,3 +446,50 @@ def test_dropout_statistics(lib):
     frac = 1 - kept.float().mean().item()
     assert abs(frac - 0.1) < 0.01, frac
     torch.testing.assert_close(y1[kept], y0[kept] / 0.9, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,HW,C,S,wide", [(3, 48, 1536, 64, False), (3, 48, 1536, 64, True), (2, 192, 960, 40, True), (4, 192, 512, 32, True),
+                                            (2, 35, 96, 8, False), (2, 192, 256, 16, True)])
+def test_squeeze_excite(lib, dt, B, HW, C, S, wide):
+    """timm SqueezeExcite (networks/EfficientSATRN.py:74,84): forward and the data path of the backward, in the per-image form
+    and (wide=True) in the forms the training step uses -- MLP + scale from pool sums over B x 8 channel groups, backward as
+    two wide launches.  The wide forms are bf16-only; for f32 the call takes the per-image form (same expected values)."""
+    x = q(rnd(B, HW, C, seed=1), dt)
+    W1, W2 = q(rnd(S, C, seed=2, scale=0.05), dt), q(rnd(C, S, seed=3, scale=0.2), dt)
+    b1, b2 = rnd(S, seed=4, scale=0.1), rnd(C, seed=5, scale=0.1)
+    dy = q(rnd(B, HW, C, seed=6), dt)
+    # reference
+    pooled = x.mean(1)
+    u1 = pooled @ W1.t() + b1
+    s1 = u1 * torch.sigmoid(u1)
+    gate = q(torch.sigmoid(s1 @ W2.t() + b2), dt)
+    y = x * gate[:, None, :]
+    dgate = (dy * x).sum(1)
+    dz2 = dgate * gate * (1 - gate)
+    ds1 = dz2 @ W2
+    sg = torch.sigmoid(u1)
+    du1 = ds1 * (sg * (1 + u1 * (1 - sg)))
+    dpooled = du1 @ W1
+    # device
+    xd, W1d, W2d, dyd = dev(x, dt), dev(W1, dt), dev(W2, dt), dev(dy, dt)
+    b1d, b2d = dev(b1), dev(b2)
+    sums = dev(x.sum(1)) if wide else None
+    pooled_d, u1_d, s1_d = (torch.zeros(B, n, device="cuda") for n in (C, S, S))
+    gate_d = torch.zeros(B, C, dtype=tdt(dt), device="cuda")
+    y_d = torch.zeros(B, HW, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_se_fwd(dti(dt), P(xd), P(W1d), P(b1d), P(W2d), P(b2d), P(sums), P(pooled_d), P(u1_d), P(s1_d), P(gate_d), P(y_d), B, HW, C, S, st()))
+    close(pooled_d, pooled, dt, "se pooled", bf16_tol=1e-3)
+    close(u1_d, u1, dt, "se u1", bf16_tol=1e-2)
+    close(gate_d, gate, dt, "se gate", bf16_tol=1e-2)
+    close(y_d, y, dt, "se y", bf16_tol=2e-2)
+    dz2_d, du1_d = torch.zeros(B, C, device="cuda"), torch.zeros(B, S, device="cuda")
+    ds1_d = torch.zeros(B, S, device="cuda") if wide else None
+    dgs = torch.zeros(B, C, dtype=tdt(dt), device="cuda")
+    dpool_d = torch.zeros(B, C, dtype=tdt(dt), device="cuda")
+    # the backward is checked with the REFERENCE's forward values (gate, u1) so that its error stands alone
+    ok(lib, lib.satrn_se_bwd(dti(dt), P(dyd), P(xd), P(dev(gate, dt)), P(dev(u1)), P(W1d), P(W2d), P(dz2_d), P(du1_d), P(ds1_d), P(dgs), P(dpool_d), B, HW, C, S,
+                             st()))
+    close(dz2_d, dz2, dt, "se dz2", bf16_tol=1e-2)
+    close(du1_d, du1, dt, "se du1", bf16_tol=1e-2)
+    close(dpool_d, dpooled, dt, "se dpooled", bf16_tol=2e-2)
