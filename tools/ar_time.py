@@ -1,20 +1,42 @@
-"""Time the train-time autoregressive branch (teacher_forcing_ratio = 0: networks/EfficientSATRN.py:496-525) forward + backward
-next to the teacher-forced one, EfficientSATRN bs32 128x384 T=128 bf16."""
-import os, sys, time
-import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
+"""Train-time autoregressive branch (teacher_forcing_ratio = 0: networks/EfficientSATRN.py:496-525) forward + backward, module
+API, EfficientSATRN bs32 128x384 T=128, next to the teacher-forced branch (run on the GPU box).
+SATRN_TIMING_SKIP_WGRAD=1 drops the weight-gradient launches (wrong gradients): what the dependent chain alone costs."""
+import os
+import sys
+import time
 
-model = bench.make_model("bf16", 128, 384, 0.1).to("cuda")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import bench  # noqa: E402
+
+dev = torch.device("cuda:0")
+H, W, T, B = 128, 384, 128, 32
+torch.manual_seed(21)
+model = bench.make_model("bf16", H, W, 0.1).to(dev)
 model.train()
-img, exp = bench.synth(int(os.environ.get("B", 32)), 128, 384, int(os.environ.get("T", 128)), 21, "cuda")
-for tf in (1.0, 0.0):
-    for it in range(3):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        logits = model(img, exp, True, tf)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
+img, exp = bench.synth(B, H, W, T, 21, dev)
+
+
+def run(tf_ratio, n):
+    fw = bw = 0.0
+    for i in range(n + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        logits = model(img, exp, True, tf_ratio)
         loss = model.criterion(logits.transpose(1, 2), exp[:, 1:])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         model.zero_grad()
         loss.backward()
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-    print(f"tf={tf}: forward {1e3*(t1-t0):.1f} ms, loss+backward {1e3*(t2-t1):.1f} ms, loss {loss.item():.4f}", flush=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if i:
+            fw += t1 - t0
+            bw += t2 - t1
+    return fw / n * 1e3, bw / n * 1e3
+
+
+for name, r in (("teacher-forced", 1.0), ("autoregressive", 0.0)):
+    run(r, 3)  # warm-up: the autograd thread's first backward calls take 50-70 ms
+    f, b = run(r, 4)
+    print(f"{name:15s}: forward {f:7.2f} ms, backward {b:7.2f} ms, total {f + b:7.2f} ms")
