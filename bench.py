@@ -161,6 +161,15 @@ def precision_report(H, W, T, B, dev):
     return res, f32
 
 
+def _decode_traffic():
+    """memory-side bytes per decode STEP of the pipelined decoder, from the committed PMC passes (None if absent)"""
+    try:
+        d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_decode_traffic.json")))
+        return round(d["families"]["decode_pipe"]["hbm_bytes_per_launch"] / 231.0)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def swin_report(dev, B=16, T=128):
     """BASELINE configs[3]: SwinTRN (networks/SWIN.py: Swin-B/384 encoder + SWIN.yaml decoder) training step, bf16, batch 16.
     The reference cannot run 256x256 (PatchEmbed asserts 384, 64 patches % window 12 != 0: SURVEY section 2 row 3), so this is
@@ -410,6 +419,7 @@ def main():
                 out["greedy_decode"]["roofline"] = dict(bound="hbm", algorithmic_bytes_per_step=38.0e6, us_per_step=round(step_us, 1),
                                                         achieved=round(38.0e6 / step_us / 1e3, 1), peak=8000.0, unit="GB/s",
                                                         frac=round(38.0e6 / step_us / 1e3 / 8000.0, 4), encoder_ms=round(esec * 1e3, 2),
+                                                        traffic=_decode_traffic(), traffic_source="profiles/r02_pmc_decode_traffic.json (memory-side bytes of the whole 231-step decode launch / 231)",
                                                         kernel="decode_pipe_kernel (one persistent workgroup per decoder role, weights resident in LDS, images pipelined through the roles)",
                                                         note="latency-bound, not HBM-bound: a token is a dependent chain of 13 role hops per step (3 layers x [Q/K/V, self-attention + out-projection, LayerNorm + cross-attention, LayerNorm + feed-forward] + generator), and at batch 64 the 244 role workgroups are ~80 % busy; the weights never leave LDS, so the 38 MB/step figure is what a weight-streaming decoder would move, kept as the algorithmic unit of SURVEY 8d")
                 # the per-image kernel of round 1 (one workgroup per image streams every weight each step), kept as the

@@ -30,6 +30,12 @@ python3 tools/pmc_mfma.py gpurun_out/pmc_region "profiles/${TAG}_mfma_busy.json"
 python3 tools/enc_attn_region.py > "profiles/${TAG}_enc_attn_region.json" 2> /dev/null
 python3 tools/enc_attn_region.py --batch 1024 --iters 50 > "profiles/${TAG}_enc_attn_region_b1024.json" 2> /dev/null
 echo "pmc mfma (region) done"
+# greedy decode (64 x 231, pipelined): memory-side bytes of the one decode launch
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_dfetch -- python3 tools/decode_time.py > gpurun_out/pmc_dfetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_dwrite -- python3 tools/decode_time.py > gpurun_out/pmc_dwrite.log 2>&1
+python3 tools/pmc_traffic.py gpurun_out/pmc_dfetch gpurun_out/pmc_dwrite "profiles/${TAG}_pmc_decode_traffic.json" "greedy decode 64 x 231 (tools/decode_time.py: per-image kernel then pipelined decoder, 2 + 4 launches each); bytes are per LAUNCH = per whole decode"
+rm -rf gpurun_out/pmc_dfetch gpurun_out/pmc_dwrite
+echo "pmc decode done"
 python3 bench.py > "$OUT/default.log" 2>&1
 grep '^{' "$OUT/default.log" > "profiles/${TAG}_bench_default.json"
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
