@@ -923,7 +923,7 @@ size_t decode_pipe_scratch_bytes(const DecodeP& p) {
 }
 int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_bytes, hipStream_t s) {
   const bool off = getenv("SATRN_DECODE_NO_PIPE") != nullptr;  // read per call: tests switch between the two decoders in one process
-  if (off || dt != DT_BF16 || d.D != 256 || d.F != 1024 || d.H * (d.D / d.H) != d.D || (d.D / d.H) % 8 || (d.H & 1) || d.V > 256 || d.B > 112 /*larger batches: the per-image kernel (1 workgroup per image, no hand-offs) wins*/ || d.nlayers < 1 || d.nlayers > 4 ||
+  if (off || dt != DT_BF16 || d.D != 256 || d.F != 1024 || d.H * (d.D / d.H) != d.D || (d.D / d.H) % 8 || (d.H & 1) || d.V > 256 || d.B > (getenv("SATRN_PIPE_MAX_B") ? atoi(getenv("SATRN_PIPE_MAX_B")) : 112) /*larger batches: the per-image kernel (1 workgroup per image, no hand-offs) wins*/ || d.nlayers < 1 || d.nlayers > 4 ||
       d.B < 1 || scratch_bytes < decode_pipe_scratch_bytes(d))
     return -1;
   typedef bf16_t T;
