@@ -631,11 +631,13 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ int s_fail, s_tok;
   __shared__ SiftState s_sift[128];   // generator role: DecodingManager memory of each image it serves
+  __shared__ int32_t s_rules[264];    // ... and the rule table (V + 8 words, V <= 256): the sift reads it per candidate token
   const PipeRole role = p.roles[blockIdx.x];
   const int tid = threadIdx.x, D = p.D, H = p.H, hd = D / H;
   const int l = role.layer, NL = p.nlayers;
   if (tid == 0) s_fail = 0;
   if (tid < 128) s_sift[tid] = SiftState{p.sos, 1, 0, 0};
+  if (p.rules && role.type == PR_GEN && tid < p.V + 8) s_rules[tid] = p.rules[tid];
   PipeCtx c;
   c.p = &p; c.mail = (gu64_t*)p.mail; c.err = (gi32_t*)p.err; c.s_fail = &s_fail;
   c.t_end = (long long)wall_clock64() + (long long)p.timeout_ticks;
@@ -761,11 +763,11 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
             // the same shard)
             SiftState& st = s_sift[(img - role.img0) / role.istep];
             if (tid < 64) {
-              const int bi = sift_wave(y, out, p.V, st, p.rules, tid);
+              const int bi = sift_wave(y, out, p.V, st, s_rules, tid);
               if (tid == 0) { s_tok = bi; p.ids[(long)img * p.steps + t] = bi; }
             }
             LDS_BARRIER();
-            if (tid == 0) sift_record(st, s_tok, p.rules, p.V);
+            if (tid == 0) sift_record(st, s_tok, s_rules, p.V);
           } else {
           for (int i = tid; i < p.V; i += PIPE_THREADS) out[i] = y[i];
           if (tid < 64) {
@@ -947,7 +949,7 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
   int SA = knob("SATRN_PIPE_ATT_SHARDS", 8), SX = knob("SATRN_PIPE_XATT_SHARDS", 6), SM = knob("SATRN_PIPE_MV_SHARDS", 4);
   // SQ: q / k(in) / v(in) projections (on every image's path, with the LayerNorm recompute); SH: the history projections and the
   // combine role (off the path: throughput only); SM: feed-forward slabs; ST: the two LayerNorm publishers (off the path)
-  int SQ = knob("SATRN_PIPE_QKV_SHARDS", 4), SH = knob("SATRN_PIPE_HIST_SHARDS", 2), ST = knob("SATRN_PIPE_LN_SHARDS", 2), SG = knob("SATRN_PIPE_GEN_SHARDS", 4);
+  int SQ = knob("SATRN_PIPE_QKV_SHARDS", 4), SH = knob("SATRN_PIPE_HIST_SHARDS", 2), ST = knob("SATRN_PIPE_LN_SHARDS", 2), SG = knob("SATRN_PIPE_GEN_SHARDS", d.rules ? 6 : 4);
   {  // one workgroup per compute unit: scale the shard counts down until the role count fits the chip
     auto count = [&]() { return d.nlayers * (3 * SQ + 3 * SH + 2 * SA + 2 * ST + 2 * SX + PIPE_NFF * SM) + SG; };
     while (count() > 250 && (SA > 1 || SX > 1 || SM > 1 || ST > 1 || SQ > 1 || SH > 1)) {
@@ -1031,7 +1033,7 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
   size_t sh = std::max(2 * half_w + fl_att_cross * 4, half_w + fl_att_self * 4);   // query + cross-attention role | self-attention role
   sh = std::max(sh, (size_t)D * D * sizeof(T) + 256 + fl_common * 4);
   sh = std::max(sh, (((size_t)d.V * D * sizeof(T) + 255) & ~(size_t)255) + fl_common * 4);
-  const size_t lds_dyn_max = 160 * 1024 - 4096;   // the kernel's static LDS (flags, the generator's DecodingManager memories) is ~2.1 KB
+  const size_t lds_dyn_max = 160 * 1024 - 4096;   // the kernel's static LDS (flags, the generator's DecodingManager memories and rule table) is ~3.2 KB
   if (sh > lds_dyn_max) return -1;
   static bool a = false;
   if (!a) { PIPE_CK(hipFuncSetAttribute((const void*)decode_pipe_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn_max)); a = true; }
