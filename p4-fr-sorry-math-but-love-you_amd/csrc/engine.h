@@ -101,7 +101,7 @@ struct Model {
   Wt conv_last; BNp bn_last;
   // SwinTRN encoder
   Wt sw_patch; Vec sw_patch_b, sw_ape; LNp sw_patch_norm, sw_norm; std::vector<SwinStage> swin; Wt sw_head; Vec sw_head_b;
-  struct SwinGeo { int res, ws, shift; size_t off; }; std::vector<SwinGeo> sw_geo;  // shifted-window mask tables in the persistent region
+  struct SwinGeo { int res, ws, shift; size_t off; size_t off_lab; }; std::vector<SwinGeo> sw_geo;  // shifted-window mask tables ([nW][N][N] fp32) and region labels ([nW][N] bytes) in the persistent region
   Wt pe_d0, pe_d1; Vec pe_b0, pe_b1;
   std::vector<EncLayer> enc;
   Wt embed;  // [V+1][Dd] (gathered directly from the fp32 master)

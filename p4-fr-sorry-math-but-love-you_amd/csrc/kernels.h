@@ -78,6 +78,10 @@ struct AttnP {
   // window attention (networks/SWIN.py:163-183): scores += bias[h][i][j] (relative position bias, shared by all windows) and
   // += wmask[b % nW][i][j] (0 / -100 shifted-window mask); both fp32 with row stride Lk, either may be null
   const float* bias; const float* wmask; int nW;
+  // the same two terms computed INSIDE the kernel (no [H][N][N] / [nW][N][N] tensors are read): rel_table = the
+  // relative_position_bias_table parameter [(2*rel_ws-1)^2][H] (fp32), token i of a window sits at (i / rel_ws, i % rel_ws);
+  // labels [nW][Lq] = region id of every token of every window of the shifted map (mask = -100 where two ids differ; null = none)
+  const float* rel_table; int rel_ws; const unsigned char* labels;
   int q_pos0;              // step mode: absolute position of query row 0 (causal uses q_pos0 + i)
   long sq_b, sk_b, sv_b, so_b;  // batch strides (elements) of Q / K / V / O(dO,dQ use sq_b/so_b)
 };

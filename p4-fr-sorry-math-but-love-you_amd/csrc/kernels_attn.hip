@@ -61,8 +61,21 @@ __global__ __launch_bounds__(QT * 4) void attn_kernel(AttnP p) {
   const T* Kg = (const T*)p.K + b * p.sk_b + h * hd;
   const T* Vg = (const T*)p.V + b * p.sv_b + h * hd;
 
+  // window attention with the bias computed here: this head's column of the relative-position table and this window's region
+  // labels go to the front of LDS ((2ws-1)^2 floats + Lq bytes, padded to 16 bytes)
+  float* sRel = nullptr;
+  unsigned char* sLab = nullptr;
+  char* sm0 = smem;
+  if (p.rel_table) {
+    const int nrel = (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1);
+    sRel = (float*)smem;
+    sLab = (unsigned char*)(sRel + nrel);
+    for (int i = tid; i < nrel; i += NT) sRel[i] = p.rel_table[(long)i * p.H + h];
+    if (p.labels) for (int i = tid; i < p.Lq; i += NT) sLab[i] = p.labels[(long)(b % p.nW) * p.Lq + i];
+    sm0 = smem + (((size_t)nrel * 4 + (size_t)p.Lq + 15) & ~(size_t)15);
+  }
   // LDS carve (elements of T)
-  T* sQ = (T*)smem;                       // [hdP/32][QT][32]
+  T* sQ = (T*)sm0;                        // [hdP/32][QT][32]
   T* sK = sQ + QT * hdP;                  // [hdP/32][LkP][32]
   T* sV = sK + LkP * hdP;                 // MODE 0: Vt [LkP/32][hdT][32]; MODE 1: V natural [hdP/32][LkP][32]
   T* sP = sV + (MODE == 0 ? LkP * hdT : LkP * hdP);  // [LkP/32][QT][32]  (P forward / dS backward)
@@ -87,6 +100,16 @@ __global__ __launch_bounds__(QT * 4) void attn_kernel(AttnP p) {
 
   // ---- S = Q K^T (scaled) with masks, all key tiles of this wave's 16 rows kept in registers
   f32x4 s[NKT];
+  // window attention: this lane's four query rows as window coordinates / region labels, once
+  const int ws_ = sRel ? p.rel_ws : 1;
+  int rel_i[4], lab_i[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qi = q0 + r0 + fq * 4 + r;
+    const int yi = qi / ws_, xi = qi - yi * ws_;
+    rel_i[r] = (yi + ws_ - 1) * (2 * ws_ - 1) + (xi + ws_ - 1);   // table index = rel_i - (yj * (2ws-1) + xj)
+    lab_i[r] = (sRel && p.labels && qi < p.Lq) ? sLab[qi] : 0;
+  }
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
     s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -99,11 +122,18 @@ __global__ __launch_bounds__(QT * 4) void attn_kernel(AttnP p) {
       const int key = kt * 16 + fr;
       bool km = key >= p.Lk;
       if (!km && p.text && key > 0) km = p.text[(long)b * p.ld_text + key] == p.pad_id;
+      const int yj = key / ws_, xj = key - yj * ws_;
+      const int rel_j = yj * (2 * ws_ - 1) + xj;
+      const int labj = (sRel && p.labels && !km) ? sLab[key] : 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qi = q0 + r0 + fq * 4 + r;
         bool m = km || (p.causal && key > p.q_pos0 + qi);
         float sv = s[kt][r] * p.inv_temp;
+        if (sRel && !km && qi < p.Lq) {
+          sv += sRel[rel_i[r] - rel_j];
+          if (lab_i[r] != labj) sv += -100.0f;
+        }
         if ((p.bias || p.wmask) && !km && qi < p.Lq) {
           if (p.bias) sv += p.bias[((long)h * p.Lq + qi) * p.Lk + key];
           if (p.wmask) sv += p.wmask[((long)(b % p.nW) * p.Lq + qi) * p.Lk + key];
@@ -236,6 +266,10 @@ __global__ __launch_bounds__(QT * 4) void attn_kernel(AttnP p) {
   }
 }
 
+static size_t attn_rel_bytes(const AttnP& p) {
+  if (!p.rel_table) return 0;
+  return ((size_t)(2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 4 + (size_t)p.Lq + 15) & ~(size_t)15;
+}
 static size_t attn_lds_bytes(int esz, int QT, int LkP, int hd, int mode) {
   int hdP = (hd + 31) & ~31, hdT = (hd + 15) & ~15;
   size_t e = (size_t)QT * hdP + (size_t)LkP * hdP + (size_t)QT * LkP;
@@ -268,11 +302,12 @@ static int launch_attn_t(const AttnP& p, hipStream_t s) {
   const int LkP = (int)attn_lkp(p.Lk);
   const int nkt = LkP / 16;
   if (nkt > 16 || p.hd > 64 || (p.hd % TT<T>::CH) != 0) return -1;
-  const size_t cap = 160 * 1024;
+  const size_t cap = 160 * 1024 - attn_rel_bytes(p);
   int qt = 64;
   while (qt > 16 && (attn_lds_bytes(sizeof(T), qt, LkP, p.hd, MODE) > cap || qt / 2 >= p.Lq)) qt /= 2;
   size_t lds = attn_lds_bytes(sizeof(T), qt, LkP, p.hd, MODE);
   if (lds > cap) return -1;
+  lds += attn_rel_bytes(p);
   if (qt == 64) launch_attn_qt<T, 64, MODE>(p, nkt, lds, s);
   else if (qt == 32) launch_attn_qt<T, 32, MODE>(p, nkt, lds, s);
   else launch_attn_qt<T, 16, MODE>(p, nkt, lds, s);
