@@ -349,6 +349,29 @@ static void launch_gemm_t(const GemmP& p, hipStream_t s) {
     }
   }
   const int nk32 = (p.K + 31) / 32;
+  if constexpr (AM == AM_DENSE && BF) {
+    // Round 2 (tools/gemm_sweep.sh over 21 shapes of the two networks, every configuration forced in turn): the 128x128 tile
+    // wins only on square-ish deep-K problems; 128x64 with ONE k-panel per barrier wins when K >= 512 and the grid is large;
+    // 64x64 everywhere else.  The old rule sent every N > 64 product with >= 1024 128x128-tiles to 128x128 with two panels per
+    // barrier: 1.8-2x slower on M=9216 N=2048 K=512, M=36864 N=1024 K=256, M=147456 N=512 K=128, M=98304 N=192 K=48, ...
+    static const bool old_rules = getenv("SATRN_GEMM_OLD_RULES") != nullptr;
+    const bool small_grid = p.N >= 64 && blocks(64, 64) <= 800;   // the late backbone stages: handled below (64x32 tiles)
+    if (!old_rules && p.N > 32 && !small_grid) {
+      if (p.N <= 64) {
+        if (nk32 >= 8) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, (AM == AM_DENSE && BF) ? 2 : 1>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, 1>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
+      } else if (nk32 >= 64 && p.N >= 1024 && blocks(128, 128) >= 1024) {
+        hipLaunchKernelGGL((gemm_kernel<T, 128, 128, AM, (AM == AM_DENSE && BF) ? 2 : 1>), dim3(blocks(128, 128)), dim3(256), 0, s, p);
+      } else if (nk32 >= 16 && blocks(128, 64) >= 512) {
+        if (nk32 >= 64) hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AM, (AM == AM_DENSE && BF) ? 2 : 1>), dim3(blocks(128, 64)), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((gemm_kernel<T, 128, 64, AM, 1>), dim3(blocks(128, 64)), dim3(256), 0, s, p);
+      } else {
+        if (nk32 >= 32) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, (AM == AM_DENSE && BF) ? 2 : 1>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, 1>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
+      }
+      return;
+    }
+  }
   // measured on MI355X (tools/gemm_bench.py): 64x64 tiles win until the 128x128 grid has >= 4 blocks per CU; staging
   // KP panels per barrier pays only while >= 3 barriers remain (K=256: KP=2 beats KP=4 by 35 %)
   constexpr bool D = AM == AM_DENSE;
