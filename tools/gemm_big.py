@@ -9,7 +9,7 @@ P = lambda t: ctypes.c_void_p(t.data_ptr())
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def bench(fn, iters=30):
+def bench(fn, iters=100):
     for _ in range(5): fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,6 +22,8 @@ def bench(fn, iters=30):
 SHAPES = [(4096, 4096, 4096), (9216, 2048, 512), (9216, 512, 2048), (9216, 1536, 512), (36864, 1024, 256), (147456, 512, 128), (147456, 128, 512)]
 if os.environ.get('SATRN_SHAPES'):   # the large dense products of the EfficientSATRN step (1x1 convolutions of the fused-MBConv stages, decoder)
     SHAPES = [(98304, 192, 48), (98304, 48, 192), (98304, 96, 48), (24576, 256, 64), (24576, 64, 256), (6144, 960, 160), (6144, 512, 128), (4096, 1024, 256), (4096, 256, 1024), (4096, 768, 256), (2304, 4096, 1024), (2304, 1024, 4096), (36864, 256, 1024), (147456, 384, 128)]
+if os.environ.get('LATE_SHAPES'):    # small-grid products of the late backbone stages, the encoder and the decoder
+    SHAPES = [(1536, 1536, 256), (1536, 256, 1536), (6144, 960, 160), (6144, 160, 960), (6144, 512, 128), (6144, 128, 512), (1536, 1536, 512), (1536, 512, 512), (1536, 512, 1536), (4096, 768, 256), (4096, 256, 256), (4096, 1024, 256), (4096, 256, 1024), (4096, 245, 256)]
 for M, N, K in SHAPES:
     x = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16(); w = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
     y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
