@@ -1652,6 +1652,7 @@ static void det_activate(Model* m) {
   g_det.scratch[0] = g_det.on ? (float*)(m->ws + m->off_det) : nullptr;
   g_det.scratch[1] = g_det.on ? (float*)(m->ws + m->off_det) + m->det_floats : nullptr;
   g_det.side = m->ex ? m->ex->s2 : nullptr;
+  g_wgrad_dense_blocks = m->cfg.network == 2 ? 160 : 0;
 }
 
 static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) {

@@ -13,6 +13,9 @@ enum { DT_F32 = 0, DT_BF16 = 1 };
 // dtype f32; operator-level C-ABI calls without an engine keep the atomic forms.
 struct DetCtx { int on = 0; float* scratch[2] = {nullptr, nullptr}; size_t cap = 0 /*floats per slab*/; hipStream_t side = nullptr; };
 extern DetCtx g_det;
+// workgroups a dense weight-gradient launch aims for on the side stream (0 = the default, 96); set per engine call like g_det:
+// SwinTRN's products are 10-40x larger than EfficientSATRN's and its chain leaves more of the chip free (160: 31.8 -> 30.7 ms/step)
+extern int g_wgrad_dense_blocks;
 void det_overflow_warn(size_t need_floats);
 static inline float* det_scratch(hipStream_t s, size_t need_floats) {
   if (!g_det.on) return nullptr;

@@ -859,6 +859,8 @@ __global__ void wgrad_fold_kernel(const float* part, int splits, int N, int K, i
   }
 }
 
+int g_wgrad_dense_blocks = 0;
+
 template <typename T, int BNW, int BKW>
 static void launch_wgrad_tile(const WgradP& p, hipStream_t s) {
   constexpr int MS = sizeof(T) == 2 ? 64 : 32;
@@ -869,7 +871,8 @@ static void launch_wgrad_tile(const WgradP& p, hipStream_t s) {
     // weight gradients run on the low-priority side stream beside the data-gradient chain and have ~2.5x slack: a grid
     // that fills the chip (768 blocks) only takes CUs away from the chain.  Measured on the bs32 step: 768/768 blocks
     // 2 429 img/s, 96 dense / 384 conv 2 535 img/s, 32 dense 2 526, 64 (all) 2 358 (side stream becomes the critical path)
-    static const long tgt_d = getenv("SATRN_WGRAD_BLOCKS") ? atol(getenv("SATRN_WGRAD_BLOCKS")) : 96;
+    static const long tgt_env = getenv("SATRN_WGRAD_BLOCKS") ? atol(getenv("SATRN_WGRAD_BLOCKS")) : 0;
+    const long tgt_d = tgt_env > 0 ? tgt_env : (g_wgrad_dense_blocks > 0 ? g_wgrad_dense_blocks : 96);
     static const long tgt_c = getenv("SATRN_WGRAD_BLOCKS_CONV") ? atol(getenv("SATRN_WGRAD_BLOCKS_CONV")) : 384;
     // deterministic mode: the split count (= the summation grouping) must not depend on which stream / graph mode runs the kernel
     const long tgt = g_det.on ? 256 : (p.full_grid ? 768 : (p.conv ? tgt_c : tgt_d));
