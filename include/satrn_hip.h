@@ -94,6 +94,26 @@ int satrn_dwconv3x3_bwd_weight(int dtype, const void* x, const void* dy, float* 
 int satrn_batchnorm_act_fwd(int dtype, const void* y, const float* weight, const float* bias, float* running_mean,
                             float* running_var, int64_t* num_batches_tracked, float eps, int train, int act,
                             const void* res, void* z, long M, int C, float* scratch, void* stream);
+/* Training-mode BatchNorm2d + activation of y[B][H][W][C] -> z, followed by the stride-1 "same" depthwise 3x3 (+bias) of z -> out,
+ * in one launch where the shape allows (the expand-BN-SiLU-depthwise seam of the timm MBConv block in the 8x24 / 4x12 stages;
+ * networks/EfficientSATRN.py:74-76 runs those blocks).  Results equal satrn_batchnorm_act_fwd + satrn_dwconv3x3_fwd bit for bit
+ * (same operand rounding, same accumulation order); other shapes / dtypes run exactly those two.  scratch as in
+ * satrn_batchnorm_act_fwd (6*C floats, first 2*C ZERO on entry); out_stats: 2*C floats, ZERO on entry, receives the column sums
+ * and sums of squares of `out` (what the next BatchNorm needs) -- may be NULL. */
+int satrn_batchnorm_act_dwconv3x3_fwd(int dtype, const void* y, const float* weight, const float* bias, float* running_mean,
+                                      float* running_var, int64_t* num_batches_tracked, float eps, int act, void* z,
+                                      const void* dw_packed, const float* dw_bias, void* out, float* out_stats, int B, int H,
+                                      int W, int C, float* scratch, void* stream);
+/* Backward of the same seam: dz (+)= data gradient of the stride-1 "same" depthwise 3x3 given d_out, AND the two column sums the
+ * BatchNorm backward of z = act(bn(y)) needs (scratch2 of satrn_batchnorm_act_bwd: sum g, sum g*xhat with g = dz*act'), one
+ * launch where the shape allows; otherwise satrn_dwconv3x3_bwd_data + the reduction pass.  `scratch` is the forward's
+ * (scale/shift at [2C,4C), mean/rstd at [4C,6C)); scratch2: 2*C floats, ZERO on entry.  Follow with
+ * satrn_batchnorm_act_bwd_apply. */
+int satrn_dwconv3x3_bwd_data_bnred(int dtype, const void* d_out, const void* dw_packed, void* dz, int accumulate, const void* y,
+                                   const float* scratch, int act, float* scratch2, int B, int H, int W, int C, void* stream);
+/* the second half of satrn_batchnorm_act_bwd for callers that already hold the column sums in scratch2 */
+int satrn_batchnorm_act_bwd_apply(int dtype, const void* dz, const void* y, const float* weight, const float* scratch, int act,
+                                  void* dy, float* dweight, float* dbias, long M, int C, const float* scratch2, void* stream);
 /* dy = d(loss)/d(y) given dz; dweight/dbias accumulate (+=).  scratch2: 2*C floats, ZERO on entry. */
 int satrn_batchnorm_act_bwd(int dtype, const void* dz, const void* y, const float* weight, const float* scratch,
                             int act, void* dy, float* dweight, float* dbias, long M, int C, float* scratch2,

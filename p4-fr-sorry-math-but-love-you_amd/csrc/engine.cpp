@@ -790,7 +790,14 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
   return y;
 }
 
-Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** pool_out = nullptr) {
+// a BatchNorm+activation whose launch is taken over by the depthwise convolution that consumes it (launch_bn_dwconv): op_bn_act
+// does all its bookkeeping (tensors, tape) and leaves the operands here instead of launching
+struct BnHold {
+  bool armed = false;
+  const void* y = nullptr; const float* sums = nullptr; int rep = 1; BNp* bn = nullptr; float* ss = nullptr; float* mr = nullptr; void* z = nullptr;
+  long M = 0; int C = 0, act = 0;
+};
+Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** pool_out = nullptr, BnHold* hold = nullptr) {
   const int C = bn->C;
   const long M = y->rows;
   if (y->pend) {
@@ -834,6 +841,10 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** poo
     *pool_out = e.zalloc((size_t)y->B * C);
     LCH(e, launch_bn_act_pool(e.dt, y->p, sums, y->stats ? y->stats_rep : 1, bn->w.p, bn->b.p, bn->rm, bn->rv, bn->nbt, bn->eps, 0.1f, ss, mr, z->p,
                               *pool_out, M, C, y->H * y->W, act, e.s));
+  } else if (hold && e.train && sums && !res) {
+    hold->armed = true; hold->y = y->p; hold->sums = sums; hold->rep = y->stats ? y->stats_rep : 1; hold->bn = bn; hold->ss = ss; hold->mr = mr;
+    hold->z = z->p; hold->M = M; hold->C = C; hold->act = act;
+    e.nflops = 0; e.nbytes = 0;
   } else
   LCH(e, launch_bn_act(e.dt, y->p, sums, y->stats ? y->stats_rep : 1, bn->w.p, bn->b.p, bn->rm, bn->rv, e.train ? bn->nbt : nullptr, bn->eps, 0.1f, ss, mr,
                        res ? res->p : nullptr, z->p, M, C, act, e.s));
@@ -877,7 +888,10 @@ Tensor* op_stem(Exec& e, const float* img, Wt* w, int B, int Cin, int H, int W, 
   return y;
 }
 
-Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int OW, int pt, int pl, bool want_stats = true) {
+Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int OW, int pt, int pl, bool want_stats = true, BnHold* hold = nullptr) {
+  // x is a BatchNorm output and this is its first consumer: the data gradient below is the last writer of x's gradient and can
+  // reduce that BatchNorm's backward column sums on the way (as the dgrad GEMM epilogue does, op_gemm)
+  const bool fuse_bnb = g_fuse_bnb && e.rec && x->bn_y && !x->bn_has_res && x->ncons == 0 && stride == 1 && pt == 1 && pl == 1 && OH == x->H && OW == x->W;
   used(x);
   const int B = x->B, H = x->H, W = x->W, C = x->C;
   Tensor* y = e.newt((long)B * OH * OW, C, B, OH, OW);
@@ -892,11 +906,29 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
     };
     return y;
   }
-  // the statistics pass behind it reads y once more
-  WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * H * W + (double)B * OH * OW * (y->stats ? 2 : 1)) * C * e.esz());
-  LCH(e, launch_dwconv(e.dt, 0, x->p, w->fwd, bias ? bias->p : nullptr, y->p, B, H, W, C, OH, OW, stride, pt, pl, 0, y->stats, e.s));
+  bool fused = false;
+  if (hold && hold->armed) {
+    // the BatchNorm in front was held back: both in one launch where the shape allows (whole image x 64 channels per workgroup)
+    BNp* bn = hold->bn;
+    if (y->stats && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && !e.dry) {
+      WORK(e, 18.0 * (double)B * OH * OW * C, (double)B * H * W * C * e.esz() * 3);
+      LCH(e, fused = launch_bn_dwconv(e.dt, hold->y, hold->sums, hold->rep, bn->w.p, bn->b.p, bn->rm, bn->rv, bn->nbt, bn->eps, 0.1f, hold->ss, hold->mr,
+                                      hold->z, w->fwd, bias ? bias->p : nullptr, y->p, y->stats, B, H, W, C, hold->act, e.s));
+    }
+    if (!fused) {
+      WORK(e, 0, (double)hold->M * hold->C * e.esz() * 2);
+      LCH(e, launch_bn_act(e.dt, hold->y, hold->sums, hold->rep, bn->w.p, bn->b.p, bn->rm, bn->rv, bn->nbt, bn->eps, 0.1f, hold->ss, hold->mr, nullptr,
+                           hold->z, hold->M, hold->C, hold->act, e.s));
+    }
+    hold->armed = false;
+  }
+  if (!fused) {
+    // the statistics pass behind it reads y once more
+    WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * H * W + (double)B * OH * OW * (y->stats ? 2 : 1)) * C * e.esz());
+    LCH(e, launch_dwconv(e.dt, 0, x->p, w->fwd, bias ? bias->p : nullptr, y->p, B, H, W, C, OH, OW, stride, pt, pl, 0, y->stats, e.s));
+  }
   if (e.rec)
-    e.tape.push_back([&e, x, y, w, bias, B, H, W, C, OH, OW, stride, pt, pl]() {
+    e.tape.push_back([&e, x, y, w, bias, B, H, W, C, OH, OW, stride, pt, pl, fuse_bnb]() {
       if (!y->g) return;
       float* scr = e.zalloc((size_t)10 * C);
       {
@@ -907,8 +939,17 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
       }
       int beta;
       void* dx = e.grad(x, &beta);
-      WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * OH * OW + (double)B * H * W * (beta ? 2 : 1)) * C * e.esz());
-      LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, nullptr, e.s));
+      bool fused = false;
+      if (fuse_bnb && !e.dry && !x->bn_red) {
+        float* red = e.zalloc((size_t)2 * C);
+        WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * OH * OW * 2 + (double)B * H * W * (beta ? 2 : 1)) * C * e.esz());
+        LCH(e, fused = launch_dwconv_bwd_bn(e.dt, y->g, w->fwd, dx, beta, x->bn_y, x->bn_ss, x->bn_mr, x->bn_act, red, B, H, W, C, e.s));
+        if (fused) { x->bn_red = red; x->bn_red_rep = 1; }
+      }
+      if (!fused) {
+        WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * OH * OW + (double)B * H * W * (beta ? 2 : 1)) * C * e.esz());
+        LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, nullptr, e.s));
+      }
     });
   return y;
 }
@@ -1430,8 +1471,9 @@ Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
   }
   Tensor* y = op_gemm(e, x, &eb->c0, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   y->B = B; y->H = H; y->W = W;
-  Tensor* z = op_bn_act(e, y, &eb->bn1, ACT_SILU, nullptr);
-  Tensor* y2 = op_dwconv(e, z, &eb->dw, nullptr, eb->stride, g.OH, g.OW, g.pt, g.pl);
+  BnHold hold;
+  Tensor* z = op_bn_act(e, y, &eb->bn1, ACT_SILU, nullptr, nullptr, &hold);
+  Tensor* y2 = op_dwconv(e, z, &eb->dw, nullptr, eb->stride, g.OH, g.OW, g.pt, g.pl, true, &hold);
   float* poolsum = nullptr;
   Tensor* z2 = op_bn_act(e, y2, &eb->bn2, ACT_SILU, nullptr, &poolsum);
   Tensor* z3 = op_se(e, z2, eb, poolsum);

@@ -127,6 +127,15 @@ void launch_pool_hw(int dt, const void* x, void* out /*[B,C] as T*/, int B, int 
 // BatchNorm(batch statistics)+activation that also accumulates poolsum[b][c] += sum_hw z (zeroed [B][C]); bn_act_pool_ok() says
 // whether the shape / mode takes it (HW % 48 == 0, not the deterministic mode)
 bool bn_act_pool_ok(long M, int C, int HW);
+// data gradient of the stride-1 depthwise 3x3 (dz (+)= conv^T(dy)) AND the BatchNorm-backward column sums of z = act(bn(y)) in red
+// (zeroed [2C]), one launch (bf16, whole image x 64 channels per workgroup); false = not taken, nothing launched
+bool launch_dwconv_bwd_bn(int dt, const void* dy, const void* wp, void* dz, int beta, const void* y, const float* ss, const float* mr, int act,
+                          float* red, int B, int H, int W, int C, hipStream_t s);
+// BatchNorm(batch statistics)+activation of y -> z AND the stride-1 depthwise 3x3 of z -> out with out's column sums in red (zeroed
+// [2C]), one launch (bf16, whole image x 64 channels per workgroup); false = shape / mode not taken, nothing launched
+bool launch_bn_dwconv(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv, int64_t* nbt,
+                      float eps, float mom, float* ss, float* mr, void* z, const void* wp, const float* dwbias, void* out, float* red, int B, int H,
+                      int W, int C, int act, hipStream_t s);
 void launch_bn_act_pool(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv,
                         int64_t* nbt, float eps, float mom, float* ss, float* mr, void* z, float* poolsum, long M, int C, int HW, int act,
                         hipStream_t s);

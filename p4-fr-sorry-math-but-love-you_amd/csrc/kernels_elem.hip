@@ -894,6 +894,281 @@ __global__ __launch_bounds__(256) void dwconv_s1_red_kernel(const T* __restrict_
   }
 }
 
+// ---- BatchNorm(batch statistics) + activation + stride-1 depthwise 3x3 + the statistics of ITS output in ONE launch --------
+// The late MBConv stages (8x24 and 4x12 maps): a workgroup owns one image x one slab of 64 channels.  It pulls the slab of
+// the expand convolution's raw output (24 KB at 8x24) with full 128-byte lines, applies the BatchNorm coefficients it derives
+// from the column sums + SiLU ONCE per element, writes the activated slab back (the depthwise weight gradient reads it on the
+// side stream) and into an LDS tile with a zero halo, and computes its 3x3 outputs from LDS -- the convolution's nine taps never
+// go to memory.  Replaces bn_act_kernel + dwconv_s1_red_kernel (one kernel boundary and one pass over the expanded activation
+// less per block, 28 blocks per step); accumulation order per output = dwconv_s1_red_kernel's, so the results are bitwise the same.
+#define BDW_SC 8    // 16-byte chunks per slab (64 channels: a full 128-byte line per pixel)
+#define BDW_RUN 3   // output pixels per thread (a horizontal run)
+__global__ __launch_bounds__(512) void bn_dw_img_kernel(const bf16_t* __restrict__ y, const float* sums, int sums_rep, const float* w,
+                                                        const float* b, float* rm, float* rv, int64_t* nbt, float eps, float mom,
+                                                        float invM, float unbias, float* ss, float* mr, bf16_t* __restrict__ z,
+                                                        const bf16_t* __restrict__ wp, const float* dwbias, bf16_t* __restrict__ out,
+                                                        float* red, int H, int W, int C, int rowpix, int act) {
+  typedef bf16_t T;
+  constexpr int CH = 8, SC = BDW_SC, RUN = BDW_RUN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char bdw_sm[];
+  __shared__ float sred[8][2][SC * CH];
+  uint4* tile = reinterpret_cast<uint4*>(bdw_sm);   // [(H + 2)][rowpix][SC] chunks; rowpix odd: two rows apart = half the banks apart
+  const int tid = threadIdx.x, NT = blockDim.x, G = NT / SC;
+  const int chunk = tid % SC, g = tid / SC;
+  const int img = blockIdx.x, c0 = (blockIdx.y * SC + chunk) * CH;
+  const int HW = H * W;
+  const long base = (long)img * HW * C + c0;
+  // the slab and the nine weight rows are requested before anything else
+  uint4 raw[RUN], wq[9];
+#pragma unroll
+  for (int k = 0; k < RUN; ++k) raw[k] = ld16(y + base + (long)(g + k * G) * C);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wq[t] = ld16(wp + (long)t * C + c0);
+  const bool publisher = img == 0 && g == 0;
+  float rm0[CH], rv0[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) rm0[j] = rv0[j] = 0.f;
+  if (publisher) { ldv(rm + c0, rm0, CH); ldv(rv + c0, rv0, CH); }
+  float sc[CH], sh[CH], mean[CH], var[CH];
+  {
+    float ww[CH], bb[CH];
+    ldv(sums + c0, mean, CH); ldv(sums + C + c0, var, CH);
+    for (int rp = 1; rp < sums_rep; ++rp) {
+      float t0[CH], t1[CH];
+      ldv(sums + (size_t)rp * 2 * C + c0, t0, CH); ldv(sums + (size_t)rp * 2 * C + C + c0, t1, CH);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { mean[j] += t0[j]; var[j] += t1[j]; }
+    }
+    ldv(w + c0, ww, CH); ldv(b + c0, bb, CH);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      mean[j] *= invM; var[j] = fmaxf(var[j] * invM - mean[j] * mean[j], 0.f);
+      const float rstd = rsqrtf(var[j] + eps);
+      sc[j] = ww[j] * rstd;
+      sh[j] = bb[j] - mean[j] * sc[j];
+    }
+  }
+  // zero halo: top and bottom rows, left and right columns
+  const int nh = 2 * (W + 2) + 2 * H;
+  for (int i = tid; i < nh * SC; i += NT) {
+    const int cell = i / SC, ch = i - cell * SC;
+    int r, c;
+    if (cell < W + 2) { r = 0; c = cell; }
+    else if (cell < 2 * (W + 2)) { r = H + 1; c = cell - (W + 2); }
+    else { const int k = cell - 2 * (W + 2); r = 1 + (k >> 1); c = (k & 1) ? W + 1 : 0; }
+    tile[(r * rowpix + c) * SC + ch] = zero16();
+  }
+#pragma unroll
+  for (int k = 0; k < RUN; ++k) {
+    const int pix = g + k * G, py = pix / W, px = pix - py * W;
+    float v[CH];
+    unpack<T>(raw[k], v);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) v[j] = act_fwd(v[j] * sc[j] + sh[j], act);
+    const uint4 q = pack<T>(v);
+    st16(z + base + (long)pix * C, q);
+    tile[((py + 1) * rowpix + px + 1) * SC + chunk] = q;
+  }
+  __syncthreads();
+  const int row = g % H, ox0 = (g / H) * RUN;
+  float acc[RUN][CH];
+#pragma unroll
+  for (int p = 0; p < RUN; ++p)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[p][j] = dwbias ? dwbias[c0 + j] : 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    float in[RUN + 2][CH];
+#pragma unroll
+    for (int t = 0; t < RUN + 2; ++t) unpack<T>(tile[((row + kh) * rowpix + ox0 + t) * SC + chunk], in[t]);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      float wv[CH];
+      unpack<T>(wq[kh * 3 + kw], wv);
+#pragma unroll
+      for (int p = 0; p < RUN; ++p)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[p][j] += in[p + kw][j] * wv[j];
+    }
+  }
+  float s1[CH], s2[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int p = 0; p < RUN; ++p) {
+    st16(out + base + (long)(row * W + ox0 + p) * C, pack<T>(acc[p]));
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { s1[j] += acc[p][j]; s2[j] += acc[p][j] * acc[p][j]; }
+  }
+  // column sums of the output: lanes of a wave that hold the same chunk (lane bits 3..5), then the waves through LDS
+#pragma unroll
+  for (int o = SC; o < 64; o <<= 1) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane < SC) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { sred[wave][0][lane * CH + j] = s1[j]; sred[wave][1][lane * CH + j] = s2[j]; }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * SC * CH; i += NT) {   // NT may be a single wave
+    const int k = i / (SC * CH), c = i - k * SC * CH;
+    float sum = 0.f;
+    for (int wv = 0; wv < NT / 64; ++wv) sum += sred[wv][k][c];
+    atomicAdd(red + (long)k * C + blockIdx.y * SC * CH + c, sum);
+  }
+  if (publisher) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      ss[c0 + j] = sc[j]; ss[C + c0 + j] = sh[j]; mr[c0 + j] = mean[j]; mr[C + c0 + j] = rsqrtf(var[j] + eps);
+      rm[c0 + j] = (1.f - mom) * rm0[j] + mom * mean[j];
+      rv[c0 + j] = (1.f - mom) * rv0[j] + mom * var[j] * unbias;
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nbt) *nbt += 1;
+}
+// false = shape / mode not taken (the caller launches launch_bn_act + launch_dwconv)
+bool launch_bn_dwconv(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv, int64_t* nbt,
+                      float eps, float mom, float* ss, float* mr, void* z, const void* wp, const float* dwbias, void* out, float* red, int B, int H,
+                      int W, int C, int act, hipStream_t s) {
+  const bool off = getenv("SATRN_NO_FUSED_BN_DW") != nullptr;   // read per call: tests compare the fused and the plain forms in one process
+  if (off || g_det.on || dt != DT_BF16 || !sums || !red || (C % (8 * BDW_SC)) != 0 || (W % BDW_RUN) != 0) return false;
+  const int HW = H * W, NT = (HW / BDW_RUN) * BDW_SC;
+  if (NT > 512 || (NT % 64) != 0) return false;
+  const int rowpix = (W + 2) | 1;
+  const size_t lds = (size_t)(H + 2) * rowpix * BDW_SC * 16;
+  if (lds > 60 * 1024) return false;
+  const long M = (long)B * HW;
+  const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
+  hipLaunchKernelGGL(bn_dw_img_kernel, dim3(B, C / (8 * BDW_SC)), dim3(NT), lds, s, (const bf16_t*)y, sums, sums_rep < 1 ? 1 : sums_rep, w, b, rm, rv, nbt,
+                     eps, mom, 1.0f / (float)M, unbias, ss, mr, (bf16_t*)z, (const bf16_t*)wp, dwbias, (bf16_t*)out, red, H, W, C, rowpix, act);
+  return true;
+}
+
+// The backward twin of bn_dw_img_kernel: data gradient of the stride-1 depthwise 3x3 from an LDS tile of dy (whole image x 64
+// channels per workgroup) AND the BatchNorm-backward column sums of the tensor it differentiates (z = act(bn(y))):
+//   dz = conv^T(dy);  red[0..C) += sum dz*act'(u),  red[C..2C) += sum dz*act'(u)*xhat      (u = y*scale+shift)
+// -- what launch_dwconv(mode 1) + launch_bn_bwd_reduce did in two launches (the thread-per-pixel-pair form of this fusion needed
+// 206 VGPRs and was slower than the pair; from LDS a thread holds 3 outputs x 8 channels).  dz is rounded to bf16 before it
+// enters the sums, as the separate reduction read it back from memory.
+__global__ __launch_bounds__(512) void dw_bwd_img_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wp, bf16_t* __restrict__ dz,
+                                                         const bf16_t* __restrict__ y, const float* ss, const float* mr, float* red, int H, int W,
+                                                         int C, int rowpix, int act, int beta) {
+  typedef bf16_t T;
+  constexpr int CH = 8, SC = BDW_SC, RUN = BDW_RUN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char bdw_sm[];
+  __shared__ float sred[8][2][SC * CH];
+  uint4* tile = reinterpret_cast<uint4*>(bdw_sm);
+  const int tid = threadIdx.x, NT = blockDim.x, G = NT / SC;
+  const int chunk = tid % SC, g = tid / SC;
+  const int img = blockIdx.x, c0 = (blockIdx.y * SC + chunk) * CH;
+  const int HW = H * W;
+  const long base = (long)img * HW * C + c0;
+  const int row = g % H, ox0 = (g / H) * RUN;
+  uint4 raw[RUN], yq[RUN], oq[RUN], wq[9];
+#pragma unroll
+  for (int k = 0; k < RUN; ++k) raw[k] = ld16(dy + base + (long)(g + k * G) * C);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wq[t] = ld16(wp + (long)t * C + c0);
+#pragma unroll
+  for (int p = 0; p < RUN; ++p) {
+    yq[p] = ld16(y + base + (long)(row * W + ox0 + p) * C);
+    oq[p] = beta ? ld16(dz + base + (long)(row * W + ox0 + p) * C) : zero16();
+  }
+  float sc[CH], sh[CH], mu[CH], rs[CH];
+  ldv(ss + c0, sc, CH); ldv(ss + C + c0, sh, CH); ldv(mr + c0, mu, CH); ldv(mr + C + c0, rs, CH);
+  const int nh = 2 * (W + 2) + 2 * H;
+  for (int i = tid; i < nh * SC; i += NT) {
+    const int cell = i / SC, ch = i - cell * SC;
+    int r, c;
+    if (cell < W + 2) { r = 0; c = cell; }
+    else if (cell < 2 * (W + 2)) { r = H + 1; c = cell - (W + 2); }
+    else { const int k = cell - 2 * (W + 2); r = 1 + (k >> 1); c = (k & 1) ? W + 1 : 0; }
+    tile[(r * rowpix + c) * SC + ch] = zero16();
+  }
+#pragma unroll
+  for (int k = 0; k < RUN; ++k) {
+    const int pix = g + k * G, py = pix / W, px = pix - py * W;
+    tile[((py + 1) * rowpix + px + 1) * SC + chunk] = raw[k];
+  }
+  __syncthreads();
+  float acc[RUN][CH];
+#pragma unroll
+  for (int p = 0; p < RUN; ++p)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[p][j] = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    float in[RUN + 2][CH];
+#pragma unroll
+    for (int t = 0; t < RUN + 2; ++t) unpack<T>(tile[((row + kh) * rowpix + ox0 + t) * SC + chunk], in[t]);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      float wv[CH];
+      unpack<T>(wq[8 - (kh * 3 + kw)], wv);   // transposed convolution: taps mirrored
+#pragma unroll
+      for (int p = 0; p < RUN; ++p)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[p][j] += in[p + kw][j] * wv[j];
+    }
+  }
+  float s1[CH], s2[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int p = 0; p < RUN; ++p) {
+    if (beta) {
+      float o[CH];
+      unpack<T>(oq[p], o);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[p][j] += o[j];
+    }
+    const uint4 q = pack<T>(acc[p]);
+    st16(dz + base + (long)(row * W + ox0 + p) * C, q);
+    float d[CH], v[CH];
+    unpack<T>(q, d);
+    unpack<T>(yq[p], v);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const float u = v[j] * sc[j] + sh[j];
+      const float gg = d[j] * act_bwd(u, act);
+      s1[j] += gg; s2[j] += gg * ((v[j] - mu[j]) * rs[j]);
+    }
+  }
+#pragma unroll
+  for (int o = SC; o < 64; o <<= 1) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane < SC) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { sred[wave][0][lane * CH + j] = s1[j]; sred[wave][1][lane * CH + j] = s2[j]; }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * SC * CH; i += NT) {
+    const int k = i / (SC * CH), c = i - k * SC * CH;
+    float sum = 0.f;
+    for (int wv = 0; wv < NT / 64; ++wv) sum += sred[wv][k][c];
+    atomicAdd(red + (long)k * C + blockIdx.y * SC * CH + c, sum);
+  }
+}
+// false = shape / mode not taken (the caller launches launch_dwconv(mode 1) and leaves the sums to launch_bn_bwd_reduce)
+bool launch_dwconv_bwd_bn(int dt, const void* dy, const void* wp, void* dz, int beta, const void* y, const float* ss, const float* mr, int act,
+                          float* red, int B, int H, int W, int C, hipStream_t s) {
+  const bool off = getenv("SATRN_NO_FUSED_DW_BWD") != nullptr;   // read per call (tests)
+  if (off || g_det.on || dt != DT_BF16 || !red || !y || (C % (8 * BDW_SC)) != 0 || (W % BDW_RUN) != 0) return false;
+  const int HW = H * W, NT = (HW / BDW_RUN) * BDW_SC;
+  if (NT > 512 || (NT % 64) != 0) return false;
+  const int rowpix = (W + 2) | 1;
+  const size_t lds = (size_t)(H + 2) * rowpix * BDW_SC * 16;
+  if (lds > 60 * 1024) return false;
+  hipLaunchKernelGGL(dw_bwd_img_kernel, dim3(B, C / (8 * BDW_SC)), dim3(NT), lds, s, (const bf16_t*)dy, (const bf16_t*)wp, (bf16_t*)dz, (const bf16_t*)y,
+                     ss, mr, red, H, W, C, rowpix, act, beta);
+  return true;
+}
+
 static bool dwconv_fuses_stats(int H, int W, int OH, int OW, int stride, int pt, int pl) {
   const bool off = getenv("SATRN_DW_NO_FUSED_RED") != nullptr;   // read per call (tests)
   return !off && !g_det.on && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && (W & 1) == 0;

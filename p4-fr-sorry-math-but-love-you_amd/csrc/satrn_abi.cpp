@@ -164,6 +164,37 @@ int satrn_batchnorm_act_fwd(int dt, const void* y, const float* w, const float* 
                 res, z, M, C, act, S(st));
   return done("batchnorm_act_fwd");
 }
+int satrn_batchnorm_act_dwconv3x3_fwd(int dt, const void* y, const float* w, const float* b, float* rm, float* rv, int64_t* nbt,
+                                      float eps, int act, void* z, const void* dwp, const float* dwb, void* out, float* out_stats,
+                                      int B, int H, int W, int C, float* scratch, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  const long M = (long)B * H * W;
+  launch_colstats(dt, y, M, C, scratch, S(st));
+  if (!launch_bn_dwconv(dt, y, scratch, 1, w, b, rm, rv, nbt, eps, 0.1f, scratch + 2 * C, scratch + 4 * C, z, dwp, dwb, out, out_stats, B, H, W, C,
+                        act, S(st))) {
+    launch_bn_act(dt, y, scratch, 1, w, b, rm, rv, nbt, eps, 0.1f, scratch + 2 * C, scratch + 4 * C, nullptr, z, M, C, act, S(st));
+    launch_dwconv(dt, 0, z, dwp, dwb, out, B, H, W, C, H, W, 1, 1, 1, 0, out_stats, S(st));
+  }
+  return done("batchnorm_act_dwconv3x3_fwd");
+}
+int satrn_dwconv3x3_bwd_data_bnred(int dt, const void* dout, const void* dwp, void* dz, int accumulate, const void* y, const float* scratch,
+                                   int act, float* scratch2, int B, int H, int W, int C, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  if (!launch_dwconv_bwd_bn(dt, dout, dwp, dz, accumulate, y, scratch + 2 * C, scratch + 4 * C, act, scratch2, B, H, W, C, S(st))) {
+    launch_dwconv(dt, 1, dout, dwp, nullptr, dz, B, H, W, C, H, W, 1, 1, 1, accumulate, nullptr, S(st));
+    launch_bn_bwd_reduce(dt, dz, y, scratch + 2 * C, scratch + 4 * C, (long)B * H * W, C, act, scratch2, S(st));
+  }
+  return done("dwconv3x3_bwd_data_bnred");
+}
+int satrn_batchnorm_act_bwd_apply(int dt, const void* dz, const void* y, const float* w, const float* scratch, int act, void* dy, float* dw,
+                                  float* db, long M, int C, const float* scratch2, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  launch_bn_bwd_apply(dt, dz, y, scratch + 2 * C, scratch + 4 * C, w, scratch2, M, C, act, dy, dw, db, S(st));
+  return done("batchnorm_act_bwd_apply");
+}
 int satrn_batchnorm_act_bwd(int dt, const void* dz, const void* y, const float* w, const float* scratch, int act,
                             void* dy, float* dw, float* db, long M, int C, float* scratch2, void* st) {
   CHK_DT(dt);

@@ -249,6 +249,115 @@ def test_batchnorm_act(lib, dt, M, C, act, res):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,bias", [(3, 8, 24, 128, False), (4, 4, 12, 192, True), (2, 8, 24, 960, False), (5, 2, 12, 64, True), (2, 6, 10, 64, True)])
+def test_batchnorm_act_dwconv_fused(lib, dt, B, H, W, C, bias, monkeypatch):
+    """BatchNorm(batch statistics) + SiLU + stride-1 depthwise 3x3 in one launch (bf16, the 8x24 / 4x12 MBConv stages) against
+    torch, and against the two separate operators it replaces (the last shape and f32 take the two-kernel route)."""
+    M = B * H * W
+    y = q(rnd(B, C, H, W, seed=1) * 2 + 0.5, dt)
+    w, b = 1 + rnd(C, seed=3, scale=0.2), rnd(C, seed=4, scale=0.1)
+    rm, rv = rnd(C, seed=5, scale=0.1), 1 + rnd(C, seed=6, scale=0.3)
+    dw = q(rnd(C, 1, 3, 3, seed=7, scale=0.3), dt)
+    db = rnd(C, seed=8, scale=0.1) if bias else None
+    eps = 1e-3
+    rmr, rvr = rm.clone(), rv.clone()
+    zr = F.silu(F.batch_norm(y, rmr, rvr, w, b, True, 0.1, eps))
+    outr = F.conv2d(q(zr, dt), dw, db, 1, 1, 1, C)
+    wp = torch.empty(9, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_pack_dwconv3x3(dti(dt), P(dev(dw)), P(wp), C, st()))
+    yd = dev(nhwc(y), dt)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("SATRN_NO_FUSED_BN_DW", raising=False)
+        else:
+            monkeypatch.setenv("SATRN_NO_FUSED_BN_DW", "1")
+        rmd, rvd = dev(rm.clone()), dev(rv.clone())
+        nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        scratch, stats = torch.zeros(6 * C, device="cuda"), torch.zeros(2 * C, device="cuda")
+        z = torch.empty(B, H, W, C, dtype=tdt(dt), device="cuda")
+        out = torch.empty(B, H, W, C, dtype=tdt(dt), device="cuda")
+        ok(lib, lib.satrn_batchnorm_act_dwconv3x3_fwd(dti(dt), P(yd), P(dev(w)), P(dev(b)), P(rmd), P(rvd), P(nbt), eps, 2, P(z), P(wp),
+                                                      P(dev(db)) if bias else None, P(out), P(stats), B, H, W, C, P(scratch), st()))
+        torch.cuda.synchronize()
+        return z, out, stats, rmd, rvd, nbt, scratch
+
+    z, out, stats, rmd, rvd, nbt, scratch = run(True)
+    close(nchw(z.float()), zr, dt, "bn_dw z", f32_tol=5e-4)
+    close(nchw(out.float()), outr, dt, "bn_dw out", f32_tol=5e-4)
+    close(rmd, rmr, "f32", "bn_dw running_mean", f32_tol=1e-4)
+    close(rvd, rvr, "f32", "bn_dw running_var", f32_tol=1e-4)
+    assert nbt.item() == 1
+    of = out.float().reshape(M, C)
+    close(stats[:C], of.sum(0).cpu(), dt, "bn_dw out sums", f32_tol=1e-3)
+    close(stats[C:], (of * of).sum(0).cpu(), dt, "bn_dw out sums of squares", f32_tol=1e-3)
+    z2, out2, stats2, rmd2, rvd2, _, scratch2 = run(False)
+    # same operand rounding and accumulation order: given the same column sums the two routes agree bit for bit; the sums
+    # themselves come from float atomics (last-bit differences from run to run), which can move a rounding decision
+    for a, c, what in ((z, z2, "z"), (out, out2, "out")):
+        same = (a == c).float().mean().item()
+        print(f"[bn_dw fused vs plain {what}:{dt}] identical elements {same:.6f}")
+        assert same > 0.995 or dt == "f32"   # f32 (always the two-kernel route) keeps every last bit of the sums' noise
+        close(a, c.cpu(), dt, f"bn_dw fused vs plain {what}", f32_tol=1e-5, bf16_tol=1e-2)
+    close(scratch[2 * C:], scratch2[2 * C:].cpu(), "f32", "bn_dw coefficients fused vs plain", f32_tol=1e-5)
+    close(stats, stats2.cpu(), "f32", "bn_dw stats fused vs plain", f32_tol=2e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,acc", [(3, 8, 24, 128, 0), (4, 4, 12, 192, 1), (2, 8, 24, 960, 0), (5, 2, 12, 64, 0), (2, 6, 10, 64, 1)])
+def test_dwconv_bwd_data_with_batchnorm_sums(lib, dt, B, H, W, C, acc, monkeypatch):
+    """backward of the BatchNorm + SiLU + depthwise seam: depthwise data gradient + the BatchNorm-backward column sums in one launch,
+    then the apply pass -- against autograd through silu(batch_norm(y)) -> depthwise conv, and against the separate operators."""
+    M = B * H * W
+    y = q(rnd(B, C, H, W, seed=1) * 2 + 0.5, dt)
+    w, b = 1 + rnd(C, seed=3, scale=0.2), rnd(C, seed=4, scale=0.1)
+    dw = q(rnd(C, 1, 3, 3, seed=7, scale=0.3), dt)
+    dout = q(rnd(B, C, H, W, seed=9), dt)
+    dz0 = q(rnd(B, C, H, W, seed=10, scale=0.5), dt) if acc else None
+    eps = 1e-3
+    yr, wr, br = y.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    zr = F.silu(F.batch_norm(yr, None, None, wr, br, True, 0.1, eps))
+    zr.retain_grad()
+    outr = F.conv2d(zr, dw, None, 1, 1, 1, C)
+    (outr * dout).sum().backward(retain_graph=True)
+    dz_ref = zr.grad.clone() + (dz0 if acc else 0)
+    yr.grad = None; wr.grad = None; br.grad = None
+    zr.backward(q(dz_ref, dt))    # what the BatchNorm backward sees: the (rounded) accumulated gradient of z
+    wp = torch.empty(9, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_pack_dwconv3x3(dti(dt), P(dev(dw)), P(wp), C, st()))
+    yd, doutd = dev(nhwc(y), dt), dev(nhwc(dout), dt)
+    rmd, rvd = dev(torch.zeros(C)), dev(torch.ones(C))
+    nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    scratch = torch.zeros(6 * C, device="cuda")
+    z = torch.empty(B, H, W, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_batchnorm_act_fwd(dti(dt), P(yd), P(dev(w)), P(dev(b)), P(rmd), P(rvd), P(nbt), eps, 1, 2, None, P(z), M, C, P(scratch), st()))
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("SATRN_NO_FUSED_DW_BWD", raising=False)
+        else:
+            monkeypatch.setenv("SATRN_NO_FUSED_DW_BWD", "1")
+        dz = dev(nhwc(dz0), dt).clone() if acc else torch.empty(B, H, W, C, dtype=tdt(dt), device="cuda")
+        s2 = torch.zeros(2 * C, device="cuda")
+        ok(lib, lib.satrn_dwconv3x3_bwd_data_bnred(dti(dt), P(doutd), P(wp), P(dz), acc, P(yd), P(scratch), 2, P(s2), B, H, W, C, st()))
+        dy = torch.empty(B, H, W, C, dtype=tdt(dt), device="cuda")
+        dwd, dbd = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        ok(lib, lib.satrn_batchnorm_act_bwd_apply(dti(dt), P(dz), P(yd), P(dev(w)), P(scratch), 2, P(dy), P(dwd), P(dbd), M, C, P(s2), st()))
+        torch.cuda.synchronize()
+        return dz, s2, dy, dwd, dbd
+
+    dz, s2, dy, dwd, dbd = run(True)
+    close(nchw(dz.float()), dz_ref, dt, "dw_bwd_bn dz")
+    close(nchw(dy.float()), yr.grad, dt, "dw_bwd_bn dy", f32_tol=1e-3, bf16_tol=5e-2)
+    close(dwd, wr.grad, dt, "dw_bwd_bn bn dweight", f32_tol=1e-3)
+    close(dbd, br.grad, dt, "dw_bwd_bn bn dbias", f32_tol=1e-3)
+    dzp, s2p, dyp, _, _ = run(False)
+    assert torch.equal(dz, dzp), "same taps, same order: the data gradient must not depend on the route"
+    close(s2, s2p.cpu(), "f32", "dw_bwd_bn sums fused vs plain", f32_tol=2e-4)
+    close(dy, dyp.float().cpu(), dt, "dw_bwd_bn dy fused vs plain", f32_tol=1e-5, bf16_tol=1e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_maxpool(lib, dt):
     B, C, H, W = 2, 32, 8, 12
     x = q(rnd(B, C, H, W, seed=1), dt)
