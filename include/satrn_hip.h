@@ -146,6 +146,14 @@ int satrn_se_fwd(int dtype, const void* x, const void* W1, const float* b1, cons
 int satrn_se_bwd(int dtype, const void* dy, const void* x, const void* gate, const float* u1, const void* W1, const void* W2,
                  float* dz2, float* du1, float* ds1_zeroed, void* dgate_scratch, void* dpooled, int B, int HW, int C, int S,
                  void* stream);
+/* satrn_se_bwd for the timm MBConv seam BatchNorm -> SiLU -> SqueezeExcite, where x = act(bn(bn_y)) feeds the SE block only: x is
+ * recomputed from bn_y (not read), and bn_scratch2 (2*C floats, ZERO on entry) receives the column sums that BatchNorm's backward
+ * needs for the gradient dy*gate + dpooled/HW reaching its output (so satrn_batchnorm_act_bwd's reduction pass is not needed;
+ * follow with the apply pass).  bn_scratch = the BatchNorm forward's scratch (scale/shift at [2C,4C), mean/rstd at [4C,6C));
+ * P_scratch: 4*B*C floats.  bf16 wide form only: returns -1 for shapes / dtypes the wide form does not take. */
+int satrn_se_bwd_bnred(int dtype, const void* dy, const void* bn_y, const float* bn_scratch, int act, const void* gate, const float* u1,
+                       const void* W1, const void* W2, float* dz2, float* du1, float* ds1_zeroed, void* dpooled, float* P_scratch,
+                       float* bn_scratch2, int B, int HW, int C, int S, void* stream);
 
 /* Adaptive 2D positional encoding, networks/EfficientSATRN.py:135-154: out = x + g0*hpos[h] + g1*wpos[w]
  * with gate [B][2C] = sigmoid(dense1(relu(dense0(mean_hw x)))) computed by satrn_pool_hw + satrn_linear_fwd. */

@@ -1418,8 +1418,18 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr) {
       float* g1 = eb->se_r.g; float* gb1 = eb->se_rb.g; float* g2 = eb->se_e.g; float* gb2 = eb->se_eb.g;
       float* ds1 = e.zalloc((size_t)B * S);
       bool wide = false;
+      static const bool fold = getenv("SATRN_NO_SE_FOLD") == nullptr;
+      // x is a BatchNorm output read by this op only: its backward computes y->g*gate + dpooled/HW on the fly, so the gradient
+      // tensor se_bwd_x would write is never materialised -- and (round 2) that BatchNorm's backward column sums come out of the
+      // two SE kernels as well
+      const bool folds = fold && x->bn_y && !x->bn_has_res && x->ncons == 1 && !x->g;
+      const bool bnred = folds && g_fuse_bnb && !x->bn_red && getenv("SATRN_SE_NO_BN_SUMS") == nullptr;   // read per call (tests)
+      float* bnP = bnred ? (float*)e.alloc((size_t)4 * B * C * 4) : nullptr;
+      float* bnR = bnred ? e.zalloc((size_t)2 * C) : nullptr;
       WORK(e, 8.0 * (double)B * C * S, (double)x->rows * C * e.esz() * 2 + (double)C * S * e.esz() * 2);
-      LCH(e, wide = launch_se_bwd_wide(dt, y->g, x->p, gp, u1, w1, w2, dz2, du1, ds1, dpooled, B, HW, C, S, e.s));
+      LCH(e, wide = launch_se_bwd_wide(dt, y->g, x->p, gp, u1, w1, w2, dz2, du1, ds1, dpooled, B, HW, C, S, e.s, bnred ? x->bn_y : nullptr, x->bn_ss, x->bn_mr,
+                                       x->bn_act, bnP, bnR));
+      if (wide && bnred && !e.dry) { x->bn_red = bnR; x->bn_red_rep = 1; }
       if (e.dry) wide = true;   // planning pass: same allocations either way
       if (wide) {
         // weight gradients of the two SE matrices: optimizer-only -> side stream
@@ -1437,10 +1447,7 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr) {
           e.defer([=](hipStream_t ws) { launch_se_bwd(dt, dgate, gp, u1, s1, pooled, w1, w2, dz2, du1, dpooled, g1, gb1, g2, gb2, B, C, S, ws, 2); });
         }
       }
-      static const bool fold = getenv("SATRN_NO_SE_FOLD") == nullptr;
-      if (fold && x->bn_y && !x->bn_has_res && x->ncons == 1 && !x->g) {
-        // x is a BatchNorm output read by this op only: its backward computes y->g*gate + dpooled/HW on the fly, so the
-        // gradient tensor se_bwd_x would write is never materialised
+      if (folds) {
         x->g = y->g; x->g_init = true;
         x->se_gate = gate->p; x->se_dpool = dpooled; x->se_hw = HW;
       } else {

@@ -143,7 +143,11 @@ void launch_se_scale(int dt, const void* x, const void* gate /*[B,C] T*/, void* 
 // dx (+)= dout*gate + dpool[b,c]/HW ; dgate[b,c] = sum_hw dout*x   (two kernels)
 // data path of the squeeze-and-excite backward in two wide launches (dgate + dz2 + ds1 | du1 + dpooled); false = not taken
 bool launch_se_bwd_wide(int dt, const void* dy, const void* x, const void* gate, const float* u1, const void* W1, const void* W2, float* dz2,
-                        float* du1, float* ds1_zeroed /*[B][S]*/, void* dpooled, int B, int HW, int C, int S, hipStream_t s);
+                        float* du1, float* ds1_zeroed /*[B][S]*/, void* dpooled, int B, int HW, int C, int S, hipStream_t s,
+                        // optional: x is act(bn(bn_y)) and read by this op only -> x is recomputed from bn_y, and bn_red (zeroed [2C]) receives that
+                        // BatchNorm's backward column sums (bn_P: [4][B][C] floats of scratch); launch_bn_bwd_reduce is then not needed
+                        const void* bn_y = nullptr, const float* bn_ss = nullptr, const float* bn_mr = nullptr, int bn_act = 0, float* bn_P = nullptr,
+                        float* bn_red = nullptr);
 void launch_se_bwd_gate(int dt, const void* dout, const void* x, void* dgate /*[B,C] T*/, int B, int HW, int C, hipStream_t s);
 void launch_se_bwd_x(int dt, const void* dout, const void* gate, const void* dpool /*[B,C] T or null*/, void* dx, int B,
                      int HW, int C, int beta, hipStream_t s);

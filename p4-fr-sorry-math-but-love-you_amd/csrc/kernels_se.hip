@@ -364,35 +364,80 @@ __global__ __launch_bounds__(1024) void se_bwd_a_kernel(const T* dgate, const T*
 // (not in the deterministic mode: the S atomics per workgroup add in arrival order)
 #define SEB_G 8
 // bf16 only (f32 is the deterministic mode, which does not come here); S = 64 hidden units at most, <= 32 chunks per group
-__global__ __launch_bounds__(256) void se_bwd_gate_ds_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate,
-                                                             const bf16_t* __restrict__ W2, float* dz2, float* ds1, int HW, int C, int S) {
+// With bn_y (the raw input of the BatchNorm whose activated output x is): x is RECOMPUTED from bn_y (same formula and rounding as the
+// forward pass, so the same values) instead of read, and the workgroup also leaves the four per-(image, channel) sums from which
+// kernel 2 assembles that BatchNorm's backward column sums -- the gradient reaching the BatchNorm output is dy*gate + dpooled/HW, so
+//   sum_hw g      = gate * sum(dy*a) + dpooled/HW * sum(a)           a = act'(u), u = bn_y*scale+shift
+//   sum_hw g*xhat = gate * sum(dy*a*xhat) + dpooled/HW * sum(a*xhat)
+// and the chip-wide reduction pass over dy / bn_y / gate / dpooled that used to follow (launch_bn_bwd_reduce, 16-29 us) is gone.
+struct SeBnP { const bf16_t* bn_y; const float* ss; const float* mr; int act; float* P; /*[4][B][C]*/ float* red; /*[2C] zeroed*/ int B; };
+#define SEB_NT 512   // phase 1 (the stream over the image) runs on 8 waves; the small matrix phases on the first four
+__global__ __launch_bounds__(SEB_NT) void se_bwd_gate_ds_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate,
+                                                                const bf16_t* __restrict__ W2, float* dz2, float* ds1, int HW, int C, int S, SeBnP bn) {
   typedef bf16_t T;
-  constexpr int CH = 8;
-  __shared__ float part[256 * CH];   // [row lane][chunk lane * CH]
+  constexpr int CH = 8, NW = SEB_NT / 64;
+  __shared__ float part[5][NW][32 * CH];   // per wave: [chunk lane * CH] partial sums (dgate, then the four BatchNorm sums)
   __shared__ float dz[32 * CH];
   __shared__ float red[4][64];
   const int b = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int CC = C / CH, ncg = (CC + SEB_G - 1) / SEB_G;   // chunks per group (<= 32)
+  const int CC = C / CH, ncg = (CC + (int)gridDim.y - 1) / (int)gridDim.y;   // chunks per group (<= 32)
   const int cbeg = grp * ncg, nch = min(ncg, CC - cbeg);     // this group's chunks [cbeg, cbeg + nch)
   const int cs = nch > 0 ? nch * CH : 0;                     // its channels
   // expand-matrix rows of this group (cs x S): thread = (16-byte chunk q of a row, channel lane), all requested now
   const int SQ = S / CH;                 // chunks per row (<= 8)
-  const int q = tid & 7, cl = tid >> 3;  // 8 chunk slots x 32 channel lanes
+  const int q = tid & 7, cl = tid >> 3;  // 8 chunk slots x 32 channel lanes (first 256 threads)
   uint4 wraw[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const int c = cl + 32 * k;
-    wraw[k] = (c < cs && q < SQ) ? ld16(W2 + (long)(cbeg * CH + c) * S + q * CH) : zero16();
+    wraw[k] = (tid < 256 && c < cs && q < SQ) ? ld16(W2 + (long)(cbeg * CH + c) * S + q * CH) : zero16();
   }
-  // dgate = sum_hw dy * x: TX chunk lanes (power of two >= nch) x TY row lanes
+  // dgate = sum_hw dy * x: TX chunk lanes (power of two >= nch, <= 32) x TY row lanes
   int txl = 0;
   while ((1 << txl) < nch) ++txl;
-  const int TX = 1 << txl, TY = 256 >> txl;
+  const int TX = 1 << txl, TY = SEB_NT >> txl;
   const int tx = tid & (TX - 1), ty = tid >> txl;
-  float a[CH];
+  float a[CH], p1[CH], p2[CH], p3[CH], p4[CH];
 #pragma unroll
-  for (int j = 0; j < CH; ++j) a[j] = 0.f;
-  if (tx < nch) {
+  for (int j = 0; j < CH; ++j) a[j] = p1[j] = p2[j] = p3[j] = p4[j] = 0.f;
+  if (bn.bn_y) {
+    if (tx < nch) {
+      const int c0 = (cbeg + tx) * CH;
+      const long base = (long)b * HW * C + c0;
+      float sc[CH], sh[CH], mu[CH], rs[CH];
+      {
+        const float4* q0 = reinterpret_cast<const float4*>(bn.ss + c0); const float4* q1 = reinterpret_cast<const float4*>(bn.ss + C + c0);
+        const float4* q2 = reinterpret_cast<const float4*>(bn.mr + c0); const float4* q3 = reinterpret_cast<const float4*>(bn.mr + C + c0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 v0 = q0[h], v1 = q1[h], v2 = q2[h], v3 = q3[h];
+          sc[4 * h] = v0.x; sc[4 * h + 1] = v0.y; sc[4 * h + 2] = v0.z; sc[4 * h + 3] = v0.w;
+          sh[4 * h] = v1.x; sh[4 * h + 1] = v1.y; sh[4 * h + 2] = v1.z; sh[4 * h + 3] = v1.w;
+          mu[4 * h] = v2.x; mu[4 * h + 1] = v2.y; mu[4 * h + 2] = v2.z; mu[4 * h + 3] = v2.w;
+          rs[4 * h] = v3.x; rs[4 * h + 1] = v3.y; rs[4 * h + 2] = v3.z; rs[4 * h + 3] = v3.w;
+        }
+      }
+      const bool silu = bn.act == ACT_SILU;
+#pragma unroll 4
+      for (int r = ty; r < HW; r += TY) {
+        float d[CH], v[CH];
+        unpack<T>(ld16(dy + base + (long)r * C), d);
+        unpack<T>(ld16(bn.bn_y + base + (long)r * C), v);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const float u = v[j] * sc[j] + sh[j];
+          float xf, ab;
+          if (silu) { const float sg = sigmoidf_(u); xf = u * sg; ab = sg * (1.f + u * (1.f - sg)); }   // one exp + one rcp for both (act_fwd / act_bwd formulas)
+          else { xf = act_fwd(u, bn.act); ab = act_bwd(u, bn.act); }
+          const float xv = to_f(from_f<T>(xf));   // the stored activation, bit for bit
+          const float da = d[j] * ab;
+          const float xh = (v[j] - mu[j]) * rs[j];
+          a[j] += d[j] * xv;
+          p1[j] += da; p2[j] += ab; p3[j] += da * xh; p4[j] += ab * xh;
+        }
+      }
+    }
+  } else if (tx < nch) {
     const long base = (long)b * HW * C + (long)(cbeg + tx) * CH;
 #pragma unroll 4
     for (int r = ty; r < HW; r += TY) {
@@ -403,17 +448,43 @@ __global__ __launch_bounds__(256) void se_bwd_gate_ds_kernel(const bf16_t* __res
       for (int j = 0; j < CH; ++j) a[j] += d[j] * v[j];
     }
   }
+  // row lanes of a wave (lane bits txl..5) by shuffles, the waves through LDS
+  for (int o = TX; o < 64; o <<= 1) {
 #pragma unroll
-  for (int j = 0; j < CH; ++j) part[(ty * TX + tx) * CH + j] = a[j];
+    for (int j = 0; j < CH; ++j) a[j] += __shfl_xor(a[j], o, 64);
+    if (bn.bn_y) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        p1[j] += __shfl_xor(p1[j], o, 64); p2[j] += __shfl_xor(p2[j], o, 64);
+        p3[j] += __shfl_xor(p3[j], o, 64); p4[j] += __shfl_xor(p4[j], o, 64);
+      }
+    }
+  }
+  if (lane < TX) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      part[0][wave][lane * CH + j] = a[j];
+      if (bn.bn_y) { part[1][wave][lane * CH + j] = p1[j]; part[2][wave][lane * CH + j] = p2[j]; part[3][wave][lane * CH + j] = p3[j]; part[4][wave][lane * CH + j] = p4[j]; }
+    }
+  }
   __syncthreads();
-  for (int c = tid; c < cs; c += 256) {
-    const int cx = c / CH, cj = c - cx * CH;
+  for (int c = tid; c < cs; c += SEB_NT) {
     float dg = 0.f;
-    for (int y2 = 0; y2 < TY; ++y2) dg += part[(y2 * TX + cx) * CH + cj];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dg += part[0][w][c];
     const float g = to_f(gate[(long)b * C + cbeg * CH + c]);
     const float v = dg * g * (1.f - g);
     dz[c] = v;
     dz2[(long)b * C + cbeg * CH + c] = v;
+    if (bn.bn_y) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += part[1 + k][w][c];
+        bn.P[((long)k * bn.B + b) * C + cbeg * CH + c] = sum;
+      }
+    }
   }
   __syncthreads();
   // ds1[j] += sum_c W2[c][j] * dz[c] over this group's channels
@@ -437,7 +508,7 @@ __global__ __launch_bounds__(256) void se_bwd_gate_ds_kernel(const bf16_t* __res
 #pragma unroll
     for (int e = 0; e < CH; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
   }
-  if (lane < 8) {
+  if (lane < 8 && wave < 4) {
 #pragma unroll
     for (int e = 0; e < CH; ++e) red[wave][lane * CH + e] = acc[e];
   }
@@ -445,13 +516,13 @@ __global__ __launch_bounds__(256) void se_bwd_gate_ds_kernel(const bf16_t* __res
   if (tid < S) atomicAdd(ds1 + (long)b * S + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
 }
 __global__ __launch_bounds__(256) void se_bwd_pool_kernel(const float* __restrict__ ds1, const float* __restrict__ u1, const bf16_t* __restrict__ W1,
-                                                          float* du1, bf16_t* dpooled, int C, int S) {
+                                                          float* du1, bf16_t* dpooled, int C, int S, SeBnP bn, const bf16_t* __restrict__ gate, float inv_hw) {
   typedef bf16_t T;
   constexpr int CH = 8;
   __shared__ float du[64];
   __shared__ float part[8][32 * CH];
   const int b = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x;
-  const int CC = C / CH, ncg = (CC + SEB_G - 1) / SEB_G;
+  const int CC = C / CH, ncg = (CC + (int)gridDim.y - 1) / (int)gridDim.y;
   const int cbeg = grp * ncg, nch = min(ncg, CC - cbeg);
   const int tx = tid & 31, jg = tid >> 5;   // chunk lane, group of 8 hidden units
   // the matrix rows of this thread are requested before the hidden-layer gradient they are multiplied with
@@ -489,17 +560,31 @@ __global__ __launch_bounds__(256) void se_bwd_pool_kernel(const float* __restric
     float v = 0.f;
 #pragma unroll
     for (int g2 = 0; g2 < 8; ++g2) v += part[g2][c];
-    dpooled[(long)b * C + cbeg * CH + c] = from_f<T>(v);
+    const T vr = from_f<T>(v);
+    dpooled[(long)b * C + cbeg * CH + c] = vr;
+    if (bn.bn_y) {   // this image's share of the BatchNorm-backward column sums (see kernel 1)
+      const long o = (long)b * C + cbeg * CH + c, ps = (long)bn.B * C;
+      const float g = to_f(gate[o]), dp = to_f(vr) * inv_hw;
+      atomicAdd(bn.red + cbeg * CH + c, g * bn.P[o] + dp * bn.P[ps + o]);
+      atomicAdd(bn.red + C + cbeg * CH + c, g * bn.P[2 * ps + o] + dp * bn.P[3 * ps + o]);
+    }
   }
 }
 // false = shape / mode not taken (the caller runs launch_se_bwd_gate + launch_se_bwd)
 bool launch_se_bwd_wide(int dt, const void* dy, const void* x, const void* gate, const float* u1, const void* W1, const void* W2, float* dz2,
-                        float* du1, float* ds1_zeroed, void* dpooled, int B, int HW, int C, int S, hipStream_t s) {
+                        float* du1, float* ds1_zeroed, void* dpooled, int B, int HW, int C, int S, hipStream_t s, const void* bn_y,
+                        const float* bn_ss, const float* bn_mr, int bn_act, float* bn_P, float* bn_red) {
   const bool off = getenv("SATRN_SE_NO_WIDE_BWD") != nullptr;   // read per call (tests)
-  if (off || g_det.on || dt != DT_BF16 || S > 64 || (S % 8) != 0 || (C % 8) != 0 || ((C / 8 + SEB_G - 1) / SEB_G) > 32) return false;
-  hipLaunchKernelGGL(se_bwd_gate_ds_kernel, dim3(B, SEB_G), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gate, (const bf16_t*)W2, dz2, ds1_zeroed,
-                     HW, C, S);
-  hipLaunchKernelGGL(se_bwd_pool_kernel, dim3(B, SEB_G), dim3(256), 0, s, ds1_zeroed, u1, (const bf16_t*)W1, du1, (bf16_t*)dpooled, C, S);
+  // channel groups: slabs of exactly 64 channels where C allows (every row of a slab is one aligned 128-byte line: 960 channels in 8
+  // groups were 240-byte rows straddling three lines), else SEB_G groups
+  const int G = SEB_G;   // 4 / 6 / 16 groups and 64-channel slabs (C / 64 groups) were measured: 25.6 / 20.2 / 33.4 / 32.9 us against 20.9
+  if (off || g_det.on || dt != DT_BF16 || S > 64 || (S % 8) != 0 || (C % 8) != 0 || ((C / 8 + G - 1) / G) > 32) return false;
+  SeBnP bn;
+  bn.bn_y = (bn_y && bn_P && bn_red) ? (const bf16_t*)bn_y : nullptr; bn.ss = bn_ss; bn.mr = bn_mr; bn.act = bn_act; bn.P = bn_P; bn.red = bn_red; bn.B = B;
+  hipLaunchKernelGGL(se_bwd_gate_ds_kernel, dim3(B, G), dim3(SEB_NT), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gate, (const bf16_t*)W2, dz2, ds1_zeroed,
+                     HW, C, S, bn);
+  hipLaunchKernelGGL(se_bwd_pool_kernel, dim3(B, G), dim3(256), 0, s, ds1_zeroed, u1, (const bf16_t*)W1, du1, (bf16_t*)dpooled, C, S, bn, (const bf16_t*)gate,
+                     1.0f / (float)HW);
   return true;
 }
 

@@ -253,6 +253,17 @@ int satrn_se_bwd(int dt, const void* dy, const void* x, const void* gate, const 
   }
   return done("se_bwd");
 }
+int satrn_se_bwd_bnred(int dt, const void* dy, const void* bn_y, const float* bn_scratch, int act, const void* gate, const float* u1, const void* W1,
+                       const void* W2, float* dz2, float* du1, float* ds1_zeroed, void* dpooled, float* P_scratch, float* bn_scratch2, int B, int HW,
+                       int C, int S, void* st) {
+  CHK_DT(dt);
+  if (B <= 0 || HW <= 0 || C <= 0 || S <= 0 || (C % 8) != 0) return fail(-1, "satrn_se_bwd_bnred: bad shape");
+  if (!bn_y || !bn_scratch || !P_scratch || !bn_scratch2 || !ds1_zeroed) return fail(-1, "satrn_se_bwd_bnred: null operand");
+  if (!launch_se_bwd_wide(dt, dy, nullptr, gate, u1, W1, W2, dz2, du1, ds1_zeroed, dpooled, B, HW, C, S, S(st), bn_y, bn_scratch + 2 * C, bn_scratch + 4 * C, act,
+                          P_scratch, bn_scratch2))
+    return fail(-1, "satrn_se_bwd_bnred: the wide form does not take this dtype / shape (use satrn_se_bwd + satrn_batchnorm_act_bwd)");
+  return done("se_bwd_bnred");
+}
 int satrn_pool_hw(int dt, const void* x, void* out, int B, int HW, int C, void* st) {
   CHK_DT(dt);
   if (chk_c(dt, C, "C")) return -1;
