@@ -111,6 +111,13 @@ int satrn_batchnorm_act_dwconv3x3_fwd(int dtype, const void* y, const float* wei
  * satrn_batchnorm_act_bwd_apply. */
 int satrn_dwconv3x3_bwd_data_bnred(int dtype, const void* d_out, const void* dw_packed, void* dz, int accumulate, const void* y,
                                    const float* scratch, int act, float* scratch2, int B, int H, int W, int C, void* stream);
+/* satrn_batchnorm_act_bwd_apply of the BatchNorm BEHIND the depthwise convolution (its output gradient dz2, raw input y2 = the
+ * convolution's output, column sums in scratch2_b) + satrn_dwconv3x3_bwd_data_bnred, one launch where the shape allows: the
+ * apply result dy2 is written (the depthwise weight gradient reads it) and consumed from LDS.  Same results as the two calls. */
+int satrn_bn_bwd_apply_dwconv3x3_bwd_data_bnred(int dtype, const void* dz2, const void* y2, const float* weight_b, const float* scratch_b, int act_b,
+                                                const float* scratch2_b, void* dy2, float* dweight_b, float* dbias_b, const void* dw_packed,
+                                                void* dz, int accumulate, const void* y, const float* scratch, int act, float* scratch2, int B,
+                                                int H, int W, int C, void* stream);
 /* the second half of satrn_batchnorm_act_bwd for callers that already hold the column sums in scratch2 */
 int satrn_batchnorm_act_bwd_apply(int dtype, const void* dz, const void* y, const float* weight, const float* scratch, int act,
                                   void* dy, float* dweight, float* dbias, long M, int C, const float* scratch2, void* stream);

@@ -861,9 +861,16 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** poo
         LCH(e, launch_bn_bwd_reduce(e.dt, z->g, y->p, ss, mr, M, C, act, red, e.s, z->se_gate, z->se_dpool, z->se_hw));
       }
       void* dy = e.grad(y, nullptr);
-      e.nbytes = (double)M * C * e.esz() * 3;
-      LCH(e, launch_bn_bwd_apply(e.dt, z->g, y->p, ss, mr, bn->w.p, red, M, C, act, dy, bn->w.g, bn->b.g, e.s, z->bn_red ? z->bn_red_rep : 1,
-                                 z->se_gate, z->se_dpool, z->se_hw, eval_stats));
+      if (y->dw_bwd_fuse && !eval_stats && (z->bn_red ? z->bn_red_rep : 1) == 1 && !e.dry) {
+        // the depthwise convolution that produced y runs this pass inside its data-gradient kernel (its closure is next)
+        BnBwdHold& h = y->bhold;
+        h.armed = true; h.dz = z->g; h.y = y->p; h.ss = ss; h.mr = mr; h.w = bn->w.p; h.red = red; h.M = M; h.C = C; h.act = act; h.dy = dy;
+        h.dwp = bn->w.g; h.dbp = bn->b.g; h.se_gate = z->se_gate; h.se_dpool = z->se_dpool; h.se_hw = z->se_hw;
+      } else {
+        e.nbytes = (double)M * C * e.esz() * 3;
+        LCH(e, launch_bn_bwd_apply(e.dt, z->g, y->p, ss, mr, bn->w.p, red, M, C, act, dy, bn->w.g, bn->b.g, e.s, z->bn_red ? z->bn_red_rep : 1,
+                                   z->se_gate, z->se_dpool, z->se_hw, eval_stats));
+      }
       if (res) acc_grad(e, res, z->g);
     });
   }
@@ -896,6 +903,8 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
   const int B = x->B, H = x->H, W = x->W, C = x->C;
   Tensor* y = e.newt((long)B * OH * OW, C, B, OH, OW);
   if (want_stats && e.train) y->stats = e.zalloc(2 * C);
+  static const bool hold_bwd = getenv("SATRN_NO_FUSED_BN_APPLY_DW") == nullptr;
+  y->dw_bwd_fuse = hold_bwd && e.rec && e.train && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && dwconv_img_ok(e.dt, H, W, C);
   if (want_stats && !e.train && !e.rec && g_fuse_bn_eval) {
     // inference: the BatchNorm that follows runs in this kernel's epilogue (launched by op_bn_act)
     Exec* ep = &e;
@@ -931,24 +940,38 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
     e.tape.push_back([&e, x, y, w, bias, B, H, W, C, OH, OW, stride, pt, pl, fuse_bnb]() {
       if (!y->g) return;
       float* scr = e.zalloc((size_t)10 * C);
+      // data gradient first: with a held BatchNorm pass (y->bhold) this launch is what PRODUCES y->g, which the weight gradient reads
+      int beta;
+      void* dx = e.grad(x, &beta);
+      BnBwdHold* hold = y->bhold.armed ? &y->bhold : nullptr;
+      bool fused = false;
+      if ((fuse_bnb || hold) && !e.dry && !x->bn_red) {
+        float* red = fuse_bnb ? e.zalloc((size_t)2 * C) : nullptr;
+        WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * OH * OW * (hold ? 4 : 2) + (double)B * H * W * (beta ? 2 : 1)) * C * e.esz());
+        LCH(e, fused = launch_dwconv_bwd_bn(e.dt, y->g, w->fwd, dx, beta, fuse_bnb ? x->bn_y : nullptr, x->bn_ss, x->bn_mr, x->bn_act, red, B, H, W, C, e.s, hold));
+        if (fused && fuse_bnb) { x->bn_red = red; x->bn_red_rep = 1; }
+      }
+      if (!fused && hold) {
+        WORK(e, 0, (double)hold->M * hold->C * e.esz() * 3);
+        LCH(e, launch_bn_bwd_apply(e.dt, hold->dz, hold->y, hold->ss, hold->mr, hold->w, hold->red, hold->M, hold->C, hold->act, hold->dy, hold->dwp, hold->dbp, e.s, 1,
+                                   hold->se_gate, hold->se_dpool, hold->se_hw, 0));
+        if (fuse_bnb && !e.dry && !x->bn_red) {
+          float* red = e.zalloc((size_t)2 * C);
+          WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * OH * OW * 2 + (double)B * H * W * (beta ? 2 : 1)) * C * e.esz());
+          LCH(e, fused = launch_dwconv_bwd_bn(e.dt, y->g, w->fwd, dx, beta, x->bn_y, x->bn_ss, x->bn_mr, x->bn_act, red, B, H, W, C, e.s));
+          if (fused) { x->bn_red = red; x->bn_red_rep = 1; }
+        }
+      }
+      y->bhold.armed = false;
+      if (!fused) {
+        WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * OH * OW + (double)B * H * W * (beta ? 2 : 1)) * C * e.esz());
+        LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, nullptr, e.s));
+      }
       {
         const int dt = e.dt; void* xp = x->p; void* yg = y->g; float* wg = w->g; float* bg = bias ? bias->g : nullptr;
         WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * H * W + (double)B * OH * OW) * C * e.esz());
         if (e.prof || e.dry) LCH(e, launch_dwconv_wgrad(dt, xp, yg, wg, bg, scr, B, H, W, C, OH, OW, stride, pt, pl, e.s));
         else e.defer([=](hipStream_t ws) { launch_dwconv_wgrad(dt, xp, yg, wg, bg, scr, B, H, W, C, OH, OW, stride, pt, pl, ws); });
-      }
-      int beta;
-      void* dx = e.grad(x, &beta);
-      bool fused = false;
-      if (fuse_bnb && !e.dry && !x->bn_red) {
-        float* red = e.zalloc((size_t)2 * C);
-        WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * OH * OW * 2 + (double)B * H * W * (beta ? 2 : 1)) * C * e.esz());
-        LCH(e, fused = launch_dwconv_bwd_bn(e.dt, y->g, w->fwd, dx, beta, x->bn_y, x->bn_ss, x->bn_mr, x->bn_act, red, B, H, W, C, e.s));
-        if (fused) { x->bn_red = red; x->bn_red_rep = 1; }
-      }
-      if (!fused) {
-        WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * OH * OW + (double)B * H * W * (beta ? 2 : 1)) * C * e.esz());
-        LCH(e, launch_dwconv(e.dt, 1, y->g, w->fwd, nullptr, dx, B, OH, OW, C, H, W, stride, pt, pl, beta, nullptr, e.s));
       }
     });
   return y;

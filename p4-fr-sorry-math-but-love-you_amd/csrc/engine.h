@@ -78,6 +78,9 @@ struct Tensor {
   // true gradient is g*se_gate[b] + se_dpool[b]/se_hw
   const void* se_gate = nullptr; const void* se_dpool = nullptr; int se_hw = 0;
   bool bn_has_res = false;  // the BatchNorm that produced this tensor also added a residual (its gradient = this tensor's)
+  // output of a depthwise convolution whose backward kernel can also run the backward-apply pass of the BatchNorm that consumes this
+  // tensor: that BatchNorm's closure leaves its operands in bhold instead of launching (op_bn_act -> op_dwconv, launch_dwconv_bwd_bn)
+  bool dw_bwd_fuse = false; BnBwdHold bhold;
   // inference: a product whose launch is postponed until the BatchNorm that consumes it is known, so that BatchNorm (eval
   // statistics) + activation + residual run in its epilogue and the raw output is never written (op_gemm -> op_bn_act)
   std::shared_ptr<GemmP> pend; int pend_mode = 0;

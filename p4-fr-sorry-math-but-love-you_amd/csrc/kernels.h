@@ -129,8 +129,19 @@ void launch_pool_hw(int dt, const void* x, void* out /*[B,C] as T*/, int B, int 
 bool bn_act_pool_ok(long M, int C, int HW);
 // data gradient of the stride-1 depthwise 3x3 (dz (+)= conv^T(dy)) AND the BatchNorm-backward column sums of z = act(bn(y)) in red
 // (zeroed [2C]), one launch (bf16, whole image x 64 channels per workgroup); false = not taken, nothing launched
+// a BatchNorm backward-apply pass handed to the kernel that consumes its result (launch_dwconv_bwd_bn): the operands of launch_bn_bwd_apply
+struct BnBwdHold {
+  bool armed = false;
+  const void* dz = nullptr; const void* y = nullptr; const float* ss = nullptr; const float* mr = nullptr; const float* w = nullptr; const float* red = nullptr;
+  long M = 0; int C = 0, act = 0; void* dy = nullptr; float* dwp = nullptr; float* dbp = nullptr;
+  const void* se_gate = nullptr; const void* se_dpool = nullptr; int se_hw = 0;
+};
+// y == nullptr: no BatchNorm sums (plain data gradient).  ap != nullptr: dy is NOT read -- it is first produced as the BatchNorm
+// backward-apply result of *ap (written to ap->dy = dy for the weight-gradient pass, parameter gradients accumulated) and consumed
+// from LDS: launch_bn_bwd_apply + the data gradient + the next BatchNorm's sums in one launch
 bool launch_dwconv_bwd_bn(int dt, const void* dy, const void* wp, void* dz, int beta, const void* y, const float* ss, const float* mr, int act,
-                          float* red, int B, int H, int W, int C, hipStream_t s);
+                          float* red, int B, int H, int W, int C, hipStream_t s, const BnBwdHold* ap = nullptr);
+bool dwconv_img_ok(int dt, int H, int W, int C);   // shape / dtype / mode test of the two image-tile depthwise kernels
 // BatchNorm(batch statistics)+activation of y -> z AND the stride-1 depthwise 3x3 of z -> out with out's column sums in red (zeroed
 // [2C]), one launch (bf16, whole image x 64 channels per workgroup); false = shape / mode not taken, nothing launched
 bool launch_bn_dwconv(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv, int64_t* nbt,

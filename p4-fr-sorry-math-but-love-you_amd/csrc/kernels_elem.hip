@@ -1052,9 +1052,17 @@ bool launch_bn_dwconv(int dt, const void* y, const float* sums, int sums_rep, co
 // -- what launch_dwconv(mode 1) + launch_bn_bwd_reduce did in two launches (the thread-per-pixel-pair form of this fusion needed
 // 206 VGPRs and was slower than the pair; from LDS a thread holds 3 outputs x 8 channels).  dz is rounded to bf16 before it
 // enters the sums, as the separate reduction read it back from memory.
+// APPLY: the tile is not dy as stored but the BatchNorm backward-apply result computed here from that BatchNorm's output gradient
+// (ap.dz, with the squeeze-and-excite fold), its raw input (ap.y) and its column sums -- bn_bwd_apply_kernel's arithmetic, rounded to
+// bf16 and written to ap.dy for the weight-gradient pass exactly as that kernel would have left it.
+struct BnApplyP {
+  const bf16_t* dz; const bf16_t* y; const float* ss; const float* mr; const float* w; const float* red; bf16_t* dy; float* dwp; float* dbp;
+  const bf16_t* se_gate; const bf16_t* se_dpool; float se_scale; float invM; int act;
+};
+template <bool APPLY>
 __global__ __launch_bounds__(512) void dw_bwd_img_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wp, bf16_t* __restrict__ dz,
                                                          const bf16_t* __restrict__ y, const float* ss, const float* mr, float* red, int H, int W,
-                                                         int C, int rowpix, int act, int beta) {
+                                                         int C, int rowpix, int act, int beta, BnApplyP ap) {
   typedef bf16_t T;
   constexpr int CH = 8, SC = BDW_SC, RUN = BDW_RUN;
   extern __shared__ __attribute__((aligned(16))) unsigned char bdw_sm[];
@@ -1066,18 +1074,61 @@ __global__ __launch_bounds__(512) void dw_bwd_img_kernel(const bf16_t* __restric
   const int HW = H * W;
   const long base = (long)img * HW * C + c0;
   const int row = g % H, ox0 = (g / H) * RUN;
-  uint4 raw[RUN], yq[RUN], oq[RUN], wq[9];
+  uint4 raw[RUN], ay[RUN], yq[RUN], oq[RUN], wq[9];
 #pragma unroll
-  for (int k = 0; k < RUN; ++k) raw[k] = ld16(dy + base + (long)(g + k * G) * C);
+  for (int k = 0; k < RUN; ++k) {
+    raw[k] = ld16((APPLY ? ap.dz : dy) + base + (long)(g + k * G) * C);
+    ay[k] = APPLY ? ld16(ap.y + base + (long)(g + k * G) * C) : zero16();
+  }
 #pragma unroll
   for (int t = 0; t < 9; ++t) wq[t] = ld16(wp + (long)t * C + c0);
 #pragma unroll
   for (int p = 0; p < RUN; ++p) {
-    yq[p] = ld16(y + base + (long)(row * W + ox0 + p) * C);
+    yq[p] = y ? ld16(y + base + (long)(row * W + ox0 + p) * C) : zero16();
     oq[p] = beta ? ld16(dz + base + (long)(row * W + ox0 + p) * C) : zero16();
   }
+  if (APPLY) {
+    // coefficients of dy = A*g + Bc + Cc*y, g = dz*act'(y*scale+shift)   (bn_bwd_apply_kernel)
+    float asc[CH], ash[CH], A[CH], Bc[CH], Cc[CH], gt[CH], dp[CH];
+    {
+      float amu[CH], ars[CH], ww[CH], r0[CH], r1[CH];
+      ldv(ap.ss + c0, asc, CH); ldv(ap.ss + C + c0, ash, CH); ldv(ap.mr + c0, amu, CH); ldv(ap.mr + C + c0, ars, CH);
+      ldv(ap.w + c0, ww, CH); ldv(ap.red + c0, r0, CH); ldv(ap.red + C + c0, r1, CH);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const float a = ww[j] * ars[j], m1 = r0[j] * ap.invM, m2 = r1[j] * ap.invM;
+        A[j] = a;
+        Cc[j] = -a * ars[j] * m2;
+        Bc[j] = -a * m1 + a * ars[j] * amu[j] * m2;
+      }
+      if (img == 0 && g == 0 && ap.dwp) {   // parameter gradients of that BatchNorm (grad buffers are zeroed per step: accumulate)
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { ap.dwp[c0 + j] += r1[j]; ap.dbp[c0 + j] += r0[j]; }
+      }
+    }
+    if (ap.se_gate) { unpack<T>(ld16(ap.se_gate + (long)img * C + c0), gt); unpack<T>(ld16(ap.se_dpool + (long)img * C + c0), dp); }
+#pragma unroll
+    for (int k = 0; k < RUN; ++k) {
+      float d[CH], v[CH];
+      unpack<T>(raw[k], d);
+      unpack<T>(ay[k], v);
+      if (ap.se_gate) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) d[j] = d[j] * gt[j] + dp[j] * ap.se_scale;
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const float gg = d[j] * act_bwd(v[j] * asc[j] + ash[j], ap.act);
+        d[j] = A[j] * gg + Bc[j] + Cc[j] * v[j];
+      }
+      raw[k] = pack<T>(d);
+      st16(ap.dy + base + (long)(g + k * G) * C, raw[k]);
+    }
+  }
   float sc[CH], sh[CH], mu[CH], rs[CH];
-  ldv(ss + c0, sc, CH); ldv(ss + C + c0, sh, CH); ldv(mr + c0, mu, CH); ldv(mr + C + c0, rs, CH);
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { sc[j] = sh[j] = mu[j] = rs[j] = 0.f; }
+  if (y) { ldv(ss + c0, sc, CH); ldv(ss + C + c0, sh, CH); ldv(mr + c0, mu, CH); ldv(mr + C + c0, rs, CH); }
   const int nh = 2 * (W + 2) + 2 * H;
   for (int i = tid; i < nh * SC; i += NT) {
     const int cell = i / SC, ch = i - cell * SC;
@@ -1136,6 +1187,7 @@ __global__ __launch_bounds__(512) void dw_bwd_img_kernel(const bf16_t* __restric
       s1[j] += gg; s2[j] += gg * ((v[j] - mu[j]) * rs[j]);
     }
   }
+  if (!y) return;   // plain data gradient (uniform: no barrier is skipped by part of the workgroup)
 #pragma unroll
   for (int o = SC; o < 64; o <<= 1) {
 #pragma unroll
@@ -1155,17 +1207,31 @@ __global__ __launch_bounds__(512) void dw_bwd_img_kernel(const bf16_t* __restric
   }
 }
 // false = shape / mode not taken (the caller launches launch_dwconv(mode 1) and leaves the sums to launch_bn_bwd_reduce)
+bool dwconv_img_ok(int dt, int H, int W, int C) {
+  if (g_det.on || dt != DT_BF16 || (C % (8 * BDW_SC)) != 0 || (W % BDW_RUN) != 0) return false;
+  const int NT = (H * W / BDW_RUN) * BDW_SC;
+  return NT <= 512 && (NT % 64) == 0 && (size_t)(H + 2) * ((W + 2) | 1) * BDW_SC * 16 <= 60 * 1024;
+}
 bool launch_dwconv_bwd_bn(int dt, const void* dy, const void* wp, void* dz, int beta, const void* y, const float* ss, const float* mr, int act,
-                          float* red, int B, int H, int W, int C, hipStream_t s) {
+                          float* red, int B, int H, int W, int C, hipStream_t s, const BnBwdHold* hold) {
   const bool off = getenv("SATRN_NO_FUSED_DW_BWD") != nullptr;   // read per call (tests)
-  if (off || g_det.on || dt != DT_BF16 || !red || !y || (C % (8 * BDW_SC)) != 0 || (W % BDW_RUN) != 0) return false;
+  if (off || !dwconv_img_ok(dt, H, W, C) || (y && !red) || (!y && !hold)) return false;
   const int HW = H * W, NT = (HW / BDW_RUN) * BDW_SC;
-  if (NT > 512 || (NT % 64) != 0) return false;
   const int rowpix = (W + 2) | 1;
   const size_t lds = (size_t)(H + 2) * rowpix * BDW_SC * 16;
-  if (lds > 60 * 1024) return false;
-  hipLaunchKernelGGL(dw_bwd_img_kernel, dim3(B, C / (8 * BDW_SC)), dim3(NT), lds, s, (const bf16_t*)dy, (const bf16_t*)wp, (bf16_t*)dz, (const bf16_t*)y,
-                     ss, mr, red, H, W, C, rowpix, act, beta);
+  BnApplyP ap = {};
+  if (hold) {
+    if (getenv("SATRN_NO_FUSED_BN_APPLY_DW") != nullptr || hold->C != C || hold->M != (long)B * HW) return false;
+    ap.dz = (const bf16_t*)hold->dz; ap.y = (const bf16_t*)hold->y; ap.ss = hold->ss; ap.mr = hold->mr; ap.w = hold->w; ap.red = hold->red;
+    ap.dy = (bf16_t*)hold->dy; ap.dwp = hold->dwp; ap.dbp = hold->dbp; ap.se_gate = (const bf16_t*)hold->se_gate; ap.se_dpool = (const bf16_t*)hold->se_dpool;
+    ap.se_scale = hold->se_hw > 0 ? 1.0f / (float)hold->se_hw : 0.f; ap.invM = 1.0f / (float)hold->M; ap.act = hold->act;
+    if (hold->se_gate && hold->se_hw != HW) return false;
+    hipLaunchKernelGGL(dw_bwd_img_kernel<true>, dim3(B, C / (8 * BDW_SC)), dim3(NT), lds, s, (const bf16_t*)dy, (const bf16_t*)wp, (bf16_t*)dz, (const bf16_t*)y,
+                       ss, mr, red, H, W, C, rowpix, act, beta, ap);
+  } else {
+    hipLaunchKernelGGL(dw_bwd_img_kernel<false>, dim3(B, C / (8 * BDW_SC)), dim3(NT), lds, s, (const bf16_t*)dy, (const bf16_t*)wp, (bf16_t*)dz, (const bf16_t*)y,
+                       ss, mr, red, H, W, C, rowpix, act, beta, ap);
+  }
   return true;
 }
 

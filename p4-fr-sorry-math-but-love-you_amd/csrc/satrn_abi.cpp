@@ -188,6 +188,24 @@ int satrn_dwconv3x3_bwd_data_bnred(int dt, const void* dout, const void* dwp, vo
   }
   return done("dwconv3x3_bwd_data_bnred");
 }
+int satrn_bn_bwd_apply_dwconv3x3_bwd_data_bnred(int dt, const void* dz2, const void* y2, const float* wb, const float* scratch_b, int act_b,
+                                                const float* scratch2_b, void* dy2, float* dwb, float* dbb, const void* dwp, void* dz, int accumulate,
+                                                const void* y, const float* scratch, int act, float* scratch2, int B, int H, int W, int C, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  const long M = (long)B * H * W;
+  BnBwdHold h;
+  h.armed = true; h.dz = dz2; h.y = y2; h.ss = scratch_b + 2 * C; h.mr = scratch_b + 4 * C; h.w = wb; h.red = scratch2_b; h.M = M; h.C = C; h.act = act_b;
+  h.dy = dy2; h.dwp = dwb; h.dbp = dbb;
+  if (!launch_dwconv_bwd_bn(dt, dy2, dwp, dz, accumulate, y, scratch + 2 * C, scratch + 4 * C, act, scratch2, B, H, W, C, S(st), &h)) {
+    launch_bn_bwd_apply(dt, dz2, y2, scratch_b + 2 * C, scratch_b + 4 * C, wb, scratch2_b, M, C, act_b, dy2, dwb, dbb, S(st));
+    if (!launch_dwconv_bwd_bn(dt, dy2, dwp, dz, accumulate, y, scratch + 2 * C, scratch + 4 * C, act, scratch2, B, H, W, C, S(st))) {
+      launch_dwconv(dt, 1, dy2, dwp, nullptr, dz, B, H, W, C, H, W, 1, 1, 1, accumulate, nullptr, S(st));
+      launch_bn_bwd_reduce(dt, dz, y, scratch + 2 * C, scratch + 4 * C, M, C, act, scratch2, S(st));
+    }
+  }
+  return done("bn_bwd_apply_dwconv3x3_bwd_data_bnred");
+}
 int satrn_batchnorm_act_bwd_apply(int dt, const void* dz, const void* y, const float* w, const float* scratch, int act, void* dy, float* dw,
                                   float* db, long M, int C, const float* scratch2, void* st) {
   CHK_DT(dt);

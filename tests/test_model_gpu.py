@@ -386,7 +386,7 @@ def test_segmented_backward_equals_whole_backward(golden_dir, name):
         model.train_step(imgd, expd, 0.0, phase=18)  # out of order
 
 
-_FUSED_SWITCHES = ("SATRN_NO_FUSED_POOL", "SATRN_DW_NO_FUSED_RED", "SATRN_GEMM_NO_G2", "SATRN_SE_NO_WIDE_BWD", "SATRN_NO_FUSED_BN_DW", "SATRN_NO_FUSED_DW_BWD", "SATRN_SE_NO_BN_SUMS")
+_FUSED_SWITCHES = ("SATRN_NO_FUSED_POOL", "SATRN_DW_NO_FUSED_RED", "SATRN_GEMM_NO_G2", "SATRN_SE_NO_WIDE_BWD", "SATRN_NO_FUSED_BN_DW", "SATRN_NO_FUSED_DW_BWD", "SATRN_SE_NO_BN_SUMS", "SATRN_NO_FUSED_BN_APPLY_DW")
 
 
 def test_fused_chain_kernels_equal_their_plain_forms(golden_dir, monkeypatch):

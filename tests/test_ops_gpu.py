@@ -357,6 +357,58 @@ def test_dwconv_bwd_data_with_batchnorm_sums(lib, dt, B, H, W, C, acc, monkeypat
     close(dy, dyp.float().cpu(), dt, "dw_bwd_bn dy fused vs plain", f32_tol=1e-5, bf16_tol=1e-2)
 
 
+@pytest.mark.parametrize("B,H,W,C,acc", [(3, 8, 24, 128, 0), (4, 4, 12, 192, 1), (2, 8, 24, 960, 0), (2, 6, 10, 64, 0)])
+def test_bn_backward_apply_inside_dwconv_backward(lib, B, H, W, C, acc, monkeypatch):
+    """bf16: the backward-apply pass of the BatchNorm behind a depthwise convolution run inside that convolution's data-gradient
+    kernel (one launch) against the same two operators called one after the other -- every output bit for bit."""
+    dt = "bf16"
+    M = B * H * W
+    y1 = q(rnd(M, C, seed=1) * 2 + 0.5, dt)          # raw input of the BatchNorm in front of the convolution
+    y2 = q(rnd(M, C, seed=2) * 1.5 - 0.2, dt)        # the convolution's output = raw input of the BatchNorm behind it
+    dz2 = q(rnd(M, C, seed=3), dt)                   # gradient of that BatchNorm's output
+    w1, b1 = 1 + rnd(C, seed=4, scale=0.2), rnd(C, seed=5, scale=0.1)
+    w2, b2 = 1 + rnd(C, seed=6, scale=0.2), rnd(C, seed=7, scale=0.1)
+    dwk = q(rnd(C, 1, 3, 3, seed=8, scale=0.3), dt)
+    dz0 = q(rnd(M, C, seed=9, scale=0.5), dt)
+    eps = 1e-3
+    wp = torch.empty(9, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_pack_dwconv3x3(dti(dt), P(dev(dwk)), P(wp), C, st()))
+    y1d, y2d, dz2d = dev(y1, dt), dev(y2, dt), dev(dz2, dt)
+    scr = []
+    for yy, ww, bb in ((y1d, w1, b1), (y2d, w2, b2)):   # forward passes leave scale/shift + mean/rstd in the scratch
+        sc = torch.zeros(6 * C, device="cuda")
+        zz = torch.empty(M, C, dtype=tdt(dt), device="cuda")
+        nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ok(lib, lib.satrn_batchnorm_act_fwd(dti(dt), P(yy), P(dev(ww)), P(dev(bb)), P(dev(torch.zeros(C))), P(dev(torch.ones(C))), P(nbt), eps, 1, 2, None,
+                                            P(zz), M, C, P(sc), st()))
+        scr.append(sc)
+    # column sums of the second BatchNorm's backward (any consistent values do: both routes read the same ones)
+    red2 = torch.zeros(2 * C, device="cuda")
+    dy_tmp = torch.empty(M, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_batchnorm_act_bwd(dti(dt), P(dz2d), P(y2d), P(dev(w2)), P(scr[1]), 2, P(dy_tmp), P(torch.zeros(C, device="cuda")),
+                                        P(torch.zeros(C, device="cuda")), M, C, P(red2), st()))
+
+    def run(one_launch):
+        dy2 = torch.empty(M, C, dtype=tdt(dt), device="cuda")
+        dwb, dbb = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        dz = dev(dz0, dt).clone() if acc else torch.empty(M, C, dtype=tdt(dt), device="cuda")
+        s1 = torch.zeros(2 * C, device="cuda")
+        if one_launch:
+            ok(lib, lib.satrn_bn_bwd_apply_dwconv3x3_bwd_data_bnred(dti(dt), P(dz2d), P(y2d), P(dev(w2)), P(scr[1]), 2, P(red2), P(dy2), P(dwb), P(dbb), P(wp), P(dz),
+                                                                    acc, P(y1d), P(scr[0]), 2, P(s1), B, H, W, C, st()))
+        else:
+            ok(lib, lib.satrn_batchnorm_act_bwd_apply(dti(dt), P(dz2d), P(y2d), P(dev(w2)), P(scr[1]), 2, P(dy2), P(dwb), P(dbb), M, C, P(red2), st()))
+            ok(lib, lib.satrn_dwconv3x3_bwd_data_bnred(dti(dt), P(dy2), P(wp), P(dz), acc, P(y1d), P(scr[0]), 2, P(s1), B, H, W, C, st()))
+        torch.cuda.synchronize()
+        return dy2, dwb, dbb, dz, s1
+
+    a, b = run(True), run(False)
+    close(a[0], dy_tmp.float().cpu(), dt, "held bn apply vs satrn_batchnorm_act_bwd", bf16_tol=1e-6)
+    for u, v, what in zip(a[:4], b[:4], ("dy2", "bn dweight", "bn dbias", "dz")):
+        assert torch.equal(u, v), f"{what}: one launch vs two"
+    close(a[4], b[4].cpu(), "f32", "next BatchNorm's sums: one launch vs two", f32_tol=2e-4)
+
+
 @pytest.mark.parametrize("B,HW,C,S", [(3, 192, 512, 32), (4, 48, 1536, 64), (2, 192, 960, 40), (5, 48, 64, 8)])
 def test_squeeze_excite_backward_with_batchnorm_sums(lib, B, HW, C, S):
     """BatchNorm -> SiLU -> SqueezeExcite seam of the MBConv block, backward (bf16): the SE input is recomputed from the
