@@ -903,52 +903,15 @@ __global__ __launch_bounds__(256) void dwconv_s1_red_kernel(const T* __restrict_
 // less per block, 28 blocks per step); accumulation order per output = dwconv_s1_red_kernel's, so the results are bitwise the same.
 #define BDW_SC 8    // 16-byte chunks per slab (64 channels: a full 128-byte line per pixel)
 #define BDW_RUN 3   // output pixels per thread (a horizontal run)
-__global__ __launch_bounds__(512) void bn_dw_img_kernel(const bf16_t* __restrict__ y, const float* sums, int sums_rep, const float* w,
-                                                        const float* b, float* rm, float* rv, int64_t* nbt, float eps, float mom,
-                                                        float invM, float unbias, float* ss, float* mr, bf16_t* __restrict__ z,
-                                                        const bf16_t* __restrict__ wp, const float* dwbias, bf16_t* __restrict__ out,
-                                                        float* red, int H, int W, int C, int rowpix, int act) {
-  typedef bf16_t T;
-  constexpr int CH = 8, SC = BDW_SC, RUN = BDW_RUN;
-  extern __shared__ __attribute__((aligned(16))) unsigned char bdw_sm[];
-  __shared__ float sred[8][2][SC * CH];
-  uint4* tile = reinterpret_cast<uint4*>(bdw_sm);   // [(H + 2)][rowpix][SC] chunks; rowpix odd: two rows apart = half the banks apart
-  const int tid = threadIdx.x, NT = blockDim.x, G = NT / SC;
-  const int chunk = tid % SC, g = tid / SC;
-  const int img = blockIdx.x, c0 = (blockIdx.y * SC + chunk) * CH;
-  const int HW = H * W;
-  const long base = (long)img * HW * C + c0;
-  // the slab and the nine weight rows are requested before anything else
-  uint4 raw[RUN], wq[9];
-#pragma unroll
-  for (int k = 0; k < RUN; ++k) raw[k] = ld16(y + base + (long)(g + k * G) * C);
-#pragma unroll
-  for (int t = 0; t < 9; ++t) wq[t] = ld16(wp + (long)t * C + c0);
-  const bool publisher = img == 0 && g == 0;
-  float rm0[CH], rv0[CH];
-#pragma unroll
-  for (int j = 0; j < CH; ++j) rm0[j] = rv0[j] = 0.f;
-  if (publisher) { ldv(rm + c0, rm0, CH); ldv(rv + c0, rv0, CH); }
-  float sc[CH], sh[CH], mean[CH], var[CH];
-  {
-    float ww[CH], bb[CH];
-    ldv(sums + c0, mean, CH); ldv(sums + C + c0, var, CH);
-    for (int rp = 1; rp < sums_rep; ++rp) {
-      float t0[CH], t1[CH];
-      ldv(sums + (size_t)rp * 2 * C + c0, t0, CH); ldv(sums + (size_t)rp * 2 * C + C + c0, t1, CH);
-#pragma unroll
-      for (int j = 0; j < CH; ++j) { mean[j] += t0[j]; var[j] += t1[j]; }
-    }
-    ldv(w + c0, ww, CH); ldv(b + c0, bb, CH);
-#pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      mean[j] *= invM; var[j] = fmaxf(var[j] * invM - mean[j] * mean[j], 0.f);
-      const float rstd = rsqrtf(var[j] + eps);
-      sc[j] = ww[j] * rstd;
-      sh[j] = bb[j] - mean[j] * sc[j];
-    }
-  }
-  // zero halo: top and bottom rows, left and right columns
+// Per-channel coefficients are derived ONCE per workgroup (one thread per channel of the slab) and handed round through LDS, as are
+// the nine weight rows: a first form where every thread derived the coefficients of its own 8 channels and kept the unpacked
+// weights needed 256 VGPRs (one workgroup per CU, two rounds over the 480-workgroup grid); this one fits 128.
+DEVI void lds8(const float* p, float* o) {   // 8 floats from LDS / memory through two 16-byte reads
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+DEVI void bdw_zero_halo(uint4* tile, int H, int W, int rowpix, int tid, int NT) {
+  constexpr int SC = BDW_SC;
   const int nh = 2 * (W + 2) + 2 * H;
   for (int i = tid; i < nh * SC; i += NT) {
     const int cell = i / SC, ch = i - cell * SC;
@@ -958,49 +921,31 @@ __global__ __launch_bounds__(512) void bn_dw_img_kernel(const bf16_t* __restrict
     else { const int k = cell - 2 * (W + 2); r = 1 + (k >> 1); c = (k & 1) ? W + 1 : 0; }
     tile[(r * rowpix + c) * SC + ch] = zero16();
   }
-#pragma unroll
-  for (int k = 0; k < RUN; ++k) {
-    const int pix = g + k * G, py = pix / W, px = pix - py * W;
-    float v[CH];
-    unpack<T>(raw[k], v);
-#pragma unroll
-    for (int j = 0; j < CH; ++j) v[j] = act_fwd(v[j] * sc[j] + sh[j], act);
-    const uint4 q = pack<T>(v);
-    st16(z + base + (long)pix * C, q);
-    tile[((py + 1) * rowpix + px + 1) * SC + chunk] = q;
-  }
-  __syncthreads();
-  const int row = g % H, ox0 = (g / H) * RUN;
-  float acc[RUN][CH];
-#pragma unroll
-  for (int p = 0; p < RUN; ++p)
-#pragma unroll
-    for (int j = 0; j < CH; ++j) acc[p][j] = dwbias ? dwbias[c0 + j] : 0.f;
-#pragma unroll
+}
+// 3x3 taps from the LDS tile: acc[p] += sum_{kh,kw} tile[row+kh][ox0+p+kw] * w[FLIP ? 8-(kh*3+kw) : kh*3+kw]  (order = dwconv_s1_kernel's)
+template <bool FLIP>
+DEVI void bdw_taps(const uint4* tile, const uint4 (*wl)[BDW_SC], int row, int ox0, int rowpix, int chunk, float (*acc)[8]) {
+  constexpr int CH = 8, SC = BDW_SC, RUN = BDW_RUN;
+#pragma unroll 1   // one tile row at a time: unrolled, the scheduler hoists all 15 tile reads and 9 weight rows (200 VGPRs, spills)
   for (int kh = 0; kh < 3; ++kh) {
     float in[RUN + 2][CH];
 #pragma unroll
-    for (int t = 0; t < RUN + 2; ++t) unpack<T>(tile[((row + kh) * rowpix + ox0 + t) * SC + chunk], in[t]);
+    for (int t = 0; t < RUN + 2; ++t) unpack<bf16_t>(tile[((row + kh) * rowpix + ox0 + t) * SC + chunk], in[t]);
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
       float wv[CH];
-      unpack<T>(wq[kh * 3 + kw], wv);
+      unpack<bf16_t>(wl[FLIP ? 8 - (kh * 3 + kw) : kh * 3 + kw][chunk], wv);
 #pragma unroll
       for (int p = 0; p < RUN; ++p)
 #pragma unroll
         for (int j = 0; j < CH; ++j) acc[p][j] += in[p + kw][j] * wv[j];
     }
   }
-  float s1[CH], s2[CH];
-#pragma unroll
-  for (int j = 0; j < CH; ++j) s1[j] = s2[j] = 0.f;
-#pragma unroll
-  for (int p = 0; p < RUN; ++p) {
-    st16(out + base + (long)(row * W + ox0 + p) * C, pack<T>(acc[p]));
-#pragma unroll
-    for (int j = 0; j < CH; ++j) { s1[j] += acc[p][j]; s2[j] += acc[p][j] * acc[p][j]; }
-  }
-  // column sums of the output: lanes of a wave that hold the same chunk (lane bits 3..5), then the waves through LDS
+}
+// column sums s1/s2 (8 channels of this thread's chunk) -> red[0..C) / red[C..2C): lanes of a wave with the same chunk, the waves
+// through LDS, then one atomic per channel and workgroup
+DEVI void bdw_colsums(float* s1, float* s2, float (*sred)[2][BDW_SC * 8], float* red, int C, int tid, int NT) {
+  constexpr int CH = 8, SC = BDW_SC;
 #pragma unroll
   for (int o = SC; o < 64; o <<= 1) {
 #pragma unroll
@@ -1018,14 +963,81 @@ __global__ __launch_bounds__(512) void bn_dw_img_kernel(const bf16_t* __restrict
     for (int wv = 0; wv < NT / 64; ++wv) sum += sred[wv][k][c];
     atomicAdd(red + (long)k * C + blockIdx.y * SC * CH + c, sum);
   }
-  if (publisher) {
+}
+__global__ __launch_bounds__(512, 4) void bn_dw_img_kernel(const bf16_t* __restrict__ y, const float* sums, int sums_rep, const float* w,
+                                                           const float* b, float* rm, float* rv, int64_t* nbt, float eps, float mom,
+                                                           float invM, float unbias, float* ss, float* mr, bf16_t* __restrict__ z,
+                                                           const bf16_t* __restrict__ wp, const float* dwbias, bf16_t* __restrict__ out,
+                                                           float* red, int H, int W, int C, int rowpix, int act) {
+  typedef bf16_t T;
+  constexpr int CH = 8, SC = BDW_SC, RUN = BDW_RUN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char bdw_sm[];
+  __shared__ float sred[8][2][SC * CH];
+  __shared__ __attribute__((aligned(16))) float cf[3][SC * CH];   // scale, shift, depthwise bias
+  __shared__ uint4 wl[9][SC];
+  uint4* tile = reinterpret_cast<uint4*>(bdw_sm);   // [(H + 2)][rowpix][SC] chunks; rowpix odd: two rows apart = half the banks apart
+  const int tid = threadIdx.x, NT = blockDim.x, G = NT / SC;
+  const int chunk = tid % SC, g = tid / SC;
+  const int img = blockIdx.x, cb = blockIdx.y * SC * CH, c0 = cb + chunk * CH;
+  const int HW = H * W;
+  const long base = (long)img * HW * C + c0;
+  // the slab is requested before anything else
+  uint4 raw[RUN];
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      ss[c0 + j] = sc[j]; ss[C + c0 + j] = sh[j]; mr[c0 + j] = mean[j]; mr[C + c0 + j] = rsqrtf(var[j] + eps);
-      rm[c0 + j] = (1.f - mom) * rm0[j] + mom * mean[j];
-      rv[c0 + j] = (1.f - mom) * rv0[j] + mom * var[j] * unbias;
+  for (int k = 0; k < RUN; ++k) raw[k] = ld16(y + base + (long)(g + k * G) * C);
+  for (int i = tid; i < 9 * SC; i += NT) wl[i / SC][i % SC] = ld16(wp + (long)(i / SC) * C + cb + (i % SC) * CH);
+  for (int c = tid; c < SC * CH; c += NT) {   // one thread per channel: BatchNorm finalize (bn_act_kernel's arithmetic)
+    const int cg = cb + c;
+    float mean = 0.f, var = 0.f;
+    for (int rp = 0; rp < sums_rep; ++rp) { mean += sums[(size_t)rp * 2 * C + cg]; var += sums[(size_t)rp * 2 * C + C + cg]; }
+    mean *= invM; var = fmaxf(var * invM - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps), sc = w[cg] * rstd, sh = b[cg] - mean * sc;
+    cf[0][c] = sc; cf[1][c] = sh; cf[2][c] = dwbias ? dwbias[cg] : 0.f;
+    if (img == 0) {   // publish for the backward, update the running statistics
+      ss[cg] = sc; ss[C + cg] = sh; mr[cg] = mean; mr[C + cg] = rstd;
+      rm[cg] = (1.f - mom) * rm[cg] + mom * mean;
+      rv[cg] = (1.f - mom) * rv[cg] + mom * var * unbias;
     }
   }
+  bdw_zero_halo(tile, H, W, rowpix, tid, NT);
+  __syncthreads();
+  {
+    float sc[CH], sh[CH];
+    lds8(cf[0] + chunk * CH, sc); lds8(cf[1] + chunk * CH, sh);
+#pragma unroll
+    for (int k = 0; k < RUN; ++k) {
+      const int pix = g + k * G, py = pix / W, px = pix - py * W;
+      float v[CH];
+      unpack<T>(raw[k], v);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) v[j] = act_fwd(v[j] * sc[j] + sh[j], act);
+      const uint4 q = pack<T>(v);
+      st16(z + base + (long)pix * C, q);
+      tile[((py + 1) * rowpix + px + 1) * SC + chunk] = q;
+    }
+  }
+  __syncthreads();
+  const int row = g % H, ox0 = (g / H) * RUN;
+  float acc[RUN][CH];
+  {
+    float bb[CH];
+    lds8(cf[2] + chunk * CH, bb);
+#pragma unroll
+    for (int p = 0; p < RUN; ++p)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[p][j] = bb[j];
+  }
+  bdw_taps<false>(tile, wl, row, ox0, rowpix, chunk, acc);
+  float s1[CH], s2[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+  for (int p = 0; p < RUN; ++p) {
+    st16(out + base + (long)(row * W + ox0 + p) * C, pack<T>(acc[p]));
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { s1[j] += acc[p][j]; s2[j] += acc[p][j] * acc[p][j]; }
+  }
+  bdw_colsums(s1, s2, sred, red, C, tid, NT);
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nbt) *nbt += 1;
 }
 // false = shape / mode not taken (the caller launches launch_bn_act + launch_dwconv)
@@ -1060,53 +1072,51 @@ struct BnApplyP {
   const bf16_t* se_gate; const bf16_t* se_dpool; float se_scale; float invM; int act;
 };
 template <bool APPLY>
-__global__ __launch_bounds__(512) void dw_bwd_img_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wp, bf16_t* __restrict__ dz,
-                                                         const bf16_t* __restrict__ y, const float* ss, const float* mr, float* red, int H, int W,
-                                                         int C, int rowpix, int act, int beta, BnApplyP ap) {
+__global__ __launch_bounds__(512, 4) void dw_bwd_img_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wp, bf16_t* __restrict__ dz,
+                                                            const bf16_t* __restrict__ y, const float* ss, const float* mr, float* red, int H, int W,
+                                                            int C, int rowpix, int act, int beta, BnApplyP ap) {
   typedef bf16_t T;
   constexpr int CH = 8, SC = BDW_SC, RUN = BDW_RUN;
   extern __shared__ __attribute__((aligned(16))) unsigned char bdw_sm[];
   __shared__ float sred[8][2][SC * CH];
+  // per-channel coefficients of the slab, derived once: 0..3 = scale, shift, mean, rstd of the BatchNorm in FRONT (its sums are
+  // reduced here); APPLY: 4..8 = scale, shift, A, Bc, Cc of the BatchNorm BEHIND, 9..10 = this image's SE gate and dpooled*scale
+  __shared__ __attribute__((aligned(16))) float cf[APPLY ? 11 : 4][SC * CH];
+  __shared__ uint4 wl[9][SC];
   uint4* tile = reinterpret_cast<uint4*>(bdw_sm);
   const int tid = threadIdx.x, NT = blockDim.x, G = NT / SC;
   const int chunk = tid % SC, g = tid / SC;
-  const int img = blockIdx.x, c0 = (blockIdx.y * SC + chunk) * CH;
+  const int img = blockIdx.x, cb = blockIdx.y * SC * CH, c0 = cb + chunk * CH;
   const int HW = H * W;
   const long base = (long)img * HW * C + c0;
   const int row = g % H, ox0 = (g / H) * RUN;
-  uint4 raw[RUN], ay[RUN], yq[RUN], oq[RUN], wq[9];
+  uint4 raw[RUN], ay[RUN];
 #pragma unroll
   for (int k = 0; k < RUN; ++k) {
     raw[k] = ld16((APPLY ? ap.dz : dy) + base + (long)(g + k * G) * C);
     ay[k] = APPLY ? ld16(ap.y + base + (long)(g + k * G) * C) : zero16();
   }
-#pragma unroll
-  for (int t = 0; t < 9; ++t) wq[t] = ld16(wp + (long)t * C + c0);
-#pragma unroll
-  for (int p = 0; p < RUN; ++p) {
-    yq[p] = y ? ld16(y + base + (long)(row * W + ox0 + p) * C) : zero16();
-    oq[p] = beta ? ld16(dz + base + (long)(row * W + ox0 + p) * C) : zero16();
-  }
-  if (APPLY) {
-    // coefficients of dy = A*g + Bc + Cc*y, g = dz*act'(y*scale+shift)   (bn_bwd_apply_kernel)
-    float asc[CH], ash[CH], A[CH], Bc[CH], Cc[CH], gt[CH], dp[CH];
-    {
-      float amu[CH], ars[CH], ww[CH], r0[CH], r1[CH];
-      ldv(ap.ss + c0, asc, CH); ldv(ap.ss + C + c0, ash, CH); ldv(ap.mr + c0, amu, CH); ldv(ap.mr + C + c0, ars, CH);
-      ldv(ap.w + c0, ww, CH); ldv(ap.red + c0, r0, CH); ldv(ap.red + C + c0, r1, CH);
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        const float a = ww[j] * ars[j], m1 = r0[j] * ap.invM, m2 = r1[j] * ap.invM;
-        A[j] = a;
-        Cc[j] = -a * ars[j] * m2;
-        Bc[j] = -a * m1 + a * ars[j] * amu[j] * m2;
-      }
-      if (img == 0 && g == 0 && ap.dwp) {   // parameter gradients of that BatchNorm (grad buffers are zeroed per step: accumulate)
-#pragma unroll
-        for (int j = 0; j < CH; ++j) { ap.dwp[c0 + j] += r1[j]; ap.dbp[c0 + j] += r0[j]; }
-      }
+  for (int i = tid; i < 9 * SC; i += NT) wl[i / SC][i % SC] = ld16(wp + (long)(i / SC) * C + cb + (i % SC) * CH);
+  for (int c = tid; c < SC * CH; c += NT) {   // one thread per channel
+    const int cg = cb + c;
+    if (y) { cf[0][c] = ss[cg]; cf[1][c] = ss[C + cg]; cf[2][c] = mr[cg]; cf[3][c] = mr[C + cg]; }
+    if (APPLY) {
+      // dy = A*g + Bc + Cc*y, g = dz*act'(y*scale+shift)   (bn_bwd_apply_kernel)
+      const float amu = ap.mr[cg], ars = ap.mr[C + cg], r0 = ap.red[cg], r1 = ap.red[C + cg];
+      const float a = ap.w[cg] * ars, m1 = r0 * ap.invM, m2 = r1 * ap.invM;
+      cf[4][c] = ap.ss[cg]; cf[5][c] = ap.ss[C + cg];
+      cf[6][c] = a; cf[7][c] = -a * m1 + a * ars * amu * m2; cf[8][c] = -a * ars * m2;
+      cf[9][c] = ap.se_gate ? to_f(ap.se_gate[(long)img * C + cg]) : 1.f;
+      cf[10][c] = ap.se_gate ? to_f(ap.se_dpool[(long)img * C + cg]) * ap.se_scale : 0.f;
+      if (img == 0 && ap.dwp) { ap.dwp[cg] += r1; ap.dbp[cg] += r0; }   // parameter gradients (zeroed per step: accumulate)
     }
-    if (ap.se_gate) { unpack<T>(ld16(ap.se_gate + (long)img * C + c0), gt); unpack<T>(ld16(ap.se_dpool + (long)img * C + c0), dp); }
+  }
+  bdw_zero_halo(tile, H, W, rowpix, tid, NT);
+  if (APPLY) {
+    __syncthreads();
+    float asc[CH], ash[CH], A[CH], Bc[CH], Cc[CH], gt[CH], dp[CH];
+    lds8(cf[4] + chunk * CH, asc); lds8(cf[5] + chunk * CH, ash); lds8(cf[6] + chunk * CH, A); lds8(cf[7] + chunk * CH, Bc);
+    lds8(cf[8] + chunk * CH, Cc); lds8(cf[9] + chunk * CH, gt); lds8(cf[10] + chunk * CH, dp);
 #pragma unroll
     for (int k = 0; k < RUN; ++k) {
       float d[CH], v[CH];
@@ -1114,7 +1124,7 @@ __global__ __launch_bounds__(512) void dw_bwd_img_kernel(const bf16_t* __restric
       unpack<T>(ay[k], v);
       if (ap.se_gate) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) d[j] = d[j] * gt[j] + dp[j] * ap.se_scale;
+        for (int j = 0; j < CH; ++j) d[j] = d[j] * gt[j] + dp[j];
       }
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
@@ -1125,48 +1135,29 @@ __global__ __launch_bounds__(512) void dw_bwd_img_kernel(const bf16_t* __restric
       st16(ap.dy + base + (long)(g + k * G) * C, raw[k]);
     }
   }
-  float sc[CH], sh[CH], mu[CH], rs[CH];
-#pragma unroll
-  for (int j = 0; j < CH; ++j) { sc[j] = sh[j] = mu[j] = rs[j] = 0.f; }
-  if (y) { ldv(ss + c0, sc, CH); ldv(ss + C + c0, sh, CH); ldv(mr + c0, mu, CH); ldv(mr + C + c0, rs, CH); }
-  const int nh = 2 * (W + 2) + 2 * H;
-  for (int i = tid; i < nh * SC; i += NT) {
-    const int cell = i / SC, ch = i - cell * SC;
-    int r, c;
-    if (cell < W + 2) { r = 0; c = cell; }
-    else if (cell < 2 * (W + 2)) { r = H + 1; c = cell - (W + 2); }
-    else { const int k = cell - 2 * (W + 2); r = 1 + (k >> 1); c = (k & 1) ? W + 1 : 0; }
-    tile[(r * rowpix + c) * SC + ch] = zero16();
-  }
 #pragma unroll
   for (int k = 0; k < RUN; ++k) {
     const int pix = g + k * G, py = pix / W, px = pix - py * W;
     tile[((py + 1) * rowpix + px + 1) * SC + chunk] = raw[k];
   }
   __syncthreads();
+  // operands of the epilogue requested now: they arrive while the taps are computed
+  uint4 yq[RUN], oq[RUN];
+#pragma unroll
+  for (int p = 0; p < RUN; ++p) {
+    yq[p] = y ? ld16(y + base + (long)(row * W + ox0 + p) * C) : zero16();
+    oq[p] = beta ? ld16(dz + base + (long)(row * W + ox0 + p) * C) : zero16();
+  }
   float acc[RUN][CH];
 #pragma unroll
   for (int p = 0; p < RUN; ++p)
 #pragma unroll
     for (int j = 0; j < CH; ++j) acc[p][j] = 0.f;
+  bdw_taps<true>(tile, wl, row, ox0, rowpix, chunk, acc);   // transposed convolution: taps mirrored
+  float s1[CH], s2[CH], sc[CH], sh[CH], mu[CH], rs[CH];
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh) {
-    float in[RUN + 2][CH];
-#pragma unroll
-    for (int t = 0; t < RUN + 2; ++t) unpack<T>(tile[((row + kh) * rowpix + ox0 + t) * SC + chunk], in[t]);
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      float wv[CH];
-      unpack<T>(wq[8 - (kh * 3 + kw)], wv);   // transposed convolution: taps mirrored
-#pragma unroll
-      for (int p = 0; p < RUN; ++p)
-#pragma unroll
-        for (int j = 0; j < CH; ++j) acc[p][j] += in[p + kw][j] * wv[j];
-    }
-  }
-  float s1[CH], s2[CH];
-#pragma unroll
-  for (int j = 0; j < CH; ++j) s1[j] = s2[j] = 0.f;
+  for (int j = 0; j < CH; ++j) s1[j] = s2[j] = sc[j] = sh[j] = mu[j] = rs[j] = 0.f;
+  if (y) { lds8(cf[0] + chunk * CH, sc); lds8(cf[1] + chunk * CH, sh); lds8(cf[2] + chunk * CH, mu); lds8(cf[3] + chunk * CH, rs); }
 #pragma unroll
   for (int p = 0; p < RUN; ++p) {
     if (beta) {
@@ -1188,23 +1179,7 @@ __global__ __launch_bounds__(512) void dw_bwd_img_kernel(const bf16_t* __restric
     }
   }
   if (!y) return;   // plain data gradient (uniform: no barrier is skipped by part of the workgroup)
-#pragma unroll
-  for (int o = SC; o < 64; o <<= 1) {
-#pragma unroll
-    for (int j = 0; j < CH; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
-  }
-  const int lane = tid & 63, wave = tid >> 6;
-  if (lane < SC) {
-#pragma unroll
-    for (int j = 0; j < CH; ++j) { sred[wave][0][lane * CH + j] = s1[j]; sred[wave][1][lane * CH + j] = s2[j]; }
-  }
-  __syncthreads();
-  for (int i = tid; i < 2 * SC * CH; i += NT) {
-    const int k = i / (SC * CH), c = i - k * SC * CH;
-    float sum = 0.f;
-    for (int wv = 0; wv < NT / 64; ++wv) sum += sred[wv][k][c];
-    atomicAdd(red + (long)k * C + blockIdx.y * SC * CH + c, sum);
-  }
+  bdw_colsums(s1, s2, sred, red, C, tid, NT);
 }
 // false = shape / mode not taken (the caller launches launch_dwconv(mode 1) and leaves the sums to launch_bn_bwd_reduce)
 bool dwconv_img_ok(int dt, int H, int W, int C) {
