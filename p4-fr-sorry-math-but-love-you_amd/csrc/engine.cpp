@@ -1401,8 +1401,9 @@ Tensor* encoder_layer(Exec& e, Tensor* x, EncLayer* el) {
   Tensor* z = op_quirk(e, y2);
   Tensor* c0 = op_gemm(e, z, &el->conv0, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   c0->B = B; c0->H = H; c0->W = W;
-  Tensor* b0 = op_bn_act(e, c0, &el->norm0, ACT_RELU, nullptr);
-  Tensor* d = op_dwconv(e, b0, &el->dw, &el->dwb, 1, H, W, 1, 1);
+  BnHold hold;   // BatchNorm + ReLU + depthwise 3x3 (+bias) in one launch where the shape allows (launch_bn_dwconv)
+  Tensor* b0 = op_bn_act(e, c0, &el->norm0, ACT_RELU, nullptr, nullptr, &hold);
+  Tensor* d = op_dwconv(e, b0, &el->dw, &el->dwb, 1, H, W, 1, 1, true, &hold);
   Tensor* b1 = op_bn_act(e, d, &el->dwnorm, ACT_RELU, nullptr);
   Tensor* c1 = op_gemm(e, b1, &el->conv1, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   c1->B = B; c1->H = H; c1->W = W;
