@@ -14,6 +14,8 @@ from collections import defaultdict
 
 FAMILIES = [("gemm_kernel", "launch_gemm"), ("conv3x3_halo_kernel", "launch_gemm"), ("gemm_skinny_kernel", "launch_gemm"), ("wgrad_kernel", "launch_wgrad"), ("bn_act_kernel", "launch_bn_act"),
             ("bn_bwd_apply_kernel", "launch_bn_bwd_apply"), ("BnBwdRedF", "launch_bn_bwd_reduce"), ("StatsF", "launch_colstats"),
+            ("bn_act_pool_kernel", "launch_bn_act_pool"), ("bn_dw_img_kernel", "launch_bn_dwconv"), ("dw_bwd_img_kernel", "launch_dwconv_bwd_bn"),
+            ("se_mlp_scale_kernel", "launch_se_mlp_scale"), ("se_bwd_gate_ds_kernel", "launch_se_bwd_wide"), ("se_bwd_pool_kernel", "launch_se_bwd_wide"),
             ("DwWgradF", "launch_dwconv_wgrad"), ("dwconv", "launch_dwconv"), ("se_fwd_kernel", "launch_se_fwd"),
             ("se_bwd_a_kernel", "launch_se_bwd"), ("se_bwd_b_kernel", "launch_se_bwd_weights"), ("attn_kernel", "launch_attn"),
             ("layernorm_bwd", "launch_layernorm_bwd"), ("layernorm", "launch_layernorm"), ("adamw_kernel", "launch_adamw"),
