@@ -1,0 +1,28 @@
+"""Dense bf16 weight-gradient throughput of the C-ABI operator (run on the GPU box): dW[N][K] += dY^T X over M rows, on the shapes
+of the SwinTRN and EfficientSATRN steps.  SATRN_WGRAD_BLOCKS sets the grid target (default 96: the partial grid of the side stream)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import satrn_amd
+lib = satrn_amd._lib.load()
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def bench(fn, iters=50):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+SHAPES = [(9216, 2048, 512), (9216, 512, 2048), (9216, 1536, 512), (9216, 512, 512), (36864, 1024, 256), (36864, 256, 1024), (36864, 768, 256),
+          (147456, 512, 128), (147456, 128, 512), (147456, 384, 128), (2304, 4096, 1024), (2304, 1024, 4096), (4096, 1024, 256), (6144, 960, 160), (1536, 1536, 256)]
+for M, N, K in SHAPES:
+    x = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16(); dy = (torch.rand(M, N, device="cuda") * 2 - 1).bfloat16()
+    dw = torch.zeros(N, K, device="cuda")
+    us = bench(lambda: lib.satrn_linear_bwd_weight(1, P(dy), N, P(x), P(dw), None, M, N, K, st()))
+    print(f"M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TFLOP/s  blocks={os.environ.get('SATRN_WGRAD_BLOCKS','96')} ms128={'off' if os.environ.get('SATRN_WGRAD_NO_MS128') else 'on'}")
