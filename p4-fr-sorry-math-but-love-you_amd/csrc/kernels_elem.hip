@@ -332,16 +332,16 @@ void launch_bn_act(int dt, const void* y, const float* sums, int sums_rep, const
 // == 0 so a workgroup never straddles two images).  The pool used to be the first phase of the per-image SE kernel, where ONE
 // workgroup pulled a whole image (up to 368 KB) through one CU: 5-8 us of the 17 that kernel took on the dependent chain.
 #define BNP_ROWS 48
-template <typename T>
+template <typename T, int ROWS = BNP_ROWS>
 __global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ y, const float* sums, int sums_rep, const float* w, const float* b,
                                                           float* rm, float* rv, int64_t* nbt, float eps, float mom, float invM, float unbias,
                                                           float* ss, float* mr, T* __restrict__ z, float* poolsum, int C, int HW, int act) {
   constexpr int CH = TT<T>::CH;
-  constexpr int RPT = BNP_ROWS / 8;
+  constexpr int RPT = ROWS / 8;
   __shared__ float sred[8][32 * CH];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int CC = C / CH, cc = blockIdx.y * 32 + tx, c0 = cc * CH;
-  const long r0 = (long)blockIdx.x * BNP_ROWS;
+  const long r0 = (long)blockIdx.x * ROWS;
   const int img = (int)(r0 / HW);
   const bool cok = cc < CC;
   uint4 yv[RPT];
@@ -418,6 +418,12 @@ void launch_bn_act_pool(int dt, const void* y, const float* sums, int sums_rep, 
   float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
   DISPATCH_T(dt, {
     const int CC = C / TT<T>::CH;
+    // 24 rows per workgroup where 48 would leave the grid under one workgroup per CU (the 4x12 stage: 192 -> 384 workgroups)
+    static const bool half_ok = getenv("SATRN_BNP_NO_HALF") == nullptr;
+    if (half_ok && (M / BNP_ROWS) * ((CC + 31) / 32) < 256)
+      hipLaunchKernelGGL((bn_act_pool_kernel<T, BNP_ROWS / 2>), dim3((int)(M / (BNP_ROWS / 2)), (CC + 31) / 32), dim3(256), 0, s, (const T*)y, sums,
+                         sums_rep < 1 ? 1 : sums_rep, w, b, rm, rv, nbt, eps, mom, 1.0f / (float)M, unbias, ss, mr, (T*)z, poolsum, C, HW, act);
+    else
     hipLaunchKernelGGL((bn_act_pool_kernel<T>), dim3((int)(M / BNP_ROWS), (CC + 31) / 32), dim3(256), 0, s, (const T*)y, sums, sums_rep < 1 ? 1 : sums_rep,
                        w, b, rm, rv, nbt, eps, mom, 1.0f / (float)M, unbias, ss, mr, (T*)z, poolsum, C, HW, act);
   });
