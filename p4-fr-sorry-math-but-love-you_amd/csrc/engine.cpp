@@ -748,9 +748,13 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       {
         const int dt = e.dt; const bool dry = e.dry;
         float* bg = bias ? bias->g : nullptr; float* wg = w->g; const int Ci = g.Ci;
+        // dense products: the weight-gradient kernel sums the bias gradient from the dY chunks it stages anyway (not in the deterministic mode,
+        // whose fixed-order column sums stay a pass of their own)
+        static const bool fold_db = getenv("SATRN_NO_WGRAD_BIAS") == nullptr;
+        if (bg && fold_db && !hasgeo && !g_det.on) { q.dbias = bg; bg = nullptr; }
         if (e.prof || dry) {
           WORK(e, 0, (double)M * N * e.esz());
-          if (bias) LCH(e, launch_colsum(dt, dY, M, N, ldy, bg, e.s));
+          if (bg) LCH(e, launch_colsum(dt, dY, M, N, ldy, bg, e.s));
           WORK(e, 2.0 * (double)M * N * w->K, ((double)M * N + (double)x->rows * x->C) * e.esz() + (double)N * w->K * 4);
           LCH(e, launch_wgrad(dt, q, e.s));
           if (tmp) { WORK(e, 0, (double)N * w->K * 12); LCH(e, launch_conv_grad_unpack(tmp, wg, N, Ci, 9, e.s)); }

@@ -65,6 +65,8 @@ struct WgradP {
   long sY_o, sY_i, sA_o, sA_i, sW_o, sW_i;  // element strides per outer/inner batch index
   int ldw;                                 // out_t==1: row stride of dW
   float* det_part;                         // deterministic mode (set by launch_wgrad): [split][N][K] partial slabs
+  float* dbias;                            // optional (dense, !out_t): dbias[n] += sum_m dY[m][n], accumulated by the k-tile-0 workgroups from the dY
+                                           // chunks they stage anyway (was a separate launch_colsum pass over dY)
 };
 void launch_wgrad(int dt, const WgradP& p, hipStream_t s);
 void launch_conv_grad_unpack(const float* tmp /*[N][taps][Ci]*/, float* dw /*[N][Ci][taps] +=*/, int N, int Ci, int taps, hipStream_t s);

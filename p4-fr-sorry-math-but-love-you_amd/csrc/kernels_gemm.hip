@@ -793,8 +793,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split
 #pragma unroll
     for (int j = 0; j < NTK; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fq = lane >> 4;
+  // bias gradient: the k-tile-0 workgroup of every n-tile sums the dY chunks it stages (rows outside the slice are zero chunks)
+  const bool want_db = !CONV && p.dbias != nullptr && tile_k == 0;
+  float dbs[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) dbs[j] = 0.f;
+  auto bias_acc = [&]() {
+    if (want_db) {
+#pragma unroll
+      for (int i = 0; i < NCY; ++i) {
+        float v[CH];
+        unpack<T>(ry[i], v);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) dbs[j] += v[j];
+      }
+    }
+  };
   if (m_begin < m_end) {
     load_tiles(m_begin);
+    bias_acc();
     store_tiles(0);
     __syncthreads();
     int cur = 0;
@@ -815,9 +832,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split
           for (int i = 0; i < MTN; ++i) mma(af[i], bf, acc[i][j]);
         }
       }
-      if (more) store_tiles(cur ^ 1);
+      if (more) { bias_acc(); store_tiles(cur ^ 1); }
       __syncthreads();
       cur ^= 1;
+    }
+  }
+  if (want_db) {   // uniform per workgroup.  Threads with the same chunk column (tid % CPN) hold partial sums of the same 8 columns
+    float* red = reinterpret_cast<float*>(lds);   // the tiles are dead: [256 / CPN][BNW] floats
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CH; ++j) red[(tid / CPN) * BNW + cy * CH + j] = dbs[j];
+    __syncthreads();
+    for (int c = tid; c < BNW; c += 256) {
+      float sum = 0.f;
+      for (int r = 0; r < 256 / CPN; ++r) sum += red[r * BNW + c];
+      if (n0 + c < p.N) atomicAdd(p.dbias + n0 + c, sum);
     }
   }
   const int taps = CONV ? (p.KW * p.KW) : 1;

@@ -75,8 +75,10 @@ int satrn_linear_bwd_weight(int dt, const void* dy, int ldy, const void* x, floa
   WgradP q;
   memset(&q, 0, sizeof(q));
   q.dY = dy; q.A = x; q.dW = dw; q.M = M; q.N = N; q.K = K; q.ldy = ldy; q.lda = K; q.nbatch = 1; q.nb_inner = 1;
+  const bool fold = db && !g_det.on && getenv("SATRN_NO_WGRAD_BIAS") == nullptr;   // bias gradient summed inside the weight-gradient kernel
+  if (fold) q.dbias = db;
   launch_wgrad(dt, q, S(st));
-  if (db) launch_colsum(dt, dy, M, N, ldy, db, S(st));
+  if (db && !fold) launch_colsum(dt, dy, M, N, ldy, db, S(st));
   return done("linear_bwd_weight");
 }
 
