@@ -202,7 +202,7 @@ def swin_report(dev, B=16, T=128):
     fl = sum(p_["flops"] for p_ in prof)
     by = sum(p_["bytes"] for p_ in prof)
     top = [dict(kernel=p_["kernel"], launches=p_["launches"], ms=round(p_["ms"], 3), gflop=round(p_["flops"] / 1e9, 1),
-                mfma_frac=round(p_["flops"] / max(p_["ms"], 1e-6) / 1e9 / PEAK_BF16_TFLOPS, 4)) for p_ in prof[:6]]
+                mfma_frac=round(p_["flops"] / max(p_["ms"], 1e-6) / 1e9 / PEAK_BF16_TFLOPS, 4)) for p_ in prof[:14]]
     del m
     return dict(workload="SwinTRN train step (fwd+CE+bwd+clip+AdamW), bs16, 3x384x384, teacher-forced T=128, dropout 0.1, drop_path 0.5 (BASELINE configs[3] at the reference's 384 geometry)",
                 ms_per_step=round(ms, 3), images_per_s=round(B / ms * 1e3, 1), steps=n, dtype="bf16", final_loss=round(loss, 4),

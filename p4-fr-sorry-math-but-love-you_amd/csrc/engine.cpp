@@ -669,6 +669,7 @@ struct Geo { int H, W, Ci, OH, OW, KW, stride, pt, pl; };
 
 static inline void used(Tensor* t) { if (t) t->ncons++; }
 static const bool g_fuse_bnb = getenv("SATRN_NO_FUSED_BN_BWD") == nullptr;
+static const bool g_fuse_actb = getenv("SATRN_NO_FUSED_ACT_BWD") == nullptr;
 static const bool g_fuse_bn_eval = getenv("SATRN_NO_FUSED_BN_EVAL") == nullptr;
 
 static void acc_grad(Exec& e, Tensor* t, const void* src) {
@@ -703,6 +704,11 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
   p.A = x->p; p.Bw = w->fwd; p.C = y->p; p.bias = bias ? bias->p : nullptr;
   p.M = (int)M; p.N = N; p.K = w->K; p.lda = x->C; p.ldc = N;
   p.act = act; p.out_f32 = out_f32 ? 1 : 0; p.drop_p = drop_p; p.seed = seed; p.site = site;
+  if (act == ACT_GELU && e.rec && !geo && !out_f32 && !out_ptr) {
+    // GELU's derivative needs the pre-activation: the epilogue stores both (product + activation pass in one launch)
+    y->act_pre = e.alloc((size_t)M * N * e.esz()); y->act_kind = act;
+    p.pre_out = y->act_pre;
+  }
   if (want_stats && e.train) {
     // tall, narrow outputs (early backbone stages): many row tiles hit the same 2N addresses -> spread over replicas
     const int rep = g_det.on ? 1 : ((N <= 64 && M >= 65536) ? 16 : ((N <= 256 && M >= 16384) ? 4 : 1));  // deterministic mode folds into ONE [2N]
@@ -731,6 +737,10 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       void* dY = y->g;
       WORK(e, 0, (double)M * N * e.esz() * (act == ACT_NONE ? 2 : 3));
       if (act == ACT_RELU) LCH(e, launch_act_bwd(e.dt, dY, y->p, dY, M * N, ACT_RELU, drop_p, e.s));
+      else if (act == ACT_GELU) {
+        if (!y->act_pre) { e.m->err = "internal: GELU epilogue without its pre-activation"; e.oom = true; return; }
+        if (!y->g_preact) LCH(e, launch_act_bwd(e.dt, dY, y->act_pre, dY, M * N, ACT_GELU, 0.f, e.s));   // else: the consumer's dgrad epilogue did it
+      }
       else if (act == ACT_SIGMOID) LCH(e, launch_act_bwd(e.dt, dY, y->p, dY, M * N, ACT_SIGMOID, 0.f, e.s));
       else if (drop_p > 0.f) LCH(e, launch_dropout_bwd(e.dt, dY, dY, M, N, drop_p, seed, site, e.s));
       WgradP q;
@@ -776,6 +786,10 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
         const int rep = g_det.on ? 1 : ((x->C <= 64 && x->rows >= 65536) ? 16 : ((x->C <= 256 && x->rows >= 16384) ? 4 : 1));
         x->bn_red = e.zalloc((size_t)rep * 2 * x->C); x->bn_red_rep = rep;
         d.stats = x->bn_red; d.stats_rep = rep; d.bnb_y = x->bn_y; d.bnb_ss = x->bn_ss; d.bnb_mr = x->bn_mr; d.bnb_act = x->bn_act;
+      }
+      if (!hasgeo && !fuse_bnb && !beta && x->act_pre && x->ncons == 1 && !x->g_preact && g_fuse_actb) {
+        // x = act(u) feeds this product only: dx leaves the epilogue as du = dx * act'(u)
+        d.bact_u = x->act_pre; d.bact = x->act_kind; x->g_preact = true;
       }
       if (!hasgeo) {
         d.M = (int)M; d.N = w->K; d.K = w->ldb; d.lda = ldy; d.ldc = x->C;
@@ -1339,8 +1353,13 @@ Tensor* swin_block(Exec& e, Tensor* x, SwinBlock* sb, int B) {
   Tensor* x1 = op_droppath_add(e, x, prt, B, sb->drop_path);
   x1->B = B; x1->H = R; x1->W = R;
   Tensor* y2 = op_ln(e, x1, nullptr, &sb->n2);
-  Tensor* h = op_gemm(e, y2, &sb->fc1, &sb->b1, ACT_NONE, 0.f, nullptr);
-  Tensor* g = op_act(e, h, ACT_GELU);
+  Tensor* g;
+  if (getenv("SATRN_SWIN_GELU_PASS") == nullptr) {   // read per call (tests compare both forms in one process)
+    g = op_gemm(e, y2, &sb->fc1, &sb->b1, ACT_GELU, 0.f, nullptr);   // GELU in the product's epilogue, pre-activation kept beside it
+  } else {
+    Tensor* h = op_gemm(e, y2, &sb->fc1, &sb->b1, ACT_NONE, 0.f, nullptr);
+    g = op_act(e, h, ACT_GELU);
+  }
   Tensor* o = op_gemm(e, g, &sb->fc2, &sb->b2, ACT_NONE, 0.f, nullptr);
   Tensor* x2 = op_droppath_add(e, x1, o, B, sb->drop_path);
   x2->B = B; x2->H = R; x2->W = R;

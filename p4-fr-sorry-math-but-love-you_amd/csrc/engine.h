@@ -78,6 +78,10 @@ struct Tensor {
   // true gradient is g*se_gate[b] + se_dpool[b]/se_hw
   const void* se_gate = nullptr; const void* se_dpool = nullptr; int se_hw = 0;
   bool bn_has_res = false;  // the BatchNorm that produced this tensor also added a residual (its gradient = this tensor's)
+  // output of a product whose epilogue applied an activation that needs its INPUT for the derivative (GELU): act_pre = the stored
+  // pre-activation values.  A consumer whose data gradient is the only contribution multiplies by act'(act_pre) in its own epilogue
+  // and sets g_preact: g then already holds the gradient of the pre-activation
+  void* act_pre = nullptr; int act_kind = 0; bool g_preact = false;
   // output of a depthwise convolution whose backward kernel can also run the backward-apply pass of the BatchNorm that consumes this
   // tensor: that BatchNorm's closure leaves its operands in bhold instead of launching (op_bn_act -> op_dwconv, launch_dwconv_bwd_bn)
   bool dw_bwd_fuse = false; BnBwdHold bhold;

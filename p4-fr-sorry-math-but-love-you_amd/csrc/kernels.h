@@ -44,6 +44,11 @@ struct GemmP {
   // optional inference epilogue (eval-mode BatchNorm folded in): out = act(acc * escale[col] + eshift[col]) + eres[row][col]
   // (eres: residual in the compute dtype with row stride ldc, may be null)
   const float* escale; const float* eshift; const void* eres;
+  // optional (dense products): pre_out != null -> the value BEFORE the activation is stored there (rounded to the compute dtype) and C
+  // gets act(that rounded value): the product and the activation pass behind it in one launch, both tensors kept for the backward.
+  // bact_u != null -> the output is multiplied by act'(bact_u[row][col]) (bact = its kind): a data gradient that arrives at an
+  // activation's output leaves as the gradient of its input (the separate act-backward pass disappears).  Row stride of both = ldc.
+  void* pre_out; const void* bact_u; int bact;
 };
 // eval-mode BatchNorm scale / shift of every BatchNorm of a model in ONE launch: out[0..C) = w * rsqrt(rv + eps),
 // out[C..2C) = b - rm * scale

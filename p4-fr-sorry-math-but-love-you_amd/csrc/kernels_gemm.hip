@@ -281,9 +281,12 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wave * (BM / 4) + i * 16 + fq * 4 + r;
         if (row >= p.M || col >= p.N || !writer) continue;
-        float v = act_fwd(acc[i][j][r] * esc + esh + bias, p.act);
-        if (p.drop_p > 0.f) v *= drop_scale(seed, p.site, (uint32_t)(row * p.N + col), p.drop_p);
         const long o = (long)row * p.ldc + col;
+        float v = acc[i][j][r] * esc + esh + bias;
+        if (p.pre_out) { const T pre = from_f<T>(v); ((T*)p.pre_out)[o] = pre; v = to_f(pre); }   // the activation pass would have read the stored value
+        v = act_fwd(v, p.act);
+        if (p.bact_u) v *= act_bwd(to_f(((const T*)p.bact_u)[o]), p.bact);
+        if (p.drop_p > 0.f) v *= drop_scale(seed, p.site, (uint32_t)(row * p.N + col), p.drop_p);
         if (p.eres) v += to_f(((const T*)p.eres)[o]);
         float tot;
         if (p.out_f32) {
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
 template <typename T>
 static bool gemm_skinny_launch(const GemmP& p, hipStream_t s) {
   static const bool off = getenv("SATRN_NO_SKINNY_GEMM") != nullptr;
-  if (off || p.M > 64 || (p.K & 31) || p.K > 1024 || p.stats || p.bnb_y || p.escale || (p.lda & 7)) return false;
+  if (off || p.M > 64 || (p.K & 31) || p.K > 1024 || p.stats || p.bnb_y || p.escale || p.pre_out || p.bact_u || (p.lda & 7)) return false;
   const int mt = (p.M + 15) / 16;
   const int steps = ((p.K >> 5) + 3) / 4;  // k-steps per wave
   const dim3 g((p.N + 15) / 16), b(256);

@@ -147,6 +147,38 @@ def test_swin_encode_and_greedy_vs_golden(golden_dir, name, dtype):
         assert (ids.cpu().numpy()[clear] == z["greedy_ids"][clear]).mean() > 0.9 if clear.any() else True
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_gelu_in_product_epilogue_equals_separate_passes(golden_dir, dtype, monkeypatch):
+    """MLP of the Swin block: fc1 with GELU in its epilogue (pre-activation kept beside it) and GELU' applied by fc2's data-gradient
+    epilogue, against fc1 -> GELU pass -> fc2 with a separate backward pass.  Forward values are identical by construction (the
+    activation is taken of the stored, rounded pre-activation); the backward differs by one rounding of the incoming gradient."""
+    scfg, dcfg = CASES["swin_mid"]
+    z, meta = load(golden_dir, "swin_mid")
+    B, T = int(meta["batch"]), int(meta["seq_len"])
+    img, expected = O.det_inputs(B, 3, scfg["img_size"], scfg["img_size"], T, seed=5, pad_tail=0)
+    imgd, expd = img.cuda(), expected.cuda()
+
+    def run(passes):
+        if passes:
+            monkeypatch.setenv("SATRN_SWIN_GELU_PASS", "1")
+        else:
+            monkeypatch.delenv("SATRN_SWIN_GELU_PASS", raising=False)
+        model, _ = build(scfg, dcfg, dtype, int(meta["wseed"]))
+        model.train()
+        logits = model(imgd, expd, True, 1.0)
+        loss = model.criterion(logits.transpose(1, 2), expd[:, 1:])
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().float().clone(), torch.cat([p_.grad.detach().float().flatten() for p_ in model.parameters()]).clone()
+
+    (l0, g0), (l1, g1) = run(True), run(False)
+    le, ge = relerr(l1, l0), (g1 - g0).norm().item() / g0.norm().item()
+    print(f"[gelu epilogue vs passes:{dtype}] logits rel err {le:.3e}, gradient rel-L2 {ge:.3e}")
+    assert le < (1e-6 if dtype == "f32" else 2e-2)
+    assert ge < (1e-5 if dtype == "f32" else 5e-2)
+
+
 def test_swin_stochastic_depth_and_fused_step():
     """train mode with the reference's drop_path_rate (0.5): per-sample branches are dropped (outputs change from step to step,
     loss stays finite), the f32 step is reproducible for a fixed RNG word, the fused train_step runs and lowers the loss."""
