@@ -709,6 +709,10 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
     y->act_pre = e.alloc((size_t)M * N * e.esz()); y->act_kind = act;
     p.pre_out = y->act_pre;
   }
+  if (act == ACT_RELU && e.rec && !geo && !out_f32 && !out_ptr) {
+    // ReLU (+dropout): the derivative is read off the stored output (zeros = clipped or dropped), no second tensor needed
+    y->act_pre = y->p; y->act_kind = ACT_RELU; y->act_scale = 1.0f / (1.0f - drop_p);
+  }
   if (want_stats && e.train) {
     // tall, narrow outputs (early backbone stages): many row tiles hit the same 2N addresses -> spread over replicas
     const int rep = g_det.on ? 1 : ((N <= 64 && M >= 65536) ? 16 : ((N <= 256 && M >= 16384) ? 4 : 1));  // deterministic mode folds into ONE [2N]
@@ -736,7 +740,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       const int ldy = out_f32 ? w->ldb : N;
       void* dY = y->g;
       WORK(e, 0, (double)M * N * e.esz() * (act == ACT_NONE ? 2 : 3));
-      if (act == ACT_RELU) LCH(e, launch_act_bwd(e.dt, dY, y->p, dY, M * N, ACT_RELU, drop_p, e.s));
+      if (act == ACT_RELU) { if (!y->g_preact) LCH(e, launch_act_bwd(e.dt, dY, y->p, dY, M * N, ACT_RELU, drop_p, e.s)); }
       else if (act == ACT_GELU) {
         if (!y->act_pre) { e.m->err = "internal: GELU epilogue without its pre-activation"; e.oom = true; return; }
         if (!y->g_preact) LCH(e, launch_act_bwd(e.dt, dY, y->act_pre, dY, M * N, ACT_GELU, 0.f, e.s));   // else: the consumer's dgrad epilogue did it
@@ -789,7 +793,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       }
       if (!hasgeo && !fuse_bnb && !beta && x->act_pre && x->ncons == 1 && !x->g_preact && g_fuse_actb) {
         // x = act(u) feeds this product only: dx leaves the epilogue as du = dx * act'(u)
-        d.bact_u = x->act_pre; d.bact = x->act_kind; x->g_preact = true;
+        d.bact_u = x->act_pre; d.bact = x->act_kind; d.bact_scale = x->act_scale; x->g_preact = true;
       }
       if (!hasgeo) {
         d.M = (int)M; d.N = w->K; d.K = w->ldb; d.lda = ldy; d.ldc = x->C;

@@ -81,7 +81,7 @@ struct Tensor {
   // output of a product whose epilogue applied an activation that needs its INPUT for the derivative (GELU): act_pre = the stored
   // pre-activation values.  A consumer whose data gradient is the only contribution multiplies by act'(act_pre) in its own epilogue
   // and sets g_preact: g then already holds the gradient of the pre-activation
-  void* act_pre = nullptr; int act_kind = 0; bool g_preact = false;
+  void* act_pre = nullptr; int act_kind = 0; bool g_preact = false; float act_scale = 0.f;   // ReLU (+dropout): act_pre = the output itself, act_scale = 1/(1-p)
   // output of a depthwise convolution whose backward kernel can also run the backward-apply pass of the BatchNorm that consumes this
   // tensor: that BatchNorm's closure leaves its operands in bhold instead of launching (op_bn_act -> op_dwconv, launch_dwconv_bwd_bn)
   bool dw_bwd_fuse = false; BnBwdHold bhold;

@@ -49,6 +49,7 @@ struct GemmP {
   // bact_u != null -> the output is multiplied by act'(bact_u[row][col]) (bact = its kind): a data gradient that arrives at an
   // activation's output leaves as the gradient of its input (the separate act-backward pass disappears).  Row stride of both = ldc.
   void* pre_out; const void* bact_u; int bact;
+  float bact_scale;   // times this (ReLU + dropout: bact_u is the stored OUTPUT, whose zeros cover both, and 1/(1-p) the kept ones' scale); 0 = 1
 };
 // eval-mode BatchNorm scale / shift of every BatchNorm of a model in ONE launch: out[0..C) = w * rsqrt(rv + eps),
 // out[C..2C) = b - rm * scale
