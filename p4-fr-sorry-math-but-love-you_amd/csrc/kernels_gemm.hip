@@ -416,12 +416,16 @@ static void launch_gemm_t(const GemmP& p, hipStream_t s) {
 // =========================================================================================
 #define HC_TH 8
 #define HC_TW 16
+// NS > 1: the input channels are taken in NS slices of C / NS, the patch re-staged per slice and the accumulators kept.  The
+// patch of a deep input (the data gradients of the fused-MBConv stages: C = 192 / 256 -> 72 / 95 KB) allowed one workgroup of
+// four waves per CU; in slices of <= 40 KB three or four share a CU and hide each other's staging and barriers.
 template <int BN>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, int Wimg, int C, int flip) {
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, int Wimg, int C, int flip, int NS) {
   typedef bf16_t T;
   constexpr int NT = BN / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
-  const int CP = C + 8;                                   // padded pixel pitch (elements): staggers banks
+  const int Ch = C / NS, Ch8 = Ch >> 3;                   // channels / 16-byte chunks per slice
+  const int CP = Ch + 8;                                  // padded pixel pitch (elements): staggers banks
   T* patch = reinterpret_cast<T*>(hsm);                   // [(TH+2)*(TW+2)][CP]
   T* wpan = patch + (size_t)(HC_TH + 2) * (HC_TW + 2) * CP;  // [2][BN*32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
@@ -435,69 +439,69 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, in
   const int y0 = tyi * HC_TH, x0 = txi * HC_TW, n0 = tile_n * BN;
   const T* in = (const T*)p.A + (long)b * Himg * Wimg * C;
   const T* Wt = (const T*)p.Bw;
-  const int K = 9 * C, C8 = C >> 3;
-
-  // ---- halo patch -> LDS (zero outside the image)
-  for (int i = tid; i < (HC_TH + 2) * (HC_TW + 2) * C8; i += 256) {
-    const int c8 = i % C8, pix = i / C8;
-    const int hy = pix / (HC_TW + 2), hx = pix - hy * (HC_TW + 2);
-    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-    uint4 v = zero16();
-    if (gy >= 0 && gy < Himg && gx >= 0 && gx < Wimg) v = ld16(in + ((long)gy * Wimg + gx) * C + c8 * 8);
-    st16(patch + (size_t)pix * CP + c8 * 8, v);
-  }
-  // ---- weight panels: thread (n = tid / 4, chunk = tid % 4) stages one 16-byte chunk per k-step
-  const int wn = tid >> 2, wc = tid & 3;
-  auto load_w = [&](int ks) -> uint4 {
-    const int k0 = ks * 32 + wc * 8;
-    if (wn < BN && n0 + wn < p.N && k0 < K) return ld16(Wt + (long)(n0 + wn) * K + k0);
-    return zero16();
-  };
-  auto store_w = [&](int buf, uint4 v) { if (wn < BN) st16(wpan + buf * BN * 32 + panel_chunk<T>(wn, wc), v); };
+  const int K = 9 * C;
 
   f32x4 acc[2][NT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = (K + 31) / 32;
-  uint4 wreg = load_w(0);
-  store_w(0, wreg);
-  __syncthreads();
-  // per-lane position in the k stream: 8-channel chunk kc = 4 * ks + fq -> (tap, channel chunk)
-  int tap = fq / C8, cch = fq - tap * C8;
-  for (int ks = 0; ks < nk; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < nk) wreg = load_w(ks + 1);
-    const T* lb = wpan + cur * BN * 32;
-    {
-      // lanes past the end of K (last k-step only) read a valid address and zero the fragment: the MFMAs below must
-      // be executed by the whole wavefront
-      const bool kvalid = tap < 9;
-      const int tp = kvalid ? tap : 8;
-      const int kh = tp / 3, kw = tp - kh * 3;
-      const int dy = flip ? 2 - kh : kh, dx = flip ? 2 - kw : kw;
-      Frag<T> af[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ty = wave * 2 + i;  // tile row of this 16-pixel MFMA row block
-        const uint4 v = ld16(patch + (size_t)((ty + dy) * (HC_TW + 2) + fr + dx) * CP + (kvalid ? cch : 0) * 8);
-        af[i].v = kvalid ? v : zero16();
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        Frag<T> bf = load_frag<T>(lb, j * 16 + fr, fq);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) mma(af[i], bf, acc[i][j]);
-      }
+  const int nk = (9 * Ch + 31) / 32;   // k-steps per slice: k' = tap * Ch + c'
+  // ---- weight panels: thread (n = tid / 4, chunk = tid % 4) stages one 16-byte chunk per k-step
+  const int wn = tid >> 2, wc = tid & 3;
+  for (int h = 0; h < NS; ++h) {
+    const int cbase = h * Ch;
+    // ---- halo patch of this channel slice -> LDS (zero outside the image); the previous slice's last k-step ended with a barrier
+    for (int i = tid; i < (HC_TH + 2) * (HC_TW + 2) * Ch8; i += 256) {
+      const int c8 = i % Ch8, pix = i / Ch8;
+      const int hy = pix / (HC_TW + 2), hx = pix - hy * (HC_TW + 2);
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      uint4 v = zero16();
+      if (gy >= 0 && gy < Himg && gx >= 0 && gx < Wimg) v = ld16(in + ((long)gy * Wimg + gx) * C + cbase + c8 * 8);
+      st16(patch + (size_t)pix * CP + c8 * 8, v);
     }
-    cch += 4;
-    while (cch >= C8) { cch -= C8; ++tap; }
-    if (ks + 1 < nk) store_w(cur ^ 1, wreg);
+    auto load_w = [&](int ks) -> uint4 {
+      const int kc = ks * 4 + wc, tp = kc / Ch8, cc = kc - tp * Ch8;   // chunk kc of the slice's k stream -> (tap, chunk in slice)
+      if (wn < BN && n0 + wn < p.N && tp < 9) return ld16(Wt + (long)(n0 + wn) * K + (long)tp * C + cbase + cc * 8);
+      return zero16();
+    };
+    auto store_w = [&](int buf, uint4 v) { if (wn < BN) st16(wpan + buf * BN * 32 + panel_chunk<T>(wn, wc), v); };
+    uint4 wreg = load_w(0);
+    store_w(0, wreg);
     __syncthreads();
+    // per-lane position in the k stream: 8-channel chunk kc = 4 * ks + fq -> (tap, channel chunk)
+    int tap = fq / Ch8, cch = fq - tap * Ch8;
+    for (int ks = 0; ks < nk; ++ks) {
+      const int cur = ks & 1;
+      if (ks + 1 < nk) wreg = load_w(ks + 1);
+      const T* lb = wpan + cur * BN * 32;
+      {
+        // lanes past the end of K (last k-step only) read a valid address and zero the fragment: the MFMAs below must
+        // be executed by the whole wavefront
+        const bool kvalid = tap < 9;
+        const int tp = kvalid ? tap : 8;
+        const int kh = tp / 3, kw = tp - kh * 3;
+        const int dy = flip ? 2 - kh : kh, dx = flip ? 2 - kw : kw;
+        Frag<T> af[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ty = wave * 2 + i;  // tile row of this 16-pixel MFMA row block
+          const uint4 v = ld16(patch + (size_t)((ty + dy) * (HC_TW + 2) + fr + dx) * CP + (kvalid ? cch : 0) * 8);
+          af[i].v = kvalid ? v : zero16();
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          Frag<T> bf = load_frag<T>(lb, j * 16 + fr, fq);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) mma(af[i], bf, acc[i][j]);
+        }
+      }
+      cch += 4;
+      while (cch >= Ch8) { cch -= Ch8; ++tap; }
+      if (ks + 1 < nk) store_w(cur ^ 1, wreg);
+      __syncthreads();
+    }
   }
-
   // ---- epilogue (same contract as gemm_kernel: beta, fused BatchNorm statistics / BatchNorm-backward sums)
   float* sred = reinterpret_cast<float*>(wpan);  // [2][BN]
   if (p.stats) {
@@ -561,18 +565,22 @@ static bool conv_halo_launch(int amode, const GemmP& p, hipStream_t s) {
   const int B = p.M / (H * W);
   if ((long)B * H * W != p.M) return false;
   const int BN = p.N <= 32 ? 32 : 64;
-  const size_t sh = (size_t)(HC_TH + 2) * (HC_TW + 2) * (C + 8) * 2 + (size_t)2 * BN * 32 * 2;
+  // channel slices (see the kernel): halve while the patch is above the threshold and the slice stays a multiple of 32 channels
+  static const int split_kb = getenv("SATRN_HALO_SPLIT_KB") ? atoi(getenv("SATRN_HALO_SPLIT_KB")) : 40;
+  int NS = 1;
+  while ((size_t)(HC_TH + 2) * (HC_TW + 2) * (C / NS + 8) * 2 > (size_t)split_kb * 1024 && (C % (NS * 2)) == 0 && ((C / (NS * 2)) % 32) == 0) NS *= 2;
+  const size_t sh = (size_t)(HC_TH + 2) * (HC_TW + 2) * (C / NS + 8) * 2 + (size_t)2 * BN * 32 * 2;
   if (sh > 150 * 1024) return false;
   const int tiles = B * ((H + HC_TH - 1) / HC_TH) * ((W + HC_TW - 1) / HC_TW) * ((p.N + BN - 1) / BN);
   const int flip = amode == AM_DGRAD ? 1 : 0;
   if (BN == 32) {
     static bool a = false;
     if (!a) { (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a = true; }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<32>), dim3(tiles), dim3(256), sh, s, p, H, W, C, flip);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<32>), dim3(tiles), dim3(256), sh, s, p, H, W, C, flip, NS);
   } else {
     static bool a = false;
     if (!a) { (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a = true; }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<64>), dim3(tiles), dim3(256), sh, s, p, H, W, C, flip);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<64>), dim3(tiles), dim3(256), sh, s, p, H, W, C, flip, NS);
   }
   return true;
 }

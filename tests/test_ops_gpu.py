@@ -139,7 +139,7 @@ def same_geo(H, W, s):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,H,W,Ci,Co,s", [(2, 8, 12, 16, 24, 1), (2, 15, 21, 24, 96, 2), (2, 16, 24, 48, 192, 2),
-                                           (3, 9, 7, 128, 64, 1), (2, 63, 191, 24, 24, 1)])
+                                           (3, 9, 7, 128, 64, 1), (2, 63, 191, 24, 24, 1), (2, 16, 24, 48, 192, 1), (2, 9, 20, 256, 64, 1)])
 def test_conv3x3(lib, dt, B, H, W, Ci, Co, s):
     x, w = q(rnd(B, Ci, H, W, seed=1), dt), q(rnd(Co, Ci, 3, 3, seed=2, scale=1 / math.sqrt(9 * Ci)), dt)
     OH, OW, pt, pl, pads = same_geo(H, W, s)
