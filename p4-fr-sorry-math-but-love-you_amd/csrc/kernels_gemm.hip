@@ -419,7 +419,8 @@ static void launch_gemm_t(const GemmP& p, hipStream_t s) {
 // NS > 1: the input channels are taken in NS slices of C / NS, the patch re-staged per slice and the accumulators kept.  The
 // patch of a deep input (the data gradients of the fused-MBConv stages: C = 192 / 256 -> 72 / 95 KB) allowed one workgroup of
 // four waves per CU; in slices of <= 40 KB three or four share a CU and hide each other's staging and barriers.
-template <int BN>
+// KP: weight panels (32 k each) staged and multiplied per barrier.
+template <int BN, int KP = 1>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, int Wimg, int C, int flip, int NS) {
   typedef bf16_t T;
   constexpr int NT = BN / 16;
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, in
   const int Ch = C / NS, Ch8 = Ch >> 3;                   // channels / 16-byte chunks per slice
   const int CP = Ch + 8;                                  // padded pixel pitch (elements): staggers banks
   T* patch = reinterpret_cast<T*>(hsm);                   // [(TH+2)*(TW+2)][CP]
-  T* wpan = patch + (size_t)(HC_TH + 2) * (HC_TW + 2) * CP;  // [2][BN*32]
+  T* wpan = patch + (size_t)(HC_TH + 2) * (HC_TW + 2) * CP;  // [2][KP][BN*32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
   const int tiles_x = (Wimg + HC_TW - 1) / HC_TW, tiles_y = (Himg + HC_TH - 1) / HC_TH;
   const int ntn = (p.N + BN - 1) / BN;
@@ -460,21 +461,30 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, in
       if (gy >= 0 && gy < Himg && gx >= 0 && gx < Wimg) v = ld16(in + ((long)gy * Wimg + gx) * C + cbase + c8 * 8);
       st16(patch + (size_t)pix * CP + c8 * 8, v);
     }
-    auto load_w = [&](int ks) -> uint4 {
-      const int kc = ks * 4 + wc, tp = kc / Ch8, cc = kc - tp * Ch8;   // chunk kc of the slice's k stream -> (tap, chunk in slice)
-      if (wn < BN && n0 + wn < p.N && tp < 9) return ld16(Wt + (long)(n0 + wn) * K + (long)tp * C + cbase + cc * 8);
-      return zero16();
+    uint4 wreg[KP];
+    auto load_w = [&](int ks) {
+#pragma unroll
+      for (int pp = 0; pp < KP; ++pp) {
+        const int kc = (ks * KP + pp) * 4 + wc, tp = kc / Ch8, cc = kc - tp * Ch8;   // chunk kc of the slice's k stream -> (tap, chunk in slice)
+        wreg[pp] = (wn < BN && n0 + wn < p.N && tp < 9) ? ld16(Wt + (long)(n0 + wn) * K + (long)tp * C + cbase + cc * 8) : zero16();
+      }
     };
-    auto store_w = [&](int buf, uint4 v) { if (wn < BN) st16(wpan + buf * BN * 32 + panel_chunk<T>(wn, wc), v); };
-    uint4 wreg = load_w(0);
-    store_w(0, wreg);
+    auto store_w = [&](int buf) {
+#pragma unroll
+      for (int pp = 0; pp < KP; ++pp) if (wn < BN) st16(wpan + (buf * KP + pp) * BN * 32 + panel_chunk<T>(wn, wc), wreg[pp]);
+    };
+    load_w(0);
+    store_w(0);
     __syncthreads();
-    // per-lane position in the k stream: 8-channel chunk kc = 4 * ks + fq -> (tap, channel chunk)
+    // per-lane position in the k stream: 8-channel chunk kc = 4 * panel + fq -> (tap, channel chunk)
     int tap = fq / Ch8, cch = fq - tap * Ch8;
-    for (int ks = 0; ks < nk; ++ks) {
+    const int nks = (nk + KP - 1) / KP;
+    for (int ks = 0; ks < nks; ++ks) {
       const int cur = ks & 1;
-      if (ks + 1 < nk) wreg = load_w(ks + 1);
-      const T* lb = wpan + cur * BN * 32;
+      if (ks + 1 < nks) load_w(ks + 1);
+#pragma unroll
+      for (int pp = 0; pp < KP; ++pp) {
+      const T* lb = wpan + (cur * KP + pp) * BN * 32;
       {
         // lanes past the end of K (last k-step only) read a valid address and zero the fragment: the MFMAs below must
         // be executed by the whole wavefront
@@ -498,7 +508,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, in
       }
       cch += 4;
       while (cch >= Ch8) { cch -= Ch8; ++tap; }
-      if (ks + 1 < nk) store_w(cur ^ 1, wreg);
+      }
+      if (ks + 1 < nks) store_w(cur ^ 1);
       __syncthreads();
     }
   }
@@ -569,7 +580,9 @@ static bool conv_halo_launch(int amode, const GemmP& p, hipStream_t s) {
   static const int split_kb = getenv("SATRN_HALO_SPLIT_KB") ? atoi(getenv("SATRN_HALO_SPLIT_KB")) : 40;
   int NS = 1;
   while ((size_t)(HC_TH + 2) * (HC_TW + 2) * (C / NS + 8) * 2 > (size_t)split_kb * 1024 && (C % (NS * 2)) == 0 && ((C / (NS * 2)) % 32) == 0) NS *= 2;
-  const size_t sh = (size_t)(HC_TH + 2) * (HC_TW + 2) * (C / NS + 8) * 2 + (size_t)2 * BN * 32 * 2;
+  static const int kp_env = getenv("SATRN_HALO_KP") ? atoi(getenv("SATRN_HALO_KP")) : 2;
+  const int KPv = (BN == 64 && kp_env == 2 && 9 * (C / NS) >= 512) ? 2 : 1;   // deep k streams: two weight panels per barrier
+  const size_t sh = (size_t)(HC_TH + 2) * (HC_TW + 2) * (C / NS + 8) * 2 + (size_t)2 * KPv * BN * 32 * 2;
   if (sh > 150 * 1024) return false;
   const int tiles = B * ((H + HC_TH - 1) / HC_TH) * ((W + HC_TW - 1) / HC_TW) * ((p.N + BN - 1) / BN);
   const int flip = amode == AM_DGRAD ? 1 : 0;
@@ -580,6 +593,12 @@ static bool conv_halo_launch(int amode, const GemmP& p, hipStream_t s) {
   } else {
     static bool a = false;
     if (!a) { (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a = true; }
+    if (KPv == 2) {
+      static bool a2 = false;
+      if (!a2) { (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); a2 = true; }
+      hipLaunchKernelGGL((conv3x3_halo_kernel<64, 2>), dim3(tiles), dim3(256), sh, s, p, H, W, C, flip, NS);
+      return true;
+    }
     hipLaunchKernelGGL((conv3x3_halo_kernel<64>), dim3(tiles), dim3(256), sh, s, p, H, W, C, flip, NS);
   }
   return true;
