@@ -584,6 +584,48 @@ void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* ss,
 }
 
 // ---- stem conv (Cin = 1 or 3, 3x3): direct, fp32 image + fp32 master weights -------------------
+// One input channel (grey-scale images: the benchmark case): the grid is a multiple of the chunk count, so a thread always meets the same
+// 8 output channels and holds their 72 weights in registers.  The generic kernel below fetches every weight through the vector
+// memory path for every pixel (81 memory instructions per thread and pixel: 65 us for the 32 x 128 x 384 batch, issue-bound).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_conv1_kernel(const float* __restrict__ img, const float* __restrict__ w, T* __restrict__ y, int B, int H, int W,
+                                                         int Co, int OH, int OW, int stride, int pad) {
+  constexpr int CH = TT<T>::CH;
+  const int CC = Co / CH;
+  const long total = (long)B * OH * OW * CC;
+  const long t0 = blockIdx.x * (long)blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+  const int cc = (int)(t0 % CC);   // nth % CC == 0 (launcher)
+  float wr[9][CH];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) wr[t][j] = w[(cc * CH + j) * 9 + t];
+  for (long i = t0; i < total; i += nth) {
+    const long pix = i / CC;
+    const int ox = (int)(pix % OW);
+    const int oy = (int)((pix / OW) % OH);
+    const int b = (int)(pix / ((long)OW * OH));
+    const float* im = img + (long)b * H * W;
+    float x[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int sy = oy * stride - pad + kh, sx = ox * stride - pad + kw;
+        const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W;
+        const float v = im[ok ? (long)sy * W + sx : 0];
+        x[kh * 3 + kw] = ok ? v : 0.f;
+      }
+    float acc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)   // same order as the generic kernel (kh, kw ascending): same sums
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[j] += x[t] * wr[t][j];
+    st16(y + pix * Co + cc * CH, pack<T>(acc));
+  }
+}
 template <typename T>
 __global__ void stem_conv_kernel(const float* img, const float* w, T* y, int B, int Cin, int H, int W, int Co, int OH,
                                  int OW, int stride, int pad) {
@@ -618,6 +660,12 @@ void launch_stem_conv(int dt, const float* img, const float* w, void* y, int B, 
                       int OW, int stride, int pad, hipStream_t s) {
   DISPATCH_T(dt, {
     long n = (long)B * OH * OW * (Co / TT<T>::CH);
+    static const bool one_ok = getenv("SATRN_STEM_GENERIC") == nullptr;
+    if (Cin == 1 && one_ok) {
+      // a few pixels per thread amortise the 72 weight loads; total threads a multiple of the chunk count
+      const int g = grid_chan((n + 3) / 4, Co / TT<T>::CH);
+      hipLaunchKernelGGL((stem_conv1_kernel<T>), dim3(g), dim3(256), 0, s, img, w, (T*)y, B, H, W, Co, OH, OW, stride, pad);
+    } else
     hipLaunchKernelGGL((stem_conv_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, img, w, (T*)y, B, Cin, H, W, Co, OH,
                        OW, stride, pad);
   });
