@@ -17,6 +17,11 @@ DEVI void ldv(const float* p, float* o, int n) {  // n (multiple of 4) floats th
   }
 }
 
+DEVI void lds8(const float* p, float* o) {   // 8 floats from LDS / memory through two 16-byte reads
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+
 DetCtx g_det;
 void det_overflow_warn(size_t need_floats) {
   static bool once = false;
@@ -412,10 +417,91 @@ bool bn_act_pool_ok(long M, int C, int HW) {
   const bool off = getenv("SATRN_NO_FUSED_POOL") != nullptr;   // read per call: tests compare the fused and the plain forms in one process
   return !off && !g_det.on && HW > 0 && (HW % BNP_ROWS) == 0 && (M % HW) == 0;
 }
+// The same pass as an image kernel for the small maps of the late stages (bf16): workgroup = one image x 64 channels (full 128-byte
+// lines), PPT pixels per thread all requested up front, coefficients derived once per workgroup -- and the pool of the image is
+// complete inside the workgroup: plain stores, no atomics on poolsum.
+template <int PPT>
+__global__ __launch_bounds__(256) void bn_pool_img_kernel(const bf16_t* __restrict__ y, const float* sums, int sums_rep, const float* w, const float* b,
+                                                          float* rm, float* rv, int64_t* nbt, float eps, float mom, float invM, float unbias,
+                                                          float* ss, float* mr, bf16_t* __restrict__ z, float* poolsum, int C, int HW, int act) {
+  typedef bf16_t T;
+  constexpr int CH = 8, SC = 8;
+  __shared__ __attribute__((aligned(16))) float cf[2][SC * CH];
+  __shared__ float sred[4][SC * CH];
+  const int tid = threadIdx.x, NT = blockDim.x, G = NT / SC;
+  const int chunk = tid % SC, g = tid / SC;
+  const int img = blockIdx.x, cb = blockIdx.y * SC * CH, c0 = cb + chunk * CH;
+  const long base = (long)img * HW * C + c0;
+  uint4 raw[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) raw[k] = ld16(y + base + (long)(g + k * G) * C);
+  for (int c = tid; c < SC * CH; c += NT) {   // one thread per channel: BatchNorm finalize (bn_act_kernel's arithmetic)
+    const int cg = cb + c;
+    float mean = 0.f, var = 0.f;
+    for (int rp = 0; rp < sums_rep; ++rp) { mean += sums[(size_t)rp * 2 * C + cg]; var += sums[(size_t)rp * 2 * C + C + cg]; }
+    mean *= invM; var = fmaxf(var * invM - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps), sc = w[cg] * rstd, sh = b[cg] - mean * sc;
+    cf[0][c] = sc; cf[1][c] = sh;
+    if (img == 0) {
+      ss[cg] = sc; ss[C + cg] = sh; mr[cg] = mean; mr[C + cg] = rstd;
+      rm[cg] = (1.f - mom) * rm[cg] + mom * mean;
+      rv[cg] = (1.f - mom) * rv[cg] + mom * var * unbias;
+    }
+  }
+  __syncthreads();
+  float sc[CH], sh[CH], acc[CH];
+  lds8(cf[0] + chunk * CH, sc); lds8(cf[1] + chunk * CH, sh);
+#pragma unroll
+  for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    float v[CH];
+    unpack<T>(raw[k], v);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) v[j] = act_fwd(v[j] * sc[j] + sh[j], act);
+    const uint4 o = pack<T>(v);
+    st16(z + base + (long)(g + k * G) * C, o);
+    float r[CH];
+    unpack<T>(o, r);   // the pool averages the STORED values
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] += r[j];
+  }
+#pragma unroll
+  for (int o = SC; o < 64; o <<= 1)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane < SC) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) sred[wave][lane * CH + j] = acc[j];
+  }
+  __syncthreads();
+  for (int c = tid; c < SC * CH; c += NT) {
+    float sum = 0.f;
+    for (int wv = 0; wv < NT / 64; ++wv) sum += sred[wv][c];
+    poolsum[(long)img * C + cb + c] = sum;
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nbt) *nbt += 1;
+}
+
 void launch_bn_act_pool(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv,
                         int64_t* nbt, float eps, float mom, float* ss, float* mr, void* z, float* poolsum, long M, int C, int HW, int act,
                         hipStream_t s) {
   float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
+  static const bool img_ok = getenv("SATRN_BNP_NO_IMG") == nullptr;
+  if (img_ok && dt == DT_BF16 && (C % 64) == 0 && HW > 0 && (M % HW) == 0 && sums) {
+    // pixel lanes: the largest of 32 / 16 / 8 that divides HW with at most 8 pixels per thread
+    const int B = (int)(M / HW);
+    for (int G = 32; G >= 8; G >>= 1) {
+      if ((HW % G) != 0 || HW / G > 8 || (G * 8) % 64 != 0) continue;
+      const int ppt = HW / G;
+      const dim3 grid(B, C / 64), blk(G * 8);
+#define BNP_IMG(P) case P: hipLaunchKernelGGL((bn_pool_img_kernel<P>), grid, blk, 0, s, (const bf16_t*)y, sums, sums_rep < 1 ? 1 : sums_rep, w, b, rm, rv, nbt, eps, mom, \
+                                             1.0f / (float)M, unbias, ss, mr, (bf16_t*)z, poolsum, C, HW, act); return;
+      switch (ppt) { BNP_IMG(1) BNP_IMG(2) BNP_IMG(3) BNP_IMG(4) BNP_IMG(5) BNP_IMG(6) BNP_IMG(7) BNP_IMG(8) }
+#undef BNP_IMG
+    }
+  }
   DISPATCH_T(dt, {
     const int CC = C / TT<T>::CH;
     // 24 rows per workgroup where 48 would leave the grid under one workgroup per CU (the 4x12 stage: 192 -> 384 workgroups)
@@ -960,10 +1046,6 @@ __global__ __launch_bounds__(256) void dwconv_s1_red_kernel(const T* __restrict_
 // Per-channel coefficients are derived ONCE per workgroup (one thread per channel of the slab) and handed round through LDS, as are
 // the nine weight rows: a first form where every thread derived the coefficients of its own 8 channels and kept the unpacked
 // weights needed 256 VGPRs (one workgroup per CU, two rounds over the 480-workgroup grid); this one fits 128.
-DEVI void lds8(const float* p, float* o) {   // 8 floats from LDS / memory through two 16-byte reads
-  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
-  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-}
 DEVI void bdw_zero_halo(uint4* tile, int H, int W, int rowpix, int tid, int NT) {
   constexpr int SC = BDW_SC;
   const int nh = 2 * (W + 2) + 2 * H;
