@@ -209,7 +209,7 @@ def test_dwconv(lib, dt, B, H, W, C, s):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("M,C,act,res", [(96, 64, 2, False), (1000, 24, 1, True), (3000, 1536, 0, True), (48, 512, 2, False)])
+@pytest.mark.parametrize("M,C,act,res", [(96, 64, 2, False), (1000, 24, 1, True), (3000, 1536, 0, True), (48, 512, 2, False), (6144, 960, 2, False), (1536, 256, 0, True)])
 def test_batchnorm_act(lib, dt, M, C, act, res):
     y = q(rnd(M, C, seed=1) * 2 + 0.5, dt)
     r = q(rnd(M, C, seed=2), dt) if res else None
