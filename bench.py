@@ -215,14 +215,41 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def visible_gpu_count():
+    """GPUs this process may use, from sysfs (/sys/class/kfd/kfd/topology/nodes/*/properties: simd_count > 0) clipped by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES; None when the topology cannot be read.  No HIP call."""
+    import glob
+    total = 0
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0   # no amdgpu compute driver on this host at all
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for f in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0:
+            total += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            total = min(total, len([x for x in v.split(",") if x.strip() != ""]))
+    return total
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py ...`
     as a child, pass its stderr through, print the ONE JSON line rank 0 produced and check it really came from N ranks."""
     import socket
     import subprocess
     n = args.gpus
-    have = torch.cuda.device_count()  # counting devices does not initialise the GPU in this process
-    if have < n:
+    # Count GPUs WITHOUT the HIP runtime: this process goes on to start a launcher, and a parent that has opened /dev/kfd
+    # (torch.cuda.device_count() can, through hipGetDeviceCount) must not spawn from that state on this pool.  The KFD topology in
+    # sysfs lists every node; GPU nodes have simd_count > 0.  If sysfs is unreadable the check is skipped: the children fail and say so.
+    have = visible_gpu_count()
+    if have is not None and have < n:
         log(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible")
         return 2
     with socket.socket() as so:
@@ -315,7 +342,10 @@ def main():
     for i in range(args.steps):
         step()
         marks[i + 1].record()
-    host_issue_ms = (time.perf_counter() - t0) / args.steps * 1e3  # host time to ISSUE a step (no sync): must stay below ms_per_step
+    # host time per step inside the back-to-back timed loop.  This is NOT what the host needs: once the launch queues are full the
+    # host blocks until the GPU retires packets, so in steady state this figure converges to the GPU's own step time
+    # (back-pressure).  The host's real cost is host_issue_ms_unblocked below (one step issued into an idle GPU, no sync).
+    host_issue_ms = (time.perf_counter() - t0) / args.steps * 1e3
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -328,6 +358,16 @@ def main():
     loss, cnt, gnorm = model.read_loss()
     if rank == 0:
         log(f"timed {args.steps} steps in {dt:.3f}s")
+    # outside the timed region: the host's own cost of issuing ONE step (GPU idle before, no sync after): median of 7
+    unb = []
+    for _ in range(7):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        unb.append((time.perf_counter() - t1) * 1e3)
+    torch.cuda.synchronize()
+    host_issue_unblocked_ms = sorted(unb)[len(unb) // 2]
+    exposed = dp.last_exchange_exposed_ms() if world > 1 else None
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -382,7 +422,9 @@ def main():
         roof["share_of_step_kernel_time"] = round(dom["ms"] / max(tot_ms, 1e-9), 4)
         roof["whole_step_mfma_frac"] = round(FLOP_PER_IMG_TRAIN * B / (ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS), 5)
         out = dict(metric="train images/sec (whole node) EfficientSATRN bs32/GPU 128x384", value=round(value, 2), unit="images/s",
-                   n_gpus=world, rccl_ranks=(dist.get_world_size() if dist is not None else 1), steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), ms_per_step_median=round(ms_median, 3), host_issue_ms_per_step=round(host_issue_ms, 3), higher_is_better=True,
+                   n_gpus=world, rccl_ranks=(dist.get_world_size() if dist is not None else 1), steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), ms_per_step_median=round(ms_median, 3), host_issue_ms_per_step=round(host_issue_ms, 3), host_issue_ms_unblocked=round(host_issue_unblocked_ms, 3),
+                   host_issue_note="host_issue_ms_per_step is measured inside the back-to-back loop and includes queue back-pressure (the host waits for the GPU once the launch queues fill); host_issue_ms_unblocked is one step issued into an idle GPU without a sync = what the host itself needs",
+                   exchange_exposed_ms=(round(exposed, 3) if exposed is not None else None), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                    config=dict(workload="EfficientSATRN train step (fwd+CE+bwd+clip+AdamW), bs32/GPU, 1x128x384, teacher-forced T=128, dropout 0.1 (BASELINE configs[1])",
                                global_batch=world * B, seq_len=T, parallelism=f"dp{world}", hipgraph=graph, streams=1 if graph else 2,
@@ -404,8 +446,12 @@ def main():
                     model.greedy(dimg, 231)
                 torch.cuda.synchronize()
                 dsec = (time.perf_counter() - t1) / reps
+                dpath, dgive, dnote = model.last_decode_path()
+                if dpath != "pipe" or dgive:
+                    raise RuntimeError(f"the benchmarked decode did not run on the role pipeline: path {dpath!r}, give-ups {dgive}, note {dnote!r}")
                 out["greedy_decode"] = dict(value=round(64 * 231 / dsec, 1), unit="tokens/s", batch=64, steps=231,
-                                            ms_per_batch=round(dsec * 1e3, 2), includes="encoder + 231 decoder steps")
+                                            ms_per_batch=round(dsec * 1e3, 2), includes="encoder + 231 decoder steps",
+                                            decoder_path=dpath, pipe_giveups=dgive)
                 # HBM roofline of the decode (38 MB of weights + mean KV history per 64-image step, bf16), with the
                 # encoder pass timed on its own and taken out
                 model.encode(dimg)
@@ -419,6 +465,8 @@ def main():
                 out["greedy_decode"]["roofline"] = dict(bound="hbm", algorithmic_bytes_per_step=38.0e6, us_per_step=round(step_us, 1),
                                                         achieved=round(38.0e6 / step_us / 1e3, 1), peak=8000.0, unit="GB/s",
                                                         frac=round(38.0e6 / step_us / 1e3 / 8000.0, 4), encoder_ms=round(esec * 1e3, 2),
+                                                        kv_only=dict(algorithmic_bytes_per_step=32.2e6, achieved=round(32.2e6 / step_us / 1e3, 1), frac=round(32.2e6 / step_us / 1e3 / 8000.0, 4),
+                                                                     note="what a weight-stationary decoder must move per 64-image step: self-attention K/V history 22.8 MB (mean over 231 steps) + cross-attention K/V 9.4 MB; the 5.8 MB of weights stay in LDS"),
                                                         traffic=_decode_traffic(), traffic_source="profiles/r02_pmc_decode_traffic.json (memory-side bytes of the whole 231-step decode launch / 231)",
                                                         kernel="decode_pipe_kernel (one persistent workgroup per decoder role, weights resident in LDS, images pipelined through the roles)",
                                                         note="latency-bound, not HBM-bound: a token is a dependent chain of 13 role hops per step (3 layers x [Q/K/V, self-attention + out-projection, LayerNorm + cross-attention, LayerNorm + feed-forward] + generator), and at batch 64 the 244 role workgroups are ~80 % busy; the weights never leave LDS, so the 38 MB/step figure is what a weight-streaming decoder would move, kept as the algorithmic unit of SURVEY 8d")
@@ -431,7 +479,7 @@ def main():
                     t1 = time.perf_counter()
                     model.greedy(dimg, 231)
                     torch.cuda.synchronize()
-                    out["greedy_decode"]["per_image_kernel"] = dict(ms_per_batch=round((time.perf_counter() - t1) * 1e3, 2),
+                    out["greedy_decode"]["per_image_kernel"] = dict(ms_per_batch=round((time.perf_counter() - t1) * 1e3, 2), decoder_path=model.last_decode_path()[0],
                                                                     note="round-1 decoder (fallback path), same batch")
                 finally:
                     os.environ.pop("SATRN_DECODE_NO_PIPE", None)
@@ -468,7 +516,7 @@ def main():
                 model.greedy(dimg112, 231)
                 torch.cuda.synchronize()
                 d112 = time.perf_counter() - t1
-                out["greedy_decode"]["batch_112"] = dict(value=round(112 * 231 / d112, 1), unit="tokens/s", ms_per_batch=round(d112 * 1e3, 2), decoder="pipelined")
+                out["greedy_decode"]["batch_112"] = dict(value=round(112 * 231 / d112, 1), unit="tokens/s", ms_per_batch=round(d112 * 1e3, 2), decoder_path=model.last_decode_path()[0])
                 dimg4 = torch.cat([dimg] * 4)
                 model.greedy(dimg4, 231)
                 torch.cuda.synchronize()
@@ -476,7 +524,7 @@ def main():
                 model.greedy(dimg4, 231)
                 torch.cuda.synchronize()
                 d4 = time.perf_counter() - t1
-                out["greedy_decode"]["batch_256"] = dict(value=round(256 * 231 / d4, 1), unit="tokens/s", ms_per_batch=round(d4 * 1e3, 2), decoder="per-image kernel (batch > 112)")
+                out["greedy_decode"]["batch_256"] = dict(value=round(256 * 231 / d4, 1), unit="tokens/s", ms_per_batch=round(d4 * 1e3, 2), decoder_path=model.last_decode_path()[0])
                 # best-first beam search of the same 64 images (EfficientSATRN.beam_search, beam 5, max_sequence 230): one launch,
                 # at most 229 decoder-step expansions per image
                 class _Loader:

@@ -306,6 +306,18 @@ int satrn_model_encode(satrn_model* m, const float* images, int B, float* src_ou
  * once per (B, steps, buffer addresses) and replays it: the four buffers must then stay at the same addresses. */
 int satrn_model_greedy(satrn_model* m, const float* images, const float* src, int B, int steps, float* logits,
                        int64_t* ids, int use_graph, void* stream);
+/* Forced replay of the same decode (the step loop of networks/EfficientSATRN.py:528-561 with `target` supplied instead of
+ * `torch.argmax(o[:, -1, :])` at :557): the token fed to step t + 1 of image b is forced_ids[b][t] (int64 [B][steps], device);
+ * logits are every step's outputs and ids their argmax, as in satrn_model_greedy.  With a reference decode's ids this compares
+ * EVERY step's logits of a kernel against that reference, not only the prefix before the first near-tie flips a token. */
+int satrn_model_greedy_forced(satrn_model* m, const float* images, const float* src, int B, int steps,
+                              const int64_t* forced_ids, float* logits, int64_t* ids, void* stream);
+/* Which kernel produced the last greedy result: 0 none yet, 1 the role pipeline (bf16, D = 256, F = 1024, B <= 112: one persistent
+ * workgroup per decoder role), 2 the one-workgroup-per-image kernel, 3 step-wise launches.  *giveups (may be NULL) = pipelines of
+ * this model that ran into a bounded wait and were re-run on path 2 (the pipeline is then disabled for the process; with
+ * SATRN_PIPE_STRICT in the environment the decode fails with -7 instead).  satrn_model_decode_note: why path 1 was not taken. */
+int satrn_model_last_decode_path(satrn_model* m, int* giveups);
+const char* satrn_model_decode_note(satrn_model* m);
 /* DecodingManager on the device (postprocessing/postprocessing.py:180-388).  rules: int32 [V + 8] in device memory, the
  * manager's rule lists compiled by satrn_amd.decoding.compile_rules: per token (flag bits: 1 next must be "_", 2 next must
  * be "{", 4 next cannot be "_", 8 next cannot be "{", 16 cannot follow <SOS>) | (run-length limit << 8), then the ids of

@@ -53,7 +53,14 @@ hipStream_t Exec::side() {
 // Side launches are queued (they only need their inputs, which the main stream has already been asked to produce) and
 // flushed a few closures later behind ONE event: keeps the host cost of forking at ~1/8 of an event pair per launch.
 void Exec::defer(std::function<void(hipStream_t)> fn) {
-  static const bool skip = getenv("SATRN_TIMING_SKIP_WGRAD") != nullptr;  // timing experiment only (wrong gradients): the chain alone
+  // timing experiment only (the chain alone; WRONG gradients): announced loudly, once, so that a stray variable cannot give a
+  // silently non-training model
+  static const bool skip = [] {
+    const bool on = getenv("SATRN_TIMING_SKIP_WGRAD") != nullptr;
+    if (on) fprintf(stderr, "[satrn] WARNING: SATRN_TIMING_SKIP_WGRAD is set -- weight / bias gradients are NOT computed; this process measures the "
+                            "data-gradient chain only and must not be used for training\n");
+    return on;
+  }();
   if (skip && !dry) return;
   if (!s2 || dry) { fn(s); return; }
   pending.push_back(std::move(fn));
@@ -2174,7 +2181,7 @@ static void fill_decode_params(Model* m, DecodeP& dp, const std::vector<Tensor*>
 // self-attention history of a layer is k/v_linear of that layer's previous OUTPUTS plus the current INPUT.
 // KV-cached: slot t first holds k/v(input_t), is attended, then is overwritten with k/v(output_t).
 static int greedy_body(Model* m, const float* img, const float* src_in, int B, int steps, float* logits_out, int64_t* ids_out,
-                       hipStream_t s, const int32_t* rules) {
+                       hipStream_t s, const int32_t* rules, const int64_t* forced) {
   Exec& e = *m->ex;
   const SatrnConfig& c = m->cfg;
   const int Dd = c.dec_hidden, V = c.num_classes;
@@ -2201,7 +2208,7 @@ static int greedy_body(Model* m, const float* img, const float* src_in, int B, i
   if (!getenv("SATRN_DECODE_STEPWISE") && L <= 4) {
     DecodeP dp;
     fill_decode_params(m, dp, crossKV, cache, B, steps, Nsrc, s);
-    dp.logits = logits_out; dp.ids = ids_out; dp.rules = rules;
+    dp.logits = logits_out; dp.ids = ids_out; dp.rules = rules; dp.forced = forced; dp.ld_forced = steps;
     // (1) bf16: the pipelined weight-stationary decoder (one workgroup per role, weights resident in LDS).  It is checked
     //     synchronously -- a decode is tens of milliseconds and its caller reads the result next -- and a pipeline that gave up
     //     (bounded waits) is re-run on the one-workgroup-per-image kernel, so a result is always the decoder's.  Not inside a
@@ -2213,16 +2220,30 @@ static int greedy_body(Model* m, const float* img, const float* src_in, int B, i
       void* scratch = e.alloc(sb);
       if (!e.oom && launch_decode_pipe(e.dt, dp, scratch, sb, s) == 0) {
         const int perr = decode_pipe_error(scratch, s);
-        if (perr == 0) return 0;
-        fprintf(stderr, "[satrn] pipelined decoder gave up (role %d): falling back to the one-workgroup-per-image decoder\n", perr - 1);
+        if (perr == 0) { m->last_decode_path = 1; m->decode_note.clear(); return 0; }
+        // A give-up (a bounded wait ran out: some role workgroup was not resident, or the device is wedged) is never silent: it is
+        // counted, reported through satrn_model_last_decode_path, and the pipeline is not tried again in this process.  With
+        // SATRN_PIPE_STRICT set it is an error instead of a re-run.
+        char why[96];
+        snprintf(why, sizeof(why), "role %d timed out", perr - 1);
+        m->pipe_giveups += 1;
+        m->decode_note = std::string("pipelined decoder gave up (") + why + ")";
+        decode_pipe_disable(why);
+        if (getenv("SATRN_PIPE_STRICT")) { m->err = m->decode_note; return -7; }
+      } else {
+        m->decode_note = decode_pipe_reason();
       }
       if (e.oom) { m->err = "workspace exhausted"; return -2; }
+    } else {
+      m->decode_note = "inside a stream capture";
     }
     if (launch_decode_greedy(e.dt, dp, s) == 0) {
       if (e.oom) { m->err = "workspace exhausted"; return -2; }
+      m->last_decode_path = 2;
       return 0;
     }
   }
+  m->last_decode_path = 3;
   int32_t* sift_state = nullptr;
   if (rules) {
     sift_state = (int32_t*)e.alloc((size_t)B * 16);
@@ -2232,7 +2253,7 @@ static int greedy_body(Model* m, const float* img, const float* src_in, int B, i
   const size_t keep = e.tens.size();
   for (int t = 0; t < steps; ++t) {
     e.off = mark;  // per-step scratch is reused
-    int rc = decode_one_step(m, t == 0 ? sos : ids_out + (t - 1), t == 0 ? 1 : steps, t, steps, crossKV, cache,
+    int rc = decode_one_step(m, t == 0 ? sos : (forced ? forced : ids_out) + (t - 1), t == 0 ? 1 : steps, t, steps, crossKV, cache,
                              logits_out + (size_t)t * V, steps * V);
     if (rc) return rc;
     if (rules) launch_sift_strided(logits_out + (size_t)t * V, steps * V, sift_state, rules, B, V, ids_out + t, steps, s);
@@ -2362,16 +2383,16 @@ int model_profile_step(Model* m, const float* img, const int64_t* expected, int 
 // Greedy decode entry: eager, or (use_graph) the whole decode -- encoder + every step's ~45 launches -- captured once
 // per (B, steps, buffer addresses) and replayed, which removes the host launch cost of ~10^4 kernels per batch.
 int model_greedy(Model* m, const float* img, const float* src_in, int B, int steps, float* logits_out, int64_t* ids_out,
-                 int use_graph, hipStream_t s, const int32_t* rules) {
+                 int use_graph, hipStream_t s, const int32_t* rules, const int64_t* forced) {
   if (!m->bound || !m->ws_set) { m->err = "bind parameters and set a workspace first"; return -1; }
   if (steps > 500) { m->err = "max 500 decode steps (PositionEncoder1D max_len)"; return -1; }
-  if (!use_graph || rules) return greedy_body(m, img, src_in, B, steps, logits_out, ids_out, s, rules);
+  if (!use_graph || rules || forced) return greedy_body(m, img, src_in, B, steps, logits_out, ids_out, s, rules, forced);
   const void* key[6] = {img, src_in, logits_out, ids_out, (void*)(intptr_t)B, (void*)(intptr_t)steps};
   if (m->decode_graph && memcmp(key, m->decode_key, sizeof(key)) != 0) { (void)hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
   if (!m->decode_graph) {
     hipGraph_t g = nullptr;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) { m->err = "stream capture failed"; return -3; }
-    int rc = greedy_body(m, img, src_in, B, steps, logits_out, ids_out, s, nullptr);
+    int rc = greedy_body(m, img, src_in, B, steps, logits_out, ids_out, s, nullptr, nullptr);
     hipError_t er = hipStreamEndCapture(s, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     if (er != hipSuccess || !g) { m->err = "decode graph capture failed"; return -3; }

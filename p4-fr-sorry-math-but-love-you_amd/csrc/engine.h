@@ -146,6 +146,9 @@ struct Model {
   size_t seg_mark[3] = {0, 0, 0}; int64_t seg_lo[4] = {0, 0, 0, 0}, seg_hi[4] = {0, 0, 0, 0}; int late_block = 0; int seg_next = 0;
   long logits_epoch = -1;  // epoch of the arena that holds the last forward's logits
   long epoch = 0, step_epoch = -1;  // every arena reset bumps epoch: a session from an older epoch is dead
+  // which decoder produced the last greedy result: 0 none yet, 1 role pipeline, 2 one workgroup per image, 3 step-wise launches;
+  // pipe_giveups counts pipelines that timed out and were re-run on another kernel (never silently: see decode_note)
+  int last_decode_path = 0, pipe_giveups = 0; std::string decode_note;
   std::string err;
 };
 
@@ -205,7 +208,7 @@ int model_last_sequence(Model* m, int64_t* ids_out, int B, int L, hipStream_t s)
 int model_read_loss(Model* m, float* out4, hipStream_t s);
 int model_encode(Model* m, const float* img, int B, float* src_out, hipStream_t s);
 int model_greedy(Model* m, const float* img, const float* src_or_null, int B, int steps, float* logits_out,
-                 int64_t* ids_out, int use_graph, hipStream_t s, const int32_t* rules = nullptr);
+                 int64_t* ids_out, int use_graph, hipStream_t s, const int32_t* rules = nullptr, const int64_t* forced = nullptr);
 int model_beam_search(Model* m, const float* img, int B, int beam_width, int max_sequence, int eos_id, int pad_id,
                       int64_t* sequences, hipStream_t s);
 int model_backward_segment(Model* m, const int64_t* expected, int B, int L, int seg, hipStream_t s, int seg_to = -1);

@@ -254,6 +254,9 @@ struct DecodeP {
   int dbg;  // timing ablation bits (SATRN_DEC_DBG), 0 in production
   const int32_t* rules;  // optional compiled DecodingManager rules [V + 8]: outputs become masked probabilities
   long long* prof;       // optional [16] cycle counters per phase family (SATRN_DEC_PROF, workgroup 0 only)
+  // forced replay (parity tests, ensemble-style teacher forcing): when non-null the token fed to step t + 1 of image b is
+  // forced[b * ld_forced + t] instead of the step's own argmax (logits / ids outputs are unchanged: ids stay the argmax)
+  const int64_t* forced; int ld_forced;
 };
 int launch_decode_greedy(int dt, const DecodeP& p, hipStream_t s);
 // pipelined weight-stationary greedy decoder (kernels_decode.hip): one persistent workgroup per ROLE (a slice of the decoder's
@@ -270,9 +273,14 @@ struct PipeP {
   const PipeRole* roles; unsigned long long* mail; int* err; long long timeout_ticks;
   const int32_t* rules;  // optional DecodingManager table (sift.h): applied by the generator role, which keeps each of its images' memory
   long long* prof;  // optional [2 * nroles]: wall-clock ticks spent waiting / in total (SATRN_PIPE_PROF)
+  const int64_t* forced; int ld_forced;   // see DecodeP
 };
 size_t decode_pipe_scratch_bytes(const DecodeP& p);
-int launch_decode_pipe(int dt, const DecodeP& p, void* scratch, size_t scratch_bytes, hipStream_t s);  // 0 launched, -1 shape not supported
+int launch_decode_pipe(int dt, const DecodeP& p, void* scratch, size_t scratch_bytes, hipStream_t s);  // 0 launched, -1 shape / device not supported
+// why the last launch_decode_pipe call returned -1 ("" after a launch): shape, device too small, co-residency not provable, disabled
+const char* decode_pipe_reason();
+// a pipeline that timed out is not tried again in this process (every later decode would burn the same timeout): sticky
+void decode_pipe_disable(const char* why);
 int decode_pipe_error(void* scratch, hipStream_t s);  // weights in DecLayerW / wgen: k-panel-major copies
 // best-first beam search (networks/EfficientSATRN.py:708-867): DecodeP.steps = max_sequence - 1 expansions (= cache rows per
 // image); node tables are per image [NN], NN >= 1 + bw*steps; path [steps][pstride] uint16; out int64 [B][max_seq]

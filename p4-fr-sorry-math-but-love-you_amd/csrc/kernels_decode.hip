@@ -350,7 +350,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
       // its argmax
       if (tid < 64) {
         const int bi = sift_wave(lg, out, V, sst, p.rules, tid);
-        if (tid == 0) { s_tok = bi; p.ids[(long)b * p.steps + t] = bi; }
+        if (tid == 0) { s_tok = p.forced ? (int)p.forced[(long)b * p.ld_forced + t] : bi; p.ids[(long)b * p.steps + t] = bi; }
       }
     } else {
       for (int i = tid; i < V; i += DEC_THREADS) out[i] = lg[i];
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_greedy_kernel(DecodeP p) {
           int oi = __shfl_xor(bi, o, 64);
           if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
-        if (tid == 0) { s_tok = bi; p.ids[(long)b * p.steps + t] = bi; }
+        if (tid == 0) { s_tok = p.forced ? (int)p.forced[(long)b * p.ld_forced + t] : bi; p.ids[(long)b * p.steps + t] = bi; }
       }
     }
     __syncthreads();
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
             SiftState& st = s_sift[(img - role.img0) / role.istep];
             if (tid < 64) {
               const int bi = sift_wave(y, out, p.V, st, s_rules, tid);
-              if (tid == 0) { s_tok = bi; p.ids[(long)img * p.steps + t] = bi; }
+              if (tid == 0) { s_tok = p.forced ? (int)p.forced[(long)img * p.ld_forced + t] : bi; p.ids[(long)img * p.steps + t] = bi; }
             }
             LDS_BARRIER();
             if (tid == 0) sift_record(st, s_tok, s_rules, p.V);
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(PIPE_THREADS) void decode_pipe_kernel(PipeP p) {
               int oi = __shfl_xor(bi, o, 64);
               if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
             }
-            if (tid == 0) { s_tok = bi; p.ids[(long)img * p.steps + t] = bi; }
+            if (tid == 0) { s_tok = p.forced ? (int)p.forced[(long)img * p.ld_forced + t] : bi; p.ids[(long)img * p.steps + t] = bi; }
           }
           }
           LDS_BARRIER();
@@ -923,11 +923,38 @@ size_t decode_pipe_scratch_bytes(const DecodeP& p) {
   const size_t nedges = (size_t)(p.nlayers + 1) + (size_t)p.nlayers * PE_PER_LAYER;
   return 256 /*err*/ + 256 * sizeof(PipeRole) + nedges * p.B * 256 * 8;
 }
+static const char* g_pipe_reason = "";
+static char g_pipe_disabled[160] = "";   // sticky: set after a give-up (decode_pipe_disable)
+const char* decode_pipe_reason() { return g_pipe_reason; }
+void decode_pipe_disable(const char* why) {
+  snprintf(g_pipe_disabled, sizeof(g_pipe_disabled), "disabled after a give-up: %s", why ? why : "");
+  fprintf(stderr, "[satrn] pipelined decoder %s -- later decodes in this process use the one-workgroup-per-image kernel\n", g_pipe_disabled);
+}
+// Compute units the role workgroups may count on: the pipeline's roles poll each other, so ALL of them must be resident at once --
+// one per compute unit (each declares ~130-160 KB of LDS).  The count comes from the device, minus a margin for whatever else holds
+// a CU (another stream's kernel, a reserved / masked CU).
+static int pipe_cu_budget() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cus = n;
+  }
+  const int margin = getenv("SATRN_PIPE_CU_MARGIN") ? atoi(getenv("SATRN_PIPE_CU_MARGIN")) : 6;
+  return cus - margin;
+}
 int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_bytes, hipStream_t s) {
   const bool off = getenv("SATRN_DECODE_NO_PIPE") != nullptr;  // read per call: tests switch between the two decoders in one process
-  if (off || dt != DT_BF16 || d.D != 256 || d.F != 1024 || d.H * (d.D / d.H) != d.D || (d.D / d.H) % 8 || (d.H & 1) || d.V > 256 || d.B > (getenv("SATRN_PIPE_MAX_B") ? atoi(getenv("SATRN_PIPE_MAX_B")) : 112) /*larger batches: the per-image kernel (1 workgroup per image, no hand-offs) wins*/ || d.nlayers < 1 || d.nlayers > 4 ||
-      d.B < 1 || scratch_bytes < decode_pipe_scratch_bytes(d))
+  g_pipe_reason = "";
+  if (off) { g_pipe_reason = "SATRN_DECODE_NO_PIPE is set"; return -1; }
+  if (g_pipe_disabled[0]) { g_pipe_reason = g_pipe_disabled; return -1; }
+  const int max_b = getenv("SATRN_PIPE_MAX_B") ? atoi(getenv("SATRN_PIPE_MAX_B")) : 112;   // larger batches: the per-image kernel (1 workgroup per image, no hand-offs) wins
+  if (dt != DT_BF16 || d.D != 256 || d.F != 1024 || d.H * (d.D / d.H) != d.D || (d.D / d.H) % 8 || (d.H & 1) || d.V > 256 || d.B > max_b || d.nlayers < 1 || d.nlayers > 4 ||
+      d.B < 1 || scratch_bytes < decode_pipe_scratch_bytes(d)) {
+    g_pipe_reason = "shape outside the pipeline (bf16, D = 256, F = 1024, even heads, V <= 256, B <= SATRN_PIPE_MAX_B)";
     return -1;
+  }
+  const int cu_budget = pipe_cu_budget();
   typedef bf16_t T;
   std::vector<PipeRole> roles;
   auto add = [&](int type, int l, int sub, int i0, int i1, const void* w, int Ntot, int row0, int kp0, int N, int K, const float* bias, const float* lnw,
@@ -952,15 +979,18 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
   int SQ = knob("SATRN_PIPE_QKV_SHARDS", 4), SH = knob("SATRN_PIPE_HIST_SHARDS", 2), ST = knob("SATRN_PIPE_LN_SHARDS", 2), SG = knob("SATRN_PIPE_GEN_SHARDS", d.rules ? 6 : 4);
   {  // one workgroup per compute unit: scale the shard counts down until the role count fits the chip
     auto count = [&]() { return d.nlayers * (3 * SQ + 3 * SH + 2 * SA + 2 * ST + 2 * SX + PIPE_NFF * SM) + SG; };
-    while (count() > 250 && (SA > 1 || SX > 1 || SM > 1 || ST > 1 || SQ > 1 || SH > 1)) {
+    while (count() > cu_budget && (SA > 1 || SX > 1 || SM > 1 || ST > 1 || SQ > 1 || SH > 1)) {
       if (SA > 1) --SA;
-      if (SX > 1 && count() > 250) --SX;
-      if (SM > 1 && count() > 250) --SM;
-      if (ST > 1 && count() > 250) --ST;
-      if (SQ > 1 && count() > 250) --SQ;
-      if (SH > 1 && count() > 250) --SH;
+      if (SX > 1 && count() > cu_budget) --SX;
+      if (SM > 1 && count() > cu_budget) --SM;
+      if (ST > 1 && count() > cu_budget) --ST;
+      if (SQ > 1 && count() > cu_budget) --SQ;
+      if (SH > 1 && count() > cu_budget) --SH;
     }
   }
+  // the generator role keeps the DecodingManager memory of every image it serves in s_sift[128]
+  if (SG < 1) SG = 1;
+  if (d.rules && (B + std::min(SG, B) - 1) / std::min(SG, B) > 128) { g_pipe_reason = "more than 128 images per generator shard (DecodingManager memories)"; return -1; }
   auto sharded = [&](int n, int type, int l, int sub, const void* w, int Ntot, int row0, int kp0, int N, int K, const float* bias, const float* lnw,
                      const float* lnb) {
     // shard k of n serves images k, k + n, k + 2n, ... in increasing order.  (Contiguous ranges made every role wait for the
@@ -998,7 +1028,8 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
     sharded(SH, PR_L3, l, 0, nullptr, 0, 0, 0, 0, 0, w.b1, w.ln3w, w.ln3b);
   }
   sharded(SG, PR_GEN, 0, 0, d.wgen, d.V, 0, 0, d.V, D, d.bgen, nullptr, nullptr);
-  if (roles.size() > 250) return -1;  // one workgroup per compute unit, all resident (256 CUs)
+  // one workgroup per compute unit, all resident
+  if ((int)roles.size() > cu_budget) { g_pipe_reason = "more role workgroups than compute units on this device"; return -1; }
   PipeP p;
   memset(&p, 0, sizeof(p));
   for (int l = 0; l < d.nlayers; ++l) p.L[l] = d.L[l];
@@ -1034,9 +1065,17 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
   sh = std::max(sh, (size_t)D * D * sizeof(T) + 256 + fl_common * 4);
   sh = std::max(sh, (((size_t)d.V * D * sizeof(T) + 255) & ~(size_t)255) + fl_common * 4);
   const size_t lds_dyn_max = 160 * 1024 - 4096;   // the kernel's static LDS (flags, the generator's DecodingManager memories and rule table) is ~3.2 KB
-  if (sh > lds_dyn_max) return -1;
+  if (sh > lds_dyn_max) { g_pipe_reason = "role LDS image above 156 KB"; return -1; }
   static bool a = false;
   if (!a) { PIPE_CK(hipFuncSetAttribute((const void*)decode_pipe_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dyn_max)); a = true; }
+  {  // residency: the occupancy query must admit at least one workgroup of this LDS size per compute unit
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)decode_pipe_kernel<T>, PIPE_THREADS, sh) != hipSuccess || per_cu < 1) {
+      g_pipe_reason = "the occupancy query admits no role workgroup per compute unit";
+      return -1;
+    }
+  }
+  p.forced = d.forced; p.ld_forced = d.ld_forced;
   static const bool want_prof = getenv("SATRN_PIPE_PROF") != nullptr;  // debugging aid: per-role wait / total wall-clock ticks
   static long long* prof_buf = nullptr;
   if (want_prof) {

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(1024) void se_mlp_scale_kernel(const bf16_t* __rest
   // expand rows of this thread's channel of the group
   uint4 raw2[8];
   {
-    const int c = cbeg + tid < cend ? cbeg + tid : cbeg;
+    // (an empty trailing group -- C / 8 not a multiple of SE_G -- has cbeg >= C: clamp the row so that the unused load stays inside W2)
+    const int c = min(cbeg + tid < cend ? cbeg + tid : cbeg, C - 1);
 #pragma unroll
     for (int u = 0; u < 8; ++u) raw2[u] = ld16(W2 + (long)c * S + (u * CH < S ? u * CH : 0));
   }
@@ -578,7 +579,7 @@ bool launch_se_bwd_wide(int dt, const void* dy, const void* x, const void* gate,
   // channel groups: slabs of exactly 64 channels where C allows (every row of a slab is one aligned 128-byte line: 960 channels in 8
   // groups were 240-byte rows straddling three lines), else SEB_G groups
   const int G = SEB_G;   // 4 / 6 / 16 groups and 64-channel slabs (C / 64 groups) were measured: 25.6 / 20.2 / 33.4 / 32.9 us against 20.9
-  if (off || g_det.on || dt != DT_BF16 || S > 64 || (S % 8) != 0 || (C % 8) != 0 || ((C / 8 + G - 1) / G) > 32) return false;
+  if (off || g_det.on || dt != DT_BF16 || S > 64 || (S % 8) != 0 || (C % 8) != 0 || ((C / 8 + G - 1) / G) > 24 /*se_bwd_gate_ds_kernel stages 6 x 32 = 192 rows of W2 per group (wraw[6]): C <= 1536*/) return false;
   SeBnP bn;
   bn.bn_y = (bn_y && bn_P && bn_red) ? (const bf16_t*)bn_y : nullptr; bn.ss = bn_ss; bn.mr = bn_mr; bn.act = bn_act; bn.P = bn_P; bn.red = bn_red; bn.B = B;
   hipLaunchKernelGGL(se_bwd_gate_ds_kernel, dim3(B, G), dim3(SEB_NT), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gate, (const bf16_t*)W2, dz2, ds1_zeroed,

@@ -485,6 +485,17 @@ int satrn_model_greedy_rules(satrn_model* h, const float* img, const float* src,
   if (!rules) return fail(-1, "satrn_model_greedy_rules: rules is null");
   return mret(h, model_greedy(h->m, img, src, B, steps, probs, ids, 0, S(st), rules), "greedy_rules");
 }
+int satrn_model_greedy_forced(satrn_model* h, const float* img, const float* src, int B, int steps, const int64_t* forced_ids,
+                              float* logits, int64_t* ids, void* st) {
+  if (!forced_ids) return fail(-1, "satrn_model_greedy_forced: forced_ids is null");
+  return mret(h, model_greedy(h->m, img, src, B, steps, logits, ids, 0, S(st), nullptr, forced_ids), "greedy_forced");
+}
+int satrn_model_last_decode_path(satrn_model* h, int* giveups_out) {
+  if (!h || !h->m) return -1;
+  if (giveups_out) *giveups_out = h->m->pipe_giveups;
+  return h->m->last_decode_path;
+}
+const char* satrn_model_decode_note(satrn_model* h) { return (h && h->m) ? h->m->decode_note.c_str() : ""; }
 int satrn_model_beam_search(satrn_model* h, const float* img, int B, int beam_width, int max_sequence, int eos_id, int pad_id,
                             int64_t* sequences, void* st) {
   if (!img || !sequences || B <= 0) return fail(-1, "satrn_model_beam_search: bad argument");

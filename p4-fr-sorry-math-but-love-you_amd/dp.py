@@ -1,6 +1,8 @@
 """Data-parallel helpers (new: the reference has no multi-GPU path).  One process per GPU; the model is a full
 replica; gradients live in ONE flat fp32 buffer, so the exchange step is a single (optionally bucketed) all-reduce.
 Backend "nccl" is RCCL on ROCm; the same code runs over "gloo" on CPU tensors (used by the CPU tests)."""
+import random
+
 import torch
 import torch.distributed as dist
 
@@ -46,6 +48,72 @@ def shard_batch(n_items, rank, world):
     return s, min(n_items, s + per)
 
 
+def sync_bn_buffers(model, mode="broadcast", src=0, group=None):
+    """BatchNorm running statistics at checkpoint time.  Every rank normalises with its OWN batch statistics (what
+    N independent reference processes would compute: no SyncBN), so the running_mean / running_var buffers drift apart between
+    ranks while the parameters stay identical.  Before a state_dict is written they are made equal:
+      mode "broadcast": rank `src`'s buffers everywhere (a checkpoint equals what a 1-GPU run on rank src's shard would store);
+      mode "average":   running_mean / running_var averaged over the ranks (an unbiased estimate over the GLOBAL batch stream);
+                        every other buffer (num_batches_tracked, SwinTRN's index / mask tables) is broadcast.
+    Works on the model's flat buffers (one or two collectives, not one per BatchNorm)."""
+    if mode not in ("broadcast", "average"):
+        raise ValueError("mode must be 'broadcast' or 'average'")
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    f32, i64 = model._flat[1], model._flat[2]
+    if world == 1:
+        return model
+    if mode == "average":
+        mean = f32.clone()
+        dist.all_reduce(mean, group=group)
+        mean.mul_(1.0 / world)
+    dist.broadcast(f32, src, group=group)
+    dist.broadcast(i64, src, group=group)
+    if mode == "average":
+        for name, kind, shp, off, numel, node, leaf in model._entries:
+            if kind == 1 and leaf in ("running_mean", "running_var"):
+                f32[off: off + numel].copy_(mean[off: off + numel])
+    return model
+
+
+def state_dict(model, bn_mode="broadcast", src=0, group=None):
+    """model.state_dict() of a data-parallel replica: BatchNorm buffers synchronised first (sync_bn_buffers), so that every rank
+    would write the same checkpoint (the reference saves `model.state_dict()`, train_modules/train_single_opt.py:497-512)."""
+    sync_bn_buffers(model, bn_mode, src, group)
+    return model.state_dict()
+
+
+class SharedCoin:
+    """The teacher-forcing coin of networks/EfficientSATRN.py:489 (`random.random() < teacher_forcing_ratio`, one flip per batch)
+    for data-parallel ranks: every rank must take the SAME decoder branch in a step, or their gradient exchanges would pair a
+    teacher-forced backward with an autoregressive one.  All ranks build it with the same seed (the reference seeds Python's
+    `random` in set_seed, utils/utils.py:167-171) and flip it once per step."""
+
+    def __init__(self, seed=21):
+        self._rng = random.Random(int(seed))
+        self.flips = 0
+
+    def random(self):
+        self.flips += 1
+        return self._rng.random()
+
+    def teacher_forced(self, ratio):
+        return self.random() < ratio
+
+
+_exposed = None
+
+
+def last_exchange_exposed_ms():
+    """GPU time between the end of the last backward segment and the start of the optimizer of the most recent dp_train_step on
+    this rank = the part of the gradient exchange that was NOT hidden behind the backward (synchronises); None if the last step
+    had no exchange."""
+    if _exposed is None:
+        return None
+    a, b = _exposed
+    b.synchronize()
+    return a.elapsed_time(b)
+
+
 def dp_train_step(model, images, expected, lr, overlap=True, force_exchange=False, **kw):
     """One data-parallel step.  overlap=True (eager execution): the backward is cut after the last backbone stage; the all-reduce
     of everything finished by then (74 % of the flat gradient) is started asynchronously (RCCL on its own stream) and runs
@@ -71,9 +139,31 @@ def dp_train_step(model, images, expected, lr, overlap=True, force_exchange=Fals
         model.train_step(images, expected, lr, phase=16 + 3, **kw2)
         if cut > 0:
             works.append(dist.all_reduce(flat[:cut], async_op=True))
+        ev = _mark(flat)
         for w in works:
             w.wait()
     else:
         model.train_step(images, expected, lr, phase=1, **kw)
+        ev = _mark(model.flat_grad())
         allreduce_flat(model.flat_grad())
+    _mark_end(ev, model.flat_grad())
     model.train_step(images, expected, lr, phase=2, grad_scale=1.0 / world, **kw)
+
+
+def _mark(flat):
+    global _exposed
+    _exposed = None
+    if not flat.is_cuda:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()   # the backward's last segment has been issued on the current stream
+    return ev
+
+
+def _mark_end(ev, flat):
+    global _exposed
+    if ev is None:
+        return
+    end = torch.cuda.Event(enable_timing=True)
+    end.record()  # the current stream has been made to wait for every collective: the optimizer starts here
+    _exposed = (ev, end)

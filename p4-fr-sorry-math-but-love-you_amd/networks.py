@@ -171,6 +171,7 @@ class _SATRNBase(nn.Module):
         self._dstage = None
         self._side = None
         self._warm = set()
+        self._coin = None
         if checkpoint and checkpoint is not True:   # networks/SWIN.py:1025 has `checkpoint=True` as its default
             self.load_state_dict(checkpoint)
 
@@ -419,18 +420,21 @@ class _SATRNBase(nn.Module):
         """networks/EfficientSATRN.py:697-706: -> [B, L-1, V] (teacher-forced logits, or greedy-step logits)."""
         if is_train:
             # the reference's coin (Python `random`, :489): teacher forced, or autoregressive WITH gradients (:496-525)
-            tf = random.random() < teacher_forcing_ratio
+            # (data-parallel ranks share the coin: set_coin(dp.SharedCoin(seed)) -- every rank must take the same branch in a step)
+            tf = (self._coin if self._coin is not None else random).random() < teacher_forcing_ratio
             self._ensure_bound(input.device)
             return _TFFunction.apply(self, self._anchor, input, expected, torch.is_grad_enabled(), tf)
         return self.greedy(input, expected.size(1) - 1)[0]
 
     @torch.no_grad()
-    def greedy(self, input, num_steps, use_graph=False):
+    def greedy(self, input, num_steps, use_graph=False, forced=None):
         """networks/EfficientSATRN.py:528-561: -> (logits [B, steps, V], ids [B, steps]); with a decoding manager the
         first tensor holds the masked softmax probabilities instead (:553-554), the rules run inside the decode kernel.
         With use_graph the whole decode (encoder + every step) replays as one hipGraph from persistent staging buffers
         (measured SLOWER than eager launches on ROCm 7.2 for this ~10^4-node graph: 100 ms vs 80 ms per 64x231 batch, so
-        it is off by default); the first call of a shape always runs eagerly."""
+        it is off by default); the first call of a shape always runs eagerly.
+        forced (int64 [B, steps]): forced replay -- step t + 1 is fed forced[:, t] instead of its own argmax (the returned ids
+        stay the argmax); with a reference decode's ids every step's logits can be compared, not only a prefix."""
         input = self._img(input)
         B = input.size(0)
         self._prepare(input, B, num_steps + 1)
@@ -447,7 +451,16 @@ class _SATRNBase(nn.Module):
         self._side.wait_stream(cur)
         mgr = self.decoder.manager
         with torch.cuda.stream(self._side):
-            if mgr is not None:
+            if forced is not None:
+                if mgr is not None:
+                    raise SatrnError("forced replay runs without a decoding manager")
+                fids = forced.to(device=input.device, dtype=torch.int64).contiguous()
+                if tuple(fids.shape) != (B, num_steps):
+                    raise SatrnError(f"forced ids must be [B, steps] = [{B}, {num_steps}], got {tuple(fids.shape)}")
+                self._keep_forced = fids
+                check(self._lib.satrn_model_greedy_forced(self._h, ptr(simg), None, B, num_steps, ptr(fids), ptr(slog), ptr(sids),
+                                                          _stream()), "satrn_model_greedy_forced")
+            elif mgr is not None:
                 check(self._lib.satrn_model_greedy_rules(self._h, ptr(simg), None, B, num_steps, ptr(mgr.table(input.device)),
                                                          ptr(slog), ptr(sids), _stream()), "satrn_model_greedy_rules")
             else:
@@ -456,6 +469,20 @@ class _SATRNBase(nn.Module):
         cur.wait_stream(self._side)
         warm[0] = True
         return slog.clone(), sids.clone()
+
+    def set_coin(self, coin):
+        """source of the per-batch teacher-forcing coin (anything with .random() -> [0, 1)); None = Python's global `random`,
+        as the reference (networks/EfficientSATRN.py:489).  Data-parallel ranks pass dp.SharedCoin(seed)."""
+        self._coin = coin
+
+    def last_decode_path(self):
+        """-> (path, giveups, note): which kernel produced the last greedy result -- "pipe" (one persistent workgroup per decoder
+        role), "per_image" (one workgroup per image) or "stepwise"; giveups = pipelines that timed out and were re-run; note =
+        why the pipeline was not taken."""
+        g = ctypes.c_int(0)
+        path = self._lib.satrn_model_last_decode_path(self._h, ctypes.byref(g))
+        note = self._lib.satrn_model_decode_note(self._h)
+        return {0: "none", 1: "pipe", 2: "per_image", 3: "stepwise"}.get(path, "?"), g.value, (note.decode() if note else "")
 
     def _feat_tokens(self):
         c = self._cfg

@@ -107,3 +107,56 @@ def test_overlapped_exchange_reduces_every_segment_once_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+class _FakeBNModel:
+    """the two flat buffers + entry table dp.sync_bn_buffers works on (networks._SATRNBase has the same attributes)"""
+
+    def __init__(self, rank):
+        f32 = torch.zeros(12)
+        f32[0:4] = float(rank + 1)          # running_mean
+        f32[4:8] = 10.0 * (rank + 1)        # running_var
+        f32[8:12] = 7.0                     # a constant table (identical on all ranks)
+        i64 = torch.full((2,), 5 + rank, dtype=torch.int64)
+        self._flat = [torch.zeros(1), f32, i64]
+        self._entries = [("bn.running_mean", 1, (4,), 0, 4, None, "running_mean"), ("bn.running_var", 1, (4,), 4, 4, None, "running_var"),
+                         ("tab", 1, (4,), 8, 4, None, "relative_position_index"), ("bn.num_batches_tracked", 2, (2,), 0, 2, None, "num_batches_tracked")]
+
+    def state_dict(self):
+        return {"f32": self._flat[1].clone(), "i64": self._flat[2].clone()}
+
+
+def _bn_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from satrn_amd import dp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a = _FakeBNModel(rank)
+    dp.sync_bn_buffers(a, "broadcast")
+    ok = bool((a._flat[1][0:4] == 1.0).all()) and bool((a._flat[1][4:8] == 10.0).all()) and bool((a._flat[2] == 5).all())
+    b = _FakeBNModel(rank)
+    sdict = dp.state_dict(b, bn_mode="average")
+    ok = ok and bool((sdict["f32"][0:4] == 1.5).all()) and bool((sdict["f32"][4:8] == 15.0).all()) and bool((sdict["f32"][8:12] == 7.0).all())
+    ok = ok and bool((sdict["i64"] == 5).all())
+    # the shared teacher-forcing coin: the same branch on every rank, step after step, and a fair coin at the ratio
+    coin = dp.SharedCoin(seed=1234)
+    flips = torch.tensor([1.0 if coin.teacher_forced(0.55) else 0.0 for _ in range(200)])
+    both = [torch.zeros_like(flips) for _ in range(world)]
+    dist.all_gather(both, flips)
+    ok = ok and all(torch.equal(both[0], f) for f in both) and 0.4 < flips.mean().item() < 0.7 and coin.flips == 200
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_bn_buffer_sync_and_shared_coin_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -668,7 +668,11 @@ def test_dropout_statistics(lib):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,HW,C,S,wide", [(3, 48, 1536, 64, False), (3, 48, 1536, 64, True), (2, 192, 960, 40, True), (4, 192, 512, 32, True),
-                                            (2, 35, 96, 8, False), (2, 192, 256, 16, True)])
+                                            (2, 35, 96, 8, False), (2, 192, 256, 16, True),
+                                            # beyond the wide kernels' staging (C > 1536: 6 x 32 W2 rows per channel group): must take the per-image form
+                                            (2, 48, 1792, 64, True), (2, 48, 2048, 64, True),
+                                            # C / 8 not a multiple of the 8 channel groups: the trailing group is empty / partial
+                                            (2, 96, 160, 8, True), (2, 48, 1288, 56, True)])
 def test_squeeze_excite(lib, dt, B, HW, C, S, wide):
     """timm SqueezeExcite (networks/EfficientSATRN.py:74,84): forward and the data path of the backward, in the per-image form
     and (wide=True) in the forms the training step uses -- MLP + scale from pool sums over B x 8 channel groups, backward as
