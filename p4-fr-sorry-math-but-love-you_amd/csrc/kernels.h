@@ -56,6 +56,8 @@ struct GemmP {
 struct BnEvalDesc { const float* w; const float* b; const float* rm; const float* rv; float* out; float eps; int C; };
 void launch_bn_eval_prepare(const BnEvalDesc* descs_dev, int n, hipStream_t s);
 void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s);
+// large dense bf16 products on the persistent 8-wave direct-to-LDS kernel (kernels_gemm_big.hip); false = shape / epilogue not taken
+bool gemm_big_launch(const GemmP& p, hipStream_t s);
 
 // dW[n][k] (+)= sum_m dY[m][n] * gatherA[m][k]
 struct WgradP {

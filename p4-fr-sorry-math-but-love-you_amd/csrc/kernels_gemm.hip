@@ -707,6 +707,7 @@ void launch_gemm(int dt, int amode, const GemmP& p0, hipStream_t s) {
   if (p.stats) p.stats_part = det_scratch(s, (size_t)(nslots + 4) * 2 * p.N);  // null unless the deterministic mode is on
   if (!p.stats_part && dt == DT_BF16 && amode != AM_DENSE && conv_halo_launch(amode, p, s)) return;
   if (amode == AM_DENSE && (dt == DT_BF16 ? gemm_skinny_launch<bf16_t>(p, s) : gemm_skinny_launch<float>(p, s))) return;
+  if (amode == AM_DENSE && dt == DT_BF16 && gemm_big_launch(p, s)) return;   // large products: persistent 8-wave direct-to-LDS kernel (kernels_gemm_big.hip)
   if (dt == DT_BF16) {
     if (amode == AM_DENSE) launch_gemm_t<bf16_t, AM_DENSE>(p, s);
     else if (amode == AM_CONV) launch_gemm_t<bf16_t, AM_CONV>(p, s);
