@@ -39,36 +39,13 @@ struct BigP {
   float bact_scale;
   int ntm, ntn, ntiles;
   unsigned a_bytes, w_bytes, c_bytes;   // buffer extents for the range check
+  int dbg;   // timing experiments (SATRN_BIG_DBG; wrong results): 1 no epilogue, 2 no DMA waits, 4 no MFMA, 8 no fragment reads
 };
 
 #define BIG_THREADS 512
 #define BIG_BK 64
 #define BIG_ROWB 128            // bytes per LDS row (64 bf16)
 #define BIG_NSTAGE 3
-
-// counted wait on the vector-memory queue: N must be a compile-time immediate, the number of younger operations that may stay in flight
-// is only known at run time (tile boundaries put stores and bias loads into the queue): dispatch over the even values
-DEVI void vm_wait_n(int n) {
-  n = n > 30 ? 30 : n;
-  switch (n >> 1) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-    case 13: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
-    case 14: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
-  }
-}
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -101,23 +78,29 @@ DEVI i32x4 make_rsrc(const void* base, unsigned bytes) {
   return r;
 }
 
-// MT: 16-row MFMA tiles per wave along M (block tile BM = 64 * MT rows); the block tile is 128 columns wide (2 waves x 4 MFMA tiles)
-template <int MT, bool HAS_BIAS, bool HAS_AUX /*pre_out / bact_u / beta*/>
+// MTW: 16-row MFMA tiles per CONSUMER wave along M.  Block tile = (32 * MTW) rows x 128 columns: consumer waves 0..3 form a 2 x 2 grid
+// of (16 * MTW) x 64 wave tiles; waves 4..7 are LOADERS and only issue the LDS-DMA stream.
+//
+// Why two roles (measured on the first, symmetric version of this kernel, tools/gemm_big_dbg.py, 4096^3): the DMA stream alone ran
+// in 88 us (70 GB/s per CU: the per-CU fill path), the MFMAs alone in ~55 us, and the kernel took their SUM, 155 us -- a wave whose
+// next instruction is an LDS-DMA waits at the issue stage while the memory pipeline's queue is full, and the MFMAs behind it in
+// program order wait with it.  A loader wave may sit there as long as it likes; the consumer waves never issue a DMA.
+// Synchronisation: ONE s_barrier per k-step, joined by all eight waves.  A loader arrives when its pieces of stage t + 1 have
+// landed (counted vmcnt), a consumer when its last fragment read of stage t has returned; behind the barrier the loaders refill
+// the slot of stage t with stage t + 3 and the consumers start reading stage t + 1.
+template <int MTW, bool HAS_BIAS, bool HAS_AUX /*pre_out / bact_u / beta*/>
 __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
-  constexpr int NT = 4;
-  constexpr int BM = 64 * MT, BN = 128;
-  constexpr int TM = 16 * MT;                                     // rows per wave
+  constexpr int NT = 4, HM = MTW / 2;
+  constexpr int BM = 32 * MTW, BN = 128;
+  constexpr int TM = 16 * MTW;                                    // rows per consumer wave
   constexpr int STAGE = (BM + BN) * BIG_ROWB;                     // bytes per ring slot
-  constexpr int EPI = BIG_NSTAGE * STAGE;                         // epilogue scratch: 8 waves x 2 KB
-  constexpr int NA = MT, NB = 2;                                  // DMA instructions per wave and stage (8 rows each)
-  constexpr int NDMA = NA + NB;
+  constexpr int EPI = BIG_NSTAGE * STAGE;                         // epilogue scratch: 4 consumer waves x 2 KB
+  constexpr int NA = MTW, NB = 4;                                 // DMA instructions per LOADER wave and stage (8 rows each)
   extern __shared__ __attribute__((aligned(16))) unsigned char big_sm[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)big_sm;   // LDS byte address of the ring
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 15, fq = lane >> 4;
   const int KT = p.K / BIG_BK;
 
   // ---- this workgroup's tiles: logical id L (XCD-contiguous) + i * gridDim; tiles ordered n fastest, so the 32 workgroups of an
@@ -128,55 +111,87 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
   const int T = my_tiles * KT;     // k-steps of this workgroup's stream
   if (T == 0) return;
 
-  const i32x4 rA = make_rsrc(p.A, p.a_bytes), rW = make_rsrc(p.W, p.w_bytes);
-  // outputs / epilogue operands through buffer descriptors too: a lane outside the matrix gets an out-of-range offset and the
-  // access is dropped by the range check, so EVERY lane issues EVERY epilogue access and the wave's operation count is exact
+  if (wave >= 4) {
+    // =============================== loader waves ===============================
+    const int lw = wave - 4;
+    const i32x4 rA = make_rsrc(p.A, p.a_bytes), rW = make_rsrc(p.W, p.w_bytes);
+    // lane -> (row within the 8-row piece, chunk slot); source chunk = slot ^ swizzle(row); piece i = lw + 4 j covers rows 8 i .. 8 i + 7
+    const int drow = lane >> 3;
+    const int dsw = ((lane >> 4) | ((lw & 1) << 2));                 // ((8 i + drow) >> 1) & 7
+    const unsigned dchunk = (unsigned)(((lane & 7) ^ dsw) * 16);
+    const unsigned lda2 = (unsigned)p.lda * 2u, ldw2 = (unsigned)p.K * 2u;
+    int d_tile = 0, d_k = 0;                 // position of the NEXT stage to request
+    unsigned voffA = 0, voffW = 0;
+    auto dma_tile_setup = [&](int ti) {
+      const int tile = L + ti * nwg;
+      const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+      voffA = (unsigned)(tm * BM + 8 * lw + drow) * lda2 + dchunk;
+      voffW = (unsigned)(tn * BN + 8 * lw + drow) * ldw2 + dchunk;
+    };
+    auto dma_issue = [&](int slot) {
+      const unsigned sbase = lds0 + (unsigned)slot * STAGE;
+      const int soff = d_k * (BIG_BK * 2);
+#pragma unroll
+      for (int j = 0; j < NA; ++j) dma16(rA, sbase + (unsigned)(lw + 4 * j) * 1024u, voffA + (unsigned)j * 32u * lda2, soff);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) dma16(rW, sbase + (unsigned)BM * BIG_ROWB + (unsigned)(lw + 4 * j) * 1024u, voffW + (unsigned)j * 32u * ldw2, soff);
+      if (++d_k == KT) { d_k = 0; ++d_tile; if (d_tile < my_tiles) dma_tile_setup(d_tile); }
+    };
+    dma_tile_setup(0);
+    dma_issue(0);
+    if (1 < T) dma_issue(1);
+    if (2 < T) dma_issue(2);
+    // stage 0 landed: all but the stages requested after it
+    if (T >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory");
+    else if (T == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int slot = 0;
+    for (int t = 0; t < T; ++t) {
+      // stage t + 1 landed (stage t + 2 may stay in flight)
+      if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + BIG_NSTAGE < T) dma_issue(slot);
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    return;
+  }
+
+  // =============================== consumer waves ===============================
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  // outputs / epilogue operands through buffer descriptors: a lane outside the matrix gets an out-of-range offset and the access is
+  // dropped by the range check (no divergent branch around the stores)
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)p.c_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre_out, 0, p.pre_out ? (int)p.c_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)p.bact_u, 0, p.bact_u ? (int)p.c_bytes : 0, 0x00020000);
 
-  // ---- DMA side: lane -> (row within the 8-row piece, chunk slot); source chunk = slot ^ swizzle(row)
-  const int drow = lane >> 3;                                                        // 0..7
-  const int dsw = ((lane >> 4) | ((wave & 1) << 2));                                 // ((8 * i + drow) >> 1) & 7 with i = wave + 8 j
-  const unsigned dchunk = (unsigned)(((lane & 7) ^ dsw) * 16);
-  const unsigned lda2 = (unsigned)p.lda * 2u, ldw2 = (unsigned)p.K * 2u;
-  int d_tile = 0, d_k = 0;                 // position of the NEXT stage to request
-  unsigned voffA = 0, voffW = 0;
-  auto dma_tile_setup = [&](int ti) {
-    const int tile = L + ti * nwg;
-    const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
-    voffA = (unsigned)(tm * BM + 8 * wave + drow) * lda2 + dchunk;
-    voffW = (unsigned)(tn * BN + 8 * wave + drow) * ldw2 + dchunk;
-  };
-  auto dma_issue = [&](int slot) {
-    const unsigned sbase = lds0 + (unsigned)slot * STAGE;
-    const int soff = d_k * (BIG_BK * 2);
-#pragma unroll
-    for (int j = 0; j < NA; ++j) dma16(rA, sbase + (unsigned)(wave + 8 * j) * 1024u, voffA + (unsigned)j * 64u * lda2, soff);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) dma16(rW, sbase + (unsigned)BM * BIG_ROWB + (unsigned)(wave + 8 * j) * 1024u, voffW + (unsigned)j * 64u * ldw2, soff);
-    if (++d_k == KT) { d_k = 0; ++d_tile; if (d_tile < my_tiles) dma_tile_setup(d_tile); }
-  };
-
-  // ---- fragment side
   const unsigned fsw0 = (unsigned)(((0 * 4 + fq) ^ ((fr >> 1) & 7)) * 16), fsw1 = (unsigned)(((1 * 4 + fq) ^ ((fr >> 1) & 7)) * 16);
   const unsigned fA = (unsigned)(wm * TM + fr) * BIG_ROWB;
   const unsigned fB = (unsigned)BM * BIG_ROWB + (unsigned)(wn * 64 + fr) * BIG_ROWB;
-  uint4 a0[MT], b0[NT], a1[MT], b1[NT];
-  auto read_half = [&](int slot, unsigned fsw, uint4* af, uint4* bf) {
-    const unsigned sbase = lds0 + (unsigned)slot * STAGE + fsw;
+  // fragments: two ping-pong sets of HM A fragments (one MFMA group = HM x 4 tiles of one 32-deep half), B fragments of both halves
+  uint4 aX[HM], aY[HM], bK0[NT], bK1[NT];
+  auto read_a = [&](int slot, unsigned fsw, int half, uint4* af) {
+    if (p.dbg & 8) return;
+    const unsigned sbase = lds0 + (unsigned)slot * STAGE + fsw + fA + (unsigned)(half * HM) * 16u * BIG_ROWB;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) af[i] = lds_read16(sbase + fA + (unsigned)i * 16u * BIG_ROWB);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bf[j] = lds_read16(sbase + fB + (unsigned)j * 16u * BIG_ROWB);
+    for (int i = 0; i < HM; ++i) af[i] = lds_read16(sbase + (unsigned)i * 16u * BIG_ROWB);
   };
-  f32x4 acc[MT][NT];
-  auto mma_half = [&](const uint4* af, const uint4* bf) {
+  auto read_b = [&](int slot, unsigned fsw, uint4* bf) {
+    if (p.dbg & 8) return;
+    const unsigned sbase = lds0 + (unsigned)slot * STAGE + fsw + fB;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int j = 0; j < NT; ++j) bf[j] = lds_read16(sbase + (unsigned)j * 16u * BIG_ROWB);
+  };
+  f32x4 acc[MTW][NT];
+  auto mma_group = [&](int half, const uint4* af, const uint4* bf) {
+    if (p.dbg & 4) return;
+#pragma unroll
+    for (int i = 0; i < HM; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+        acc[half * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[j]), __builtin_bit_cast(bf16x8, af[i]), acc[half * HM + i][j], 0, 0, 0);
   };
 
   // ---- bias of a tile in accumulator layout: lane holds columns nt * 16 + fq * 4 + r of its wave's 64
@@ -188,24 +203,17 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = nb + j * 16;
-      // (rows of bias past N: clamp, the columns are never stored)
-      const float* src = p.bias + (n + 3 < p.N ? n : 0);
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias_r[j]) : "v"(src) : "memory");
+      bias_r[j] = *reinterpret_cast<const f32x4*>(p.bias + (n + 3 < p.N ? n : 0));   // (columns past N are never stored)
     }
-  };
-  // after the counted wait: makes every later use of the asm-loaded registers depend on a statement behind that wait
-  auto bias_tie = [&]() {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(bias_r[j]));
   };
   auto acc_init = [&]() {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = HAS_BIAS ? bias_r[j] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  // ---- epilogue of one finished tile
+  // ---- epilogue of one finished tile: 16 rows x 64 columns per pass through this wave's 2 KB of LDS (XOR-swizzled 128-byte rows)
   const unsigned eW = lds0 + EPI + (unsigned)wave * 2048u;
   const int e_row = lane >> 3, e_chunk = (lane & 7) ^ ((lane >> 3) & 7);
   auto epilogue = [&](int ti) {
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
     const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
     const int col = tn * BN + wn * 64 + e_chunk * 8;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < MTW; ++i) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const uint2 w2 = make_uint2(pack2bf(acc[i][j][0], acc[i][j][1]), pack2bf(acc[i][j][2], acc[i][j][3]));
@@ -253,58 +261,40 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
       }
     }
   };
-  // vector-memory operations a wave issues per epilogue (stores; the aux forms add loads the compiler waits for itself)
-  const int n_epi_ops = 2 * MT * (1 + ((HAS_AUX && p.pre_out) ? 1 : 0) + ((HAS_AUX && p.bact_u) ? 1 : 0) + ((HAS_AUX && p.beta) ? 1 : 0));
 
-  // ---- prologue: stages 0, 1, 2 requested; bias of tile 0
-  int issued = 0;                    // vector-memory operations issued by this wave so far (the queue retires in order)
-  // `issued` right after the DMA of the stage that is needed next (mk1: stage t + 1), the one after (mk2: t + 2), and of the
-  // newest request (mk3); scalar variables, rotated (a runtime-indexed array would live in scratch memory)
-  int mk0, mk1, mk2, mk3 = 0, mark_bias = 0;
-  dma_tile_setup(0);
-  if (HAS_BIAS) { bias_load(0); issued += NT; mark_bias = issued; }
-  if (0 < T) { dma_issue(0); issued += NDMA; }
-  mk0 = issued;
-  if (1 < T) { dma_issue(1); issued += NDMA; }
-  mk1 = issued;
-  if (2 < T) { dma_issue(2); issued += NDMA; }
-  mk2 = issued;
-  if (HAS_BIAS) { vm_wait_n(issued - mark_bias); bias_tie(); }
+  if (HAS_BIAS) bias_load(0);
   acc_init();
-  vm_wait_n(issued - mk0);
-  __builtin_amdgcn_s_barrier();
-  read_half(0, fsw0, a0, b0);
-
-  int c_tile = 0, c_k = 0;
-  // stage index modulo 3 without a division
-  int slot = 0;
+  __builtin_amdgcn_s_barrier();      // stage 0 has landed
+  read_a(0, fsw0, 0, aX);
+  read_b(0, fsw0, bK0);
+  int c_tile = 0, c_k = 0, slot = 0;
   for (int t = 0; t < T; ++t) {
     const int slot1 = slot == 2 ? 0 : slot + 1;
     const bool last_k = c_k == KT - 1;
-    // bias of the next tile, requested a whole k-step before it is needed
-    if (HAS_BIAS && last_k && c_tile + 1 < my_tiles) { bias_load(c_tile + 1); issued += NT; mark_bias = issued; }
-    read_half(slot, fsw1, a1, b1);
+    read_a(slot, fsw0, 1, aY);
+    read_b(slot, fsw1, bK1);
     __builtin_amdgcn_s_setprio(1);
-    mma_half(a0, b0);
+    mma_group(0, aX, bK0);
     __builtin_amdgcn_s_setprio(0);
-    // stage t + 1 has landed (this wave's pieces), every wave is past its reads of stage t: the slot of stage t is free
-    if (t + 1 < T) vm_wait_n(issued - mk1);
+    read_a(slot, fsw1, 0, aX);
+    __builtin_amdgcn_s_setprio(1);
+    mma_group(1, aY, bK0);
+    __builtin_amdgcn_s_setprio(0);
+    read_a(slot, fsw1, 1, aY);
+    __builtin_amdgcn_s_setprio(1);
+    mma_group(0, aX, bK1);
+    __builtin_amdgcn_s_setprio(0);
+    // every fragment of stage t is in registers: its slot may be refilled; stage t + 1 is complete once every loader has arrived
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + BIG_NSTAGE < T) { dma_issue(slot); issued += NDMA; }
-    mk3 = issued;
-    mk1 = mk2; mk2 = mk3;
-    if (t + 1 < T) read_half(slot1, fsw0, a0, b0);
+    if (t + 1 < T) { read_a(slot1, fsw0, 0, aX); read_b(slot1, fsw0, bK0); }
     __builtin_amdgcn_s_setprio(1);
-    mma_half(a1, b1);
+    mma_group(1, aY, bK1);
     __builtin_amdgcn_s_setprio(0);
     if (last_k) {
-      epilogue(c_tile);
-      issued += n_epi_ops;
-      if (c_tile + 1 < my_tiles) {
-        if (HAS_BIAS) { vm_wait_n(issued - mark_bias); bias_tie(); }
-        acc_init();
-      }
+      if (HAS_BIAS && c_tile + 1 < my_tiles) bias_load(c_tile + 1);   // in flight during the epilogue
+      if (!(p.dbg & 1)) epilogue(c_tile);
+      if (c_tile + 1 < my_tiles) acc_init();
       c_k = 0; ++c_tile;
     } else {
       ++c_k;
@@ -322,14 +312,15 @@ static int big_cu_count() {
   return cus;
 }
 
-template <int MT>
+template <int MT /*block tile = 64 * MT rows*/>
 static void big_launch_t(const BigP& p, int grid, hipStream_t s) {
-  constexpr size_t sh = (size_t)BIG_NSTAGE * (64 * MT + 128) * BIG_ROWB + 8 * 2048;
+  constexpr int MTW = 2 * MT;
+  constexpr size_t sh = (size_t)BIG_NSTAGE * (64 * MT + 128) * BIG_ROWB + 4 * 2048;
   const bool aux = p.pre_out || p.bact_u || p.beta;
 #define BIG_GO(HB, HA) do { \
     static bool attr = false; \
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_big_kernel<MT, HB, HA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
-    hipLaunchKernelGGL((gemm_big_kernel<MT, HB, HA>), dim3(grid), dim3(BIG_THREADS), sh, s, p); } while (0)
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_big_kernel<MTW, HB, HA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
+    hipLaunchKernelGGL((gemm_big_kernel<MTW, HB, HA>), dim3(grid), dim3(BIG_THREADS), sh, s, p); } while (0)
   if (p.bias) { if (aux) BIG_GO(true, true); else BIG_GO(true, false); }
   else { if (aux) BIG_GO(false, true); else BIG_GO(false, false); }
 #undef BIG_GO
@@ -353,6 +344,7 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
   p.w_bytes = (unsigned)((size_t)g.N * g.K * 2);
   p.c_bytes = (unsigned)(((size_t)(g.M - 1) * g.ldc + g.N) * 2);
   p.ntn = (g.N + 127) / 128;
+  p.dbg = getenv("SATRN_BIG_DBG") ? atoi(getenv("SATRN_BIG_DBG")) : 0;
   const int cus = big_cu_count();
   // tile height: the candidate whose tile count leaves the smallest idle share in the last round of the persistent grid
   const int force_mt = getenv("SATRN_GEMM_BIG_MT") ? atoi(getenv("SATRN_GEMM_BIG_MT")) : 0;
