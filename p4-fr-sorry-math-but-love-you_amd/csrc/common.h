@@ -78,6 +78,26 @@ DEVI float act_bwd(float u, int act) {
   return 1.f;
 }
 
+// ---- exact-erf GELU at VALU cost ~1/3 of erff(): erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32 rounding noise),
+// one v_rcp + one v_exp per element.  Used where the result is rounded to bf16 anyway (the epilogue of the persistent GEMM runs on four
+// consumer waves per CU: erff() there cost more than the product itself).  GELU'(u) = Phi(u) + u phi(u) shares the exponential.
+DEVI float gelu_core(float u, float* phi_out) {   // returns Phi(u) = 0.5 (1 + erf(u / sqrt 2)); *phi_out = exp(-u^2 / 2)
+  const float z = fabsf(u) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  poly = __builtin_fmaf(poly, t, 1.421413741f);
+  poly = __builtin_fmaf(poly, t, -0.284496736f);
+  poly = __builtin_fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * z * z);   // exp(-z^2) = exp(-u^2 / 2)
+  const float erf_abs = __builtin_fmaf(-poly, e, 1.0f);                    // erf(|u| / sqrt 2)
+  *phi_out = e;
+  const float half_erf = 0.5f * erf_abs;
+  return u >= 0.f ? 0.5f + half_erf : 0.5f - half_erf;
+}
+DEVI float gelu_fast(float u) { float e; return u * gelu_core(u, &e); }
+DEVI float gelu_grad_fast(float u) { float e; const float P = gelu_core(u, &e); return __builtin_fmaf(u * 0.3989422804014327f, e, P); }
+
 // ---- counter-based dropout: keep-scale for element `idx` of dropout site `site` ------------
 // seed lives in device memory so a captured hipGraph sees a fresh value every replay.
 DEVI uint32_t mix32(uint32_t x) {

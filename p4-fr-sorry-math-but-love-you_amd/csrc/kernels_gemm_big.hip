@@ -94,7 +94,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
   constexpr int BM = 32 * MTW, BN = 128;
   constexpr int TM = 16 * MTW;                                    // rows per consumer wave
   constexpr int STAGE = (BM + BN) * BIG_ROWB;                     // bytes per ring slot
-  constexpr int EPI = BIG_NSTAGE * STAGE;                         // epilogue scratch: 4 consumer waves x 2 KB
+  constexpr int EPI = BIG_NSTAGE * STAGE;                         // epilogue scratch: 4 consumer waves x 2 x 2 KB
   constexpr int NA = MTW, NB = 4;                                 // DMA instructions per LOADER wave and stage (8 rows each)
   extern __shared__ __attribute__((aligned(16))) unsigned char big_sm[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)big_sm;   // LDS byte address of the ring
@@ -214,7 +214,8 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
   };
 
   // ---- epilogue of one finished tile: 16 rows x 64 columns per pass through this wave's 2 KB of LDS (XOR-swizzled 128-byte rows)
-  const unsigned eW = lds0 + EPI + (unsigned)wave * 2048u;
+  // (two 2 KB buffers per consumer wave, alternated per pass: the writes of pass i + 1 do not wait for the reads of pass i)
+  const unsigned eW0 = lds0 + EPI + (unsigned)wave * 4096u;
   const int e_row = lane >> 3, e_chunk = (lane & 7) ^ ((lane >> 3) & 7);
   auto epilogue = [&](int ti) {
     const int tile = L + ti * nwg;
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
     const int col = tn * BN + wn * 64 + e_chunk * 8;
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
+      const unsigned eW = eW0 + (unsigned)(i & 1) * 2048u;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const uint2 w2 = make_uint2(pack2bf(acc[i][j][0], acc[i][j][1]), pack2bf(acc[i][j][2], acc[i][j][3]));
@@ -238,7 +240,10 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
           float f[8];
           unpack<bf16_t>(v, f);
           if (HAS_AUX && p.pre_out) __builtin_amdgcn_raw_buffer_store_b128(to_u32x4(v), rP, (int)o, 0, 0);
-          if (p.act != ACT_NONE) {
+          if (p.act == ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = gelu_fast(f[e]);
+          } else if (p.act != ACT_NONE) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = act_fwd(f[e], p.act);
           }
@@ -246,8 +251,13 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
             float u[8];
             unpack<bf16_t>(from_u32x4(__builtin_amdgcn_raw_buffer_load_b128(rU, (int)o, 0, 0)), u);
             const float sc = p.bact_scale != 0.f ? p.bact_scale : 1.f;
+            if (p.bact == ACT_GELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] *= act_bwd(u[e], p.bact) * sc;
+              for (int e = 0; e < 8; ++e) f[e] *= gelu_grad_fast(u[e]) * sc;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] *= act_bwd(u[e], p.bact) * sc;
+            }
           }
           if (HAS_AUX && p.beta) {
             float c0[8];
@@ -315,7 +325,7 @@ static int big_cu_count() {
 template <int MT /*block tile = 64 * MT rows*/>
 static void big_launch_t(const BigP& p, int grid, hipStream_t s) {
   constexpr int MTW = 2 * MT;
-  constexpr size_t sh = (size_t)BIG_NSTAGE * (64 * MT + 128) * BIG_ROWB + 4 * 2048;
+  constexpr size_t sh = (size_t)BIG_NSTAGE * (64 * MT + 128) * BIG_ROWB + 4 * 4096;
   const bool aux = p.pre_out || p.bact_u || p.beta;
 #define BIG_GO(HB, HA) do { \
     static bool attr = false; \

@@ -64,5 +64,11 @@ if __name__ == "__main__":
                 us = bench(lambda: lib.satrn_linear_fwd(1, P(x), P(w), None, P(y), M, N, K, 0, 0, 0.0, None, 0, st()))
                 gb = (M * K + N * K + M * N) * 2 / us / 1e3
                 line += f"  [{'old' if mode == '0' else 'big'}] {us:8.1f} us {2.0*M*N*K/us/1e6:7.1f} TF {gb:6.0f} GB/s"
+            if (M, N, K) in ((9216, 2048, 512), (147456, 512, 128)):
+                b = torch.rand(N, device="cuda")
+                for mode in ("0", "2"):
+                    os.environ["SATRN_GEMM_BIG"] = mode
+                    us = bench(lambda: lib.satrn_linear_fwd(1, P(x), P(w), P(b), P(y), M, N, K, 4, 0, 0.0, None, 0, st()))
+                    line += f"  [{'old' if mode == '0' else 'big'} +bias+GELU] {us:8.1f} us"
             print(line, flush=True)
     sys.exit(0 if ok else 1)
