@@ -53,6 +53,15 @@ int satrn_pack_dwconv3x3(int dtype, const float* w, void* out, int C, void* stre
  * out_f32 != 0 writes fp32 (the logits).  seed: device uint32 (may be NULL when drop_p == 0). */
 int satrn_linear_fwd(int dtype, const void* x, const void* w_fwd, const float* bias, void* y, int M, int N, int K,
                      int act, int out_f32, float drop_p, const uint32_t* seed, uint32_t site, void* stream);
+/* The 1x1 convolution / linear product whose epilogue also feeds the BatchNorm beside it (no bias; timm's conv_pw / conv_pwl + bn of
+ * the EfficientNetV2 blocks, networks/EfficientSATRN.py:66,74,84, and the encoder's conv0 / norm0, conv1 / norm1, :243-252):
+ *   y[M][N] (+)= x[M][K] * Wfwd[N][K]^T, and stats[r][0][n] += sum_m v, stats[r][1][n] += sum_m v^2 over the rows of replica r
+ *   (stats: fp32 [stats_rep][2][N], ZERO on entry; the consumer adds the replicas) -- the batch statistics of the BatchNorm that follows;
+ * with bnb_y != NULL (y is then the GRADIENT wrt a BatchNorm's output z = act(bn(bnb_y)), bnb_y [M][N]): the two sums are that BatchNorm's
+ * backward reductions  sum g  and  sum g * xhat,  g = y_total * act'(bnb_y * scale + shift), xhat = (bnb_y - mean) * rstd, with
+ * bnb_ss = [scale | shift] and bnb_mr = [mean | rstd] (fp32 [2N] each, as written by satrn_batchnorm_act_fwd). */
+int satrn_linear_fwd_stats(int dtype, const void* x, const void* w_fwd, void* y, int M, int N, int K, float* stats, int stats_rep,
+                           const void* bnb_y, const float* bnb_ss, const float* bnb_mr, int bnb_act, int accumulate, void* stream);
 /* dx[M][K] (+)= dy[M][ldy(>=N)] * W  using Wbwd [K][ldb]; `accumulate` adds into dx. */
 int satrn_linear_bwd_data(int dtype, const void* dy, int ldy, const void* w_bwd, int ldb, void* dx, int M, int N,
                           int K, int accumulate, void* stream);

@@ -39,6 +39,10 @@ struct BigP {
   float bact_scale;
   int ntm, ntn, ntiles;
   unsigned a_bytes, w_bytes, c_bytes;   // buffer extents for the range check
+  // STATS 1: stats[(tile_m % stats_rep)][2][N] += per-column sum / sum of squares of the stored output (the BatchNorm that follows);
+  // STATS 2: the same slots receive the BatchNorm-backward sums [sum g, sum g * xhat], g = out * act'(y * scale + shift)  (GemmP::bnb_*)
+  float* stats; int stats_rep;
+  const bf16_t* bnb_y; const float* bnb_ss; const float* bnb_mr; int bnb_act; unsigned y_bytes;
   int dbg;   // timing experiments (SATRN_BIG_DBG; wrong results): 1 no epilogue, 2 no DMA waits, 4 no MFMA, 8 no fragment reads
 };
 
@@ -88,7 +92,7 @@ DEVI i32x4 make_rsrc(const void* base, unsigned bytes) {
 // Synchronisation: ONE s_barrier per k-step, joined by all eight waves.  A loader arrives when its pieces of stage t + 1 have
 // landed (counted vmcnt), a consumer when its last fragment read of stage t has returned; behind the barrier the loaders refill
 // the slot of stage t with stage t + 3 and the consumers start reading stage t + 1.
-template <int MTW, bool HAS_BIAS, bool HAS_AUX /*pre_out / bact_u / beta*/>
+template <int MTW, bool HAS_BIAS, bool HAS_AUX /*pre_out / bact_u / beta*/, int STATS = 0 /*1 BatchNorm statistics, 2 BatchNorm-backward sums*/>
 __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
   constexpr int NT = 4, HM = MTW / 2;
   constexpr int BM = 32 * MTW, BN = 128;
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int KT = p.K / BIG_BK;
+  const int KT = (p.K + BIG_BK - 1) / BIG_BK;   // K % 8 == 0; a partial last k-step is zero-filled (both operands) by the loaders
 
   // ---- this workgroup's tiles: logical id L (XCD-contiguous) + i * gridDim; tiles ordered n fastest, so the 32 workgroups of an
   // XCD share two row blocks of A and all of W in their L2
@@ -128,13 +132,16 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
       voffA = (unsigned)(tm * BM + 8 * lw + drow) * lda2 + dchunk;
       voffW = (unsigned)(tn * BN + 8 * lw + drow) * ldw2 + dchunk;
     };
+    // K tail: in the last k-step of a tile the lanes whose 16-byte chunk lies past K get an out-of-range offset (zero fill)
+    const bool tail_dead = (KT - 1) * BIG_BK + (int)(dchunk >> 1) >= p.K;
     auto dma_issue = [&](int slot) {
       const unsigned sbase = lds0 + (unsigned)slot * STAGE;
       const int soff = d_k * (BIG_BK * 2);
+      const bool dead = tail_dead && d_k == KT - 1;
 #pragma unroll
-      for (int j = 0; j < NA; ++j) dma16(rA, sbase + (unsigned)(lw + 4 * j) * 1024u, voffA + (unsigned)j * 32u * lda2, soff);
+      for (int j = 0; j < NA; ++j) dma16(rA, sbase + (unsigned)(lw + 4 * j) * 1024u, dead ? 0xfffffff0u : voffA + (unsigned)j * 32u * lda2, soff);
 #pragma unroll
-      for (int j = 0; j < NB; ++j) dma16(rW, sbase + (unsigned)BM * BIG_ROWB + (unsigned)(lw + 4 * j) * 1024u, voffW + (unsigned)j * 32u * ldw2, soff);
+      for (int j = 0; j < NB; ++j) dma16(rW, sbase + (unsigned)BM * BIG_ROWB + (unsigned)(lw + 4 * j) * 1024u, dead ? 0xfffffff0u : voffW + (unsigned)j * 32u * ldw2, soff);
       if (++d_k == KT) { d_k = 0; ++d_tile; if (d_tile < my_tiles) dma_tile_setup(d_tile); }
     };
     dma_tile_setup(0);
@@ -166,6 +173,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)p.c_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre_out, 0, p.pre_out ? (int)p.c_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)p.bact_u, 0, p.bact_u ? (int)p.c_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)p.bnb_y, 0, STATS == 2 ? (int)p.y_bytes : 0, 0x00020000);
 
   const unsigned fsw0 = (unsigned)(((0 * 4 + fq) ^ ((fr >> 1) & 7)) * 16), fsw1 = (unsigned)(((1 * 4 + fq) ^ ((fr >> 1) & 7)) * 16);
   const unsigned fA = (unsigned)(wm * TM + fr) * BIG_ROWB;
@@ -221,6 +229,21 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
     const int tile = L + ti * nwg;
     const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
     const int col = tn * BN + wn * 64 + e_chunk * 8;
+    // column sums of this lane's eight columns over the tile's rows (STATS): a lane keeps the same columns in every pass
+    float s1[8], s2[8], bsc[8], bsh[8], bmu[8], brs[8];
+    if (STATS) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    }
+    if (STATS == 2) {
+      const int cc = col + 7 < p.N ? col : 0;   // (columns past N contribute nothing: masked below)
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.bnb_ss + cc), t1 = *reinterpret_cast<const f32x4*>(p.bnb_ss + cc + 4);
+      const f32x4 t2 = *reinterpret_cast<const f32x4*>(p.bnb_ss + p.N + cc), t3 = *reinterpret_cast<const f32x4*>(p.bnb_ss + p.N + cc + 4);
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.bnb_mr + cc), t5 = *reinterpret_cast<const f32x4*>(p.bnb_mr + cc + 4);
+      const f32x4 t6 = *reinterpret_cast<const f32x4*>(p.bnb_mr + p.N + cc), t7 = *reinterpret_cast<const f32x4*>(p.bnb_mr + p.N + cc + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bsc[e] = t0[e]; bsc[4 + e] = t1[e]; bsh[e] = t2[e]; bsh[4 + e] = t3[e]; bmu[e] = t4[e]; bmu[4 + e] = t5[e]; brs[e] = t6[e]; brs[4 + e] = t7[e]; }
+    }
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
       const unsigned eW = eW0 + (unsigned)(i & 1) * 2048u;
@@ -236,7 +259,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
         uint4 v = lds_read16(eW + (unsigned)rl * 128u + (unsigned)(lane & 7) * 16u);
         const int row = tm * BM + wm * TM + i * 16 + rl;
         const unsigned o = (row < p.M && col < p.N) ? (unsigned)(((long)row * p.ldc + col) * 2) : 0xfffffff0u;   // out of range: dropped
-        if (HAS_AUX || p.act != ACT_NONE) {
+        if (HAS_AUX || STATS || p.act != ACT_NONE) {
           float f[8];
           unpack<bf16_t>(v, f);
           if (HAS_AUX && p.pre_out) __builtin_amdgcn_raw_buffer_store_b128(to_u32x4(v), rP, (int)o, 0, 0);
@@ -259,15 +282,55 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
               for (int e = 0; e < 8; ++e) f[e] *= act_bwd(u[e], p.bact) * sc;
             }
           }
+          if (STATS == 1 && o != 0xfffffff0u) {   // sums of the value this product contributes (before an accumulate), as gemm_kernel
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += f[e]; s2[e] = __builtin_fmaf(f[e], f[e], s2[e]); }
+          }
           if (HAS_AUX && p.beta) {
             float c0[8];
             unpack<bf16_t>(from_u32x4(__builtin_amdgcn_raw_buffer_load_b128(rC, (int)o, 0, 0)), c0);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] += c0[e];
           }
+          if (STATS == 2) {
+            // y of the BatchNorm whose output gradient this is ([M][N], row stride N); out-of-range lanes read zeros and are masked
+            const unsigned oy = (row < p.M && col < p.N) ? (unsigned)(((long)row * p.N + col) * 2) : 0xfffffff0u;
+            float yv[8];
+            unpack<bf16_t>(from_u32x4(__builtin_amdgcn_raw_buffer_load_b128(rY, (int)oy, 0, 0)), yv);
+            if (oy != 0xfffffff0u) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float g = f[e] * act_bwd(__builtin_fmaf(yv[e], bsc[e], bsh[e]), p.bnb_act);
+                s1[e] += g; s2[e] = __builtin_fmaf(g, (yv[e] - bmu[e]) * brs[e], s2[e]);
+              }
+            }
+          }
           v = pack<bf16_t>(f);
         }
         __builtin_amdgcn_raw_buffer_store_b128(to_u32x4(v), rC, (int)o, 0, 0);
+      }
+    }
+    if (STATS) {
+      // lanes r * 8 + (chunk ^ r), r = 0..7, hold the same eight columns: butterfly over r (lane ^ 9, ^ 18, ^ 36), then lanes 0..7
+      // (r = 0: chunk = lane) lay the 64 column sums out through the scratch so that lane c adds column c: two 256-byte atomic
+      // wave-instructions per tile and wave
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s1[e] += __shfl_xor(s1[e], 9, 64); s2[e] += __shfl_xor(s2[e], 9, 64);
+        s1[e] += __shfl_xor(s1[e], 18, 64); s2[e] += __shfl_xor(s2[e], 18, 64);
+        s1[e] += __shfl_xor(s1[e], 36, 64); s2[e] += __shfl_xor(s2[e], 36, 64);
+      }
+      __attribute__((address_space(3))) float* sc = (__attribute__((address_space(3))) float*)(lds_u8*)(size_t)eW0;   // [2][64]
+      if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[lane * 8 + e] = s1[e]; sc[64 + lane * 8 + e] = s2[e]; }
+      }
+      const float a1 = sc[lane], a2 = sc[64 + lane];   // (same wave: LDS operations execute in order)
+      const int c = tn * BN + wn * 64 + lane;
+      if (c < p.N) {
+        float* dst = p.stats + (size_t)(tm % p.stats_rep) * 2 * p.N + c;
+        atomicAdd(dst, a1);
+        atomicAdd(dst + p.N, a2);
       }
     }
   };
@@ -327,12 +390,15 @@ static void big_launch_t(const BigP& p, int grid, hipStream_t s) {
   constexpr int MTW = 2 * MT;
   constexpr size_t sh = (size_t)BIG_NSTAGE * (64 * MT + 128) * BIG_ROWB + 4 * 4096;
   const bool aux = p.pre_out || p.bact_u || p.beta;
-#define BIG_GO(HB, HA) do { \
+#define BIG_GO(HB, HA, ST) do { \
     static bool attr = false; \
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_big_kernel<MTW, HB, HA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
-    hipLaunchKernelGGL((gemm_big_kernel<MTW, HB, HA>), dim3(grid), dim3(BIG_THREADS), sh, s, p); } while (0)
-  if (p.bias) { if (aux) BIG_GO(true, true); else BIG_GO(true, false); }
-  else { if (aux) BIG_GO(false, true); else BIG_GO(false, false); }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_big_kernel<MTW, HB, HA, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
+    hipLaunchKernelGGL((gemm_big_kernel<MTW, HB, HA, ST>), dim3(grid), dim3(BIG_THREADS), sh, s, p); } while (0)
+  // the statistics forms keep 16 (sums) / 48 (+ BatchNorm coefficients) more registers: tiles of at most 192 / 128 rows
+  if constexpr (MT <= 2) { if (p.stats && p.bnb_y) { BIG_GO(false, true, 2); return; } }
+  if constexpr (MT <= 3) { if (p.stats && !p.bnb_y) { BIG_GO(false, true, 1); return; } }
+  if (p.bias) { if (aux) BIG_GO(true, true, 0); else BIG_GO(true, false, 0); }
+  else { if (aux) BIG_GO(false, true, 0); else BIG_GO(false, false, 0); }
 #undef BIG_GO
 }
 
@@ -341,11 +407,20 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
   const char* mode_env = getenv("SATRN_GEMM_BIG");   // read per call (tests and tools switch it): 0 = off, 2 = take every shape that fits
   const int mode = mode_env ? atoi(mode_env) : 1;
   if (!mode) return false;
-  if (g.stats || g.bnb_y || g.escale || g.eres || g.out_f32 || g.drop_p > 0.f) return false;
-  if ((g.K % BIG_BK) != 0 || (g.lda & 7) || (g.ldc & 7) || (g.N & 7) || g.M < 1) return false;
+  if (g.escale || g.eres || g.out_f32 || g.drop_p > 0.f) return false;
+  if (g.stats && (g.stats_part || g.bias || g.stats_rep < 1)) return false;   // deterministic slabs / biased statistics: gemm_kernel
+  if (g.bnb_y && !g.stats) return false;
+  if ((g.K & 7) || (g.lda & 7) || (g.ldc & 7) || (g.N & 7) || g.M < 1) return false;
   if ((size_t)g.M * g.lda * 2 >= (1ull << 31) || (size_t)g.N * g.K * 2 >= (1ull << 31) || (size_t)g.M * g.ldc * 2 >= (1ull << 31)) return false;   // 32-bit buffer offsets
-  const double flops = 2.0 * g.M * g.N * g.K;
-  if (mode != 2 && (flops < 2.0e9 || g.N < 128 || g.M < 2048)) return false;   // small products: the 4-wave tiles fill the chip better
+  {
+    // default mode: the large products only (SwinTRN's linears, M = 2 304 .. 147 456 with N >= 128).  Measured inside the EfficientSATRN
+    // step (tools/shape_prof.py, SATRN_GEMM_BIG_MIN_GFLOP=0.5 against the default): its 1x1 convolutions -- 0.5 .. 2 GFLOP each, inputs
+    // just written by another kernel, a weight-gradient kernel running beside them -- gain nothing from the persistent form (4.66 ->
+    // 4.91 ms over the family): a 160 KB workgroup needs a whole drained CU to start and leaves no room for the side stream
+    const double min_gflop = getenv("SATRN_GEMM_BIG_MIN_GFLOP") ? atof(getenv("SATRN_GEMM_BIG_MIN_GFLOP")) : 2.0;
+    const double flops = 2.0 * g.M * g.N * g.K;
+    if (mode != 2 && (flops < min_gflop * 1e9 || g.N < 128 || g.M < 2048)) return false;
+  }
   BigP p;
   p.A = (const bf16_t*)g.A; p.W = (const bf16_t*)g.Bw; p.C = (bf16_t*)g.C; p.bias = g.bias;
   p.pre_out = (bf16_t*)g.pre_out; p.bact_u = (const bf16_t*)g.bact_u;
@@ -353,6 +428,8 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
   p.a_bytes = (unsigned)(((size_t)(g.M - 1) * g.lda + g.K) * 2);
   p.w_bytes = (unsigned)((size_t)g.N * g.K * 2);
   p.c_bytes = (unsigned)(((size_t)(g.M - 1) * g.ldc + g.N) * 2);
+  p.stats = g.stats; p.stats_rep = g.stats_rep; p.bnb_y = (const bf16_t*)g.bnb_y; p.bnb_ss = g.bnb_ss; p.bnb_mr = g.bnb_mr; p.bnb_act = g.bnb_act;
+  p.y_bytes = (unsigned)((size_t)g.M * g.N * 2);
   p.ntn = (g.N + 127) / 128;
   p.dbg = getenv("SATRN_BIG_DBG") ? atoi(getenv("SATRN_BIG_DBG")) : 0;
   const int cus = big_cu_count();
@@ -360,14 +437,14 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
   const int force_mt = getenv("SATRN_GEMM_BIG_MT") ? atoi(getenv("SATRN_GEMM_BIG_MT")) : 0;
   int best_mt = 4;
   double best_cost = 1e30;
-  for (int mt = 4; mt >= 2; --mt) {
+  for (int mt = (g.bnb_y ? 2 : (g.stats ? 3 : 4)); mt >= 2; --mt) {
     const long tiles = (long)((g.M + 64 * mt - 1) / (64 * mt)) * p.ntn;
     const long rounds = (tiles + cus - 1) / cus;
     // cost ~ rounds x (rows per tile + a fixed per-tile part worth ~48 rows: epilogue + the wider share of W traffic of flat tiles)
     const double cost = (double)rounds * (64.0 * mt + 48.0);
     if (cost < best_cost) { best_cost = cost; best_mt = mt; }
   }
-  if (force_mt >= 2 && force_mt <= 4) best_mt = force_mt;
+  if (force_mt >= 2 && force_mt <= (g.bnb_y ? 2 : (g.stats ? 3 : 4))) best_mt = force_mt;
   p.ntm = (g.M + 64 * best_mt - 1) / (64 * best_mt);
   p.ntiles = p.ntm * p.ntn;
   const int grid = p.ntiles < cus ? p.ntiles : cus;

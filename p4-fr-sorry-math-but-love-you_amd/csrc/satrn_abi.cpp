@@ -57,6 +57,19 @@ int satrn_linear_fwd(int dt, const void* x, const void* w, const float* bias, vo
   launch_gemm(dt, AM_DENSE, p, S(st));
   return done("linear_fwd");
 }
+int satrn_linear_fwd_stats(int dt, const void* x, const void* w, void* y, int M, int N, int K, float* stats, int stats_rep, const void* bnb_y,
+                           const float* bnb_ss, const float* bnb_mr, int bnb_act, int accumulate, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, K, "K") || chk_c(dt, N, "N")) return -1;
+  if (!stats || stats_rep < 1) return fail(-1, "satrn_linear_fwd_stats: stats [stats_rep][2N] (zeroed) is required");
+  if (bnb_y && (!bnb_ss || !bnb_mr)) return fail(-1, "satrn_linear_fwd_stats: bnb_y needs bnb_ss and bnb_mr");
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = x; p.Bw = w; p.C = y; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldc = N; p.beta = accumulate;
+  p.stats = stats; p.stats_rep = stats_rep; p.bnb_y = bnb_y; p.bnb_ss = bnb_ss; p.bnb_mr = bnb_mr; p.bnb_act = bnb_act;
+  launch_gemm(dt, AM_DENSE, p, S(st));
+  return done("linear_fwd_stats");
+}
 int satrn_linear_bwd_data(int dt, const void* dy, int ldy, const void* wb, int ldb, void* dx, int M, int N, int K,
                           int accumulate, void* st) {
   CHK_DT(dt);

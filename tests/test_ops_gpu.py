@@ -129,6 +129,95 @@ def test_linear(lib, dt, M, N, K, act):
     close(db, dy.sum(0), dt, "linear_bwd_bias")
 
 
+@pytest.fixture
+def big_gemm_mode():
+    """SATRN_GEMM_BIG is read per call: '2' = every dense bf16 product that fits takes the persistent direct-to-LDS kernel
+    (kernels_gemm_big.hip), '0' = the 4-wave tile kernel"""
+    import os
+
+    def set_mode(m):
+        os.environ["SATRN_GEMM_BIG"] = str(m)
+    yield set_mode
+    os.environ.pop("SATRN_GEMM_BIG", None)
+    os.environ.pop("SATRN_GEMM_BIG_MT", None)
+
+
+@pytest.mark.parametrize("M,N,K,act,mt", [(256, 128, 64, 0, 0), (300, 136, 192, 1, 0), (1000, 384, 512, 4, 0), (777, 128, 64, 0, 4), (6144, 960, 160, 0, 3), (1000, 48, 96, 0, 2),
+                                          (555, 256, 24, 3, 0), (4099, 520, 256, 2, 4), (2304, 1024, 2048, 0, 0), (9216, 2048, 512, 4, 0), (20000, 128, 128, 0, 2), (64, 128, 64, 0, 0)])
+def test_linear_big_kernel(lib, big_gemm_mode, M, N, K, act, mt):
+    """the persistent 8-wave direct-to-LDS GEMM (bf16): M / N tails (range-checked DMA), K tails (zero-filled last k-step), every tile
+    height, bias + activations (GELU = the fast exact-erf form), accumulate; against fp32 torch"""
+    import os
+    dt = "bf16"
+    big_gemm_mode(2)
+    if mt:
+        os.environ["SATRN_GEMM_BIG_MT"] = str(mt)
+    x, w, b = q(rnd(M, K, seed=1), dt), q(rnd(N, K, seed=2, scale=1 / math.sqrt(K)), dt), rnd(N, seed=3, scale=0.1)
+    fwd, bwd, ldb = pack_dense(lib, w, dt)
+    y = torch.full((M, N), 7.0, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_linear_fwd(dti(dt), P(dev(x, dt)), P(fwd), P(dev(b)), P(y), M, N, K, act, 0, 0.0, None, 0, st()))
+    ref = F.linear(x, w, b)
+    ref = {0: ref, 1: F.relu(ref), 2: F.silu(ref), 3: torch.sigmoid(ref), 4: F.gelu(ref)}[act]
+    close(y, ref, dt, f"big linear_fwd {M}x{N}x{K} act {act}")
+    # the 4-wave kernel on the same inputs: same values up to summation order / one bf16 rounding
+    big_gemm_mode(0)
+    y0 = torch.empty(M, N, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_linear_fwd(dti(dt), P(dev(x, dt)), P(fwd), P(dev(b)), P(y0), M, N, K, act, 0, 0.0, None, 0, st()))
+    close(y, y0.float().cpu(), dt, "big vs 4-wave kernel", bf16_tol=1e-2)
+    big_gemm_mode(2)
+    if N % 8 == 0 and K % 8 == 0:
+        dy = q(rnd(M, N, seed=4), dt)
+        dyp = torch.zeros(M, ldb, dtype=tdt(dt), device="cuda")
+        dyp[:, :N] = dev(dy, dt)
+        dx = torch.empty(M, K, dtype=tdt(dt), device="cuda")
+        ok(lib, lib.satrn_linear_bwd_data(dti(dt), P(dyp), ldb, P(bwd), ldb, P(dx), M, N, K, 0, st()))
+        close(dx, dy @ w, dt, "big linear_bwd_data")
+        ok(lib, lib.satrn_linear_bwd_data(dti(dt), P(dyp), ldb, P(bwd), ldb, P(dx), M, N, K, 1, st()))
+        close(dx, 2 * (dy @ w), dt, "big linear_bwd_data(acc)")
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("M,N,K,rep,bnb", [(6144, 960, 160, 1, 0), (6144, 160, 960, 4, 0), (1536, 1536, 256, 1, 0), (3000, 48, 96, 8, 0), (700, 136, 64, 2, 0),
+                                           (6144, 160, 960, 1, 2), (1536, 256, 1536, 2, 1), (3000, 192, 48, 1, 2), (700, 136, 64, 1, 0 + 2)])
+def test_linear_with_batchnorm_sums(lib, big_gemm_mode, mode, M, N, K, rep, bnb):
+    """the product that also produces the BatchNorm sums of its output (forward: sum v, sum v^2; data gradient of a BatchNorm output:
+    sum g, sum g * xhat with g = dy * act'(y * scale + shift)), on the 4-wave kernel (mode 0) and the persistent kernel (mode 2)"""
+    dt = "bf16"
+    big_gemm_mode(mode)
+    x, w = q(rnd(M, K, seed=1), dt), q(rnd(N, K, seed=2, scale=1 / math.sqrt(K)), dt)
+    fwd, _, _ = pack_dense(lib, w, dt)
+    y = torch.empty(M, N, dtype=tdt(dt), device="cuda")
+    stats = torch.zeros(rep, 2, N, device="cuda")
+    ref = x @ w.t()
+    if not bnb:
+        ok(lib, lib.satrn_linear_fwd_stats(dti(dt), P(dev(x, dt)), P(fwd), P(y), M, N, K, P(stats), rep, None, None, None, 0, 0, st()))
+        close(y, ref, dt, "linear_fwd_stats y")
+        tot = stats.sum(0).cpu()
+        yr = y.float().cpu()
+        # (the sums are taken from the f32 values in one kernel and from the bf16-rounded ones in the other: both within bf16 noise)
+        close(tot[0], ref.sum(0), "f32", "sum v", f32_tol=3e-3)
+        close(tot[1], (ref * ref).sum(0), "f32", "sum v^2", f32_tol=3e-3)
+        assert (tot[0] - yr.sum(0)).abs().max().item() < 3e-3 * ref.sum(0).abs().max().item() + 0.5
+    else:
+        act = bnb   # 1 relu, 2 silu
+        by = q(rnd(M, N, seed=7, scale=2.0), dt)
+        scale, shift = rnd(N, seed=8) + 1.5, rnd(N, seed=9, scale=0.3)
+        mean, rstd = rnd(N, seed=10, scale=0.2), rnd(N, seed=11, scale=0.2) + 1.0
+        ss, mr = dev(torch.cat([scale, shift])), dev(torch.cat([mean, rstd]))
+        ok(lib, lib.satrn_linear_fwd_stats(dti(dt), P(dev(x, dt)), P(fwd), P(y), M, N, K, P(stats), rep, P(dev(by, dt)), P(ss), P(mr), act, 0, st()))
+        close(y, ref, dt, "linear_fwd_stats(bnb) y")
+        u = by * scale + shift
+        if act == 1:
+            d = (u > 0).float()
+        else:
+            sg = torch.sigmoid(u)
+            d = sg * (1 + u * (1 - sg))
+        g = ref * d
+        tot = stats.sum(0).cpu()
+        close(tot[0], g.sum(0), "f32", "sum g", f32_tol=6e-3)
+        close(tot[1], (g * ((by - mean) * rstd)).sum(0), "f32", "sum g xhat", f32_tol=6e-3)
+
+
 def same_geo(H, W, s):
     if s == 1:
         return H, W, 1, 1, (1, 1, 1, 1)

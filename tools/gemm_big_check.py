@@ -35,7 +35,7 @@ if __name__ == "__main__":
     ok = True
     if "--check" in sys.argv or len(sys.argv) == 1:
         for (M, N, K, bias, act) in [(256, 128, 64, False, 0), (256, 128, 128, True, 0), (300, 136, 192, True, 1), (1000, 384, 512, True, 4), (9216, 2048, 512, True, 4),
-                                     (777, 128, 64, False, 0), (2304, 1024, 4096, True, 0), (4099, 520, 256, True, 2), (147456, 128, 128, True, 0), (64, 128, 64, False, 0)]:
+                                     (777, 128, 64, False, 0), (6144, 960, 160, True, 0), (1000, 48, 96, False, 0), (3000, 192, 48, True, 1), (555, 256, 24, False, 0), (2304, 1024, 4096, True, 0), (4099, 520, 256, True, 2), (147456, 128, 128, True, 0), (64, 128, 64, False, 0)]:
             x, w, b, y = run(M, N, K, bias, act, 2)
             ref = x.float() @ w.float().t()
             if b is not None: ref = ref + b
@@ -55,6 +55,9 @@ if __name__ == "__main__":
         SHAPES = [(9216, 2048, 512), (9216, 512, 2048), (9216, 1536, 512), (9216, 512, 512), (36864, 1024, 256), (36864, 256, 1024), (36864, 768, 256), (147456, 512, 128), (147456, 128, 512),
                   (147456, 384, 128), (147456, 128, 128), (2304, 4096, 1024), (2304, 1024, 4096), (2304, 3072, 1024), (4096, 4096, 4096), (8192, 8192, 8192),
                   (24576, 256, 64), (24576, 64, 256), (6144, 960, 160), (4096, 1024, 256)]
+        if os.environ.get("EFF_SHAPES"):
+            SHAPES = [(98304, 192, 48), (98304, 48, 192), (98304, 96, 48), (98304, 48, 96), (24576, 256, 64), (24576, 64, 256), (6144, 512, 128), (6144, 128, 512), (6144, 960, 160), (6144, 160, 960),
+                      (1536, 1536, 256), (1536, 256, 1536), (1536, 512, 256), (1536, 1536, 512), (1536, 512, 512), (1536, 512, 1536), (4096, 768, 256), (4096, 256, 256), (4096, 1024, 256), (4096, 256, 1024)]
         for M, N, K in SHAPES:
             x = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16(); w = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
             y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
