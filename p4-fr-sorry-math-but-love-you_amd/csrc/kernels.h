@@ -77,6 +77,8 @@ struct WgradP {
                                            // chunks they stage anyway (was a separate launch_colsum pass over dY)
 };
 void launch_wgrad(int dt, const WgradP& p, hipStream_t s);
+// large dense bf16 weight gradients on the persistent direct-to-LDS kernel (kernels_gemm_big.hip); false = not taken
+bool wgrad_big_launch(const WgradP& p, hipStream_t s);
 void launch_conv_grad_unpack(const float* tmp /*[N][taps][Ci]*/, float* dw /*[N][Ci][taps] +=*/, int N, int Ci, int taps, hipStream_t s);
 
 // ---- attention ---------------------------------------------------------------------------

@@ -968,6 +968,7 @@ static void launch_wgrad_tile(const WgradP& p, hipStream_t s) {
 void launch_wgrad(int dt, const WgradP& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return;
   const bool big = p.N > 64 && p.K > 64 && (long)p.M * p.N * p.K >= (1L << 28);
+  if (dt == DT_BF16 && !g_det.on && wgrad_big_launch(p, s)) return;   // large dense products: persistent direct-to-LDS kernel
   if (dt == DT_BF16) {
     if (big) launch_wgrad_tile<bf16_t, 128, 128>(p, s); else launch_wgrad_tile<bf16_t, 64, 64>(p, s);
   } else {

@@ -376,6 +376,241 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
   }
 }
 
+// =========================================================================================
+// Weight gradient on the same skeleton:  dW[n][k] += sum_m dY[m][n] * X[m][k]   (fp32 atomics; + the bias gradient sum_m dY[m][n])
+// The contraction index m is the ROW index of both operands, so the tiles are staged in their natural layout ([64 rows of m][n or k
+// columns], whole 1 KiB DMA pieces = 2 rows of dY / 4 rows of X) and the MFMA fragments -- 8 consecutive m of one column -- come
+// out of LDS with the transposing read ds_read_b64_tr_b16 (two per fragment).  A 16-lane group of that read touches 4 rows x 32
+// bytes and a 32-lane half 8 rows (m = 0..3 and 8..11, or 4..7 and 12..15) at the SAME 32-byte column granule: with 512- / 256-byte rows
+// all eight would sit on the same banks, so granule j of row m is stored at granule j ^ h(m), h(m) = (m & 3) | ((m >> 3) & 1) << 2
+// (applied to each lane's DMA source address and to the fragment reads): eight distinct granules of one 256-byte bank row.
+// Work item = (output tile BNo x 128, slice of M); items of one tile add their partial tiles with fp32 atomics (64-byte row segments
+// straight from the accumulator layout).  The persistent grid, the loader / consumer roles and the one-barrier-per-k-step ring are
+// the GEMM's above.  Reference: the weight / bias gradients autograd computes for every nn.Linear of networks/SWIN.py:24-47,84-209
+// and the decoder (networks/EfficientSATRN.py:326-397).
+// =========================================================================================
+struct BigWP {
+  const bf16_t* Y; const bf16_t* X; float* dW; float* dbias;
+  int M, N, K, ldy, lda, ldw;
+  int ntn, ntk, nitems, splits, rows_per_split;   // rows_per_split: a multiple of 64
+  unsigned y_bytes, x_bytes;
+  int dbg;
+};
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+DEVI uint2 lds_read_tr8(unsigned addr) {
+  const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lds_u8*)(size_t)addr);
+  return __builtin_bit_cast(uint2, v);
+}
+
+// NTW: 16-row MFMA tiles per consumer wave along n (output tile = 32 * NTW rows of dW x 128 columns)
+template <int NTW, bool DBIAS>
+__global__ __launch_bounds__(BIG_THREADS, 2) void wgrad_big_kernel(BigWP p) {
+  constexpr int KTW = 4, HN = NTW / 2;
+  constexpr int BNo = 32 * NTW, BKo = 128;
+  constexpr int YROW = BNo * 2, XROW = BKo * 2;                    // bytes per LDS row
+  constexpr int RPY = 1024 / YROW, RPX = 1024 / XROW;              // rows per 1 KiB DMA piece
+  constexpr int NYP = 64 / RPY / 4, NXP = 64 / RPX / 4;            // pieces per loader wave and stage
+  constexpr int STAGE = 64 * (YROW + XROW);
+  constexpr int XOFF = 64 * YROW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char big_sm[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)big_sm;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KT = p.rows_per_split / 64;
+
+  const int nwg = gridDim.x;
+  const int L = xcd_remap(blockIdx.x, nwg);
+  const int my_items = L < p.nitems ? (p.nitems - L + nwg - 1) / nwg : 0;
+  const int T = my_items * KT;
+  if (T == 0) return;
+  // item -> (slice of M, n tile, k tile); k tile fastest: neighbouring items share their dY panel
+  auto item_of = [&](int ii, int& sp, int& tn, int& tk) {
+    const int it = L + ii * nwg;
+    tk = it % p.ntk;
+    const int r = it / p.ntk;
+    tn = r % p.ntn;
+    sp = r / p.ntn;
+  };
+
+  if (wave >= 4) {
+    // =============================== loader waves ===============================
+    const int lw = wave - 4;
+    const i32x4 rY = make_rsrc(p.Y, p.y_bytes), rX = make_rsrc(p.X, p.x_bytes);
+    // dY piece i = lw + 4 j: rows RPY * i + (lane / (YROW / 16)), chunk slot lane % (YROW / 16); granule of the source = (slot >> 1) ^ h(row)
+    const int yr = lane / (YROW / 16), ys = lane % (YROW / 16);
+    const int xr = lane / (XROW / 16), xs = lane % (XROW / 16);
+    const unsigned ldy2 = (unsigned)p.ldy * 2u, lda2 = (unsigned)p.lda * 2u;
+    int d_item = 0, d_k = 0;
+    int m_item0 = 0, m_end = 0, n0 = 0, k0 = 0;
+    auto dma_item_setup = [&](int ii) {
+      int sp, tn, tk;
+      item_of(ii, sp, tn, tk);
+      m_item0 = sp * p.rows_per_split;
+      m_end = min(p.M, m_item0 + p.rows_per_split);
+      n0 = tn * BNo; k0 = tk * BKo;
+    };
+    auto dma_issue = [&](int slot) {
+      const unsigned sbase = lds0 + (unsigned)slot * STAGE;
+      const int mb = m_item0 + d_k * 64;
+#pragma unroll
+      for (int j = 0; j < NYP; ++j) {
+        const int ml = (lw + 4 * j) * RPY + yr;                                  // row of the stage
+        const int h = (ml & 3) | (((ml >> 3) & 1) << 2);
+        const int c = ((((ys >> 1) ^ h) << 1) | (ys & 1));                        // source chunk (8 columns)
+        const bool okr = mb + ml < m_end && n0 + c * 8 < p.N;
+        dma16(rY, sbase + (unsigned)(lw + 4 * j) * 1024u, okr ? (unsigned)(mb + ml) * ldy2 + (unsigned)(n0 + c * 8) * 2u : 0xfffffff0u, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < NXP; ++j) {
+        const int ml = (lw + 4 * j) * RPX + xr;
+        const int h = (ml & 3) | (((ml >> 3) & 1) << 2);
+        const int c = ((((xs >> 1) ^ h) << 1) | (xs & 1));
+        const bool okr = mb + ml < m_end && k0 + c * 8 < p.K;
+        dma16(rX, sbase + XOFF + (unsigned)(lw + 4 * j) * 1024u, okr ? (unsigned)(mb + ml) * lda2 + (unsigned)(k0 + c * 8) * 2u : 0xfffffff0u, 0);
+      }
+      if (++d_k == KT) { d_k = 0; ++d_item; if (d_item < my_items) dma_item_setup(d_item); }
+    };
+    dma_item_setup(0);
+    dma_issue(0);
+    if (1 < T) dma_issue(1);
+    if (2 < T) dma_issue(2);
+    if (T >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NYP + NXP)) : "memory");
+    else if (T == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NYP + NXP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int slot = 0;
+    for (int t = 0; t < T; ++t) {
+      if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NYP + NXP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + BIG_NSTAGE < T) dma_issue(slot);
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    return;
+  }
+
+  // =============================== consumer waves ===============================
+  const int wm = wave >> 1, wn = wave & 1;          // halves of the tile along n / along k
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tq = fr >> 2, tp = fr & 3;               // transposing read: lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3
+  const int h = tq | ((fq & 1) << 2);                // h(m) of the rows this lane addresses (m = 32 ks + 8 fq + tq (+ 4))
+  const unsigned rowoff = (unsigned)(8 * fq + tq);
+  // per-lane byte offsets inside a stage (without the k-half and the tile index)
+  const unsigned yA = rowoff * YROW + (unsigned)tp * 8u, xB = XOFF + rowoff * XROW + (unsigned)tp * 8u;
+  uint4 aX[HN], aY[HN], bK0[KTW], bK1[KTW];
+  auto read_y = [&](int slot, int ks, int half, uint4* af) {
+    if (p.dbg & 8) return;
+    const unsigned sbase = lds0 + (unsigned)slot * STAGE + yA + (unsigned)(ks * 32) * YROW;
+#pragma unroll
+    for (int i = 0; i < HN; ++i) {
+      const unsigned a = sbase + (unsigned)(((wm * NTW + half * HN + i) ^ h) * 32);
+      const uint2 lo = lds_read_tr8(a), hi = lds_read_tr8(a + 4u * YROW);
+      af[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+  };
+  auto read_x = [&](int slot, int ks, uint4* bf) {
+    if (p.dbg & 8) return;
+    const unsigned sbase = lds0 + (unsigned)slot * STAGE + xB + (unsigned)(ks * 32) * XROW;
+#pragma unroll
+    for (int j = 0; j < KTW; ++j) {
+      const unsigned a = sbase + (unsigned)(((wn * KTW + j) ^ h) * 32);
+      const uint2 lo = lds_read_tr8(a), hi = lds_read_tr8(a + 4u * XROW);
+      bf[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+  };
+  f32x4 acc[NTW][KTW];
+  f32x4 accb[DBIAS ? NTW : 1];
+  bool do_bias = false;                       // this wave sums the bias gradient of the current item (k tile 0, k half 0)
+  const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // eight bf16 1.0
+  auto mma_group = [&](int half, const uint4* af, const uint4* bf) {
+    if (p.dbg & 4) return;
+#pragma unroll
+    for (int i = 0; i < HN; ++i) {
+#pragma unroll
+      for (int j = 0; j < KTW; ++j)
+        acc[half * HN + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]), acc[half * HN + i][j], 0, 0, 0);
+      if (DBIAS && do_bias)
+        accb[half * HN + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, ones), accb[half * HN + i], 0, 0, 0);
+    }
+  };
+  auto acc_init = [&](int ii) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int j = 0; j < KTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (DBIAS) {
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int sp, tn, tk;
+      item_of(ii, sp, tn, tk);
+      do_bias = p.dbias != nullptr && tk == 0 && wn == 0;
+    }
+  };
+  auto epilogue = [&](int ii) {
+    int sp, tn, tk;
+    item_of(ii, sp, tn, tk);
+    const int nb = tn * BNo + wm * 16 * NTW + fq * 4, kb = tk * BKo + wn * 64 + fr;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+      for (int j = 0; j < KTW; ++j) {
+        const int k = kb + j * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = nb + i * 16 + r;
+          if (n < p.N && k < p.K) atomicAdd(p.dW + (size_t)n * p.ldw + k, acc[i][j][r]);
+        }
+      }
+    if (DBIAS && do_bias && fr == 0) {
+#pragma unroll
+      for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = nb + i * 16 + r;
+          if (n < p.N) atomicAdd(p.dbias + n, accb[i][r]);
+        }
+    }
+  };
+
+  acc_init(0);
+  __builtin_amdgcn_s_barrier();      // stage 0 has landed
+  read_y(0, 0, 0, aX);
+  read_x(0, 0, bK0);
+  int c_item = 0, c_k = 0, slot = 0;
+  for (int t = 0; t < T; ++t) {
+    const int slot1 = slot == 2 ? 0 : slot + 1;
+    const bool last_k = c_k == KT - 1;
+    read_y(slot, 0, 1, aY);
+    read_x(slot, 1, bK1);
+    __builtin_amdgcn_s_setprio(1);
+    mma_group(0, aX, bK0);
+    __builtin_amdgcn_s_setprio(0);
+    read_y(slot, 1, 0, aX);
+    __builtin_amdgcn_s_setprio(1);
+    mma_group(1, aY, bK0);
+    __builtin_amdgcn_s_setprio(0);
+    read_y(slot, 1, 1, aY);
+    __builtin_amdgcn_s_setprio(1);
+    mma_group(0, aX, bK1);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < T) { read_y(slot1, 0, 0, aX); read_x(slot1, 0, bK0); }
+    __builtin_amdgcn_s_setprio(1);
+    mma_group(1, aY, bK1);
+    __builtin_amdgcn_s_setprio(0);
+    if (last_k) {
+      if (!(p.dbg & 1)) epilogue(c_item);
+      if (c_item + 1 < my_items) acc_init(c_item + 1);
+      c_k = 0; ++c_item;
+    } else {
+      ++c_k;
+    }
+    slot = slot1;
+  }
+}
+
 static int big_cu_count() {
   static int cus = 0;
   if (!cus) {
@@ -451,5 +686,50 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
   if (best_mt == 4) big_launch_t<4>(p, grid, s);
   else if (best_mt == 3) big_launch_t<3>(p, grid, s);
   else big_launch_t<2>(p, grid, s);
+  return true;
+}
+
+template <int NTW, bool DB>
+static void wgrad_big_go(const BigWP& p, int grid, hipStream_t s) {
+  constexpr size_t sh = (size_t)BIG_NSTAGE * 64 * (32 * NTW * 2 + 256);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_big_kernel<NTW, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
+  hipLaunchKernelGGL((wgrad_big_kernel<NTW, DB>), dim3(grid), dim3(BIG_THREADS), sh, s, p);
+}
+
+// dense bf16 weight gradient (fp32 atomics into dW, optional bias gradient); true = launched
+bool wgrad_big_launch(const WgradP& w, hipStream_t s) {
+  const char* mode_env = getenv("SATRN_WGRAD_BIG");   // read per call: 0 = off, 2 = every shape that fits
+  const int mode = mode_env ? atoi(mode_env) : 1;
+  if (!mode || w.conv || w.out_t || w.det_part || (w.nbatch > 1)) return false;
+  if ((w.N & 7) || (w.K & 7) || (w.ldy & 7) || (w.lda & 7) || w.M < 64) return false;
+  if ((size_t)w.M * w.ldy * 2 >= (1ull << 31) || (size_t)w.M * w.lda * 2 >= (1ull << 31)) return false;
+  const double flops = 2.0 * w.M * w.N * w.K;
+  if (mode != 2 && (flops < 2.0e9 || w.M < 2048)) return false;
+  BigWP p;
+  p.Y = (const bf16_t*)w.dY; p.X = (const bf16_t*)w.A; p.dW = (float*)w.dW; p.dbias = w.dbias;
+  p.M = w.M; p.N = w.N; p.K = w.K; p.ldy = w.ldy; p.lda = w.lda; p.ldw = w.K;
+  p.y_bytes = (unsigned)(((size_t)(w.M - 1) * w.ldy + w.N) * 2);
+  p.x_bytes = (unsigned)(((size_t)(w.M - 1) * w.lda + w.K) * 2);
+  p.dbg = getenv("SATRN_BIG_DBG") ? atoi(getenv("SATRN_BIG_DBG")) : 0;
+  const int cus = big_cu_count();
+  const bool tall = w.N > 128 && !w.dbias;      // 256-row tiles; the bias-gradient form keeps NTW more accumulators and takes 128-row tiles
+  const int bno = tall ? 256 : 128;
+  p.ntn = (w.N + bno - 1) / bno; p.ntk = (w.K + 127) / 128;
+  const int tiles = p.ntn * p.ntk;
+  // slices of M: enough items to fill the persistent grid (at least 256 rows per slice)
+  int target = w.full_grid ? cus : (getenv("SATRN_WGRAD_BIG_ITEMS") ? atoi(getenv("SATRN_WGRAD_BIG_ITEMS")) : cus);
+  int splits = (target + tiles - 1) / tiles;
+  const int max_splits = (w.M + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int rps = (w.M + splits - 1) / splits;
+  rps = ((rps + 63) / 64) * 64;
+  splits = (w.M + rps - 1) / rps;
+  p.splits = splits; p.rows_per_split = rps; p.nitems = tiles * splits;
+  const int grid = p.nitems < target ? p.nitems : target;
+  if (tall) wgrad_big_go<8, false>(p, grid, s);
+  else if (w.dbias) wgrad_big_go<4, true>(p, grid, s);
+  else wgrad_big_go<4, false>(p, grid, s);
   return true;
 }

@@ -176,6 +176,32 @@ def test_linear_big_kernel(lib, big_gemm_mode, M, N, K, act, mt):
         close(dx, 2 * (dy @ w), dt, "big linear_bwd_data(acc)")
 
 
+@pytest.mark.parametrize("M,N,K,bias", [(9216, 2048, 512, False), (9216, 512, 2048, True), (4099, 520, 264, True), (4099, 520, 264, False), (2304, 136, 1024, False),
+                                        (1000, 384, 128, True), (300, 48, 96, False), (64, 128, 128, True), (20000, 128, 384, True), (777, 256, 128, False)])
+def test_linear_bwd_weight_big_kernel(lib, M, N, K, bias):
+    """the persistent direct-to-LDS weight-gradient kernel (bf16): natural-layout tiles + transposing LDS reads, slices of M added with fp32
+    atomics, bias gradient as a ones-column product; M / N / K tails; against fp32 torch"""
+    import os
+    dt = "bf16"
+    os.environ["SATRN_WGRAD_BIG"] = "2"
+    try:
+        x, dy = q(rnd(M, K, seed=1), dt), q(rnd(M, N, seed=4), dt)
+        ldy = (N + 7) // 8 * 8 + 8    # a padded gradient buffer (row stride > N)
+        dyp = torch.zeros(M, ldy, dtype=tdt(dt), device="cuda")
+        dyp[:, :N] = dev(dy, dt)
+        dw = torch.zeros(N, K, device="cuda")
+        db = torch.zeros(N, device="cuda") if bias else None
+        ok(lib, lib.satrn_linear_bwd_weight(dti(dt), P(dyp), ldy, P(dev(x, dt)), P(dw), P(db), M, N, K, st()))
+        close(dw, dy.t() @ x, dt, f"big linear_bwd_weight {M}x{N}x{K}", bf16_tol=2e-3)
+        if bias:
+            close(db, dy.sum(0), dt, "big linear_bwd_bias", bf16_tol=2e-3)
+        # accumulates into dW (a second call doubles it)
+        ok(lib, lib.satrn_linear_bwd_weight(dti(dt), P(dyp), ldy, P(dev(x, dt)), P(dw), P(db), M, N, K, st()))
+        close(dw, 2 * (dy.t() @ x), dt, "big linear_bwd_weight (accumulated)", bf16_tol=2e-3)
+    finally:
+        os.environ.pop("SATRN_WGRAD_BIG", None)
+
+
 @pytest.mark.parametrize("mode", [0, 2])
 @pytest.mark.parametrize("M,N,K,rep,bnb", [(6144, 960, 160, 1, 0), (6144, 160, 960, 4, 0), (1536, 1536, 256, 1, 0), (3000, 48, 96, 8, 0), (700, 136, 64, 2, 0),
                                            (6144, 160, 960, 1, 2), (1536, 256, 1536, 2, 1), (3000, 192, 48, 1, 2), (700, 136, 64, 1, 0 + 2)])
