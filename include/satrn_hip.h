@@ -293,7 +293,10 @@ int satrn_model_loss_backward(satrn_model* m, const int64_t* expected, int B, in
  * 0-2: 74 % of the parameters) followed by 16 + 3.
  * + 32 (any of the above, eager): module.eval() semantics WITH gradients -- BatchNorm uses (and does not update) its running
  * statistics, dropout is off; every sample is then independent of the rest of the batch, which is the mode the data-parallel
- * equivalence test runs in (N ranks' averaged gradient == one rank's gradient on the concatenated batch). */
+ * equivalence test runs in (N ranks' averaged gradient == one rank's gradient on the concatenated batch).
+ * + 64 (any of the above, eager): the NON-teacher-forced training branch, networks/EfficientSATRN.py:496-525 (the decoder feeds on its
+ * own argmax, `expected` only gives the length; gradients flow through every step) -- the branch the reference's per-batch coin
+ * (`random.random() < teacher_forcing_ratio`, :489) takes on 20-70 % of the training batches of the shipped schedule. */
 int satrn_model_train_step(satrn_model* m, const float* images, const int64_t* expected, int B, int L,
                            const float* hyper9, int use_graph, int phase, void* stream);
 /* The dual-optimizer iteration of train_modules/train_dual_opt.py:87-113: as satrn_model_train_step (eager), but phase

@@ -1690,6 +1690,8 @@ Tensor* decoder_ar(Exec& e, Tensor* src, int B, int L, float* logits_out) {
   // full logits tensor [B*T][V] (fp32, caller's buffer); its gradient arrives as [B*T][Vp] in the compute dtype
   e.tens.emplace_back(new Tensor());
   Tensor* full = e.tens.back().get();
+  // (the fused training step passes no buffer: the logits then live in the arena, like decoder_tf's)
+  if (!logits_out) logits_out = (float*)e.alloc((size_t)B * T * V * sizeof(float));
   full->rows = (long)B * T; full->C = V; full->f32 = true; full->p = logits_out;
   const int Vp = m->gen.ldb;
   const float fp = (e.train && e.drop > 0.f) ? 0.1f : 0.f;
@@ -1934,13 +1936,18 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
   // + 32: forward with BatchNorm RUNNING statistics and no dropout (module.eval() semantics) but gradients recorded -- the
   // per-sample-independent mode in which N ranks' averaged gradients equal one rank's on the concatenated batch
   const bool train_mode = !(phase & 32);
+  // + 64: the reference's NON-teacher-forced training branch (networks/EfficientSATRN.py:496-525: the decoder feeds on its own argmax,
+  // gradients flow through every step) instead of the teacher-forced one -- the branch its coin takes on 20-70 % of the training batches
+  // (train_modules/train_single_opt.py:75, tf ratio 0.8 -> 0.3).  Eager only.
+  const bool teacher_forced = !(phase & 64);
+  if (!teacher_forced) use_graph = 0;
   const int seg = (phase & 16) ? (phase & 3) : -1;
   const int seg_to = (phase >> 2) & 3;
   if (seg >= 0) {
     if (!m->bound || !m->ws_set || !m->grads) { m->err = "bind parameters/grads and set a workspace first"; return -1; }
     if (seg == 0) {
       launch_fill(m->grads, 0, (size_t)m->n_params * 4, s);
-      int rc = model_forward(m, img, expected, B, L, train_mode, true, nullptr, s);
+      int rc = model_forward(m, img, expected, B, L, train_mode, true, nullptr, s, teacher_forced);
       if (rc) return rc;
     }
     return model_backward_segment(m, expected, B, L, seg, s, seg_to);
@@ -1991,7 +1998,7 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
       } else {
         launch_fill(m->grads, 0, (size_t)m->n_params * 4, s);
       }
-      int rc = model_forward(m, img, expected, B, L, train_mode, true, nullptr, s);
+      int rc = model_forward(m, img, expected, B, L, train_mode, true, nullptr, s, teacher_forced);
       if (rc) return rc;
       if (side_zero) (void)hipStreamWaitEvent(s, evz1, 0);
       if (g_stage_prof) m->ex->mark("f:decoder");

@@ -120,7 +120,9 @@ def dp_train_step(model, images, expected, lr, overlap=True, force_exchange=Fals
     beside the backward of the early backbone, whose range is reduced at the end.  Otherwise:
     forward/backward -> one flat all-reduce -> clip + AdamW.  Both end with grad_scale = 1/world inside the optimizer.
     force_exchange: take the split-phase path and issue the collectives even when the group has ONE rank (how the one-GPU
-    test box executes the RCCL calls and the stream hand-offs of the real path)."""
+    test box executes the RCCL calls and the stream hand-offs of the real path).
+    teacher_forcing_ratio=... (in kw): the branch coin is flipped ONCE, by the call that starts the step; every rank must flip the same
+    coin (model.set_coin(dp.SharedCoin(seed)) on all ranks), or their exchanges would pair different decoder branches."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1 and not (force_exchange and dist.is_initialized()):
         model.train_step(images, expected, lr, **kw)

@@ -172,6 +172,7 @@ class _SATRNBase(nn.Module):
         self._side = None
         self._warm = set()
         self._coin = None
+        self.last_teacher_forced = True
         if checkpoint and checkpoint is not True:   # networks/SWIN.py:1025 has `checkpoint=True` as its default
             self.load_state_dict(checkpoint)
 
@@ -504,7 +505,7 @@ class _SATRNBase(nn.Module):
 
     # ------------------------------------------------------------------ fused training step (bench / trainer fast path)
     def train_step(self, input, expected, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-6, max_grad_norm=2.0,
-                   grad_scale=1.0, use_graph=False, phase=3, bn_eval=False):
+                   grad_scale=1.0, use_graph=False, phase=3, bn_eval=False, teacher_forcing_ratio=1.0, teacher_forced=None):
         """forward + CE + backward + clip_grad_norm_ + AdamW + weight re-pack in ONE library call
         (train_modules/train_single_opt.py:80-98 with teacher forcing).  Default: eager launches on two HIP streams (weight
         gradients run beside the data-gradient chain; measured 12.5 ms vs 15.2 ms for the single-chain hipGraph replay,
@@ -515,7 +516,23 @@ class _SATRNBase(nn.Module):
         iteration (train_modules/train_dual_opt.py:87-113): encoder.* and decoder.* gradients are clipped separately and
         stepped with their own learning rates (eager only; plain Adam = weight_decay 0, what that trainer uses).
         bn_eval=True: module.eval() semantics with gradients (BatchNorm running statistics, no dropout; eager) -- every
-        sample independent of its batch, the mode of the data-parallel equivalence test."""
+        sample independent of its batch, the mode of the data-parallel equivalence test.
+        teacher_forcing_ratio < 1: the reference's per-batch coin (networks/EfficientSATRN.py:489; Python's `random`, or the coin given
+        to set_coin -- data-parallel ranks share one, dp.SharedCoin) decides between the teacher-forced decoder and the
+        autoregressive one WITH gradients (:496-525); the coin is flipped by the call that starts a step (phase bit 0 / segment 0).
+        teacher_forced=True/False overrides the coin (the later calls of a split step must repeat the first call's branch:
+        last_teacher_forced)."""
+        starts = (int(phase) & 31) in (1, 3) or (int(phase) & 16 and int(phase) & 3 == 0)
+        if teacher_forced is None:
+            if starts:
+                teacher_forced = True if teacher_forcing_ratio >= 1.0 else \
+                    (self._coin if self._coin is not None else random).random() < teacher_forcing_ratio
+            else:
+                teacher_forced = self.last_teacher_forced
+        self.last_teacher_forced = bool(teacher_forced)
+        if not teacher_forced:
+            phase = int(phase) | 64
+            use_graph = False
         if bn_eval:
             phase = int(phase) | 32
             use_graph = False
@@ -535,7 +552,7 @@ class _SATRNBase(nn.Module):
             self._ensure_packed()
         if self._stage is None or self._stage[0].shape != input.shape or self._stage[1].shape != expected.shape:
             self._stage = (torch.empty_like(input), torch.empty_like(expected.contiguous()))
-        if (int(phase) & 31) in (1, 3) or (int(phase) & 16 and int(phase) & 3 == 0):  # calls that start a step stage its inputs
+        if starts:  # calls that start a step stage its inputs
             self._stage[0].copy_(input, non_blocking=True)
             self._stage[1].copy_(expected, non_blocking=True)
         if dual:

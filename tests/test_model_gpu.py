@@ -330,6 +330,46 @@ def test_train_autoregressive_branch_with_gradients(dtype):
         assert float(np.median([e_ for e_, _ in errs])) < 1e-3 and worst[0][0] < 3e-2
 
 
+def test_fused_train_step_takes_the_autoregressive_branch():
+    """train_step(teacher_forced=False / teacher_forcing_ratio < 1 + coin): the fused step (the one dp.dp_train_step and bench.py drive)
+    runs the reference's non-teacher-forced branch (networks/EfficientSATRN.py:496-525) -- same gradient as the module-API path that
+    test_train_autoregressive_branch_with_gradients pins to the oracle, whole and in data-parallel backward segments; the coin of
+    :489 is flipped once per step from a shareable source."""
+    from satrn_amd import dp
+    cfg = dict(O.CFG_LITE)
+    B, H, W, T = 3, 64, 192, 7
+    model, sd = build(cfg, H, W, "f32", 6)
+    img, expected = O.det_inputs(B, 1, H, W, T, seed=44, pad_tail=2)
+    imgd, expd = img.cuda(), expected.cuda()
+    model.train()
+    logits = model(imgd, expd, True, 0.0)
+    loss = model.criterion(logits.transpose(1, 2), expd[:, 1:])
+    model.zero_grad()
+    loss.backward()
+    g_ref = model.flat_grad().detach().clone()
+    model.train_step(imgd, expd, 0.0, phase=1, teacher_forced=False)
+    g = model.flat_grad().detach().clone()
+    assert not model.last_teacher_forced
+    scale = g_ref.abs().max().item()
+    print(f"[fused AR] max |g - g_module| / max |g| = {(g - g_ref).abs().max().item() / scale:.3e}, loss {model.read_loss()[0]:.6f} vs {loss.item():.6f}")
+    assert (g - g_ref).abs().max().item() <= 1e-6 * scale
+    assert abs(model.read_loss()[0] - loss.item()) < 1e-5
+    # the teacher-forced gradient is a different one (the branch really switched)
+    model.train_step(imgd, expd, 0.0, phase=1, teacher_forced=True)
+    assert (model.flat_grad() - g_ref).abs().max().item() > 1e-3 * scale
+    # backward segments (the overlapped data-parallel exchange): segment 0 flips / fixes the branch, the later calls repeat it
+    model.train_step(imgd, expd, 0.0, phase=16 + 0 + 4 * 2, teacher_forced=False)
+    model.train_step(imgd, expd, 0.0, phase=16 + 3)
+    assert (model.flat_grad() - g_ref).abs().max().item() <= 1e-6 * scale
+    # the coin: one flip per step, from the shared source
+    model.set_coin(dp.SharedCoin(seed=11))
+    twin = dp.SharedCoin(seed=11)
+    for _ in range(6):
+        model.train_step(imgd, expd, 0.0, phase=1, teacher_forcing_ratio=0.5)
+        assert model.last_teacher_forced == twin.teacher_forced(0.5)
+    assert model._coin.flips == 6
+
+
 @pytest.mark.parametrize("name", ["lite_c1_pad", "eff_c2_b2"])
 def test_segmented_backward_equals_whole_backward(golden_dir, name):
     """train_step(phase=16+k), k = 0..3 (the overlapped data-parallel exchange's backward segments) leaves the same flat

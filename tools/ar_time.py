@@ -40,3 +40,15 @@ for name, r in (("teacher-forced", 1.0), ("autoregressive", 0.0)):
     run(r, 3)  # warm-up: the autograd thread's first backward calls take 50-70 ms
     f, b = run(r, 4)
     print(f"{name:15s}: forward {f:7.2f} ms, backward {b:7.2f} ms, total {f + b:7.2f} ms")
+
+# the fused step (one library call: forward + CE + backward + clip + AdamW), both branches
+for name, tf in (("fused teacher-forced", True), ("fused autoregressive", False)):
+    for _ in range(3):
+        model.train_step(img, exp, 5e-4, teacher_forced=tf)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        model.train_step(img, exp, 5e-4, teacher_forced=tf)
+    torch.cuda.synchronize()
+    print(f"{name:22s}: {(time.perf_counter() - t0) / n * 1e3:7.2f} ms/step")
