@@ -545,6 +545,28 @@ def main():
                 out.setdefault("greedy_decode", {})["error"] = repr(ex)
                 model.train()
         if world == 1 and not args.no_extras:
+            # the reference's own training schedule flips a coin per batch (teacher_forcing_ratio 0.8 -> 0.3 over the epochs,
+            # configs/EfficientSATRN.yaml:35-37, train_modules/train_single_opt.py:75): the non-teacher-forced branch
+            # (networks/EfficientSATRN.py:496-525) through the same fused step, and the schedule's mean step at ratio 0.55
+            try:
+                model.train()
+                for _ in range(2):
+                    model.train_step(img, exp, lr, teacher_forced=False)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                nar = 4
+                for _ in range(nar):
+                    model.train_step(img, exp, lr, teacher_forced=False)
+                torch.cuda.synchronize()
+                ar_ms = (time.perf_counter() - t1) / nar * 1e3
+                out["train_tf_schedule"] = dict(teacher_forced_ms=round(ms, 3), autoregressive_ms=round(ar_ms, 3), ratio=round(ar_ms / ms, 2),
+                                                mean_ms_at_tf_0_55=round(0.55 * ms + 0.45 * ar_ms, 3),
+                                                images_per_s_at_tf_0_55=round(B / (0.55 * ms + 0.45 * ar_ms) * 1e3, 1),
+                                                note="autoregressive branch = 127 dependent decoder steps with gradients (~46 launches forward, ~80 backward per step): launch-bound, not rebuilt this round; reachable from the fused / data-parallel step (train_step(teacher_forcing_ratio=...), rank-shared coin)")
+            except Exception as ex:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                out["train_tf_schedule"] = dict(error=repr(ex))
             try:
                 out["accuracy_bf16_vs_f32"], out["f32_mode"] = precision_report(H, W, T, B, dev)
             except Exception as ex:  # noqa: BLE001
