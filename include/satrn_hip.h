@@ -62,6 +62,18 @@ int satrn_linear_fwd(int dtype, const void* x, const void* w_fwd, const float* b
  * bnb_ss = [scale | shift] and bnb_mr = [mean | rstd] (fp32 [2N] each, as written by satrn_batchnorm_act_fwd). */
 int satrn_linear_fwd_stats(int dtype, const void* x, const void* w_fwd, void* y, int M, int N, int K, float* stats, int stats_rep,
                            const void* bnb_y, const float* bnb_ss, const float* bnb_mr, int bnb_act, int accumulate, void* stream);
+/* The encoder layer's self-attention region in one launch + the LayerNorm behind it (bf16; EncoderLayer.forward,
+ * networks/EfficientSATRN.py:260-268: `out = self.norm(input); out = attention(out, out, out); out = self.norm(out + input)` with the
+ * SHARED LayerNorm, MultiHeadAttention :198-228, temperature sqrt(heads * head_dim) :187-189).  x [B*L][D] (L = h*w tokens <= 64,
+ * D = 256 or 512, head_dim 64, even head count); wqkv = the packed fused projection [3D][D] (q | k | v rows), wo [D][D].
+ * Outputs = everything the step-wise operators would have produced (the unfused backward reads them): y1 = norm(x) with mean | rstd,
+ * qkv [B*L][3D], the attention output [B*L][D] and its log-sum-exp [B][heads][L], o = dropout(out_linear(att) + bo) and y2 = norm(o + x)
+ * with its mean | rstd.  parts_scratch: (heads / 2) * B*L*D elements.  Dropout sites / indices are those of satrn_attention_fwd and
+ * satrn_linear_fwd, so both forms draw the same masks. */
+int satrn_enc_attn_region_fwd(const void* x, const float* ln_w, const float* ln_b, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
+                              int B, int L, int D, int heads, float attn_drop, float out_drop, const uint32_t* seed, uint32_t site_attn, uint32_t site_out,
+                              void* y1, float* mean_rstd1, void* qkv, void* att, float* lse, void* parts_scratch, void* o, void* y2, float* mean_rstd2,
+                              void* stream);
 /* dx[M][K] (+)= dy[M][ldy(>=N)] * W  using Wbwd [K][ldb]; `accumulate` adds into dx. */
 int satrn_linear_bwd_data(int dtype, const void* dy, int ldy, const void* w_bwd, int ldb, void* dx, int M, int N,
                           int K, int accumulate, void* stream);

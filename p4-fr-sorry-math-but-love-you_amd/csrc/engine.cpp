@@ -18,7 +18,7 @@ void launch_act_fwd(int dt, const void* u, void* z, long n, int act, hipStream_t
 
 // launch wrapper: skipped in dry (sizing) runs; with profiling on, each launch is bracketed by HIP events on the
 // engine's stream and attributed to a kernel family (the launcher's name) with its algorithmic flops / bytes.
-#define LCH(e, call) do { if (!(e).dry) { if ((e).prof) (e).prof_begin(#call); call; if ((e).prof) (e).prof_end(); } (e).nflops = 0; (e).nbytes = 0; } while (0)
+#define LCH(e, call) do { if (!(e).dry && !(e).nolaunch) { if ((e).prof) (e).prof_begin(#call); call; if ((e).prof) (e).prof_end(); } (e).nflops = 0; (e).nbytes = 0; } while (0)
 
 // algorithmic work of the next launch, attributed by the profiler (satrn_model_profile_step): bytes = every operand read
 // once + every result written once in its storage dtype, flops = 2 x multiply-accumulates
@@ -705,6 +705,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
   }
   if (!e.train) drop_p = 0.f;
   const uint32_t site = drop_p > 0.f ? e.site++ : 0;
+  e.last_site = site; e.last_drop = drop_p;
   const uint32_t* seed = (const uint32_t*)(scal(e.m) + SC_SEED);
   GemmP p;
   memset(&p, 0, sizeof(p));
@@ -1102,6 +1103,7 @@ Tensor* op_ln(Exec& e, Tensor* a, Tensor* b, LNp* ln) {
   const int C = a->C;
   Tensor* y = e.newt(R, C, a->B, a->H, a->W);
   float* mr = (float*)e.alloc((size_t)2 * R * 4);
+  e.last_mr = mr;
   WORK(e, 0, (double)R * C * e.esz() * (b ? 3 : 2));
   LCH(e, launch_layernorm(e.dt, a->p, b ? b->p : nullptr, ln->w.p, ln->b.p, y->p, mr, R, C, 1e-5f, 0.f, nullptr, 0, e.s));
   if (e.rec)
@@ -1143,6 +1145,7 @@ Tensor* op_attn(Exec& e, Tensor* qt, int qoff, Tensor* kvt, int koff, int voff, 
   float* lse = (float*)e.alloc((size_t)B * heads * Lq * 4);
   if (!e.train) drop_p = 0.f;
   const uint32_t site = drop_p > 0.f ? e.site++ : 0;
+  e.last_lse = lse; e.last_site = site; e.last_drop = drop_p;
   const uint32_t* seed = (const uint32_t*)(scal(e.m) + SC_SEED);
   const size_t es = e.esz();
   AttnP p;
@@ -1427,10 +1430,58 @@ Tensor* mha_self(Exec& e, Tensor* x, MHAp* a, int B, int L, int causal, const in
 Tensor* encoder_layer(Exec& e, Tensor* x, EncLayer* el) {
   const int B = x->B, H = x->H, W = x->W;
   const float p = e.drop;
-  Tensor* y1 = op_ln(e, x, nullptr, &el->norm);
   // MultiHeadAttention.dropout followed by EncoderLayer.dropout0: two independent masks == one mask with 1-(1-p)^2
-  Tensor* o = mha_self(e, y1, &el->att, B, H * W, 0, nullptr, 0, 1.f - (1.f - p) * (1.f - p));
-  Tensor* y2 = op_ln(e, o, x, &el->norm);
+  const float out_drop = 1.f - (1.f - p) * (1.f - p);
+  Tensor* y2;
+  if (enc_attn_fused_ok(e.dt, H * W, el->att.D, el->att.heads) && !g_det.on) {
+    // ONE launch for LayerNorm -> q|k|v -> attention -> output-projection partials (kernels_encattn.hip).  The four ops are run with
+    // nolaunch: they allocate their outputs and record their (unfused) backward closures exactly as before; the fused kernel then fills
+    // those outputs, and the LayerNorm behind the block adds the partial projections (+ bias, dropout) in a fixed order.
+    MHAp* a = &el->att;
+    const int L = H * W, D = a->D;
+    e.nolaunch = true;
+    Tensor* y1 = op_ln(e, x, nullptr, &el->norm);
+    float* mr1 = e.last_mr;
+    Tensor* qkv = op_gemm(e, y1, &a->qkv, &a->bqkv, ACT_NONE, 0.f, nullptr);
+    Tensor* att = op_attn(e, qkv, 0, qkv, D, 2 * D, B, L, L, a->heads, D, 0, nullptr, 0, e.drop);
+    float* lse = e.last_lse; const uint32_t site_att = e.last_site; const float drop_att = e.last_drop;
+    Tensor* o = op_gemm(e, att, &a->out, &a->bout, ACT_NONE, out_drop, nullptr);
+    const uint32_t site_out = e.last_site; const float drop_out = e.last_drop;
+    e.nolaunch = false;
+    const int HP = a->heads / 2;
+    void* parts = e.alloc((size_t)HP * B * L * D * e.esz());
+    EncAttnP q;
+    memset(&q, 0, sizeof(q));
+    q.x = x->p; q.ln_w = el->norm.w.p; q.ln_b = el->norm.b.p; q.wqkv = a->qkv.fwd; q.bqkv = a->bqkv.p; q.wo = a->out.fwd;
+    q.y1 = y1->p; q.mr = mr1; q.qkv = qkv->p; q.att = att->p; q.lse = lse; q.parts = parts;
+    q.B = B; q.L = L; q.D = D; q.H = a->heads; q.LkP = (int)attn_lkp(L);
+    q.inv_temp = 1.0f / sqrtf((float)D); q.drop_p = drop_att; q.seed = (const uint32_t*)(scal(e.m) + SC_SEED); q.site = site_att;
+    WORK(e, 2.0 * (double)B * L * D * 4 * D + 4.0 * (double)B * L * L * D, ((double)B * L * D * 11 + 4.0 * D * D) * e.esz());
+    LCH(e, launch_enc_attn_fwd(q, e.s));
+    // y2 = norm(x + attention) with the attention output formed from the partial projections
+    used(o); used(x);
+    y2 = e.newt(o->rows, D, B, H, W);
+    float* mr2 = (float*)e.alloc((size_t)2 * o->rows * 4);
+    WORK(e, 0, (double)o->rows * D * e.esz() * (3 + HP));
+    LCH(e, launch_layernorm_parts(parts, HP, (long)B * L * D, a->bout.p, drop_out, (const uint32_t*)(scal(e.m) + SC_SEED), site_out, o->p, x->p, el->norm.w.p,
+                                  el->norm.b.p, y2->p, mr2, o->rows, D, e.s));
+    if (e.rec) {
+      LNp* ln = &el->norm;
+      const long R = o->rows;
+      e.tape.push_back([&e, o, x, y2, ln, mr2, R, D]() {
+        if (!y2->g) return;
+        int ba = 0, bb = 0;
+        void* da = e.grad(o, &ba);
+        void* db = e.grad(x, &bb);
+        WORK(e, 0, (double)R * D * e.esz() * (5 + ba + bb));
+        LCH(e, launch_layernorm_bwd(e.dt, y2->g, o->p, x->p, ln->w.p, mr2, da, db, ba, bb, ln->w.g, ln->b.g, R, D, 0.f, nullptr, 0, e.s));
+      });
+    }
+  } else {
+    Tensor* y1 = op_ln(e, x, nullptr, &el->norm);
+    Tensor* o = mha_self(e, y1, &el->att, B, H * W, 0, nullptr, 0, out_drop);
+    y2 = op_ln(e, o, x, &el->norm);
+  }
   y2->B = B; y2->H = H; y2->W = W;
   Tensor* z = op_quirk(e, y2);
   Tensor* c0 = op_gemm(e, z, &el->conv0, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
@@ -1800,6 +1851,19 @@ size_t model_workspace_bytes(Model* m, int B, int L) {
     Tensor* l2 = decoder_ar(e, s2, B, L, nullptr);
     l2->g = e.alloc((size_t)l2->rows * m->gen.ldb * e.esz());
     e.alloc((size_t)l2->rows * 4);
+    for (auto it = e.tape.rbegin(); it != e.tape.rend(); ++it) (*it)();
+    if (e.peak > train_peak) train_peak = e.peak;
+    e.tape.clear(); e.tens.clear();
+  }
+  // module.eval() semantics WITH gradients (train_step phase + 32: BatchNorm running statistics, the unfused BatchNorm-backward forms):
+  // its backward allocates differently from the training-mode tape (found at bs4 128x384 bf16: "workspace exhausted in backward")
+  {
+    exec_begin(m, nullptr, false, true, true);
+    e.cap = (size_t)1 << 60; e.zcap = m->zero_bytes;
+    Tensor* s3 = encoder_forward(e, nullptr, B);
+    Tensor* l3 = decoder_tf(e, s3, nullptr, B, L, nullptr);
+    l3->g = e.alloc((size_t)l3->rows * m->gen.ldb * e.esz());
+    e.alloc((size_t)l3->rows * 4);
     for (auto it = e.tape.rbegin(); it != e.tape.rend(); ++it) (*it)();
     if (e.peak > train_peak) train_peak = e.peak;
     e.tape.clear(); e.tens.clear();

@@ -165,6 +165,10 @@ struct Exec {
   hipStream_t s = nullptr;
   int dt = 0;
   bool train = false, rec = false, dry = false;
+  // nolaunch: ops allocate their outputs and record their backward closures but launch nothing -- the caller produces the outputs with
+  // ONE fused kernel (encoder self-attention region); the slots below hand it what the ops allocated internally
+  bool nolaunch = false;
+  float* last_mr = nullptr; float* last_lse = nullptr; uint32_t last_site = 0; float last_drop = 0.f;
   bool serial = false;  // no concurrent side stream (hipGraph capture / profiling): side kernels may fill the chip
   float drop = 0.f;
   char* base = nullptr; size_t cap = 0, off = 0, peak = 0;  // bump arena

@@ -103,6 +103,24 @@ struct AttnP {
 void launch_attn(int dt, int mode, const AttnP& p, hipStream_t s);
 size_t attn_lkp(int Lk);  // padded key count used for dS/Pd workspaces
 
+// ---- the encoder's self-attention region as one launch (kernels_encattn.hip): LayerNorm -> q|k|v -> attention -> output projection partials
+struct EncAttnP {
+  const void* x;                                  // [B*L][D] layer input (bf16)
+  const float* ln_w; const float* ln_b;           // the layer's shared LayerNorm
+  const void* wqkv; const float* bqkv;            // fused projection [3D][D] (compute copy), bias [3D]
+  const void* wo;                                 // output projection [D][D]
+  void* y1; float* mr;                            // saved: LayerNorm output [B*L][D], mean | rstd [2 * B*L]
+  void* qkv; void* att; float* lse;               // saved: q|k|v [B*L][3D], attention output [B*L][D], log-sum-exp [B][H][L]
+  void* parts;                                    // [H/2][B*L][D] partial output projections (bias / dropout / sum: launch_layernorm_parts)
+  int B, L, D, H, LkP;
+  float inv_temp, drop_p; const uint32_t* seed; uint32_t site;   // attention-probability dropout (same counter hash as attn_kernel)
+  int dbg;
+};
+bool enc_attn_fused_ok(int dt, int L, int D, int H);
+bool launch_enc_attn_fwd(const EncAttnP& p, hipStream_t s);
+void launch_layernorm_parts(const void* parts, int nparts, long pstride, const float* abias, float drop_p, const uint32_t* seed, uint32_t site, void* a_out,
+                            const void* b, const float* w, const float* bias, void* out, float* mr, long R, int C, hipStream_t s);
+
 // ---- elementwise / reductions (all NHWC, C % (16/sizeof(T)) == 0 unless stated) ------------
 void launch_colstats(int dt, const void* y, long M, int C, float* sums /*[2C], zeroed*/, hipStream_t s);
 void launch_bn_finalize(const float* sums, long M, int C, const float* w, const float* b, float* rm, float* rv,

@@ -1,4 +1,5 @@
 // extern "C" boundary of libsatrn_hip.so (declarations + reference citations: include/satrn_hip.h).
+#include <math.h>
 #include <string.h>
 
 #include <string>
@@ -69,6 +70,21 @@ int satrn_linear_fwd_stats(int dt, const void* x, const void* w, void* y, int M,
   p.stats = stats; p.stats_rep = stats_rep; p.bnb_y = bnb_y; p.bnb_ss = bnb_ss; p.bnb_mr = bnb_mr; p.bnb_act = bnb_act;
   launch_gemm(dt, AM_DENSE, p, S(st));
   return done("linear_fwd_stats");
+}
+int satrn_enc_attn_region_fwd(const void* x, const float* ln_w, const float* ln_b, const void* wqkv, const float* bqkv, const void* wo, const float* bo,
+                              int B, int L, int D, int heads, float attn_drop, float out_drop, const uint32_t* seed, uint32_t site_attn, uint32_t site_out,
+                              void* y1, float* mean_rstd1, void* qkv, void* att, float* lse, void* parts_scratch, void* o, void* y2, float* mean_rstd2,
+                              void* st) {
+  if (!enc_attn_fused_ok(DT_BF16, L, D, heads)) return fail(-1, "satrn_enc_attn_region_fwd: bf16, L <= 64, D in {256, 512}, head_dim 64, even head count");
+  if ((attn_drop > 0.f || out_drop > 0.f) && !seed) return fail(-1, "dropout needs a device seed");
+  EncAttnP q;
+  memset(&q, 0, sizeof(q));
+  q.x = x; q.ln_w = ln_w; q.ln_b = ln_b; q.wqkv = wqkv; q.bqkv = bqkv; q.wo = wo; q.y1 = y1; q.mr = mean_rstd1; q.qkv = qkv; q.att = att; q.lse = lse;
+  q.parts = parts_scratch; q.B = B; q.L = L; q.D = D; q.H = heads; q.LkP = (int)attn_lkp(L); q.inv_temp = 1.0f / sqrtf((float)D);
+  q.drop_p = attn_drop; q.seed = seed; q.site = site_attn;
+  if (!launch_enc_attn_fwd(q, S(st))) return fail(-1, "satrn_enc_attn_region_fwd: launch refused");
+  launch_layernorm_parts(parts_scratch, heads / 2, (long)B * L * D, bo, out_drop, seed, site_out, o, x, ln_w, ln_b, y2, mean_rstd2, (long)B * L, D, S(st));
+  return done("enc_attn_region_fwd");
 }
 int satrn_linear_bwd_data(int dt, const void* dy, int ldy, const void* wb, int ldb, void* dx, int M, int N, int K,
                           int accumulate, void* st) {

@@ -330,6 +330,53 @@ def test_train_autoregressive_branch_with_gradients(dtype):
         assert float(np.median([e_ for e_, _ in errs])) < 1e-3 and worst[0][0] < 3e-2
 
 
+@pytest.mark.parametrize("net,H,W,B", [("eff", 128, 384, 4), ("eff", 64, 96, 3), ("lite", 64, 192, 3)])
+def test_fused_encoder_attention_region_equals_the_four_launches(net, H, W, B):
+    """kernels_encattn.hip (LayerNorm -> q|k|v -> attention -> output-projection partials in ONE launch, partials folded by the LayerNorm
+    behind the block) against the four launches it replaces (SATRN_NO_FUSED_ENC_ATTN=1), bf16, through the whole model.  The operator
+    test (test_ops_gpu.py::test_encoder_attention_region_fused) pins every tensor the kernel writes to fp32 torch; here: (1) eval-mode
+    encoder output, (2) the flat gradient of a step with BatchNorm in running-statistics mode (train_step(bn_eval=True): with BATCH
+    statistics on 4 x 12 maps a bf16 rounding anywhere moves the gradient by tens of percent -- bench.py's accuracy_bf16_vs_f32 -- so two
+    correct forms cannot be compared there), (3) a training step with dropout: both forms draw the same masks (same counter hash, sites
+    and indices), loss and greedy ids of the step agree."""
+    import os
+    cfg = dict(O.CFG_EFF if net == "eff" else O.CFG_LITE)
+    T = 9
+    img, expected = O.det_inputs(B, cfg["rgb"], H, W, T, seed=71, pad_tail=2)
+    imgd, expd = img.cuda(), expected.cuda()
+    res = {}
+    for name, env in (("fused", None), ("four", "1")):
+        if env:
+            os.environ["SATRN_NO_FUSED_ENC_ATTN"] = env
+        else:
+            os.environ.pop("SATRN_NO_FUSED_ENC_ATTN", None)
+        try:
+            model, sd = build(cfg, H, W, "bf16", 9, dropout=0.1)
+            model.eval()
+            src = model.encode(imgd).float().cpu()
+            model.train()
+            model.train_step(imgd, expd, 0.0, phase=1, bn_eval=True)
+            torch.cuda.synchronize()
+            g_eval = model.flat_grad().detach().float().cpu().clone()
+            l_eval = model.read_loss()[0]
+            model.train_step(imgd, expd, 0.0, phase=1)
+            torch.cuda.synchronize()
+            res[name] = (src, g_eval, l_eval, model.read_loss()[0], model.flat_grad().detach().float().cpu().clone())
+        finally:
+            os.environ.pop("SATRN_NO_FUSED_ENC_ATTN", None)
+    (s0, g0, le0, l0, gt0), (s1, g1, le1, l1, gt1) = res["fused"], res["four"]
+    es = (s0 - s1).abs().max().item() / s1.abs().max().item()
+    eg = (g0 - g1).norm().item() / g1.norm().item()
+    cos_t = torch.dot(gt0, gt1).item() / (gt0.norm().item() * gt1.norm().item())
+    print(f"[enc attn region {net} {H}x{W}] encoder output rel err {es:.3e}; running-statistics step: flat gradient rel-L2 {eg:.3e}, loss {le0:.5f} vs {le1:.5f}; "
+          f"training step (batch statistics, dropout): loss {l0:.5f} vs {l1:.5f}, gradient cosine {cos_t:.4f}")
+    assert torch.isfinite(s0).all() and torch.isfinite(g0).all() and torch.isfinite(gt0).all()
+    assert es < 2e-2          # bf16 rounding of the partial sums instead of one f32 accumulation
+    assert eg < 6e-2
+    assert abs(le0 - le1) < 1e-2 and abs(l0 - l1) < 3e-2
+    assert cos_t > (0.95 if net == "lite" else 0.5)   # (batch statistics over 18 rows at 64x96 bs3: see the docstring)
+
+
 def test_fused_train_step_takes_the_autoregressive_branch():
     """train_step(teacher_forced=False / teacher_forcing_ratio < 1 + coin): the fused step (the one dp.dp_train_step and bench.py drive)
     runs the reference's non-teacher-forced branch (networks/EfficientSATRN.py:496-525) -- same gradient as the module-API path that

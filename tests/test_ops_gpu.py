@@ -244,6 +244,46 @@ def test_linear_with_batchnorm_sums(lib, big_gemm_mode, mode, M, N, K, rep, bnb)
         close(tot[1], (g * ((by - mean) * rstd)).sum(0), "f32", "sum g xhat", f32_tol=6e-3)
 
 
+@pytest.mark.parametrize("B,L,D,heads", [(4, 48, 512, 8), (3, 6, 512, 8), (2, 64, 256, 4), (5, 33, 256, 4), (32, 48, 512, 8)])
+def test_encoder_attention_region_fused(lib, B, L, D, heads):
+    """kernels_encattn.hip: LayerNorm -> q|k|v -> attention -> output-projection partials in one launch + the LayerNorm that folds the
+    partials, every saved tensor against fp32 torch (networks/EfficientSATRN.py:260-268, :157-228; temperature sqrt(D))"""
+    dt = "bf16"
+    x = q(rnd(B * L, D, seed=1, scale=2.0), dt)
+    lw, lb = rnd(D, seed=2, scale=0.2) + 1.0, rnd(D, seed=3, scale=0.1)
+    wqkv, bqkv = q(rnd(3 * D, D, seed=4, scale=1.5 / math.sqrt(D)), dt), rnd(3 * D, seed=5, scale=0.1)
+    wo, bo = q(rnd(D, D, seed=6, scale=1.5 / math.sqrt(D)), dt), rnd(D, seed=7, scale=0.1)
+    # reference (f32 math; the tensors the kernel stores in bf16 are rounded where the next stage reads them)
+    y1 = q(F.layer_norm(x, (D,), lw, lb, 1e-5), dt)
+    qkv = q(y1 @ wqkv.t() + bqkv, dt)
+    hd = D // heads
+    Q, K, V = (qkv[:, i * D:(i + 1) * D].view(B, L, heads, hd).transpose(1, 2) for i in range(3))
+    sc = (Q @ K.transpose(-1, -2)) / math.sqrt(D)
+    lse = torch.logsumexp(sc, dim=-1)
+    att = q((q(torch.softmax(sc, dim=-1), dt) @ V).transpose(1, 2).reshape(B * L, D), dt)
+    o = q(att @ wo.t() + bo, dt)
+    y2 = F.layer_norm(o + x, (D,), lw, lb, 1e-5)
+    # device
+    e = lambda *shape: torch.zeros(*shape, dtype=tdt(dt), device="cuda")
+    f = lambda *shape: torch.zeros(*shape, device="cuda")
+    y1d, qkvd, attd, od, y2d, parts = e(B * L, D), e(B * L, 3 * D), e(B * L, D), e(B * L, D), e(B * L, D), e(heads // 2, B * L, D)
+    mr1, mr2, lsed = f(2 * B * L), f(2 * B * L), f(B, heads, L)
+    ok(lib, lib.satrn_enc_attn_region_fwd(P(dev(x, dt)), P(dev(lw)), P(dev(lb)), P(dev(wqkv, dt)), P(dev(bqkv)), P(dev(wo, dt)), P(dev(bo)), B, L, D, heads,
+                                          0.0, 0.0, None, 0, 0, P(y1d), P(mr1), P(qkvd), P(attd), P(lsed), P(parts), P(od), P(y2d), P(mr2), st()))
+    close(y1d, y1, dt, "region y1", bf16_tol=1e-2)
+    mean = x.mean(-1)
+    rstd = 1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-5)
+    close(mr1[:B * L], mean, "f32", "region mean", f32_tol=1e-4)
+    close(mr1[B * L:], rstd, "f32", "region rstd", f32_tol=1e-4)
+    close(qkvd, qkv, dt, "region qkv", bf16_tol=1.5e-2)
+    close(lsed, lse, "f32", "region lse", f32_tol=5e-3)
+    close(attd, att, dt, "region attention output", bf16_tol=2e-2)
+    close(od, o, dt, "region o", bf16_tol=2e-2)
+    close(y2d, y2, dt, "region y2", bf16_tol=2e-2)
+    m2 = (o + x).mean(-1)
+    close(mr2[:B * L], m2, "f32", "region mean2", f32_tol=2e-2)
+
+
 def same_geo(H, W, s):
     if s == 1:
         return H, W, 1, 1, (1, 1, 1, 1)

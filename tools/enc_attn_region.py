@@ -75,6 +75,14 @@ def main():
         ("qkv_projection_bwd_data", 2.0 * M * 3 * D * D, lambda: lib.satrn_linear_bwd_data(dt, P(dqkv), 3 * D, P(wqkv_b), 3 * D, P(dy), M, 3 * D, D, 0, st())),
         ("qkv_projection_bwd_weight", 2.0 * M * 3 * D * D, lambda: lib.satrn_linear_bwd_weight(dt, P(dqkv), 3 * D, P(y), P(dwqkv), P(dbqkv), M, 3 * D, D, st())),
     ]
+    if dt == 1 and B * L > 0:
+        # round 3: the forward half of the region as ONE launch (+ the LayerNorm behind the block, which folds the partial projections)
+        y2, o_full, mr2 = torch.empty(M, D, dtype=tdt, device=dev), torch.empty(M, D, dtype=tdt, device=dev), torch.empty(2 * M, device=dev)
+        parts = torch.empty(H // 2, M, D, dtype=tdt, device=dev)
+        fl_fwd = 2.0 * M * 3 * D * D + 4.0 * B * H * L * L * hd + 2.0 * M * D * D
+        ops.insert(0, ("FUSED_region_fwd (LN + qkv + attention + out-proj partials) + LN(fold)", fl_fwd,
+                       lambda: lib.satrn_enc_attn_region_fwd(P(x), P(lnw), P(lnb), P(wqkv_f), P(bqkv), P(wo_f), P(bo), B, L, D, H, 0.0, 0.0, None, 0, 0, P(y), P(mr), P(qkv),
+                                                             P(att), P(lse), P(parts), P(o_full), P(y2), P(mr2), st())))
     for _, _, f in ops:  # warm-up
         ok(f())
     torch.cuda.synchronize()
