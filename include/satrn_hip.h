@@ -375,6 +375,16 @@ int satrn_model_step(satrn_model* m, const int64_t* target, float* logits, void*
  * [{"kernel", "launches", "ms", "flops", "bytes"}...] (per kernel family, algorithmic flops / bytes) to json_out. */
 int satrn_model_profile_step(satrn_model* m, const float* images, const int64_t* expected, int B, int L, char* json_out,
                              size_t cap, void* stream);
+/* Diagnostics: stage-boundary probes.  With probes enabled, a forward remembers the activation at the end of the stem, of every backbone
+ * stage, of the backbone, of the positional encoding, of every encoder / decoder layer (satrn_model_probe_count / _info: name, rows,
+ * columns; row-major [rows][cols], NHWC for feature maps).  _read casts an activation to fp32 into a caller buffer; a buffer registered
+ * with _set_grad BEFORE the backward receives the gradient wrt that activation (fp32).  tools/bf16_grad_error.py uses this to locate where
+ * the bf16 mode's error against the f32 mode enters. */
+int satrn_model_probe_enable(satrn_model* m, int on);
+int satrn_model_probe_count(satrn_model* m);
+int satrn_model_probe_info(satrn_model* m, int i, const char** name, int64_t* rows, int* cols);
+int satrn_model_probe_read(satrn_model* m, int i, float* out_f32, void* stream);
+int satrn_model_probe_set_grad(satrn_model* m, int i, float* grad_out_f32);
 /* Evaluation-time image transform for a batch of variable-size images in one launch (image half):
  * data/dataset.py:76-81 ([h / w > 2: rotate(90, expand=True)]) + data/augmentations.py:28-44 (A.Resize(H, W) = cv2 INTER_LINEAR
  * on uint8, A.Normalize(mean, std, max_pixel_value = 255), ToTensorV2).  descs: DEVICE array of B records

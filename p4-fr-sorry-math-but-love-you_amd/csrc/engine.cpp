@@ -1615,6 +1615,19 @@ static void bn_eval_prepare(Exec& e) {
 }
 
 Tensor* swin_encoder_forward(Exec& e, const float* img, int B);
+// diagnostics: remember a stage-boundary tensor (satrn_model_probe_enable); its gradient is cast out when the backward passes this point
+static void probe(Exec& e, const std::string& name, Tensor* t) {
+  if (!e.probe_on || e.dry || t->f32) return;
+  e.probes.push_back({name, t, nullptr});
+  if (e.rec) {
+    const size_t idx = e.probes.size() - 1;
+    e.tape.push_back([&e, idx]() {
+      Exec::Probe& pr = e.probes[idx];
+      if (pr.gout && pr.t->g) launch_cast(e.dt, DT_F32, pr.t->g, pr.gout, pr.t->rows * pr.t->C, e.s);
+    });
+  }
+}
+
 Tensor* encoder_forward(Exec& e, const float* img, int B) {
   if (e.m->cfg.network == 2) return swin_encoder_forward(e, img, B);
   if (!e.train && !e.rec) bn_eval_prepare(e);
@@ -1642,10 +1655,14 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
     x = op_stem(e, img, &m->stem, B, c.rgb, c.height, c.width, 2, 0);
     x = op_bn_act(e, x, &m->stem_bn, ACT_SILU, nullptr);
     stage_mark("stem");
+    probe(e, "stem", x);
     for (size_t bi = 0; bi < m->blocks.size(); ++bi) {
       if ((int)bi == m->late_block) m->seg_mark[0] = e.tape.size();
       x = eff_block(e, x, &m->blocks[bi]);
-      if (bi + 1 == m->blocks.size() || m->blocks[bi + 1].cout != m->blocks[bi].cout) stage_mark("cout" + std::to_string(m->blocks[bi].cout));
+      if (bi + 1 == m->blocks.size() || m->blocks[bi + 1].cout != m->blocks[bi].cout) {
+        stage_mark("cout" + std::to_string(m->blocks[bi].cout));
+        probe(e, "backbone_c" + std::to_string(m->blocks[bi].cout), x);
+      }
     }
     int H = x->H, W = x->W;
     x = op_gemm(e, x, &m->conv_last, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
@@ -1653,6 +1670,7 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
     x = op_bn_act(e, x, &m->bn_last, ACT_SILU, nullptr);
   }
   if (x->H != m->feat_h || x->W != m->feat_w) { m->err = "feature map size does not match input_size/32 (or /16)"; e.oom = true; }
+  probe(e, "backbone_out", x);
   m->seg_mark[1] = e.tape.size();  // end of the backbone
   if (c.network == 0) m->seg_mark[0] = 0;
   // adaptive 2D positional encoding (networks/EfficientSATRN.py:135-154)
@@ -1661,7 +1679,8 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
   Tensor* gate = op_gemm(e, h0, &m->pe_d1, &m->pe_b1, ACT_SIGMOID, 0.f, nullptr);
   x = op_posenc_apply(e, x, gate);
   if (g_stage_prof && !e.dry) { e.mark("f:posenc"); if (e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->mark("b:enc_layers"); }); } }
-  for (auto& el : m->enc) x = encoder_layer(e, x, &el);
+  probe(e, "posenc", x);
+  { int li = 0; for (auto& el : m->enc) { x = encoder_layer(e, x, &el); probe(e, "enc_layer" + std::to_string(li++), x); } }
   if (g_stage_prof && !e.dry) { e.mark("f:enc_layers"); if (e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->mark("b:decoder"); }); } }
   // inference postpones products until their BatchNorm is known (op_gemm / op_dwconv -> op_bn_act): none may be left over
   for (auto& t : e.tens)
@@ -1784,6 +1803,7 @@ Tensor* decoder_tf(Exec& e, Tensor* src, const int64_t* expected, int B, int L, 
   const SatrnConfig& c = m->cfg;
   const int T = L - 1, Dd = c.dec_hidden, Nsrc = (int)(src->rows / B);
   Tensor* t = op_embed(e, expected, L, B, T, 0, e.drop);
+  probe(e, "dec_embed", t);
   for (auto& dl : m->dec) {
     Tensor* o = mha_self(e, t, &dl.self_att, B, T, 1, expected, L, e.drop);
     Tensor* t1 = op_ln(e, o, t, &dl.ln1);
@@ -1796,6 +1816,7 @@ Tensor* decoder_tf(Exec& e, Tensor* src, const int64_t* expected, int B, int L, 
     Tensor* f0 = op_gemm(e, t2, &dl.lin0, &dl.b0, ACT_RELU, e.drop > 0.f ? fp : 0.f, nullptr);
     Tensor* f1 = op_gemm(e, f0, &dl.lin1, &dl.b1, ACT_RELU, e.drop > 0.f ? fp : 0.f, nullptr);
     t = op_ln(e, f1, t2, &dl.ln3);
+    probe(e, "dec_layer" + std::to_string(&dl - &m->dec[0]), t);
   }
   return op_gemm(e, t, &m->gen, &m->gen_b, ACT_NONE, 0.f, nullptr, 0, true, logits_out);
 }
@@ -1820,6 +1841,7 @@ static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) 
   det_activate(m);
   e.s = s; e.dt = m->cfg.dtype; e.train = train; e.rec = rec; e.dry = dry;
   e.drop = train ? m->cfg.dropout : 0.f;
+  e.probes.clear(); e.probe_on = m->probe_on;
   if (!e.dry && e.zbase && e.zoff > m->zero_hwm) m->zero_hwm = e.zoff;  // what the previous call dirtied at most
   e.reset(m->ws + m->persist_bytes, m->ws_bytes > m->persist_bytes ? m->ws_bytes - m->persist_bytes : 0,
           m->ws + m->off_zero, m->zero_bytes);
@@ -2473,5 +2495,29 @@ int model_greedy(Model* m, const float* img, const float* src_in, int B, int ste
   }
   (void)hipStreamSynchronize(s);
   if (hipGraphLaunch(m->decode_graph, s) != hipSuccess) { m->err = "decode graph launch failed"; return -3; }
+  return 0;
+}
+
+// ---- probes (diagnostics) ------------------------------------------------------------------------------------------------
+int model_probe_count(Model* m) { return (int)m->ex->probes.size(); }
+int model_probe_info(Model* m, int i, const char** name, int64_t* rows, int* cols) {
+  Exec& e = *m->ex;
+  if (i < 0 || i >= (int)e.probes.size()) { m->err = "probe index out of range"; return -1; }
+  if (name) *name = e.probes[i].name.c_str();
+  if (rows) *rows = e.probes[i].t->rows;
+  if (cols) *cols = e.probes[i].t->C;
+  return 0;
+}
+int model_probe_read(Model* m, int i, float* out_f32, hipStream_t s) {
+  Exec& e = *m->ex;
+  if (i < 0 || i >= (int)e.probes.size() || !out_f32) { m->err = "probe index out of range"; return -1; }
+  Tensor* t = e.probes[i].t;
+  launch_cast(e.dt, DT_F32, t->p, out_f32, t->rows * t->C, s);
+  return 0;
+}
+int model_probe_set_grad(Model* m, int i, float* gout_f32) {
+  Exec& e = *m->ex;
+  if (i < 0 || i >= (int)e.probes.size()) { m->err = "probe index out of range"; return -1; }
+  e.probes[i].gout = gout_f32;
   return 0;
 }

@@ -149,6 +149,7 @@ struct Model {
   // which decoder produced the last greedy result: 0 none yet, 1 role pipeline, 2 one workgroup per image, 3 step-wise launches;
   // pipe_giveups counts pipelines that timed out and were re-run on another kernel (never silently: see decode_note)
   int last_decode_path = 0, pipe_giveups = 0; std::string decode_note;
+  bool probe_on = false;
   std::string err;
 };
 
@@ -167,6 +168,11 @@ struct Exec {
   bool train = false, rec = false, dry = false;
   // nolaunch: ops allocate their outputs and record their backward closures but launch nothing -- the caller produces the outputs with
   // ONE fused kernel (encoder self-attention region); the slots below hand it what the ops allocated internally
+  // probes (diagnostics, satrn_model_probe_*): tensors at the stage boundaries of the last forward; gout != null -> the backward casts
+  // the tensor's gradient into it (fp32) at the moment the tape passes the probe point (later the buffer may be aliased by another
+  // tensor's gradient)
+  struct Probe { std::string name; Tensor* t; float* gout; };
+  std::vector<Probe> probes; bool probe_on = false;
   bool nolaunch = false;
   float* last_mr = nullptr; float* last_lse = nullptr; uint32_t last_site = 0; float last_drop = 0.f;
   bool serial = false;  // no concurrent side stream (hipGraph capture / profiling): side kernels may fill the chip
@@ -220,3 +226,7 @@ int model_step_begin(Model* m, const float* src, int B, int max_steps, hipStream
 int model_step(Model* m, const int64_t* target, float* logits_out, hipStream_t s);
 int model_profile_step(Model* m, const float* img, const int64_t* expected, int B, int L, char* out, size_t out_cap,
                        hipStream_t s);
+int model_probe_count(Model* m);
+int model_probe_info(Model* m, int i, const char** name, int64_t* rows, int* cols);
+int model_probe_read(Model* m, int i, float* out_f32, hipStream_t s);
+int model_probe_set_grad(Model* m, int i, float* gout_f32);

@@ -519,6 +519,11 @@ int satrn_model_greedy_forced(satrn_model* h, const float* img, const float* src
   if (!forced_ids) return fail(-1, "satrn_model_greedy_forced: forced_ids is null");
   return mret(h, model_greedy(h->m, img, src, B, steps, logits, ids, 0, S(st), nullptr, forced_ids), "greedy_forced");
 }
+int satrn_model_probe_enable(satrn_model* h, int on) { if (!h || !h->m) return -1; h->m->probe_on = on != 0; return 0; }
+int satrn_model_probe_count(satrn_model* h) { return (h && h->m) ? model_probe_count(h->m) : -1; }
+int satrn_model_probe_info(satrn_model* h, int i, const char** name, int64_t* rows, int* cols) { return mret(h, model_probe_info(h->m, i, name, rows, cols), "probe_info"); }
+int satrn_model_probe_read(satrn_model* h, int i, float* out_f32, void* st) { return mret(h, model_probe_read(h->m, i, out_f32, S(st)), "probe_read"); }
+int satrn_model_probe_set_grad(satrn_model* h, int i, float* gout_f32) { return mret(h, model_probe_set_grad(h->m, i, gout_f32), "probe_set_grad"); }
 int satrn_model_last_decode_path(satrn_model* h, int* giveups_out) {
   if (!h || !h->m) return -1;
   if (giveups_out) *giveups_out = h->m->pipe_giveups;

@@ -480,6 +480,39 @@ class _SATRNBase(nn.Module):
         warm[0] = True
         return slog.clone(), sids.clone()
 
+    # ------------------------------------------------------------------ diagnostics: stage-boundary probes
+    def enable_probes(self, on=True):
+        """the next forwards remember the activation at every stage boundary (read with probes()) and, for buffers registered by
+        probe_grads() before the backward, the gradient wrt it"""
+        check(self._lib.satrn_model_probe_enable(self._h, int(on)), "probe_enable")
+
+    def _probe_info(self):
+        out = []
+        name, rows, cols = ctypes.c_char_p(), ctypes.c_int64(), ctypes.c_int()
+        for i in range(self._lib.satrn_model_probe_count(self._h)):
+            check(self._lib.satrn_model_probe_info(self._h, i, ctypes.byref(name), ctypes.byref(rows), ctypes.byref(cols)), "probe_info")
+            out.append((name.value.decode(), rows.value, cols.value))
+        return out
+
+    def probes(self):
+        """-> {name: fp32 tensor [rows, cols]}: the stage-boundary activations of the last forward"""
+        res = {}
+        for i, (name, rows, cols) in enumerate(self._probe_info()):
+            t = torch.empty(rows, cols, dtype=torch.float32, device=self._bound)
+            check(self._lib.satrn_model_probe_read(self._h, i, ptr(t), _stream()), "probe_read")
+            res[name] = t
+        return res
+
+    def probe_grads(self):
+        """call between forward and backward: -> {name: fp32 tensor} that the backward fills with d loss / d activation"""
+        res = {}
+        for i, (name, rows, cols) in enumerate(self._probe_info()):
+            t = torch.zeros(rows, cols, dtype=torch.float32, device=self._bound)
+            check(self._lib.satrn_model_probe_set_grad(self._h, i, ptr(t)), "probe_set_grad")
+            res[name] = t
+        self._probe_keep = res
+        return res
+
     def set_coin(self, coin):
         """source of the per-batch teacher-forcing coin (anything with .random() -> [0, 1)); None = Python's global `random`,
         as the reference (networks/EfficientSATRN.py:489).  Data-parallel ranks pass dp.SharedCoin(seed)."""
