@@ -1161,12 +1161,20 @@ Tensor* op_attn(Exec& e, Tensor* qt, int qoff, Tensor* kvt, int koff, int voff, 
     e.tape.push_back([&e, qt, qoff, kvt, koff, voff, o, p, B, Lq, Lk, heads, hd, D, es]() {
       if (!o->g) return;
       const size_t LkP = attn_lkp(Lk);
-      void* dS = e.alloc((size_t)B * heads * Lq * LkP * es);
-      void* Pd = e.alloc((size_t)B * heads * Lq * LkP * es);
       int bq = 0, bkv = 0;
       void* dq = e.grad(qt, &bq);
       void* dkv = qt == kvt ? dq : e.grad(kvt, &bkv);  // K/V shared by several attention calls (step decoder): accumulate
       (void)bq;
+      if (attn2_ok(e.dt, p)) {
+        // short sequences: dQ, dK, dV finished inside one workgroup per (batch, head) -- no dS / Pd tensors, no batched products
+        AttnP q = p;
+        q.dO = o->g; q.dQ = (char*)dq + qoff * es; q.dK = (char*)dkv + koff * es; q.dV = (char*)dkv + voff * es; q.kv_accum = bkv;
+        WORK(e, 14.0 * (double)B * heads * Lq * Lk * hd, ((double)B * Lq * D * 4 + (double)B * Lk * D * 4) * es);
+        LCH(e, launch_attn2_bwd(q, e.s));
+        return;
+      }
+      void* dS = e.alloc((size_t)B * heads * Lq * LkP * es);
+      void* Pd = e.alloc((size_t)B * heads * Lq * LkP * es);
       AttnP q = p;
       q.dO = o->g; q.dQ = (char*)dq + qoff * es; q.dS = dS; q.Pd = Pd;
       // reads q, k, v, o, dO; writes dQ and the two [B, heads, Lq, LkP] probability / score-gradient tensors
@@ -1317,12 +1325,24 @@ Tensor* op_window_attn(Exec& e, Tensor* qkv, SwinBlock* sb, int B_, const float*
     e.tape.push_back([&e, qkv, o, sb, p, B_, N, C, heads, hd, es]() {
       if (!o->g) return;
       const size_t LkP = attn_lkp(N);
-      void* dS = e.alloc((size_t)B_ * heads * N * LkP * es);
-      void* Pd = e.alloc((size_t)B_ * heads * N * LkP * es);
       int bq = 0;
       void* dq = e.grad(qkv, &bq);
       if (bq) { e.m->err = "internal: qkv tensor has two consumers"; e.oom = true; return; }
+      void* dS = e.alloc((size_t)B_ * heads * N * LkP * es);
+      const bool fused = attn2_ok(e.dt, p);
+      if (fused) {
+        // dQ, dK and dV in one launch (kernels_attn2.hip); it also leaves the raw-score gradient for the table gradient below
+        AttnP q = p;
+        q.dO = o->g; q.dQ = dq; q.dK = (char*)dq + (size_t)C * es; q.dV = (char*)dq + (size_t)2 * C * es; q.kv_accum = 0; q.dS = dS;
+        static const bool hist = getenv("SATRN_A2_HIST") != nullptr;   // the in-kernel LDS histogram instead (measured slower)
+        if (hist) { q.dS = nullptr; q.drel = sb->rpb.g; }
+        WORK(e, 14.0 * (double)B_ * heads * N * N * hd, ((double)B_ * N * C * 8 + (double)B_ * heads * N * LkP) * es);
+        LCH(e, launch_attn2_bwd(q, e.s));
+        if (hist) return;
+      }
+      void* Pd = fused ? nullptr : e.alloc((size_t)B_ * heads * N * LkP * es);
       AttnP q = p;
+      if (!fused) {
       q.dO = o->g; q.dQ = dq; q.dS = dS; q.Pd = Pd;
       WORK(e, 6.0 * (double)B_ * heads * N * N * hd, ((double)B_ * N * C * 6 + 2.0 * B_ * heads * N * LkP) * es);
       LCH(e, launch_attn(e.dt, 1, q, e.s));
@@ -1337,6 +1357,7 @@ Tensor* op_window_attn(Exec& e, Tensor* qkv, SwinBlock* sb, int B_, const float*
       WORK(e, 2.0 * (double)B_ * heads * N * N * hd, ((double)B_ * heads * N * LkP + 2.0 * B_ * N * C) * es);
       w.dY = dS; w.A = qkv->p; w.lda = 3 * C; w.sA_o = (long)N * 3 * C; w.sA_i = hd; w.dW = (char*)dq + (size_t)C * es;    // dK = dS^T Q
       LCH(e, launch_wgrad(e.dt, w, e.s));
+      }
       // d table: dS (gradient of the raw q k^T product) summed over the windows = inv_temp * d bias; optimizer-only -> side stream
       float* dbias = e.zalloc((size_t)heads * N * LkP);
       {

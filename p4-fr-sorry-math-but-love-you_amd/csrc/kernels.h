@@ -97,11 +97,18 @@ struct AttnP {
   // relative_position_bias_table parameter [(2*rel_ws-1)^2][H] (fp32), token i of a window sits at (i / rel_ws, i % rel_ws);
   // labels [nW][Lq] = region id of every token of every window of the shifted map (mask = -100 where two ids differ; null = none)
   const float* rel_table; int rel_ws; const unsigned char* labels;
+  // fused backward (kernels_attn2.hip, launch_attn2_bwd): dK / dV are finished inside the workgroup (same strides as K / V; kv_accum: add to the
+  // existing values), drel (optional, fp32 [(2 rel_ws - 1)^2][H]) receives the relative-position-table gradient with atomics
+  void* dK; void* dV; int kv_accum; float* drel; int dbg;
   int q_pos0;              // step mode: absolute position of query row 0 (causal uses q_pos0 + i)
   long sq_b, sk_b, sv_b, so_b;  // batch strides (elements) of Q / K / V / O(dO,dQ use sq_b/so_b)
 };
 void launch_attn(int dt, int mode, const AttnP& p, hipStream_t s);
 size_t attn_lkp(int Lk);  // padded key count used for dS/Pd workspaces
+// register-resident attention for short sequences (kernels_attn2.hip; bf16, Lq <= 144, Lk <= 160, head_dim 32 / 64); false = not taken
+bool attn2_ok(int dt, const AttnP& p);
+bool launch_attn2_fwd(const AttnP& p, hipStream_t s);
+bool launch_attn2_bwd(const AttnP& p, hipStream_t s);   // needs Q, K, V, O, lse, dO -> dQ, dK, dV (+ drel)
 
 // ---- the encoder's self-attention region as one launch (kernels_encattn.hip): LayerNorm -> q|k|v -> attention -> output projection partials
 struct EncAttnP {

@@ -321,6 +321,7 @@ static int launch_attn_t(const AttnP& p, hipStream_t s) {
 }
 
 int launch_attn_checked(int dt, int mode, const AttnP& p, hipStream_t s) {
+  if (mode == 0 && dt == DT_BF16 && launch_attn2_fwd(p, s)) return 0;   // short sequences: the register-resident kernel (kernels_attn2.hip)
   if (dt == DT_BF16) return mode == 0 ? launch_attn_t<bf16_t, 0>(p, s) : launch_attn_t<bf16_t, 1>(p, s);
   return mode == 0 ? launch_attn_t<float, 0>(p, s) : launch_attn_t<float, 1>(p, s);
 }

@@ -368,6 +368,9 @@ int satrn_attention_bwd(int dt, const void* q, const void* k, const void* v, con
   const size_t es = dt == DT_BF16 ? 2 : 4;
   const size_t LkP = attn_lkp(Lk);
   p.O = (void*)o; p.lse = (float*)lse; p.dO = d_o; p.dQ = dq; p.dS = ws; p.Pd = (char*)ws + (size_t)B * heads * Lq * LkP * es;
+  // short sequences (bf16): dQ, dK and dV in ONE launch, no dS / Pd workspace traffic (kernels_attn2.hip)
+  p.dK = dk; p.dV = dv; p.kv_accum = 0;
+  if (dt == DT_BF16 && launch_attn2_bwd(p, S(st))) return done("attention_bwd");
   if (launch_attn_checked(dt, 1, p, S(st))) return fail(-1, "attention: unsupported shape (Lk <= 256, head_dim <= 64, LDS fit)");
   WgradP w;
   memset(&w, 0, sizeof(w));

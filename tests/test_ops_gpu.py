@@ -676,7 +676,9 @@ def ref_attention(qh, kh, vh, temp, mask):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,H,Lq,Lk,hd,causal,pad", [(2, 8, 48, 48, 64, 0, 0), (2, 8, 37, 37, 32, 1, 1), (2, 8, 128, 128, 32, 1, 1),
                                                      (3, 4, 37, 48, 32, 0, 0), (4, 8, 1, 5, 32, 0, 0), (2, 4, 6, 6, 8, 1, 1),
-                                                     (2, 8, 230, 230, 32, 1, 0)])
+                                                     (2, 8, 230, 230, 32, 1, 0),
+                                                     # the register-resident kernel's limits (bf16: Lq <= 144, Lk <= 160, head_dim 32 / 64)
+                                                     (3, 4, 144, 144, 32, 0, 0), (2, 4, 144, 160, 64, 1, 1), (2, 2, 100, 17, 64, 0, 0), (2, 4, 16, 33, 32, 0, 1)])
 def test_attention(lib, dt, B, H, Lq, Lk, hd, causal, pad):
     D = H * hd
     # fused projection layout: q|k|v column slices of one [B, L, 3D] buffer when Lq == Lk
