@@ -1097,6 +1097,20 @@ Tensor* op_posenc_apply(Exec& e, Tensor* x, Tensor* gate) {
   return y;
 }
 
+// LayerNorm backward: dx on the main stream; the per-block (dw | dbias) partials are folded on the side stream (optimizer-only sums)
+static void ln_backward(Exec& e, const void* dy, const void* a, const void* b, LNp* ln, const float* mr, void* da, void* db, int ba, int bb,
+                        long R, int C) {
+  const int g = layernorm_bwd_blocks(R);
+  float* part = (float*)e.alloc((size_t)g * 2 * C * sizeof(float));
+  LCH(e, launch_layernorm_bwd(e.dt, dy, a, b, ln->w.p, mr, da, db, ba, bb, ln->w.g, ln->b.g, R, C, 0.f, nullptr, 0, e.s, part));
+  float* dw = ln->w.g; float* dbias = ln->b.g;
+  if (e.prof || e.dry) {
+    LCH(e, launch_layernorm_fold(part, g, C, dw, dbias, e.s));
+  } else {
+    e.defer([=](hipStream_t s2) { launch_layernorm_fold(part, g, C, dw, dbias, s2); });
+  }
+}
+
 Tensor* op_ln(Exec& e, Tensor* a, Tensor* b, LNp* ln) {
   used(a); used(b);
   const long R = a->rows;
@@ -1113,8 +1127,7 @@ Tensor* op_ln(Exec& e, Tensor* a, Tensor* b, LNp* ln) {
       void* da = e.grad(a, &ba);
       void* db = b ? e.grad(b, &bb) : nullptr;
       WORK(e, 0, (double)R * C * e.esz() * ((b ? 5 : 3) + ba + (b ? bb : 0)));
-      LCH(e, launch_layernorm_bwd(e.dt, y->g, a->p, b ? b->p : nullptr, ln->w.p, mr, da, db, ba, bb, ln->w.g, ln->b.g, R, C,
-                                  0.f, nullptr, 0, e.s));
+      ln_backward(e, y->g, a->p, b ? b->p : nullptr, ln, mr, da, db, ba, bb, R, C);
     });
   return y;
 }
@@ -1495,7 +1508,7 @@ Tensor* encoder_layer(Exec& e, Tensor* x, EncLayer* el) {
         void* da = e.grad(o, &ba);
         void* db = e.grad(x, &bb);
         WORK(e, 0, (double)R * D * e.esz() * (5 + ba + bb));
-        LCH(e, launch_layernorm_bwd(e.dt, y2->g, o->p, x->p, ln->w.p, mr2, da, db, ba, bb, ln->w.g, ln->b.g, R, D, 0.f, nullptr, 0, e.s));
+        ln_backward(e, y2->g, o->p, x->p, ln, mr2, da, db, ba, bb, R, D);
       });
     }
   } else {

@@ -209,7 +209,12 @@ void launch_layernorm(int dt, const void* a, const void* b_or_null, const float*
                       uint32_t site, hipStream_t s);
 void launch_layernorm_bwd(int dt, const void* dout, const void* a, const void* b_or_null, const float* w,
                           const float* mean_rstd, void* da, void* db_or_null, int beta_a, int beta_b, float* dw,
-                          float* dbias, long R, int C, float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s);
+                          float* dbias, long R, int C, float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s,
+                          float* part_ws = nullptr);
+// part_ws != null: [layernorm_bwd_blocks(R)][2][C] floats receive per-block (dw | dbias) partials instead of atomics; fold them with
+// launch_layernorm_fold (any stream ordered after the backward kernel)
+int layernorm_bwd_blocks(long R);
+void launch_layernorm_fold(const float* part, int nblocks, int C, float* dw, float* dbias, hipStream_t s);
 void launch_reshape_quirk(int dt, int inverse, const void* in, void* out, int B, int HW, int C, int beta, hipStream_t s);
 void launch_embed(int dt, const int64_t* ids, const float* table, const float* pe, void* out, int B, int L, int ld_ids,
                   int D, int pos0, float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s, int nrows = 0);

@@ -1680,18 +1680,28 @@ void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw, float
 }
 
 // ---- LayerNorm: one wave per row ----------------------------------------------------------------------
-template <typename T, int NCH>
+// RPW rows share a wave when a row has at most 64 / RPW chunks (SwinTRN's 96- and 192-channel stages would otherwise leave 52 / 40 of the
+// 64 lanes idle): G = 64 / RPW lanes per row, reductions stay inside the G-lane group.
+template <int G>
+DEVI float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int NCH, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* a, const T* b, const float* w, const float* bias,
                                                         T* out, float* mr, long R, int C, float eps) {
   constexpr int CH = TT<T>::CH;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int G = 64 / RPW;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane / G, l = lane % G;
   const int CC = C / CH;
-  for (long r = (long)blockIdx.x * 4 + wv; r < R; r += (long)gridDim.x * 4) {
+  for (long r = ((long)blockIdx.x * 4 + wv) * RPW + sub; r < R; r += (long)gridDim.x * 4 * RPW) {
     float v[NCH][CH];
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      int c = lane + k * 64;
+      int c = l + k * G;
       if (c < CC) {
         unpack<T>(ld16(a + r * C + c * CH), v[k]);
         if (b) {
@@ -1704,21 +1714,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* a, const T* b, 
         for (int j = 0; j < CH; ++j) sum += v[k][j];
       }
     }
-    float mean = wave_sum(sum) / (float)C;
+    float mean = group_sum<G>(sum) / (float)C;
     float sq = 0.f;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      int c = lane + k * 64;
+      int c = l + k * G;
       if (c < CC) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) { float d = v[k][j] - mean; sq += d * d; }
       }
     }
-    float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
-    if (lane == 0 && mr) { mr[r] = mean; mr[R + r] = rstd; }
+    float rstd = rsqrtf(group_sum<G>(sq) / (float)C + eps);
+    if (l == 0 && mr) { mr[r] = mean; mr[R + r] = rstd; }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      int c = lane + k * 64;
+      int c = l + k * G;
       if (c < CC) {
         float o[CH];
 #pragma unroll
@@ -1728,33 +1738,29 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* a, const T* b, 
     }
   }
 }
+#define LN_GO(NCH, RPW) hipLaunchKernelGGL((layernorm_kernel<T, NCH, RPW>), dim3(grid_for(R, 4 * RPW, 2048)), dim3(256), 0, s, (const T*)a, \
+                                           (const T*)b, w, bias, (T*)out, mr, R, C, eps)
 void launch_layernorm(int dt, const void* a, const void* b, const float* w, const float* bias, void* out, float* mr,
                       long R, int C, float eps, float, const uint32_t*, uint32_t, hipStream_t s) {
   DISPATCH_T(dt, {
     int cc = C / TT<T>::CH;
-    int g = grid_for(R, 4, 2048);
-    if (cc <= 64)
-      hipLaunchKernelGGL((layernorm_kernel<T, 1>), dim3(g), dim3(256), 0, s, (const T*)a, (const T*)b, w, bias, (T*)out,
-                         mr, R, C, eps);
-    else if (cc <= 128)
-      hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(g), dim3(256), 0, s, (const T*)a, (const T*)b, w, bias, (T*)out,
-                         mr, R, C, eps);
-    else if (cc <= 256)
-      hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(g), dim3(256), 0, s, (const T*)a, (const T*)b, w, bias, (T*)out,
-                         mr, R, C, eps);
-    else  // up to 512 chunks per row (SwinTRN patch merging normalises 4*512 channels: 512 chunks in f32)
-      hipLaunchKernelGGL((layernorm_kernel<T, 8>), dim3(g), dim3(256), 0, s, (const T*)a, (const T*)b, w, bias, (T*)out,
-                         mr, R, C, eps);
+    if (cc <= 16) LN_GO(1, 4);
+    else if (cc <= 32) LN_GO(1, 2);
+    else if (cc <= 64) LN_GO(1, 1);
+    else if (cc <= 128) LN_GO(2, 1);
+    else if (cc <= 256) LN_GO(4, 1);
+    else LN_GO(8, 1);  // up to 512 chunks per row (SwinTRN patch merging normalises 4*512 channels: 512 chunks in f32)
   });
 }
 
-template <typename T, int NCH>
+template <typename T, int NCH, int RPW>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const T* a, const T* b, const float* w,
                                                             const float* mr, T* da, T* db, int beta_a, int beta_b,
                                                             float* dw, float* dbias, long R, int C, float* part) {
   constexpr int CH = TT<T>::CH;
+  constexpr int G = 64 / RPW;
   extern __shared__ float red[];  // [4 waves][2][C]
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane / G, l = lane % G;
   const int CC = C / CH;
   float gw[NCH][CH], gb[NCH][CH];
 #pragma unroll
@@ -1769,7 +1775,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
     q.mean = mr[r]; q.rstd = mr[R + r];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      const int c = lane + k * 64;
+      const int c = l + k * G;
       if (c < CC) {
         q.xa[k] = ld16(a + r * C + c * CH);
         if (b) q.xb[k] = ld16(b + r * C + c * CH);
@@ -1779,8 +1785,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
       }
     }
   };
-  const long rstep = (long)gridDim.x * 4;
-  long r = (long)blockIdx.x * 4 + wv;
+  const long rstep = (long)gridDim.x * 4 * RPW;
+  long r = ((long)blockIdx.x * 4 + wv) * RPW + sub;
   RowRaw cur, nxt;
   if (r < R) load_row(r, cur);
   for (; r < R; r += rstep) {
@@ -1790,7 +1796,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      int c = lane + k * 64;
+      int c = l + k * G;
       if (c < CC) {
         float d[CH];
         unpack<T>(cur.xa[k], xh[k]);
@@ -1812,11 +1818,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
         }
       }
     }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
+    s1 = group_sum<G>(s1) / (float)C;
+    s2 = group_sum<G>(s2) / (float)C;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      int c = lane + k * 64;
+      int c = l + k * G;
       if (c < CC) {
         float o[CH], t[CH];
 #pragma unroll
@@ -1843,11 +1849,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
     }
     cur = nxt;
   }
-  // the four waves' partials go to their own LDS slots and are added in a fixed order
+  // the rows that shared a wave first (fixed order), then the four waves' partials through their own LDS slots
+  if (RPW > 1) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+#pragma unroll
+      for (int o = G; o < 64; o <<= 1) { gw[0][j] += __shfl_xor(gw[0][j], o, 64); gb[0][j] += __shfl_xor(gb[0][j], o, 64); }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
-    int c = lane + k * 64;
-    if (c < CC) {
+    int c = l + k * G;
+    if (c < CC && sub == 0) {
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         red[wv * 2 * C + c * CH + j] = gw[k][j];
@@ -1858,31 +1871,56 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     const float a = ((red[i] + red[2 * C + i]) + red[4 * C + i]) + red[6 * C + i];
-    if (part) part[(size_t)blockIdx.x * 2 * C + i] = a;   // deterministic mode: folded afterwards
+    if (part) part[(size_t)blockIdx.x * 2 * C + i] = a;   // partial rows: folded afterwards in block order
     else atomicAdd((i < C ? dw : dbias - C) + i, a);
   }
 }
+// Weight / bias gradient partials folded off the critical path: with `part_ws` ([layernorm_bwd_blocks(R, C)][2][C] floats, the caller's)
+// the kernel leaves one plain-stored partial row per block instead of 2*C contended atomics per block (512 blocks on 768 addresses cost
+// half of the kernel's 30 us at [9216][384]), and launch_layernorm_fold adds them in block order -- on whichever stream the caller likes
+// (the engine: the side stream, the sums feed only the optimizer).
+int layernorm_bwd_blocks(long R) { return grid_for(R, 16, 1024); }
+
+__global__ __launch_bounds__(256) void layernorm_fold_kernel(const float* part, int nrep, int n, int C, float* dw, float* dbias) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (i < n) {
+    int r = wv;
+    for (; r + 12 < nrep; r += 16) {
+      a0 += part[(size_t)r * n + i]; a1 += part[(size_t)(r + 4) * n + i]; a2 += part[(size_t)(r + 8) * n + i]; a3 += part[(size_t)(r + 12) * n + i];
+    }
+    for (; r < nrep; r += 4) a0 += part[(size_t)r * n + i];
+  }
+  red[wv][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wv == 0 && i < n) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (i < C) dw[i] += t; else dbias[i - C] += t;
+  }
+}
+void launch_layernorm_fold(const float* part, int nblocks, int C, float* dw, float* dbias, hipStream_t s) {
+  hipLaunchKernelGGL(layernorm_fold_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, s, part, nblocks, 2 * C, C, dw, dbias);
+}
+
+#define LNB_GO(NCH, RPW) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, RPW>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a, \
+                                            (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part)
 void launch_layernorm_bwd(int dt, const void* dout, const void* a, const void* b, const float* w, const float* mr,
                           void* da, void* db, int beta_a, int beta_b, float* dw, float* dbias, long R, int C, float,
-                          const uint32_t*, uint32_t, hipStream_t s) {
+                          const uint32_t*, uint32_t, hipStream_t s, float* part_ws) {
   DISPATCH_T(dt, {
     int cc = C / TT<T>::CH;
-    int g = grid_for(R, 16, 512);
+    int g = part_ws ? layernorm_bwd_blocks(R) : grid_for(R, 16, 512);
     size_t sh = (size_t)8 * C * sizeof(float);
-    float* part = det_scratch(s, (size_t)g * 2 * C);
-    if (cc <= 64)
-      hipLaunchKernelGGL((layernorm_bwd_kernel<T, 1>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a,
-                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part);
-    else if (cc <= 128)
-      hipLaunchKernelGGL((layernorm_bwd_kernel<T, 2>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a,
-                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part);
-    else if (cc <= 256)
-      hipLaunchKernelGGL((layernorm_bwd_kernel<T, 4>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a,
-                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part);
-    else
-      hipLaunchKernelGGL((layernorm_bwd_kernel<T, 8>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a,
-                         (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part);
-    if (part) { launch_fold(part, g, 2L * C, C, dw, s); launch_fold(part + C, g, 2L * C, C, dbias, s); }
+    float* part = part_ws ? part_ws : det_scratch(s, (size_t)g * 2 * C);
+    if (cc <= 16) LNB_GO(1, 4);
+    else if (cc <= 32) LNB_GO(1, 2);
+    else if (cc <= 64) LNB_GO(1, 1);
+    else if (cc <= 128) LNB_GO(2, 1);
+    else if (cc <= 256) LNB_GO(4, 1);
+    else LNB_GO(8, 1);
+    if (part && !part_ws) { launch_fold(part, g, 2L * C, C, dw, s); launch_fold(part + C, g, 2L * C, C, dbias, s); }
   });
 }
 

@@ -639,7 +639,8 @@ def test_maxpool(lib, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("R,C,two", [(100, 256, True), (1536, 512, True), (7, 32, False), (300, 1024, False)])
+@pytest.mark.parametrize("R,C,two", [(100, 256, True), (1536, 512, True), (7, 32, False), (300, 1024, False),
+                                       (1001, 96, False), (530, 192, True)])   # the last two: several rows per wave
 def test_layernorm(lib, dt, R, C, two):
     a = q(rnd(R, C, seed=1), dt)
     b = q(rnd(R, C, seed=2), dt) if two else None
