@@ -75,6 +75,7 @@ DEVI float act_bwd(float u, int act) {
   if (act == ACT_SILU) { float s = sigmoidf_(u); return s * (1.f + u * (1.f - s)); }
   if (act == ACT_SIGMOID) { float s = sigmoidf_(u); return s * (1.f - s); }
   if (act == ACT_GELU) return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+  if (act == ACT_DFACTOR) return u;   // the stored value is the derivative itself
   return 1.f;
 }
 

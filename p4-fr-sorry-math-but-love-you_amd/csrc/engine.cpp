@@ -713,9 +713,10 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
   p.M = (int)M; p.N = N; p.K = w->K; p.lda = x->C; p.ldc = N;
   p.act = act; p.out_f32 = out_f32 ? 1 : 0; p.drop_p = drop_p; p.seed = seed; p.site = site;
   if (act == ACT_GELU && e.rec && !geo && !out_f32 && !out_ptr) {
-    // GELU's derivative needs the pre-activation: the epilogue stores both (product + activation pass in one launch)
-    y->act_pre = e.alloc((size_t)M * N * e.esz()); y->act_kind = act;
-    p.pre_out = y->act_pre;
+    // GELU's derivative needs the pre-activation -- but only through act'(u), which the epilogue has almost for free beside the
+    // activation itself: that factor is what is kept (product + activation pass in one launch, the backward multiplies)
+    y->act_pre = e.alloc((size_t)M * N * e.esz()); y->act_kind = ACT_DFACTOR;
+    p.pre_out = y->act_pre; p.pre_grad = 1;
   }
   if (act == ACT_RELU && e.rec && !geo && !out_f32 && !out_ptr) {
     // ReLU (+dropout): the derivative is read off the stored output (zeros = clipped or dropped), no second tensor needed
@@ -751,7 +752,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       if (act == ACT_RELU) { if (!y->g_preact) LCH(e, launch_act_bwd(e.dt, dY, y->p, dY, M * N, ACT_RELU, drop_p, e.s)); }
       else if (act == ACT_GELU) {
         if (!y->act_pre) { e.m->err = "internal: GELU epilogue without its pre-activation"; e.oom = true; return; }
-        if (!y->g_preact) LCH(e, launch_act_bwd(e.dt, dY, y->act_pre, dY, M * N, ACT_GELU, 0.f, e.s));   // else: the consumer's dgrad epilogue did it
+        if (!y->g_preact) LCH(e, launch_act_bwd(e.dt, dY, y->act_pre, dY, M * N, ACT_DFACTOR, 0.f, e.s));   // else: the consumer's dgrad epilogue did it
       }
       else if (act == ACT_SIGMOID) LCH(e, launch_act_bwd(e.dt, dY, y->p, dY, M * N, ACT_SIGMOID, 0.f, e.s));
       else if (drop_p > 0.f) LCH(e, launch_dropout_bwd(e.dt, dY, dY, M, N, drop_p, seed, site, e.s));

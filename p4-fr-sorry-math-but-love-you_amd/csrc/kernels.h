@@ -25,7 +25,8 @@ static inline float* det_scratch(hipStream_t s, size_t need_floats) {
 // out[i] += sum_{r < nrep} part[r * stride + i]  (r ascending), i < n
 void launch_fold(const float* part, int nrep, long stride, long n, float* out, hipStream_t s);
 enum { AM_DENSE = 0, AM_CONV = 1, AM_DGRAD = 2 };
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3, ACT_GELU = 4 /*exact erf form, nn.GELU (networks/SWIN.py:29)*/ };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3, ACT_GELU = 4 /*exact erf form, nn.GELU (networks/SWIN.py:29)*/,
+       ACT_DFACTOR = 5 /*backward only: the stored tensor already IS act'(u) (GemmP::pre_grad)*/ };
 
 // C[M,N] = act(gatherA[M,K] * Bw[N,K]^T + bias) (+dropout) (+= if beta)
 struct GemmP {
@@ -49,6 +50,10 @@ struct GemmP {
   // bact_u != null -> the output is multiplied by act'(bact_u[row][col]) (bact = its kind): a data gradient that arrives at an
   // activation's output leaves as the gradient of its input (the separate act-backward pass disappears).  Row stride of both = ldc.
   void* pre_out; const void* bact_u; int bact;
+  // pre_grad: pre_out receives act'(u) instead of u -- the backward needs u only through that factor, and the forward epilogue has the
+  // erf / exp of it in hand already (GELU: the dgrad epilogue's derivative pass, 55 us of VALU work on four waves per CU at
+  // [9216][1536], becomes one multiply); the consumer then passes bact = ACT_DFACTOR
+  int pre_grad;
   float bact_scale;   // times this (ReLU + dropout: bact_u is the stored OUTPUT, whose zeros cover both, and 1/(1-p) the kept ones' scale); 0 = 1
 };
 // eval-mode BatchNorm scale / shift of every BatchNorm of a model in ONE launch: out[0..C) = w * rsqrt(rv + eps),

@@ -2082,7 +2082,7 @@ __global__ void act_bwd_kernel(const T* dz, const T* zu, T* du, long n, int act,
     float d = to_f(dz[i]), z = to_f(zu[i]), r;
     if (act == ACT_RELU) r = z > 0.f ? d * keep_inv : 0.f;
     else if (act == ACT_SIGMOID) r = d * z * (1.f - z);
-    else if (act == ACT_SILU || act == ACT_GELU) r = d * act_bwd(z, act);   // zu holds the PRE-activation
+    else if (act == ACT_SILU || act == ACT_GELU || act == ACT_DFACTOR) r = d * act_bwd(z, act);   // zu holds the PRE-activation (DFACTOR: the derivative)
     else r = d;
     du[i] = from_f<T>(r);
   }

@@ -283,7 +283,11 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
         if (row >= p.M || col >= p.N || !writer) continue;
         const long o = (long)row * p.ldc + col;
         float v = acc[i][j][r] * esc + esh + bias;
-        if (p.pre_out) { const T pre = from_f<T>(v); ((T*)p.pre_out)[o] = pre; v = to_f(pre); }   // the activation pass would have read the stored value
+        if (p.pre_out) {   // the activation pass would have read the stored (rounded) value
+          const T pre = from_f<T>(v);
+          v = to_f(pre);
+          ((T*)p.pre_out)[o] = p.pre_grad ? from_f<T>(act_bwd(v, p.act)) : pre;
+        }
         v = act_fwd(v, p.act);
         if (p.bact_u) v *= act_bwd(to_f(((const T*)p.bact_u)[o]), p.bact) * (p.bact_scale != 0.f ? p.bact_scale : 1.f);
         if (p.drop_p > 0.f) v *= drop_scale(seed, p.site, (uint32_t)(row * p.N + col), p.drop_p);

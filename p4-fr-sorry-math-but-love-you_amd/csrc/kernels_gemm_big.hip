@@ -35,7 +35,7 @@ struct BigP {
   const float* bias;
   bf16_t* pre_out; const bf16_t* bact_u;
   int M, N, K, lda, ldc;
-  int act, bact, beta;
+  int act, bact, beta, pre_grad;
   float bact_scale;
   int ntm, ntn, ntiles;
   unsigned a_bytes, w_bytes, c_bytes;   // buffer extents for the range check
@@ -92,8 +92,18 @@ DEVI i32x4 make_rsrc(const void* base, unsigned bytes) {
 // Synchronisation: ONE s_barrier per k-step, joined by all eight waves.  A loader arrives when its pieces of stage t + 1 have
 // landed (counted vmcnt), a consumer when its last fragment read of stage t has returned; behind the barrier the loaders refill
 // the slot of stage t with stage t + 3 and the consumers start reading stage t + 1.
-template <int MTW, bool HAS_BIAS, bool HAS_AUX /*pre_out / bact_u / beta*/, int STATS = 0 /*1 BatchNorm statistics, 2 BatchNorm-backward sums*/>
+// EK, the epilogue kind, is a template parameter because the epilogue is unrolled over the wave tile's 2 * MTW row groups: every
+// run-time branch in it is replicated 2 * MTW times, and the all-purpose form (EK 1: any activation, any derivative, accumulate) is an
+// 34 K-instruction kernel whose epilogue ran 3x slower than its arithmetic (SwinTRN fc1 + GELU 73 us, fc2's data gradient 90 us
+// against 22-25 us for the plain product).  The two forms the training step uses all the time get lean code of their own:
+//   EK 0  no second tensor (activation by run-time switch, GELU through gelu_fast)
+//   EK 1  all-purpose: pre_out / bact_u / beta in any combination
+//   EK 2  GELU + its derivative stored beside it (pre_out with pre_grad; networks/SWIN.py:24-47 fc1)
+//   EK 3  times a stored factor: bact_u with ACT_DFACTOR (the stored derivative) or ACT_RELU (sign of the stored output, x bact_scale);
+//         the factor loads run four row groups ahead of their use (one dependent round trip per group otherwise)
+template <int MTW, bool HAS_BIAS, int EK, int STATS = 0 /*1 BatchNorm statistics, 2 BatchNorm-backward sums*/>
 __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
+  constexpr bool HAS_AUX = EK == 1;
   constexpr int NT = 4, HM = MTW / 2;
   constexpr int BM = 32 * MTW, BN = 128;
   constexpr int TM = 16 * MTW;                                    // rows per consumer wave
@@ -244,6 +254,16 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { bsc[e] = t0[e]; bsc[4 + e] = t1[e]; bsh[e] = t2[e]; bsh[4 + e] = t3[e]; bmu[e] = t4[e]; bmu[4 + e] = t5[e]; brs[e] = t6[e]; brs[4 + e] = t7[e]; }
     }
+    auto out_off = [&](int n) {   // byte offset of this lane's 16 bytes in row group n = 2 i + h (8 rows each); out of range: dropped
+      const int row = tm * BM + wm * TM + n * 8 + e_row;
+      return (row < p.M && col < p.N) ? (unsigned)(((long)row * p.ldc + col) * 2) : 0xfffffff0u;
+    };
+    constexpr int UQ = 4;
+    u32x4_t uq[EK == 3 ? UQ : 1];
+    if constexpr (EK == 3) {
+#pragma unroll
+      for (int n = 0; n < UQ; ++n) uq[n] = __builtin_amdgcn_raw_buffer_load_b128(rU, (int)out_off(n), 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
       const unsigned eW = eW0 + (unsigned)(i & 1) * 2048u;
@@ -259,22 +279,60 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
         uint4 v = lds_read16(eW + (unsigned)rl * 128u + (unsigned)(lane & 7) * 16u);
         const int row = tm * BM + wm * TM + i * 16 + rl;
         const unsigned o = (row < p.M && col < p.N) ? (unsigned)(((long)row * p.ldc + col) * 2) : 0xfffffff0u;   // out of range: dropped
-        if (HAS_AUX || STATS || p.act != ACT_NONE) {
+        if constexpr (EK == 2) {
+          // GELU and its derivative from one erf / exp evaluation; the derivative is what the backward keeps
+          float f[8], d[8];
+          unpack<bf16_t>(v, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float ex;
+            const float P = gelu_core(f[e], &ex);
+            d[e] = __builtin_fmaf(f[e] * 0.3989422804014327f, ex, P);
+            f[e] *= P;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(to_u32x4(pack<bf16_t>(d)), rP, (int)o, 0, 0);
+          v = pack<bf16_t>(f);
+        } else if constexpr (EK == 3) {
+          float f[8], u[8];   // (the row group index 2 * i + h is a compile-time constant under the unrolling)
+          unpack<bf16_t>(v, f);
+          unpack<bf16_t>(from_u32x4(uq[(2 * i + h) % UQ]), u);
+          if (2 * i + h + UQ < 2 * MTW) uq[(2 * i + h) % UQ] = __builtin_amdgcn_raw_buffer_load_b128(rU, (int)out_off(2 * i + h + UQ), 0, 0);
+          const float sc = p.bact_scale != 0.f ? p.bact_scale : 1.f;
+          if (p.bact == ACT_DFACTOR) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= u[e] * sc;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = u[e] > 0.f ? f[e] * sc : 0.f;
+          }
+          v = pack<bf16_t>(f);
+        } else if (HAS_AUX || STATS || p.act != ACT_NONE) {
           float f[8];
           unpack<bf16_t>(v, f);
-          if (HAS_AUX && p.pre_out) __builtin_amdgcn_raw_buffer_store_b128(to_u32x4(v), rP, (int)o, 0, 0);
-          if (p.act == ACT_GELU) {
+          if (HAS_AUX && p.pre_out && !p.pre_grad) __builtin_amdgcn_raw_buffer_store_b128(to_u32x4(v), rP, (int)o, 0, 0);
+          if (HAS_AUX && p.pre_out && p.pre_grad) {
+            float d[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { d[e] = act_bwd(f[e], p.act); f[e] = act_fwd(f[e], p.act); }
+            __builtin_amdgcn_raw_buffer_store_b128(to_u32x4(pack<bf16_t>(d)), rP, (int)o, 0, 0);
+          } else if (p.act == ACT_GELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = gelu_fast(f[e]);
-          } else if (p.act != ACT_NONE) {
+          } else if (p.act == ACT_RELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = act_fwd(f[e], p.act);
+            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+          } else if (p.act != ACT_NONE) {   // SiLU / sigmoid (not through act_fwd: its erff branch would be unrolled in here too)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float sg = sigmoidf_(f[e]); f[e] = p.act == ACT_SILU ? f[e] * sg : sg; }
           }
           if (HAS_AUX && p.bact_u) {
             float u[8];
             unpack<bf16_t>(from_u32x4(__builtin_amdgcn_raw_buffer_load_b128(rU, (int)o, 0, 0)), u);
             const float sc = p.bact_scale != 0.f ? p.bact_scale : 1.f;
-            if (p.bact == ACT_GELU) {
+            if (p.bact == ACT_DFACTOR) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] *= u[e] * sc;
+            } else if (p.bact == ACT_GELU) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) f[e] *= gelu_grad_fast(u[e]) * sc;
             } else {
@@ -625,15 +683,23 @@ static void big_launch_t(const BigP& p, int grid, hipStream_t s) {
   constexpr int MTW = 2 * MT;
   constexpr size_t sh = (size_t)BIG_NSTAGE * (64 * MT + 128) * BIG_ROWB + 4 * 4096;
   const bool aux = p.pre_out || p.bact_u || p.beta;
-#define BIG_GO(HB, HA, ST) do { \
+  // epilogue kind (see the kernel): the two lean forms when nothing else is asked for, the all-purpose one otherwise
+  const bool ek2 = p.pre_out && p.pre_grad && p.act == ACT_GELU && !p.bact_u && !p.beta && !p.stats;
+  const bool ek3 = p.bact_u && (p.bact == ACT_DFACTOR || p.bact == ACT_RELU) && !p.pre_out && !p.beta && !p.stats && p.act == ACT_NONE;
+#define BIG_GO(HB, EKIND, ST) do { \
     static bool attr = false; \
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_big_kernel<MTW, HB, HA, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
-    hipLaunchKernelGGL((gemm_big_kernel<MTW, HB, HA, ST>), dim3(grid), dim3(BIG_THREADS), sh, s, p); } while (0)
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_big_kernel<MTW, HB, EKIND, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
+    hipLaunchKernelGGL((gemm_big_kernel<MTW, HB, EKIND, ST>), dim3(grid), dim3(BIG_THREADS), sh, s, p); } while (0)
   // the statistics forms keep 16 (sums) / 48 (+ BatchNorm coefficients) more registers: tiles of at most 192 / 128 rows
-  if constexpr (MT <= 2) { if (p.stats && p.bnb_y) { BIG_GO(false, true, 2); return; } }
-  if constexpr (MT <= 3) { if (p.stats && !p.bnb_y) { BIG_GO(false, true, 1); return; } }
-  if (p.bias) { if (aux) BIG_GO(true, true, 0); else BIG_GO(true, false, 0); }
-  else { if (aux) BIG_GO(false, true, 0); else BIG_GO(false, false, 0); }
+  if constexpr (MT <= 2) { if (p.stats && p.bnb_y) { if (aux) BIG_GO(false, 1, 2); else BIG_GO(false, 0, 2); return; } }
+  if constexpr (MT <= 3) { if (p.stats && !p.bnb_y) { if (aux) BIG_GO(false, 1, 1); else BIG_GO(false, 0, 1); return; } }
+  // (the forms with a second tensor in the epilogue -- pre_out / bact_u / beta -- spill at 256-row tiles: at most 192 rows, as the statistics forms)
+  if constexpr (MT <= 3) {
+    if (ek2) { if (p.bias) BIG_GO(true, 2, 0); else BIG_GO(false, 2, 0); return; }
+    if (ek3) { if (p.bias) BIG_GO(true, 3, 0); else BIG_GO(false, 3, 0); return; }
+    if (aux) { if (p.bias) BIG_GO(true, 1, 0); else BIG_GO(false, 1, 0); return; }
+  }
+  if (p.bias) BIG_GO(true, 0, 0); else BIG_GO(false, 0, 0);
 #undef BIG_GO
 }
 
@@ -659,7 +725,7 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
   BigP p;
   p.A = (const bf16_t*)g.A; p.W = (const bf16_t*)g.Bw; p.C = (bf16_t*)g.C; p.bias = g.bias;
   p.pre_out = (bf16_t*)g.pre_out; p.bact_u = (const bf16_t*)g.bact_u;
-  p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldc = g.ldc; p.act = g.act; p.bact = g.bact; p.beta = g.beta; p.bact_scale = g.bact_scale;
+  p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldc = g.ldc; p.act = g.act; p.bact = g.bact; p.beta = g.beta; p.bact_scale = g.bact_scale; p.pre_grad = g.pre_grad;
   p.a_bytes = (unsigned)(((size_t)(g.M - 1) * g.lda + g.K) * 2);
   p.w_bytes = (unsigned)((size_t)g.N * g.K * 2);
   p.c_bytes = (unsigned)(((size_t)(g.M - 1) * g.ldc + g.N) * 2);
@@ -670,16 +736,18 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
   const int cus = big_cu_count();
   // tile height: the candidate whose tile count leaves the smallest idle share in the last round of the persistent grid
   const int force_mt = getenv("SATRN_GEMM_BIG_MT") ? atoi(getenv("SATRN_GEMM_BIG_MT")) : 0;
-  int best_mt = 4;
+  int best_mt = 3;
   double best_cost = 1e30;
-  for (int mt = (g.bnb_y ? 2 : (g.stats ? 3 : 4)); mt >= 2; --mt) {
+  const bool aux_form = g.pre_out || g.bact_u || g.beta;
+  const int mt_max = g.bnb_y ? 2 : ((g.stats || aux_form) ? 3 : 4);
+  for (int mt = mt_max; mt >= 2; --mt) {
     const long tiles = (long)((g.M + 64 * mt - 1) / (64 * mt)) * p.ntn;
     const long rounds = (tiles + cus - 1) / cus;
     // cost ~ rounds x (rows per tile + a fixed per-tile part worth ~48 rows: epilogue + the wider share of W traffic of flat tiles)
     const double cost = (double)rounds * (64.0 * mt + 48.0);
     if (cost < best_cost) { best_cost = cost; best_mt = mt; }
   }
-  if (force_mt >= 2 && force_mt <= (g.bnb_y ? 2 : (g.stats ? 3 : 4))) best_mt = force_mt;
+  if (force_mt >= 2 && force_mt <= mt_max) best_mt = force_mt;
   p.ntm = (g.M + 64 * best_mt - 1) / (64 * best_mt);
   p.ntiles = p.ntm * p.ntn;
   const int grid = p.ntiles < cus ? p.ntiles : cus;
@@ -719,13 +787,23 @@ bool wgrad_big_launch(const WgradP& w, hipStream_t s) {
   const int tiles = p.ntn * p.ntk;
   // slices of M: enough items to fill the persistent grid (at least 256 rows per slice)
   int target = w.full_grid ? cus : (getenv("SATRN_WGRAD_BIG_ITEMS") ? atoi(getenv("SATRN_WGRAD_BIG_ITEMS")) : cus);
-  int splits = (target + tiles - 1) / tiles;
+  // Slices of M: the persistent grid runs its items in rounds, so what counts is rounds x (k-steps per item + the item's fixed part, its
+  // 16 K atomics ~ 3 k-steps) -- not merely "at least one item per CU": 36 tiles x 8 slices = 288 items on 256 CUs cost two rounds of 18
+  // k-steps where 7 slices (252 items) cost one round of 21 (SwinTRN fc1 / fc2 at M = 9 216: 55 -> 3x us).
   const int max_splits = (w.M + 255) / 256;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  int rps = (w.M + splits - 1) / splits;
-  rps = ((rps + 63) / 64) * 64;
-  splits = (w.M + rps - 1) / rps;
+  int splits = 1, rps = ((w.M + 63) / 64) * 64;
+  {
+    double best = 1e30;
+    for (int sp = 1; sp <= max_splits; ++sp) {
+      int r = (w.M + sp - 1) / sp;
+      r = ((r + 63) / 64) * 64;
+      const int sp2 = (w.M + r - 1) / r;
+      const long items = (long)tiles * sp2;
+      const long rounds = (items + target - 1) / target;
+      const double cost = (double)rounds * (r / 64 + 3.0);
+      if (cost < best - 1e-9) { best = cost; splits = sp2; rps = r; }
+    }
+  }
   p.splits = splits; p.rows_per_split = rps; p.nitems = tiles * splits;
   const int grid = p.nitems < target ? p.nitems : target;
   if (tall) wgrad_big_go<8, false>(p, grid, s);

@@ -24,6 +24,8 @@ if os.environ.get('SATRN_SHAPES'):   # the large dense products of the Efficient
     SHAPES = [(98304, 192, 48), (98304, 48, 192), (98304, 96, 48), (24576, 256, 64), (24576, 64, 256), (6144, 960, 160), (6144, 512, 128), (4096, 1024, 256), (4096, 256, 1024), (4096, 768, 256), (2304, 4096, 1024), (2304, 1024, 4096), (36864, 256, 1024), (147456, 384, 128)]
 if os.environ.get('LATE_SHAPES'):    # small-grid products of the late backbone stages, the encoder and the decoder
     SHAPES = [(1536, 1536, 256), (1536, 256, 1536), (6144, 960, 160), (6144, 160, 960), (6144, 512, 128), (6144, 128, 512), (1536, 1536, 512), (1536, 512, 512), (1536, 512, 1536), (4096, 768, 256), (4096, 256, 256), (4096, 1024, 256), (4096, 256, 1024), (4096, 245, 256)]
+if os.environ.get('SHAPES'):         # SHAPES="9216,1536,384;9216,384,1536"
+    SHAPES = [tuple(int(v) for v in t.split(',')) for t in os.environ['SHAPES'].split(';')]
 for M, N, K in SHAPES:
     x = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16(); w = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
     y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)

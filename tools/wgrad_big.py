@@ -21,8 +21,12 @@ def bench(fn, iters=50):
 
 SHAPES = [(9216, 2048, 512), (9216, 512, 2048), (9216, 1536, 512), (9216, 512, 512), (36864, 1024, 256), (36864, 256, 1024), (36864, 768, 256),
           (147456, 512, 128), (147456, 128, 512), (147456, 384, 128), (2304, 4096, 1024), (2304, 1024, 4096), (4096, 1024, 256), (6144, 960, 160), (1536, 1536, 256)]
+if os.environ.get('SHAPES'):         # SHAPES="9216,1536,384;9216,384,1536"
+    SHAPES = [tuple(int(v) for v in t.split(',')) for t in os.environ['SHAPES'].split(';')]
+WITH_BIAS = bool(os.environ.get('WITH_BIAS'))   # also the bias gradient (the form the training step's linears take)
 for M, N, K in SHAPES:
     x = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16(); dy = (torch.rand(M, N, device="cuda") * 2 - 1).bfloat16()
     dw = torch.zeros(N, K, device="cuda")
-    us = bench(lambda: lib.satrn_linear_bwd_weight(1, P(dy), N, P(x), P(dw), None, M, N, K, st()))
+    db = torch.zeros(N, device="cuda") if WITH_BIAS else None
+    us = bench(lambda: lib.satrn_linear_bwd_weight(1, P(dy), N, P(x), P(dw), P(db) if WITH_BIAS else None, M, N, K, st()))
     print(f"M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TFLOP/s  blocks={os.environ.get('SATRN_WGRAD_BLOCKS','96')} ms128={'off' if os.environ.get('SATRN_WGRAD_NO_MS128') else 'on'}")
