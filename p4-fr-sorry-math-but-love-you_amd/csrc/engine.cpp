@@ -494,6 +494,11 @@ Model* model_create(const SatrnConfig& cfg) {
     m->det_floats = (size_t)8 << 20;
     m->off_det = take(2 * m->det_floats * sizeof(float));
   }
+  if (cfg.dtype == DT_BF16 && !m->det_floats) {
+    // partial tiles of one launch of the persistent weight-gradient kernel: at most one 128 x 128 fp32 tile per item, CU-count items (+ slack)
+    m->wgpart_floats = (size_t)320 * 128 * 128;
+    m->off_wgpart = take(2 * m->wgpart_floats * sizeof(float));
+  }
   m->zero_bytes = 40u << 20;
   m->off_zero = take(m->zero_bytes);
   m->persist_bytes = (o + 255) & ~(size_t)255;
@@ -1869,6 +1874,11 @@ static void det_activate(Model* m) {
   g_det.scratch[1] = g_det.on ? (float*)(m->ws + m->off_det) + m->det_floats : nullptr;
   g_det.side = m->ex ? m->ex->s2 : nullptr;
   g_wgrad_dense_blocks = m->cfg.network == 2 ? 160 : 0;
+  const bool wp = m->wgpart_floats && m->ws;
+  g_wgpart.cap = wp ? m->wgpart_floats : 0;
+  g_wgpart.scratch[0] = wp ? (float*)(m->ws + m->off_wgpart) : nullptr;
+  g_wgpart.scratch[1] = wp ? (float*)(m->ws + m->off_wgpart) + m->wgpart_floats : nullptr;
+  g_wgpart.side = m->ex ? m->ex->s2 : nullptr;
 }
 
 static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) {

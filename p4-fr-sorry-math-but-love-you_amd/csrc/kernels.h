@@ -16,6 +16,13 @@ extern DetCtx g_det;
 // workgroups a dense weight-gradient launch aims for on the side stream (0 = the default, 96); set per engine call like g_det:
 // SwinTRN's products are 10-40x larger than EfficientSATRN's and its chain leaves more of the chip free (160: 31.8 -> 30.7 ms/step)
 extern int g_wgrad_dense_blocks;
+// Partial-tile slabs of the persistent weight-gradient kernel (kernels_gemm_big.hip): with a slab its items store their fp32 partial
+// tiles [slice][N][K] with plain stores and a fold launch adds the slices in order -- instead of items x 16 K float atomics, which
+// inside a training step (gradient buffers cold) cost as much as the product itself.  Two slabs like g_det (chain, side stream);
+// the engine points them into its workspace per call, operator-level C-ABI calls keep the atomic form (cap = 0).
+struct WgPartCtx { float* scratch[2] = {nullptr, nullptr}; size_t cap = 0 /*floats per slab*/; hipStream_t side = nullptr; };
+extern WgPartCtx g_wgpart;
+void launch_fold4(const float* part, int nrep, long stride, long n, float* out, hipStream_t s);   // launch_fold with 16-byte accesses (n, stride % 4 == 0)
 void det_overflow_warn(size_t need_floats);
 static inline float* det_scratch(hipStream_t s, size_t need_floats) {
   if (!g_det.on) return nullptr;

@@ -23,6 +23,7 @@ DEVI void lds8(const float* p, float* o) {   // 8 floats from LDS / memory throu
 }
 
 DetCtx g_det;
+WgPartCtx g_wgpart;
 void det_overflow_warn(size_t need_floats) {
   static bool once = false;
   if (!once) { once = true; fprintf(stderr, "[satrn] deterministic-reduction scratch too small (%zu floats needed, %zu available): this reduction falls back to float atomics\n", need_floats, g_det.cap); }
@@ -39,6 +40,43 @@ void launch_fold(const float* part, int nrep, long stride, long n, float* out, h
   long g = (n + 255) / 256;
   if (g > 1024) g = 1024;
   hipLaunchKernelGGL(fold_kernel, dim3((int)g), dim3(256), 0, s, part, nrep, stride, n, out);
+}
+
+// G slice groups per column quad: many slices of a small matrix (SwinTRN stage 1: 256 slices of 96 x 96) would otherwise be a handful of
+// threads walking hundreds of dependent-free but serial loads each; the groups' sums meet in LDS in group order (fixed order: deterministic)
+template <int G>
+__global__ __launch_bounds__(256) void fold4_kernel(const float4* part, int nrep, long stride4, long n4, float4* out) {
+  constexpr int CPB = 256 / G;   // column quads per block
+  __shared__ float4 red[G][CPB];
+  const int c = threadIdx.x % CPB, g = threadIdx.x / CPB;
+  const long i = (long)blockIdx.x * CPB + c;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    const int per = (nrep + G - 1) / G, r0 = g * per, r1 = min(nrep, r0 + per);
+    for (int r = r0; r < r1; ++r) { const float4 v = part[(size_t)r * stride4 + i]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+  }
+  if (G > 1) {
+    red[g][c] = a;
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+      for (int q = 1; q < G; ++q) { const float4 v = red[q][c]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    }
+  }
+  if (g == 0 && i < n4) {
+    float4 o = out[i];
+    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    out[i] = o;
+  }
+}
+void launch_fold4(const float* part, int nrep, long stride, long n, float* out, hipStream_t s) {
+  if (n <= 0 || nrep <= 0) return;
+  const long n4 = n / 4;
+  // enough blocks for the chip, few enough slices per thread
+  const int G = (nrep >= 32 || n4 < 32768) ? (nrep >= 8 ? 16 : 4) : (nrep >= 8 && n4 < 131072 ? 4 : 1);
+  if (G == 16) hipLaunchKernelGGL(fold4_kernel<16>, dim3((int)((n4 + 15) / 16)), dim3(256), 0, s, (const float4*)part, nrep, stride / 4, n4, (float4*)out);
+  else if (G == 4) hipLaunchKernelGGL(fold4_kernel<4>, dim3((int)((n4 + 63) / 64)), dim3(256), 0, s, (const float4*)part, nrep, stride / 4, n4, (float4*)out);
+  else hipLaunchKernelGGL(fold4_kernel<1>, dim3((int)((n4 + 255) / 256)), dim3(256), 0, s, (const float4*)part, nrep, stride / 4, n4, (float4*)out);
 }
 
 static inline int grid_for(long work, int per_block = 256, int cap = 4096) {

@@ -449,6 +449,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
 // =========================================================================================
 struct BigWP {
   const bf16_t* Y; const bf16_t* X; float* dW; float* dbias;
+  float* part;   // null: fp32 atomics into dW; else the items' partial tiles go to part[slice][N][K] (plain stores; folded by the launcher)
   int M, N, K, ldy, lda, ldw;
   int ntn, ntk, nitems, splits, rows_per_split;   // rows_per_split: a multiple of 64
   unsigned y_bytes, x_bytes;
@@ -462,7 +463,10 @@ DEVI uint2 lds_read_tr8(unsigned addr) {
 }
 
 // NTW: 16-row MFMA tiles per consumer wave along n (output tile = 32 * NTW rows of dW x 128 columns)
-template <int NTW, bool DBIAS>
+// NS: ring depth.  The bytes in flight per CU (NS - 1 stages) over the memory latency are the per-CU bandwidth: with three 32 KB stages the
+// kernel ran at 34 GB/s per CU inside the training step (activations from the forward pass come from HBM, not from the cache-warm loop of
+// a microbenchmark: 55 us against 32 us for the same shape), so the 128-row form takes a fourth stage (128 KB of LDS).
+template <int NTW, bool DBIAS, int NS>
 __global__ __launch_bounds__(BIG_THREADS, 2) void wgrad_big_kernel(BigWP p) {
   constexpr int KTW = 4, HN = NTW / 2;
   constexpr int BNo = 32 * NTW, BKo = 128;
@@ -529,21 +533,29 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void wgrad_big_kernel(BigWP p) {
       }
       if (++d_k == KT) { d_k = 0; ++d_item; if (d_item < my_items) dma_item_setup(d_item); }
     };
+    constexpr int P = NYP + NXP;   // DMA instructions per loader wave and stage
+    static_assert(NS == 3 || NS == 4, "ring depth");
+    static_assert((NS - 1) * P <= 63, "vmcnt is a 6-bit counter");
     dma_item_setup(0);
     dma_issue(0);
     if (1 < T) dma_issue(1);
     if (2 < T) dma_issue(2);
-    if (T >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NYP + NXP)) : "memory");
-    else if (T == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NYP + NXP) : "memory");
+    if (NS > 3 && 3 < T) dma_issue(3);
+    // stage 0 landed: all but the stages requested after it
+    if (NS > 3 && T >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * P) : "memory");
+    else if (T >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    else if (T == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int slot = 0;
     for (int t = 0; t < T; ++t) {
-      if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NYP + NXP) : "memory");
+      // stage t + 1 landed (the stages behind it, at most NS - 2 of them, may stay in flight)
+      if (NS > 3 && t + 3 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+      else if (t + 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (t + BIG_NSTAGE < T) dma_issue(slot);
-      slot = slot == 2 ? 0 : slot + 1;
+      if (t + NS < T) dma_issue(slot);
+      slot = slot == NS - 1 ? 0 : slot + 1;
     }
     return;
   }
@@ -617,7 +629,10 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void wgrad_big_kernel(BigWP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n = nb + i * 16 + r;
-          if (n < p.N && k < p.K) atomicAdd(p.dW + (size_t)n * p.ldw + k, acc[i][j][r]);
+          if (n < p.N && k < p.K) {
+            if (p.part) p.part[((size_t)sp * p.N + n) * p.K + k] = acc[i][j][r];
+            else atomicAdd(p.dW + (size_t)n * p.ldw + k, acc[i][j][r]);
+          }
         }
       }
     if (DBIAS && do_bias && fr == 0) {
@@ -637,7 +652,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void wgrad_big_kernel(BigWP p) {
   read_x(0, 0, bK0);
   int c_item = 0, c_k = 0, slot = 0;
   for (int t = 0; t < T; ++t) {
-    const int slot1 = slot == 2 ? 0 : slot + 1;
+    const int slot1 = slot == NS - 1 ? 0 : slot + 1;
     const bool last_k = c_k == KT - 1;
     read_y(slot, 0, 1, aY);
     read_x(slot, 1, bK1);
@@ -759,10 +774,11 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
 
 template <int NTW, bool DB>
 static void wgrad_big_go(const BigWP& p, int grid, hipStream_t s) {
-  constexpr size_t sh = (size_t)BIG_NSTAGE * 64 * (32 * NTW * 2 + 256);
+  constexpr int NS = NTW <= 4 ? 4 : 3;   // 4 x 32 KB or 3 x 48 KB
+  constexpr size_t sh = (size_t)NS * 64 * (32 * NTW * 2 + 256);
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_big_kernel<NTW, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
-  hipLaunchKernelGGL((wgrad_big_kernel<NTW, DB>), dim3(grid), dim3(BIG_THREADS), sh, s, p);
+  if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_big_kernel<NTW, DB, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
+  hipLaunchKernelGGL((wgrad_big_kernel<NTW, DB, NS>), dim3(grid), dim3(BIG_THREADS), sh, s, p);
 }
 
 // dense bf16 weight gradient (fp32 atomics into dW, optional bias gradient); true = launched
@@ -781,7 +797,9 @@ bool wgrad_big_launch(const WgradP& w, hipStream_t s) {
   p.x_bytes = (unsigned)(((size_t)(w.M - 1) * w.lda + w.K) * 2);
   p.dbg = getenv("SATRN_BIG_DBG") ? atoi(getenv("SATRN_BIG_DBG")) : 0;
   const int cus = big_cu_count();
-  const bool tall = w.N > 128 && !w.dbias;      // 256-row tiles; the bias-gradient form keeps NTW more accumulators and takes 128-row tiles
+  // 256-row tiles only where the output alone fills the grid: an item's partial tile leaves as fp32 atomics (1.3 TB/s over the chip), so
+  // with slices of M the atomic bytes are items x tile -- the tall form doubles them (9216 x 1536 x 384: 40 us against 32 us with 128 rows)
+  const bool tall = w.N > 128 && !w.dbias && (long)((w.N + 255) / 256) * ((w.K + 127) / 128) >= cus;
   const int bno = tall ? 256 : 128;
   p.ntn = (w.N + bno - 1) / bno; p.ntk = (w.K + 127) / 128;
   const int tiles = p.ntn * p.ntk;
@@ -805,9 +823,15 @@ bool wgrad_big_launch(const WgradP& w, hipStream_t s) {
     }
   }
   p.splits = splits; p.rows_per_split = rps; p.nitems = tiles * splits;
+  // partial tiles instead of atomics when a slab is there (engine calls) and there is something to fold
+  p.part = nullptr;
+  const size_t need = (size_t)splits * w.N * w.K;
+  if (splits > 1 && g_wgpart.cap >= need && p.ldw == w.K && (((size_t)w.N * w.K) & 3) == 0 && !getenv("SATRN_WGRAD_BIG_ATOMICS"))
+    p.part = g_wgpart.scratch[(g_wgpart.side && s == g_wgpart.side) ? 1 : 0];
   const int grid = p.nitems < target ? p.nitems : target;
   if (tall) wgrad_big_go<8, false>(p, grid, s);
   else if (w.dbias) wgrad_big_go<4, true>(p, grid, s);
   else wgrad_big_go<4, false>(p, grid, s);
+  if (p.part) launch_fold4(p.part, splits, (long)w.N * w.K, (long)w.N * w.K, p.dW, s);
   return true;
 }

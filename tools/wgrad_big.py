@@ -28,5 +28,15 @@ for M, N, K in SHAPES:
     x = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16(); dy = (torch.rand(M, N, device="cuda") * 2 - 1).bfloat16()
     dw = torch.zeros(N, K, device="cuda")
     db = torch.zeros(N, device="cuda") if WITH_BIAS else None
+    if os.environ.get('COLD'):   # rotate through operand sets larger than the 256 MB memory-side cache: operands come from HBM, as in a training step
+        nset = max(2, int(600e6 / ((M * K + M * N) * 2)) + 1)
+        xs = [x] + [x.clone() for _ in range(nset - 1)]; dys = [dy] + [dy.clone() for _ in range(nset - 1)]
+        it = [0]
+        def fn():
+            i = it[0] % nset; it[0] += 1
+            lib.satrn_linear_bwd_weight(1, P(dys[i]), N, P(xs[i]), P(dw), P(db) if WITH_BIAS else None, M, N, K, st())
+        us = bench(fn)
+        print(f"M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TFLOP/s  cold ({nset} operand sets)")
+        continue
     us = bench(lambda: lib.satrn_linear_bwd_weight(1, P(dy), N, P(x), P(dw), P(db) if WITH_BIAS else None, M, N, K, st()))
     print(f"M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TFLOP/s  blocks={os.environ.get('SATRN_WGRAD_BLOCKS','96')} ms128={'off' if os.environ.get('SATRN_WGRAD_NO_MS128') else 'on'}")
