@@ -212,7 +212,7 @@ __global__ __launch_bounds__(576, HD == 32 ? 5 : 3) void attn2_bwd_kernel(AttnP 
   float* sDelta = sLse + LqP;                          // [LqP]
   float* sRel = nullptr; float* sHist = nullptr; short* sRelJ = nullptr; short* sRelI = nullptr; unsigned char* sLab = nullptr;
   int nrel = 0;
-  if (p.rel_table) {
+  if (p.rel_table && !(p.dbg & 16)) {
     nrel = (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1);
     sRel = sDelta + LqP;
     sHist = sRel + nrel;
@@ -233,11 +233,14 @@ __global__ __launch_bounds__(576, HD == 32 ? 5 : 3) void attn2_bwd_kernel(AttnP 
   const T* Vg = (const T*)p.V + b * p.sv_b + h * HD;
   const T* Og = (const T*)p.O + b * p.so_b + h * HD;
   const T* dOg = (const T*)p.dO + b * p.so_b + h * HD;
+  if (!(p.dbg & 32)) {
   a2_stage<HD>(sK, Kg, p.Lk, LkP, p.ldk, tid, nthreads);
   a2_stage<HD>(sV, Vg, p.Lk, LkP, p.ldv, tid, nthreads);
   a2_stage<HD>(sQ, Qg, p.Lq, LqP, p.ldq, tid, nthreads);
   a2_stage<HD>(sdO, dOg, p.Lq, LqP, p.ldo, tid, nthreads);
+  }
   // lse and delta[q] = sum_d dO * O: four lanes per query row
+  if (!(p.dbg & 8))
   for (int qq = tid >> 2; qq < LqP; qq += nthreads >> 2) {
     const int part = tid & 3;
     float acc = 0.f;
@@ -395,6 +398,241 @@ __global__ __launch_bounds__(576, HD == 32 ? 5 : 3) void attn2_bwd_kernel(AttnP 
   }
 }
 
+// ---- backward, window form (networks/SWIN.py:163-183: relative position bias + shifted-window mask, no pad / causal mask, no dropout): the
+// same two phases with the per-score work cut to ~12 VALU instructions + one LDS gather.  attn2_bwd_kernel's scores pay a run-time branch
+// per mask kind and four to five scalar LDS lookups each; 41 K scores per workgroup and phase made it VALU-bound at 2 workgroups per CU
+// (SwinTRN stage 3: 123 us per launch, 45 % phase B, 35 % phase A, 20 % a prologue of eight dependent global round trips).  Here
+//   * everything per token is packed once: meta[token] = (4 * rel index) | label << 16 (keys: rel index of the column role, minus a whole
+//     table for keys past Lk so that their bias gather lands in a second, -inf half of the table: no mask instructions), lse * log2(e)
+//     (+inf for queries past Lq), delta; a lane fetches the four tokens of an accumulator tile with ONE 16-byte LDS read each;
+//   * the table is kept times log2(e), scores go through exp2 with the temperature folded into one fma;
+//   * the prologue issues every global load of the workgroup (K, V, Q, dO chunks, the O / dO chunk of the delta dot product, lse, table,
+//     labels) before the first LDS write: one memory round trip.
+template <int HD>
+__global__ __launch_bounds__(576, HD == 32 ? 5 : 3) void attn2_bwd_win_kernel(AttnP p) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char a2sm[];
+  const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6, fr = lane & 15, fq = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int nkt = ((p.Lk + 31) / 32) * 2, LkP = nkt * 16;
+  const int nqt = ((p.Lq + 31) / 32) * 2, LqP = nqt * 16;
+  constexpr int ROWB = A2L<HD>::ROWB, CPR = HD / 8;
+  const int ws2 = 2 * p.rel_ws - 1, nrel = ws2 * ws2;
+  unsigned char* sK = a2sm;
+  unsigned char* sV = sK + (size_t)LkP * ROWB;
+  unsigned char* sQ = sV + (size_t)LkP * ROWB;
+  unsigned char* sdO = sQ + (size_t)LqP * ROWB;
+  float* sLse = (float*)(sdO + (size_t)LqP * ROWB);   // [160] lse * log2(e), +inf past Lq
+  float* sDelta = sLse + 160;                           // [160]
+  uint32_t* sKM = (uint32_t*)(sDelta + 160);            // [160] key meta
+  uint32_t* sQM = sKM + 160;                            // [160] query meta
+  float* sRel = (float*)(sQM + 160);                    // [2 * nrel]: table * log2(e) | -inf
+  const long bh = (long)b * p.H + h;
+  const T* Qg = (const T*)p.Q + b * p.sq_b + h * HD;
+  const T* Kg = (const T*)p.K + b * p.sk_b + h * HD;
+  const T* Vg = (const T*)p.V + b * p.sv_b + h * HD;
+  const T* Og = (const T*)p.O + b * p.so_b + h * HD;
+  const T* dOg = (const T*)p.dO + b * p.so_b + h * HD;
+  constexpr float LOG2E = 1.4426950408889634f;
+
+  // ---- prologue: all global loads first
+  const int chK = LkP * CPR, chQ = LqP * CPR, chAll = 2 * chK + 2 * chQ;
+  constexpr int NLD = HD == 32 ? 5 : 9;                 // >= ceil(chAll / 576) at 160-row images
+  uint4 stg[NLD];
+  if (!(p.dbg & 32)) {
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int i = tid + k * nthreads;
+    stg[k] = zero16();
+    if (i < chAll) {
+      const int t = i < chK ? 0 : (i < 2 * chK ? 1 : (i < 2 * chK + chQ ? 2 : 3));
+      const int j = i - (t == 0 ? 0 : (t == 1 ? chK : (t == 2 ? 2 * chK : 2 * chK + chQ)));
+      const int row = j / CPR, c = j - row * CPR;
+      const T* src = t == 0 ? Kg : (t == 1 ? Vg : (t == 2 ? Qg : dOg));
+      const long ld = t == 0 ? p.ldk : (t == 1 ? p.ldv : (t == 2 ? p.ldq : p.ldo));
+      if (row < (t < 2 ? p.Lk : p.Lq)) stg[k] = ld16(src + (long)row * ld + c * 8);
+    }
+  }
+  }
+  // delta[q] = sum_d dO * O: CPR lanes per query row, one chunk each (HD 32: exactly one chunk per thread at 144 rows)
+  constexpr int NDL = (160 * CPR + 575) / 576;
+  uint4 dlo[NDL], dld[NDL];
+#pragma unroll
+  for (int k = 0; k < NDL; ++k) {
+    const int i = tid + k * nthreads, row = i / CPR, c = i - row * CPR;
+    dlo[k] = zero16(); dld[k] = zero16();
+    if (row < p.Lq) { dlo[k] = ld16(Og + (long)row * p.ldo + c * 8); dld[k] = ld16(dOg + (long)row * p.ldo + c * 8); }
+  }
+  float lse_v = INFINITY;
+  if (tid < 160 && tid < p.Lq) lse_v = p.lse[bh * p.Lq + tid] * LOG2E;
+  float relv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int i = tid + k * nthreads; relv[k] = i < nrel ? p.rel_table[(long)i * p.H + h] * LOG2E : -INFINITY; }
+  unsigned lab_v = 0;
+  if (tid < 160 && p.labels && tid < p.Lq) lab_v = p.labels[(long)(b % p.nW) * p.Lq + tid];
+
+  // ---- LDS images
+  if (!(p.dbg & 32)) {
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int i = tid + k * nthreads;
+    if (i < chAll) {
+      const int t = i < chK ? 0 : (i < 2 * chK ? 1 : (i < 2 * chK + chQ ? 2 : 3));
+      const int j = i - (t == 0 ? 0 : (t == 1 ? chK : (t == 2 ? 2 * chK : 2 * chK + chQ)));
+      const int row = j / CPR, c = j - row * CPR;
+      unsigned char* dst = t == 0 ? sK : (t == 1 ? sV : (t == 2 ? sQ : sdO));
+      *reinterpret_cast<uint4*>(dst + A2L<HD>::gran(row, c >> 1) + (c & 1) * 16) = stg[k];
+    }
+  }
+  }
+#pragma unroll
+  for (int k = 0; k < NDL; ++k) {
+    const int i = tid + k * nthreads, row = i / CPR;
+    float a[8], o[8], acc = 0.f;
+    unpack<T>(dld[k], a); unpack<T>(dlo[k], o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += a[j] * o[j];
+#pragma unroll
+    for (int m = 1; m < CPR; m <<= 1) acc += __shfl_xor(acc, m, 64);
+    if ((i % CPR) == 0 && row < 160) sDelta[row] = acc;
+  }
+  if (tid < 160) {
+    sLse[tid] = lse_v;
+    const int tq = tid < p.Lq ? tid : 0;   // (rows past the end: any in-range index, their probabilities are zero through lse = +inf)
+    const int y = tid / p.rel_ws, x = tid - y * p.rel_ws, yq = tq / p.rel_ws, xq = tq - yq * p.rel_ws;
+    const int relJ = y * ws2 + x, relI = (yq + p.rel_ws - 1) * ws2 + (xq + p.rel_ws - 1);
+    // byte offset of a score's bias = query meta - key meta: (relI - relJ) * 4 for a key in range, relI * 4 + 4 * nrel (the -inf half) past Lk
+    sKM[tid] = (uint32_t)(tid < p.Lk ? relJ * 4 + 4 * nrel : 0) | (lab_v << 16);
+    sQM[tid] = (uint32_t)(relI * 4 + 4 * nrel) | (lab_v << 16);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int i = tid + k * nthreads; if (i < 2 * nrel) sRel[i] = relv[k]; }
+  __syncthreads();
+
+  const float c1 = p.inv_temp * LOG2E;
+  constexpr float PEN = -100.0f * LOG2E;
+  const unsigned sRelA = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)sRel;
+  auto rel_at = [&](int off4) {   // byte offset into the table image
+    return *reinterpret_cast<const __attribute__((address_space(3))) float*>((const __attribute__((address_space(3))) unsigned char*)(size_t)(sRelA + (unsigned)off4));
+  };
+  const int LkPd = (int)(((p.Lk + 31) / 32) * 32);
+
+  // ================= phase A: query blocks -> dQ (+ the raw-score gradient for the table gradient) =================
+  if (!(p.dbg & 2))
+  for (int qb = wave; qb * 16 < p.Lq; qb += nw) {
+    const int qi = qb * 16 + fr;
+    uint4 qf[HD / 32], dof[HD / 32];
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) { qf[ks] = a2_rowfrag<HD>(sQ, qi, ks, fq); dof[ks] = a2_rowfrag<HD>(sdO, qi, ks, fq); }
+    const uint32_t qm = sQM[qi];
+    const int relI4 = (int)(qm & 0xffffu); const unsigned lab_i = qm >> 16;
+    const float nlse = -sLse[qi], nlse_pen = nlse + PEN, delta = sDelta[qi];
+    f32x4 accQ[HD / 16];
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) accQ[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; 2 * s2 < nkt; ++s2) {
+      float v[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int kt = 2 * s2 + half;
+        if (kt * 16 < p.Lk) {
+          f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < HD / 32; ++ks) {
+            sc = a2_mma(a2_rowfrag<HD>(sK, kt * 16 + fr, ks, fq), qf[ks], sc);
+            dp = a2_mma(a2_rowfrag<HD>(sV, kt * 16 + fr, ks, fq), dof[ks], dp);
+          }
+          const uint4 km = *reinterpret_cast<const uint4*>(sKM + kt * 16 + fq * 4);
+          const uint32_t kmv[4] = {km.x, km.y, km.z, km.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float bias = rel_at(relI4 - (int)(kmv[r] & 0xffffu));
+            const float t = __builtin_fmaf(sc[r], c1, bias) + ((kmv[r] >> 16) != lab_i ? nlse_pen : nlse);
+            const float pr = __builtin_amdgcn_exp2f(t);
+            v[half * 4 + r] = pr * (dp[r] - delta) * p.inv_temp;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[half * 4 + r] = 0.f;
+        }
+      }
+      const uint4 dsp = pack<T>(v);
+      if (p.dS && qi < p.Lq) {
+        T* dSg = (T*)p.dS + ((bh * p.Lq + qi) * (long)LkPd) + s2 * 32 + fq * 4;
+        *reinterpret_cast<uint2*>(dSg) = make_uint2(dsp.x, dsp.y);
+        if (s2 * 32 + 16 < LkPd) *reinterpret_cast<uint2*>(dSg + 16) = make_uint2(dsp.z, dsp.w);
+      }
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) accQ[dt] = a2_mma(a2_colfrag<HD>(sK, s2 * 32, dt, lane), dsp, accQ[dt]);
+    }
+    T* dQg = (T*)p.dQ + b * p.sq_b + h * HD;
+    if (qi < p.Lq) {
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt)
+        *reinterpret_cast<uint2*>(dQg + (long)qi * p.ldq + dt * 16 + fq * 4) = make_uint2(pack2bf(accQ[dt][0], accQ[dt][1]), pack2bf(accQ[dt][2], accQ[dt][3]));
+    }
+  }
+
+  // ================= phase B: key blocks -> dK, dV =================
+  if (!(p.dbg & 4))
+  for (int kb = wave; kb * 16 < p.Lk; kb += nw) {
+    const int key = kb * 16 + fr;
+    uint4 kf[HD / 32], vf[HD / 32];
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) { kf[ks] = a2_rowfrag<HD>(sK, key, ks, fq); vf[ks] = a2_rowfrag<HD>(sV, key, ks, fq); }
+    const uint32_t km = sKM[key];
+    const int relJ4 = (int)(km & 0xffffu); const unsigned lab_j = km >> 16;
+    f32x4 accK[HD / 16], accV[HD / 16];
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) { accK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; accV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int s2 = 0; 2 * s2 < nqt; ++s2) {
+      float dsv[8], pdv[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int qt = 2 * s2 + half;
+        if (qt * 16 < p.Lq) {
+          f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < HD / 32; ++ks) {
+            sc = a2_mma(a2_rowfrag<HD>(sQ, qt * 16 + fr, ks, fq), kf[ks], sc);
+            dp = a2_mma(a2_rowfrag<HD>(sdO, qt * 16 + fr, ks, fq), vf[ks], dp);
+          }
+          const uint4 qm4 = *reinterpret_cast<const uint4*>(sQM + qt * 16 + fq * 4);
+          const f32x4 ls4 = *reinterpret_cast<const f32x4*>(sLse + qt * 16 + fq * 4);
+          const f32x4 de4 = *reinterpret_cast<const f32x4*>(sDelta + qt * 16 + fq * 4);
+          const uint32_t qmv[4] = {qm4.x, qm4.y, qm4.z, qm4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float bias = rel_at((int)(qmv[r] & 0xffffu) - relJ4);
+            const float t = __builtin_fmaf(sc[r], c1, bias) + ((qmv[r] >> 16) != lab_j ? PEN : 0.f) - ls4[r];
+            const float pr = __builtin_amdgcn_exp2f(t);
+            pdv[half * 4 + r] = pr;
+            dsv[half * 4 + r] = pr * (dp[r] - de4[r]) * p.inv_temp;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pdv[half * 4 + r] = 0.f; dsv[half * 4 + r] = 0.f; }
+        }
+      }
+      const uint4 pdp = pack<T>(pdv), dsp = pack<T>(dsv);
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        accV[dt] = a2_mma(a2_colfrag<HD>(sdO, s2 * 32, dt, lane), pdp, accV[dt]);
+        accK[dt] = a2_mma(a2_colfrag<HD>(sQ, s2 * 32, dt, lane), dsp, accK[dt]);
+      }
+    }
+    if (key < p.Lk) {
+      T* dKg = (T*)p.dK + b * p.sk_b + h * HD + (long)key * p.ldk;
+      T* dVg = (T*)p.dV + b * p.sv_b + h * HD + (long)key * p.ldv;
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        *reinterpret_cast<uint2*>(dKg + dt * 16 + fq * 4) = make_uint2(pack2bf(accK[dt][0], accK[dt][1]), pack2bf(accK[dt][2], accK[dt][3]));
+        *reinterpret_cast<uint2*>(dVg + dt * 16 + fq * 4) = make_uint2(pack2bf(accV[dt][0], accV[dt][1]), pack2bf(accV[dt][2], accV[dt][3]));
+      }
+    }
+  }
+}
+
 static size_t a2_rel_bytes(const AttnP& p) {
   if (!p.rel_table) return 0;
   return ((size_t)(2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 4 + 320 + (size_t)p.Lq + 15) & ~(size_t)15;
@@ -427,7 +665,23 @@ bool launch_attn2_bwd(const AttnP& p, hipStream_t s) {
   if (p.rel_table) sh += (((size_t)(2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 8 + 640 + (size_t)p.Lq + 15) & ~(size_t)15);
   const dim3 grid(p.H, p.B), block(nw * 64);
   AttnP pp = p;
-  pp.dbg = getenv("SATRN_A2_DBG") ? atoi(getenv("SATRN_A2_DBG")) : 0;   // timing experiments (wrong results): 1 no histogram, 2 no phase A, 4 no phase B
+  pp.dbg = getenv("SATRN_A2_DBG") ? atoi(getenv("SATRN_A2_DBG")) : 0;   // timing experiments (wrong results): 1 no histogram, 2 no phase A, 4 no phase B, 8 no delta / lse, 16 no relative-position tables, 32 no staging
+  // window form: relative-position table, no pad / causal mask, no dropout, gradients written (not accumulated), table gradient through dS
+  const bool win = p.rel_table && !p.text && !p.causal && p.drop_p == 0.f && !p.kv_accum && !p.drel && p.rel_ws * p.rel_ws <= 160 && p.Lq == p.Lk &&
+                   (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 8 < 65536 && nw * 64 == 576 && getenv("SATRN_NO_ATTN2_WIN") == nullptr;
+  if (win) {
+    const size_t shw = (size_t)(2 * LkP + 2 * LqP) * p.hd * 2 + (size_t)4 * 160 * 4 + (size_t)2 * (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 4 + 16;
+    if (p.hd == 32) {
+      static bool a = false;
+      if (!a) { (void)hipFuncSetAttribute((const void*)attn2_bwd_win_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a = true; }
+      hipLaunchKernelGGL((attn2_bwd_win_kernel<32>), grid, block, shw, s, pp);
+    } else {
+      static bool a = false;
+      if (!a) { (void)hipFuncSetAttribute((const void*)attn2_bwd_win_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a = true; }
+      hipLaunchKernelGGL((attn2_bwd_win_kernel<64>), grid, block, shw, s, pp);
+    }
+    return true;
+  }
   if (p.hd == 32) {
     static bool a = false;
     if (!a) { (void)hipFuncSetAttribute((const void*)attn2_bwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a = true; }
