@@ -192,6 +192,121 @@ __global__ __launch_bounds__(576) void attn2_fwd_kernel(AttnP p) {
 }
 
 
+// ---- forward, window form (see attn2_bwd_win_kernel below for the packing): scores in the log2 domain, key metadata one 16-byte LDS read
+// per accumulator tile, all global loads of the prologue issued before the first LDS write
+template <int HD>
+__global__ __launch_bounds__(576) void attn2_fwd_win_kernel(AttnP p) {
+  typedef bf16_t T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char a2sm[];
+  const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int nkt = ((p.Lk + 31) / 32) * 2, LkP = nkt * 16;
+  constexpr int ROWB = A2L<HD>::ROWB, CPR = HD / 8;
+  const int ws2 = 2 * p.rel_ws - 1, nrel = ws2 * ws2;
+  unsigned char* sK = a2sm;
+  unsigned char* sV = sK + (size_t)LkP * ROWB;
+  uint32_t* sKM = (uint32_t*)(sV + (size_t)LkP * ROWB);   // [160]
+  float* sRel = (float*)(sKM + 160);                        // [2 * nrel]
+  const long bh = (long)b * p.H + h;
+  const T* Qg = (const T*)p.Q + b * p.sq_b + h * HD;
+  const T* Kg = (const T*)p.K + b * p.sk_b + h * HD;
+  const T* Vg = (const T*)p.V + b * p.sv_b + h * HD;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const int chK = LkP * CPR;
+  constexpr int NLD = HD == 32 ? 3 : 5;   // >= ceil(2 * 160 * CPR / 576)
+  uint4 stg[NLD];
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int i = tid + k * nthreads;
+    stg[k] = zero16();
+    if (i < 2 * chK) {
+      const int t = i < chK ? 0 : 1, j = i - t * chK, row = j / CPR, c = j - row * CPR;
+      if (row < p.Lk) stg[k] = ld16((t ? Vg : Kg) + (long)row * (t ? p.ldv : p.ldk) + c * 8);
+    }
+  }
+  const int qi = wave * 16 + fr;
+  uint4 qf[HD / 32];
+#pragma unroll
+  for (int ks = 0; ks < HD / 32; ++ks) qf[ks] = qi < p.Lq ? ld16(Qg + (long)qi * p.ldq + ks * 32 + fq * 8) : zero16();
+  float relv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int i = tid + k * nthreads; relv[k] = i < nrel ? p.rel_table[(long)i * p.H + h] * LOG2E : -INFINITY; }
+  unsigned lab_v = 0;
+  if (tid < 160 && p.labels && tid < p.Lk) lab_v = p.labels[(long)(b % p.nW) * p.Lq + tid];
+  const unsigned lab_i = (p.labels && qi < p.Lq) ? p.labels[(long)(b % p.nW) * p.Lq + qi] : 0u;
+#pragma unroll
+  for (int k = 0; k < NLD; ++k) {
+    const int i = tid + k * nthreads;
+    if (i < 2 * chK) {
+      const int t = i < chK ? 0 : 1, j = i - t * chK, row = j / CPR, c = j - row * CPR;
+      *reinterpret_cast<uint4*>((t ? sV : sK) + A2L<HD>::gran(row, c >> 1) + (c & 1) * 16) = stg[k];
+    }
+  }
+  if (tid < 160) {
+    const int y = tid / p.rel_ws, x = tid - y * p.rel_ws;
+    sKM[tid] = (uint32_t)(tid < p.Lk ? (y * ws2 + x) * 4 + 4 * nrel : 0) | (lab_v << 16);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int i = tid + k * nthreads; if (i < 2 * nrel) sRel[i] = relv[k]; }
+  __syncthreads();
+
+  const int tq = qi < p.Lq ? qi : 0, yq = tq / p.rel_ws, xq = tq - yq * p.rel_ws;
+  const int relI4 = ((yq + p.rel_ws - 1) * ws2 + (xq + p.rel_ws - 1)) * 4 + 4 * nrel;
+  const float c1 = p.inv_temp * LOG2E;
+  constexpr float PEN = -100.0f * LOG2E;
+  const unsigned sRelA = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)sRel;
+  f32x4 s[A2_MAXKT];
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < A2_MAXKT; ++kt) {
+    s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (kt * 16 < p.Lk) {
+      f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) sc = a2_mma(a2_rowfrag<HD>(sK, kt * 16 + fr, ks, fq), qf[ks], sc);
+      const uint4 km = *reinterpret_cast<const uint4*>(sKM + kt * 16 + fq * 4);
+      const uint32_t kmv[4] = {km.x, km.y, km.z, km.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float bias = *reinterpret_cast<const __attribute__((address_space(3))) float*>(
+            (const __attribute__((address_space(3))) unsigned char*)(size_t)(sRelA + (unsigned)(relI4 - (int)(kmv[r] & 0xffffu))));
+        const float t = __builtin_fmaf(sc[r], c1, bias) + ((kmv[r] >> 16) != lab_i ? PEN : 0.f);
+        s[kt][r] = t;
+        m = fmaxf(m, t);
+      }
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < A2_MAXKT; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] - m); s[kt][r] = e; sum += e; }
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = __builtin_amdgcn_rcpf(sum);
+  if (p.lse && fq == 0 && qi < p.Lq) p.lse[bh * p.Lq + qi] = (m + __builtin_amdgcn_logf(sum)) * 0.6931471805599453f;   // natural log-sum-exp
+  uint4 pa[A2_MAXKT / 2];
+#pragma unroll
+  for (int s2 = 0; s2 < A2_MAXKT / 2; ++s2) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = s[2 * s2 + (j >> 2)][j & 3] * inv;
+    pa[s2] = pack<T>(v);
+  }
+  T* Og = (T*)p.O + b * p.so_b + h * HD;
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt) {
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < A2_MAXKT / 2; ++s2)
+      if (2 * s2 * 16 < p.Lk) o = a2_mma(a2_colfrag<HD>(sV, s2 * 32, dt, lane), pa[s2], o);
+    if (qi < p.Lq) *reinterpret_cast<uint2*>(Og + (long)qi * p.ldo + dt * 16 + fq * 4) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+  }
+}
+
 // ---- backward: grid (H, B).  Phase A: wave = 16-query block (transposed scores) -> dQ, bias-table histogram.  Phase B: wave = 16-key block
 // (scores in the normal orientation) -> dK, dV.  Both recompute P from the saved log-sum-exp; nothing but K, V, Q, dO (staged once) and
 // the per-query lse / delta arrays goes through LDS.
@@ -652,6 +767,14 @@ bool launch_attn2_fwd(const AttnP& p, hipStream_t s) {
   const int nw = (p.Lq + 15) / 16;
   const size_t sh = (size_t)2 * LkP * p.hd * 2 + a2_rel_bytes(p);
   const dim3 grid(p.H, p.B), block(nw * 64);
+  const bool win = p.rel_table && !p.text && !p.causal && p.drop_p == 0.f && p.rel_ws * p.rel_ws <= 160 && p.Lq == p.Lk &&
+                   (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 8 < 65536 && nw * 64 == 576 && getenv("SATRN_NO_ATTN2_WIN") == nullptr;
+  if (win) {
+    const size_t shw = (size_t)2 * LkP * p.hd * 2 + 160 * 4 + (size_t)2 * (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 4 + 16;
+    if (p.hd == 32) hipLaunchKernelGGL((attn2_fwd_win_kernel<32>), grid, block, shw, s, p);
+    else hipLaunchKernelGGL((attn2_fwd_win_kernel<64>), grid, block, shw, s, p);
+    return true;
+  }
   if (p.hd == 32) hipLaunchKernelGGL((attn2_fwd_kernel<32>), grid, block, sh, s, p);
   else hipLaunchKernelGGL((attn2_fwd_kernel<64>), grid, block, sh, s, p);
   return true;
