@@ -80,6 +80,23 @@ int satrn_linear_bwd_data(int dtype, const void* dy, int ldy, const void* w_bwd,
 /* dw[N][K] += dy^T x  (fp32, atomics: zero dw first);  db[N] += column sums of dy (db may be NULL). */
 int satrn_linear_bwd_weight(int dtype, const void* dy, int ldy, const void* x, float* dw, float* db, int M, int N,
                             int K, void* stream);
+/* The same with a caller-provided partial-tile slab (fp32, ws_floats >= slices * N * K; 320 * 16384 always suffices): the large-product
+ * kernel then stores each item's partial tile [slice][N][K] with plain stores and a fold launch adds the slices in slice order --
+ * no float atomics into dw (deterministic; inside a training step, where the gradient buffers are cold, the atomics cost as much
+ * as the product).  This is the form the engine's steps use.  Shapes the large-product kernel does not take behave like
+ * satrn_linear_bwd_weight. */
+int satrn_linear_bwd_weight_ws(int dtype, const void* dy, int ldy, const void* x, float* dw, float* db, int M, int N, int K,
+                               float* ws, size_t ws_floats, void* stream);
+/* Linear + activation for a training forward: y = act(x W^T + b) and dact = act'(x W^T + b), both [M][N] in the compute dtype --
+ * the backward needs the pre-activation only through that derivative, which the epilogue has beside the activation (GELU: one erf / exp
+ * evaluation for both).  SwinTRN's Mlp.fc1 + nn.GELU (networks/SWIN.py:24-47).  act: 1 ReLU, 2 SiLU, 3 sigmoid, 4 GELU (exact erf form). */
+int satrn_linear_act_fwd(int dtype, const void* x, const void* w_fwd, const float* bias, void* y, void* dact, int M, int N, int K, int act,
+                         void* stream);
+/* dx[M][K] = (dy[M][ldy(>=N)] * W) (.) dact[M][K] * scale: the data gradient of the linear layer BEHIND an activation, leaving as the
+ * gradient of that activation's input (dact = satrn_linear_act_fwd's second output of the layer in front; kind 5).  kind 1: dact is
+ * the stored OUTPUT of a ReLU (+ dropout with keep scale `scale`): factor = scale where it is positive, else 0.  scale 0 means 1. */
+int satrn_linear_bwd_data_act(int dtype, const void* dy, int ldy, const void* w_bwd, int ldb, const void* dact, int kind, float scale,
+                              void* dx, int M, int N, int K, void* stream);
 
 /* 3x3 convolution, NHWC, im2col-free implicit GEMM on MFMA.  Replaces nn.Conv2d(k=3) of
  * networks/LiteSATRN.py:50-70 (ShallowCNN conv1..3) and the timm EfficientNetV2-S 3x3 convs behind

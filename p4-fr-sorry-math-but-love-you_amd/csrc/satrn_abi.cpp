@@ -97,6 +97,47 @@ int satrn_linear_bwd_data(int dt, const void* dy, int ldy, const void* wb, int l
   launch_gemm(dt, AM_DENSE, p, S(st));
   return done("linear_bwd_data");
 }
+int satrn_linear_bwd_weight_ws(int dt, const void* dy, int ldy, const void* x, float* dw, float* db, int M, int N, int K, float* ws,
+                               size_t ws_floats, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, K, "K") || chk_c(dt, ldy, "ldy")) return -1;
+  if (!ws || !ws_floats) return fail(-1, "satrn_linear_bwd_weight_ws: a partial-tile slab is required");
+  WgradP q;
+  memset(&q, 0, sizeof(q));
+  q.dY = dy; q.A = x; q.dW = dw; q.M = M; q.N = N; q.K = K; q.ldy = ldy; q.lda = K; q.nbatch = 1; q.nb_inner = 1;
+  if (db && getenv("SATRN_NO_WGRAD_BIAS") == nullptr) q.dbias = db;
+  g_wgpart.cap = ws_floats; g_wgpart.scratch[0] = g_wgpart.scratch[1] = ws; g_wgpart.side = nullptr;
+  launch_wgrad(dt, q, S(st));
+  g_wgpart.cap = 0;
+  if (db && !q.dbias) launch_colsum(dt, dy, M, N, ldy, db, S(st));
+  return done("linear_bwd_weight_ws");
+}
+int satrn_linear_act_fwd(int dt, const void* x, const void* w, const float* bias, void* y, void* dact, int M, int N, int K, int act, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, K, "K")) return -1;
+  if (act < ACT_RELU || act > ACT_GELU) return fail(-1, "satrn_linear_act_fwd: act must be 1 (ReLU) .. 4 (GELU)");
+  if (!dact) return fail(-1, "satrn_linear_act_fwd: dact is required (satrn_linear_fwd is the form without it)");
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = x; p.Bw = w; p.C = y; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldc = N; p.act = act;
+  p.pre_out = dact; p.pre_grad = 1;
+  launch_gemm(dt, AM_DENSE, p, S(st));
+  return done("linear_act_fwd");
+}
+int satrn_linear_bwd_data_act(int dt, const void* dy, int ldy, const void* wb, int ldb, const void* dact, int kind, float scale, void* dx, int M,
+                              int N, int K, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, ldb, "ldb") || chk_c(dt, ldy, "ldy")) return -1;
+  if (kind != ACT_DFACTOR && kind != ACT_RELU) return fail(-1, "satrn_linear_bwd_data_act: kind must be 5 (stored derivative) or 1 (ReLU output)");
+  if (!dact) return fail(-1, "satrn_linear_bwd_data_act: dact is required");
+  (void)N;
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = dy; p.Bw = wb; p.C = dx; p.M = M; p.N = K; p.K = ldb; p.lda = ldy; p.ldc = K;
+  p.bact_u = dact; p.bact = kind; p.bact_scale = scale;
+  launch_gemm(dt, AM_DENSE, p, S(st));
+  return done("linear_bwd_data_act");
+}
 int satrn_linear_bwd_weight(int dt, const void* dy, int ldy, const void* x, float* dw, float* db, int M, int N, int K,
                             void* st) {
   CHK_DT(dt);

@@ -176,6 +176,68 @@ def test_linear_big_kernel(lib, big_gemm_mode, M, N, K, act, mt):
         close(dx, 2 * (dy @ w), dt, "big linear_bwd_data(acc)")
 
 
+@pytest.mark.parametrize("big", [2, 0])
+@pytest.mark.parametrize("M,N,K,act", [(1000, 384, 96, 4), (4099, 520, 256, 4), (9216, 1536, 384, 4), (777, 128, 64, 1), (2304, 256, 128, 2)])
+def test_linear_act_fwd_and_bwd_data_act(lib, big_gemm_mode, big, M, N, K, act):
+    """training-forward linear + activation that keeps act'(u) instead of u (SwinTRN Mlp.fc1 + GELU, networks/SWIN.py:24-47), and the data
+    gradient of the NEXT linear multiplied by that stored factor in its epilogue; persistent kernel (lean epilogue kinds 2 / 3) and
+    4-wave kernel; against fp32 torch autograd"""
+    dt = "bf16"
+    big_gemm_mode(big)
+    x, w, b = q(rnd(M, K, seed=1), dt), q(rnd(N, K, seed=2, scale=1 / math.sqrt(K)), dt), rnd(N, seed=3, scale=0.1)
+    fwd, bwd, ldb = pack_dense(lib, w, dt)
+    y = torch.empty(M, N, dtype=tdt(dt), device="cuda")
+    dact = torch.empty(M, N, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_linear_act_fwd(dti(dt), P(dev(x, dt)), P(fwd), P(dev(b)), P(y), P(dact), M, N, K, act, st()))
+    u = q(F.linear(x, w, b), dt).clone().requires_grad_(True)      # the activation sees the pre-activation rounded to the compute dtype
+    fn = {1: F.relu, 2: F.silu, 3: torch.sigmoid, 4: F.gelu}[act]
+    z = fn(u)
+    z.sum().backward()
+    close(y, z.detach(), dt, f"linear_act_fwd y act {act}")
+    close(dact, u.grad, dt, f"linear_act_fwd act'(u) act {act}", bf16_tol=1e-2)
+    # the layer behind it: g[M][N2] -> dz = g W2 [M][N] (.) act'(u)
+    N2 = 128
+    w2 = q(rnd(N2, N, seed=5, scale=1 / math.sqrt(N)), dt)
+    fwd2, bwd2, ldb2 = pack_dense(lib, w2, dt)
+    g = q(rnd(M, N2, seed=6), dt)
+    gp = torch.zeros(M, ldb2, dtype=tdt(dt), device="cuda")
+    gp[:, :N2] = dev(g, dt)
+    du = torch.empty(M, N, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_linear_bwd_data_act(dti(dt), P(gp), ldb2, P(bwd2), ldb2, P(dact), 5, 0.0, P(du), M, N2, N, st()))
+    close(du, (g @ w2) * dact.float().cpu(), dt, "linear_bwd_data_act (stored derivative)", bf16_tol=1e-2)
+    # ReLU form: the factor is the sign of the stored output, times the keep scale
+    yr = torch.relu(q(rnd(M, N, seed=7), dt))
+    ok(lib, lib.satrn_linear_bwd_data_act(dti(dt), P(gp), ldb2, P(bwd2), ldb2, P(dev(yr, dt)), 1, 1.25, P(du), M, N2, N, st()))
+    close(du, (g @ w2) * (yr > 0).float() * 1.25, dt, "linear_bwd_data_act (ReLU output)", bf16_tol=1e-2)
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(9216, 1536, 384, True), (9216, 384, 384, False), (147456, 96, 96, True), (4099, 520, 264, True), (20000, 128, 384, False)])
+def test_linear_bwd_weight_partial_tiles(lib, M, N, K, bias):
+    """the persistent weight-gradient kernel in the form the engine uses: partial tiles [slice][N][K] in a caller slab + an ordered fold,
+    no float atomics; added to what dw already holds; bit-identical from run to run; against fp32 torch"""
+    dt = "bf16"
+    x, dy = q(rnd(M, K, seed=1), dt), q(rnd(M, N, seed=2), dt)
+    xd, dyd = dev(x, dt), dev(dy, dt)
+    ws = torch.empty(320 * 16384, device="cuda")
+    outs = []
+    import os
+    os.environ["SATRN_WGRAD_BIG"] = "2"     # (read per call) every shape that fits, not only the >= 2 GFLOP ones
+    try:
+        for rep in range(2):
+            dw = torch.full((N, K), 0.5, device="cuda")
+            db = torch.zeros(N, device="cuda") if bias else None
+            ok(lib, lib.satrn_linear_bwd_weight_ws(dti(dt), P(dyd), N, P(xd), P(dw), P(db), M, N, K, P(ws), ws.numel(), st()))
+            outs.append(dw.clone())
+    finally:
+        os.environ.pop("SATRN_WGRAD_BIG", None)
+    ref = dy.double().t() @ x.double()
+    err = (outs[0].double().cpu() - 0.5 - ref).norm() / ref.norm()
+    assert err < 2e-3, f"wgrad partial tiles {M}x{N}x{K}: rel err {err:.3e}"
+    assert torch.equal(outs[0], outs[1]), "partial-tile weight gradient is not deterministic"
+    if bias:
+        close(db, dy.sum(0), dt, "wgrad partial tiles db", bf16_tol=2e-2)
+
+
 @pytest.mark.parametrize("M,N,K,bias", [(9216, 2048, 512, False), (9216, 512, 2048, True), (4099, 520, 264, True), (4099, 520, 264, False), (2304, 136, 1024, False),
                                         (1000, 384, 128, True), (300, 48, 96, False), (64, 128, 128, True), (20000, 128, 384, True), (777, 256, 128, False)])
 def test_linear_bwd_weight_big_kernel(lib, M, N, K, bias):
