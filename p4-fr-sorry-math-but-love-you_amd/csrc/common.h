@@ -58,6 +58,20 @@ template <> DEVI uint4 pack<bf16_t>(const float* i) {
   return make_uint4(pack2bf(i[0], i[1]), pack2bf(i[2], i[3]), pack2bf(i[4], i[5]), pack2bf(i[6], i[7]));
 }
 
+// window row of token row `tok` of a [B][H][W] map (RowMap, kernels.h)
+DEVI long rowmap_row(long tok, const RowMap& m) {
+  if (!m.ws) return tok;
+  const int x = (int)(tok % m.W);
+  const long t = tok / m.W;
+  const int y = (int)(t % m.H);
+  const long b = t / m.H;
+  int ys = y - m.shift, xs = x - m.shift;
+  if (ys < 0) ys += m.H;
+  if (xs < 0) xs += m.W;
+  const int wy = ys / m.ws, py = ys - wy * m.ws, wx = xs / m.ws, px = xs - wx * m.ws;
+  return ((b * (m.H / m.ws) + wy) * (m.W / m.ws) + wx) * (long)(m.ws * m.ws) + py * m.ws + px;
+}
+
 // ---- activations ----------------------------------------------------------------------
 // v_exp_f32 + v_rcp_f32 (1 ulp each): an IEEE division here costs ~10 VALU instructions per element, and the streaming
 // kernels that apply SiLU are issue-bound, not byte-bound

@@ -1105,10 +1105,10 @@ Tensor* op_posenc_apply(Exec& e, Tensor* x, Tensor* gate) {
 
 // LayerNorm backward: dx on the main stream; the per-block (dw | dbias) partials are folded on the side stream (optimizer-only sums)
 static void ln_backward(Exec& e, const void* dy, const void* a, const void* b, LNp* ln, const float* mr, void* da, void* db, int ba, int bb,
-                        long R, int C) {
+                        long R, int C, RowMap dmap = RowMap()) {
   const int g = layernorm_bwd_blocks(R);
   float* part = (float*)e.alloc((size_t)g * 2 * C * sizeof(float));
-  LCH(e, launch_layernorm_bwd(e.dt, dy, a, b, ln->w.p, mr, da, db, ba, bb, ln->w.g, ln->b.g, R, C, 0.f, nullptr, 0, e.s, part));
+  LCH(e, launch_layernorm_bwd(e.dt, dy, a, b, ln->w.p, mr, da, db, ba, bb, ln->w.g, ln->b.g, R, C, 0.f, nullptr, 0, e.s, part, dmap));
   float* dw = ln->w.g; float* dbias = ln->b.g;
   if (e.prof || e.dry) {
     LCH(e, launch_layernorm_fold(part, g, C, dw, dbias, e.s));
@@ -1117,7 +1117,8 @@ static void ln_backward(Exec& e, const void* dy, const void* a, const void* b, L
   }
 }
 
-Tensor* op_ln(Exec& e, Tensor* a, Tensor* b, LNp* ln) {
+// map: the output (and its gradient) are kept in window order (RowMap): LayerNorm + shift / window partition in one pass
+Tensor* op_ln(Exec& e, Tensor* a, Tensor* b, LNp* ln, RowMap map = RowMap()) {
   used(a); used(b);
   const long R = a->rows;
   const int C = a->C;
@@ -1125,15 +1126,15 @@ Tensor* op_ln(Exec& e, Tensor* a, Tensor* b, LNp* ln) {
   float* mr = (float*)e.alloc((size_t)2 * R * 4);
   e.last_mr = mr;
   WORK(e, 0, (double)R * C * e.esz() * (b ? 3 : 2));
-  LCH(e, launch_layernorm(e.dt, a->p, b ? b->p : nullptr, ln->w.p, ln->b.p, y->p, mr, R, C, 1e-5f, 0.f, nullptr, 0, e.s));
+  LCH(e, launch_layernorm(e.dt, a->p, b ? b->p : nullptr, ln->w.p, ln->b.p, y->p, mr, R, C, 1e-5f, 0.f, nullptr, 0, e.s, map));
   if (e.rec)
-    e.tape.push_back([&e, a, b, y, ln, mr, R, C]() {
+    e.tape.push_back([&e, a, b, y, ln, mr, R, C, map]() {
       if (!y->g) return;
       int ba = 0, bb = 0;
       void* da = e.grad(a, &ba);
       void* db = b ? e.grad(b, &bb) : nullptr;
       WORK(e, 0, (double)R * C * e.esz() * ((b ? 5 : 3) + ba + (b ? bb : 0)));
-      ln_backward(e, y->g, a->p, b ? b->p : nullptr, ln, mr, da, db, ba, bb, R, C);
+      ln_backward(e, y->g, a->p, b ? b->p : nullptr, ln, mr, da, db, ba, bb, R, C, map);
     });
   return y;
 }
@@ -1272,7 +1273,8 @@ Tensor* op_patch_merge(Exec& e, Tensor* x, int B, int H, int W) {
 }
 
 // out = shortcut + DropPath(branch): per-sample keep mask, scale 1/(1-p) (timm DropPath; identity in eval)
-Tensor* op_droppath_add(Exec& e, Tensor* shortcut, Tensor* branch, int B, float p) {
+// map: the branch (and its gradient) are in window order (RowMap): window reverse / shift back folded into the residual add
+Tensor* op_droppath_add(Exec& e, Tensor* shortcut, Tensor* branch, int B, float p, RowMap map = RowMap()) {
   used(shortcut); used(branch);
   if (!e.train) p = 0.f;
   const uint32_t site = p > 0.f ? e.site++ : 0;
@@ -1281,15 +1283,15 @@ Tensor* op_droppath_add(Exec& e, Tensor* shortcut, Tensor* branch, int B, float 
   const long per = branch->rows / B * C;
   Tensor* y = e.newt(branch->rows, C, B, shortcut->H, shortcut->W);
   WORK(e, 0, (double)branch->rows * C * e.esz() * 3);
-  LCH(e, launch_droppath(e.dt, 0, shortcut->p, branch->p, y->p, B, per, p, seed, site, e.s));
+  LCH(e, launch_droppath(e.dt, 0, shortcut->p, branch->p, y->p, B, per, p, seed, site, e.s, map, C));
   if (e.rec)
-    e.tape.push_back([&e, shortcut, branch, y, B, per, C, p, seed, site]() {
+    e.tape.push_back([&e, shortcut, branch, y, B, per, C, p, seed, site, map]() {
       if (!y->g) return;
       int beta;
       void* db = e.grad(branch, &beta);
       if (beta) { e.m->err = "internal: drop-path branch has two consumers"; e.oom = true; return; }
       WORK(e, 0, (double)branch->rows * C * e.esz() * 2);
-      LCH(e, launch_droppath(e.dt, 1, y->g, nullptr, db, B, per, p, seed, site, e.s));
+      LCH(e, launch_droppath(e.dt, 1, y->g, nullptr, db, B, per, p, seed, site, e.s, map, C));
       acc_grad(e, shortcut, y->g);
     });
   return y;
@@ -1397,14 +1399,19 @@ Tensor* op_window_attn(Exec& e, Tensor* qkv, SwinBlock* sb, int B_, const float*
 Tensor* swin_block(Exec& e, Tensor* x, SwinBlock* sb, int B) {
   Model* m = e.m;
   const int R = sb->res, nWw = R / sb->ws, nW = nWw * nWw;
-  Tensor* y = op_ln(e, x, nullptr, &sb->n1);
-  Tensor* yw = (nW > 1 || sb->shift) ? op_window_perm(e, y, B, R, R, sb->ws, sb->shift, 0) : y;
+  // shift + window partition ride on the LayerNorm in front of the attention (it writes window order) and on the residual add behind
+  // it (it reads window order): no permutation passes (SATRN_SWIN_PERM_PASS=1 keeps the four separate ones, for tests)
+  RowMap wmap;
+  const bool perm_pass = getenv("SATRN_SWIN_PERM_PASS") != nullptr;   // read per call
+  if ((nW > 1 || sb->shift) && !perm_pass) { wmap.H = R; wmap.W = R; wmap.ws = sb->ws; wmap.shift = sb->shift; }
+  Tensor* y = op_ln(e, x, nullptr, &sb->n1, wmap);
+  Tensor* yw = ((nW > 1 || sb->shift) && perm_pass) ? op_window_perm(e, y, B, R, R, sb->ws, sb->shift, 0) : y;
   Tensor* qkv = op_gemm(e, yw, &sb->qkv, &sb->bqkv, ACT_NONE, 0.f, nullptr);
   const float* mask = sb->geo >= 0 ? (const float*)(m->ws + m->sw_geo[sb->geo].off) : nullptr;
   Tensor* att = op_window_attn(e, qkv, sb, B * nW, mask, nW);
   Tensor* pr = op_gemm(e, att, &sb->proj, &sb->bproj, ACT_NONE, 0.f, nullptr);
-  Tensor* prt = (nW > 1 || sb->shift) ? op_window_perm(e, pr, B, R, R, sb->ws, sb->shift, 1) : pr;
-  Tensor* x1 = op_droppath_add(e, x, prt, B, sb->drop_path);
+  Tensor* prt = ((nW > 1 || sb->shift) && perm_pass) ? op_window_perm(e, pr, B, R, R, sb->ws, sb->shift, 1) : pr;
+  Tensor* x1 = op_droppath_add(e, x, prt, B, sb->drop_path, wmap);
   x1->B = B; x1->H = R; x1->W = R;
   Tensor* y2 = op_ln(e, x1, nullptr, &sb->n2);
   Tensor* g;

@@ -32,6 +32,11 @@ static inline float* det_scratch(hipStream_t s, size_t need_floats) {
 // out[i] += sum_{r < nrep} part[r * stride + i]  (r ascending), i < n
 void launch_fold(const float* part, int nrep, long stride, long n, float* out, hipStream_t s);
 enum { AM_DENSE = 0, AM_CONV = 1, AM_DGRAD = 2 };
+// Cyclic shift + window partition as a row map (networks/SWIN.py:338-371): token (b, y, x) of a [B][H][W] map lives at window row
+// ((b * nWh + wy) * nWw + wx) * ws * ws + py * ws + px with (wy * ws + py, wx * ws + px) = ((y - shift) mod H, (x - shift) mod W).
+// ws == 0: identity.  Kernels that take one read or write their WINDOW-ordered operand through it, which removes the separate
+// permutation passes around the attention (launch_window_perm: four per block and step).
+struct RowMap { int H = 0, W = 0, ws = 0, shift = 0; };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3, ACT_GELU = 4 /*exact erf form, nn.GELU (networks/SWIN.py:29)*/,
        ACT_DFACTOR = 5 /*backward only: the stored tensor already IS act'(u) (GemmP::pre_grad)*/ };
 
@@ -218,11 +223,11 @@ void launch_posenc2d_bwd(int dt, const void* dout, const float* hpos, const floa
                          int H, int W, int C, hipStream_t s);
 void launch_layernorm(int dt, const void* a, const void* b_or_null, const float* w, const float* bias, void* out,
                       float* mean_rstd /*[2R]*/, long R, int C, float eps, float drop_p, const uint32_t* seed,
-                      uint32_t site, hipStream_t s);
+                      uint32_t site, hipStream_t s, RowMap out_map = RowMap());   // out_map: token row r is written at its window row
 void launch_layernorm_bwd(int dt, const void* dout, const void* a, const void* b_or_null, const float* w,
                           const float* mean_rstd, void* da, void* db_or_null, int beta_a, int beta_b, float* dw,
                           float* dbias, long R, int C, float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s,
-                          float* part_ws = nullptr);
+                          float* part_ws = nullptr, RowMap dout_map = RowMap());   // dout_map: dout is in window order
 // part_ws != null: [layernorm_bwd_blocks(R)][2][C] floats receive per-block (dw | dbias) partials instead of atomics; fold them with
 // launch_layernorm_fold (any stream ordered after the backward kernel)
 int layernorm_bwd_blocks(long R);
@@ -358,5 +363,6 @@ void launch_window_perm(int dt, const void* in, void* out, int B, int H, int W, 
 void launch_patch_merge(int dt, const void* in, void* out, int B, int H, int W, int C /*input channels*/, int reverse, int beta, hipStream_t s);
 void launch_relpos_bias(const float* table /*[(2ws-1)^2][heads]*/, float* bias /*[heads][N][N]*/, int ws, int heads, hipStream_t s);
 void launch_relpos_bias_bwd(const float* dbias /*[heads][N][ld]*/, float* dtable, int ws, int heads, int ld, float scale, hipStream_t s);
+// map (ws != 0, C = channels): the BRANCH side is in window order -- mode 0 reads b at the window row of each token, mode 1 writes out there
 void launch_droppath(int dt, int mode, const void* a, const void* b, void* out, int B, long per_sample, float p, const uint32_t* seed,
-                     uint32_t site, hipStream_t s);
+                     uint32_t site, hipStream_t s, RowMap map = RowMap(), int C = 0);

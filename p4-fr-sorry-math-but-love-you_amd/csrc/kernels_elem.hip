@@ -1729,7 +1729,7 @@ DEVI float group_sum(float v) {
 
 template <typename T, int NCH, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* a, const T* b, const float* w, const float* bias,
-                                                        T* out, float* mr, long R, int C, float eps) {
+                                                        T* out, float* mr, long R, int C, float eps, RowMap omap) {
   constexpr int CH = TT<T>::CH;
   constexpr int G = 64 / RPW;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane / G, l = lane % G;
@@ -1764,6 +1764,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* a, const T* b, 
     }
     float rstd = rsqrtf(group_sum<G>(sq) / (float)C + eps);
     if (l == 0 && mr) { mr[r] = mean; mr[R + r] = rstd; }
+    const long ro = rowmap_row(r, omap);
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       int c = l + k * G;
@@ -1771,15 +1772,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* a, const T* b, 
         float o[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) o[j] = (v[k][j] - mean) * rstd * w[c * CH + j] + bias[c * CH + j];
-        st16(out + r * C + c * CH, pack<T>(o));
+        st16(out + ro * C + c * CH, pack<T>(o));
       }
     }
   }
 }
 #define LN_GO(NCH, RPW) hipLaunchKernelGGL((layernorm_kernel<T, NCH, RPW>), dim3(grid_for(R, 4 * RPW, 2048)), dim3(256), 0, s, (const T*)a, \
-                                           (const T*)b, w, bias, (T*)out, mr, R, C, eps)
+                                           (const T*)b, w, bias, (T*)out, mr, R, C, eps, out_map)
 void launch_layernorm(int dt, const void* a, const void* b, const float* w, const float* bias, void* out, float* mr,
-                      long R, int C, float eps, float, const uint32_t*, uint32_t, hipStream_t s) {
+                      long R, int C, float eps, float, const uint32_t*, uint32_t, hipStream_t s, RowMap out_map) {
   DISPATCH_T(dt, {
     int cc = C / TT<T>::CH;
     if (cc <= 16) LN_GO(1, 4);
@@ -1794,7 +1795,7 @@ void launch_layernorm(int dt, const void* a, const void* b, const float* w, cons
 template <typename T, int NCH, int RPW>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const T* a, const T* b, const float* w,
                                                             const float* mr, T* da, T* db, int beta_a, int beta_b,
-                                                            float* dw, float* dbias, long R, int C, float* part) {
+                                                            float* dw, float* dbias, long R, int C, float* part, RowMap dmap) {
   constexpr int CH = TT<T>::CH;
   constexpr int G = 64 / RPW;
   extern __shared__ float red[];  // [4 waves][2][C]
@@ -1811,13 +1812,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
   struct RowRaw { uint4 xa[NCH], xb[NCH], dd[NCH], oa[NCH], ob[NCH]; float mean, rstd; };
   auto load_row = [&](long r, RowRaw& q) {
     q.mean = mr[r]; q.rstd = mr[R + r];
+    const long rd = rowmap_row(r, dmap);
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int c = l + k * G;
       if (c < CC) {
         q.xa[k] = ld16(a + r * C + c * CH);
         if (b) q.xb[k] = ld16(b + r * C + c * CH);
-        q.dd[k] = ld16(dout + r * C + c * CH);
+        q.dd[k] = ld16(dout + rd * C + c * CH);
         if (beta_a) q.oa[k] = ld16(da + r * C + c * CH);
         if (db && beta_b) q.ob[k] = ld16(db + r * C + c * CH);
       }
@@ -1943,10 +1945,10 @@ void launch_layernorm_fold(const float* part, int nblocks, int C, float* dw, flo
 }
 
 #define LNB_GO(NCH, RPW) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, RPW>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a, \
-                                            (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part)
+                                            (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part, dout_map)
 void launch_layernorm_bwd(int dt, const void* dout, const void* a, const void* b, const float* w, const float* mr,
                           void* da, void* db, int beta_a, int beta_b, float* dw, float* dbias, long R, int C, float,
-                          const uint32_t*, uint32_t, hipStream_t s, float* part_ws) {
+                          const uint32_t*, uint32_t, hipStream_t s, float* part_ws, RowMap dout_map) {
   DISPATCH_T(dt, {
     int cc = C / TT<T>::CH;
     int g = part_ws ? layernorm_bwd_blocks(R) : grid_for(R, 16, 512);

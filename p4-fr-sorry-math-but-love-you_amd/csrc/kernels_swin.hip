@@ -171,28 +171,32 @@ void launch_relpos_bias_bwd(const float* dbias, float* dtable, int ws, int heads
 // mode 0 forward (out = a + b * s), mode 1 backward of the branch (out = a * s; `b` unused)
 template <typename T>
 __global__ void droppath_kernel(const T* a, const T* b, T* out, long per_sample_chunks, long total_chunks, float p, const uint32_t* seedp,
-                                uint32_t site, int mode) {
+                                uint32_t site, int mode, RowMap map, int CC) {
   constexpr int CH = TT<T>::CH;
   const uint32_t seed = p > 0.f ? *seedp : 0u;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total_chunks; i += (long)gridDim.x * blockDim.x) {
     const float sc = p > 0.f ? drop_scale(seed, site, (uint32_t)(i / per_sample_chunks), p) : 1.f;
+    long iw = i;   // chunk index on the window-ordered (branch) side
+    if (map.ws) { const long tok = i / CC; iw = rowmap_row(tok, map) * CC + (i - tok * CC); }
     float x[CH], y[CH];
     unpack<T>(ld16(a + i * CH), x);
     if (mode == 0) {
-      unpack<T>(ld16(b + i * CH), y);
+      unpack<T>(ld16(b + iw * CH), y);
 #pragma unroll
       for (int j = 0; j < CH; ++j) x[j] += y[j] * sc;
+      st16(out + i * CH, pack<T>(x));
     } else {
 #pragma unroll
       for (int j = 0; j < CH; ++j) x[j] *= sc;
+      st16(out + iw * CH, pack<T>(x));
     }
-    st16(out + i * CH, pack<T>(x));
   }
 }
 void launch_droppath(int dt, int mode, const void* a, const void* b, void* out, int B, long per_sample, float p, const uint32_t* seed,
-                     uint32_t site, hipStream_t s) {
+                     uint32_t site, hipStream_t s, RowMap map, int C) {
   DISPATCH_T(dt, {
     const long per = per_sample / TT<T>::CH, n = per * B;
-    hipLaunchKernelGGL((droppath_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)a, (const T*)b, (T*)out, per, n, p, seed, site, mode);
+    hipLaunchKernelGGL((droppath_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, (const T*)a, (const T*)b, (T*)out, per, n, p, seed, site, mode, map,
+                       map.ws ? C / TT<T>::CH : 1);
   });
 }

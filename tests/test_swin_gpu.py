@@ -179,6 +179,38 @@ def test_gelu_in_product_epilogue_equals_separate_passes(golden_dir, dtype, monk
     assert ge < (1e-5 if dtype == "f32" else 5e-2)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_window_order_folded_into_layernorm_and_residual(golden_dir, dtype, monkeypatch):
+    """shift + window partition written by the LayerNorm in front of the attention and read back by the residual add behind it (RowMap)
+    against the four separate permutation passes per block: a pure re-indexing, so the logits are identical and the gradients differ
+    only by the order of the float atomics of the weight gradients"""
+    scfg, dcfg = CASES["swin_mid"]
+    z, meta = load(golden_dir, "swin_mid")
+    B, T = int(meta["batch"]), int(meta["seq_len"])
+    img, expected = O.det_inputs(B, 3, scfg["img_size"], scfg["img_size"], T, seed=5, pad_tail=0)
+    imgd, expd = img.cuda(), expected.cuda()
+
+    def run(passes):
+        if passes:
+            monkeypatch.setenv("SATRN_SWIN_PERM_PASS", "1")
+        else:
+            monkeypatch.delenv("SATRN_SWIN_PERM_PASS", raising=False)
+        model, _ = build(scfg, dcfg, dtype, int(meta["wseed"]))
+        model.train()
+        logits = model(imgd, expd, True, 1.0)
+        loss = model.criterion(logits.transpose(1, 2), expd[:, 1:])
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().float().clone(), torch.cat([p_.grad.detach().float().flatten() for p_ in model.parameters()]).clone()
+
+    (l0, g0), (l1, g1) = run(True), run(False)
+    ge = (g1 - g0).norm().item() / g0.norm().item()
+    print(f"[window order folded:{dtype}] logits equal {torch.equal(l0, l1)}, gradient rel-L2 {ge:.3e}")
+    assert torch.equal(l0, l1)
+    assert ge < (1e-6 if dtype == "f32" else 1e-3)
+
+
 def test_swin_stochastic_depth_and_fused_step():
     """train mode with the reference's drop_path_rate (0.5): per-sample branches are dropped (outputs change from step to step,
     loss stays finite), the f32 step is reproducible for a fixed RNG word, the fused train_step runs and lowers the loss."""
