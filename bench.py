@@ -163,11 +163,23 @@ def precision_report(H, W, T, B, dev):
 
 def _decode_traffic():
     """memory-side bytes per decode STEP of the pipelined decoder, from the committed PMC passes (None if absent)"""
-    try:
-        d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_decode_traffic.json")))
-        return round(d["families"]["decode_pipe"]["hbm_bytes_per_launch"] / 231.0)
-    except Exception:  # noqa: BLE001
-        return None
+    for pf in DECODE_TRAFFIC_FILES:
+        try:
+            d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pf)))
+            return round(d["families"]["decode_pipe"]["hbm_bytes_per_launch"] / 231.0)
+        except Exception:  # noqa: BLE001
+            continue
+    return None
+
+
+DECODE_TRAFFIC_FILES = ("r03_pmc_decode_traffic.json", "r02_pmc_decode_traffic.json")
+
+
+def _decode_traffic_source():
+    for pf in DECODE_TRAFFIC_FILES:
+        if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pf)):
+            return f"profiles/{pf} (memory-side bytes of the whole 231-step decode launch / 231)"
+    return None
 
 
 def swin_report(dev, B=16, T=128):
@@ -392,7 +404,7 @@ def main():
         roof["hbm_frac"] = round(ach_b / PEAK_HBM_GBS, 5)
         roof["kernel"] = dom["kernel"]
         pmc_all = {}
-        for pf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for pf in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:  # HBM bytes per launch of every kernel family from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
                 pmc_all = json.load(open(os.path.join(ROOT, "profiles", pf)))["families"]
                 roof["traffic_source"] = f"profiles/{pf} (rocprofv3 --pmc passes of this command, collected with tools/round_profile.sh; NOT measured in this run)"
@@ -467,7 +479,7 @@ def main():
                                                         frac=round(38.0e6 / step_us / 1e3 / 8000.0, 4), encoder_ms=round(esec * 1e3, 2),
                                                         kv_only=dict(algorithmic_bytes_per_step=32.2e6, achieved=round(32.2e6 / step_us / 1e3, 1), frac=round(32.2e6 / step_us / 1e3 / 8000.0, 4),
                                                                      note="what a weight-stationary decoder must move per 64-image step: self-attention K/V history 22.8 MB (mean over 231 steps) + cross-attention K/V 9.4 MB; the 5.8 MB of weights stay in LDS"),
-                                                        traffic=_decode_traffic(), traffic_source="profiles/r02_pmc_decode_traffic.json (memory-side bytes of the whole 231-step decode launch / 231)",
+                                                        traffic=_decode_traffic(), traffic_source=_decode_traffic_source(),
                                                         kernel="decode_pipe_kernel (one persistent workgroup per decoder role, weights resident in LDS, images pipelined through the roles)",
                                                         note="latency-bound, not HBM-bound: a token is a dependent chain of 13 role hops per step (3 layers x [Q/K/V, self-attention + out-projection, LayerNorm + cross-attention, LayerNorm + feed-forward] + generator), and at batch 64 the 244 role workgroups are ~80 % busy; the weights never leave LDS, so the 38 MB/step figure is what a weight-streaming decoder would move, kept as the algorithmic unit of SURVEY 8d")
                 # the per-image kernel of round 1 (one workgroup per image streams every weight each step), kept as the
