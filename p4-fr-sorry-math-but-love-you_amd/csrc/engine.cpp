@@ -74,7 +74,7 @@ void Exec::defer(std::function<void(hipStream_t)> fn) {
 void Exec::flush_side() {
   if (pending.empty()) return;
   // fork events order device work only (nobody on the host reads them): no system-scope fence at the record
-  static const unsigned evflags = getenv("SATRN_EV_FLAGS") ? (unsigned)strtoul(getenv("SATRN_EV_FLAGS"), nullptr, 0) : (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+  const unsigned evflags = (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
   if (nfork >= (int)evs.size()) { hipEvent_t ev; (void)hipEventCreateWithFlags(&ev, evflags); evs.push_back(ev); }
   hipEvent_t ev = evs[nfork++];
   (void)hipEventRecord(ev, s);
@@ -509,7 +509,7 @@ Model* model_create(const SatrnConfig& cfg) {
     // data-gradient chain (the critical path) is dispatched first
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically greatest = lowest priority
-    if (getenv("SATRN_SIDE_PRIO_DEFAULT") || hipStreamCreateWithPriority(&m->ex->s2, hipStreamNonBlocking, lo) != hipSuccess)
+    if (hipStreamCreateWithPriority(&m->ex->s2, hipStreamNonBlocking, lo) != hipSuccess)
       (void)hipStreamCreateWithFlags(&m->ex->s2, hipStreamNonBlocking);
   }
   segment_ranges(m);
@@ -680,9 +680,7 @@ namespace {
 struct Geo { int H, W, Ci, OH, OW, KW, stride, pt, pl; };
 
 static inline void used(Tensor* t) { if (t) t->ncons++; }
-static const bool g_fuse_bnb = getenv("SATRN_NO_FUSED_BN_BWD") == nullptr;
-static const bool g_fuse_actb = getenv("SATRN_NO_FUSED_ACT_BWD") == nullptr;
-static const bool g_fuse_bn_eval = getenv("SATRN_NO_FUSED_BN_EVAL") == nullptr;
+static constexpr bool g_fuse_bnb = true, g_fuse_actb = true, g_fuse_bn_eval = true;   // (round-2 A/B switches, retired)
 
 static void acc_grad(Exec& e, Tensor* t, const void* src) {
   // first contribution: alias the producer's gradient buffer (it has no reader left once its own backward ran)
@@ -1324,11 +1322,10 @@ Tensor* op_window_attn(Exec& e, Tensor* qkv, SwinBlock* sb, int B_, const float*
   Tensor* o = e.newt((long)B_ * N, C, B_);
   float* lse = (float*)e.alloc((size_t)B_ * heads * N * 4);
   // relative position bias + shifted-window mask: computed inside the attention kernel from the table parameter and one region
-  // label per token (SATRN_SWIN_BIAS_TENSOR=1: the first form -- gather the bias into [heads][N][N], read it and the
-  // [nW][N][N] mask per score; 10.4 vs 7.1 ms of attention per step)
-  static const bool bias_tensor = getenv("SATRN_SWIN_BIAS_TENSOR") != nullptr;
-  float* bias = (float*)e.alloc((size_t)heads * N * N * 4);
-  if (bias_tensor) LCH(e, launch_relpos_bias(sb->rpb.p, bias, sb->ws, heads, e.s));
+  // label per token (the first form gathered the bias into [heads][N][N] and read it and the [nW][N][N] mask per score: 10.4 vs
+  // 7.1 ms of attention per step in round 2)
+  constexpr bool bias_tensor = false;
+  float* bias = nullptr;
   const size_t es = e.esz();
   AttnP p;
   memset(&p, 0, sizeof(p));
@@ -1355,11 +1352,8 @@ Tensor* op_window_attn(Exec& e, Tensor* qkv, SwinBlock* sb, int B_, const float*
         // dQ, dK and dV in one launch (kernels_attn2.hip); it also leaves the raw-score gradient for the table gradient below
         AttnP q = p;
         q.dO = o->g; q.dQ = dq; q.dK = (char*)dq + (size_t)C * es; q.dV = (char*)dq + (size_t)2 * C * es; q.kv_accum = 0; q.dS = dS;
-        static const bool hist = getenv("SATRN_A2_HIST") != nullptr;   // the in-kernel LDS histogram instead (measured slower)
-        if (hist) { q.dS = nullptr; q.drel = sb->rpb.g; }
         WORK(e, 14.0 * (double)B_ * heads * N * N * hd, ((double)B_ * N * C * 8 + (double)B_ * heads * N * LkP) * es);
         LCH(e, launch_attn2_bwd(q, e.s));
-        if (hist) return;
       }
       void* Pd = fused ? nullptr : e.alloc((size_t)B_ * heads * N * LkP * es);
       AttnP q = p;
@@ -1574,7 +1568,7 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr) {
       float* g1 = eb->se_r.g; float* gb1 = eb->se_rb.g; float* g2 = eb->se_e.g; float* gb2 = eb->se_eb.g;
       float* ds1 = e.zalloc((size_t)B * S);
       bool wide = false;
-      static const bool fold = getenv("SATRN_NO_SE_FOLD") == nullptr;
+      constexpr bool fold = true;
       // x is a BatchNorm output read by this op only: its backward computes y->g*gate + dpooled/HW on the fly, so the gradient
       // tensor se_bwd_x would write is never materialised -- and (round 2) that BatchNorm's backward column sums come out of the
       // two SE kernels as well
@@ -2125,7 +2119,7 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
       // clearing the 109 MB gradient buffer is not on the forward's path: eager two-stream steps do it on the side stream
       // (behind everything the previous step queued on `s`, i.e. its optimizer), beside the forward; the backward waits for it
       Exec& ex = *m->ex;
-      const bool side_zero = ex.s2 && !ex.serial && !use_graph && !getenv("SATRN_ZERO_ON_CHAIN");
+      const bool side_zero = ex.s2 && !ex.serial && !use_graph;
       static hipEvent_t evz0 = nullptr, evz1 = nullptr;
       if (side_zero) {
         if (!evz0) { (void)hipEventCreateWithFlags(&evz0, hipEventDisableTiming); (void)hipEventCreateWithFlags(&evz1, hipEventDisableTiming); }

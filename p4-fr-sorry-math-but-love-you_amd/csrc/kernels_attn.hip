@@ -308,8 +308,7 @@ static int launch_attn_t(const AttnP& p, hipStream_t s) {
   size_t lds = attn_lds_bytes(sizeof(T), qt, LkP, p.hd, MODE);
   if (lds > cap) return -1;
   // a 12 x 12 window: one workgroup (9 waves) takes all 144 queries of a (window, head), so K / V are staged once, not per 64
-  static const bool no144 = getenv("SATRN_ATTN_NO_QT144") != nullptr;
-  if (!no144 && p.Lq == 144 && p.Lk == 144 && attn_lds_bytes(sizeof(T), 144, LkP, p.hd, MODE) <= cap) {
+  if (p.Lq == 144 && p.Lk == 144 && attn_lds_bytes(sizeof(T), 144, LkP, p.hd, MODE) <= cap) {
     launch_attn_inst<T, 144, 16, MODE>(p, attn_lds_bytes(sizeof(T), 144, LkP, p.hd, MODE) + attn_rel_bytes(p), s);
     return 0;
   }

@@ -1137,8 +1137,7 @@ void launch_repack_kpanel(int dt, const void* src, void* dst, int N, int K, hipS
 
 int launch_decode_greedy(int dt, const DecodeP& p0, hipStream_t s) {
   DecodeP p = p0;
-  static const char* dbg = getenv("SATRN_DEC_DBG");  // timing-only ablations (outputs wrong)
-  p.dbg = dbg ? atoi(dbg) : 0;
+  p.dbg = 0;
   if (p.D % 32 || p.F % 32 || p.D > DEC_THREADS || p.nlayers > 4 || (p.D / p.H) % 4) return -1;
   {
     const int ch = dt == DT_BF16 ? 8 : 4, cpr = p.D / ch;

@@ -169,7 +169,7 @@ static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain
   long rpt = (M * gy) / ((long)TY * target_blocks);
   if (rpt < 1) rpt = 1;
   if (rpt > rows_per_thread) rpt = rows_per_thread;
-  static const int force_rpt = getenv("SATRN_COLRED_RPT") ? atoi(getenv("SATRN_COLRED_RPT")) : 0;  // tuning hook
+  constexpr int force_rpt = 0;
   if (force_rpt > 0 && NO <= 2) rpt = force_rpt;
   long rpb = (long)TY * rpt;
   long gx = (M + rpb - 1) / rpb;
@@ -181,11 +181,10 @@ static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain
     gx = (M + rpb - 1) / rpb;
   }
   // the row loop is unrolled by the largest of 4 / 2 / 1 that DIVIDES the rows per thread (see colreduce_kernel)
-  static const bool unr4 = getenv("SATRN_COLRED_UNR4") != nullptr;  // A/B switch: the old fixed unroll factor
   float* part = det_scratch(s, (size_t)gx * NO * C);
-  if (!unr4 && NO <= 2 && rpt % 4 != 0 && rpt % 2 == 0)
+  if (NO <= 2 && rpt % 4 != 0 && rpt % 2 == 0)
     hipLaunchKernelGGL((colreduce_kernel<T, NO, F, (NO <= 2 ? 2 : 4)>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1, nmain, part);
-  else if (!unr4 && NO <= 2 && rpt % 2 != 0 && rpt < 4)
+  else if (NO <= 2 && rpt % 2 != 0 && rpt < 4)
     hipLaunchKernelGGL((colreduce_kernel<T, NO, F, (NO <= 2 ? 1 : 4)>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1, nmain, part);
   else
     hipLaunchKernelGGL((colreduce_kernel<T, NO, F, 4>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1, nmain, part);
@@ -362,7 +361,7 @@ void launch_bn_act(int dt, const void* y, const float* sums, int sums_rep, const
   DISPATCH_T(dt, {
     long n = M * C / TT<T>::CH;
     int CC = C / TT<T>::CH;
-    static const int gdiv = getenv("SATRN_BN_GRIDDIV") ? atoi(getenv("SATRN_BN_GRIDDIV")) : 1;  // tuning hook: chunks per thread
+    constexpr int gdiv = 1;   // chunks per thread
     int g = grid_chan((n + gdiv - 1) / gdiv, CC);
     while ((long)g * 256 < CC) g *= 2;
     hipLaunchKernelGGL((bn_act_kernel<T>), dim3(g), dim3(256), 0, s, (const T*)y, sums, sums_rep < 1 ? 1 : sums_rep, w, b, rm, rv, nbt, eps, mom,
@@ -526,7 +525,7 @@ void launch_bn_act_pool(int dt, const void* y, const float* sums, int sums_rep, 
                         int64_t* nbt, float eps, float mom, float* ss, float* mr, void* z, float* poolsum, long M, int C, int HW, int act,
                         hipStream_t s) {
   float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
-  static const bool img_ok = getenv("SATRN_BNP_NO_IMG") == nullptr;
+  constexpr bool img_ok = true;
   if (img_ok && dt == DT_BF16 && (C % 64) == 0 && HW > 0 && (M % HW) == 0 && sums) {
     // pixel lanes: the largest of 32 / 16 / 8 that divides HW with at most 8 pixels per thread
     const int B = (int)(M / HW);
@@ -543,7 +542,7 @@ void launch_bn_act_pool(int dt, const void* y, const float* sums, int sums_rep, 
   DISPATCH_T(dt, {
     const int CC = C / TT<T>::CH;
     // 24 rows per workgroup where 48 would leave the grid under one workgroup per CU (the 4x12 stage: 192 -> 384 workgroups)
-    static const bool half_ok = getenv("SATRN_BNP_NO_HALF") == nullptr;
+    constexpr bool half_ok = true;
     if (half_ok && (M / BNP_ROWS) * ((CC + 31) / 32) < 256)
       hipLaunchKernelGGL((bn_act_pool_kernel<T, BNP_ROWS / 2>), dim3((int)(M / (BNP_ROWS / 2)), (CC + 31) / 32), dim3(256), 0, s, (const T*)y, sums,
                          sums_rep < 1 ? 1 : sums_rep, w, b, rm, rv, nbt, eps, mom, 1.0f / (float)M, unbias, ss, mr, (T*)z, poolsum, C, HW, act);
@@ -591,7 +590,7 @@ void launch_bn_bwd_reduce(int dt, const void* dz, const void* y, const float* ss
     BnBwdRedF<T> f;
     f.dz = (const T*)dz; f.y = (const T*)y; f.ss = ss; f.mr = mr; f.C = C; f.act = act;
     f.se_gate = (const T*)se_gate; f.se_dpool = (const T*)se_dpool; f.se_hw = se_hw > 0 ? se_hw : 1; f.se_scale = se_hw > 0 ? 1.0f / (float)se_hw : 0.f;
-    static const int tb = getenv("SATRN_BNRED_BLOCKS") ? atoi(getenv("SATRN_BNRED_BLOCKS")) : 512;
+    constexpr int tb = 512;
     launch_colreduce<T, 2>(f, M, C, red, red + C, 1, s, 8, tb, 1024);
   });
 }
@@ -697,7 +696,7 @@ void launch_bn_bwd_apply(int dt, const void* dz, const void* y, const float* ss,
                          int red_rep, const void* se_gate, const void* se_dpool, int se_hw, int eval_stats) {
   DISPATCH_T(dt, {
     long n = M * C / TT<T>::CH;
-    static const int gdiv = getenv("SATRN_BN_GRIDDIV") ? atoi(getenv("SATRN_BN_GRIDDIV")) : 1;  // tuning hook: chunks per thread
+    constexpr int gdiv = 1;   // chunks per thread
     int g = grid_chan((n + gdiv - 1) / gdiv, C / TT<T>::CH);
     while ((long)g * 256 < C) g *= 2;
     // eval statistics: invM = 0 removes the batch-mean / batch-variance terms (Bc = Cc = 0), dw / db stay sum(g*xhat) / sum(g)
@@ -784,7 +783,7 @@ void launch_stem_conv(int dt, const float* img, const float* w, void* y, int B, 
                       int OW, int stride, int pad, hipStream_t s) {
   DISPATCH_T(dt, {
     long n = (long)B * OH * OW * (Co / TT<T>::CH);
-    static const bool one_ok = getenv("SATRN_STEM_GENERIC") == nullptr;
+    constexpr bool one_ok = true;
     if (Cin == 1 && one_ok) {
       // a few pixels per thread amortise the 72 weight loads; total threads a multiple of the chunk count
       const int g = grid_chan((n + 3) / 4, Co / TT<T>::CH);
@@ -1392,7 +1391,7 @@ static bool dwconv_fuses_stats(int H, int W, int OH, int OW, int stride, int pt,
 void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float* bias, void* y, int B, int H, int W,
                    int C, int OH, int OW, int stride, int pt, int pl, int beta, float* stats, hipStream_t s,
                    const float* esc, const float* esh, int eact) {
-  static const bool no_s1 = getenv("SATRN_DW_NO_S1") != nullptr;
+  constexpr bool no_s1 = false;
   if (!no_s1 && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && (W & 1) == 0) {
     if (mode == 0 && stats && !esc && dwconv_fuses_stats(H, W, OH, OW, stride, pt, pl)) {
       DISPATCH_T(dt, {
@@ -1432,8 +1431,7 @@ void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float*
 }
 
 // side-stream kernel (see launch_wgrad_tile): a small grid keeps it out of the data-gradient chain's way
-static const int DWW_BLK = getenv("SATRN_DWW_BLOCKS") ? atoi(getenv("SATRN_DWW_BLOCKS")) : 512;
-static const int DWW_RPT = getenv("SATRN_DWW_RPT") ? atoi(getenv("SATRN_DWW_RPT")) : 8;
+static constexpr int DWW_BLK = 512, DWW_RPT = 8;   // target grid / rows per thread of the depthwise weight gradient (tools/elem_bench.cpp sweeps)
 template <typename T> struct DwWgradF {
   const T* x; const T* dy; int H, W, C, OH, OW, stride, pt, pl;
   __device__ void prep(int) {}

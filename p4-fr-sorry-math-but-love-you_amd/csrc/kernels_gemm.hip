@@ -361,9 +361,8 @@ static void launch_gemm_t(const GemmP& p, hipStream_t s) {
     // wins only on square-ish deep-K problems; 128x64 with ONE k-panel per barrier wins when K >= 512 and the grid is large;
     // 64x64 everywhere else.  The old rule sent every N > 64 product with >= 1024 128x128-tiles to 128x128 with two panels per
     // barrier: 1.8-2x slower on M=9216 N=2048 K=512, M=36864 N=1024 K=256, M=147456 N=512 K=128, M=98304 N=192 K=48, ...
-    static const bool old_rules = getenv("SATRN_GEMM_OLD_RULES") != nullptr;
     const bool small_grid = p.N >= 64 && blocks(64, 64) <= 800;   // the late backbone stages: handled below (64x32 tiles)
-    if (!old_rules && p.N > 32 && !small_grid) {
+    if (p.N > 32 && !small_grid) {
       if (p.N <= 64) {
         if (nk32 >= 8) hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, (AM == AM_DENSE && BF) ? 2 : 1>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((gemm_kernel<T, 64, 64, AM, 1>), dim3(blocks(64, 64)), dim3(256), 0, s, p);
@@ -395,9 +394,7 @@ static void launch_gemm_t(const GemmP& p, hipStream_t s) {
     // small grids (late stages: M <= 6144): 64x32 tiles double the number of workgroups; 13-20 % faster on the
     // M=1536/6144 shapes of tools/gemm_bench.py (SMALLN=1), deep K staged 4 panels per barrier
     const bool no_g2 = getenv("SATRN_GEMM_NO_G2") != nullptr;   // A/B switch, read per call (tests)
-    static const bool g4 = getenv("SATRN_GEMM_G4") != nullptr;
-    if (nk32 >= 24 && BF && !no_g2 && g4 && blocks(64, 32) <= 512) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D && BF ? 4 : 1), (D && BF ? 4 : 1)>), dim3(blocks(64, 32)), dim3(D && BF ? 1024 : 256), 0, s, p);
-    else if (nk32 >= 24 && BF && !no_g2 && blocks(64, 32) <= 512) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D && BF ? 4 : 1), (D && BF ? 2 : 1)>), dim3(blocks(64, 32)), dim3(D && BF ? 512 : 256), 0, s, p);
+    if (nk32 >= 24 && BF && !no_g2 && blocks(64, 32) <= 512) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D && BF ? 4 : 1), (D && BF ? 2 : 1)>), dim3(blocks(64, 32)), dim3(D && BF ? 512 : 256), 0, s, p);
     else if (nk32 >= 24 && BF) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D && BF ? 4 : 1)>), dim3(blocks(64, 32)), dim3(256), 0, s, p);
     else if (nk32 >= 4) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D ? 2 : 1)>), dim3(blocks(64, 32)), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, 1>), dim3(blocks(64, 32)), dim3(256), 0, s, p);
@@ -581,10 +578,10 @@ static bool conv_halo_launch(int amode, const GemmP& p, hipStream_t s) {
   if ((long)B * H * W != p.M) return false;
   const int BN = p.N <= 32 ? 32 : 64;
   // channel slices (see the kernel): halve while the patch is above the threshold and the slice stays a multiple of 32 channels
-  static const int split_kb = getenv("SATRN_HALO_SPLIT_KB") ? atoi(getenv("SATRN_HALO_SPLIT_KB")) : 40;
+  constexpr int split_kb = 40;
   int NS = 1;
   while ((size_t)(HC_TH + 2) * (HC_TW + 2) * (C / NS + 8) * 2 > (size_t)split_kb * 1024 && (C % (NS * 2)) == 0 && ((C / (NS * 2)) % 32) == 0) NS *= 2;
-  static const int kp_env = getenv("SATRN_HALO_KP") ? atoi(getenv("SATRN_HALO_KP")) : 2;
+  constexpr int kp_env = 2;
   const int KPv = (BN == 64 && kp_env == 2 && 9 * (C / NS) >= 512) ? 2 : 1;   // deep k streams: two weight panels per barrier
   const size_t sh = (size_t)(HC_TH + 2) * (HC_TW + 2) * (C / NS + 8) * 2 + (size_t)2 * KPv * BN * 32 * 2;
   if (sh > 150 * 1024) return false;
@@ -690,7 +687,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
 
 template <typename T>
 static bool gemm_skinny_launch(const GemmP& p, hipStream_t s) {
-  static const bool off = getenv("SATRN_NO_SKINNY_GEMM") != nullptr;
+  constexpr bool off = false;
   if (off || p.M > 64 || (p.K & 31) || p.K > 1024 || p.stats || p.bnb_y || p.escale || p.pre_out || p.bact_u || (p.lda & 7)) return false;
   const int mt = (p.M + 15) / 16;
   const int steps = ((p.K >> 5) + 3) / 4;  // k-steps per wave

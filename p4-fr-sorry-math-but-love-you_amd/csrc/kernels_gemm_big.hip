@@ -804,7 +804,7 @@ bool wgrad_big_launch(const WgradP& w, hipStream_t s) {
   p.ntn = (w.N + bno - 1) / bno; p.ntk = (w.K + 127) / 128;
   const int tiles = p.ntn * p.ntk;
   // slices of M: enough items to fill the persistent grid (at least 256 rows per slice)
-  int target = w.full_grid ? cus : (getenv("SATRN_WGRAD_BIG_ITEMS") ? atoi(getenv("SATRN_WGRAD_BIG_ITEMS")) : cus);
+  const int target = cus;   // (a smaller item count for the side stream was measured: no gain)
   // Slices of M: the persistent grid runs its items in rounds, so what counts is rounds x (k-steps per item + the item's fixed part, its
   // 16 K atomics ~ 3 k-steps) -- not merely "at least one item per CU": 36 tiles x 8 slices = 288 items on 256 CUs cost two rounds of 18
   // k-steps where 7 slices (252 items) cost one round of 21 (SwinTRN fc1 / fc2 at M = 9 216: 55 -> 3x us).
