@@ -23,6 +23,7 @@
 // with gemm_kernel; gemm_big_launch() returns false for those.
 // Reference shapes: networks/SWIN.py:84-209 (qkv / proj), :24-47 (Mlp fc1 / fc2), networks/EfficientSATRN.py:66-87 (1x1 convs).
 #include <stdio.h>
+#include <algorithm>
 #include <stdlib.h>
 
 #include "common.h"
@@ -765,7 +766,8 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
   if (force_mt >= 2 && force_mt <= mt_max) best_mt = force_mt;
   p.ntm = (g.M + 64 * best_mt - 1) / (64 * best_mt);
   p.ntiles = p.ntm * p.ntn;
-  const int grid = p.ntiles < cus ? p.ntiles : cus;
+  int grid = p.ntiles < cus ? p.ntiles : cus;
+  if (getenv("SATRN_BIG_GRID")) grid = std::min(grid, std::max(1, atoi(getenv("SATRN_BIG_GRID"))));   // experiment: fewer CUs, same tiles
   if (best_mt == 4) big_launch_t<4>(p, grid, s);
   else if (best_mt == 3) big_launch_t<3>(p, grid, s);
   else big_launch_t<2>(p, grid, s);
