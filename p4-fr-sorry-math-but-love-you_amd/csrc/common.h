@@ -110,6 +110,27 @@ DEVI float gelu_core(float u, float* phi_out) {   // returns Phi(u) = 0.5 (1 + e
   const float half_erf = 0.5f * erf_abs;
   return u >= 0.f ? 0.5f + half_erf : 0.5f - half_erf;
 }
+// two elements at a time: the polynomial, the scalings and the combinations become packed f32 instructions (v_pk_fma_f32 / v_pk_mul_f32:
+// one issue slot per PAIR), only v_rcp / v_exp stay per element.  g = gelu(u), d = gelu'(u).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEVI void gelu_pair(f32x2 u, f32x2* g, f32x2* d) {
+  const f32x2 au = __builtin_elementwise_abs(u);
+  const f32x2 z = au * 0.70710678118654752f;
+  const f32x2 den = __builtin_elementwise_fma(z, (f32x2)(0.3275911f), (f32x2)(1.0f));
+  f32x2 t; t.x = __builtin_amdgcn_rcpf(den.x); t.y = __builtin_amdgcn_rcpf(den.y);
+  f32x2 poly = __builtin_elementwise_fma(t, (f32x2)(1.061405429f), (f32x2)(-1.453152027f));
+  poly = __builtin_elementwise_fma(poly, t, (f32x2)(1.421413741f));
+  poly = __builtin_elementwise_fma(poly, t, (f32x2)(-0.284496736f));
+  poly = __builtin_elementwise_fma(poly, t, (f32x2)(0.254829592f));
+  poly = poly * t;
+  const f32x2 a = (z * z) * -1.44269504088896341f;
+  f32x2 e; e.x = __builtin_amdgcn_exp2f(a.x); e.y = __builtin_amdgcn_exp2f(a.y);   // exp(-u^2 / 2)
+  const f32x2 half_erf = __builtin_elementwise_fma(poly * -0.5f, e, (f32x2)(0.5f));   // 0.5 erf(|u| / sqrt 2)
+  // Phi(u) = 0.5 + sign(u) * half_erf;  u * Phi(u) = 0.5 u + |u| * half_erf
+  const f32x2 P = (f32x2)(0.5f) + __builtin_elementwise_copysign(half_erf, u);
+  *g = __builtin_elementwise_fma(au, half_erf, u * 0.5f);
+  *d = __builtin_elementwise_fma(u * 0.3989422804014327f, e, P);
+}
 DEVI float gelu_fast(float u) { float e; return u * gelu_core(u, &e); }
 DEVI float gelu_grad_fast(float u) { float e; const float P = gelu_core(u, &e); return __builtin_fmaf(u * 0.3989422804014327f, e, P); }
 

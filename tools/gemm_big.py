@@ -29,5 +29,12 @@ if os.environ.get('SHAPES'):         # SHAPES="9216,1536,384;9216,384,1536"
 for M, N, K in SHAPES:
     x = (torch.rand(M, K, device="cuda") * 2 - 1).bfloat16(); w = (torch.rand(N, K, device="cuda") * 2 - 1).bfloat16()
     y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    us = bench(lambda: lib.satrn_linear_fwd(1, P(x), P(w), None, P(y), M, N, K, 0, 0, 0.0, None, 0, st()))
+    if os.environ.get('ACT_FWD'):     # the training-forward form: bias + GELU + act'(u) stored beside it (epilogue kind 2)
+        b = torch.rand(N, device="cuda"); d = torch.empty_like(y)
+        us = bench(lambda: lib.satrn_linear_act_fwd(1, P(x), P(w), P(b), P(y), P(d), M, N, K, 4, st()))
+    elif os.environ.get('BIAS'):
+        b = torch.rand(N, device="cuda")
+        us = bench(lambda: lib.satrn_linear_fwd(1, P(x), P(w), P(b), P(y), M, N, K, 0, 0, 0.0, None, 0, st()))
+    else:
+        us = bench(lambda: lib.satrn_linear_fwd(1, P(x), P(w), None, P(y), M, N, K, 0, 0, 0.0, None, 0, st()))
     print(f"M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TFLOP/s  force={os.environ.get('SATRN_GEMM_FORCE','-')}")
