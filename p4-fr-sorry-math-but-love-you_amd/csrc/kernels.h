@@ -66,6 +66,7 @@ struct GemmP {
   // erf / exp of it in hand already (GELU: the dgrad epilogue's derivative pass, 55 us of VALU work on four waves per CU at
   // [9216][1536], becomes one multiply); the consumer then passes bact = ACT_DFACTOR
   int pre_grad;
+  int dbg_no_stats_atomics;   // timing experiment (SATRN_TIMING_NO_STATS_ATOMICS; wrong statistics)
   float bact_scale;   // times this (ReLU + dropout: bact_u is the stored OUTPUT, whose zeros cover both, and 1/(1-p) the kept ones' scale); 0 = 1
 };
 // eval-mode BatchNorm scale / shift of every BatchNorm of a model in ONE launch: out[0..C) = w * rsqrt(rv + eps),

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
           p.stats_part[((size_t)(tile_m * (BM / 64) + q) * 2 + (i < BN ? 0 : 1)) * p.N + col] = q == 0 ? tot : 0.f;
       } else {
         // narrow outputs with a tall grid: spread the same-address atomics over stats_rep replicas of [2N]
-        atomicAdd(p.stats + (size_t)(tile_m % p.stats_rep) * 2 * p.N + (i < BN ? 0 : p.N) + col, tot);
+        if (!p.dbg_no_stats_atomics) atomicAdd(p.stats + (size_t)(tile_m % p.stats_rep) * 2 * p.N + (i < BN ? 0 : p.N) + col, tot);
       }
     }
   }
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, in
     __syncthreads();
     for (int i = tid; i < 2 * BN; i += 256) {
       const int cc = i < BN ? i : i - BN, col = n0 + cc;
-      if (col < p.N) atomicAdd(p.stats + (size_t)(tile_m % p.stats_rep) * 2 * p.N + (i < BN ? 0 : p.N) + col, sred[i]);
+      if (col < p.N && !p.dbg_no_stats_atomics) atomicAdd(p.stats + (size_t)(tile_m % p.stats_rep) * 2 * p.N + (i < BN ? 0 : p.N) + col, sred[i]);
     }
   }
 }
@@ -704,6 +704,10 @@ void launch_gemm(int dt, int amode, const GemmP& p0, hipStream_t s) {
   if (p0.M <= 0 || p0.N <= 0) return;
   GemmP p = p0;
   p.stats_part = nullptr;
+  {
+    static const bool nsa = [] { const bool on = getenv("SATRN_TIMING_NO_STATS_ATOMICS") != nullptr; if (on) fprintf(stderr, "[satrn] WARNING: SATRN_TIMING_NO_STATS_ATOMICS is set -- BatchNorm statistics are NOT accumulated (timing experiment)\n"); return on; }();
+    p.dbg_no_stats_atomics = nsa ? 1 : 0;
+  }
   const int nslots = (p.M + 63) / 64;
   if (p.stats) p.stats_part = det_scratch(s, (size_t)(nslots + 4) * 2 * p.N);  // null unless the deterministic mode is on
   if (!p.stats_part && dt == DT_BF16 && amode != AM_DENSE && conv_halo_launch(amode, p, s)) return;

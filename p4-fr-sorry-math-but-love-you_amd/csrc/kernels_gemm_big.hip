@@ -1,26 +1,32 @@
 // Large dense bf16 GEMM for gfx950:  C[M,N] = epilogue(A[M,K] * W[N,K]^T)   (both operands K-contiguous)
 //
 // The 4-wave register-staged kernel of kernels_gemm.hip tops out below 20 % of the MFMA peak on the big products of SwinTRN
-// (M = 9 216 .. 147 456, K = 128 .. 2 048) and the early backbone stages: every k-step is global load -> VGPR -> ds_write ->
+// (M = 9 216 .. 147 456, K = 96 .. 2 048) and the early backbone stages: every k-step is global load -> VGPR -> ds_write ->
 // barrier -> ds_read -> MFMA by the same four waves, and every tile pays its own prologue and store tail.  This kernel is
 // the chip-filling form:
-//   * PERSISTENT: one 512-thread workgroup (8 waves, 4 along M x 2 along N) per compute unit walks a list of output tiles; the
-//     (tile, k-step) pairs of a workgroup form ONE stream, so the operand loads of the next tile are in flight while the
-//     current tile is multiplied and stored -- no per-tile prologue bubble (K = 128 .. 512 means only 2 .. 8 k-steps per tile).
-//   * DIRECT-TO-LDS: operands go global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPRs, no ds_write); three 64-deep
-//     stages of (BM + 128) rows x 128 B form a ring, two stages in flight behind a COUNTED s_waitcnt vmcnt and ONE raw
-//     s_barrier per k-step.  Out-of-range rows (M / N tails) are zero-filled by the buffer descriptor's range check.
+//   * PERSISTENT: one 512-thread workgroup per compute unit walks a list of output tiles (BM x 128, BM = 128 / 192 / 256 chosen per
+//     launch: fewest rounds x rows on the grid); the (tile, k-step) pairs of a workgroup form ONE stream, so the operand loads of the next
+//     tile are in flight while the current tile is multiplied and stored (K = 96 .. 512 means only 2 .. 8 k-steps per tile).
+//   * PRODUCER / CONSUMER WAVES: waves 4-7 only issue loads, waves 0-3 (2 along M x 2 along N, wave tile BM/2 x 64) only multiply and
+//     store.  The loaders count their own DMA operations (`s_waitcnt vmcnt(N)` with N = the operations of the stages allowed to stay in
+//     flight); the two groups meet at ONE raw s_barrier per k-step.
+//   * DIRECT-TO-LDS: operands go global -> LDS with `buffer_load_dwordx4 ... offen lds` (no VGPRs, no ds_write); three 64-deep
+//     stages of (BM + 128) rows x 128 B form a ring.  Out-of-range rows (M / N tails) and the K tail are zero-filled by the buffer
+//     descriptor's range check.
 //   * LDS image: row-major 128-byte rows, 16-byte chunk c of row r stored at chunk position c ^ ((r >> 1) & 7): the DMA writes
 //     lane-linear (8 lanes = one row), so the swizzle is applied to each lane's SOURCE address and again on the fragment
 //     reads -- ds_read_b128 of an MFMA fragment (16 rows x one chunk per 16-lane group) is then bank-conflict free.
-//   * fragments are double-buffered in registers across the barrier: the ds_reads of half a k-step run under the 16 MFMAs
-//     of the other half.
+//   * fragments are double-buffered in registers across the barrier: the ds_reads of half a k-step run under the MFMAs of the other half.
 //   * the MFMA is issued with the operands swapped (D' = W_frag x A_frag^T), so a lane holds FOUR CONSECUTIVE output columns of
-//     one row; the tile goes through a per-wave LDS scratch (16 rows x 128 B, XOR-swizzled) and leaves as whole 128-byte row
-//     segments, 16 bytes per lane (the old epilogue stored one 2-byte element per lane).
-// Epilogue subset: bias (added to the initial accumulator), activation, pre-activation copy (pre_out), act'(u) factor of a data
-// gradient (bact_u), accumulate (beta).  Everything else (BatchNorm statistics, dropout, f32 output, inference scale/shift) stays
-// with gemm_kernel; gemm_big_launch() returns false for those.
+//     one row; the tile goes through a per-wave LDS scratch (2 x 16 rows x 128 B, XOR-swizzled) and leaves as whole 128-byte row
+//     segments, 16 bytes per lane (the 4-wave kernel stores one 2-byte element per lane; 8-byte stores straight from the accumulator
+//     layout were measured too: 10-25 % slower than the LDS hop).
+// Epilogue: bias (the initial accumulator), activation, BatchNorm statistics / BatchNorm-backward sums (STATS), and by epilogue kind EK
+// a second tensor: act'(u) stored beside the activation, a stored factor multiplied in, accumulate.  Dropout, f32 output and the
+// inference scale / shift stay with gemm_kernel; gemm_big_launch() returns false for those.
+// Measured limits: the main loop runs at the LDS fill rate, 63 GB/s per CU alone and 48 GB/s per CU with all 256 CUs
+// busy (tools/gemm_big_grid.sh), i.e. ~50 % of the MFMA rate of its tile; LDS reads (each operand row is read by two consumer waves)
+// plus DMA writes are 120 KB per k-step against 128 B/clk.
 // Reference shapes: networks/SWIN.py:84-209 (qkv / proj), :24-47 (Mlp fc1 / fc2), networks/EfficientSATRN.py:66-87 (1x1 convs).
 #include <stdio.h>
 #include <algorithm>
@@ -388,8 +394,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
       const int c = tn * BN + wn * 64 + lane;
       if (c < p.N) {
         float* dst = p.stats + (size_t)(tm % p.stats_rep) * 2 * p.N + c;
-        atomicAdd(dst, a1);
-        atomicAdd(dst + p.N, a2);
+        if (!(p.dbg & 32)) { atomicAdd(dst, a1); atomicAdd(dst + p.N, a2); }
       }
     }
   };
@@ -736,7 +741,8 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
     // 4.91 ms over the family): a 160 KB workgroup needs a whole drained CU to start and leaves no room for the side stream
     const double min_gflop = getenv("SATRN_GEMM_BIG_MIN_GFLOP") ? atof(getenv("SATRN_GEMM_BIG_MIN_GFLOP")) : 2.0;
     const double flops = 2.0 * g.M * g.N * g.K;
-    if (mode != 2 && (flops < min_gflop * 1e9 || g.N < 128 || g.M < 2048)) return false;
+    const int min_n = getenv("SATRN_GEMM_BIG_MIN_N") ? atoi(getenv("SATRN_GEMM_BIG_MIN_N")) : 128;
+    if (mode != 2 && (flops < min_gflop * 1e9 || g.N < min_n || g.M < 2048)) return false;
   }
   BigP p;
   p.A = (const bf16_t*)g.A; p.W = (const bf16_t*)g.Bw; p.C = (bf16_t*)g.C; p.bias = g.bias;
