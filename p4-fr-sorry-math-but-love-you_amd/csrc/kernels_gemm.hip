@@ -266,7 +266,14 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
   // [4 waves][2][BN] column sums for the BatchNorm that follows (LDS is free now).  Every (wave, column) slot has exactly one
   // writer and the four row groups are summed in a fixed order: the in-block part of the statistics is deterministic
   float* sred = reinterpret_cast<float*>(lds);
-  if (p.stats) __syncthreads();  // all waves are done reading the last k-panel
+  // bf16 outputs leave through an LDS image of the tile (behind the column-sum slots) and are stored as whole 16-byte chunks, rows
+  // contiguous: straight from the accumulator layout a lane stores ONE 2-byte element (16 lanes = 32 contiguous bytes per instruction),
+  // i.e. eight times the store instructions and a 1.45x write amplification at the memory side (profiles/r02_pmc_traffic.json).  Chunk c of
+  // row r sits at chunk position c ^ ((r >> 2) & (BN / 8 - 1)): the four row groups of a wave's 2-byte writes land on different banks.
+  constexpr bool STG = sizeof(T) == 2 && (32 * BN + BM * BN * 2 <= 2 * STAGE * (int)sizeof(T));
+  T* stg = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(lds) + 32 * BN);
+  const bool stage_out = STG && !p.out_f32 && (p.ldc & 7) == 0 && (p.N & 7) == 0 && (((size_t)p.C) & 15) == 0;
+  if (p.stats || stage_out) __syncthreads();  // all waves are done reading the last k-panel
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + j * 16 + fr;
@@ -300,7 +307,12 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
         } else {
           T* c = (T*)p.C;
           tot = p.beta ? to_f(c[o]) + v : v;
-          c[o] = from_f<T>(tot);
+          if (STG && stage_out) {
+            const int rl = wave * (BM / 4) + i * 16 + fq * 4 + r, cl = j * 16 + fr;
+            stg[rl * BN + ((((cl >> 3) ^ ((rl >> 2) & (BN / 8 - 1))) << 3) | (cl & 7))] = from_f<T>(tot);
+          } else {
+            c[o] = from_f<T>(tot);
+          }
         }
         if (p.bnb_y) {
           const float yv = to_f(((const T*)p.bnb_y)[(long)row * p.N + col]);
@@ -317,8 +329,20 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
       if (fq == 0 && writer) { sred[wave * 2 * BN + j * 16 + fr] = s1; sred[wave * 2 * BN + BN + j * 16 + fr] = s2; }
     }
   }
+  if (p.stats || stage_out) __syncthreads();
+  if (stage_out && writer) {
+    T* c = (T*)p.C;
+    constexpr int CPRW = BN / 8;   // 16-byte chunks per tile row
+#pragma unroll
+    for (int q = 0; q < (BM * CPRW + 255) / 256; ++q) {
+      const int idx = tid + q * 256;
+      const int rl = idx / CPRW, cc8 = idx - rl * CPRW;
+      const int row = m0 + rl, col = n0 + cc8 * 8;
+      if (idx < BM * CPRW && row < p.M && col < p.N)
+        st16(c + (long)row * p.ldc + col, ld16(stg + rl * BN + ((cc8 ^ ((rl >> 2) & (CPRW - 1))) << 3)));
+    }
+  }
   if (p.stats) {
-    __syncthreads();
     for (int i = tid; i < 2 * BN; i += 256) {
       int c = i < BN ? i : i - BN, col = n0 + c;
       if (col >= p.N || !writer) continue;
