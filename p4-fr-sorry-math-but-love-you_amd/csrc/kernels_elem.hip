@@ -1919,10 +1919,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
 // (the engine: the side stream, the sums feed only the optimizer).
 int layernorm_bwd_blocks(long R) { return grid_for(R, 16, 1024); }
 
-__global__ __launch_bounds__(256) void layernorm_fold_kernel(const float* part, int nrep, int n, int C, float* dw, float* dbias) {
+__global__ __launch_bounds__(256) void layernorm_fold_kernel(const float* part, int nrep_all, int n, int C, float* dw, float* dbias) {
+  // gridDim.y > 1: the partial rows are split over blockIdx.y and each slice adds its sums with one atomic per column (a dozen blocks
+  // walking 576 rows of 3 KB took 15 us; not in the deterministic mode, which keeps gridDim.y = 1 and the plain add)
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
+  const int per = (nrep_all + gridDim.y - 1) / gridDim.y;
+  part += (size_t)blockIdx.y * per * n;
+  const int nrep = max(0, min(per, nrep_all - (int)blockIdx.y * per));
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (i < n) {
     int r = wv;
@@ -1935,11 +1940,13 @@ __global__ __launch_bounds__(256) void layernorm_fold_kernel(const float* part, 
   __syncthreads();
   if (wv == 0 && i < n) {
     const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    if (i < C) dw[i] += t; else dbias[i - C] += t;
+    float* dst = i < C ? dw + i : dbias + (i - C);
+    if (gridDim.y > 1) atomicAdd(dst, t); else *dst += t;
   }
 }
 void launch_layernorm_fold(const float* part, int nblocks, int C, float* dw, float* dbias, hipStream_t s) {
-  hipLaunchKernelGGL(layernorm_fold_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, s, part, nblocks, 2 * C, C, dw, dbias);
+  const int ys = g_det.on ? 1 : (nblocks >= 256 ? 8 : (nblocks >= 64 ? 4 : 1));
+  hipLaunchKernelGGL(layernorm_fold_kernel, dim3((2 * C + 63) / 64, ys), dim3(256), 0, s, part, nblocks, 2 * C, C, dw, dbias);
 }
 
 #define LNB_GO(NCH, RPW) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, RPW>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a, \

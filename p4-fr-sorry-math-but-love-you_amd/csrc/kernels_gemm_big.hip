@@ -830,6 +830,8 @@ bool wgrad_big_launch(const WgradP& w, hipStream_t s) {
       if (cost < best - 1e-9) { best = cost; splits = sp2; rps = r; }
     }
   }
+  // (measured: 2-4x more, shorter items on the side stream, one per workgroup, so that CUs are released more often for the chain's
+  // persistent kernels -- SwinTRN 17.9 -> 19.4-20.3 ms per step: the extra partial-tile traffic and fold work cost more)
   p.splits = splits; p.rows_per_split = rps; p.nitems = tiles * splits;
   // partial tiles instead of atomics when a slab is there (engine calls) and there is something to fold
   p.part = nullptr;
