@@ -2105,7 +2105,58 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, long M, int C, 
     else atomicAdd(out + c, a);
   }
 }
+// wide matrices (the raw-score gradients of SwinTRN's windows summed over the windows: 69 K .. 553 K columns, 16 .. 1 024 rows): a thread owns
+// one 16-byte chunk of columns and walks a slice of the rows (colsum_kernel reads ONE element per thread and row: 127 us for 189 MB)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const T* x, long M, int CC, int ld, float* out, int rows_per_block) {
+  constexpr int CH = TT<T>::CH;
+  const int cc = blockIdx.y * 256 + threadIdx.x;
+  if (cc >= CC) return;
+  long r0 = (long)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  float acc[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+  const T* px = x + (long)cc * CH;
+  long r = r0;
+  for (; r + 3 < r1; r += 4) {
+    const uint4 v0 = ld16(px + r * ld), v1 = ld16(px + (r + 1) * ld), v2 = ld16(px + (r + 2) * ld), v3 = ld16(px + (r + 3) * ld);
+    float f0[CH], f1[CH], f2[CH], f3[CH];
+    unpack<T>(v0, f0); unpack<T>(v1, f1); unpack<T>(v2, f2); unpack<T>(v3, f3);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] += (f0[j] + f1[j]) + (f2[j] + f3[j]);
+  }
+  for (; r < r1; ++r) {
+    float f[CH];
+    unpack<T>(ld16(px + r * ld), f);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] += f[j];
+  }
+  float* po = out + (long)cc * CH;
+  if (gridDim.x == 1) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) po[j] += acc[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) atomicAdd(po + j, acc[j]);
+  }
+}
 void launch_colsum(int dt, const void* x, long M, int C, int ld, float* out, hipStream_t s) {
+  if (!g_det.on && C >= 8192 && (C % 8) == 0 && (ld % 8) == 0) {
+    DISPATCH_T(dt, {
+      const int CC = C / TT<T>::CH;
+      const int gy = (CC + 255) / 256;
+      // row slices only where the rows are many: a slice costs eight atomics per thread, which at 64 rows outweighed the reads (57 us against
+      // 21 us for the one-element kernel); with one slice the sums are added with plain stores
+      long gx = M >= 256 ? 1024 / gy : 1;
+      if (gx > M / 32) gx = M / 32;
+      if (gx < 1) gx = 1;
+      const long rpb = (M + gx - 1) / gx;
+      gx = (M + rpb - 1) / rpb;
+      hipLaunchKernelGGL((colsum_wide_kernel<T>), dim3((int)gx, gy), dim3(256), 0, s, (const T*)x, M, CC, ld, out, (int)rpb);
+    });
+    return;
+  }
   DISPATCH_T(dt, {
     int gy = (C + 63) / 64;
     long want = 512 / gy;

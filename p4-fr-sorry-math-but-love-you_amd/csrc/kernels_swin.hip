@@ -144,27 +144,27 @@ __global__ void relpos_bias_kernel(const float* table, float* bias, int ws, int 
 void launch_relpos_bias(const float* table, float* bias, int ws, int heads, hipStream_t s) {
   hipLaunchKernelGGL(relpos_bias_kernel, dim3(grid_for((long)heads * ws * ws * ws * ws)), dim3(256), 0, s, table, bias, ws, heads);
 }
-// dtable[e][h] += sum over the (i, j) pairs with idx(i, j) == e of dbias[h][i][ld*..]: one workgroup per table entry walks the
-// (at most ws*ws) pairs that map to it in a fixed order -- no atomics, deterministic.  dbias [heads][N][ld] (ld >= N).
-__global__ __launch_bounds__(64) void relpos_bias_bwd_kernel(const float* dbias, float* dtable, int ws, int heads, int ld, float scale) {
+// dtable[e][h] += sum over the (i, j) pairs with idx(i, j) == e of dbias[h][i][ld*..]: one workgroup per table entry; wave w takes the heads
+// w, w + 4, ..., its lanes the (at most ws*ws) query positions i whose partner j = i - (dy, dx) lies in the window, summed by a wave
+// reduction in a fixed order -- no atomics, deterministic.  (The first form gave every HEAD a lane, 3 .. 24 active lanes each walking up to
+// 144 strided loads: 25 us per launch for 276 K floats.)  dbias [heads][N][ld] (ld >= N).
+__global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const float* dbias, float* dtable, int ws, int heads, int ld, float scale) {
   const int N = ws * ws, e = blockIdx.x;
   const int dy = e / (2 * ws - 1) - (ws - 1), dx = e % (2 * ws - 1) - (ws - 1);
-  for (int h = threadIdx.x; h < heads; h += blockDim.x) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int h = wv; h < heads; h += 4) {
     float a = 0.f;
-    for (int yi = 0; yi < ws; ++yi) {
-      const int yj = yi - dy;
-      if (yj < 0 || yj >= ws) continue;
-      for (int xi = 0; xi < ws; ++xi) {
-        const int xj = xi - dx;
-        if (xj < 0 || xj >= ws) continue;
-        a += dbias[((long)h * N + yi * ws + xi) * ld + yj * ws + xj];
-      }
+    for (int i = lane; i < N; i += 64) {
+      const int yi = i / ws, xi = i - yi * ws;
+      const int yj = yi - dy, xj = xi - dx;
+      if (yj >= 0 && yj < ws && xj >= 0 && xj < ws) a += dbias[((long)h * N + i) * ld + yj * ws + xj];
     }
-    dtable[(long)e * heads + h] += a * scale;
+    a = wave_sum(a);
+    if (lane == 0) dtable[(long)e * heads + h] += a * scale;
   }
 }
 void launch_relpos_bias_bwd(const float* dbias, float* dtable, int ws, int heads, int ld, float scale, hipStream_t s) {
-  hipLaunchKernelGGL(relpos_bias_bwd_kernel, dim3((2 * ws - 1) * (2 * ws - 1)), dim3(64), 0, s, dbias, dtable, ws, heads, ld, scale);
+  hipLaunchKernelGGL(relpos_bias_bwd_kernel, dim3((2 * ws - 1) * (2 * ws - 1)), dim3(256), 0, s, dbias, dtable, ws, heads, ld, scale);
 }
 
 // ---- stochastic depth (timm DropPath): out = shortcut + branch * keep[b] / (1 - p), keep[b] drawn per SAMPLE.
