@@ -510,33 +510,41 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void wgrad_big_kernel(BigWP p) {
     const int xr = lane / (XROW / 16), xs = lane % (XROW / 16);
     const unsigned ldy2 = (unsigned)p.ldy * 2u, lda2 = (unsigned)p.lda * 2u;
     int d_item = 0, d_k = 0;
-    int m_item0 = 0, m_end = 0, n0 = 0, k0 = 0;
+    // per-lane source offsets of this wave's pieces, fixed for an item (rows of the stage x the lane's swizzled 16-byte column chunk); the
+    // k-step only adds a wave-uniform row offset.  Rows past the end of M are zero-filled by the descriptor's range check -- slices
+    // are whole multiples of 64 rows, so only the last slice can run past its end, and its end is M.  (The first form recomputed row,
+    // swizzle, chunk, bounds and a 32-bit multiply per piece and k-step: ~40 VALU instructions x 8 pieces per loader wave and k-step.)
+    unsigned offY[NYP], offX[NXP];
+    int m_item0 = 0;
     auto dma_item_setup = [&](int ii) {
       int sp, tn, tk;
       item_of(ii, sp, tn, tk);
       m_item0 = sp * p.rows_per_split;
-      m_end = min(p.M, m_item0 + p.rows_per_split);
-      n0 = tn * BNo; k0 = tk * BKo;
-    };
-    auto dma_issue = [&](int slot) {
-      const unsigned sbase = lds0 + (unsigned)slot * STAGE;
-      const int mb = m_item0 + d_k * 64;
+      const int n0 = tn * BNo, k0 = tk * BKo;
 #pragma unroll
       for (int j = 0; j < NYP; ++j) {
         const int ml = (lw + 4 * j) * RPY + yr;                                  // row of the stage
         const int h = (ml & 3) | (((ml >> 3) & 1) << 2);
         const int c = ((((ys >> 1) ^ h) << 1) | (ys & 1));                        // source chunk (8 columns)
-        const bool okr = mb + ml < m_end && n0 + c * 8 < p.N;
-        dma16(rY, sbase + (unsigned)(lw + 4 * j) * 1024u, okr ? (unsigned)(mb + ml) * ldy2 + (unsigned)(n0 + c * 8) * 2u : 0xfffffff0u, 0);
+        offY[j] = n0 + c * 8 < p.N ? (unsigned)ml * ldy2 + (unsigned)(n0 + c * 8) * 2u : 0xfffffff0u;
       }
 #pragma unroll
       for (int j = 0; j < NXP; ++j) {
         const int ml = (lw + 4 * j) * RPX + xr;
         const int h = (ml & 3) | (((ml >> 3) & 1) << 2);
         const int c = ((((xs >> 1) ^ h) << 1) | (xs & 1));
-        const bool okr = mb + ml < m_end && k0 + c * 8 < p.K;
-        dma16(rX, sbase + XOFF + (unsigned)(lw + 4 * j) * 1024u, okr ? (unsigned)(mb + ml) * lda2 + (unsigned)(k0 + c * 8) * 2u : 0xfffffff0u, 0);
+        offX[j] = k0 + c * 8 < p.K ? (unsigned)ml * lda2 + (unsigned)(k0 + c * 8) * 2u : 0xfffffff0u;
       }
+    };
+    auto dma_issue = [&](int slot) {
+      const unsigned sbase = lds0 + (unsigned)slot * STAGE;
+      const int mb = m_item0 + d_k * 64;
+      // (the row offset goes into the VECTOR offset: the range check does not see the scalar offset)
+      const unsigned rY0 = (unsigned)mb * ldy2, rX0 = (unsigned)mb * lda2;
+#pragma unroll
+      for (int j = 0; j < NYP; ++j) dma16(rY, sbase + (unsigned)(lw + 4 * j) * 1024u, offY[j] == 0xfffffff0u ? 0xfffffff0u : offY[j] + rY0, 0);
+#pragma unroll
+      for (int j = 0; j < NXP; ++j) dma16(rX, sbase + XOFF + (unsigned)(lw + 4 * j) * 1024u, offX[j] == 0xfffffff0u ? 0xfffffff0u : offX[j] + rX0, 0);
       if (++d_k == KT) { d_k = 0; ++d_item; if (d_item < my_items) dma_item_setup(d_item); }
     };
     constexpr int P = NYP + NXP;   // DMA instructions per loader wave and stage
