@@ -1103,10 +1103,10 @@ Tensor* op_posenc_apply(Exec& e, Tensor* x, Tensor* gate) {
 
 // LayerNorm backward: dx on the main stream; the per-block (dw | dbias) partials are folded on the side stream (optimizer-only sums)
 static void ln_backward(Exec& e, const void* dy, const void* a, const void* b, LNp* ln, const float* mr, void* da, void* db, int ba, int bb,
-                        long R, int C, RowMap dmap = RowMap()) {
+                        long R, int C, RowMap dmap = RowMap(), LnAdd add = LnAdd()) {
   const int g = layernorm_bwd_blocks(R);
   float* part = (float*)e.alloc((size_t)g * 2 * C * sizeof(float));
-  LCH(e, launch_layernorm_bwd(e.dt, dy, a, b, ln->w.p, mr, da, db, ba, bb, ln->w.g, ln->b.g, R, C, 0.f, nullptr, 0, e.s, part, dmap));
+  LCH(e, launch_layernorm_bwd(e.dt, dy, a, b, ln->w.p, mr, da, db, ba, bb, ln->w.g, ln->b.g, R, C, 0.f, nullptr, 0, e.s, part, dmap, add));
   float* dw = ln->w.g; float* dbias = ln->b.g;
   if (e.prof || e.dry) {
     LCH(e, launch_layernorm_fold(part, g, C, dw, dbias, e.s));
@@ -1135,6 +1135,44 @@ Tensor* op_ln(Exec& e, Tensor* a, Tensor* b, LNp* ln, RowMap map = RowMap()) {
       ln_backward(e, y->g, a->p, b ? b->p : nullptr, ln, mr, da, db, ba, bb, R, C, map);
     });
   return y;
+}
+
+// sum = a + DropPath(b) (b read through bmap: window order), y = LayerNorm(sum) written through out_map -- the residual add folded into the
+// LayerNorm behind it (networks/SWIN.py:283-300: `x = shortcut + self.drop_path(x)` then `self.norm2(x)`; likewise the MLP's residual and the
+// next block's norm1).  The backward hands d sum (its own LayerNorm backward + what later consumers of the sum left in sum->g) to a and,
+// scaled and re-ordered, to b.  Same stochastic-depth site sequence as op_droppath_add.
+struct AddLn { Tensor* sum; Tensor* y; };
+AddLn op_add_ln(Exec& e, Tensor* a, Tensor* b, int B, float p, RowMap bmap, LNp* ln, RowMap out_map) {
+  used(a); used(b);
+  if (!e.train) p = 0.f;
+  const uint32_t site = p > 0.f ? e.site++ : 0;
+  const uint32_t* seed = (const uint32_t*)(scal(e.m) + SC_SEED);
+  const long R = a->rows;
+  const int C = a->C;
+  Tensor* sum = e.newt(R, C, B, a->H, a->W);
+  Tensor* y = e.newt(R, C, B, a->H, a->W);
+  float* mr = (float*)e.alloc((size_t)2 * R * 4);
+  e.last_mr = mr;
+  LnAdd add;
+  add.on = 1; add.sum_out = sum->p; add.bmap = bmap; add.drop_p = p; add.seed = seed; add.site = site; add.rows_per_sample = R / B;
+  WORK(e, 0, (double)R * C * e.esz() * 4);
+  LCH(e, launch_layernorm(e.dt, a->p, b->p, ln->w.p, ln->b.p, y->p, mr, R, C, 1e-5f, 0.f, nullptr, 0, e.s, out_map, add));
+  if (e.rec)
+    e.tape.push_back([&e, a, b, sum, y, ln, mr, R, C, out_map, add]() {
+      if (!y->g) {
+        if (sum->g) { e.m->err = "internal: add+LayerNorm whose normalised output has no gradient"; e.oom = true; }
+        return;
+      }
+      int ba = 0, bb = 0;
+      void* da = e.grad(a, &ba);
+      void* db = e.grad(b, &bb);
+      if (bb) { e.m->err = "internal: add+LayerNorm branch has two consumers"; e.oom = true; return; }
+      LnAdd q = add;
+      q.sum_out = nullptr; q.gsum = sum->g;
+      WORK(e, 0, (double)R * C * e.esz() * (5 + ba + (sum->g ? 1 : 0)));
+      ln_backward(e, y->g, sum->p, nullptr, ln, mr, da, db, ba, 0, R, C, out_map, q);
+    });
+  return {sum, y};
 }
 
 Tensor* op_quirk(Exec& e, Tensor* yv) {  // networks/EfficientSATRN.py:269
@@ -1390,32 +1428,54 @@ Tensor* op_window_attn(Exec& e, Tensor* qkv, SwinBlock* sb, int B_, const float*
   return o;
 }
 
-Tensor* swin_block(Exec& e, Tensor* x, SwinBlock* sb, int B) {
+// One Swin block.  `pend` = the MLP branch of the block in front whose residual add has not been materialised yet: it is folded into this
+// block's first LayerNorm (op_add_ln), as this block's attention branch is folded into its second one; `keep_pending` leaves this block's own
+// MLP branch pending for the next block of the stage (the last block of a stage adds it with op_droppath_add: patch merging needs the sum).
+// SATRN_SWIN_NO_ADD_LN=1 (read per call, tests) keeps the separate residual adds.
+struct SwinPend { Tensor* o = nullptr; float p = 0.f; };
+Tensor* swin_block(Exec& e, Tensor* x, SwinBlock* sb, int B, SwinPend* pend, bool keep_pending) {
   Model* m = e.m;
   const int R = sb->res, nWw = R / sb->ws, nW = nWw * nWw;
   // shift + window partition ride on the LayerNorm in front of the attention (it writes window order) and on the residual add behind
   // it (it reads window order): no permutation passes (SATRN_SWIN_PERM_PASS=1 keeps the four separate ones, for tests)
   RowMap wmap;
   const bool perm_pass = getenv("SATRN_SWIN_PERM_PASS") != nullptr;   // read per call
+  const bool fuse_add = getenv("SATRN_SWIN_NO_ADD_LN") == nullptr;
   if ((nW > 1 || sb->shift) && !perm_pass) { wmap.H = R; wmap.W = R; wmap.ws = sb->ws; wmap.shift = sb->shift; }
-  Tensor* y = op_ln(e, x, nullptr, &sb->n1, wmap);
+  Tensor* y;
+  if (pend->o) {
+    AddLn r = op_add_ln(e, x, pend->o, B, pend->p, RowMap(), &sb->n1, wmap);
+    x = r.sum; y = r.y;
+    x->B = B; x->H = R; x->W = R;
+    pend->o = nullptr;
+  } else {
+    y = op_ln(e, x, nullptr, &sb->n1, wmap);
+  }
   Tensor* yw = ((nW > 1 || sb->shift) && perm_pass) ? op_window_perm(e, y, B, R, R, sb->ws, sb->shift, 0) : y;
   Tensor* qkv = op_gemm(e, yw, &sb->qkv, &sb->bqkv, ACT_NONE, 0.f, nullptr);
   const float* mask = sb->geo >= 0 ? (const float*)(m->ws + m->sw_geo[sb->geo].off) : nullptr;
   Tensor* att = op_window_attn(e, qkv, sb, B * nW, mask, nW);
   Tensor* pr = op_gemm(e, att, &sb->proj, &sb->bproj, ACT_NONE, 0.f, nullptr);
   Tensor* prt = ((nW > 1 || sb->shift) && perm_pass) ? op_window_perm(e, pr, B, R, R, sb->ws, sb->shift, 1) : pr;
-  Tensor* x1 = op_droppath_add(e, x, prt, B, sb->drop_path, wmap);
-  x1->B = B; x1->H = R; x1->W = R;
-  Tensor* y2 = op_ln(e, x1, nullptr, &sb->n2);
+  Tensor* x1; Tensor* y2;
+  if (fuse_add) {
+    AddLn r = op_add_ln(e, x, prt, B, sb->drop_path, wmap, &sb->n2, RowMap());
+    x1 = r.sum; y2 = r.y;
+    x1->B = B; x1->H = R; x1->W = R;
+  } else {
+    x1 = op_droppath_add(e, x, prt, B, sb->drop_path, wmap);
+    x1->B = B; x1->H = R; x1->W = R;
+    y2 = op_ln(e, x1, nullptr, &sb->n2);
+  }
   Tensor* g;
   if (getenv("SATRN_SWIN_GELU_PASS") == nullptr) {   // read per call (tests compare both forms in one process)
-    g = op_gemm(e, y2, &sb->fc1, &sb->b1, ACT_GELU, 0.f, nullptr);   // GELU in the product's epilogue, pre-activation kept beside it
+    g = op_gemm(e, y2, &sb->fc1, &sb->b1, ACT_GELU, 0.f, nullptr);   // GELU in the product's epilogue, its derivative kept beside it
   } else {
     Tensor* h = op_gemm(e, y2, &sb->fc1, &sb->b1, ACT_NONE, 0.f, nullptr);
     g = op_act(e, h, ACT_GELU);
   }
   Tensor* o = op_gemm(e, g, &sb->fc2, &sb->b2, ACT_NONE, 0.f, nullptr);
+  if (fuse_add && keep_pending) { pend->o = o; pend->p = sb->drop_path; return x1; }
   Tensor* x2 = op_droppath_add(e, x1, o, B, sb->drop_path);
   x2->B = B; x2->H = R; x2->W = R;
   return x2;
@@ -1436,7 +1496,8 @@ Tensor* swin_encoder_forward(Exec& e, const float* img, int B) {
   x = op_add_table(e, x, &m->sw_ape, B);
   (void)E;
   for (auto& st : m->swin) {
-    for (auto& sb : st.blocks) x = swin_block(e, x, &sb, B);
+    SwinPend pend;
+    for (size_t bi = 0; bi < st.blocks.size(); ++bi) x = swin_block(e, x, &st.blocks[bi], B, &pend, bi + 1 < st.blocks.size());
     if (st.down) {
       Tensor* mg = op_patch_merge(e, x, B, st.res, st.res);
       Tensor* mn = op_ln(e, mg, nullptr, &st.dnorm);

@@ -37,6 +37,18 @@ enum { AM_DENSE = 0, AM_CONV = 1, AM_DGRAD = 2 };
 // ws == 0: identity.  Kernels that take one read or write their WINDOW-ordered operand through it, which removes the separate
 // permutation passes around the attention (launch_window_perm: four per block and step).
 struct RowMap { int H = 0, W = 0, ws = 0, shift = 0; };
+// Residual add in front of a LayerNorm, folded into it (SwinTRN: x = shortcut + DropPath(branch), then norm(x); networks/SWIN.py:283-300):
+// forward  sum[r] = a[r] + scale(sample of r) * b[bmap(r)], stored to sum_out, and normalised;
+// backward d sum = LayerNorm backward + gsum (the gradient other consumers of the sum left there), then a's gradient (+)= d sum and
+//          b's gradient [bmap(r)] = scale * d sum.
+// scale = stochastic-depth keep / (1 - p) per SAMPLE (rows_per_sample rows each), 1 when drop_p == 0.  Inactive when sum_out / on == 0.
+struct LnAdd {
+  int on = 0;
+  void* sum_out = nullptr;        // forward: where the sum goes
+  const void* gsum = nullptr;     // backward: incoming gradient of the sum (may be null)
+  RowMap bmap;                    // b (and its gradient) are in window order
+  float drop_p = 0.f; const uint32_t* seed = nullptr; uint32_t site = 0; long rows_per_sample = 1;
+};
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SIGMOID = 3, ACT_GELU = 4 /*exact erf form, nn.GELU (networks/SWIN.py:29)*/,
        ACT_DFACTOR = 5 /*backward only: the stored tensor already IS act'(u) (GemmP::pre_grad)*/ };
 
@@ -224,11 +236,11 @@ void launch_posenc2d_bwd(int dt, const void* dout, const float* hpos, const floa
                          int H, int W, int C, hipStream_t s);
 void launch_layernorm(int dt, const void* a, const void* b_or_null, const float* w, const float* bias, void* out,
                       float* mean_rstd /*[2R]*/, long R, int C, float eps, float drop_p, const uint32_t* seed,
-                      uint32_t site, hipStream_t s, RowMap out_map = RowMap());   // out_map: token row r is written at its window row
+                      uint32_t site, hipStream_t s, RowMap out_map = RowMap(), LnAdd add = LnAdd());   // out_map: token row r is written at its window row
 void launch_layernorm_bwd(int dt, const void* dout, const void* a, const void* b_or_null, const float* w,
                           const float* mean_rstd, void* da, void* db_or_null, int beta_a, int beta_b, float* dw,
                           float* dbias, long R, int C, float drop_p, const uint32_t* seed, uint32_t site, hipStream_t s,
-                          float* part_ws = nullptr, RowMap dout_map = RowMap());   // dout_map: dout is in window order
+                          float* part_ws = nullptr, RowMap dout_map = RowMap(), LnAdd add = LnAdd());   // dout_map: dout is in window order
 // part_ws != null: [layernorm_bwd_blocks(R)][2][C] floats receive per-block (dw | dbias) partials instead of atomics; fold them with
 // launch_layernorm_fold (any stream ordered after the backward kernel)
 int layernorm_bwd_blocks(long R);

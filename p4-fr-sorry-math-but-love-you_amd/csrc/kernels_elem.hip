@@ -1727,14 +1727,17 @@ DEVI float group_sum(float v) {
 
 template <typename T, int NCH, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* a, const T* b, const float* w, const float* bias,
-                                                        T* out, float* mr, long R, int C, float eps, RowMap omap) {
+                                                        T* out, float* mr, long R, int C, float eps, RowMap omap, LnAdd add) {
   constexpr int CH = TT<T>::CH;
   constexpr int G = 64 / RPW;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane / G, l = lane % G;
   const int CC = C / CH;
+  const uint32_t dseed = (add.on && add.drop_p > 0.f) ? *add.seed : 0u;
   for (long r = ((long)blockIdx.x * 4 + wv) * RPW + sub; r < R; r += (long)gridDim.x * 4 * RPW) {
     float v[NCH][CH];
     float sum = 0.f;
+    const long rb = add.on ? rowmap_row(r, add.bmap) : r;
+    const float bsc = (add.on && add.drop_p > 0.f) ? drop_scale(dseed, add.site, (uint32_t)(r / add.rows_per_sample), add.drop_p) : 1.f;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       int c = l + k * G;
@@ -1742,9 +1745,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* a, const T* b, 
         unpack<T>(ld16(a + r * C + c * CH), v[k]);
         if (b) {
           float t[CH];
-          unpack<T>(ld16(b + r * C + c * CH), t);
+          unpack<T>(ld16(b + rb * C + c * CH), t);
 #pragma unroll
-          for (int j = 0; j < CH; ++j) v[k][j] += t[j];
+          for (int j = 0; j < CH; ++j) v[k][j] += t[j] * bsc;
+          if (add.on) {   // the sum is kept (rounded to the compute dtype, and normalised from the rounded value: what a separate add would hand over)
+            const uint4 pk = pack<T>(v[k]);
+            st16((T*)add.sum_out + r * C + c * CH, pk);
+            unpack<T>(pk, v[k]);
+          }
         }
 #pragma unroll
         for (int j = 0; j < CH; ++j) sum += v[k][j];
@@ -1776,9 +1784,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* a, const T* b, 
   }
 }
 #define LN_GO(NCH, RPW) hipLaunchKernelGGL((layernorm_kernel<T, NCH, RPW>), dim3(grid_for(R, 4 * RPW, 2048)), dim3(256), 0, s, (const T*)a, \
-                                           (const T*)b, w, bias, (T*)out, mr, R, C, eps, out_map)
+                                           (const T*)b, w, bias, (T*)out, mr, R, C, eps, out_map, add)
 void launch_layernorm(int dt, const void* a, const void* b, const float* w, const float* bias, void* out, float* mr,
-                      long R, int C, float eps, float, const uint32_t*, uint32_t, hipStream_t s, RowMap out_map) {
+                      long R, int C, float eps, float, const uint32_t*, uint32_t, hipStream_t s, RowMap out_map, LnAdd add) {
   DISPATCH_T(dt, {
     int cc = C / TT<T>::CH;
     if (cc <= 16) LN_GO(1, 4);
@@ -1793,9 +1801,11 @@ void launch_layernorm(int dt, const void* a, const void* b, const float* w, cons
 template <typename T, int NCH, int RPW>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const T* a, const T* b, const float* w,
                                                             const float* mr, T* da, T* db, int beta_a, int beta_b,
-                                                            float* dw, float* dbias, long R, int C, float* part, RowMap dmap) {
+                                                            float* dw, float* dbias, long R, int C, float* part, RowMap dmap, LnAdd add) {
   constexpr int CH = TT<T>::CH;
   constexpr int G = 64 / RPW;
+  const T* gsum = add.on ? (const T*)add.gsum : nullptr;
+  const uint32_t dseed = (add.on && add.drop_p > 0.f) ? *add.seed : 0u;
   extern __shared__ float red[];  // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane / G, l = lane % G;
   const int CC = C / CH;
@@ -1807,7 +1817,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
   // a wave walks its rows with the NEXT row's operands (inputs, statistics and, when accumulating, the old gradient
   // values) already requested: every row would otherwise cost two dependent far round trips (inputs, then the
   // read-modify-write of da / db after the reduction)
-  struct RowRaw { uint4 xa[NCH], xb[NCH], dd[NCH], oa[NCH], ob[NCH]; float mean, rstd; };
+  struct RowRaw { uint4 xa[NCH], xb[NCH], dd[NCH], oa[NCH], ob[NCH], gs[NCH]; float mean, rstd; };
   auto load_row = [&](long r, RowRaw& q) {
     q.mean = mr[r]; q.rstd = mr[R + r];
     const long rd = rowmap_row(r, dmap);
@@ -1820,6 +1830,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
         q.dd[k] = ld16(dout + rd * C + c * CH);
         if (beta_a) q.oa[k] = ld16(da + r * C + c * CH);
         if (db && beta_b) q.ob[k] = ld16(db + r * C + c * CH);
+        if (gsum) q.gs[k] = ld16(gsum + r * C + c * CH);
       }
     }
   };
@@ -1865,6 +1876,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
         float o[CH], t[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) o[j] = rstd * (g[k][j] - s1 - xh[k][j] * s2);
+        if (gsum) {
+          unpack<T>(cur.gs[k], t);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) o[j] += t[j];
+        }
         if (beta_a) {
           unpack<T>(cur.oa[k], t);
 #pragma unroll
@@ -1874,7 +1890,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dout, const
           st16(da + r * C + c * CH, pack<T>(o));
         }
         if (db) {
-          if (beta_b) {
+          if (add.on) {   // the branch's gradient: scaled by its sample's stochastic-depth factor, at its window row
+            const long rb = rowmap_row(r, add.bmap);
+            const float bsc = add.drop_p > 0.f ? drop_scale(dseed, add.site, (uint32_t)(r / add.rows_per_sample), add.drop_p) : 1.f;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) t[j] = o[j] * bsc;
+            st16(db + rb * C + c * CH, pack<T>(t));
+          } else if (beta_b) {
             unpack<T>(cur.ob[k], t);
 #pragma unroll
             for (int j = 0; j < CH; ++j) t[j] += o[j];
@@ -1950,10 +1972,10 @@ void launch_layernorm_fold(const float* part, int nblocks, int C, float* dw, flo
 }
 
 #define LNB_GO(NCH, RPW) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH, RPW>), dim3(g), dim3(256), sh, s, (const T*)dout, (const T*)a, \
-                                            (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part, dout_map)
+                                            (const T*)b, w, mr, (T*)da, (T*)db, beta_a, beta_b, dw, dbias, R, C, part, dout_map, add)
 void launch_layernorm_bwd(int dt, const void* dout, const void* a, const void* b, const float* w, const float* mr,
                           void* da, void* db, int beta_a, int beta_b, float* dw, float* dbias, long R, int C, float,
-                          const uint32_t*, uint32_t, hipStream_t s, float* part_ws, RowMap dout_map) {
+                          const uint32_t*, uint32_t, hipStream_t s, float* part_ws, RowMap dout_map, LnAdd add) {
   DISPATCH_T(dt, {
     int cc = C / TT<T>::CH;
     int g = part_ws ? layernorm_bwd_blocks(R) : grid_for(R, 16, 512);

@@ -211,6 +211,39 @@ def test_window_order_folded_into_layernorm_and_residual(golden_dir, dtype, monk
     assert ge < (1e-6 if dtype == "f32" else 1e-3)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("drop_path", [0.0, 0.5])
+def test_residual_adds_folded_into_layernorm(golden_dir, dtype, drop_path, monkeypatch):
+    """x = shortcut + DropPath(branch) folded into the LayerNorm behind it (the attention branch into norm2, the MLP branch into the next
+    block's norm1; the backward hands d(sum) to the shortcut and, scaled / window-ordered, to the branch) against the separate residual
+    adds: same stochastic-depth masks (same sites), logits identical, gradients equal up to one bf16 rounding of the summed gradient"""
+    scfg, dcfg = CASES["swin_mid"]
+    z, meta = load(golden_dir, "swin_mid")
+    B, T = int(meta["batch"]), int(meta["seq_len"])
+    img, expected = O.det_inputs(B, 3, scfg["img_size"], scfg["img_size"], T, seed=5, pad_tail=0)
+    imgd, expd = img.cuda(), expected.cuda()
+
+    def run(separate):
+        if separate:
+            monkeypatch.setenv("SATRN_SWIN_NO_ADD_LN", "1")
+        else:
+            monkeypatch.delenv("SATRN_SWIN_NO_ADD_LN", raising=False)
+        model, _ = build(scfg, dcfg, dtype, int(meta["wseed"]), drop_path=drop_path)
+        model.train()
+        logits = model(imgd, expd, True, 1.0)
+        loss = model.criterion(logits.transpose(1, 2), expd[:, 1:])
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().float().clone(), torch.cat([p_.grad.detach().float().flatten() for p_ in model.parameters()]).clone()
+
+    (l0, g0), (l1, g1) = run(True), run(False)
+    le, ge = relerr(l1, l0), (g1 - g0).norm().item() / g0.norm().item()
+    print(f"[add+LayerNorm folded:{dtype}, drop_path {drop_path}] logits rel err {le:.3e}, gradient rel-L2 {ge:.3e}")
+    assert le < (1e-6 if dtype == "f32" else 1e-6)
+    assert ge < (1e-5 if dtype == "f32" else 2e-2)
+
+
 def test_swin_stochastic_depth_and_fused_step():
     """train mode with the reference's drop_path_rate (0.5): per-sample branches are dropped (outputs change from step to step,
     loss stays finite), the f32 step is reproducible for a fixed RNG word, the fused train_step runs and lowers the loss."""
