@@ -38,6 +38,9 @@ typedef unsigned int a2_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int a2_u32x2 __attribute__((ext_vector_type(2)));
 
 #define A2_MAXKT 10      // key tiles of 16 (Lk <= 160)
+#ifndef A2_WIN_OCC
+#define A2_WIN_OCC 5   // (7 waves per SIMD = three workgroups per CU was measured: 12 spilled dwords, 67 vs 63 us)
+#endif
 
 template <int HD> struct A2L {
   static constexpr int ROWB = HD * 2;                         // bytes per row
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(576, HD == 32 ? 5 : 3) void attn2_bwd_kernel(AttnP 
 //   * the prologue issues every global load of the workgroup (K, V, Q, dO chunks, the O / dO chunk of the delta dot product, lse, table,
 //     labels) before the first LDS write: one memory round trip.
 template <int HD>
-__global__ __launch_bounds__(576, HD == 32 ? 5 : 3) void attn2_bwd_win_kernel(AttnP p) {
+__global__ __launch_bounds__(576, HD == 32 ? A2_WIN_OCC : 3) void attn2_bwd_win_kernel(AttnP p) {
   typedef bf16_t T;
   extern __shared__ __attribute__((aligned(16))) unsigned char a2sm[];
   const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6, fr = lane & 15, fq = lane >> 4;

@@ -53,7 +53,13 @@ __global__ __launch_bounds__(256) void fold4_kernel(const float4* part, int nrep
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4) {
     const int per = (nrep + G - 1) / G, r0 = g * per, r1 = min(nrep, r0 + per);
-    for (int r = r0; r < r1; ++r) { const float4 v = part[(size_t)r * stride4 + i]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {   // four slices requested together (one dependent round trip per slice otherwise); summed in slice order
+      const float4 v0 = part[(size_t)r * stride4 + i], v1 = part[(size_t)(r + 1) * stride4 + i], v2 = part[(size_t)(r + 2) * stride4 + i], v3 = part[(size_t)(r + 3) * stride4 + i];
+      a.x = (((a.x + v0.x) + v1.x) + v2.x) + v3.x; a.y = (((a.y + v0.y) + v1.y) + v2.y) + v3.y;
+      a.z = (((a.z + v0.z) + v1.z) + v2.z) + v3.z; a.w = (((a.w + v0.w) + v1.w) + v2.w) + v3.w;
+    }
+    for (; r < r1; ++r) { const float4 v = part[(size_t)r * stride4 + i]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
   }
   if (G > 1) {
     red[g][c] = a;
