@@ -373,7 +373,9 @@ def test_fused_encoder_attention_region_equals_the_four_launches(net, H, W, B):
     assert torch.isfinite(s0).all() and torch.isfinite(g0).all() and torch.isfinite(gt0).all()
     assert es < 2e-2          # bf16 rounding of the partial sums instead of one f32 accumulation
     assert eg < 6e-2
-    assert abs(le0 - le1) < 1e-2 and abs(l0 - l1) < 3e-2
+    # the training-mode loss of the tiny batch moves by ~0.04 from run to run on its own (batch statistics over 18 rows, float atomics in
+    # the statistics, bf16): observed 5.739 and 5.779 for the SAME form in two runs -- the bound is that scale, not a kernel tolerance
+    assert abs(le0 - le1) < 1e-2 and abs(l0 - l1) < (3e-2 if net == "lite" else 1e-1)
     assert cos_t > (0.95 if net == "lite" else 0.5)   # (batch statistics over 18 rows at 64x96 bs3: see the docstring)
 
 
