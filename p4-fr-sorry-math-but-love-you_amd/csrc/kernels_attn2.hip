@@ -770,12 +770,12 @@ bool launch_attn2_fwd(const AttnP& p, hipStream_t s) {
   const int nw = (p.Lq + 15) / 16;
   const size_t sh = (size_t)2 * LkP * p.hd * 2 + a2_rel_bytes(p);
   const dim3 grid(p.H, p.B), block(nw * 64);
-  const bool win = p.rel_table && !p.text && !p.causal && p.drop_p == 0.f && p.rel_ws * p.rel_ws <= 160 && p.Lq == p.Lk &&
+  // (head_dim 32 only: every SwinTRN geometry of the reference and of the tests has embed_dim / heads = 32; 64 takes the general kernel)
+  const bool win = p.hd == 32 && p.rel_table && !p.text && !p.causal && p.drop_p == 0.f && p.rel_ws * p.rel_ws <= 160 && p.Lq == p.Lk &&
                    (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 8 < 65536 && nw * 64 == 576 && getenv("SATRN_NO_ATTN2_WIN") == nullptr;
   if (win) {
     const size_t shw = (size_t)2 * LkP * p.hd * 2 + 160 * 4 + (size_t)2 * (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 4 + 16;
-    if (p.hd == 32) hipLaunchKernelGGL((attn2_fwd_win_kernel<32>), grid, block, shw, s, p);
-    else hipLaunchKernelGGL((attn2_fwd_win_kernel<64>), grid, block, shw, s, p);
+    hipLaunchKernelGGL((attn2_fwd_win_kernel<32>), grid, block, shw, s, p);
     return true;
   }
   if (p.hd == 32) hipLaunchKernelGGL((attn2_fwd_kernel<32>), grid, block, sh, s, p);
@@ -793,19 +793,13 @@ bool launch_attn2_bwd(const AttnP& p, hipStream_t s) {
   AttnP pp = p;
   pp.dbg = getenv("SATRN_A2_DBG") ? atoi(getenv("SATRN_A2_DBG")) : 0;   // timing experiments (wrong results): 1 no histogram, 2 no phase A, 4 no phase B, 8 no delta / lse, 16 no relative-position tables, 32 no staging
   // window form: relative-position table, no pad / causal mask, no dropout, gradients written (not accumulated), table gradient through dS
-  const bool win = p.rel_table && !p.text && !p.causal && p.drop_p == 0.f && !p.kv_accum && !p.drel && p.rel_ws * p.rel_ws <= 160 && p.Lq == p.Lk &&
+  const bool win = p.hd == 32 && p.rel_table && !p.text && !p.causal && p.drop_p == 0.f && !p.kv_accum && !p.drel && p.rel_ws * p.rel_ws <= 160 && p.Lq == p.Lk &&
                    (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 8 < 65536 && nw * 64 == 576 && getenv("SATRN_NO_ATTN2_WIN") == nullptr;
   if (win) {
     const size_t shw = (size_t)(2 * LkP + 2 * LqP) * p.hd * 2 + (size_t)4 * 160 * 4 + (size_t)2 * (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 4 + 16;
-    if (p.hd == 32) {
-      static bool a = false;
-      if (!a) { (void)hipFuncSetAttribute((const void*)attn2_bwd_win_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a = true; }
-      hipLaunchKernelGGL((attn2_bwd_win_kernel<32>), grid, block, shw, s, pp);
-    } else {
-      static bool a = false;
-      if (!a) { (void)hipFuncSetAttribute((const void*)attn2_bwd_win_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a = true; }
-      hipLaunchKernelGGL((attn2_bwd_win_kernel<64>), grid, block, shw, s, pp);
-    }
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute((const void*)attn2_bwd_win_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a = true; }
+    hipLaunchKernelGGL((attn2_bwd_win_kernel<32>), grid, block, shw, s, pp);
     return true;
   }
   if (p.hd == 32) {
