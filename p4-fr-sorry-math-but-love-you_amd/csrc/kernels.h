@@ -24,6 +24,8 @@ struct WgPartCtx { float* scratch[2] = {nullptr, nullptr}; size_t cap = 0 /*floa
 extern WgPartCtx g_wgpart;
 void launch_fold4(const float* part, int nrep, long stride, long n, float* out, hipStream_t s);   // launch_fold with 16-byte accesses (n, stride % 4 == 0)
 void det_overflow_warn(size_t need_floats);
+// value of a timing-experiment switch (results are WRONG when it is set): read once, announced once on stderr
+int timing_switch(const char* name);
 static inline float* det_scratch(hipStream_t s, size_t need_floats) {
   if (!g_det.on) return nullptr;
   if (need_floats > g_det.cap) { det_overflow_warn(need_floats); return nullptr; }

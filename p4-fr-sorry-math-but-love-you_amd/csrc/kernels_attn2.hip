@@ -791,7 +791,8 @@ bool launch_attn2_bwd(const AttnP& p, hipStream_t s) {
   if (p.rel_table) sh += (((size_t)(2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 8 + 640 + (size_t)p.Lq + 15) & ~(size_t)15);
   const dim3 grid(p.H, p.B), block(nw * 64);
   AttnP pp = p;
-  pp.dbg = getenv("SATRN_A2_DBG") ? atoi(getenv("SATRN_A2_DBG")) : 0;   // timing experiments (wrong results): 1 no histogram, 2 no phase A, 4 no phase B, 8 no delta / lse, 16 no relative-position tables, 32 no staging
+  static const int a2_dbg = timing_switch("SATRN_A2_DBG");
+  pp.dbg = a2_dbg;   // timing experiments (wrong results): 1 no histogram, 2 no phase A, 4 no phase B, 8 no delta / lse, 16 no relative-position tables, 32 no staging
   // window form: relative-position table, no pad / causal mask, no dropout, gradients written (not accumulated), table gradient through dS
   const bool win = p.hd == 32 && p.rel_table && !p.text && !p.causal && p.drop_p == 0.f && !p.kv_accum && !p.drel && p.rel_ws * p.rel_ws <= 160 && p.Lq == p.Lk &&
                    (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 8 < 65536 && nw * 64 == 576 && getenv("SATRN_NO_ATTN2_WIN") == nullptr;

@@ -24,6 +24,12 @@ DEVI void lds8(const float* p, float* o) {   // 8 floats from LDS / memory throu
 
 DetCtx g_det;
 WgPartCtx g_wgpart;
+int timing_switch(const char* name) {
+  const char* v = getenv(name);
+  const int x = v ? atoi(v) : 0;
+  if (x) fprintf(stderr, "[satrn] WARNING: %s=%d -- a timing experiment: parts of a kernel are skipped and its results are WRONG\n", name, x);
+  return x;
+}
 void det_overflow_warn(size_t need_floats) {
   static bool once = false;
   if (!once) { once = true; fprintf(stderr, "[satrn] deterministic-reduction scratch too small (%zu floats needed, %zu available): this reduction falls back to float atomics\n", need_floats, g_det.cap); }

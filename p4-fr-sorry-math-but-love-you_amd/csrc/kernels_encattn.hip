@@ -264,7 +264,8 @@ bool launch_enc_attn_fwd(const EncAttnP& p, hipStream_t s) {
   if (!enc_attn_fused_ok(DT_BF16, p.L, p.D, p.H)) return false;
   const dim3 grid(p.H / 2, p.B), block(EA_THREADS);
   EncAttnP pp = p;
-  pp.dbg = getenv("SATRN_EA_DBG") ? atoi(getenv("SATRN_EA_DBG")) : 0;   // timing experiments: leave after phase N (wrong results)
+  static const int ea_dbg = timing_switch("SATRN_EA_DBG");
+  pp.dbg = ea_dbg;   // timing experiments: leave after phase N (wrong results)
   const size_t sh = (size_t)p.D * 128 + 3 * 4 * 64 * 32 * 2;
   if (p.D == 512) {
     static bool a = false;

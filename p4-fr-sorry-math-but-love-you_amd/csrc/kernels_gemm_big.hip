@@ -698,6 +698,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void wgrad_big_kernel(BigWP p) {
   }
 }
 
+static int big_dbg() { static const int v = timing_switch("SATRN_BIG_DBG"); return v; }
 static int big_cu_count() {
   static int cus = 0;
   if (!cus) {
@@ -747,9 +748,9 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
     // step (tools/shape_prof.py, SATRN_GEMM_BIG_MIN_GFLOP=0.5 against the default): its 1x1 convolutions -- 0.5 .. 2 GFLOP each, inputs
     // just written by another kernel, a weight-gradient kernel running beside them -- gain nothing from the persistent form (4.66 ->
     // 4.91 ms over the family): a 160 KB workgroup needs a whole drained CU to start and leaves no room for the side stream
-    const double min_gflop = getenv("SATRN_GEMM_BIG_MIN_GFLOP") ? atof(getenv("SATRN_GEMM_BIG_MIN_GFLOP")) : 2.0;
+    static const double min_gflop = getenv("SATRN_GEMM_BIG_MIN_GFLOP") ? atof(getenv("SATRN_GEMM_BIG_MIN_GFLOP")) : 2.0;
     const double flops = 2.0 * g.M * g.N * g.K;
-    const int min_n = getenv("SATRN_GEMM_BIG_MIN_N") ? atoi(getenv("SATRN_GEMM_BIG_MIN_N")) : 128;
+    static const int min_n = getenv("SATRN_GEMM_BIG_MIN_N") ? atoi(getenv("SATRN_GEMM_BIG_MIN_N")) : 128;
     if (mode != 2 && (flops < min_gflop * 1e9 || g.N < min_n || g.M < 2048)) return false;
   }
   BigP p;
@@ -762,7 +763,7 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
   p.stats = g.stats; p.stats_rep = g.stats_rep; p.bnb_y = (const bf16_t*)g.bnb_y; p.bnb_ss = g.bnb_ss; p.bnb_mr = g.bnb_mr; p.bnb_act = g.bnb_act;
   p.y_bytes = (unsigned)((size_t)g.M * g.N * 2);
   p.ntn = (g.N + 127) / 128;
-  p.dbg = getenv("SATRN_BIG_DBG") ? atoi(getenv("SATRN_BIG_DBG")) : 0;
+  p.dbg = big_dbg();
   const int cus = big_cu_count();
   // tile height: the candidate whose tile count leaves the smallest idle share in the last round of the persistent grid
   const int force_mt = getenv("SATRN_GEMM_BIG_MT") ? atoi(getenv("SATRN_GEMM_BIG_MT")) : 0;
@@ -781,7 +782,8 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
   p.ntm = (g.M + 64 * best_mt - 1) / (64 * best_mt);
   p.ntiles = p.ntm * p.ntn;
   int grid = p.ntiles < cus ? p.ntiles : cus;
-  if (getenv("SATRN_BIG_GRID")) grid = std::min(grid, std::max(1, atoi(getenv("SATRN_BIG_GRID"))));   // experiment: fewer CUs, same tiles
+  static const int grid_env = getenv("SATRN_BIG_GRID") ? atoi(getenv("SATRN_BIG_GRID")) : 0;   // experiment (tools/gemm_big_grid.sh): fewer CUs, same tiles
+  if (grid_env > 0) grid = std::min(grid, grid_env);
   if (best_mt == 4) big_launch_t<4>(p, grid, s);
   else if (best_mt == 3) big_launch_t<3>(p, grid, s);
   else big_launch_t<2>(p, grid, s);
@@ -811,7 +813,7 @@ bool wgrad_big_launch(const WgradP& w, hipStream_t s) {
   p.M = w.M; p.N = w.N; p.K = w.K; p.ldy = w.ldy; p.lda = w.lda; p.ldw = w.K;
   p.y_bytes = (unsigned)(((size_t)(w.M - 1) * w.ldy + w.N) * 2);
   p.x_bytes = (unsigned)(((size_t)(w.M - 1) * w.lda + w.K) * 2);
-  p.dbg = getenv("SATRN_BIG_DBG") ? atoi(getenv("SATRN_BIG_DBG")) : 0;
+  p.dbg = big_dbg();
   const int cus = big_cu_count();
   // 256-row tiles only where the output alone fills the grid: an item's partial tile leaves as fp32 atomics (1.3 TB/s over the chip), so
   // with slices of M the atomic bytes are items x tile -- the tall form doubles them (9216 x 1536 x 384: 40 us against 32 us with 128 rows)
@@ -841,10 +843,11 @@ bool wgrad_big_launch(const WgradP& w, hipStream_t s) {
   // (measured: 2-4x more, shorter items on the side stream, one per workgroup, so that CUs are released more often for the chain's
   // persistent kernels -- SwinTRN 17.9 -> 19.4-20.3 ms per step: the extra partial-tile traffic and fold work cost more)
   p.splits = splits; p.rows_per_split = rps; p.nitems = tiles * splits;
+  static const bool wgrad_atomics = getenv("SATRN_WGRAD_BIG_ATOMICS") != nullptr;   // A/B: keep the float atomics
   // partial tiles instead of atomics when a slab is there (engine calls) and there is something to fold
   p.part = nullptr;
   const size_t need = (size_t)splits * w.N * w.K;
-  if (splits > 1 && g_wgpart.cap >= need && p.ldw == w.K && (((size_t)w.N * w.K) & 3) == 0 && !getenv("SATRN_WGRAD_BIG_ATOMICS"))
+  if (splits > 1 && g_wgpart.cap >= need && p.ldw == w.K && (((size_t)w.N * w.K) & 3) == 0 && !wgrad_atomics)
     p.part = g_wgpart.scratch[(g_wgpart.side && s == g_wgpart.side) ? 1 : 0];
   const int grid = p.nitems < target ? p.nitems : target;
   if (tall) wgrad_big_go<8, false>(p, grid, s);
