@@ -1936,6 +1936,7 @@ static void det_activate(Model* m) {
   g_det.scratch[1] = g_det.on ? (float*)(m->ws + m->off_det) + m->det_floats : nullptr;
   g_det.side = m->ex ? m->ex->s2 : nullptr;
   g_wgrad_dense_blocks = m->cfg.network == 2 ? 160 : 0;
+  g_wgrad_big_min_gflop = m->cfg.network == 2 ? 1.0f : 2.0f;
   const bool wp = m->wgpart_floats && m->ws;
   g_wgpart.cap = wp ? m->wgpart_floats : 0;
   g_wgpart.scratch[0] = wp ? (float*)(m->ws + m->off_wgpart) : nullptr;

@@ -16,6 +16,9 @@ extern DetCtx g_det;
 // workgroups a dense weight-gradient launch aims for on the side stream (0 = the default, 96); set per engine call like g_det:
 // SwinTRN's products are 10-40x larger than EfficientSATRN's and its chain leaves more of the chip free (160: 31.8 -> 30.7 ms/step)
 extern int g_wgrad_dense_blocks;
+// smallest dense weight gradient (GFLOP) the persistent kernel takes; set per engine call: 1.0 for SwinTRN (16.25 -> 16.05-16.12 ms per step
+// against 2.0), 2.0 otherwise (EfficientSATRN: 10.40 -> 10.51-10.56 ms at 1.0)
+extern float g_wgrad_big_min_gflop;
 // Partial-tile slabs of the persistent weight-gradient kernel (kernels_gemm_big.hip): with a slab its items store their fp32 partial
 // tiles [slice][N][K] with plain stores and a fold launch adds the slices in order -- instead of items x 16 K float atomics, which
 // inside a training step (gradient buffers cold) cost as much as the product itself.  Two slabs like g_det (chain, side stream);

@@ -949,6 +949,7 @@ __global__ void wgrad_fold_kernel(const float* part, int splits, int N, int K, i
 }
 
 int g_wgrad_dense_blocks = 0;
+float g_wgrad_big_min_gflop = 2.0f;
 
 template <typename T, int BNW, int BKW>
 static void launch_wgrad_tile(const WgradP& p, hipStream_t s) {

@@ -807,7 +807,9 @@ bool wgrad_big_launch(const WgradP& w, hipStream_t s) {
   if ((w.N & 7) || (w.K & 7) || (w.ldy & 7) || (w.lda & 7) || w.M < 64) return false;
   if ((size_t)w.M * w.ldy * 2 >= (1ull << 31) || (size_t)w.M * w.lda * 2 >= (1ull << 31)) return false;
   const double flops = 2.0 * w.M * w.N * w.K;
-  if (mode != 2 && (flops < 2.0e9 || w.M < 2048)) return false;
+  static const double wenv = getenv("SATRN_WGRAD_BIG_MIN_GFLOP") ? atof(getenv("SATRN_WGRAD_BIG_MIN_GFLOP")) : 0.0;   // knob: overrides the per-network value
+  const double wmin = wenv > 0.0 ? wenv : (double)g_wgrad_big_min_gflop;
+  if (mode != 2 && (flops < wmin * 1e9 || w.M < 2048)) return false;
   BigWP p;
   p.Y = (const bf16_t*)w.dY; p.X = (const bf16_t*)w.A; p.dW = (float*)w.dW; p.dbias = w.dbias;
   p.M = w.M; p.N = w.N; p.K = w.K; p.ldy = w.ldy; p.lda = w.lda; p.ldw = w.K;
