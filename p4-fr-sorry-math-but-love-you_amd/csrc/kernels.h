@@ -93,6 +93,7 @@ void launch_bn_eval_prepare(const BnEvalDesc* descs_dev, int n, hipStream_t s);
 void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s);
 // large dense bf16 products on the persistent 8-wave direct-to-LDS kernel (kernels_gemm_big.hip); false = shape / epilogue not taken
 bool gemm_big_launch(const GemmP& p, hipStream_t s);
+bool gemm_big_conv_launch(int amode, const GemmP& p, hipStream_t s);   // 3x3 stride-1 'same' convolution / its data gradient as a shifted GEMM
 
 // dW[n][k] (+)= sum_m dY[m][n] * gatherA[m][k]
 struct WgradP {

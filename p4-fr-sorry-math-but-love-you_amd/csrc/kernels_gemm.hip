@@ -734,6 +734,14 @@ void launch_gemm(int dt, int amode, const GemmP& p0, hipStream_t s) {
   }
   const int nslots = (p.M + 63) / 64;
   if (p.stats) p.stats_part = det_scratch(s, (size_t)(nslots + 4) * 2 * p.N);  // null unless the deterministic mode is on
+  {
+    // large 3x3 stride-1 convolutions and their data gradients (>= 64 output channels, >= 2 GFLOP: the fused-MBConv stages) as shifted
+    // GEMMs on the persistent kernel: 66 -> 62 us (48 -> 192 channels at 32 x 96), 30 -> 25 and 63 -> 54 us (64 <-> 256 at 16 x 48) against the
+    // halo-tiled kernel.  SATRN_CONV_BIG=0 (read per call: tests) keeps the halo kernel.
+    const char* cb = getenv("SATRN_CONV_BIG");
+    if (!(cb && atoi(cb) == 0) && !p.stats_part && dt == DT_BF16 && (amode == AM_CONV || amode == AM_DGRAD) && p.N >= 64 &&
+        gemm_big_conv_launch(amode, p, s)) return;
+  }
   if (!p.stats_part && dt == DT_BF16 && amode != AM_DENSE && conv_halo_launch(amode, p, s)) return;
   if (amode == AM_DENSE && (dt == DT_BF16 ? gemm_skinny_launch<bf16_t>(p, s) : gemm_skinny_launch<float>(p, s))) return;
   if (amode == AM_DENSE && dt == DT_BF16 && gemm_big_launch(p, s)) return;   // large products: persistent 8-wave direct-to-LDS kernel (kernels_gemm_big.hip)

@@ -51,6 +51,11 @@ struct BigP {
   float* stats; int stats_rep;
   const bf16_t* bnb_y; const float* bnb_ss; const float* bnb_mr; int bnb_act; unsigned y_bytes;
   int dbg;   // timing experiments (SATRN_BIG_DBG; wrong results): 1 no epilogue, 2 no DMA waits, 4 no MFMA, 8 no fragment reads
+  // 3x3 stride-1 'same' convolution over NHWC as a shifted GEMM (conv != 0): row r of A is output pixel r, k-step s = tap s / kpt (+ 64-channel
+  // slice s % kpt): the loaders read pixel (y + dy, x + dx) of the same image -- or nothing (zero fill) outside the image / past Ci --
+  // and the tap's Ci columns of the packed weights [N][9][Ci]; the consumers see ordinary 64-deep stages.  flip: the data gradient
+  // (dy -> -dy, dx -> -dx; weights = the backward pack [Ci_out][9][Co]).
+  int conv, cH, cW, cCi, flip, kpt;
 };
 
 #define BIG_THREADS 512
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int KT = (p.K + BIG_BK - 1) / BIG_BK;   // K % 8 == 0; a partial last k-step is zero-filled (both operands) by the loaders
+  const int KT = p.conv ? 9 * p.kpt : (p.K + BIG_BK - 1) / BIG_BK;   // K % 8 == 0; a partial last k-step is zero-filled (both operands) by the loaders
 
   // ---- this workgroup's tiles: logical id L (XCD-contiguous) + i * gridDim; tiles ordered n fastest, so the 32 workgroups of an
   // XCD share two row blocks of A and all of W in their L2
@@ -143,16 +148,49 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
     const unsigned lda2 = (unsigned)p.lda * 2u, ldw2 = (unsigned)p.K * 2u;
     int d_tile = 0, d_k = 0;                 // position of the NEXT stage to request
     unsigned voffA = 0, voffW = 0;
+    // convolution mode: per piece of this lane the pixel's (y, x) and its byte offset (row r = pixel r of the NHWC map)
+    int cy[NA], cx[NA];
+    unsigned cbase[NA];
+    const int cch = (int)(dchunk >> 4);      // this lane's 8-channel chunk inside a 64-channel slice
     auto dma_tile_setup = [&](int ti) {
       const int tile = L + ti * nwg;
       const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
       voffA = (unsigned)(tm * BM + 8 * lw + drow) * lda2 + dchunk;
       voffW = (unsigned)(tn * BN + 8 * lw + drow) * ldw2 + dchunk;
+      if (p.conv) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          const int r = tm * BM + 8 * (lw + 4 * j) + drow;
+          const int rem = r % (p.cH * p.cW);
+          cy[j] = r < p.M ? rem / p.cW : -4;           // rows past M: never inside the image
+          cx[j] = rem % p.cW;
+          cbase[j] = (unsigned)r * (unsigned)(p.cCi * 2) + dchunk;
+        }
+      }
     };
     // K tail: in the last k-step of a tile the lanes whose 16-byte chunk lies past K get an out-of-range offset (zero fill)
     const bool tail_dead = (KT - 1) * BIG_BK + (int)(dchunk >> 1) >= p.K;
     auto dma_issue = [&](int slot) {
       const unsigned sbase = lds0 + (unsigned)slot * STAGE;
+      if (p.conv) {
+        const int tap = d_k / p.kpt, kk = d_k - tap * p.kpt;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int dy = p.flip ? 1 - kh : kh - 1, dx = p.flip ? 1 - kw : kw - 1;
+        const bool cdead = kk * 64 + cch * 8 >= p.cCi;                                  // past the tap's channels (Ci not a multiple of 64)
+        const int aoff = ((dy * p.cW + dx) * p.cCi + kk * 64) * 2;
+        const int woff = (tap * p.cCi + kk * 64) * 2;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          const int yy = cy[j] + dy, xx = cx[j] + dx;
+          const bool ok = !cdead && yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW;
+          dma16(rA, sbase + (unsigned)(lw + 4 * j) * 1024u, ok ? cbase[j] + (unsigned)aoff : 0xfffffff0u, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          dma16(rW, sbase + (unsigned)BM * BIG_ROWB + (unsigned)(lw + 4 * j) * 1024u, cdead ? 0xfffffff0u : voffW + (unsigned)j * 32u * ldw2 + (unsigned)woff, 0);
+        if (++d_k == KT) { d_k = 0; ++d_tile; if (d_tile < my_tiles) dma_tile_setup(d_tile); }
+        return;
+      }
       const int soff = d_k * (BIG_BK * 2);
       const bool dead = tail_dead && d_k == KT - 1;
 #pragma unroll
@@ -734,15 +772,25 @@ static void big_launch_t(const BigP& p, int grid, hipStream_t s) {
 }
 
 // true = launched.  amode must be AM_DENSE, dtype bf16.
-bool gemm_big_launch(const GemmP& g, hipStream_t s) {
+static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip);
+bool gemm_big_launch(const GemmP& g, hipStream_t s) { return gemm_big_go(g, s, false, 0); }
+// 3x3 stride-1 'same' convolution (forward: amode AM_CONV, weights [N][9][Ci]; data gradient: AM_DGRAD, weights = the backward pack) on the
+// persistent kernel.  Same epilogue subset as the dense form (BatchNorm statistics / backward sums, accumulate).
+bool gemm_big_conv_launch(int amode, const GemmP& g, hipStream_t s) {
+  if (g.KW != 3 || g.stride != 1 || g.pt != 1 || g.pl != 1 || g.OH != g.H || g.OW != g.W || (g.Ci & 7) || g.ldc != g.N) return false;
+  if (g.bias || g.act || g.pre_out || g.bact_u) return false;
+  if ((long)(g.M / (g.H * g.W)) * g.H * g.W != g.M || g.K != 9 * g.Ci) return false;
+  return gemm_big_go(g, s, true, amode == AM_DGRAD ? 1 : 0);
+}
+static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
   const char* mode_env = getenv("SATRN_GEMM_BIG");   // read per call (tests and tools switch it): 0 = off, 2 = take every shape that fits
   const int mode = mode_env ? atoi(mode_env) : 1;
   if (!mode) return false;
   if (g.escale || g.eres || g.out_f32 || g.drop_p > 0.f) return false;
   if (g.stats && (g.stats_part || g.bias || g.stats_rep < 1)) return false;   // deterministic slabs / biased statistics: gemm_kernel
   if (g.bnb_y && !g.stats) return false;
-  if ((g.K & 7) || (g.lda & 7) || (g.ldc & 7) || (g.N & 7) || g.M < 1) return false;
-  if ((size_t)g.M * g.lda * 2 >= (1ull << 31) || (size_t)g.N * g.K * 2 >= (1ull << 31) || (size_t)g.M * g.ldc * 2 >= (1ull << 31)) return false;   // 32-bit buffer offsets
+  if ((g.K & 7) || (!conv && (g.lda & 7)) || (g.ldc & 7) || (g.N & 7) || g.M < 1) return false;
+  if ((size_t)g.M * (conv ? g.Ci : g.lda) * 2 >= (1ull << 31) || (size_t)g.N * g.K * 2 >= (1ull << 31) || (size_t)g.M * g.ldc * 2 >= (1ull << 31)) return false;   // 32-bit buffer offsets
   {
     // default mode: the large products only (SwinTRN's linears, M = 2 304 .. 147 456 with N >= 128).  Measured inside the EfficientSATRN
     // step (tools/shape_prof.py, SATRN_GEMM_BIG_MIN_GFLOP=0.5 against the default): its 1x1 convolutions -- 0.5 .. 2 GFLOP each, inputs
@@ -751,13 +799,14 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) {
     static const double min_gflop = getenv("SATRN_GEMM_BIG_MIN_GFLOP") ? atof(getenv("SATRN_GEMM_BIG_MIN_GFLOP")) : 2.0;
     const double flops = 2.0 * g.M * g.N * g.K;
     static const int min_n = getenv("SATRN_GEMM_BIG_MIN_N") ? atoi(getenv("SATRN_GEMM_BIG_MIN_N")) : 128;
-    if (mode != 2 && (flops < min_gflop * 1e9 || g.N < min_n || g.M < 2048)) return false;
+    if (mode != 2 && (flops < min_gflop * 1e9 || g.N < (conv ? 64 : min_n) || g.M < 2048)) return false;
   }
   BigP p;
   p.A = (const bf16_t*)g.A; p.W = (const bf16_t*)g.Bw; p.C = (bf16_t*)g.C; p.bias = g.bias;
   p.pre_out = (bf16_t*)g.pre_out; p.bact_u = (const bf16_t*)g.bact_u;
   p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldc = g.ldc; p.act = g.act; p.bact = g.bact; p.beta = g.beta; p.bact_scale = g.bact_scale; p.pre_grad = g.pre_grad;
-  p.a_bytes = (unsigned)(((size_t)(g.M - 1) * g.lda + g.K) * 2);
+  p.a_bytes = conv ? (unsigned)((size_t)g.M * g.Ci * 2) : (unsigned)(((size_t)(g.M - 1) * g.lda + g.K) * 2);
+  p.conv = conv ? 1 : 0; p.cH = g.H; p.cW = g.W; p.cCi = g.Ci; p.flip = flip; p.kpt = conv ? (g.Ci + 63) / 64 : 0;
   p.w_bytes = (unsigned)((size_t)g.N * g.K * 2);
   p.c_bytes = (unsigned)(((size_t)(g.M - 1) * g.ldc + g.N) * 2);
   p.stats = g.stats; p.stats_rep = g.stats_rep; p.bnb_y = (const bf16_t*)g.bnb_y; p.bnb_ss = g.bnb_ss; p.bnb_mr = g.bnb_mr; p.bnb_act = g.bnb_act;

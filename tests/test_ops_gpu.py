@@ -382,6 +382,42 @@ def test_conv3x3(lib, dt, B, H, W, Ci, Co, s):
     close(dw, wr.grad, dt, f"conv3x3_bwd_weight s{s}")
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 24, 48, 192), (3, 9, 7, 128, 64), (2, 9, 20, 256, 64), (2, 32, 96, 48, 192), (4, 16, 48, 64, 256),
+                                         (2, 13, 11, 24, 72), (2, 8, 12, 72, 136)])
+def test_conv3x3_as_shifted_gemm_on_the_persistent_kernel(lib, big_gemm_mode, B, H, W, Ci, Co):
+    """3x3 stride-1 'same' convolution and its data gradient as shifted GEMMs on the persistent direct-to-LDS kernel (the loaders read pixel
+    (y + dy, x + dx) per tap, zero outside the image and past Ci): image borders, Ci below / above / not a multiple of 64, row and column
+    tails; against fp32 torch and against the halo-tiled kernel"""
+    import os
+    dt = "bf16"
+    x, w = q(rnd(B, Ci, H, W, seed=1), dt), q(rnd(Co, Ci, 3, 3, seed=2, scale=1 / math.sqrt(9 * Ci)), dt)
+    fwd = torch.empty(Co, 9, Ci, dtype=tdt(dt), device="cuda")
+    bwd = torch.empty(Ci, 9, Co, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_pack_conv3x3(dti(dt), P(dev(w)), P(fwd), P(bwd), Co, Ci, st()))
+    xd = dev(nhwc(x), dt)
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv2d(F.pad(xr, (1, 1, 1, 1)), w, None, 1, 0)
+    dy = q(rnd(*ref.shape, seed=5), dt)
+    ref.backward(dy)
+    dyd = dev(nhwc(dy), dt)
+    outs = {}
+    try:
+        for name, mode, cb in (("persistent", 2, "1"), ("halo", 0, "0")):
+            big_gemm_mode(mode)
+            os.environ["SATRN_CONV_BIG"] = cb
+            y = torch.empty(B, H, W, Co, dtype=tdt(dt), device="cuda")
+            ok(lib, lib.satrn_conv3x3_fwd(dti(dt), P(xd), P(fwd), P(y), B, H, W, Ci, Co, H, W, 1, 1, 1, st()))
+            dx = torch.empty(B, H, W, Ci, dtype=tdt(dt), device="cuda")
+            ok(lib, lib.satrn_conv3x3_bwd_data(dti(dt), P(dyd), P(bwd), P(dx), B, H, W, Ci, Co, H, W, 1, 1, 1, 0, st()))
+            outs[name] = (y.float().cpu(), dx.float().cpu())
+            close(nchw(y.float()), ref, dt, f"conv3x3_fwd ({name})")
+            close(nchw(dx.float()), xr.grad, dt, f"conv3x3_bwd_data ({name})")
+    finally:
+        os.environ.pop("SATRN_CONV_BIG", None)
+    close(outs["persistent"][0], outs["halo"][0], dt, "persistent vs halo forward", bf16_tol=1e-2)
+    close(outs["persistent"][1], outs["halo"][1], dt, "persistent vs halo data gradient", bf16_tol=1e-2)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,Cin,H,W,Co,s,pad", [(2, 1, 32, 48, 24, 2, 0), (2, 1, 16, 24, 16, 1, 1), (2, 3, 17, 23, 128, 1, 1)])
 def test_stem_conv(lib, dt, B, Cin, H, W, Co, s, pad):
