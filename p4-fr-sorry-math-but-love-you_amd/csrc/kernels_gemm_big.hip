@@ -113,7 +113,9 @@ DEVI i32x4 make_rsrc(const void* base, unsigned bytes) {
 //   EK 2  GELU + its derivative stored beside it (pre_out with pre_grad; networks/SWIN.py:24-47 fc1)
 //   EK 3  times a stored factor: bact_u with ACT_DFACTOR (the stored derivative) or ACT_RELU (sign of the stored output, x bact_scale);
 //         the factor loads run four row groups ahead of their use (one dependent round trip per group otherwise)
-template <int MTW, bool HAS_BIAS, int EK, int STATS = 0 /*1 BatchNorm statistics, 2 BatchNorm-backward sums*/>
+// CONV (the shifted-GEMM convolution mode, BigP::conv) is a template parameter as well: as a run-time branch in the loaders it cost the
+// dense products 5 % (the loaders' issue rate is what bounds the main loop).
+template <int MTW, bool HAS_BIAS, int EK, int STATS = 0 /*1 BatchNorm statistics, 2 BatchNorm-backward sums*/, bool CONV = false>
 __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
   constexpr bool HAS_AUX = EK == 1;
   constexpr int NT = 4, HM = MTW / 2;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int KT = p.conv ? 9 * p.kpt : (p.K + BIG_BK - 1) / BIG_BK;   // K % 8 == 0; a partial last k-step is zero-filled (both operands) by the loaders
+  const int KT = CONV ? 9 * p.kpt : (p.K + BIG_BK - 1) / BIG_BK;   // K % 8 == 0; a partial last k-step is zero-filled (both operands) by the loaders
 
   // ---- this workgroup's tiles: logical id L (XCD-contiguous) + i * gridDim; tiles ordered n fastest, so the 32 workgroups of an
   // XCD share two row blocks of A and all of W in their L2
@@ -149,15 +151,15 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
     int d_tile = 0, d_k = 0;                 // position of the NEXT stage to request
     unsigned voffA = 0, voffW = 0;
     // convolution mode: per piece of this lane the pixel's (y, x) and its byte offset (row r = pixel r of the NHWC map)
-    int cy[NA], cx[NA];
-    unsigned cbase[NA];
+    int cy[CONV ? NA : 1], cx[CONV ? NA : 1];
+    unsigned cbase[CONV ? NA : 1];
     const int cch = (int)(dchunk >> 4);      // this lane's 8-channel chunk inside a 64-channel slice
     auto dma_tile_setup = [&](int ti) {
       const int tile = L + ti * nwg;
       const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
       voffA = (unsigned)(tm * BM + 8 * lw + drow) * lda2 + dchunk;
       voffW = (unsigned)(tn * BN + 8 * lw + drow) * ldw2 + dchunk;
-      if (p.conv) {
+      if constexpr (CONV) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
           const int r = tm * BM + 8 * (lw + 4 * j) + drow;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
     const bool tail_dead = (KT - 1) * BIG_BK + (int)(dchunk >> 1) >= p.K;
     auto dma_issue = [&](int slot) {
       const unsigned sbase = lds0 + (unsigned)slot * STAGE;
-      if (p.conv) {
+      if constexpr (CONV) {
         const int tap = d_k / p.kpt, kk = d_k - tap * p.kpt;
         const int kh = tap / 3, kw = tap - kh * 3;
         const int dy = p.flip ? 1 - kh : kh - 1, dx = p.flip ? 1 - kw : kw - 1;
@@ -759,6 +761,21 @@ static void big_launch_t(const BigP& p, int grid, hipStream_t s) {
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_big_kernel<MTW, HB, EKIND, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
     hipLaunchKernelGGL((gemm_big_kernel<MTW, HB, EKIND, ST>), dim3(grid), dim3(BIG_THREADS), sh, s, p); } while (0)
   // the statistics forms keep 16 (sums) / 48 (+ BatchNorm coefficients) more registers: tiles of at most 192 / 128 rows
+  if (p.conv) {
+    // convolution mode: no bias / activation / second tensor besides accumulate (gemm_big_conv_launch filters)
+#define BIG_GOC(EKIND, ST) do { \
+    static bool attr = false; \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_big_kernel<MTW, false, EKIND, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
+    hipLaunchKernelGGL((gemm_big_kernel<MTW, false, EKIND, ST, true>), dim3(grid), dim3(BIG_THREADS), sh, s, p); } while (0)
+    if constexpr (MT <= 2) { if (p.stats && p.bnb_y) { if (aux) BIG_GOC(1, 2); else BIG_GOC(0, 2); return; } }
+    if constexpr (MT <= 3) {
+      if (p.stats && !p.bnb_y) { if (aux) BIG_GOC(1, 1); else BIG_GOC(0, 1); return; }
+      if (aux) { BIG_GOC(1, 0); return; }
+    }
+    BIG_GOC(0, 0);
+#undef BIG_GOC
+    return;
+  }
   if constexpr (MT <= 2) { if (p.stats && p.bnb_y) { if (aux) BIG_GO(false, 1, 2); else BIG_GO(false, 0, 2); return; } }
   if constexpr (MT <= 3) { if (p.stats && !p.bnb_y) { if (aux) BIG_GO(false, 1, 1); else BIG_GO(false, 0, 1); return; } }
   // (the forms with a second tensor in the epilogue -- pre_out / bact_u / beta -- spill at 256-row tiles: at most 192 rows, as the statistics forms)
