@@ -735,11 +735,13 @@ void launch_gemm(int dt, int amode, const GemmP& p0, hipStream_t s) {
   const int nslots = (p.M + 63) / 64;
   if (p.stats) p.stats_part = det_scratch(s, (size_t)(nslots + 4) * 2 * p.N);  // null unless the deterministic mode is on
   {
-    // large 3x3 stride-1 convolutions and their data gradients (>= 64 output channels, >= 2 GFLOP: the fused-MBConv stages) as shifted
-    // GEMMs on the persistent kernel: 66 -> 62 us (48 -> 192 channels at 32 x 96), 30 -> 25 and 63 -> 54 us (64 <-> 256 at 16 x 48) against the
-    // halo-tiled kernel.  SATRN_CONV_BIG=0 (read per call: tests) keeps the halo kernel.
+    // large 3x3 stride-1 convolutions and their data gradients (>= 32 output channels, >= 2 GFLOP: the fused-MBConv stages) as shifted
+    // GEMMs on the persistent kernel, 64-column tiles for the narrow data gradients: forward 66 -> 58 us (48 -> 192 channels at 32 x 96) and
+    // 30 -> 23 us (64 -> 256 at 16 x 48), data gradients 98 -> 80 us (192 -> 48) and 63 -> 41 us (256 -> 64) against the halo-tiled kernel.
+    // SATRN_CONV_BIG=0 (read per call: tests) keeps the halo kernel.
     const char* cb = getenv("SATRN_CONV_BIG");
-    if (!(cb && atoi(cb) == 0) && !p.stats_part && dt == DT_BF16 && (amode == AM_CONV || amode == AM_DGRAD) && p.N >= 64 &&
+    static const int conv_min_n = getenv("SATRN_CONV_BIG_MIN_N") ? atoi(getenv("SATRN_CONV_BIG_MIN_N")) : 32;   // knob
+    if (!(cb && atoi(cb) == 0) && !p.stats_part && dt == DT_BF16 && (amode == AM_CONV || amode == AM_DGRAD) && p.N >= conv_min_n &&
         gemm_big_conv_launch(amode, p, s)) return;
   }
   if (!p.stats_part && dt == DT_BF16 && amode != AM_DENSE && conv_halo_launch(amode, p, s)) return;

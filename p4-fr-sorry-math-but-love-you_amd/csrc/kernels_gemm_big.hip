@@ -56,6 +56,7 @@ struct BigP {
   // and the tap's Ci columns of the packed weights [N][9][Ci]; the consumers see ordinary 64-deep stages.  flip: the data gradient
   // (dy -> -dy, dx -> -dx; weights = the backward pack [Ci_out][9][Co]).
   int conv, cH, cW, cCi, flip, kpt;
+  int narrow;   // 64-column tiles (WN = 1)
 };
 
 #define BIG_THREADS 512
@@ -115,15 +116,18 @@ DEVI i32x4 make_rsrc(const void* base, unsigned bytes) {
 //         the factor loads run four row groups ahead of their use (one dependent round trip per group otherwise)
 // CONV (the shifted-GEMM convolution mode, BigP::conv) is a template parameter as well: as a run-time branch in the loaders it cost the
 // dense products 5 % (the loaders' issue rate is what bounds the main loop).
-template <int MTW, bool HAS_BIAS, int EK, int STATS = 0 /*1 BatchNorm statistics, 2 BatchNorm-backward sums*/, bool CONV = false>
+// WN = consumer waves along N: 2 = the 128-column tile (consumers 2 x 2, BM = 32 MTW), 1 = a 64-column tile for narrow outputs (consumers 4 x 1,
+// BM = 64 MTW: the data gradients of the 3 x 3 convolutions have 48 / 64 output channels, on the 128-column tile most of the MFMA and LDS
+// work multiplied zeros).
+template <int MTW, bool HAS_BIAS, int EK, int STATS = 0 /*1 BatchNorm statistics, 2 BatchNorm-backward sums*/, bool CONV = false, int WN = 2>
 __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
   constexpr bool HAS_AUX = EK == 1;
   constexpr int NT = 4, HM = MTW / 2;
-  constexpr int BM = 32 * MTW, BN = 128;
+  constexpr int BM = 16 * MTW * (4 / WN), BN = 64 * WN;
   constexpr int TM = 16 * MTW;                                    // rows per consumer wave
   constexpr int STAGE = (BM + BN) * BIG_ROWB;                     // bytes per ring slot
   constexpr int EPI = BIG_NSTAGE * STAGE;                         // epilogue scratch: 4 consumer waves x 2 x 2 KB
-  constexpr int NA = MTW, NB = 4;                                 // DMA instructions per LOADER wave and stage (8 rows each)
+  constexpr int NA = BM / 32, NB = BN / 32;                       // DMA instructions per LOADER wave and stage (8 rows each)
   extern __shared__ __attribute__((aligned(16))) unsigned char big_sm[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)big_sm;   // LDS byte address of the ring
 
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
   }
 
   // =============================== consumer waves ===============================
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? (wave & 1) : 0;
   const int fr = lane & 15, fq = lane >> 4;
   // outputs / epilogue operands through buffer descriptors: a lane outside the matrix gets an out-of-range offset and the access is
   // dropped by the range check (no divergent branch around the stores)
@@ -761,6 +765,20 @@ static void big_launch_t(const BigP& p, int grid, hipStream_t s) {
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_big_kernel<MTW, HB, EKIND, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
     hipLaunchKernelGGL((gemm_big_kernel<MTW, HB, EKIND, ST>), dim3(grid), dim3(BIG_THREADS), sh, s, p); } while (0)
   // the statistics forms keep 16 (sums) / 48 (+ BatchNorm coefficients) more registers: tiles of at most 192 / 128 rows
+  if (p.conv && p.narrow) {
+    // 64-column tiles, BM = 64 MT rows (MT = 2 / 4 only: the fragment ping-pong needs an even number of row groups per wave)
+    constexpr int MTN = MT == 3 ? 2 : MT;
+    constexpr size_t shn = (size_t)BIG_NSTAGE * (64 * MTN + 64) * BIG_ROWB + 4 * 4096;
+#define BIG_GON(EKIND, ST) do { \
+    static bool attr = false; \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_big_kernel<MTN, false, EKIND, ST, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shn); attr = true; } \
+    hipLaunchKernelGGL((gemm_big_kernel<MTN, false, EKIND, ST, true, 1>), dim3(grid), dim3(BIG_THREADS), shn, s, p); } while (0)
+    if (p.stats && p.bnb_y) { if (aux) BIG_GON(1, 2); else BIG_GON(0, 2); return; }
+    if (p.stats) { if (aux) BIG_GON(1, 1); else BIG_GON(0, 1); return; }
+    if (aux) BIG_GON(1, 0); else BIG_GON(0, 0);
+#undef BIG_GON
+    return;
+  }
   if (p.conv) {
     // convolution mode: no bias / activation / second tensor besides accumulate (gemm_big_conv_launch filters)
 #define BIG_GOC(EKIND, ST) do { \
@@ -816,7 +834,7 @@ static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
     static const double min_gflop = getenv("SATRN_GEMM_BIG_MIN_GFLOP") ? atof(getenv("SATRN_GEMM_BIG_MIN_GFLOP")) : 2.0;
     const double flops = 2.0 * g.M * g.N * g.K;
     static const int min_n = getenv("SATRN_GEMM_BIG_MIN_N") ? atoi(getenv("SATRN_GEMM_BIG_MIN_N")) : 128;
-    if (mode != 2 && (flops < min_gflop * 1e9 || g.N < (conv ? 64 : min_n) || g.M < 2048)) return false;
+    if (mode != 2 && (flops < min_gflop * 1e9 || g.N < (conv ? 32 : min_n) || g.M < 2048)) return false;
   }
   BigP p;
   p.A = (const bf16_t*)g.A; p.W = (const bf16_t*)g.Bw; p.C = (bf16_t*)g.C; p.bias = g.bias;
@@ -828,7 +846,8 @@ static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
   p.c_bytes = (unsigned)(((size_t)(g.M - 1) * g.ldc + g.N) * 2);
   p.stats = g.stats; p.stats_rep = g.stats_rep; p.bnb_y = (const bf16_t*)g.bnb_y; p.bnb_ss = g.bnb_ss; p.bnb_mr = g.bnb_mr; p.bnb_act = g.bnb_act;
   p.y_bytes = (unsigned)((size_t)g.M * g.N * 2);
-  p.ntn = (g.N + 127) / 128;
+  p.narrow = (conv && g.N <= 64) ? 1 : 0;
+  p.ntn = p.narrow ? (g.N + 63) / 64 : (g.N + 127) / 128;
   p.dbg = big_dbg();
   const int cus = big_cu_count();
   // tile height: the candidate whose tile count leaves the smallest idle share in the last round of the persistent grid
@@ -836,8 +855,9 @@ static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
   int best_mt = 3;
   double best_cost = 1e30;
   const bool aux_form = g.pre_out || g.bact_u || g.beta;
-  const int mt_max = g.bnb_y ? 2 : ((g.stats || aux_form) ? 3 : 4);
+  const int mt_max = p.narrow ? 4 : (g.bnb_y ? 2 : ((g.stats || aux_form) ? 3 : 4));
   for (int mt = mt_max; mt >= 2; --mt) {
+    if (p.narrow && mt == 3) continue;   // (64-column tiles: 128 or 256 rows)
     const long tiles = (long)((g.M + 64 * mt - 1) / (64 * mt)) * p.ntn;
     const long rounds = (tiles + cus - 1) / cus;
     // cost ~ rounds x (rows per tile + a fixed per-tile part worth ~48 rows: epilogue + the wider share of W traffic of flat tiles)

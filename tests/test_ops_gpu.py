@@ -383,7 +383,7 @@ def test_conv3x3(lib, dt, B, H, W, Ci, Co, s):
 
 
 @pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 24, 48, 192), (3, 9, 7, 128, 64), (2, 9, 20, 256, 64), (2, 32, 96, 48, 192), (4, 16, 48, 64, 256),
-                                         (2, 13, 11, 24, 72), (2, 8, 12, 72, 136)])
+                                         (2, 13, 11, 24, 72), (2, 8, 12, 72, 136), (2, 16, 24, 192, 48), (3, 11, 13, 136, 40)])   # last two: 64-column tiles
 def test_conv3x3_as_shifted_gemm_on_the_persistent_kernel(lib, big_gemm_mode, B, H, W, Ci, Co):
     """3x3 stride-1 'same' convolution and its data gradient as shifted GEMMs on the persistent direct-to-LDS kernel (the loaders read pixel
     (y + dy, x + dx) per tap, zero outside the image and past Ci): image borders, Ci below / above / not a multiple of 64, row and column
