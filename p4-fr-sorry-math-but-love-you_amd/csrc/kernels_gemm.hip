@@ -740,7 +740,7 @@ void launch_gemm(int dt, int amode, const GemmP& p0, hipStream_t s) {
     // 30 -> 23 us (64 -> 256 at 16 x 48), data gradients 98 -> 80 us (192 -> 48) and 63 -> 41 us (256 -> 64) against the halo-tiled kernel.
     // SATRN_CONV_BIG=0 (read per call: tests) keeps the halo kernel.
     const char* cb = getenv("SATRN_CONV_BIG");
-    static const int conv_min_n = getenv("SATRN_CONV_BIG_MIN_N") ? atoi(getenv("SATRN_CONV_BIG_MIN_N")) : 32;   // knob
+    const int conv_min_n = getenv("SATRN_CONV_BIG_MIN_N") ? atoi(getenv("SATRN_CONV_BIG_MIN_N")) : 32;   // knob (read per call: tests)
     if (!(cb && atoi(cb) == 0) && !p.stats_part && dt == DT_BF16 && (amode == AM_CONV || amode == AM_DGRAD) && p.N >= conv_min_n &&
         gemm_big_conv_launch(amode, p, s)) return;
   }

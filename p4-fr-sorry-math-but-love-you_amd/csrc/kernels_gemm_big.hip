@@ -56,6 +56,7 @@ struct BigP {
   // and the tap's Ci columns of the packed weights [N][9][Ci]; the consumers see ordinary 64-deep stages.  flip: the data gradient
   // (dy -> -dy, dx -> -dx; weights = the backward pack [Ci_out][9][Co]).
   int conv, cH, cW, cCi, flip, kpt;
+  int cOH, cOW, cstride, cpt, cpl;   // rows run over [B][cOH][cOW]; the source tensor is [B][cH][cW][cCi]; stride 1 or 2, top / left padding
   int narrow;   // 64-column tiles (WN = 1)
 };
 
@@ -167,10 +168,11 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
           const int r = tm * BM + 8 * (lw + 4 * j) + drow;
-          const int rem = r % (p.cH * p.cW);
-          cy[j] = r < p.M ? rem / p.cW : -4;           // rows past M: never inside the image
-          cx[j] = rem % p.cW;
-          cbase[j] = (unsigned)r * (unsigned)(p.cCi * 2) + dchunk;
+          const int ohw = p.cOH * p.cOW, b = r / ohw, rem = r - b * ohw;
+          cy[j] = r < p.M ? rem / p.cOW : -(1 << 20);  // rows past M: never inside the image
+          cx[j] = rem % p.cOW;
+          // stride 1: the row's own pixel (a tap then adds a constant); stride 2: the image's first source pixel
+          cbase[j] = (p.cstride == 1 ? (unsigned)r : (unsigned)(b * p.cH * p.cW)) * (unsigned)(p.cCi * 2) + dchunk;
         }
       }
     };
@@ -181,15 +183,35 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
       if constexpr (CONV) {
         const int tap = d_k / p.kpt, kk = d_k - tap * p.kpt;
         const int kh = tap / 3, kw = tap - kh * 3;
-        const int dy = p.flip ? 1 - kh : kh - 1, dx = p.flip ? 1 - kw : kw - 1;
         const bool cdead = kk * 64 + cch * 8 >= p.cCi;                                  // past the tap's channels (Ci not a multiple of 64)
-        const int aoff = ((dy * p.cW + dx) * p.cCi + kk * 64) * 2;
         const int woff = (tap * p.cCi + kk * 64) * 2;
+        const int sh1 = p.cstride - 1;   // stride 1 or 2
+        if (p.cstride == 1) {
+          // (the common case kept lean -- the loaders' issue rate bounds the main loop: the general form below cost the stride-1 data
+          // gradients 20 %)
+          const int dy = p.flip ? p.cpt - kh : kh - p.cpt, dx = p.flip ? p.cpl - kw : kw - p.cpl;
+          const int aoff = ((dy * p.cW + dx) * p.cCi + kk * 64) * 2;
+#pragma unroll
+          for (int j = 0; j < NA; ++j) {
+            const int yy = cy[j] + dy, xx = cx[j] + dx;
+            const bool ok = !cdead && yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW;
+            dma16(rA, sbase + (unsigned)(lw + 4 * j) * 1024u, ok ? cbase[j] + (unsigned)aoff : 0xfffffff0u, 0);
+          }
+        } else
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-          const int yy = cy[j] + dy, xx = cx[j] + dx;
-          const bool ok = !cdead && yy >= 0 && yy < p.cH && xx >= 0 && xx < p.cW;
-          dma16(rA, sbase + (unsigned)(lw + 4 * j) * 1024u, ok ? cbase[j] + (unsigned)aoff : 0xfffffff0u, 0);
+          // source pixel of output pixel (cy, cx) under this tap: forward (oy * stride - pt + kh, ..); data gradient ((oy + pt - kh) / stride, ..)
+          // where that division is exact
+          int sy, sx;
+          bool ok = !cdead;
+          if (!p.flip) { sy = (cy[j] << sh1) - p.cpt + kh; sx = (cx[j] << sh1) - p.cpl + kw; }
+          else {
+            const int ty = cy[j] + p.cpt - kh, tx = cx[j] + p.cpl - kw;
+            ok = ok && ((ty | tx) & sh1) == 0;
+            sy = ty >> sh1; sx = tx >> sh1;
+          }
+          ok = ok && sy >= 0 && sy < p.cH && sx >= 0 && sx < p.cW;
+          dma16(rA, sbase + (unsigned)(lw + 4 * j) * 1024u, ok ? cbase[j] + (unsigned)(((sy * p.cW + sx) * p.cCi + kk * 64) * 2) : 0xfffffff0u, 0);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j)
@@ -812,9 +834,9 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) { return gemm_big_go(g, s, f
 // 3x3 stride-1 'same' convolution (forward: amode AM_CONV, weights [N][9][Ci]; data gradient: AM_DGRAD, weights = the backward pack) on the
 // persistent kernel.  Same epilogue subset as the dense form (BatchNorm statistics / backward sums, accumulate).
 bool gemm_big_conv_launch(int amode, const GemmP& g, hipStream_t s) {
-  if (g.KW != 3 || g.stride != 1 || g.pt != 1 || g.pl != 1 || g.OH != g.H || g.OW != g.W || (g.Ci & 7) || g.ldc != g.N) return false;
+  if (g.KW != 3 || (g.stride != 1 && g.stride != 2) || (g.Ci & 7) || g.ldc != g.N) return false;
   if (g.bias || g.act || g.pre_out || g.bact_u) return false;
-  if ((long)(g.M / (g.H * g.W)) * g.H * g.W != g.M || g.K != 9 * g.Ci) return false;
+  if ((long)(g.M / (g.OH * g.OW)) * g.OH * g.OW != g.M || g.K != 9 * g.Ci) return false;
   return gemm_big_go(g, s, true, amode == AM_DGRAD ? 1 : 0);
 }
 static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
@@ -825,7 +847,7 @@ static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
   if (g.stats && (g.stats_part || g.bias || g.stats_rep < 1)) return false;   // deterministic slabs / biased statistics: gemm_kernel
   if (g.bnb_y && !g.stats) return false;
   if ((g.K & 7) || (!conv && (g.lda & 7)) || (g.ldc & 7) || (g.N & 7) || g.M < 1) return false;
-  if ((size_t)g.M * (conv ? g.Ci : g.lda) * 2 >= (1ull << 31) || (size_t)g.N * g.K * 2 >= (1ull << 31) || (size_t)g.M * g.ldc * 2 >= (1ull << 31)) return false;   // 32-bit buffer offsets
+  if ((conv ? (size_t)(g.M / (g.OH * g.OW)) * g.H * g.W * g.Ci : (size_t)g.M * g.lda) * 2 >= (1ull << 31) || (size_t)g.N * g.K * 2 >= (1ull << 31) || (size_t)g.M * g.ldc * 2 >= (1ull << 31)) return false;   // 32-bit buffer offsets
   {
     // default mode: the large products only (SwinTRN's linears, M = 2 304 .. 147 456 with N >= 128).  Measured inside the EfficientSATRN
     // step (tools/shape_prof.py, SATRN_GEMM_BIG_MIN_GFLOP=0.5 against the default): its 1x1 convolutions -- 0.5 .. 2 GFLOP each, inputs
@@ -840,7 +862,8 @@ static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
   p.A = (const bf16_t*)g.A; p.W = (const bf16_t*)g.Bw; p.C = (bf16_t*)g.C; p.bias = g.bias;
   p.pre_out = (bf16_t*)g.pre_out; p.bact_u = (const bf16_t*)g.bact_u;
   p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldc = g.ldc; p.act = g.act; p.bact = g.bact; p.beta = g.beta; p.bact_scale = g.bact_scale; p.pre_grad = g.pre_grad;
-  p.a_bytes = conv ? (unsigned)((size_t)g.M * g.Ci * 2) : (unsigned)(((size_t)(g.M - 1) * g.lda + g.K) * 2);
+  p.a_bytes = conv ? (unsigned)((size_t)(g.M / (g.OH * g.OW)) * g.H * g.W * g.Ci * 2) : (unsigned)(((size_t)(g.M - 1) * g.lda + g.K) * 2);
+  p.cOH = g.OH; p.cOW = g.OW; p.cstride = g.stride; p.cpt = g.pt; p.cpl = g.pl;
   p.conv = conv ? 1 : 0; p.cH = g.H; p.cW = g.W; p.cCi = g.Ci; p.flip = flip; p.kpt = conv ? (g.Ci + 63) / 64 : 0;
   p.w_bytes = (unsigned)((size_t)g.N * g.K * 2);
   p.c_bytes = (unsigned)(((size_t)(g.M - 1) * g.ldc + g.N) * 2);

@@ -382,40 +382,45 @@ def test_conv3x3(lib, dt, B, H, W, Ci, Co, s):
     close(dw, wr.grad, dt, f"conv3x3_bwd_weight s{s}")
 
 
-@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 24, 48, 192), (3, 9, 7, 128, 64), (2, 9, 20, 256, 64), (2, 32, 96, 48, 192), (4, 16, 48, 64, 256),
-                                         (2, 13, 11, 24, 72), (2, 8, 12, 72, 136), (2, 16, 24, 192, 48), (3, 11, 13, 136, 40)])   # last two: 64-column tiles
-def test_conv3x3_as_shifted_gemm_on_the_persistent_kernel(lib, big_gemm_mode, B, H, W, Ci, Co):
-    """3x3 stride-1 'same' convolution and its data gradient as shifted GEMMs on the persistent direct-to-LDS kernel (the loaders read pixel
-    (y + dy, x + dx) per tap, zero outside the image and past Ci): image borders, Ci below / above / not a multiple of 64, row and column
-    tails; against fp32 torch and against the halo-tiled kernel"""
+@pytest.mark.parametrize("B,H,W,Ci,Co,s", [(2, 16, 24, 48, 192, 1), (3, 9, 7, 128, 64, 1), (2, 9, 20, 256, 64, 1), (2, 32, 96, 48, 192, 1), (4, 16, 48, 64, 256, 1),
+                                           (2, 13, 11, 24, 72, 1), (2, 8, 12, 72, 136, 1), (2, 16, 24, 192, 48, 1), (3, 11, 13, 136, 40, 1),   # the last two: 64-column tiles
+                                           (2, 16, 24, 48, 192, 2), (2, 15, 21, 24, 96, 2), (2, 32, 96, 24, 48, 2), (3, 17, 9, 64, 40, 2)])   # stride 2
+def test_conv3x3_as_shifted_gemm_on_the_persistent_kernel(lib, big_gemm_mode, B, H, W, Ci, Co, s):
+    """3x3 'same' convolution (stride 1 / 2) and its data gradient as shifted GEMMs on the persistent direct-to-LDS kernel (the loaders read the
+    tap's source pixel, zero outside the image / past Ci / where a stride-2 data gradient has no contribution): image borders, Ci below /
+    above / not a multiple of 64, row and column tails, 64-column tiles; against fp32 torch and against the kernels it replaces"""
     import os
     dt = "bf16"
     x, w = q(rnd(B, Ci, H, W, seed=1), dt), q(rnd(Co, Ci, 3, 3, seed=2, scale=1 / math.sqrt(9 * Ci)), dt)
+    OH, OW, pt, pl, pads = same_geo(H, W, s)
     fwd = torch.empty(Co, 9, Ci, dtype=tdt(dt), device="cuda")
     bwd = torch.empty(Ci, 9, Co, dtype=tdt(dt), device="cuda")
     ok(lib, lib.satrn_pack_conv3x3(dti(dt), P(dev(w)), P(fwd), P(bwd), Co, Ci, st()))
     xd = dev(nhwc(x), dt)
     xr = x.clone().requires_grad_(True)
-    ref = F.conv2d(F.pad(xr, (1, 1, 1, 1)), w, None, 1, 0)
+    ref = F.conv2d(F.pad(xr, pads), w, None, s, 0)
+    assert ref.shape[2:] == (OH, OW)
     dy = q(rnd(*ref.shape, seed=5), dt)
     ref.backward(dy)
     dyd = dev(nhwc(dy), dt)
     outs = {}
     try:
-        for name, mode, cb in (("persistent", 2, "1"), ("halo", 0, "0")):
+        for name, mode, cb in (("persistent", 2, "1"), ("other", 0, "0")):
             big_gemm_mode(mode)
             os.environ["SATRN_CONV_BIG"] = cb
-            y = torch.empty(B, H, W, Co, dtype=tdt(dt), device="cuda")
-            ok(lib, lib.satrn_conv3x3_fwd(dti(dt), P(xd), P(fwd), P(y), B, H, W, Ci, Co, H, W, 1, 1, 1, st()))
+            os.environ["SATRN_CONV_BIG_MIN_N"] = "16"
+            y = torch.empty(B, OH, OW, Co, dtype=tdt(dt), device="cuda")
+            ok(lib, lib.satrn_conv3x3_fwd(dti(dt), P(xd), P(fwd), P(y), B, H, W, Ci, Co, OH, OW, s, pt, pl, st()))
             dx = torch.empty(B, H, W, Ci, dtype=tdt(dt), device="cuda")
-            ok(lib, lib.satrn_conv3x3_bwd_data(dti(dt), P(dyd), P(bwd), P(dx), B, H, W, Ci, Co, H, W, 1, 1, 1, 0, st()))
+            ok(lib, lib.satrn_conv3x3_bwd_data(dti(dt), P(dyd), P(bwd), P(dx), B, H, W, Ci, Co, OH, OW, s, pt, pl, 0, st()))
             outs[name] = (y.float().cpu(), dx.float().cpu())
-            close(nchw(y.float()), ref, dt, f"conv3x3_fwd ({name})")
-            close(nchw(dx.float()), xr.grad, dt, f"conv3x3_bwd_data ({name})")
+            close(nchw(y.float()), ref, dt, f"conv3x3_fwd s{s} ({name})")
+            close(nchw(dx.float()), xr.grad, dt, f"conv3x3_bwd_data s{s} ({name})")
     finally:
         os.environ.pop("SATRN_CONV_BIG", None)
-    close(outs["persistent"][0], outs["halo"][0], dt, "persistent vs halo forward", bf16_tol=1e-2)
-    close(outs["persistent"][1], outs["halo"][1], dt, "persistent vs halo data gradient", bf16_tol=1e-2)
+        os.environ.pop("SATRN_CONV_BIG_MIN_N", None)
+    close(outs["persistent"][0], outs["other"][0], dt, "persistent vs tile kernel forward", bf16_tol=1e-2)
+    close(outs["persistent"][1], outs["other"][1], dt, "persistent vs tile kernel data gradient", bf16_tol=1e-2)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
