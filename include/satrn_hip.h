@@ -118,6 +118,13 @@ int satrn_stem_conv_bwd_weight(int dtype, const float* img, const void* dy, floa
 /* depthwise 3x3 (+bias): networks/EfficientSATRN.py:245-247,274 and the timm MBConv conv_dw. */
 int satrn_dwconv3x3_fwd(int dtype, const void* x, const void* w_packed, const float* bias, void* y, int B, int H, int W,
                         int C, int OH, int OW, int stride, int pt, int pl, void* stream);
+/* Inference form of the MBConv depthwise seam (timm DepthwiseSeparable / InvertedResidual: conv_dw -> bn2 -> SiLU -> se pool, as
+ * run by networks/EfficientSATRN.py:74-76 under model.eval()): stride-1 "same" depthwise 3x3 (+bias) of an already activated x,
+ * eval-mode BatchNorm handed over as per-channel escale = weight/sqrt(running_var+eps), eshift = bias - running_mean*escale,
+ * activation, and -- optional -- pool[b][c] = sum over the image of y (the squeeze-and-excite mean is pool/(H*W)).  One launch on
+ * the small maps (bf16, C % 64 == 0, W % 3 == 0, H*W/3*8 <= 512 threads); other shapes run the generic kernel + a pooling pass. */
+int satrn_dwconv3x3_bn_eval_act_pool_fwd(int dtype, const void* x, const void* w_packed, const float* bias, const float* escale,
+                                         const float* eshift, int act, void* y, float* pool, int B, int H, int W, int C, void* stream);
 int satrn_dwconv3x3_bwd_data(int dtype, const void* dy, const void* w_packed, void* dx, int B, int H, int W, int C, int OH,
                              int OW, int stride, int pt, int pl, int accumulate, void* stream);
 int satrn_dwconv3x3_bwd_weight(int dtype, const void* x, const void* dy, float* dw, float* dbias, int B, int H, int W,

@@ -518,7 +518,7 @@ Model* model_create(const SatrnConfig& cfg) {
 
 void model_destroy(Model* m) {
   if (!m) return;
-  for (int i = 0; i < 4; ++i) if (m->graphs[i]) (void)hipGraphExecDestroy(m->graphs[i]);
+  for (int i = 0; i < 8; ++i) if (m->graphs[i]) (void)hipGraphExecDestroy(m->graphs[i]);
   if (m->hy_pinned) (void)hipHostFree(m->hy_pinned);
   delete m->ex;
   delete m;
@@ -532,7 +532,7 @@ int model_bind(Model* m, float* params, float* grads, float* buf_f32, int64_t* b
   m->bound = true;
   m->pack_dirty = true;
   m->bn_desc_dirty = true;
-  for (int i = 0; i < 4; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
+  for (int i = 0; i < 8; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
   if (m->decode_graph) { (void)hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
   return 0;
 }
@@ -541,7 +541,7 @@ static float* scal(Model* m) { return (float*)(m->ws + m->off_scalars); }
 
 int model_bind_optimizer(Model* m, float* exp_avg, float* exp_avg_sq) {
   m->adam_m = exp_avg; m->adam_v = exp_avg_sq;
-  for (int i = 0; i < 4; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
+  for (int i = 0; i < 8; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
   return 0;
 }
 
@@ -575,7 +575,7 @@ int model_set_workspace(Model* m, void* ws, size_t bytes, hipStream_t s) {
     w->fwd = w->pk_fwd_off >= 0 ? m->ws + w->pk_fwd_off : nullptr;
     w->bwd = w->pk_bwd_off >= 0 ? m->ws + w->pk_bwd_off : nullptr;
   }
-  for (int i = 0; i < 4; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
+  for (int i = 0; i < 8; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
   if (m->decode_graph) { (void)hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
   // tables: 1-D PE (networks/EfficientSATRN.py:408-418) and 2-D PE (:111-127), built in fp32 like the reference
   const int Dd = m->cfg.dec_hidden, D = m->cfg.enc_hidden;
@@ -852,10 +852,11 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** poo
       Tensor* z = e.newt(M, C, y->B, y->H, y->W);
       const float* ev = (const float*)(e.m->ws + e.m->off_bn_eval) + bn->eval_off;
       e.nbytes = (double)M * C * e.esz() * 2;
-      fn(ev, ev + C, act, z->p);
+      float* pool = pool_out && y->B > 0 ? (float*)e.alloc((size_t)y->B * C * 4) : nullptr;
+      if (fn(ev, ev + C, act, z->p, pool)) *pool_out = pool;
       return z;
     }
-    fn(nullptr, nullptr, 0, y->p);  // a residual is added by the separate pass below: run the plain convolution first
+    fn(nullptr, nullptr, 0, y->p, nullptr);  // a residual is added by the separate pass below: run the plain convolution first
   }
   float* ss = (float*)e.alloc((size_t)2 * C * 4);
   float* mr = (float*)e.alloc((size_t)2 * C * 4);
@@ -943,9 +944,15 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
     // inference: the BatchNorm that follows runs in this kernel's epilogue (launched by op_bn_act)
     Exec* ep = &e;
     const void* xp = x->p; const void* wf = w->fwd; const float* bp = bias ? bias->p : nullptr;
-    y->pend_dw = [=](const float* esc, const float* esh, int act, void* out) {
+    y->pend_dw = [=](const float* esc, const float* esh, int act, void* out, float* pool) -> bool {
       WORK((*ep), 18.0 * (double)B * OH * OW * C, ((double)B * H * W + (double)B * OH * OW) * C * ep->esz());
+      // small maps: whole image x 64 channels per workgroup, which also leaves the squeeze-and-excite pool complete
+      bool img = false;
+      if (esc && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W)
+        LCH((*ep), img = launch_dwconv_eval_img(ep->dt, xp, wf, bp, esc, esh, act, out, pool, B, H, W, C, ep->s));
+      if (img) return pool != nullptr;
       LCH((*ep), launch_dwconv(ep->dt, 0, xp, wf, bp, out, B, H, W, C, OH, OW, stride, pt, pl, 0, nullptr, ep->s, esc, esh, act));
+      return false;
     };
     return y;
   }
@@ -2132,9 +2139,8 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
   const bool train_mode = !(phase & 32);
   // + 64: the reference's NON-teacher-forced training branch (networks/EfficientSATRN.py:496-525: the decoder feeds on its own argmax,
   // gradients flow through every step) instead of the teacher-forced one -- the branch its coin takes on 20-70 % of the training batches
-  // (train_modules/train_single_opt.py:75, tf ratio 0.8 -> 0.3).  Eager only.
+  // (train_modules/train_single_opt.py:75, tf ratio 0.8 -> 0.3).
   const bool teacher_forced = !(phase & 64);
-  if (!teacher_forced) use_graph = 0;
   const int seg = (phase & 16) ? (phase & 3) : -1;
   const int seg_to = (phase >> 2) & 3;
   if (seg >= 0) {
@@ -2225,11 +2231,11 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
   };
   if (!use_graph) return body();
   if (m->graph_B != B || m->graph_L != L) {
-    for (int i = 0; i < 4; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
+    for (int i = 0; i < 8; ++i) if (m->graphs[i]) { (void)hipGraphExecDestroy(m->graphs[i]); m->graphs[i] = nullptr; }
   if (m->decode_graph) { (void)hipGraphExecDestroy(m->decode_graph); m->decode_graph = nullptr; }
     m->graph_B = B; m->graph_L = L;
   }
-  hipGraphExec_t& gx = m->graphs[phase];
+  hipGraphExec_t& gx = m->graphs[phase + (teacher_forced ? 0 : 4)];   // the two decoder branches are two graphs
   if (!gx) {
     // the caller must keep img / expected at the same addresses across replays (bench + trainer use staging buffers)
     hipGraph_t g = nullptr;

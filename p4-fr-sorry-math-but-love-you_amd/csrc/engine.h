@@ -88,7 +88,7 @@ struct Tensor {
   // inference: a product whose launch is postponed until the BatchNorm that consumes it is known, so that BatchNorm (eval
   // statistics) + activation + residual run in its epilogue and the raw output is never written (op_gemm -> op_bn_act)
   std::shared_ptr<GemmP> pend; int pend_mode = 0;
-  std::function<void(const float* escale, const float* eshift, int act, void* out)> pend_dw;  // same for a depthwise conv
+  std::function<bool(const float* escale, const float* eshift, int act, void* out, float* pool)> pend_dw;  // same for a depthwise conv
 };
 
 struct SwinBlock { LNp n1, n2; Wt qkv, proj, fc1, fc2; Vec bqkv, bproj, b1, b2, rpb; int dim = 0, heads = 0, res = 0, ws = 0, shift = 0; float drop_path = 0.f; int geo = -1; };
@@ -133,7 +133,7 @@ struct Model {
   bool bound = false, ws_set = false, tables_ready = false;
   // execution state
   struct Exec* ex = nullptr;
-  hipGraphExec_t graphs[4] = {nullptr, nullptr, nullptr, nullptr}; int graph_B = 0, graph_L = 0;
+  hipGraphExec_t graphs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int graph_B = 0, graph_L = 0;
   long adam_t = 0;
   // optimizer state lives OUTSIDE the resizable workspace (caller-owned flat fp32 buffers, one element per parameter):
   // a workspace regrown for a longer batch must not restart Adam

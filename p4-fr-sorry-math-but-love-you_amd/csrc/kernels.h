@@ -191,6 +191,11 @@ void launch_dwconv(int dt, int mode /*0 fwd,1 dgrad*/, const void* x, const void
                    void* y, int B, int H, int W, int C, int OH, int OW, int stride, int pt, int pl, int beta,
                    float* stats /*optional [2C] zeroed: column sums of y (mode 0)*/, hipStream_t s,
                    const float* escale = nullptr, const float* eshift = nullptr, int eact = 0 /*inference (mode 0): y = act(conv*escale[c] + eshift[c])*/);
+// inference, stride 1, whole image x 64 channels per workgroup: out = act((dw3x3(x) + bias)*escale + eshift), pool[b][c] = sum over the
+// image of out (optional; complete, no atomics).  false = shape not taken
+bool launch_dwconv_eval_img(int dt, const void* x, const void* wp, const float* dwbias, const float* escale, const float* eshift, int act, void* out,
+                            float* pool /*[B][C] or null*/, int B, int H, int W, int C, hipStream_t s);
+void launch_image_pool(int dt, const void* x /*[B][HW][C]*/, float* pool /*[B][C] sums over HW*/, int B, int HW, int C, hipStream_t s);
 void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw /*[C][9] torch layout*/, float* dbias,
                          float* scratch10C /*optional zeroed [10][C]: contiguous atomics + scatter*/, int B, int H, int W,
                          int C, int OH, int OW, int stride, int pt, int pl, hipStream_t s);

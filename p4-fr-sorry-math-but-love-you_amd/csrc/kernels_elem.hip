@@ -1243,6 +1243,132 @@ bool launch_bn_dwconv(int dt, const void* y, const float* sums, int sums_rep, co
   return true;
 }
 
+// Inference form of the same tile: the input is already activated (the expand GEMM's epilogue applied the eval-mode BatchNorm), so the
+// slab goes to LDS as loaded; the epilogue applies the NEXT BatchNorm's eval scale/shift + activation and -- the workgroup holds the
+// whole image for its 64 channels -- leaves the squeeze-and-excite pool sums complete, no atomics:  pool[img][c] = sum_pix out.
+// Replaces dwconv_s1_kernel (eval epilogue) + the pooling half of se_fwd_kernel on the greedy-decode encoder.
+__global__ __launch_bounds__(512, 4) void dw_eval_img_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* dwbias,
+                                                             const float* esc, const float* esh, bf16_t* __restrict__ out, float* pool, int H,
+                                                             int W, int C, int rowpix, int act) {
+  typedef bf16_t T;
+  constexpr int CH = 8, SC = BDW_SC, RUN = BDW_RUN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char bdw_sm[];
+  __shared__ float sred[8][SC * CH];
+  __shared__ __attribute__((aligned(16))) float cf[3][SC * CH];   // scale, shift, depthwise bias
+  __shared__ uint4 wl[9][SC];
+  uint4* tile = reinterpret_cast<uint4*>(bdw_sm);
+  const int tid = threadIdx.x, NT = blockDim.x, G = NT / SC;
+  const int chunk = tid % SC, g = tid / SC;
+  const int img = blockIdx.x, cb = blockIdx.y * SC * CH, c0 = cb + chunk * CH;
+  const int HW = H * W;
+  const long base = (long)img * HW * C + c0;
+  uint4 raw[RUN];
+#pragma unroll
+  for (int k = 0; k < RUN; ++k) raw[k] = ld16(x + base + (long)(g + k * G) * C);
+  for (int i = tid; i < 9 * SC; i += NT) wl[i / SC][i % SC] = ld16(wp + (long)(i / SC) * C + cb + (i % SC) * CH);
+  for (int c = tid; c < SC * CH; c += NT) {
+    cf[0][c] = esc ? esc[cb + c] : 1.f; cf[1][c] = esh ? esh[cb + c] : 0.f; cf[2][c] = dwbias ? dwbias[cb + c] : 0.f;
+  }
+  bdw_zero_halo(tile, H, W, rowpix, tid, NT);
+#pragma unroll
+  for (int k = 0; k < RUN; ++k) {
+    const int pix = g + k * G, py = pix / W, px = pix - py * W;
+    tile[((py + 1) * rowpix + px + 1) * SC + chunk] = raw[k];
+  }
+  __syncthreads();
+  const int row = g % H, ox0 = (g / H) * RUN;
+  float acc[RUN][CH];
+  {
+    float bb[CH];
+    lds8(cf[2] + chunk * CH, bb);
+#pragma unroll
+    for (int p = 0; p < RUN; ++p)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[p][j] = bb[j];
+  }
+  bdw_taps<false>(tile, wl, row, ox0, rowpix, chunk, acc);
+  float sc[CH], sh[CH], s1[CH];
+  lds8(cf[0] + chunk * CH, sc); lds8(cf[1] + chunk * CH, sh);
+#pragma unroll
+  for (int j = 0; j < CH; ++j) s1[j] = 0.f;
+#pragma unroll
+  for (int p = 0; p < RUN; ++p) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[p][j] = act_fwd(acc[p][j] * sc[j] + sh[j], esc ? act : 0);
+    const uint4 q = pack<T>(acc[p]);
+    st16(out + base + (long)(row * W + ox0 + p) * C, q);
+    float r[CH];
+    unpack<T>(q, r);   // the pool sums what the consumer reads (rounded), as se_fwd_kernel did
+#pragma unroll
+    for (int j = 0; j < CH; ++j) s1[j] += r[j];
+  }
+  if (!pool) return;
+#pragma unroll
+  for (int o = SC; o < 64; o <<= 1) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) s1[j] += __shfl_xor(s1[j], o, 64);
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane < SC) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) sred[wave][lane * CH + j] = s1[j];
+  }
+  __syncthreads();
+  if (tid < SC * CH) {
+    float sum = 0.f;
+    for (int wv = 0; wv < NT / 64; ++wv) sum += sred[wv][tid];
+    pool[(long)img * C + cb + tid] = sum;
+  }
+}
+// false = shape not taken (the caller launches launch_dwconv with the eval epilogue; the pool stays with the SE kernel)
+bool launch_dwconv_eval_img(int dt, const void* x, const void* wp, const float* dwbias, const float* esc, const float* esh, int act, void* out,
+                            float* pool, int B, int H, int W, int C, hipStream_t s) {
+  const bool off = getenv("SATRN_NO_DW_EVAL_IMG") != nullptr;   // read per call: tests compare the two forms in one process
+  if (off || dt != DT_BF16 || (C % (8 * BDW_SC)) != 0 || (W % BDW_RUN) != 0) return false;
+  const int HW = H * W, NT = (HW / BDW_RUN) * BDW_SC;
+  if (NT > 512 || (NT % 64) != 0) return false;
+  const int rowpix = (W + 2) | 1;
+  const size_t lds = (size_t)(H + 2) * rowpix * BDW_SC * 16;
+  if (lds > 60 * 1024) return false;
+  hipLaunchKernelGGL(dw_eval_img_kernel, dim3(B, C / (8 * BDW_SC)), dim3(NT), lds, s, (const bf16_t*)x, (const bf16_t*)wp, dwbias, esc, esh, (bf16_t*)out,
+                     pool, H, W, C, rowpix, act);
+  return true;
+}
+
+// per-image column sums (the squeeze-and-excite pool) for shapes the image tile does not take: one workgroup per image x 16-byte chunk
+// column block, 256 threads = 8 chunks x 32 pixel lanes
+template <typename T>
+__global__ __launch_bounds__(256) void image_pool_kernel(const T* __restrict__ x, float* pool, int HW, int C) {
+  constexpr int CH = TT<T>::CH;
+  __shared__ float sm[32][8 * CH + 1];
+  const int tid = threadIdx.x, ck = tid & 7, pl = tid >> 3;
+  const int c0 = (blockIdx.y * 8 + ck) * CH, img = blockIdx.x;
+  float a[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) a[j] = 0.f;
+  if (c0 < C)
+    for (int p = pl; p < HW; p += 32) {
+      float v[CH];
+      unpack<T>(ld16(x + ((long)img * HW + p) * C + c0), v);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) a[j] += v[j];
+    }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) sm[pl][ck * CH + j] = a[j];
+  __syncthreads();
+  if (tid < 8 * CH && blockIdx.y * 8 * CH + tid < C) {
+    float sum = 0.f;
+    for (int r = 0; r < 32; ++r) sum += sm[r][tid];
+    pool[(long)img * C + blockIdx.y * 8 * CH + tid] = sum;
+  }
+}
+void launch_image_pool(int dt, const void* x, float* pool, int B, int HW, int C, hipStream_t s) {
+  DISPATCH_T(dt, {
+    constexpr int CH = TT<T>::CH;
+    hipLaunchKernelGGL((image_pool_kernel<T>), dim3(B, (C + 8 * CH - 1) / (8 * CH)), dim3(256), 0, s, (const T*)x, pool, HW, C);
+  });
+}
+
 // The backward twin of bn_dw_img_kernel: data gradient of the stride-1 depthwise 3x3 from an LDS tile of dy (whole image x 64
 // channels per workgroup) AND the BatchNorm-backward column sums of the tensor it differentiates (z = act(bn(y))):
 //   dz = conv^T(dy);  red[0..C) += sum dz*act'(u),  red[C..2C) += sum dz*act'(u)*xhat      (u = y*scale+shift)

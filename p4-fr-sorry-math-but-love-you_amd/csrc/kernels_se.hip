@@ -136,13 +136,14 @@ __global__ __launch_bounds__(1024) void se_mlp_scale_kernel(const bf16_t* __rest
                                                             const float* b1, const bf16_t* __restrict__ W2, const float* b2, float* pooled, float* u1,
                                                             float* s1, bf16_t* gate, bf16_t* __restrict__ y, int HW, int C, int S) {
   constexpr int CH = 8;
-  extern __shared__ float sm[];  // p[C] | h[64] | g[C / SE_G (+pad)]
+  extern __shared__ float sm[];  // p[C] | h[64] | g[C / groups (+pad)]
   float* p = sm;
   float* h = sm + C;
   float* g = h + 64;
   const int b = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int CC = C / CH;
-  const int cs = ((CC + SE_G - 1) / SE_G) * CH;  // channels per group (multiple of 8)
+  const int G = gridDim.y;
+  const int cs = ((CC + G - 1) / G) * CH;  // channels per group (multiple of 8)
   const int cbeg = grp * cs, cend = min(C, cbeg + cs);
   uint4 raw[4][3];
   float bj[4];
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(1024) void se_mlp_scale_kernel(const bf16_t* __rest
   // expand rows of this thread's channel of the group
   uint4 raw2[8];
   {
-    // (an empty trailing group -- C / 8 not a multiple of SE_G -- has cbeg >= C: clamp the row so that the unused load stays inside W2)
+    // (an empty trailing group -- C / 8 not a multiple of the group count -- has cbeg >= C: clamp the row so that the unused load stays inside W2)
     const int c = min(cbeg + tid < cend ? cbeg + tid : cbeg, C - 1);
 #pragma unroll
     for (int u = 0; u < 8; ++u) raw2[u] = ld16(W2 + (long)c * S + (u * CH < S ? u * CH : 0));
@@ -639,9 +640,20 @@ bool launch_se_mlp_scale(int dt, const void* x, const float* poolsum, const void
                          float* pooled, float* u1, float* s1, void* gate, void* y, int B, int HW, int C, int S, hipStream_t s) {
   // a group's channels must fit one thread each (<= 1024) and the reduce matrix 12 chunks per thread (C <= 1536)
   if (dt != DT_BF16 || S > 64 || (S % 8) != 0 || C > 1536 || (C % 8) != 0) return false;
-  const int cs = (((C / 8) + SE_G - 1) / SE_G) * 8;
+  // 1024-thread workgroups, one per CU: more groups than fit in one round over the chip cost a second round (B = 64 at 8 groups:
+  // 22 us against 13 at B = 32) -- halve the group count instead while a group's channels still fit one thread each
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  int G = SE_G;
+  if (const char* e = getenv("SATRN_SE_GROUPS")) G = atoi(e) > 0 ? atoi(e) : G;   // A/B (tools)
+  else while (G > 2 && (long)B * G > cus) G >>= 1;
+  const int cs = (((C / 8) + G - 1) / G) * 8;
+  if (cs > 1024) return false;
   size_t sh = (size_t)(C + 64 + cs) * sizeof(float);
-  hipLaunchKernelGGL(se_mlp_scale_kernel, dim3(B, SE_G), dim3(1024), sh, s, (const bf16_t*)x, poolsum, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2,
+  hipLaunchKernelGGL(se_mlp_scale_kernel, dim3(B, G), dim3(1024), sh, s, (const bf16_t*)x, poolsum, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2,
                      pooled, u1, s1, (bf16_t*)gate, (bf16_t*)y, HW, C, S);
   return true;
 }

@@ -211,6 +211,17 @@ int satrn_dwconv3x3_fwd(int dt, const void* x, const void* wp, const float* bias
   launch_dwconv(dt, 0, x, wp, bias, y, B, H, W, C, OH, OW, stride, pt, pl, 0, nullptr, S(st));
   return done("dwconv3x3_fwd");
 }
+int satrn_dwconv3x3_bn_eval_act_pool_fwd(int dt, const void* x, const void* wp, const float* bias, const float* escale, const float* eshift, int act,
+                                         void* y, float* pool, int B, int H, int W, int C, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  if (!escale || !eshift) return fail(-1, "dwconv3x3_bn_eval_act_pool_fwd: escale / eshift are required");
+  if (!launch_dwconv_eval_img(dt, x, wp, bias, escale, eshift, act, y, pool, B, H, W, C, S(st))) {
+    launch_dwconv(dt, 0, x, wp, bias, y, B, H, W, C, H, W, 1, 1, 1, 0, nullptr, S(st), escale, eshift, act);
+    if (pool) launch_image_pool(dt, y, pool, B, H * W, C, S(st));
+  }
+  return done("dwconv3x3_bn_eval_act_pool_fwd");
+}
 int satrn_dwconv3x3_bwd_data(int dt, const void* dy, const void* wp, void* dx, int B, int H, int W, int C, int OH, int OW,
                              int stride, int pt, int pl, int accumulate, void* st) {
   CHK_DT(dt);

@@ -574,7 +574,6 @@ class _SATRNBase(nn.Module):
         self.last_teacher_forced = bool(teacher_forced)
         if not teacher_forced:
             phase = int(phase) | 64
-            use_graph = False
         if bn_eval:
             phase = int(phase) | 32
             use_graph = False

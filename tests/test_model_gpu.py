@@ -516,3 +516,24 @@ def test_fused_chain_kernels_equal_their_plain_forms(golden_dir, monkeypatch):
     print(f"[plain vs plain] logits rel err {nl:.3e}, gradient rel-L2 {ng:.3e}   [fused vs plain] {fl:.3e}, {fg:.3e}")
     assert fl < 2.0 * nl + 5e-3
     assert fg < 2.0 * ng + 5e-2
+
+
+def test_eval_encoder_image_tile_depthwise_equals_generic(golden_dir, monkeypatch):
+    """Inference encoder at the benchmark's image size: the depthwise + eval-BatchNorm + SiLU + SE-pool image-tile kernel followed by
+    the SE MLP + scale kernel (round 3) against the generic depthwise kernel + pool/MLP + scale launches it replaces.  The depthwise
+    outputs are bit-identical; the pool is summed in another order, so the gate -- and what follows -- may move in the last bf16
+    bit."""
+    _, meta, cfg = load_case(golden_dir, "eff_c2_b2")
+    H, W = 128, 384
+    model, _ = build(cfg, H, W, "bf16", int(meta["wseed"]))
+    model.eval()
+    img, _ = O.det_inputs(4, cfg["rgb"], H, W, 8, seed=5, pad_tail=0)
+    imgd = img.cuda()
+    monkeypatch.setenv("SATRN_NO_DW_EVAL_IMG", "1")
+    a = model.encode(imgd).float().clone()
+    monkeypatch.delenv("SATRN_NO_DW_EVAL_IMG")
+    b = model.encode(imgd).float().clone()
+    err = relerr(b, a)
+    print(f"[eval encoder, image-tile depthwise vs generic] rel err {err:.3e}")
+    assert torch.isfinite(b).all()
+    assert err < 3e-2

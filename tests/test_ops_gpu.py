@@ -562,6 +562,48 @@ def test_batchnorm_act_dwconv_fused(lib, dt, B, H, W, C, bias, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,bias,pool", [(3, 8, 24, 128, False, True), (4, 4, 12, 192, True, True), (2, 8, 24, 960, False, True),
+                                               (5, 2, 12, 64, True, False), (2, 6, 10, 64, True, True), (2, 16, 48, 96, False, True)])
+def test_dwconv_bn_eval_act_pool(lib, dt, B, H, W, C, bias, pool, monkeypatch):
+    """inference depthwise seam: stride-1 depthwise 3x3 (+bias) + eval-mode BatchNorm + SiLU + the squeeze-and-excite pool sums in one
+    launch on the small maps, against torch and against the generic kernel + pooling pass (other shapes and f32 take that route)."""
+    x = q(F.silu(rnd(B, C, H, W, seed=1) * 2), dt)
+    w, b = 1 + rnd(C, seed=3, scale=0.2), rnd(C, seed=4, scale=0.1)
+    rm, rv = rnd(C, seed=5, scale=0.1), 1 + rnd(C, seed=6, scale=0.3).abs()
+    dw = q(rnd(C, 1, 3, 3, seed=7, scale=0.3), dt)
+    db = rnd(C, seed=8, scale=0.1) if bias else None
+    eps = 1e-3
+    ref = F.silu(F.batch_norm(F.conv2d(x, dw, db, 1, 1, 1, C), rm, rv, w, b, False, 0.1, eps))
+    esc = w / torch.sqrt(rv + eps)
+    esh = b - rm * esc
+    wp = torch.empty(9, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_pack_dwconv3x3(dti(dt), P(dev(dw)), P(wp), C, st()))
+    xd = dev(nhwc(x), dt)
+
+    def run(img_kernel):
+        if img_kernel:
+            monkeypatch.delenv("SATRN_NO_DW_EVAL_IMG", raising=False)
+        else:
+            monkeypatch.setenv("SATRN_NO_DW_EVAL_IMG", "1")
+        y = torch.empty(B, H, W, C, dtype=tdt(dt), device="cuda")
+        ps = torch.full((B, C), float("nan"), device="cuda")
+        ok(lib, lib.satrn_dwconv3x3_bn_eval_act_pool_fwd(dti(dt), P(xd), P(wp), P(dev(db)) if bias else None, P(dev(esc)), P(dev(esh)), 2, P(y),
+                                                         P(ps) if pool else None, B, H, W, C, st()))
+        torch.cuda.synchronize()
+        return y, ps
+
+    y, ps = run(True)
+    close(nchw(y.float()), ref, dt, "dw eval y", f32_tol=5e-4)
+    if pool:
+        # the pool sums the ROUNDED outputs (what the SE kernel used to read back)
+        close(ps, y.float().sum((1, 2)).cpu(), "f32", "dw eval pool", f32_tol=1e-4)
+    y2, ps2 = run(False)
+    assert (y == y2).all(), "image-tile and generic depthwise kernels differ"
+    if pool:
+        close(ps, ps2.cpu(), "f32", "dw eval pool vs pooling pass", f32_tol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,H,W,C,acc", [(3, 8, 24, 128, 0), (4, 4, 12, 192, 1), (2, 8, 24, 960, 0), (5, 2, 12, 64, 0), (2, 6, 10, 64, 1)])
 def test_dwconv_bwd_data_with_batchnorm_sums(lib, dt, B, H, W, C, acc, monkeypatch):
     """backward of the BatchNorm + SiLU + depthwise seam: depthwise data gradient + the BatchNorm-backward column sums in one launch,
