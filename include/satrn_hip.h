@@ -104,6 +104,16 @@ int satrn_linear_bwd_data_act(int dtype, const void* dy, int ldy, const void* w_
  * strided convs pad bottom/right more). */
 int satrn_conv3x3_fwd(int dtype, const void* x, const void* w_fwd, void* y, int B, int H, int W, int Ci, int Co, int OH,
                       int OW, int stride, int pt, int pl, void* stream);
+/* Inference forms of the backbone's convolutions (model.eval(): timm ConvBnAct / FusedMBConv / MBConv run by
+ * networks/EfficientSATRN.py:74-76,82-87 and the shallow CNN of networks/LiteSATRN.py:51-69): the product with the eval-mode BatchNorm
+ * that follows it (escale = weight/sqrt(running_var+eps), eshift = bias - running_mean*escale), its activation and the block's
+ * residual (res, [rows][Co] in the compute dtype, may be NULL) in the epilogue:  y = act(conv(x)*escale + eshift) + res.
+ * The 1x1 convolutions are the linear form over NHWC rows. */
+int satrn_conv3x3_bn_eval_act_fwd(int dtype, const void* x, const void* w_packed, const float* escale, const float* eshift, int act,
+                                  const void* res, void* y, int B, int H, int W, int Ci, int Co, int OH, int OW, int stride, int pt,
+                                  int pl, void* stream);
+int satrn_linear_bn_eval_act_fwd(int dtype, const void* x, const void* w, const float* escale, const float* eshift, int act,
+                                 const void* res, void* y, int M, int N, int K, void* stream);
 int satrn_conv3x3_bwd_data(int dtype, const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Ci, int Co,
                            int OH, int OW, int stride, int pt, int pl, int accumulate, void* stream);
 /* dw in the torch layout [Co][Ci][3][3], fp32 atomics (zero first) */

@@ -22,8 +22,8 @@
 //     segments, 16 bytes per lane (the 4-wave kernel stores one 2-byte element per lane; 8-byte stores straight from the accumulator
 //     layout were measured too: 10-25 % slower than the LDS hop).
 // Epilogue: bias (the initial accumulator), activation, BatchNorm statistics / BatchNorm-backward sums (STATS), and by epilogue kind EK
-// a second tensor: act'(u) stored beside the activation, a stored factor multiplied in, accumulate.  Dropout, f32 output and the
-// inference scale / shift stay with gemm_kernel; gemm_big_launch() returns false for those.
+// a second tensor: act'(u) stored beside the activation, a stored factor multiplied in, accumulate.  Dropout and f32 output
+// stay with gemm_kernel; gemm_big_launch() returns false for those.
 // Measured limits: the main loop runs at the LDS fill rate, 63 GB/s per CU alone and 48 GB/s per CU with all 256 CUs
 // busy (tools/gemm_big_grid.sh), i.e. ~50 % of the MFMA rate of its tile; LDS reads (each operand row is read by two consumer waves)
 // plus DMA writes are 120 KB per k-step against 128 B/clk.
@@ -41,6 +41,7 @@ struct BigP {
   const bf16_t* A; const bf16_t* W; bf16_t* C;
   const float* bias;
   bf16_t* pre_out; const bf16_t* bact_u;
+  const float* escale; const float* eshift; const bf16_t* eres;   // EK 4 (inference)
   int M, N, K, lda, ldc;
   int act, bact, beta, pre_grad;
   float bact_scale;
@@ -113,6 +114,7 @@ DEVI i32x4 make_rsrc(const void* base, unsigned bytes) {
 //   EK 0  no second tensor (activation by run-time switch, GELU through gelu_fast)
 //   EK 1  all-purpose: pre_out / bact_u / beta in any combination
 //   EK 2  GELU + its derivative stored beside it (pre_out with pre_grad; networks/SWIN.py:24-47 fc1)
+//   EK 4  inference: per-column scale / shift (eval-mode BatchNorm), activation, residual -- the encoder of the greedy decode
 //   EK 3  times a stored factor: bact_u with ACT_DFACTOR (the stored derivative) or ACT_RELU (sign of the stored output, x bact_scale);
 //         the factor loads run four row groups ahead of their use (one dependent round trip per group otherwise)
 // CONV (the shifted-GEMM convolution mode, BigP::conv) is a template parameter as well: as a run-time branch in the loaders it cost the
@@ -255,7 +257,8 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
   // dropped by the range check (no divergent branch around the stores)
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (int)p.c_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)p.pre_out, 0, p.pre_out ? (int)p.c_bytes : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)p.bact_u, 0, p.bact_u ? (int)p.c_bytes : 0, 0x00020000);
+  const bf16_t* second = EK == 4 ? p.eres : p.bact_u;   // the tensor read beside the output: stored factor, or the inference residual
+  const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)second, 0, second ? (int)p.c_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)p.bnb_y, 0, STATS == 2 ? (int)p.y_bytes : 0, 0x00020000);
 
   const unsigned fsw0 = (unsigned)(((0 * 4 + fq) ^ ((fr >> 1) & 7)) * 16), fsw1 = (unsigned)(((1 * 4 + fq) ^ ((fr >> 1) & 7)) * 16);
@@ -332,10 +335,18 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
       return (row < p.M && col < p.N) ? (unsigned)(((long)row * p.ldc + col) * 2) : 0xfffffff0u;
     };
     constexpr int UQ = 4;
-    u32x4_t uq[EK == 3 ? UQ : 1];
-    if constexpr (EK == 3) {
+    u32x4_t uq[(EK == 3 || EK == 4) ? UQ : 1];
+    if constexpr (EK == 3 || EK == 4) {   // (EK 4 without a residual: the resource has no extent, the loads return zeros)
 #pragma unroll
       for (int n = 0; n < UQ; ++n) uq[n] = __builtin_amdgcn_raw_buffer_load_b128(rU, (int)out_off(n), 0, 0);
+    }
+    float esc8[8], esh8[8];
+    if constexpr (EK == 4) {
+      const int cc = col + 7 < p.N ? col : 0;   // (columns past N are never stored)
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(p.escale + cc), t1 = *reinterpret_cast<const f32x4*>(p.escale + cc + 4);
+      const f32x4 t2 = *reinterpret_cast<const f32x4*>(p.eshift + cc), t3 = *reinterpret_cast<const f32x4*>(p.eshift + cc + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { esc8[e] = t0[e]; esc8[4 + e] = t1[e]; esh8[e] = t2[e]; esh8[4 + e] = t3[e]; }
     }
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
@@ -378,6 +389,24 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void gemm_big_kernel(BigP p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = u[e] > 0.f ? f[e] * sc : 0.f;
           }
+          v = pack<bf16_t>(f);
+        } else if constexpr (EK == 4) {
+          // inference: eval-mode BatchNorm as per-column scale / shift, activation, residual (gemm_kernel's escale / eshift / eres)
+          float f[8], u[8];
+          unpack<bf16_t>(v, f);
+          unpack<bf16_t>(from_u32x4(uq[(2 * i + h) % UQ]), u);
+          if (2 * i + h + UQ < 2 * MTW) uq[(2 * i + h) % UQ] = __builtin_amdgcn_raw_buffer_load_b128(rU, (int)out_off(2 * i + h + UQ), 0, 0);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = __builtin_fmaf(f[e], esc8[e], esh8[e]);
+          if (p.act == ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+          } else if (p.act != ACT_NONE) {   // SiLU / sigmoid
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float sg = sigmoidf_(f[e]); f[e] = p.act == ACT_SILU ? f[e] * sg : sg; }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += u[e];
           v = pack<bf16_t>(f);
         } else if (HAS_AUX || STATS || p.act != ACT_NONE) {
           float f[8];
@@ -787,6 +816,7 @@ static void big_launch_t(const BigP& p, int grid, hipStream_t s) {
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_big_kernel<MTW, HB, EKIND, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
     hipLaunchKernelGGL((gemm_big_kernel<MTW, HB, EKIND, ST>), dim3(grid), dim3(BIG_THREADS), sh, s, p); } while (0)
   // the statistics forms keep 16 (sums) / 48 (+ BatchNorm coefficients) more registers: tiles of at most 192 / 128 rows
+  const bool ek4 = p.escale != nullptr;   // inference epilogue: nothing else with it (gemm_big_go filters)
   if (p.conv && p.narrow) {
     // 64-column tiles, BM = 64 MT rows (MT = 2 / 4 only: the fragment ping-pong needs an even number of row groups per wave)
     constexpr int MTN = MT == 3 ? 2 : MT;
@@ -795,6 +825,7 @@ static void big_launch_t(const BigP& p, int grid, hipStream_t s) {
     static bool attr = false; \
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_big_kernel<MTN, false, EKIND, ST, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shn); attr = true; } \
     hipLaunchKernelGGL((gemm_big_kernel<MTN, false, EKIND, ST, true, 1>), dim3(grid), dim3(BIG_THREADS), shn, s, p); } while (0)
+    if (ek4) { BIG_GON(4, 0); return; }
     if (p.stats && p.bnb_y) { if (aux) BIG_GON(1, 2); else BIG_GON(0, 2); return; }
     if (p.stats) { if (aux) BIG_GON(1, 1); else BIG_GON(0, 1); return; }
     if (aux) BIG_GON(1, 0); else BIG_GON(0, 0);
@@ -807,6 +838,7 @@ static void big_launch_t(const BigP& p, int grid, hipStream_t s) {
     static bool attr = false; \
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_big_kernel<MTW, false, EKIND, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; } \
     hipLaunchKernelGGL((gemm_big_kernel<MTW, false, EKIND, ST, true>), dim3(grid), dim3(BIG_THREADS), sh, s, p); } while (0)
+    if constexpr (MT <= 3) { if (ek4) { BIG_GOC(4, 0); return; } }
     if constexpr (MT <= 2) { if (p.stats && p.bnb_y) { if (aux) BIG_GOC(1, 2); else BIG_GOC(0, 2); return; } }
     if constexpr (MT <= 3) {
       if (p.stats && !p.bnb_y) { if (aux) BIG_GOC(1, 1); else BIG_GOC(0, 1); return; }
@@ -820,6 +852,7 @@ static void big_launch_t(const BigP& p, int grid, hipStream_t s) {
   if constexpr (MT <= 3) { if (p.stats && !p.bnb_y) { if (aux) BIG_GO(false, 1, 1); else BIG_GO(false, 0, 1); return; } }
   // (the forms with a second tensor in the epilogue -- pre_out / bact_u / beta -- spill at 256-row tiles: at most 192 rows, as the statistics forms)
   if constexpr (MT <= 3) {
+    if (ek4) { BIG_GO(false, 4, 0); return; }
     if (ek2) { if (p.bias) BIG_GO(true, 2, 0); else BIG_GO(false, 2, 0); return; }
     if (ek3) { if (p.bias) BIG_GO(true, 3, 0); else BIG_GO(false, 3, 0); return; }
     if (aux) { if (p.bias) BIG_GO(true, 1, 0); else BIG_GO(false, 1, 0); return; }
@@ -835,7 +868,7 @@ bool gemm_big_launch(const GemmP& g, hipStream_t s) { return gemm_big_go(g, s, f
 // persistent kernel.  Same epilogue subset as the dense form (BatchNorm statistics / backward sums, accumulate).
 bool gemm_big_conv_launch(int amode, const GemmP& g, hipStream_t s) {
   if (g.KW != 3 || (g.stride != 1 && g.stride != 2) || (g.Ci & 7) || g.ldc != g.N) return false;
-  if (g.bias || g.act || g.pre_out || g.bact_u) return false;
+  if (g.bias || (g.act && !g.escale) || g.pre_out || g.bact_u) return false;
   if ((long)(g.M / (g.OH * g.OW)) * g.OH * g.OW != g.M || g.K != 9 * g.Ci) return false;
   return gemm_big_go(g, s, true, amode == AM_DGRAD ? 1 : 0);
 }
@@ -843,7 +876,9 @@ static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
   const char* mode_env = getenv("SATRN_GEMM_BIG");   // read per call (tests and tools switch it): 0 = off, 2 = take every shape that fits
   const int mode = mode_env ? atoi(mode_env) : 1;
   if (!mode) return false;
-  if (g.escale || g.eres || g.out_f32 || g.drop_p > 0.f) return false;
+  if (g.out_f32 || g.drop_p > 0.f || (g.eres && !g.escale)) return false;
+  // inference epilogue (eval-mode BatchNorm scale / shift + activation + residual): on its own only
+  if (g.escale && (!g.eshift || g.bias || g.stats || g.pre_out || g.bact_u || g.beta || g.bnb_y)) return false;
   if (g.stats && (g.stats_part || g.bias || g.stats_rep < 1)) return false;   // deterministic slabs / biased statistics: gemm_kernel
   if (g.bnb_y && !g.stats) return false;
   if ((g.K & 7) || (!conv && (g.lda & 7)) || (g.ldc & 7) || (g.N & 7) || g.M < 1) return false;
@@ -856,11 +891,14 @@ static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
     static const double min_gflop = getenv("SATRN_GEMM_BIG_MIN_GFLOP") ? atof(getenv("SATRN_GEMM_BIG_MIN_GFLOP")) : 2.0;
     const double flops = 2.0 * g.M * g.N * g.K;
     static const int min_n = getenv("SATRN_GEMM_BIG_MIN_N") ? atoi(getenv("SATRN_GEMM_BIG_MIN_N")) : 128;
-    if (mode != 2 && (flops < min_gflop * 1e9 || g.N < (conv ? 32 : min_n) || g.M < 2048)) return false;
+    // (inference products -- escale set -- run with no weight-gradient stream beside them: the smaller ones gain as well, 13 -> 7 us at 1.6 GFLOP)
+    const double mg = g.escale ? std::min(min_gflop, 1.0) : min_gflop;
+    if (mode != 2 && (flops < mg * 1e9 || g.N < (conv ? 32 : min_n) || g.M < 2048)) return false;
   }
   BigP p;
   p.A = (const bf16_t*)g.A; p.W = (const bf16_t*)g.Bw; p.C = (bf16_t*)g.C; p.bias = g.bias;
   p.pre_out = (bf16_t*)g.pre_out; p.bact_u = (const bf16_t*)g.bact_u;
+  p.escale = g.escale; p.eshift = g.eshift; p.eres = (const bf16_t*)g.eres;
   p.M = g.M; p.N = g.N; p.K = g.K; p.lda = g.lda; p.ldc = g.ldc; p.act = g.act; p.bact = g.bact; p.beta = g.beta; p.bact_scale = g.bact_scale; p.pre_grad = g.pre_grad;
   p.a_bytes = conv ? (unsigned)((size_t)(g.M / (g.OH * g.OW)) * g.H * g.W * g.Ci * 2) : (unsigned)(((size_t)(g.M - 1) * g.lda + g.K) * 2);
   p.cOH = g.OH; p.cOW = g.OW; p.cstride = g.stride; p.cpt = g.pt; p.cpl = g.pl;
@@ -877,7 +915,7 @@ static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
   const int force_mt = getenv("SATRN_GEMM_BIG_MT") ? atoi(getenv("SATRN_GEMM_BIG_MT")) : 0;
   int best_mt = 3;
   double best_cost = 1e30;
-  const bool aux_form = g.pre_out || g.bact_u || g.beta;
+  const bool aux_form = g.pre_out || g.bact_u || g.beta || g.escale;
   const int mt_max = p.narrow ? 4 : (g.bnb_y ? 2 : ((g.stats || aux_form) ? 3 : 4));
   for (int mt = mt_max; mt >= 2; --mt) {
     if (p.narrow && mt == 3) continue;   // (64-column tiles: 128 or 256 rows)

@@ -166,6 +166,31 @@ int satrn_conv3x3_fwd(int dt, const void* x, const void* w, void* y, int B, int 
   launch_gemm(dt, AM_CONV, p, S(st));
   return done("conv3x3_fwd");
 }
+int satrn_conv3x3_bn_eval_act_fwd(int dt, const void* x, const void* w, const float* escale, const float* eshift, int act, const void* res, void* y,
+                                  int B, int H, int W, int Ci, int Co, int OH, int OW, int stride, int pt, int pl, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, Ci, "Ci") || chk_c(dt, Co, "Co")) return -1;
+  if (!escale || !eshift) return fail(-1, "conv3x3_bn_eval_act_fwd: escale / eshift are required");
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = x; p.Bw = w; p.C = y; p.M = B * OH * OW; p.N = Co; p.K = 9 * Ci; p.ldc = Co;
+  p.escale = escale; p.eshift = eshift; p.act = act; p.eres = res;
+  conv_geo(p, H, W, Ci, OH, OW, stride, pt, pl);
+  launch_gemm(dt, AM_CONV, p, S(st));
+  return done("conv3x3_bn_eval_act_fwd");
+}
+int satrn_linear_bn_eval_act_fwd(int dt, const void* x, const void* w, const float* escale, const float* eshift, int act, const void* res, void* y,
+                                 int M, int N, int K, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, K, "K") || chk_c(dt, N, "N")) return -1;
+  if (!escale || !eshift) return fail(-1, "linear_bn_eval_act_fwd: escale / eshift are required");
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = x; p.Bw = w; p.C = y; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldc = N;
+  p.escale = escale; p.eshift = eshift; p.act = act; p.eres = res;
+  launch_gemm(dt, AM_DENSE, p, S(st));
+  return done("linear_bn_eval_act_fwd");
+}
 int satrn_conv3x3_bwd_data(int dt, const void* dy, const void* wb, void* dx, int B, int H, int W, int Ci, int Co, int OH,
                            int OW, int stride, int pt, int pl, int accumulate, void* st) {
   CHK_DT(dt);

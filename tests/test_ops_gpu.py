@@ -423,6 +423,60 @@ def test_conv3x3_as_shifted_gemm_on_the_persistent_kernel(lib, big_gemm_mode, B,
     close(outs["persistent"][1], outs["other"][1], dt, "persistent vs tile kernel data gradient", bf16_tol=1e-2)
 
 
+@pytest.mark.parametrize("kind,shape,act,res", [("linear", (3000, 960, 160), 0, True), ("linear", (2100, 160, 960), 2, False), ("linear", (777, 256, 1536), 2, True),
+                                                ("conv", (2, 16, 24, 48, 192, 1), 2, False), ("conv", (2, 16, 24, 192, 48, 1), 0, True),
+                                                ("conv", (2, 15, 21, 24, 96, 2), 2, False), ("conv", (3, 9, 7, 128, 64, 1), 2, True)])
+def test_inference_epilogue_on_the_persistent_kernel(lib, big_gemm_mode, kind, shape, act, res):
+    """inference products (1x1 / 3x3 convolutions of the backbone under model.eval()): eval-mode BatchNorm scale / shift + SiLU + residual in
+    the epilogue of the persistent kernel (epilogue kind 4, 128- and 64-column tiles) against torch and against the tile kernels'
+    inference epilogue (they differ by one rounding: the persistent kernel's accumulator passes through bf16 before the scale)."""
+    import os
+    dt = "bf16"
+    if kind == "linear":
+        M, N, K = shape
+        x, w = q(rnd(M, K, seed=1), dt), q(rnd(N, K, seed=2, scale=1 / math.sqrt(K)), dt)
+        raw = x @ w.t()
+        wd, xd = dev(w, dt), dev(x, dt)
+    else:
+        B, H, W, Ci, Co, s_ = shape
+        N = Co
+        x, w = q(rnd(B, Ci, H, W, seed=1), dt), q(rnd(Co, Ci, 3, 3, seed=2, scale=1 / math.sqrt(9 * Ci)), dt)
+        OH, OW, pt, pl, pads = same_geo(H, W, s_)
+        raw = F.conv2d(F.pad(x, pads), w, None, s_, 0).permute(0, 2, 3, 1).reshape(-1, Co)
+        M = raw.shape[0]
+        wd = torch.empty(Co, 9, Ci, dtype=tdt(dt), device="cuda")
+        bwd = torch.empty(Ci, 9, Co, dtype=tdt(dt), device="cuda")
+        ok(lib, lib.satrn_pack_conv3x3(dti(dt), P(dev(w)), P(wd), P(bwd), Co, Ci, st()))
+        xd = dev(nhwc(x), dt)
+    esc, esh = 1 + rnd(N, seed=3, scale=0.3), rnd(N, seed=4, scale=0.2)
+    r = q(rnd(M, N, seed=5), dt) if res else None
+    ref = raw * esc + esh
+    if act == 2:
+        ref = F.silu(ref)
+    if res:
+        ref = ref + r
+    rd = dev(r, dt) if res else None
+    outs = {}
+    try:
+        for name, mode, cb in (("persistent", 2, "1"), ("other", 0, "0")):
+            big_gemm_mode(mode)
+            os.environ["SATRN_CONV_BIG"] = cb
+            os.environ["SATRN_CONV_BIG_MIN_N"] = "16"
+            y = torch.empty(M, N, dtype=tdt(dt), device="cuda")
+            if kind == "linear":
+                ok(lib, lib.satrn_linear_bn_eval_act_fwd(dti(dt), P(xd), P(wd), P(dev(esc)), P(dev(esh)), act, P(rd) if res else None, P(y), M, N, K, st()))
+            else:
+                ok(lib, lib.satrn_conv3x3_bn_eval_act_fwd(dti(dt), P(xd), P(wd), P(dev(esc)), P(dev(esh)), act, P(rd) if res else None, P(y), B, H, W, Ci, Co,
+                                                          OH, OW, s_, pt, pl, st()))
+            torch.cuda.synchronize()
+            outs[name] = y.float().cpu()
+            close(y, ref, dt, f"inference epilogue {kind} ({name})")
+    finally:
+        os.environ.pop("SATRN_CONV_BIG", None)
+        os.environ.pop("SATRN_CONV_BIG_MIN_N", None)
+    close(outs["persistent"], outs["other"], dt, "persistent vs tile kernel, inference epilogue", bf16_tol=1e-2)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,Cin,H,W,Co,s,pad", [(2, 1, 32, 48, 24, 2, 0), (2, 1, 16, 24, 16, 1, 1), (2, 3, 17, 23, 128, 1, 1)])
 def test_stem_conv(lib, dt, B, Cin, H, W, Co, s, pad):
