@@ -550,8 +550,8 @@ class _SATRNBase(nn.Module):
                    grad_scale=1.0, use_graph=False, phase=3, bn_eval=False, teacher_forcing_ratio=1.0, teacher_forced=None):
         """forward + CE + backward + clip_grad_norm_ + AdamW + weight re-pack in ONE library call
         (train_modules/train_single_opt.py:80-98 with teacher forcing).  Default: eager launches on two HIP streams (weight
-        gradients run beside the data-gradient chain; measured 12.5 ms vs 15.2 ms for the single-chain hipGraph replay,
-        which use_graph=True selects).  phase: 1 = forward/backward only,
+        gradients run beside the data-gradient chain; measured 10.4 ms vs 13.1 ms for the single-chain hipGraph replay,
+        which use_graph=True selects; the autoregressive branch replays in 112 ms vs 88 ms eager).  phase: 1 = forward/backward only,
         2 = clip + AdamW only (data-parallel callers all-reduce the flat gradient in between), 3 = both; 16 + k = backward
         segment k of phase 1 (k = 0..3 in order; overlapped gradient exchange, see dp.dp_train_step).
         lr = (encoder_lr, decoder_lr) and/or weight_decay = (encoder_wd, decoder_wd) select the reference's DUAL-optimizer

@@ -410,6 +410,13 @@ def test_fused_train_step_takes_the_autoregressive_branch():
     model.train_step(imgd, expd, 0.0, phase=16 + 0 + 4 * 2, teacher_forced=False)
     model.train_step(imgd, expd, 0.0, phase=16 + 3)
     assert (model.flat_grad() - g_ref).abs().max().item() <= 1e-6 * scale
+    # hipGraph replay of the branch (captured by the second call of a shape / phase; its own graph beside the teacher-forced one)
+    for _ in range(3):
+        model.train_step(imgd, expd, 0.0, phase=1, teacher_forced=False, use_graph=True)
+    assert (model.flat_grad() - g_ref).abs().max().item() <= 1e-6 * scale
+    model.train_step(imgd, expd, 0.0, phase=1, teacher_forced=True, use_graph=True)
+    model.train_step(imgd, expd, 0.0, phase=1, teacher_forced=True, use_graph=True)
+    assert (model.flat_grad() - g_ref).abs().max().item() > 1e-3 * scale
     # the coin: one flip per step, from the shared source
     model.set_coin(dp.SharedCoin(seed=11))
     twin = dp.SharedCoin(seed=11)
