@@ -1029,7 +1029,9 @@ def test_dropout_statistics(lib):
                                             # beyond the wide kernels' staging (C > 1536: 6 x 32 W2 rows per channel group): must take the per-image form
                                             (2, 48, 1792, 64, True), (2, 48, 2048, 64, True),
                                             # C / 8 not a multiple of the 8 channel groups: the trailing group is empty / partial
-                                            (2, 96, 160, 8, True), (2, 48, 1288, 56, True)])
+                                            (2, 96, 160, 8, True), (2, 48, 1288, 56, True),
+                                            # batches whose B x 8 groups exceed one round over the chip: 4 and 2 channel groups (inference at B = 64)
+                                            (40, 48, 960, 40, True), (40, 24, 1288, 56, True), (136, 12, 1536, 64, True), (136, 6, 160, 8, True)])
 def test_squeeze_excite(lib, dt, B, HW, C, S, wide):
     """timm SqueezeExcite (networks/EfficientSATRN.py:74,84): forward and the data path of the backward, in the per-image form
     and (wide=True) in the forms the training step uses -- MLP + scale from pool sums over B x 8 channel groups, backward as
