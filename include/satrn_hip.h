@@ -149,6 +149,19 @@ int satrn_dwconv3x3_bwd_weight(int dtype, const void* x, const void* dy, float* 
 int satrn_batchnorm_act_fwd(int dtype, const void* y, const float* weight, const float* bias, float* running_mean,
                             float* running_var, int64_t* num_batches_tracked, float eps, int train, int act,
                             const void* res, void* z, long M, int C, float* scratch, void* stream);
+/* Training-mode BatchNorm2d + activation + the squeeze-and-excite block behind it (timm MBConv: bn2 -> SiLU -> SqueezeExcite, run by
+ * networks/EfficientSATRN.py:74-76): z = act(bn(y)), pooled = mean over the image, u1 = W1 pooled + b1, s1 = silu(u1),
+ * gate = sigmoid(W2 s1 + b2), out = z * gate.  One launch on the small maps (bf16, C % 64 == 0, C <= 1536, S <= 64, S % 8 == 0,
+ * B * C / 64 workgroups within three per compute unit): the workgroups of an image hand their shares of the hidden layer to each
+ * other through `mailbox` -- mailbox_images * 1600 8-byte words that are ZERO before the first call and that nothing else writes
+ * (a launch number tags every word, so the mailbox is never cleared between calls).  Other shapes / dtypes: the separate kernels.
+ * keep_z == 0: z need not hold the activated tensor afterwards (the engine's backward recomputes it from y); z must be a valid
+ * [B][HW][C] buffer either way.  scratch as in satrn_batchnorm_act_fwd (6*C floats, first 2*C ZERO on entry).  A hand-off that
+ * does not complete within 2 s sets bit 2 of the device error word (satrn_device_error) instead of hanging. */
+int satrn_batchnorm_act_se_fwd(int dtype, const void* y, const float* weight, const float* bias, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, float eps, int act, void* z, int keep_z, const void* W1, const float* b1,
+                               const void* W2, const float* b2, float* pooled, float* u1, float* s1, void* gate, void* out, int B, int HW,
+                               int C, int S, float* scratch, unsigned long long* mailbox, int mailbox_images, void* stream);
 /* Training-mode BatchNorm2d + activation of y[B][H][W][C] -> z, followed by the stride-1 "same" depthwise 3x3 (+bias) of z -> out,
  * in one launch where the shape allows (the expand-BN-SiLU-depthwise seam of the timm MBConv block in the 8x24 / 4x12 stages;
  * networks/EfficientSATRN.py:74-76 runs those blocks).  Results equal satrn_batchnorm_act_fwd + satrn_dwconv3x3_fwd bit for bit
@@ -435,7 +448,7 @@ int satrn_image_preprocess(const void* descs, int B, int C, int H, int W, float*
  * must stay allocated until that call returns.  satrn_model_rng_state reads (set == 0) or writes the RNG word. */
 int satrn_model_bind_optimizer(satrn_model* m, float* exp_avg, float* exp_avg_sq);
 /* Device error word (read and cleared; synchronises `stream`): bit 0 = a decoder-input token id outside the embedding table,
- * bit 1 = a loss target outside [0, V) other than ignore_index.  nn.Embedding / nn.CrossEntropyLoss raise on such input
+ * bit 1 = a loss target outside [0, V) other than ignore_index, bit 2 = a hand-off of satrn_batchnorm_act_se_fwd timed out.  nn.Embedding / nn.CrossEntropyLoss raise on such input
  * (the reference's loader pads `expected` with -1, data/loader.py:12-16, rewritten to <PAD> at
  * train_modules/train_single_opt.py:78); the kernels skip the element and set the bit instead of reading out of bounds.
  * satrn_model_read_loss checks the word too and fails with -6. */

@@ -498,6 +498,8 @@ Model* model_create(const SatrnConfig& cfg) {
     // partial tiles of one launch of the persistent weight-gradient kernel: at most one 128 x 128 fp32 tile per item, CU-count items (+ slack)
     m->wgpart_floats = (size_t)320 * 128 * 128;
     m->off_wgpart = take(2 * m->wgpart_floats * sizeof(float));
+    // mailbox of launch_bn_pool_se (starts zeroed with the workspace; only that kernel writes it, with a new tag per launch)
+    m->off_sebox = take((size_t)Model::SEBOX_IMAGES * (1536 + 64) * 8);
   }
   m->zero_bytes = 40u << 20;
   m->off_zero = take(m->zero_bytes);
@@ -831,7 +833,14 @@ struct BnHold {
   const void* y = nullptr; const float* sums = nullptr; int rep = 1; BNp* bn = nullptr; float* ss = nullptr; float* mr = nullptr; void* z = nullptr;
   long M = 0; int C = 0, act = 0;
 };
-Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** pool_out = nullptr, BnHold* hold = nullptr) {
+// the BatchNorm in front of a squeeze-and-excite block, held back like BnHold: op_se launches both as one kernel (launch_bn_pool_se) or, where
+// that does not take the shape, this pass (launch_bn_act_pool) followed by its own kernels
+struct SeHold {
+  bool armed = false;
+  const void* y = nullptr; const float* sums = nullptr; int rep = 1; BNp* bn = nullptr; float* ss = nullptr; float* mr = nullptr; void* z = nullptr;
+  float* pool = nullptr; long M = 0; int C = 0, HW = 0, act = 0;
+};
+Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** pool_out = nullptr, BnHold* hold = nullptr, SeHold* sehold = nullptr) {
   const int C = bn->C;
   const long M = y->rows;
   if (y->pend) {
@@ -874,6 +883,11 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** poo
   if (pool_out && e.train && !res && sums && y->B > 0 && bn_act_pool_ok(M, C, y->H * y->W)) {
     // a squeeze-and-excite block follows: its average pool is accumulated here (zeroed [B][C] sums)
     *pool_out = e.zalloc((size_t)y->B * C);
+    if (sehold && !e.dry) {   // op_se launches this pass, fused with its own where the shape allows
+      sehold->armed = true; sehold->y = y->p; sehold->sums = sums; sehold->rep = y->stats ? y->stats_rep : 1; sehold->bn = bn; sehold->ss = ss; sehold->mr = mr;
+      sehold->z = z->p; sehold->pool = *pool_out; sehold->M = M; sehold->C = C; sehold->HW = y->H * y->W; sehold->act = act;
+      e.nflops = 0; e.nbytes = 0;
+    } else
     LCH(e, launch_bn_act_pool(e.dt, y->p, sums, y->stats ? y->stats_rep : 1, bn->w.p, bn->b.p, bn->rm, bn->rv, bn->nbt, bn->eps, 0.1f, ss, mr, z->p,
                               *pool_out, M, C, y->H * y->W, act, e.s));
   } else if (hold && e.train && sums && !res) {
@@ -1605,7 +1619,7 @@ Tensor* encoder_layer(Exec& e, Tensor* x, EncLayer* el) {
 }
 
 // squeeze-and-excite: pool + MLP in one kernel, x*gate in a second; backward = dgate reduction, two SE kernels, dx
-Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr) {
+Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr, SeHold* sh = nullptr) {
   used(x);
   const int B = x->B, HW = x->H * x->W, C = x->C, S = eb->se;
   float* pooled = (float*)e.alloc((size_t)B * C * 4);
@@ -1614,7 +1628,28 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr) {
   Tensor* gate = e.newt(B, C);
   Tensor* y = e.newt(x->rows, C, B, x->H, x->W);
   bool fused = false;
-  if (poolsum) {  // the pool was accumulated by the BatchNorm pass in front: MLP + x*gate in one launch
+  if (sh && sh->armed) {
+    // BatchNorm + activation + pool + MLP + x*gate in ONE launch (the image's workgroups hand the pool and the hidden layer to each other).
+    // The activated tensor x is stored only if something will read it: the backward recomputes it from the BatchNorm's input whenever
+    // the wide squeeze-and-excite backward with the folded BatchNorm sums applies (the closure below decides the same way).
+    BNp* bn = sh->bn;
+    const bool bwd_recomputes = g_fuse_bnb && e.dt == DT_BF16 && !g_det.on && S <= 64 && (S % 8) == 0 && (C % 8) == 0 && ((C / 8 + 7) / 8) <= 24 &&
+                                getenv("SATRN_SE_NO_WIDE_BWD") == nullptr && getenv("SATRN_SE_NO_BN_SUMS") == nullptr;
+    const bool need_x = e.rec && !(e.train && bwd_recomputes);
+    // (not under hipGraph capture: the per-launch mailbox tag would be replayed)
+    unsigned long long* box = e.serial ? nullptr : (unsigned long long*)(e.m->ws + e.m->off_sebox);
+    WORK(e, 4.0 * (double)B * C * S, (double)x->rows * C * e.esz() * (need_x ? 3 : 2) + (double)C * S * e.esz() * 2);
+    LCH(e, fused = launch_bn_pool_se(e.dt, sh->y, sh->sums, sh->rep, bn->w.p, bn->b.p, bn->rm, bn->rv, bn->nbt, bn->eps, 0.1f, sh->ss, sh->mr,
+                                     need_x ? sh->z : nullptr, eb->se_r.fwd, eb->se_rb.p, eb->se_e.fwd, eb->se_eb.p, pooled, u1, s1, gate->p, y->p, box,
+                                     Model::SEBOX_IMAGES, B, HW, C, S, sh->act, e.s));
+    if (!fused) {
+      WORK(e, 0, (double)sh->M * sh->C * e.esz() * 2);
+      LCH(e, launch_bn_act_pool(e.dt, sh->y, sh->sums, sh->rep, bn->w.p, bn->b.p, bn->rm, bn->rv, bn->nbt, bn->eps, 0.1f, sh->ss, sh->mr, sh->z, sh->pool,
+                                sh->M, sh->C, sh->HW, sh->act, e.s));
+    }
+    sh->armed = false;
+  }
+  if (!fused && poolsum) {  // the pool was accumulated by the BatchNorm pass in front: MLP + x*gate in one launch
     WORK(e, 4.0 * (double)B * C * S, (double)x->rows * C * e.esz() * 2 + (double)C * S * e.esz() * 2);
     LCH(e, fused = launch_se_mlp_scale(e.dt, x->p, poolsum, eb->se_r.fwd, eb->se_rb.p, eb->se_e.fwd, eb->se_eb.p, pooled, u1, s1, gate->p, y->p, B, HW, C, S, e.s));
     if (e.dry) fused = e.dt == DT_BF16 && S <= 64 && (S % 8) == 0 && C <= 1536 && (C % 8) == 0;
@@ -1700,8 +1735,9 @@ Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
   Tensor* z = op_bn_act(e, y, &eb->bn1, ACT_SILU, nullptr, nullptr, &hold);
   Tensor* y2 = op_dwconv(e, z, &eb->dw, nullptr, eb->stride, g.OH, g.OW, g.pt, g.pl, true, &hold);
   float* poolsum = nullptr;
-  Tensor* z2 = op_bn_act(e, y2, &eb->bn2, ACT_SILU, nullptr, &poolsum);
-  Tensor* z3 = op_se(e, z2, eb, poolsum);
+  SeHold sehold;
+  Tensor* z2 = op_bn_act(e, y2, &eb->bn2, ACT_SILU, nullptr, &poolsum, nullptr, &sehold);
+  Tensor* z3 = op_se(e, z2, eb, poolsum, &sehold);
   Tensor* y3 = op_gemm(e, z3, &eb->c1, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   y3->B = B; y3->H = g.OH; y3->W = g.OW;
   return op_bn_act(e, y3, &eb->bn3, ACT_NONE, skip);
@@ -2267,6 +2303,7 @@ int model_read_loss(Model* m, float* out4, hipStream_t s) {
   (void)hipMemcpyAsync(out4 + 3, scal(m) + SC_GNORM, 4, hipMemcpyDeviceToHost, s);
   (void)hipStreamSynchronize(s);
   if (unsigned ef = device_error_read_clear(s)) {
+    if (ef & 4u) { m->err = "a hand-off inside the fused BatchNorm + squeeze-and-excite kernel timed out (results of that step are invalid; SATRN_NO_FUSED_POOL_SE=1 selects the separate kernels)"; return -7; }
     m->err = std::string("token ids out of range reached the model (") + ((ef & 1) ? "decoder input outside the embedding table; " : "") +
              ((ef & 2) ? "loss target outside the vocabulary; " : "") + "rewrite the loader's -1 padding to <PAD> first, train_modules/train_single_opt.py:78)";
     return -6;

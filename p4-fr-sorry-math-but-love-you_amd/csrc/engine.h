@@ -124,6 +124,7 @@ struct Model {
          off_stage_img = 0, off_stage_tgt = 0, off_zero = 0;
   size_t zero_bytes = 0, zero_hwm = 0;
   size_t off_sumsq = 0;
+  static constexpr int SEBOX_IMAGES = 128; size_t off_sebox = 0;
   size_t off_wgpart = 0, wgpart_floats = 0;   // two partial-tile slabs of the persistent weight-gradient kernel (bf16)
   size_t off_det = 0, det_floats = 0;  // two scratch slabs of the deterministic reductions (f32 parity mode), 0 = atomics
   size_t off_bn_eval = 0, off_bn_desc = 0; std::vector<BnEvalDesc> bn_desc_host; bool bn_desc_dirty = true;

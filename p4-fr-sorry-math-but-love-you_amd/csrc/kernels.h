@@ -305,6 +305,13 @@ void launch_adamw(float* p, const float* g, float* m, float* v, long n, const fl
 // W1 [S][C], W2 [C][S]: the packed compute-dtype copies (dt)
 // squeeze-and-excite MLP + x*gate from pool SUMS (launch_bn_act_pool): grid (B, 4 channel groups); false = shape / dtype not
 // taken (the caller then runs launch_se_fwd + launch_se_scale)
+// BatchNorm (batch statistics) + activation + squeeze-and-excite (pool, MLP, x*gate) in one launch on the small maps; box: a persistent
+// mailbox of (box_images * (1536 + 64)) 8-byte words that starts zeroed and is only ever touched by this kernel.  z may be null (the
+// activated tensor is then not stored).  false = shape / mode not taken.  A wait that times out sets device error bit 2.
+bool launch_bn_pool_se(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv, int64_t* nbt,
+                       float eps, float mom, float* ss, float* mr, void* z, const void* W1, const float* b1, const void* W2, const float* b2,
+                       float* pooled, float* u1, float* s1, void* gate, void* out, unsigned long long* box, int box_images, int B, int HW, int C,
+                       int S, int act, hipStream_t s);
 bool launch_se_mlp_scale(int dt, const void* x, const float* poolsum, const void* W1, const float* b1, const void* W2, const float* b2,
                          float* pooled, float* u1, float* s1, void* gate, void* y, int B, int HW, int C, int S, hipStream_t s);
 void launch_se_fwd(int dt, const void* x, const void* W1, const float* b1, const void* W2, const float* b2, float* pooled,

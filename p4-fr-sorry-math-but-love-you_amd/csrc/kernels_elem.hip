@@ -533,6 +533,231 @@ __global__ __launch_bounds__(256) void bn_pool_img_kernel(const bf16_t* __restri
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nbt) *nbt += 1;
 }
 
+// ---- BatchNorm (batch statistics) + activation + the WHOLE squeeze-and-excite block in one launch, for the small maps of the late stages
+// (bn_pool_img_kernel + se_mlp_scale_kernel: 6.6 + 13.2 us per MBConv block, two launch floors, the activated tensor written and read back).
+// Workgroup = one image x 64 channels as in bn_pool_img_kernel; the activated tile stays in registers while the image's squeeze-and-
+// excite MLP happens BETWEEN the workgroups of that image:
+//   1. every workgroup computes ITS 64 channels' share of the hidden layer (S <= 64 partial dot products over its own pool: no wait) and
+//      publishes it as {tag, f32} granules (8-byte relaxed agent-scope stores: the data is the flag, the hand-off form of the pipelined
+//      decoder, cdna_hip_programming.md Guideline 16 R2; tag = a per-launch number, so the mailbox is never cleared);
+//   2. every workgroup gathers the image's C/64 x S partial sums in a fixed order -> hidden layer -> the gates of its 64 channels -> tile * gate.
+// (A first form with two hand-offs -- pool sums to a per-image workgroup that computed the hidden layer alone -- took 43 us: its row loop
+// over the reduce matrix was one dependent round trip per row.)
+// The image's workgroups wait for each other, so all of them must become resident: the launcher only takes grids that fit the chip
+// several times over (other kernels holding CUs delay them but finish on their own).  Every wait is bounded by the wall clock: on a
+// timeout the kernel flags g_satrn_errflag bit 2 and returns (wrong values, reported by the next read_loss) instead of hanging.
+// Arithmetic and rounding are those of the two kernels it replaces (pool over the STORED bf16 values, gate rounded to bf16).
+extern __device__ unsigned g_satrn_errflag;   // (defined with device_error_read_clear below)
+typedef __attribute__((address_space(1))) unsigned long long se_box_t;
+struct BnSeP {
+  const bf16_t* y; const float* sums; int sums_rep; const float* w; const float* b; float* rm; float* rv; int64_t* nbt;
+  float eps, mom, invM, unbias; float* ss; float* mr; bf16_t* z /*null: the activated tensor is not kept*/;
+  const bf16_t* W1; const float* b1; const bf16_t* W2; const float* b2;
+  float* pooled; float* u1; float* s1; bf16_t* gate; bf16_t* out;
+  unsigned long long* box;   // [B][C / 64][64] hidden-layer partial sums as granules
+  unsigned tag; long long timeout_ticks;
+  int B, C, HW, S, act;
+};
+DEVI bool se_box_wait(se_box_t* g, unsigned want, long long t_end, float& val) {
+  unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned spins = 0;
+  while ((unsigned)(v >> 32) != want) {
+    if (spins > 32) __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 1023u) == 0 && (long long)wall_clock64() > t_end) { atomicOr(&g_satrn_errflag, 4u); val = 0.f; return false; }
+    v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  val = __uint_as_float((unsigned)v);
+  return true;
+}
+template <int PPT>
+__global__ __launch_bounds__(256) void bn_pool_se_img_kernel(BnSeP p) {
+  typedef bf16_t T;
+  constexpr int CH = 8, SC = 8;
+  __shared__ __attribute__((aligned(16))) float cf[2][SC * CH];
+  __shared__ float sred[4][SC * CH];
+  __shared__ __attribute__((aligned(16))) float ps[SC * CH];   // this workgroup's pooled means
+  __shared__ float hq[4][64];                                  // hidden-layer partial sums per group lane
+  __shared__ __attribute__((aligned(16))) float hs[64];        // hidden layer
+  __shared__ __attribute__((aligned(16))) float gl[SC * CH]; // this workgroup's gates (as stored: bf16-rounded)
+  const int tid = threadIdx.x, NT = blockDim.x, G = NT / SC, lane = tid & 63, wave = tid >> 6;
+  const int chunk = tid % SC, g = tid / SC;
+  const int C = p.C, HW = p.HW, S = p.S;
+  const int img = blockIdx.x, cb = blockIdx.y * SC * CH, c0 = cb + chunk * CH;
+  const long base = (long)img * HW * C + c0;
+  const long long t_end = (long long)wall_clock64() + p.timeout_ticks;
+  uint4 raw[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) raw[k] = ld16(p.y + base + (long)(g + k * G) * C);
+  // this thread's row of the expand matrix (threads 0..63: one gate each), requested now, used after two hand-offs
+  uint4 w2r[8], w1r[8];
+  float b2v = 0.f;
+  if (tid < SC * CH) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w2r[u] = ld16(p.W2 + (long)(cb + tid) * S + (u * CH < S ? u * CH : 0));
+    b2v = p.b2[cb + tid];
+    // ... and, threads 0..S-1, the 64 columns of reduce-matrix row `tid` that belong to this workgroup's channels
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w1r[u] = ld16(p.W1 + (long)(tid < S ? tid : 0) * C + cb + u * CH);
+  }
+  for (int c = tid; c < SC * CH; c += NT) {   // one thread per channel: BatchNorm finalize (bn_act_kernel's arithmetic)
+    const int cg = cb + c;
+    float mean = 0.f, var = 0.f;
+    for (int rp = 0; rp < p.sums_rep; ++rp) { mean += p.sums[(size_t)rp * 2 * C + cg]; var += p.sums[(size_t)rp * 2 * C + C + cg]; }
+    mean *= p.invM; var = fmaxf(var * p.invM - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + p.eps), sc = p.w[cg] * rstd, sh = p.b[cg] - mean * sc;
+    cf[0][c] = sc; cf[1][c] = sh;
+    if (img == 0) {
+      p.ss[cg] = sc; p.ss[C + cg] = sh; p.mr[cg] = mean; p.mr[C + cg] = rstd;
+      p.rm[cg] = (1.f - p.mom) * p.rm[cg] + p.mom * mean;
+      p.rv[cg] = (1.f - p.mom) * p.rv[cg] + p.mom * var * p.unbias;
+    }
+  }
+  __syncthreads();
+  uint4 zq[PPT];
+  {
+    float sc[CH], sh[CH], acc[CH];
+    lds8(cf[0] + chunk * CH, sc); lds8(cf[1] + chunk * CH, sh);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      float v[CH];
+      unpack<T>(raw[k], v);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) v[j] = act_fwd(v[j] * sc[j] + sh[j], p.act);
+      zq[k] = pack<T>(v);
+      if (p.z) st16(p.z + base + (long)(g + k * G) * C, zq[k]);
+      float r[CH];
+      unpack<T>(zq[k], r);   // the pool averages the ROUNDED values
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[j] += r[j];
+    }
+#pragma unroll
+    for (int o = SC; o < 64; o <<= 1)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+    if (lane < SC) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) sred[wave][lane * CH + j] = acc[j];
+    }
+  }
+  __syncthreads();
+  // 1. this workgroup's share of the hidden layer: hp[j] = sum over ITS 64 channels of W1[j][c] * mean[c] (its own pool only: no wait),
+  //    published as {tag, f32} granules; the pooled means themselves go to the backward's buffer
+  if (tid < SC * CH) {
+    float sum = 0.f;
+    for (int wv = 0; wv < NT / 64; ++wv) sum += sred[wv][tid];
+    const float m = sum * (1.0f / (float)HW);
+    ps[tid] = m;
+    p.pooled[(long)img * C + cb + tid] = m;
+  }
+  __syncthreads();
+  const int NG = C / (SC * CH);
+  se_box_t* ibox = (se_box_t*)p.box + (size_t)img * NG * 64;
+  if (tid < S) {
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float wv[CH];
+      unpack<bf16_t>(w1r[u], wv);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) a += wv[e] * ps[u * CH + e];
+    }
+    __hip_atomic_store(ibox + (size_t)blockIdx.y * 64 + tid, ((unsigned long long)p.tag << 32) | (unsigned long long)__float_as_uint(a), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // 2. every workgroup gathers the image's NG x S partial sums (thread = hidden unit j x group lane q; groups q, q + NQ, ... in order, then
+  //    the NQ lanes in order: a fixed summation order whichever workgroup arrives when) -> hidden layer
+  {
+    const int jj = tid & 63, q = tid >> 6, NQ = NT / 64;
+    float a = 0.f;
+    if (jj < S)
+      for (int yy = q; yy < NG; yy += NQ) {
+        float v;
+        se_box_wait(ibox + (size_t)yy * 64 + jj, p.tag, t_end, v);
+        a += v;
+      }
+    hq[q][jj] = a;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float v = 0.f;
+    if (tid < S) {
+      float a = 0.f;
+      for (int q = 0; q < NT / 64; ++q) a += hq[q][tid];
+      const float uu = a + p.b1[tid];
+      v = uu * sigmoidf_(uu);
+      if (blockIdx.y == 0) { p.u1[(long)img * S + tid] = uu; p.s1[(long)img * S + tid] = v; }
+    }
+    hs[tid] = v;
+  }
+  __syncthreads();
+  if (tid < SC * CH) {
+    float acc = b2v;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u * CH < S) {
+        float wv[CH];
+        unpack<bf16_t>(w2r[u], wv);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc += wv[e] * hs[u * CH + e];
+      }
+    }
+    const bf16_t gb = from_f<bf16_t>(sigmoidf_(acc));
+    p.gate[(long)img * C + cb + tid] = gb;
+    gl[tid] = to_f(gb);
+  }
+  __syncthreads();
+  {
+    float gv[CH];
+    lds8(gl + chunk * CH, gv);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      float v[CH];
+      unpack<T>(zq[k], v);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) v[j] *= gv[j];
+      st16(p.out + base + (long)(g + k * G) * C, pack<T>(v));
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && p.nbt) *p.nbt += 1;
+}
+// false = shape / mode not taken (the caller launches launch_bn_act_pool and the squeeze-and-excite kernels)
+bool launch_bn_pool_se(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv, int64_t* nbt,
+                       float eps, float mom, float* ss, float* mr, void* z /*may be null*/, const void* W1, const float* b1, const void* W2,
+                       const float* b2, float* pooled, float* u1, float* s1, void* gate, void* out, unsigned long long* box, int box_images,
+                       int B, int HW, int C, int S, int act, hipStream_t s) {
+  const bool off = getenv("SATRN_NO_FUSED_POOL_SE") != nullptr;   // read per call: tests compare the fused and the plain forms in one process
+  if (off || g_det.on || dt != DT_BF16 || !sums || !box || B > box_images || (C % 64) != 0 || C > 1536 || S > 64 || (S % 8) != 0 || HW <= 0) return false;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  // the image's workgroups wait for each other: the whole grid must fit the chip with room to spare (8 x 256 threads per CU at most)
+  if ((long)B * (C / 64) > 3L * cus) return false;
+  static unsigned tag = 0;
+  BnSeP p;
+  p.y = (const bf16_t*)y; p.sums = sums; p.sums_rep = sums_rep < 1 ? 1 : sums_rep; p.w = w; p.b = b; p.rm = rm; p.rv = rv; p.nbt = nbt;
+  const long M = (long)B * HW;
+  p.eps = eps; p.mom = mom; p.invM = 1.0f / (float)M; p.unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
+  p.ss = ss; p.mr = mr; p.z = (bf16_t*)z; p.W1 = (const bf16_t*)W1; p.b1 = b1; p.W2 = (const bf16_t*)W2; p.b2 = b2;
+  p.pooled = pooled; p.u1 = u1; p.s1 = s1; p.gate = (bf16_t*)gate; p.out = (bf16_t*)out; p.box = box;
+  p.timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
+  p.B = B; p.C = C; p.HW = HW; p.S = S; p.act = act;
+  for (int G = 32; G >= 8; G >>= 1) {
+    if ((HW % G) != 0 || HW / G > 8 || (G * 8) % 64 != 0) continue;
+    const int ppt = HW / G;
+    if (++tag == 0) tag = 1;   // (0 is what a fresh mailbox holds)
+    p.tag = tag;
+    const dim3 grid(B, C / 64), blk(G * 8);
+#define BNSE_IMG(P) case P: hipLaunchKernelGGL((bn_pool_se_img_kernel<P>), grid, blk, 0, s, p); return true;
+    switch (ppt) { BNSE_IMG(1) BNSE_IMG(2) BNSE_IMG(3) BNSE_IMG(4) BNSE_IMG(5) BNSE_IMG(6) BNSE_IMG(7) BNSE_IMG(8) }
+#undef BNSE_IMG
+  }
+  return false;
+}
+
 void launch_bn_act_pool(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv,
                         int64_t* nbt, float eps, float mom, float* ss, float* mr, void* z, float* poolsum, long M, int C, int HW, int act,
                         hipStream_t s) {

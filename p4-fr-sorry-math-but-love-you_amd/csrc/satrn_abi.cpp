@@ -272,6 +272,23 @@ int satrn_batchnorm_act_fwd(int dt, const void* y, const float* w, const float* 
                 res, z, M, C, act, S(st));
   return done("batchnorm_act_fwd");
 }
+int satrn_batchnorm_act_se_fwd(int dt, const void* y, const float* w, const float* b, float* rm, float* rv, int64_t* nbt, float eps, int act, void* z,
+                               int keep_z, const void* W1, const float* b1, const void* W2, const float* b2, float* pooled, float* u1, float* s1, void* gate,
+                               void* out, int B, int HW, int C, int S, float* scratch, unsigned long long* mailbox, int mailbox_images, void* st) {
+  CHK_DT(dt);
+  if (chk_c(dt, C, "C")) return -1;
+  if (!z || !scratch) return fail(-1, "batchnorm_act_se_fwd: z and scratch are required");
+  const long M = (long)B * HW;
+  launch_colstats(dt, y, M, C, scratch, S(st));
+  if (!launch_bn_pool_se(dt, y, scratch, 1, w, b, rm, rv, nbt, eps, 0.1f, scratch + 2 * C, scratch + 4 * C, keep_z ? z : nullptr, W1, b1, W2, b2, pooled, u1, s1,
+                         gate, out, mailbox, mailbox_images, B, HW, C, S, act, S(st))) {
+    // the separate kernels (the squeeze-and-excite kernel pools by itself)
+    launch_bn_act(dt, y, scratch, 1, w, b, rm, rv, nbt, eps, 0.1f, scratch + 2 * C, scratch + 4 * C, nullptr, z, M, C, act, S(st));
+    launch_se_fwd(dt, z, W1, b1, W2, b2, pooled, u1, s1, gate, B, HW, C, S, S(st));
+    launch_se_scale(dt, z, gate, out, B, HW, C, S(st));
+  }
+  return done("batchnorm_act_se_fwd");
+}
 int satrn_batchnorm_act_dwconv3x3_fwd(int dt, const void* y, const float* w, const float* b, float* rm, float* rv, int64_t* nbt,
                                       float eps, int act, void* z, const void* dwp, const float* dwb, void* out, float* out_stats,
                                       int B, int H, int W, int C, float* scratch, void* st) {

@@ -482,7 +482,7 @@ def test_segmented_backward_equals_whole_backward(golden_dir, name):
         model.train_step(imgd, expd, 0.0, phase=18)  # out of order
 
 
-_FUSED_SWITCHES = ("SATRN_NO_FUSED_POOL", "SATRN_DW_NO_FUSED_RED", "SATRN_GEMM_NO_G2", "SATRN_SE_NO_WIDE_BWD", "SATRN_NO_FUSED_BN_DW", "SATRN_NO_FUSED_DW_BWD", "SATRN_SE_NO_BN_SUMS", "SATRN_NO_FUSED_BN_APPLY_DW")
+_FUSED_SWITCHES = ("SATRN_NO_FUSED_POOL_SE", "SATRN_NO_FUSED_POOL", "SATRN_DW_NO_FUSED_RED", "SATRN_GEMM_NO_G2", "SATRN_SE_NO_WIDE_BWD", "SATRN_NO_FUSED_BN_DW", "SATRN_NO_FUSED_DW_BWD", "SATRN_SE_NO_BN_SUMS", "SATRN_NO_FUSED_BN_APPLY_DW")
 
 
 def test_fused_chain_kernels_equal_their_plain_forms(golden_dir, monkeypatch):
@@ -497,9 +497,9 @@ def test_fused_chain_kernels_equal_their_plain_forms(golden_dir, monkeypatch):
     img, expected = O.det_inputs(B, cfg["rgb"], H, W, T, seed=77, pad_tail=0)
     imgd, expd = img.cuda(), expected.cuda()
 
-    def run(plain):
+    def run(plain, only=None):
         for k in _FUSED_SWITCHES:
-            if plain:
+            if plain or k == only:
                 monkeypatch.setenv(k, "1")
             else:
                 monkeypatch.delenv(k, raising=False)
@@ -523,6 +523,16 @@ def test_fused_chain_kernels_equal_their_plain_forms(golden_dir, monkeypatch):
     print(f"[plain vs plain] logits rel err {nl:.3e}, gradient rel-L2 {ng:.3e}   [fused vs plain] {fl:.3e}, {fg:.3e}")
     assert fl < 2.0 * nl + 5e-3
     assert fg < 2.0 * ng + 5e-2
+    # round 3: BatchNorm + activation + the whole squeeze-and-excite block as one launch (the image's workgroups hand the pool and the
+    # hidden layer to each other through a tagged mailbox) against the same step with only that kernel switched off
+    s0 = run(False, only="SATRN_NO_FUSED_POOL_SE")
+    sl, sg = dist(s0, f0)
+    print(f"[one-launch BatchNorm + squeeze-and-excite vs its two launches] logits rel err {sl:.3e}, gradient rel-L2 {sg:.3e}")
+    assert sl < 2.0 * nl + 5e-3
+    assert sg < 2.0 * ng + 5e-2
+    import satrn_amd
+    import ctypes
+    assert satrn_amd._lib.load().satrn_device_error(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0   # bit 2 = a hand-off wait of the fused kernel timed out
 
 
 def test_eval_encoder_image_tile_depthwise_equals_generic(golden_dir, monkeypatch):

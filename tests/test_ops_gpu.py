@@ -1024,6 +1024,62 @@ def test_dropout_statistics(lib):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,HW,C,S", [(32, 192, 960, 40), (32, 48, 1536, 64), (5, 24, 128, 8), (3, 192, 256, 16), (2, 35, 96, 8), (2, 48, 1792, 64)])
+def test_batchnorm_act_squeeze_excite_one_launch(lib, dt, B, HW, C, S, monkeypatch):
+    """BatchNorm (batch statistics) + SiLU + the whole squeeze-and-excite block in ONE launch (the image's workgroups exchange their shares
+    of the hidden layer through a tagged mailbox; bf16, the MBConv shapes of the late stages) against torch and against the separate
+    kernels (the last two shapes and f32 take those); called several times on the same never-cleared mailbox."""
+    y = q(rnd(B, HW, C, seed=1) * 2 + 0.5, dt)
+    w, b = 1 + rnd(C, seed=3, scale=0.2), rnd(C, seed=4, scale=0.1)
+    rm, rv = rnd(C, seed=5, scale=0.1), 1 + rnd(C, seed=6, scale=0.3).abs()
+    W1, W2 = q(rnd(S, C, seed=7, scale=0.05), dt), q(rnd(C, S, seed=8, scale=0.2), dt)
+    b1, b2 = rnd(S, seed=9, scale=0.1), rnd(C, seed=10, scale=0.1)
+    eps = 1e-3
+    yn = y.reshape(B * HW, C)
+    mean, var = yn.mean(0), yn.var(0, unbiased=False)
+    z = q(F.silu((y - mean) / torch.sqrt(var + eps) * w + b), dt)
+    pooled = z.mean(1)
+    u1 = pooled @ W1.t() + b1
+    s1 = u1 * torch.sigmoid(u1)
+    gate = q(torch.sigmoid(s1 @ W2.t() + b2), dt)
+    ref = z * gate[:, None, :]
+    yd, W1d, W2d = dev(y, dt), dev(W1, dt), dev(W2, dt)
+    box = torch.zeros(128 * 1600, dtype=torch.int64, device="cuda")
+
+    def run(one_launch, keep_z):
+        if one_launch:
+            monkeypatch.delenv("SATRN_NO_FUSED_POOL_SE", raising=False)
+        else:
+            monkeypatch.setenv("SATRN_NO_FUSED_POOL_SE", "1")
+        rmd, rvd = dev(rm.clone()), dev(rv.clone())
+        nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        scratch = torch.zeros(6 * C, device="cuda")
+        zd = torch.zeros(B, HW, C, dtype=tdt(dt), device="cuda")
+        out = torch.zeros(B, HW, C, dtype=tdt(dt), device="cuda")
+        po, u1d, s1d = torch.zeros(B, C, device="cuda"), torch.zeros(B, S, device="cuda"), torch.zeros(B, S, device="cuda")
+        gd = torch.zeros(B, C, dtype=tdt(dt), device="cuda")
+        ok(lib, lib.satrn_batchnorm_act_se_fwd(dti(dt), P(yd), P(dev(w)), P(dev(b)), P(rmd), P(rvd), P(nbt), eps, 2, P(zd), keep_z, P(W1d), P(dev(b1)), P(W2d),
+                                               P(dev(b2)), P(po), P(u1d), P(s1d), P(gd), P(out), B, HW, C, S, P(scratch), P(box), 128, st()))
+        torch.cuda.synchronize()
+        assert lib.satrn_device_error(st()) == 0
+        return zd, out, po, u1d, s1d, gd, rmd, nbt
+
+    for rep in range(3):   # the mailbox is reused as it is
+        zd, out, po, u1d, s1d, gd, rmd, nbt = run(True, rep % 2)
+        close(out, ref, dt, "bn+se out", bf16_tol=3e-2, f32_tol=1e-3)
+        close(po, pooled, dt, "bn+se pooled", bf16_tol=1e-2, f32_tol=1e-4)
+        close(u1d, u1, dt, "bn+se u1", bf16_tol=2e-2, f32_tol=1e-4)
+        close(gd, gate, dt, "bn+se gate", bf16_tol=1e-2, f32_tol=1e-4)
+        assert nbt.item() == 1
+        if rep % 2:
+            close(zd, z, dt, "bn+se z", bf16_tol=3e-2, f32_tol=1e-3)
+    _, out2, po2, u12, _, gd2, rmd2, _ = run(False, 1)
+    close(out, out2.cpu(), dt, "one launch vs separate kernels: out", bf16_tol=1e-2, f32_tol=1e-5)
+    close(gd, gd2.cpu(), dt, "one launch vs separate kernels: gate", bf16_tol=1e-2, f32_tol=1e-5)
+    close(rmd, rmd2.cpu(), "f32", "running mean", f32_tol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,HW,C,S,wide", [(3, 48, 1536, 64, False), (3, 48, 1536, 64, True), (2, 192, 960, 40, True), (4, 192, 512, 32, True),
                                             (2, 35, 96, 8, False), (2, 192, 256, 16, True),
                                             # beyond the wide kernels' staging (C > 1536: 6 x 32 W2 rows per channel group): must take the per-image form
