@@ -229,6 +229,15 @@ int satrn_se_bwd(int dtype, const void* dy, const void* x, const void* gate, con
 int satrn_se_bwd_bnred(int dtype, const void* dy, const void* bn_y, const float* bn_scratch, int act, const void* gate, const float* u1,
                        const void* W1, const void* W2, float* dz2, float* du1, float* ds1_zeroed, void* dpooled, float* P_scratch,
                        float* bn_scratch2, int B, int HW, int C, int S, void* stream);
+/* The same in ONE launch, given a mailbox (mailbox_images * 1600 8-byte words, ZERO before the first use, written by nothing but the
+ * mailbox operators -- the one of satrn_batchnorm_act_se_fwd can be shared): the workgroups of an image exchange their shares of
+ * W2^T dz2 through it and add them in a fixed order (no float atomics on ds1: that part is deterministic); ds1_zeroed then receives
+ * the sums (it need not be zero).  B > mailbox_images, B * 8 workgroups beyond two per compute unit, or mailbox == NULL: the two
+ * launches of satrn_se_bwd_bnred.  A hand-off that times out sets device error bit 2.  (Alone on the device the one launch is
+ * shorter; inside the engine's training step, beside the weight-gradient stream, it measured slower and the engine keeps the two.) */
+int satrn_se_bwd_bnred_mbox(int dtype, const void* dy, const void* bn_y, const float* bn_scratch, int act, const void* gate, const float* u1,
+                            const void* W1, const void* W2, float* dz2, float* du1, float* ds1_zeroed, void* dpooled, float* P_scratch,
+                            float* bn_scratch2, int B, int HW, int C, int S, unsigned long long* mailbox, int mailbox_images, void* stream);
 
 /* Adaptive 2D positional encoding, networks/EfficientSATRN.py:135-154: out = x + g0*hpos[h] + g1*wpos[w]
  * with gate [B][2C] = sigmoid(dense1(relu(dense0(mean_hw x)))) computed by satrn_pool_hw + satrn_linear_fwd. */

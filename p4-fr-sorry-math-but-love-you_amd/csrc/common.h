@@ -215,3 +215,22 @@ DEVI int xcd_remap(int bid, int nwg) {
   int q = nwg >> 3, r = nwg & 7, x = bid & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
+
+// ---- {tag, f32} mailbox granules between the workgroups of one launch (8-byte relaxed agent-scope accesses: the data is the flag).
+// A wait is bounded by the wall clock; on a timeout *err |= 4 and the caller goes on with 0 (the results of the step are invalid, the
+// host reports it at the next read_loss / satrn_device_error).
+typedef __attribute__((address_space(1))) unsigned long long se_box_t;
+DEVI void se_box_put(se_box_t* g, unsigned tag, float v) {
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEVI bool se_box_wait(se_box_t* g, unsigned want, long long t_end, float& val, unsigned* err) {
+  unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned spins = 0;
+  while ((unsigned)(v >> 32) != want) {
+    if (spins > 32) __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 1023u) == 0 && (long long)wall_clock64() > t_end) { atomicOr(err, 4u); val = 0.f; return false; }
+    v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  val = __uint_as_float((unsigned)v);
+  return true;
+}

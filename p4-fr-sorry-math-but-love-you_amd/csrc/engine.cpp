@@ -1637,11 +1637,11 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr, SeHold
                                 getenv("SATRN_SE_NO_WIDE_BWD") == nullptr && getenv("SATRN_SE_NO_BN_SUMS") == nullptr;
     const bool need_x = e.rec && !(e.train && bwd_recomputes);
     // (not under hipGraph capture: the per-launch mailbox tag would be replayed)
-    unsigned long long* box = e.serial ? nullptr : (unsigned long long*)(e.m->ws + e.m->off_sebox);
+    unsigned long long* box = g_sebox.box;
     WORK(e, 4.0 * (double)B * C * S, (double)x->rows * C * e.esz() * (need_x ? 3 : 2) + (double)C * S * e.esz() * 2);
     LCH(e, fused = launch_bn_pool_se(e.dt, sh->y, sh->sums, sh->rep, bn->w.p, bn->b.p, bn->rm, bn->rv, bn->nbt, bn->eps, 0.1f, sh->ss, sh->mr,
                                      need_x ? sh->z : nullptr, eb->se_r.fwd, eb->se_rb.p, eb->se_e.fwd, eb->se_eb.p, pooled, u1, s1, gate->p, y->p, box,
-                                     Model::SEBOX_IMAGES, B, HW, C, S, sh->act, e.s));
+                                     g_sebox.images, B, HW, C, S, sh->act, e.s));
     if (!fused) {
       WORK(e, 0, (double)sh->M * sh->C * e.esz() * 2);
       LCH(e, launch_bn_act_pool(e.dt, sh->y, sh->sums, sh->rep, bn->w.p, bn->b.p, bn->rm, bn->rv, bn->nbt, bn->eps, 0.1f, sh->ss, sh->mr, sh->z, sh->pool,
@@ -1985,6 +1985,11 @@ static void det_activate(Model* m) {
   g_wgpart.scratch[0] = wp ? (float*)(m->ws + m->off_wgpart) : nullptr;
   g_wgpart.scratch[1] = wp ? (float*)(m->ws + m->off_wgpart) + m->wgpart_floats : nullptr;
   g_wgpart.side = m->ex ? m->ex->s2 : nullptr;
+  // (not under hipGraph capture -- Exec::serial: a captured launch would replay its mailbox tag)
+  const bool mbox = wp && m->off_sebox && !(m->ex && m->ex->serial);
+  g_sebox.box = mbox ? (unsigned long long*)(m->ws + m->off_sebox) : nullptr;
+  g_sebox.images = mbox ? Model::SEBOX_IMAGES : 0;
+  g_sebox.bwd = mbox && getenv("SATRN_SE_BWD_ONE_LAUNCH") != nullptr;   // (measured slower inside the step: off by default)
 }
 
 static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) {

@@ -25,6 +25,13 @@ extern float g_wgrad_big_min_gflop;
 // the engine points them into its workspace per call, operator-level C-ABI calls keep the atomic form (cap = 0).
 struct WgPartCtx { float* scratch[2] = {nullptr, nullptr}; size_t cap = 0 /*floats per slab*/; hipStream_t side = nullptr; };
 extern WgPartCtx g_wgpart;
+// mailbox for kernels whose workgroups hand small vectors to each other inside ONE launch (launch_bn_pool_se, launch_se_bwd_wide): `images`
+// x 1600 8-byte words that start zeroed and are only written by those kernels, each launch with its own tag (se_next_tag).  Set per
+// engine call (the model's workspace); null for operator calls that bring none.
+struct SeBoxCtx { unsigned long long* box = nullptr; int images = 0; bool bwd = false /*the squeeze-and-excite backward may use it too*/; };
+extern SeBoxCtx g_sebox;
+unsigned se_next_tag();
+unsigned* device_error_word();   // device address of the error word (bit 2: a mailbox wait timed out)
 void launch_fold4(const float* part, int nrep, long stride, long n, float* out, hipStream_t s);   // launch_fold with 16-byte accesses (n, stride % 4 == 0)
 void det_overflow_warn(size_t need_floats);
 // value of a timing-experiment switch (results are WRONG when it is set): read once, announced once on stderr

@@ -24,6 +24,12 @@ DEVI void lds8(const float* p, float* o) {   // 8 floats from LDS / memory throu
 
 DetCtx g_det;
 WgPartCtx g_wgpart;
+SeBoxCtx g_sebox;
+unsigned se_next_tag() {   // one number per launch that uses a mailbox, whichever kernel (0 is what a fresh mailbox holds)
+  static unsigned tag = 0;
+  if (++tag == 0) tag = 1;
+  return tag;
+}
 int timing_switch(const char* name) {
   const char* v = getenv(name);
   const int x = v ? atoi(v) : 0;
@@ -548,7 +554,6 @@ __global__ __launch_bounds__(256) void bn_pool_img_kernel(const bf16_t* __restri
 // timeout the kernel flags g_satrn_errflag bit 2 and returns (wrong values, reported by the next read_loss) instead of hanging.
 // Arithmetic and rounding are those of the two kernels it replaces (pool over the STORED bf16 values, gate rounded to bf16).
 extern __device__ unsigned g_satrn_errflag;   // (defined with device_error_read_clear below)
-typedef __attribute__((address_space(1))) unsigned long long se_box_t;
 struct BnSeP {
   const bf16_t* y; const float* sums; int sums_rep; const float* w; const float* b; float* rm; float* rv; int64_t* nbt;
   float eps, mom, invM, unbias; float* ss; float* mr; bf16_t* z /*null: the activated tensor is not kept*/;
@@ -558,17 +563,6 @@ struct BnSeP {
   unsigned tag; long long timeout_ticks;
   int B, C, HW, S, act;
 };
-DEVI bool se_box_wait(se_box_t* g, unsigned want, long long t_end, float& val) {
-  unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  unsigned spins = 0;
-  while ((unsigned)(v >> 32) != want) {
-    if (spins > 32) __builtin_amdgcn_s_sleep(1);
-    if ((++spins & 1023u) == 0 && (long long)wall_clock64() > t_end) { atomicOr(&g_satrn_errflag, 4u); val = 0.f; return false; }
-    v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  val = __uint_as_float((unsigned)v);
-  return true;
-}
 template <int PPT>
 __global__ __launch_bounds__(256) void bn_pool_se_img_kernel(BnSeP p) {
   typedef bf16_t T;
@@ -663,8 +657,7 @@ __global__ __launch_bounds__(256) void bn_pool_se_img_kernel(BnSeP p) {
 #pragma unroll
       for (int e = 0; e < CH; ++e) a += wv[e] * ps[u * CH + e];
     }
-    __hip_atomic_store(ibox + (size_t)blockIdx.y * 64 + tid, ((unsigned long long)p.tag << 32) | (unsigned long long)__float_as_uint(a), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    se_box_put(ibox + (size_t)blockIdx.y * 64 + tid, p.tag, a);
   }
   // 2. every workgroup gathers the image's NG x S partial sums (thread = hidden unit j x group lane q; groups q, q + NQ, ... in order, then
   //    the NQ lanes in order: a fixed summation order whichever workgroup arrives when) -> hidden layer
@@ -674,7 +667,7 @@ __global__ __launch_bounds__(256) void bn_pool_se_img_kernel(BnSeP p) {
     if (jj < S)
       for (int yy = q; yy < NG; yy += NQ) {
         float v;
-        se_box_wait(ibox + (size_t)yy * 64 + jj, p.tag, t_end, v);
+        se_box_wait(ibox + (size_t)yy * 64 + jj, p.tag, t_end, v, &g_satrn_errflag);
         a += v;
       }
     hq[q][jj] = a;
@@ -736,7 +729,6 @@ bool launch_bn_pool_se(int dt, const void* y, const float* sums, int sums_rep, c
   }
   // the image's workgroups wait for each other: the whole grid must fit the chip with room to spare (8 x 256 threads per CU at most)
   if ((long)B * (C / 64) > 3L * cus) return false;
-  static unsigned tag = 0;
   BnSeP p;
   p.y = (const bf16_t*)y; p.sums = sums; p.sums_rep = sums_rep < 1 ? 1 : sums_rep; p.w = w; p.b = b; p.rm = rm; p.rv = rv; p.nbt = nbt;
   const long M = (long)B * HW;
@@ -748,8 +740,7 @@ bool launch_bn_pool_se(int dt, const void* y, const float* sums, int sums_rep, c
   for (int G = 32; G >= 8; G >>= 1) {
     if ((HW % G) != 0 || HW / G > 8 || (G * 8) % 64 != 0) continue;
     const int ppt = HW / G;
-    if (++tag == 0) tag = 1;   // (0 is what a fresh mailbox holds)
-    p.tag = tag;
+    p.tag = se_next_tag();
     const dim3 grid(B, C / 64), blk(G * 8);
 #define BNSE_IMG(P) case P: hipLaunchKernelGGL((bn_pool_se_img_kernel<P>), grid, blk, 0, s, p); return true;
     switch (ppt) { BNSE_IMG(1) BNSE_IMG(2) BNSE_IMG(3) BNSE_IMG(4) BNSE_IMG(5) BNSE_IMG(6) BNSE_IMG(7) BNSE_IMG(8) }
@@ -2384,6 +2375,11 @@ void launch_reshape_quirk(int dt, int inverse, const void* in, void* out, int B,
 // train_modules/train_single_opt.py:78); nn.Embedding / CrossEntropyLoss raise there, these kernels skip the element and
 // flag it, and the next satrn_model_read_loss / satrn_device_error call reports it
 __device__ unsigned g_satrn_errflag = 0;
+unsigned* device_error_word() {
+  static unsigned* p = nullptr;
+  if (!p && hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_satrn_errflag)) != hipSuccess) p = nullptr;
+  return p;
+}
 unsigned device_error_read_clear(hipStream_t s) {
   unsigned v = 0;
   if (hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(g_satrn_errflag), sizeof(v), 0, hipMemcpyDeviceToHost, s) != hipSuccess) return 0;

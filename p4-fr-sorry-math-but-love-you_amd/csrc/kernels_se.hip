@@ -373,9 +373,13 @@ __global__ __launch_bounds__(1024) void se_bwd_a_kernel(const T* dgate, const T*
 //   sum_hw g*xhat = gate * sum(dy*a*xhat) + dpooled/HW * sum(a*xhat)
 // and the chip-wide reduction pass over dy / bn_y / gate / dpooled that used to follow (launch_bn_bwd_reduce, 16-29 us) is gone.
 struct SeBnP { const bf16_t* bn_y; const float* ss; const float* mr; int act; float* P; /*[4][B][C]*/ float* red; /*[2C] zeroed*/ int B; };
+// ONE launch instead of the two (round 3): the workgroups of an image publish their shares of ds1 as {tag, f32} granules, every one of
+// them gathers the eight shares in group order (deterministic: no atomics on ds1) and runs kernel 2's part for its channels.
+struct SeOneP { unsigned long long* box; unsigned tag; long long timeout_ticks; unsigned* err; const float* u1; const bf16_t* W1; float* du1; bf16_t* dpooled; float inv_hw; };
 #define SEB_NT 512   // phase 1 (the stream over the image) runs on 8 waves; the small matrix phases on the first four
 __global__ __launch_bounds__(SEB_NT) void se_bwd_gate_ds_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate,
-                                                                const bf16_t* __restrict__ W2, float* dz2, float* ds1, int HW, int C, int S, SeBnP bn) {
+                                                                const bf16_t* __restrict__ W2, float* dz2, float* ds1, int HW, int C, int S, SeBnP bn,
+                                                                SeOneP one) {
   typedef bf16_t T;
   constexpr int CH = 8, NW = SEB_NT / 64;
   __shared__ float part[5][NW][32 * CH];   // per wave: [chunk lane * CH] partial sums (dgate, then the four BatchNorm sums)
@@ -515,7 +519,72 @@ __global__ __launch_bounds__(SEB_NT) void se_bwd_gate_ds_kernel(const bf16_t* __
     for (int e = 0; e < CH; ++e) red[wave][lane * CH + e] = acc[e];
   }
   __syncthreads();
-  if (tid < S) atomicAdd(ds1 + (long)b * S + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+  if (!one.box) {
+    if (tid < S) atomicAdd(ds1 + (long)b * S + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+    return;
+  }
+  // ---- the second kernel's part, behind a hand-off between the image's workgroups
+  const long long t_end = (long long)wall_clock64() + one.timeout_ticks;
+  const int NG = (int)gridDim.y;
+  se_box_t* ibox = (se_box_t*)one.box + (size_t)b * NG * 64;
+  if (tid < S) se_box_put(ibox + (size_t)grp * 64 + tid, one.tag, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+  // the reduce-matrix rows of this thread (first 256 threads: chunk lane tx2 x group of 8 hidden units jg), requested before the wait
+  const int tx2 = tid & 31, jg = (tid >> 5) & 7;
+  uint4 raw[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int j = jg * 8 + k;
+    raw[k] = (tid < 256 && tx2 < nch && j < S) ? ld16(one.W1 + (long)j * C + (long)(cbeg + tx2) * CH) : zero16();
+  }
+  float* du = red[0];                 // [64] (the partial sums above were published: red is free after the barrier below)
+  float (*part2)[32 * CH] = part[0];  // [8][256]
+  float dsv = 0.f;
+  if (tid < S) {
+    for (int g2 = 0; g2 < NG; ++g2) {   // group order: the same sum in every workgroup, whoever arrives when
+      float v;
+      se_box_wait(ibox + (size_t)g2 * 64 + tid, one.tag, t_end, v, one.err);
+      dsv += v;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float v = 0.f;
+    if (tid < S) {
+      v = dsv * act_bwd(one.u1[(long)b * S + tid], ACT_SILU);
+      if (grp == 0) { one.du1[(long)b * S + tid] = v; ds1[(long)b * S + tid] = dsv; }
+    }
+    du[tid] = v;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    float acc2[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc2[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float wv[CH];
+      unpack<T>(raw[k], wv);
+      const float d = du[jg * 8 + k];
+#pragma unroll
+      for (int e = 0; e < CH; ++e) acc2[e] += wv[e] * d;
+    }
+#pragma unroll
+    for (int e = 0; e < CH; ++e) part2[jg][tx2 * CH + e] = acc2[e];
+  }
+  __syncthreads();
+  for (int c = tid; c < cs; c += SEB_NT) {
+    float v = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 8; ++g2) v += part2[g2][c];
+    const T vr = from_f<T>(v);
+    one.dpooled[(long)b * C + cbeg * CH + c] = vr;
+    if (bn.bn_y) {   // this image's share of the BatchNorm-backward column sums (as se_bwd_pool_kernel)
+      const long o = (long)b * C + cbeg * CH + c, ps = (long)bn.B * C;
+      const float g = to_f(gate[o]), dp = to_f(vr) * one.inv_hw;
+      atomicAdd(bn.red + cbeg * CH + c, g * bn.P[o] + dp * bn.P[ps + o]);
+      atomicAdd(bn.red + C + cbeg * CH + c, g * bn.P[2 * ps + o] + dp * bn.P[3 * ps + o]);
+    }
+  }
 }
 __global__ __launch_bounds__(256) void se_bwd_pool_kernel(const float* __restrict__ ds1, const float* __restrict__ u1, const bf16_t* __restrict__ W1,
                                                           float* du1, bf16_t* dpooled, int C, int S, SeBnP bn, const bf16_t* __restrict__ gate, float inv_hw) {
@@ -583,8 +652,26 @@ bool launch_se_bwd_wide(int dt, const void* dy, const void* x, const void* gate,
   if (off || g_det.on || dt != DT_BF16 || S > 64 || (S % 8) != 0 || (C % 8) != 0 || ((C / 8 + G - 1) / G) > 24 /*se_bwd_gate_ds_kernel stages 6 x 32 = 192 rows of W2 per group (wraw[6]): C <= 1536*/) return false;
   SeBnP bn;
   bn.bn_y = (bn_y && bn_P && bn_red) ? (const bf16_t*)bn_y : nullptr; bn.ss = bn_ss; bn.mr = bn_mr; bn.act = bn_act; bn.P = bn_P; bn.red = bn_red; bn.B = B;
+  SeOneP one;
+  one.box = nullptr; one.tag = 0; one.timeout_ticks = 200000000LL; one.err = nullptr; one.u1 = u1; one.W1 = (const bf16_t*)W1; one.du1 = du1;
+  one.dpooled = (bf16_t*)dpooled; one.inv_hw = 1.0f / (float)HW;
+  // one launch when the caller asks for it (SeBoxCtx::bwd), a mailbox is there and the grid (B x 8 workgroups of 512 threads, ~48 KB of
+  // LDS) fits the chip at once: the image's workgroups wait for each other.  Measured inside the EfficientSATRN step it LOSES (10.25 ms
+  // against 10.11 with the two launches): the backward shares the chip with the weight-gradient stream, the workgroups of an image
+  // start at different times and the early ones hold their slots while they wait -- so the engine leaves it off (SATRN_SE_BWD_ONE_LAUNCH=1
+  // switches it on); the forward twin (launch_bn_pool_se), which runs with nothing beside it, wins 0.23 ms.
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  if (g_sebox.box && g_sebox.bwd && B <= g_sebox.images && (long)B * G <= 2L * cus) {
+    one.err = device_error_word();
+    if (one.err) { one.box = g_sebox.box; one.tag = se_next_tag(); }
+  }
   hipLaunchKernelGGL(se_bwd_gate_ds_kernel, dim3(B, G), dim3(SEB_NT), 0, s, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)gate, (const bf16_t*)W2, dz2, ds1_zeroed,
-                     HW, C, S, bn);
+                     HW, C, S, bn, one);
+  if (one.box) return true;
   hipLaunchKernelGGL(se_bwd_pool_kernel, dim3(B, G), dim3(256), 0, s, ds1_zeroed, u1, (const bf16_t*)W1, du1, (bf16_t*)dpooled, C, S, bn, (const bf16_t*)gate,
                      1.0f / (float)HW);
   return true;

@@ -18,7 +18,7 @@ static int done(const char* what) {
 }
 #define S(x) ((hipStream_t)(x))
 // operator-level calls have no engine workspace behind them: they always use the atomic reduction forms
-#define CHK_DT(dt) do { g_det.on = 0; g_wgpart.cap = 0; if ((dt) != 0 && (dt) != 1) return fail(-1, "dtype must be 0 (f32) or 1 (bf16)"); } while (0)
+#define CHK_DT(dt) do { g_det.on = 0; g_sebox.box = nullptr; g_sebox.images = 0; g_sebox.bwd = false; g_wgpart.cap = 0; if ((dt) != 0 && (dt) != 1) return fail(-1, "dtype must be 0 (f32) or 1 (bf16)"); } while (0)
 static int chk_c(int dt, int c, const char* what) {
   int ch = dt == DT_BF16 ? 8 : 4;
   if (c <= 0 || c % ch) return fail(-1, std::string(what) + " must be a positive multiple of " + std::to_string(ch));
@@ -406,6 +406,19 @@ int satrn_se_bwd_bnred(int dt, const void* dy, const void* bn_y, const float* bn
                           P_scratch, bn_scratch2))
     return fail(-1, "satrn_se_bwd_bnred: the wide form does not take this dtype / shape (use satrn_se_bwd + satrn_batchnorm_act_bwd)");
   return done("se_bwd_bnred");
+}
+int satrn_se_bwd_bnred_mbox(int dt, const void* dy, const void* bn_y, const float* bn_scratch, int act, const void* gate, const float* u1, const void* W1,
+                            const void* W2, float* dz2, float* du1, float* ds1_zeroed, void* dpooled, float* P_scratch, float* bn_scratch2, int B, int HW,
+                            int C, int S, unsigned long long* mailbox, int mailbox_images, void* st) {
+  CHK_DT(dt);
+  if (B <= 0 || HW <= 0 || C <= 0 || S <= 0 || (C % 8) != 0) return fail(-1, "satrn_se_bwd_bnred_mbox: bad shape");
+  if (!bn_y || !bn_scratch || !P_scratch || !bn_scratch2 || !ds1_zeroed) return fail(-1, "satrn_se_bwd_bnred_mbox: null operand");
+  g_sebox.box = mailbox; g_sebox.images = mailbox ? mailbox_images : 0; g_sebox.bwd = mailbox != nullptr;
+  const bool okw = launch_se_bwd_wide(dt, dy, nullptr, gate, u1, W1, W2, dz2, du1, ds1_zeroed, dpooled, B, HW, C, S, S(st), bn_y, bn_scratch + 2 * C,
+                                      bn_scratch + 4 * C, act, P_scratch, bn_scratch2);
+  g_sebox.box = nullptr; g_sebox.images = 0; g_sebox.bwd = false;
+  if (!okw) return fail(-1, "satrn_se_bwd_bnred_mbox: the wide form does not take this dtype / shape (use satrn_se_bwd + satrn_batchnorm_act_bwd)");
+  return done("se_bwd_bnred_mbox");
 }
 int satrn_pool_hw(int dt, const void* x, void* out, int B, int HW, int C, void* st) {
   CHK_DT(dt);

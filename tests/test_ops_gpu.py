@@ -763,7 +763,7 @@ def test_bn_backward_apply_inside_dwconv_backward(lib, B, H, W, C, acc, monkeypa
     close(a[4], b[4].cpu(), "f32", "next BatchNorm's sums: one launch vs two", f32_tol=2e-4)
 
 
-@pytest.mark.parametrize("B,HW,C,S", [(3, 192, 512, 32), (4, 48, 1536, 64), (2, 192, 960, 40), (5, 48, 64, 8)])
+@pytest.mark.parametrize("B,HW,C,S", [(3, 192, 512, 32), (4, 48, 1536, 64), (2, 192, 960, 40), (5, 48, 64, 8), (32, 48, 1536, 64), (32, 192, 960, 40)])
 def test_squeeze_excite_backward_with_batchnorm_sums(lib, B, HW, C, S):
     """BatchNorm -> SiLU -> SqueezeExcite seam of the MBConv block, backward (bf16): the SE input is recomputed from the
     BatchNorm's raw input, and the BatchNorm-backward column sums of the gradient dy*gate + dpooled/HW come out of the two SE
@@ -801,6 +801,26 @@ def test_squeeze_excite_backward_with_batchnorm_sums(lib, B, HW, C, S):
     Pd, s2 = torch.zeros(4 * B * C, device="cuda"), torch.zeros(2 * C, device="cuda")
     ok(lib, lib.satrn_se_bwd_bnred(dti(dt), P(dyd), P(yd), P(scratch), 2, P(gate_d), P(u1_d), P(W1d), P(W2d), P(dz2_d), P(du1_d), P(ds1_d), P(dpool_d),
                                    P(Pd), P(s2), B, HW, C, S, st()))
+    # the same in ONE launch (the image's workgroups exchange their shares of ds1 through a mailbox and add them in a fixed order): same
+    # outputs up to the order of that one sum, bit-identical from call to call on a never-cleared mailbox
+    box = torch.zeros(128 * 1600, dtype=torch.int64, device="cuda")
+    prev = None
+    for rep in range(3):
+        o = [torch.zeros(B, C, device="cuda"), torch.zeros(B, S, device="cuda"), torch.full((B, S), 7.0, device="cuda"),
+             torch.zeros(B, C, dtype=tdt(dt), device="cuda"), torch.zeros(4 * B * C, device="cuda"), torch.zeros(2 * C, device="cuda")]
+        ok(lib, lib.satrn_se_bwd_bnred_mbox(dti(dt), P(dyd), P(yd), P(scratch), 2, P(gate_d), P(u1_d), P(W1d), P(W2d), P(o[0]), P(o[1]), P(o[2]), P(o[3]),
+                                            P(o[4]), P(o[5]), B, HW, C, S, P(box), 128, st()))
+        torch.cuda.synchronize()
+        assert lib.satrn_device_error(st()) == 0
+        assert torch.equal(o[0], dz2_d), "dz2: one launch vs two"
+        close(o[1], du1_d.cpu(), "f32", "du1: one launch vs two", f32_tol=1e-5)
+        close(o[2], ds1_d.cpu(), "f32", "ds1: one launch vs two", f32_tol=1e-5)
+        close(o[3], dpool_d.float().cpu(), dt, "dpooled: one launch vs two", bf16_tol=1e-2)
+        close(o[5], s2.cpu(), "f32", "BatchNorm sums: one launch vs two", f32_tol=2e-3)
+        if prev is not None:
+            for u_, v_, what in zip(o[:4], prev[:4], ("dz2", "du1", "ds1", "dpooled")):
+                assert torch.equal(u_, v_), f"{what}: one-launch form differs from call to call"
+        prev = o
     # the separate reduction over the folded gradient gives the same sums
     s2p = torch.zeros(2 * C, device="cuda")
     dzfull = (dyd.float() * gate_d.float()[:, None, :] + dpool_d.float()[:, None, :] / HW)
