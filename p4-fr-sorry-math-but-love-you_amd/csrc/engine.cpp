@@ -839,6 +839,8 @@ struct SeHold {
   bool armed = false;
   const void* y = nullptr; const float* sums = nullptr; int rep = 1; BNp* bn = nullptr; float* ss = nullptr; float* mr = nullptr; void* z = nullptr;
   float* pool = nullptr; long M = 0; int C = 0, HW = 0, act = 0;
+  // inference: the depthwise convolution in front (Tensor::pend_dw), held back with the eval-mode BatchNorm's scale / shift
+  std::function<int(const float*, const float*, int, void*, float*, void*, const SeEvalArgs*)> dwfn; const float* esc = nullptr; const float* esh = nullptr;
 };
 Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** pool_out = nullptr, BnHold* hold = nullptr, SeHold* sehold = nullptr) {
   const int C = bn->C;
@@ -862,10 +864,15 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** poo
       const float* ev = (const float*)(e.m->ws + e.m->off_bn_eval) + bn->eval_off;
       e.nbytes = (double)M * C * e.esz() * 2;
       float* pool = pool_out && y->B > 0 ? (float*)e.alloc((size_t)y->B * C * 4) : nullptr;
-      if (fn(ev, ev + C, act, z->p, pool)) *pool_out = pool;
+      if (sehold && pool && !e.dry) {   // a squeeze-and-excite block follows: op_se launches the depthwise kernel, with its own part where it can
+        sehold->armed = true; sehold->dwfn = fn; sehold->esc = ev; sehold->esh = ev + C; sehold->act = act; sehold->z = z->p; sehold->pool = pool;
+        *pool_out = pool;
+        return z;
+      }
+      if (fn(ev, ev + C, act, z->p, pool, nullptr, nullptr) == 1) *pool_out = pool;
       return z;
     }
-    fn(nullptr, nullptr, 0, y->p, nullptr);  // a residual is added by the separate pass below: run the plain convolution first
+    fn(nullptr, nullptr, 0, y->p, nullptr, nullptr, nullptr);  // a residual is added by the separate pass below: run the plain convolution first
   }
   float* ss = (float*)e.alloc((size_t)2 * C * 4);
   float* mr = (float*)e.alloc((size_t)2 * C * 4);
@@ -958,15 +965,21 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
     // inference: the BatchNorm that follows runs in this kernel's epilogue (launched by op_bn_act)
     Exec* ep = &e;
     const void* xp = x->p; const void* wf = w->fwd; const float* bp = bias ? bias->p : nullptr;
-    y->pend_dw = [=](const float* esc, const float* esh, int act, void* out, float* pool) -> bool {
+    // -> 0: out written, no pool; 1: out + pool sums; 2: se_out = out * gate written (the squeeze-and-excite block ran in the same launch)
+    y->pend_dw = [=](const float* esc, const float* esh, int act, void* out, float* pool, void* se_out, const SeEvalArgs* se) -> int {
       WORK((*ep), 18.0 * (double)B * OH * OW * C, ((double)B * H * W + (double)B * OH * OW) * C * ep->esz());
       // small maps: whole image x 64 channels per workgroup, which also leaves the squeeze-and-excite pool complete
       bool img = false;
-      if (esc && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W)
+      if (esc && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W) {
+        if (se && se_out) {
+          LCH((*ep), img = launch_dwconv_eval_img(ep->dt, xp, wf, bp, esc, esh, act, se_out, nullptr, B, H, W, C, ep->s, se));
+          if (img) return 2;
+        }
         LCH((*ep), img = launch_dwconv_eval_img(ep->dt, xp, wf, bp, esc, esh, act, out, pool, B, H, W, C, ep->s));
-      if (img) return pool != nullptr;
+      }
+      if (img) return pool != nullptr ? 1 : 0;
       LCH((*ep), launch_dwconv(ep->dt, 0, xp, wf, bp, out, B, H, W, C, OH, OW, stride, pt, pl, 0, nullptr, ep->s, esc, esh, act));
-      return false;
+      return 0;
     };
     return y;
   }
@@ -1628,6 +1641,14 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr, SeHold
   Tensor* gate = e.newt(B, C);
   Tensor* y = e.newt(x->rows, C, B, x->H, x->W);
   bool fused = false;
+  if (sh && sh->armed && sh->dwfn) {
+    // inference: depthwise 3x3 + eval BatchNorm + SiLU + pool + MLP + x*gate in ONE launch where the grid is resident at once
+    SeEvalArgs a{g_sebox.box, g_sebox.images, eb->se_r.fwd, eb->se_rb.p, eb->se_e.fwd, eb->se_eb.p, S};
+    const int r = sh->dwfn(sh->esc, sh->esh, sh->act, sh->z, sh->pool, y->p, g_sebox.box ? &a : nullptr);
+    fused = r == 2;
+    if (r == 0) poolsum = nullptr;   // the generic depthwise kernel left no pool: the squeeze-and-excite kernel pools by itself
+    sh->armed = false; sh->dwfn = nullptr;
+  }
   if (sh && sh->armed) {
     // BatchNorm + activation + pool + MLP + x*gate in ONE launch (the image's workgroups hand the pool and the hidden layer to each other).
     // The activated tensor x is stored only if something will read it: the backward recomputes it from the BatchNorm's input whenever

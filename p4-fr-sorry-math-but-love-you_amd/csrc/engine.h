@@ -88,7 +88,7 @@ struct Tensor {
   // inference: a product whose launch is postponed until the BatchNorm that consumes it is known, so that BatchNorm (eval
   // statistics) + activation + residual run in its epilogue and the raw output is never written (op_gemm -> op_bn_act)
   std::shared_ptr<GemmP> pend; int pend_mode = 0;
-  std::function<bool(const float* escale, const float* eshift, int act, void* out, float* pool)> pend_dw;  // same for a depthwise conv
+  std::function<int(const float* escale, const float* eshift, int act, void* out, float* pool, void* se_out, const SeEvalArgs* se)> pend_dw;  // same for a depthwise conv
 };
 
 struct SwinBlock { LNp n1, n2; Wt qkv, proj, fc1, fc2; Vec bqkv, bproj, b1, b2, rpb; int dim = 0, heads = 0, res = 0, ws = 0, shift = 0; float drop_path = 0.f; int geo = -1; };

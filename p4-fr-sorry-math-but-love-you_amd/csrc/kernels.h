@@ -31,6 +31,7 @@ extern WgPartCtx g_wgpart;
 struct SeBoxCtx { unsigned long long* box = nullptr; int images = 0; bool bwd = false /*the squeeze-and-excite backward may use it too*/; };
 extern SeBoxCtx g_sebox;
 unsigned se_next_tag();
+bool se_box_usable(hipStream_t s);   // false while `s` is being captured into a hipGraph
 unsigned* device_error_word();   // device address of the error word (bit 2: a mailbox wait timed out)
 void launch_fold4(const float* part, int nrep, long stride, long n, float* out, hipStream_t s);   // launch_fold with 16-byte accesses (n, stride % 4 == 0)
 void det_overflow_warn(size_t need_floats);
@@ -200,8 +201,11 @@ void launch_dwconv(int dt, int mode /*0 fwd,1 dgrad*/, const void* x, const void
                    const float* escale = nullptr, const float* eshift = nullptr, int eact = 0 /*inference (mode 0): y = act(conv*escale[c] + eshift[c])*/);
 // inference, stride 1, whole image x 64 channels per workgroup: out = act((dw3x3(x) + bias)*escale + eshift), pool[b][c] = sum over the
 // image of out (optional; complete, no atomics).  false = shape not taken
+// se != null: the squeeze-and-excite block behind it in the same launch -- out = act(...) * sigmoid(W2 silu(W1 mean + b1) + b2); false when the
+// grid would not be resident at once (the image's workgroups exchange the hidden layer through se->box, see SeBoxCtx) or the shape is not taken
+struct SeEvalArgs { unsigned long long* box; int box_images; const void* W1; const float* b1; const void* W2; const float* b2; int S; };
 bool launch_dwconv_eval_img(int dt, const void* x, const void* wp, const float* dwbias, const float* escale, const float* eshift, int act, void* out,
-                            float* pool /*[B][C] or null*/, int B, int H, int W, int C, hipStream_t s);
+                            float* pool /*[B][C] or null*/, int B, int H, int W, int C, hipStream_t s, const SeEvalArgs* se = nullptr);
 void launch_image_pool(int dt, const void* x /*[B][HW][C]*/, float* pool /*[B][C] sums over HW*/, int B, int HW, int C, hipStream_t s);
 void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw /*[C][9] torch layout*/, float* dbias,
                          float* scratch10C /*optional zeroed [10][C]: contiguous atomics + scatter*/, int B, int H, int W,

@@ -25,6 +25,11 @@ DEVI void lds8(const float* p, float* o) {   // 8 floats from LDS / memory throu
 DetCtx g_det;
 WgPartCtx g_wgpart;
 SeBoxCtx g_sebox;
+// a mailbox launch must not be captured into a hipGraph: its tag would be replayed and the stale granules of the previous replay would match
+bool se_box_usable(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusNone;
+}
 unsigned se_next_tag() {   // one number per launch that uses a mailbox, whichever kernel (0 is what a fresh mailbox holds)
   static unsigned tag = 0;
   if (++tag == 0) tag = 1;
@@ -554,6 +559,70 @@ __global__ __launch_bounds__(256) void bn_pool_img_kernel(const bf16_t* __restri
 // timeout the kernel flags g_satrn_errflag bit 2 and returns (wrong values, reported by the next read_loss) instead of hanging.
 // Arithmetic and rounding are those of the two kernels it replaces (pool over the STORED bf16 values, gate rounded to bf16).
 extern __device__ unsigned g_satrn_errflag;   // (defined with device_error_read_clear below)
+// The squeeze-and-excite MLP BETWEEN the (image, 64-channel) workgroups of one launch.  In: ps[64] = this workgroup's pooled means (LDS,
+// written and synchronised by the caller); w1r = the 64 columns of reduce-matrix row `tid` that belong to this workgroup's channels and
+// w2r = expand-matrix row `tid` (threads 0..63, requested by the caller long before); hq [NT / 64][64], hs [64], gl [64]: LDS scratch.
+// Out: gl[c] = the gate of channel c of this workgroup as stored (bf16-rounded), after a final barrier; hidden (thread < S, group 0 only
+// meaningful for the caller's u1 / s1 stores) is returned through u_out / s_out.
+struct SeXchg { se_box_t* ibox; unsigned tag; long long t_end; unsigned* err; int NG, S; };
+DEVI void se_exchange_gates(const SeXchg& x, const float* ps, const uint4* w1r, const uint4* w2r, float b1v, float b2v, float (*hq)[64], float* hs, float* gl,
+                            float& u_out, float& s_out) {
+  constexpr int CH = 8;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  // 1. this workgroup's share of the hidden layer: sum over ITS 64 channels of W1[j][c] * mean[c] (its own pool only: no wait)
+  if (tid < x.S) {
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float wv[CH];
+      unpack<bf16_t>(w1r[u], wv);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) a += wv[e] * ps[u * CH + e];
+    }
+    se_box_put(x.ibox + (size_t)blockIdx.y * 64 + tid, x.tag, a);
+  }
+  // 2. gather the image's NG x S shares (thread = hidden unit jj x group lane q; groups q, q + NQ, ... in order, then the NQ lanes in
+  //    order: a fixed summation order whichever workgroup arrives when) -> hidden layer
+  {
+    const int jj = tid & 63, q = tid >> 6, NQ = NT / 64;
+    float a = 0.f;
+    if (jj < x.S)
+      for (int yy = q; yy < x.NG; yy += NQ) {
+        float v;
+        se_box_wait(x.ibox + (size_t)yy * 64 + jj, x.tag, x.t_end, v, x.err);
+        a += v;
+      }
+    hq[q][jj] = a;
+  }
+  __syncthreads();
+  u_out = s_out = 0.f;
+  if (tid < 64) {
+    float v = 0.f;
+    if (tid < x.S) {
+      float a = 0.f;
+      for (int q = 0; q < NT / 64; ++q) a += hq[q][tid];
+      const float uu = a + b1v;
+      v = uu * sigmoidf_(uu);
+      u_out = uu; s_out = v;
+    }
+    hs[tid] = v;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float acc = b2v;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u * CH < x.S) {
+        float wv[CH];
+        unpack<bf16_t>(w2r[u], wv);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) acc += wv[e] * hs[u * CH + e];
+      }
+    }
+    gl[tid] = to_f(from_f<bf16_t>(sigmoidf_(acc)));
+  }
+  __syncthreads();
+}
 struct BnSeP {
   const bf16_t* y; const float* sums; int sums_rep; const float* w; const float* b; float* rm; float* rv; int64_t* nbt;
   float eps, mom, invM, unbias; float* ss; float* mr; bf16_t* z /*null: the activated tensor is not kept*/;
@@ -584,7 +653,7 @@ __global__ __launch_bounds__(256) void bn_pool_se_img_kernel(BnSeP p) {
   for (int k = 0; k < PPT; ++k) raw[k] = ld16(p.y + base + (long)(g + k * G) * C);
   // this thread's row of the expand matrix (threads 0..63: one gate each), requested now, used after two hand-offs
   uint4 w2r[8], w1r[8];
-  float b2v = 0.f;
+  float b2v = 0.f, b1v = 0.f;
   if (tid < SC * CH) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) w2r[u] = ld16(p.W2 + (long)(cb + tid) * S + (u * CH < S ? u * CH : 0));
@@ -592,6 +661,7 @@ __global__ __launch_bounds__(256) void bn_pool_se_img_kernel(BnSeP p) {
     // ... and, threads 0..S-1, the 64 columns of reduce-matrix row `tid` that belong to this workgroup's channels
 #pragma unroll
     for (int u = 0; u < 8; ++u) w1r[u] = ld16(p.W1 + (long)(tid < S ? tid : 0) * C + cb + u * CH);
+    if (tid < S) b1v = p.b1[tid];
   }
   for (int c = tid; c < SC * CH; c += NT) {   // one thread per channel: BatchNorm finalize (bn_act_kernel's arithmetic)
     const int cg = cb + c;
@@ -646,61 +716,15 @@ __global__ __launch_bounds__(256) void bn_pool_se_img_kernel(BnSeP p) {
     p.pooled[(long)img * C + cb + tid] = m;
   }
   __syncthreads();
-  const int NG = C / (SC * CH);
-  se_box_t* ibox = (se_box_t*)p.box + (size_t)img * NG * 64;
-  if (tid < S) {
-    float a = 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      float wv[CH];
-      unpack<bf16_t>(w1r[u], wv);
-#pragma unroll
-      for (int e = 0; e < CH; ++e) a += wv[e] * ps[u * CH + e];
-    }
-    se_box_put(ibox + (size_t)blockIdx.y * 64 + tid, p.tag, a);
-  }
-  // 2. every workgroup gathers the image's NG x S partial sums (thread = hidden unit j x group lane q; groups q, q + NQ, ... in order, then
-  //    the NQ lanes in order: a fixed summation order whichever workgroup arrives when) -> hidden layer
   {
-    const int jj = tid & 63, q = tid >> 6, NQ = NT / 64;
-    float a = 0.f;
-    if (jj < S)
-      for (int yy = q; yy < NG; yy += NQ) {
-        float v;
-        se_box_wait(ibox + (size_t)yy * 64 + jj, p.tag, t_end, v, &g_satrn_errflag);
-        a += v;
-      }
-    hq[q][jj] = a;
+    SeXchg xc;
+    xc.NG = C / (SC * CH); xc.S = S; xc.tag = p.tag; xc.t_end = t_end; xc.err = &g_satrn_errflag;
+    xc.ibox = (se_box_t*)p.box + (size_t)img * xc.NG * 64;
+    float uu, sv;
+    se_exchange_gates(xc, ps, w1r, w2r, b1v, b2v, hq, hs, gl, uu, sv);
+    if (tid < S && blockIdx.y == 0) { p.u1[(long)img * S + tid] = uu; p.s1[(long)img * S + tid] = sv; }
+    if (tid < SC * CH) p.gate[(long)img * C + cb + tid] = from_f<bf16_t>(gl[tid]);
   }
-  __syncthreads();
-  if (tid < 64) {
-    float v = 0.f;
-    if (tid < S) {
-      float a = 0.f;
-      for (int q = 0; q < NT / 64; ++q) a += hq[q][tid];
-      const float uu = a + p.b1[tid];
-      v = uu * sigmoidf_(uu);
-      if (blockIdx.y == 0) { p.u1[(long)img * S + tid] = uu; p.s1[(long)img * S + tid] = v; }
-    }
-    hs[tid] = v;
-  }
-  __syncthreads();
-  if (tid < SC * CH) {
-    float acc = b2v;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (u * CH < S) {
-        float wv[CH];
-        unpack<bf16_t>(w2r[u], wv);
-#pragma unroll
-        for (int e = 0; e < CH; ++e) acc += wv[e] * hs[u * CH + e];
-      }
-    }
-    const bf16_t gb = from_f<bf16_t>(sigmoidf_(acc));
-    p.gate[(long)img * C + cb + tid] = gb;
-    gl[tid] = to_f(gb);
-  }
-  __syncthreads();
   {
     float gv[CH];
     lds8(gl + chunk * CH, gv);
@@ -722,6 +746,7 @@ bool launch_bn_pool_se(int dt, const void* y, const float* sums, int sums_rep, c
                        int B, int HW, int C, int S, int act, hipStream_t s) {
   const bool off = getenv("SATRN_NO_FUSED_POOL_SE") != nullptr;   // read per call: tests compare the fused and the plain forms in one process
   if (off || g_det.on || dt != DT_BF16 || !sums || !box || B > box_images || (C % 64) != 0 || C > 1536 || S > 64 || (S % 8) != 0 || HW <= 0) return false;
+  if (!se_box_usable(s)) return false;
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -1463,15 +1488,22 @@ bool launch_bn_dwconv(int dt, const void* y, const float* sums, int sums_rep, co
 // slab goes to LDS as loaded; the epilogue applies the NEXT BatchNorm's eval scale/shift + activation and -- the workgroup holds the
 // whole image for its 64 channels -- leaves the squeeze-and-excite pool sums complete, no atomics:  pool[img][c] = sum_pix out.
 // Replaces dwconv_s1_kernel (eval epilogue) + the pooling half of se_fwd_kernel on the greedy-decode encoder.
+// se.box != null: the squeeze-and-excite block behind it as well (se_exchange_gates: the image's workgroups hand their shares of the hidden
+// layer to each other) -- out = act(...) * gate, one launch for depthwise + BatchNorm + SiLU + SE on the inference encoder.
+struct SeEvalP { unsigned long long* box; unsigned tag; long long timeout_ticks; const bf16_t* W1; const float* b1; const bf16_t* W2; const float* b2; int S; };
 __global__ __launch_bounds__(512, 4) void dw_eval_img_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* dwbias,
                                                              const float* esc, const float* esh, bf16_t* __restrict__ out, float* pool, int H,
-                                                             int W, int C, int rowpix, int act) {
+                                                             int W, int C, int rowpix, int act, SeEvalP se) {
   typedef bf16_t T;
   constexpr int CH = 8, SC = BDW_SC, RUN = BDW_RUN;
   extern __shared__ __attribute__((aligned(16))) unsigned char bdw_sm[];
   __shared__ float sred[8][SC * CH];
   __shared__ __attribute__((aligned(16))) float cf[3][SC * CH];   // scale, shift, depthwise bias
   __shared__ uint4 wl[9][SC];
+  __shared__ __attribute__((aligned(16))) float se_ps[SC * CH];
+  __shared__ float se_hq[8][64];
+  __shared__ __attribute__((aligned(16))) float se_hs[64];
+  __shared__ __attribute__((aligned(16))) float se_gl[SC * CH];
   uint4* tile = reinterpret_cast<uint4*>(bdw_sm);
   const int tid = threadIdx.x, NT = blockDim.x, G = NT / SC;
   const int chunk = tid % SC, g = tid / SC;
@@ -1503,22 +1535,35 @@ __global__ __launch_bounds__(512, 4) void dw_eval_img_kernel(const bf16_t* __res
       for (int j = 0; j < CH; ++j) acc[p][j] = bb[j];
   }
   bdw_taps<false>(tile, wl, row, ox0, rowpix, chunk, acc);
+  // squeeze-and-excite operands of threads 0..63 (expand-matrix row, 64 columns of reduce-matrix row tid), requested before the pool
+  const long long t_end = se.box ? (long long)wall_clock64() + se.timeout_ticks : 0;
+  uint4 w2r[8], w1r[8];
+  float b2v = 0.f, b1v = 0.f;
+  if (se.box && tid < SC * CH) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w2r[u] = ld16(se.W2 + (long)(cb + tid) * se.S + (u * CH < se.S ? u * CH : 0));
+    b2v = se.b2[cb + tid];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w1r[u] = ld16(se.W1 + (long)(tid < se.S ? tid : 0) * C + cb + u * CH);
+    if (tid < se.S) b1v = se.b1[tid];
+  }
   float sc[CH], sh[CH], s1[CH];
   lds8(cf[0] + chunk * CH, sc); lds8(cf[1] + chunk * CH, sh);
 #pragma unroll
   for (int j = 0; j < CH; ++j) s1[j] = 0.f;
+  uint4 zq[RUN];
 #pragma unroll
   for (int p = 0; p < RUN; ++p) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) acc[p][j] = act_fwd(acc[p][j] * sc[j] + sh[j], esc ? act : 0);
-    const uint4 q = pack<T>(acc[p]);
-    st16(out + base + (long)(row * W + ox0 + p) * C, q);
+    zq[p] = pack<T>(acc[p]);
+    if (!se.box) st16(out + base + (long)(row * W + ox0 + p) * C, zq[p]);
     float r[CH];
-    unpack<T>(q, r);   // the pool sums what the consumer reads (rounded), as se_fwd_kernel did
+    unpack<T>(zq[p], r);   // the pool sums what the consumer reads (rounded), as se_fwd_kernel did
 #pragma unroll
     for (int j = 0; j < CH; ++j) s1[j] += r[j];
   }
-  if (!pool) return;
+  if (!pool && !se.box) return;
 #pragma unroll
   for (int o = SC; o < 64; o <<= 1) {
 #pragma unroll
@@ -1533,12 +1578,32 @@ __global__ __launch_bounds__(512, 4) void dw_eval_img_kernel(const bf16_t* __res
   if (tid < SC * CH) {
     float sum = 0.f;
     for (int wv = 0; wv < NT / 64; ++wv) sum += sred[wv][tid];
-    pool[(long)img * C + cb + tid] = sum;
+    if (pool) pool[(long)img * C + cb + tid] = sum;
+    se_ps[tid] = sum * (1.0f / (float)HW);
+  }
+  if (!se.box) return;
+  __syncthreads();
+  {
+    SeXchg xc;
+    xc.NG = C / (SC * CH); xc.S = se.S; xc.tag = se.tag; xc.t_end = t_end; xc.err = &g_satrn_errflag;
+    xc.ibox = (se_box_t*)se.box + (size_t)img * xc.NG * 64;
+    float uu, sv;
+    se_exchange_gates(xc, se_ps, w1r, w2r, b1v, b2v, se_hq, se_hs, se_gl, uu, sv);
+    float gv[CH];
+    lds8(se_gl + chunk * CH, gv);
+#pragma unroll
+    for (int p = 0; p < RUN; ++p) {
+      float v[CH];
+      unpack<T>(zq[p], v);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) v[j] *= gv[j];
+      st16(out + base + (long)(row * W + ox0 + p) * C, pack<T>(v));
+    }
   }
 }
 // false = shape not taken (the caller launches launch_dwconv with the eval epilogue; the pool stays with the SE kernel)
 bool launch_dwconv_eval_img(int dt, const void* x, const void* wp, const float* dwbias, const float* esc, const float* esh, int act, void* out,
-                            float* pool, int B, int H, int W, int C, hipStream_t s) {
+                            float* pool, int B, int H, int W, int C, hipStream_t s, const SeEvalArgs* se) {
   const bool off = getenv("SATRN_NO_DW_EVAL_IMG") != nullptr;   // read per call: tests compare the two forms in one process
   if (off || dt != DT_BF16 || (C % (8 * BDW_SC)) != 0 || (W % BDW_RUN) != 0) return false;
   const int HW = H * W, NT = (HW / BDW_RUN) * BDW_SC;
@@ -1546,8 +1611,24 @@ bool launch_dwconv_eval_img(int dt, const void* x, const void* wp, const float* 
   const int rowpix = (W + 2) | 1;
   const size_t lds = (size_t)(H + 2) * rowpix * BDW_SC * 16;
   if (lds > 60 * 1024) return false;
+  SeEvalP sp;
+  sp.box = nullptr; sp.tag = 0; sp.timeout_ticks = 200000000LL; sp.W1 = nullptr; sp.b1 = nullptr; sp.W2 = nullptr; sp.b2 = nullptr; sp.S = 0;
+  if (se) {
+    // with the squeeze-and-excite block: the image's workgroups wait for each other, so the WHOLE grid must be resident at once
+    if (getenv("SATRN_NO_DW_EVAL_SE") != nullptr || !se->box || B > se->box_images || se->S > 64 || (se->S % 8) != 0 || C > 1536 || !esc) return false;
+    if (!se_box_usable(s)) return false;
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dw_eval_img_kernel, NT, lds) != hipSuccess || per_cu < 1) return false;
+    if ((long)B * (C / (8 * BDW_SC)) > (long)per_cu * cus) return false;
+    sp.box = se->box; sp.tag = se_next_tag(); sp.W1 = (const bf16_t*)se->W1; sp.b1 = se->b1; sp.W2 = (const bf16_t*)se->W2; sp.b2 = se->b2; sp.S = se->S;
+  }
   hipLaunchKernelGGL(dw_eval_img_kernel, dim3(B, C / (8 * BDW_SC)), dim3(NT), lds, s, (const bf16_t*)x, (const bf16_t*)wp, dwbias, esc, esh, (bf16_t*)out,
-                     pool, H, W, C, rowpix, act);
+                     pool, H, W, C, rowpix, act, sp);
   return true;
 }
 

@@ -665,7 +665,7 @@ bool launch_se_bwd_wide(int dt, const void* dy, const void* x, const void* gate,
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   }
-  if (g_sebox.box && g_sebox.bwd && B <= g_sebox.images && (long)B * G <= 2L * cus) {
+  if (g_sebox.box && g_sebox.bwd && B <= g_sebox.images && (long)B * G <= 2L * cus && se_box_usable(s)) {
     one.err = device_error_word();
     if (one.err) { one.box = g_sebox.box; one.tag = se_next_tag(); }
   }

@@ -554,3 +554,20 @@ def test_eval_encoder_image_tile_depthwise_equals_generic(golden_dir, monkeypatc
     print(f"[eval encoder, image-tile depthwise vs generic] rel err {err:.3e}")
     assert torch.isfinite(b).all()
     assert err < 3e-2
+    # ... and with the squeeze-and-excite block in the same launch (the default) against the depthwise kernel + SE kernel pair, at the
+    # benchmark's batch as well (64 images: the grid must still be resident at once, or the launcher falls back by itself)
+    for B2 in (4, 64):
+        img2, _ = O.det_inputs(B2, cfg["rgb"], H, W, 8, seed=6, pad_tail=0)
+        img2 = img2.cuda()
+        monkeypatch.setenv("SATRN_NO_DW_EVAL_SE", "1")
+        a2 = model.encode(img2).float().clone()
+        monkeypatch.delenv("SATRN_NO_DW_EVAL_SE")
+        for _ in range(3):
+            b2 = model.encode(img2).float().clone()
+        err2 = relerr(b2, a2)
+        print(f"[eval encoder B={B2}, depthwise + SE in one launch vs two] rel err {err2:.3e}")
+        assert torch.isfinite(b2).all()
+        assert err2 < 3e-2
+    import ctypes
+    import satrn_amd
+    assert satrn_amd._lib.load().satrn_device_error(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
