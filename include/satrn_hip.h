@@ -239,6 +239,13 @@ int satrn_se_bwd_bnred_mbox(int dtype, const void* dy, const void* bn_y, const f
                             const void* W1, const void* W2, float* dz2, float* du1, float* ds1_zeroed, void* dpooled, float* P_scratch,
                             float* bn_scratch2, int B, int HW, int C, int S, unsigned long long* mailbox, int mailbox_images, void* stream);
 
+/* Weight gradients of the two SqueezeExcite matrices (timm SqueezeExcite conv_reduce / conv_expand, networks/EfficientSATRN.py:74,84)
+ * from what satrn_se_fwd / satrn_se_bwd left: dW2 [C][S] += dz2^T s1, db2 [C] += colsum(dz2), dW1 [S][C] += du1^T pooled,
+ * db1 [S] += colsum(du1).  All operands fp32 (dz2, pooled [B][C]; du1, s1 [B][S]); the outputs are ACCUMULATED into (the engine's
+ * fp32 gradient buffers).  The sum over the batch is taken in a fixed order (no atomics). */
+int satrn_se_bwd_weights(const float* dz2, const float* du1, const float* s1, const float* pooled, float* dW1, float* db1, float* dW2,
+                         float* db2, int B, int C, int S, void* stream);
+
 /* Adaptive 2D positional encoding, networks/EfficientSATRN.py:135-154: out = x + g0*hpos[h] + g1*wpos[w]
  * with gate [B][2C] = sigmoid(dense1(relu(dense0(mean_hw x)))) computed by satrn_pool_hw + satrn_linear_fwd. */
 int satrn_pool_hw(int dtype, const void* x, void* out, int B, int HW, int C, void* stream);

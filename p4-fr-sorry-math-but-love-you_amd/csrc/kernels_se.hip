@@ -678,30 +678,70 @@ bool launch_se_bwd_wide(int dt, const void* dy, const void* x, const void* gate,
 }
 
 // ---- backward B: weight gradients dW2[c][j] = sum_b dz2[b][c]*s1[b][j], dW1[j][c] = sum_b du1[b][j]*pooled[b][c].
-// thread = (channel c, group of 8 hidden units): no atomics (each thread owns its outputs), 16 accumulators
-__global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* dz2, const float* du1, const float* s1,
-                                                       const float* pooled, float* dW1, float* db1, float* dW2,
+// thread = (channel c, group of 8 hidden units, quarter of the batch): each thread owns 16 accumulators over its batch rows (all their
+// loads in flight at once), the four quarters are added in a fixed order through LDS; no atomics.  64 channels per workgroup: a
+// C = 1536, S = 64 block is 192 workgroups (it was 48 with a 32-deep dependent loop each: 17 us of latency on the side stream)
+__global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* __restrict__ dz2, const float* __restrict__ du1, const float* __restrict__ s1,
+                                                       const float* __restrict__ pooled, float* dW1, float* db1, float* dW2,
                                                        float* db2, int B, int C, int S) {
-  extern __shared__ float sm[];  // s1[B][8] | du1[B][8] for this block's 8 hidden units
-  const int tid = threadIdx.x;
+  extern __shared__ float sm[];  // s1[B][8] | du1[B][8] for this block's 8 hidden units | partials [3][64][17]
+  const int tid = threadIdx.x, cl = tid & 63, bq = tid >> 6;
   const int j0 = blockIdx.y * 8;
+  const int c = blockIdx.x * 64 + cl;
+  float a2[8], a1[8], sb = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a2[j] = a1[j] = 0.f;
+  // the operands of this thread's batch rows are requested before the LDS table is complete
+  float zz[8], pq[8];
+  const int nb = (B - bq + 3) >> 2;   // rows bq, bq + 4, ...
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int b = bq + 4 * i;
+    const bool ok = c < C && i < nb;
+    zz[i] = ok ? dz2[(long)b * C + c] : 0.f;
+    pq[i] = ok ? pooled[(long)b * C + c] : 0.f;
+  }
   for (int i = tid; i < B * 8; i += 256) {
     int b = i >> 3, j = j0 + (i & 7);
     sm[i] = j < S ? s1[b * S + j] : 0.f;
     sm[B * 8 + i] = j < S ? du1[b * S + j] : 0.f;
   }
   __syncthreads();
-  const int c = blockIdx.x * 256 + tid;
-  if (c < C) {
-    float a2[8], a1[8], sb = 0.f;
+  for (int i0 = 0; i0 < nb; i0 += 8) {
+    if (i0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a2[j] = a1[j] = 0.f;
-#pragma unroll 4
-    for (int b = 0; b < B; ++b) {
-      const float z = dz2[(long)b * C + c], pp = pooled[(long)b * C + c];
-      sb += z;
+      for (int i = 0; i < 8; ++i) {
+        const int b = bq + 4 * (i0 + i);
+        const bool ok = c < C && i0 + i < nb;
+        zz[i] = ok ? dz2[(long)b * C + c] : 0.f;
+        pq[i] = ok ? pooled[(long)b * C + c] : 0.f;
+      }
+    }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { a2[j] += z * sm[b * 8 + j]; a1[j] += sm[B * 8 + b * 8 + j] * pp; }
+    for (int i = 0; i < 8; ++i) {
+      if (i0 + i < nb) {
+        const int b = bq + 4 * (i0 + i);
+        sb += zz[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a2[j] += zz[i] * sm[b * 8 + j]; a1[j] += sm[B * 8 + b * 8 + j] * pq[i]; }
+      }
+    }
+  }
+  float* red = sm + 2 * B * 8;
+  if (bq) {
+    float* r = red + ((bq - 1) * 64 + cl) * 17;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { r[j] = a2[j]; r[8 + j] = a1[j]; }
+    r[16] = sb;
+  }
+  __syncthreads();
+  if (bq == 0 && c < C) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float* r = red + (q * 64 + cl) * 17;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a2[j] += r[j]; a1[j] += r[8 + j]; }
+      sb += r[16];
     }
     if (blockIdx.y == 0) db2[c] += sb;
 #pragma unroll
@@ -753,8 +793,8 @@ void launch_se_bwd(int dt, const void* dgate, const void* gate, const float* u1,
     hipLaunchKernelGGL((se_bwd_a_kernel<bf16_t>), dim3(B), dim3(1024), sh, s, (const bf16_t*)dgate, (const bf16_t*)gate, u1, (const bf16_t*)W1, (const bf16_t*)W2, dz2, du1, (bf16_t*)dpooled, C, S);
   else
     hipLaunchKernelGGL((se_bwd_a_kernel<float>), dim3(B), dim3(1024), sh, s, (const float*)dgate, (const float*)gate, u1, (const float*)W1, (const float*)W2, dz2, du1, (float*)dpooled, C, S);
-  size_t sh2 = (size_t)2 * B * 8 * sizeof(float);
+  size_t sh2 = (size_t)(2 * B * 8 + 3 * 64 * 17) * sizeof(float);
   if (parts & 2)
-    hipLaunchKernelGGL(se_bwd_b_kernel, dim3((C + 255) / 256, (S + 7) / 8), dim3(256), sh2, s, dz2, du1, s1, pooled, dW1, db1, dW2,
+    hipLaunchKernelGGL(se_bwd_b_kernel, dim3((C + 63) / 64, (S + 7) / 8), dim3(256), sh2, s, dz2, du1, s1, pooled, dW1, db1, dW2,
                      db2, B, C, S);
 }

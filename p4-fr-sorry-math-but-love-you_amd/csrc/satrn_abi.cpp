@@ -420,6 +420,14 @@ int satrn_se_bwd_bnred_mbox(int dt, const void* dy, const void* bn_y, const floa
   if (!okw) return fail(-1, "satrn_se_bwd_bnred_mbox: the wide form does not take this dtype / shape (use satrn_se_bwd + satrn_batchnorm_act_bwd)");
   return done("se_bwd_bnred_mbox");
 }
+int satrn_se_bwd_weights(const float* dz2, const float* du1, const float* s1, const float* pooled, float* dW1, float* db1, float* dW2, float* db2,
+                         int B, int C, int S, void* st) {
+  if (B <= 0 || C <= 0 || S <= 0) return fail(-1, "satrn_se_bwd_weights: bad shape");
+  if (!dz2 || !du1 || !s1 || !pooled || !dW1 || !db1 || !dW2 || !db2) return fail(-1, "satrn_se_bwd_weights: null operand");
+  launch_se_bwd(DT_F32, nullptr, nullptr, nullptr, s1, pooled, nullptr, nullptr, const_cast<float*>(dz2), const_cast<float*>(du1), nullptr, dW1, db1, dW2, db2,
+                B, C, S, S(st), 2);
+  return done("se_bwd_weights");
+}
 int satrn_pool_hw(int dt, const void* x, void* out, int B, int HW, int C, void* st) {
   CHK_DT(dt);
   if (chk_c(dt, C, "C")) return -1;

@@ -1099,6 +1099,26 @@ def test_batchnorm_act_squeeze_excite_one_launch(lib, dt, B, HW, C, S, monkeypat
     close(rmd, rmd2.cpu(), "f32", "running mean", f32_tol=1e-5)
 
 
+@pytest.mark.parametrize("B,C,S", [(32, 1536, 64), (2, 96, 8), (3, 1288, 56), (40, 960, 40), (5, 160, 8), (70, 200, 12)])
+def test_squeeze_excite_weight_gradients(lib, B, C, S):
+    """Weight gradients of timm SqueezeExcite's conv_reduce / conv_expand (networks/EfficientSATRN.py:74,84) over the batch: the
+    side-stream kernel of the training step (threads split the batch in quarters and add them in a fixed order), accumulated
+    into non-zero gradient buffers; batches above 32 take its second round of operand loads."""
+    dz2, pooled = rnd(B, C, seed=1), rnd(B, C, seed=2)
+    du1, s1 = rnd(B, S, seed=3), rnd(B, S, seed=4)
+    g0 = [rnd(S, C, seed=5), rnd(S, seed=6), rnd(C, S, seed=7), rnd(C, seed=8)]
+    gd = [dev(g.clone()) for g in g0]
+    for rep in range(2):   # run-to-run identical (fixed summation order)
+        cur = [dev(g.clone()) for g in g0]
+        ok(lib, lib.satrn_se_bwd_weights(P(dev(dz2)), P(dev(du1)), P(dev(s1)), P(dev(pooled)), P(cur[0]), P(cur[1]), P(cur[2]), P(cur[3]), B, C, S, st()))
+        torch.cuda.synchronize()
+        if rep: assert all(torch.equal(a, b) for a, b in zip(cur, gd))
+        gd = cur
+    ref = [g0[0] + du1.t() @ pooled, g0[1] + du1.sum(0), g0[2] + dz2.t() @ s1, g0[3] + dz2.sum(0)]
+    for got, want, nm in zip(gd, ref, ("dW1", "db1", "dW2", "db2")):
+        close(got, want, "f32", "se " + nm)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("B,HW,C,S,wide", [(3, 48, 1536, 64, False), (3, 48, 1536, 64, True), (2, 192, 960, 40, True), (4, 192, 512, 32, True),
                                             (2, 35, 96, 8, False), (2, 192, 256, 16, True),
