@@ -117,6 +117,7 @@ struct WgradP {
   long sY_o, sY_i, sA_o, sA_i, sW_o, sW_i;  // element strides per outer/inner batch index
   int ldw;                                 // out_t==1: row stride of dW
   float* det_part;                         // deterministic mode (set by launch_wgrad): [split][N][K] partial slabs
+  int launch_order;                        // 1: (tile, slice) in launch order instead of slice-major per XCD (A/B: SATRN_WGRAD_LAUNCH_ORDER, set by launch_wgrad)
   float* dbias;                            // optional (dense, !out_t): dbias[n] += sum_m dY[m][n], accumulated by the k-tile-0 workgroups from the dY
                                            // chunks they stage anyway (was a separate launch_colsum pass over dY)
 };

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
   const int tiles_x = (Wimg + HC_TW - 1) / HC_TW, tiles_y = (Himg + HC_TH - 1) / HC_TH;
   const int ntn = (p.N + BN - 1) / BN;
-  int bid = blockIdx.x;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);   // the n-tiles of a spatial patch (and neighbouring patches) share one XCD's L2
   const int tile_n = bid % ntn; bid /= ntn;
   const int txi = bid % tiles_x; bid /= tiles_x;
   const int tyi = bid % tiles_y;
@@ -807,13 +807,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntk = (p.K + BKW - 1) / BKW;
-  const int tile_k = blockIdx.x % ntk, tile_n = blockIdx.x / ntk;
+  // XCD-aware (tile, slice of M) assignment: workgroups are dealt round-robin to the eight XCDs, each with its own L2, and only the
+  // tiles of ONE slice share operands (an n-tile row shares dY columns, a k-tile column shares X columns).  In launch order
+  // (tile fastest) every XCD got the same few tiles of EVERY slice, so each slice of dY / X was fetched by up to eight L2s; dealt
+  // slice-major, an XCD owns whole slices (or a contiguous run of one slice's tiles) and a slice is fetched once or twice.
+  const int lin0 = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+  const int lin = p.launch_order ? lin0 : xcd_remap(lin0, (int)(gridDim.x * gridDim.y));
+  const int split = lin / (int)gridDim.x, tile = lin - split * (int)gridDim.x;
+  const int tile_k = tile % ntk, tile_n = tile / ntk;
   const int n0 = tile_n * BNW, k0 = tile_k * BKW;
   const int z = blockIdx.z;
   const int zo = z / p.nb_inner, zi = z % p.nb_inner;
   const T* dY = (const T*)p.dY + zo * p.sY_o + zi * p.sY_i;
   const T* A = (const T*)p.A + zo * p.sA_o + zi * p.sA_i;
-  const int m_begin = blockIdx.y * rows_per_split;
+  const int m_begin = split * rows_per_split;
   const int m_end = min(p.M, m_begin + rows_per_split);
 
   const int cy = tid % CPN, cx = tid % CPK;  // chunk column of this thread in each tile (fixed: 256 % CPx == 0)
@@ -936,7 +943,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split
           *op = from_f<T>(p.out_accum ? to_f(*op) + acc[i][j][r] : acc[i][j][r]);
         } else {
           long dst;
-          if (p.det_part) { p.det_part[((size_t)blockIdx.y * p.N + n) * p.K + k] = acc[i][j][r]; continue; }  // folded afterwards
+          if (p.det_part) { p.det_part[((size_t)split * p.N + n) * p.K + k] = acc[i][j][r]; continue; }  // folded afterwards
           if (CONV && !p.conv_packed_out) { int tp = k / p.Ci, c = k - tp * p.Ci; dst = ((long)n * p.Ci + c) * taps + tp; }
           else dst = (long)n * p.K + k;
           atomicAdd((float*)p.dW + dst, acc[i][j][r]);
@@ -991,6 +998,8 @@ static void launch_wgrad_tile(const WgradP& p, hipStream_t s) {
   rps = ((rps + MS - 1) / MS) * MS;
   splits = (p.M + rps - 1) / rps;
   WgradP q = p;
+  static const bool launch_order = getenv("SATRN_WGRAD_LAUNCH_ORDER") != nullptr;   // A/B (tools/ab_bench.sh), read once
+  q.launch_order = launch_order ? 1 : 0;
   q.det_part = det ? det_scratch(s, (size_t)splits * p.N * p.K) : nullptr;
   // (measured: the partial-tile slab of the persistent kernel for this kernel's split-M sums instead of atomics -- 10.56 vs 10.47 ms per
   // EfficientSATRN step, one more side launch per weight gradient -- not kept)
