@@ -92,6 +92,10 @@ struct GemmP {
   // [9216][1536], becomes one multiply); the consumer then passes bact = ACT_DFACTOR
   int pre_grad;
   int dbg_no_stats_atomics;   // timing experiment (SATRN_TIMING_NO_STATS_ATOMICS; wrong statistics)
+  // AM_DGRAD with stride 2 (set by launch_gemm): rows are dealt to the workgroups by PARITY CLASS of the output pixel ((oy + pt) & 1,
+  // (ox + pl) & 1) -- a class meets only 4 / 2 / 2 / 1 of the nine taps, so a workgroup's k loop visits those taps only (2.25 on
+  // average instead of 9 of which 6.75 staged zeros).  Needs OH, OW even and M / 4 a multiple of the tile height.
+  int dgrad_classes;
   float bact_scale;   // times this (ReLU + dropout: bact_u is the stored OUTPUT, whose zeros cover both, and 1/(1-p) the kept ones' scale); 0 = 1
 };
 // eval-mode BatchNorm scale / shift of every BatchNorm of a model in ONE launch: out[0..C) = w * rsqrt(rv + eps),

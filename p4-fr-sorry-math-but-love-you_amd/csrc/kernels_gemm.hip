@@ -56,6 +56,17 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
 
   // ---- per-thread staging assignments (chunk column is the same for all of a thread's chunks)
   const int cc = tid % CPR;
+  // stride-2 data gradient by parity classes (GemmP::dgrad_classes): logical row -> (class, image, y / 2, x / 2) -> output pixel
+  const bool cls = AM == AM_DGRAD && p.dgrad_classes != 0;
+  const int Mc = p.M >> 2, cid = cls ? m0 / Mc : 0, cls_y = cid >> 1, cls_x = cid & 1;   // uniform per workgroup (Mc % BM == 0)
+  const int cls_nth = cls_y ? 1 : 2, cls_ntw = cls_x ? 1 : 2;
+  const int Keff = cls ? cls_nth * cls_ntw * p.Ci : p.K;
+  auto real_row = [&](int ml) -> int {
+    if (!cls) return ml;
+    const int q = ml - cid * Mc, ow2 = p.OW >> 1, hw2 = (p.OH >> 1) * ow2;
+    const int b = q / hw2, r = q - b * hw2, yy = r / ow2, xx = r - yy * ow2;
+    return (b * p.OH + 2 * yy + ((cls_y + p.pt) & 1)) * p.OW + 2 * xx + ((cls_x + p.pl) & 1);
+  };
   RowInfo<AM> ri[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -63,6 +74,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
     int row = idx / CPR;
     int m = m0 + row;
     ri[i].ok = (idx < BM * CPR) && (m < p.M);
+    if (AM == AM_DGRAD) m = real_row(m);
     if (AM == AM_DENSE) {
       ri[i].img = m;
       ri[i].by = ri[i].bx = 0;
@@ -87,13 +99,19 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
     for (int pj = 0; pj < KP / G; ++pj) {
       const int pp = grp + pj * G;   // this group's panels (register slot pj)
       const int k0 = (kt * KP + pp) * 32 + cc * CH;
-      const bool kok = k0 < p.K;
-      int kh = 0, kw = 0, ci = 0;
+      const bool kok = k0 < Keff;
+      int kh = 0, kw = 0, ci = 0, kreal = k0;
       if (AM != AM_DENSE) {
         int tap = k0 / p.Ci;
         ci = k0 - tap * p.Ci;
-        kh = (p.KW == 1) ? 0 : (tap * 11) >> 5;
-        kw = tap - kh * p.KW;
+        if (AM == AM_DGRAD && cls) {   // the class's taps only: kh = cls_y ? 1 : {0, 2}, kw likewise
+          const int th = cls_x ? tap : tap >> 1, tw = tap - th * cls_ntw;
+          kh = cls_y ? 1 : 2 * th; kw = cls_x ? 1 : 2 * tw;
+          kreal = (kh * 3 + kw) * p.Ci + ci;
+        } else {
+          kh = (p.KW == 1) ? 0 : (tap * 11) >> 5;
+          kw = tap - kh * p.KW;
+        }
       }
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
@@ -135,7 +153,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
           if constexpr (PF == 2) { rb[S][pj][i] = gload16_async(src); continue; }
           v = ld16(src);
         } else if (ok) {
-          v = ld16(Bw + (long)n * p.K + k0);
+          v = ld16(Bw + (long)n * p.K + kreal);
         }
         rb[S][pj][i] = as_u32x4(v);
       }
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + 32 * KP - 1) / (32 * KP);
+  const int nk = (Keff + 32 * KP - 1) / (32 * KP);
   const int fr = lane & 15, fq = lane >> 4;
   auto compute = [&](int cur) {
 #pragma unroll
@@ -274,6 +292,14 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
   T* stg = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(lds) + 32 * BN);
   const bool stage_out = STG && !p.out_f32 && (p.ldc & 7) == 0 && (p.N & 7) == 0 && (((size_t)p.C) & 15) == 0;
   if (p.stats || stage_out) __syncthreads();  // all waves are done reading the last k-panel
+  int rrow[MT][4];   // output rows of this lane's accumulator rows (the logical row except in the parity-class data gradient)
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rl = m0 + wave * (BM / 4) + i * 16 + fq * 4 + r;
+      rrow[i][r] = rl >= p.M ? p.M : (AM == AM_DGRAD ? real_row(rl) : rl);
+    }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + j * 16 + fr;
@@ -286,7 +312,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wave * (BM / 4) + i * 16 + fq * 4 + r;
+        const int row = rrow[i][r];
         if (row >= p.M || col >= p.N || !writer) continue;
         const long o = (long)row * p.ldc + col;
         float v = acc[i][j][r] * esc + esh + bias;
@@ -339,7 +365,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
       const int rl = idx / CPRW, cc8 = idx - rl * CPRW;
       const int row = m0 + rl, col = n0 + cc8 * 8;
       if (idx < BM * CPRW && row < p.M && col < p.N)
-        st16(c + (long)row * p.ldc + col, ld16(stg + rl * BN + ((cc8 ^ ((rl >> 2) & (CPRW - 1))) << 3)));
+        st16(c + (long)(AM == AM_DGRAD ? real_row(row) : row) * p.ldc + col, ld16(stg + rl * BN + ((cc8 ^ ((rl >> 2) & (CPRW - 1))) << 3)));
     }
   }
   if (p.stats) {
@@ -362,7 +388,12 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
 }
 
 template <typename T, int AM>
-static void launch_gemm_t(const GemmP& p, hipStream_t s) {
+static void launch_gemm_t(const GemmP& p_in, hipStream_t s) {
+  GemmP p = p_in;
+  p.dgrad_classes = 0;
+  if (AM == AM_DGRAD && p.stride == 2 && p.KW == 3 && (p.OH & 1) == 0 && (p.OW & 1) == 0 && (p.M & 3) == 0 && ((p.M >> 2) % 256) == 0 &&
+      (long)p.M == (long)(p.M / (p.OH * p.OW)) * p.OH * p.OW && getenv("SATRN_DGRAD_NO_CLASSES") == nullptr /* A/B, read per call (tests) */)
+    p.dgrad_classes = 1;
   // tile choice: narrow-N problems get tall tiles; small problems get small tiles to fill 256 CUs; deep-K dense
   // problems stage several k-panels per barrier (64 KiB of LDS per block at most)
   constexpr bool BF = sizeof(T) == 2;

@@ -382,6 +382,46 @@ def test_conv3x3(lib, dt, B, H, W, Ci, Co, s):
     close(dw, wr.grad, dt, f"conv3x3_bwd_weight s{s}")
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,H,W,Ci,Co,pt,pl", [(2, 32, 64, 24, 96, 0, 0), (2, 32, 64, 24, 96, 1, 1), (1, 64, 32, 24, 40, 0, 1), (2, 32, 64, 48, 64, 0, 0),
+                                               (4, 16, 32, 8, 16, 1, 0)])
+def test_conv3x3_stride2_data_gradient_by_parity_classes(lib, monkeypatch, dt, B, H, W, Ci, Co, pt, pl):
+    """Data gradient of a stride-2 3x3 convolution (timm EfficientNetV2-S stage entries behind networks/EfficientSATRN.py:74) with the
+    output pixels dealt to the workgroups by parity class, each class visiting only the taps that reach it (4 / 2 / 2 / 1 of 9):
+    against fp32 torch, and EQUAL to the all-taps form where a tap is whole k-steps (the skipped ones only ever added zeros), also when
+    accumulating."""
+    monkeypatch.setenv("SATRN_CONV_BIG", "0")   # the tile kernel (the persistent kernel takes N >= 32 in bf16 otherwise)
+    s = 2
+    x, w = q(rnd(B, Ci, H, W, seed=1), dt), q(rnd(Co, Ci, 3, 3, seed=2, scale=1 / math.sqrt(9 * Ci)), dt)
+    OH, OW = H // 2, W // 2
+    pads = (pl, 1 - pl, pt, 1 - pt)
+    fwd = torch.empty(Co, 9, Ci, dtype=tdt(dt), device="cuda")
+    bwd = torch.empty(Ci, 9, Co, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_pack_conv3x3(dti(dt), P(dev(w)), P(fwd), P(bwd), Co, Ci, st()))
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv2d(F.pad(xr, pads), w, None, s, 0)
+    assert ref.shape[2:] == (OH, OW)
+    dy = q(rnd(*ref.shape, seed=5), dt)
+    ref.backward(dy)
+    dyd = dev(nhwc(dy), dt)
+    base = q(rnd(B, H, W, Ci, seed=9), dt)
+    outs = []
+    for no_classes in (False, True):
+        if no_classes: monkeypatch.setenv("SATRN_DGRAD_NO_CLASSES", "1")
+        dx = torch.empty(B, H, W, Ci, dtype=tdt(dt), device="cuda")
+        ok(lib, lib.satrn_conv3x3_bwd_data(dti(dt), P(dyd), P(bwd), P(dx), B, H, W, Ci, Co, OH, OW, s, pt, pl, 0, st()))
+        acc = dev(base, dt)
+        ok(lib, lib.satrn_conv3x3_bwd_data(dti(dt), P(dyd), P(bwd), P(acc), B, H, W, Ci, Co, OH, OW, s, pt, pl, 1, st()))
+        outs.append((dx.float().cpu(), acc.float().cpu()))
+        close(nchw(dx.float()), xr.grad, dt, f"conv3x3_bwd_data s2 (all taps: {no_classes})")
+        close(nchw(acc.float()), xr.grad + base.permute(0, 3, 1, 2), dt, f"conv3x3_bwd_data s2 accumulate (all taps: {no_classes})")
+    if Co % 32 == 0:   # whole 32-deep k-steps per tap: the all-taps form's extra k-steps are all zeros, the sums are the same sums
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "parity-class form differs from the all-taps form"
+    else:              # k-steps straddle taps: the same terms grouped differently
+        close(outs[0][0], outs[1][0], dt, "parity classes vs all taps", f32_tol=2e-6, bf16_tol=1e-2)
+        close(outs[0][1], outs[1][1], dt, "parity classes vs all taps (accumulate)", f32_tol=2e-6, bf16_tol=1e-2)
+
+
 @pytest.mark.parametrize("B,H,W,Ci,Co,s", [(2, 16, 24, 48, 192, 1), (3, 9, 7, 128, 64, 1), (2, 9, 20, 256, 64, 1), (2, 32, 96, 48, 192, 1), (4, 16, 48, 64, 256, 1),
                                            (2, 13, 11, 24, 72, 1), (2, 8, 12, 72, 136, 1), (2, 16, 24, 192, 48, 1), (3, 11, 13, 136, 40, 1),   # the last two: 64-column tiles
                                            (2, 16, 24, 48, 192, 2), (2, 15, 21, 24, 96, 2), (2, 32, 96, 24, 48, 2), (3, 17, 9, 64, 40, 2)])   # stride 2
