@@ -93,6 +93,10 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
   // 12 iterations, 16-22 us)
   constexpr int PF = (BM * BN <= 64 * 64 && AM == AM_DENSE) ? 2 : 1;
   u32x4 ra[PF][KP / G][NA], rb[PF][KP / G][NB];
+  // convolution modes: which of a stage's A chunks are real (inside the image, a tap the pixel meets); the loads themselves are
+  // unconditional (an always-valid address) and the zero is selected in store_tiles -- a load under a branch is waited for on the spot
+  // (vmcnt(0)), which made the chunks of a k-step one round trip EACH
+  uint32_t amask[PF][KP / G];
   auto load_tiles = [&](int kt, auto SET) {
     constexpr int S = decltype(SET)::value;
 #pragma unroll
@@ -113,6 +117,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
           kw = tap - kh * p.KW;
         }
       }
+      uint32_t am = 0;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         uint4 v = zero16();
@@ -124,24 +129,24 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
           const T* src = A + (ok ? (long)ri[i].img * p.lda + k0 : 0L);
           if constexpr (PF == 2) { ra[S][pj][i] = gload16_async(src); continue; }
           v = ld16(src);
-        } else if (ri[i].ok && kok) {
-          if (AM == AM_DENSE) {
-            v = ld16(A + (long)ri[i].img * p.lda + k0);
-          } else if (AM == AM_CONV) {
-            int sy = ri[i].by + kh, sx = ri[i].bx + kw;
-            if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
-              v = ld16(A + ((long)(ri[i].img + sy * p.W + sx)) * p.Ci + ci);
+        } else {
+          bool ok = ri[i].ok && kok;
+          int sy, sx;
+          if (AM == AM_CONV) {
+            sy = ri[i].by + kh; sx = ri[i].bx + kw;
+            ok = ok && sy >= 0 && sx >= 0;
           } else {
-            int ty = ri[i].by - kh, tx = ri[i].bx - kw;
-            if (ty >= 0 && tx >= 0) {
-              int sy = ty / p.stride, sx = tx / p.stride;
-              if (sy * p.stride == ty && sx * p.stride == tx && sy < p.H && sx < p.W)
-                v = ld16(A + ((long)(ri[i].img + sy * p.W + sx)) * p.Ci + ci);
-            }
+            const int ty = ri[i].by - kh, tx = ri[i].bx - kw;
+            sy = ty / p.stride; sx = tx / p.stride;
+            ok = ok && ty >= 0 && tx >= 0 && sy * p.stride == ty && sx * p.stride == tx;
           }
+          ok = ok && sy < p.H && sx < p.W;
+          v = ld16(A + (ok ? ((long)(ri[i].img + sy * p.W + sx)) * p.Ci + ci : 0L));
+          am |= (ok ? 1u : 0u) << i;
         }
         ra[S][pj][i] = as_u32x4(v);
       }
+      amask[S][pj] = am;
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         int idx = tid + i * 256;
@@ -152,8 +157,8 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
           const T* src = Bw + (ok ? (long)n * p.K + k0 : 0L);
           if constexpr (PF == 2) { rb[S][pj][i] = gload16_async(src); continue; }
           v = ld16(src);
-        } else if (ok) {
-          v = ld16(Bw + (long)n * p.K + kreal);
+        } else {
+          v = ld16(Bw + (ok ? (long)n * p.K + kreal : 0L));   // zero selected in store_tiles
         }
         rb[S][pj][i] = as_u32x4(v);
       }
@@ -175,19 +180,21 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
       const int pp = grp + pj * G;
       T* la = lds + buf * STAGE + pp * (BM + BN) * 32;
       T* lb = la + BM * 32;
-      const bool kok = (kt * KP + pp) * 32 + cc * CH < p.K;
+      const bool kok = (kt * KP + pp) * 32 + cc * CH < Keff;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         int idx = tid + i * 256;
         uint4 v = as_uint4(ra[S][pj][i]);
-        if constexpr (AM == AM_DENSE) { if (!(ri[i].ok && kok)) v = zero16(); }  // dense loads are unconditional (see load_tiles)
+        // the loads are unconditional (see load_tiles)
+        if constexpr (AM == AM_DENSE) { if (!(ri[i].ok && kok)) v = zero16(); }
+        else { if (!((amask[S][pj] >> i) & 1u)) v = zero16(); }
         if (idx < BM * CPR) st16(la + panel_chunk<T>(idx / CPR, cc), v);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         int idx = tid + i * 256;
         uint4 v = as_uint4(rb[S][pj][i]);
-        if constexpr (AM == AM_DENSE) { if (!(n0 + idx / CPR < p.N && kok)) v = zero16(); }
+        if (!(n0 + idx / CPR < p.N && kok)) v = zero16();
         if (idx < BN * CPR) st16(lb + panel_chunk<T>(idx / CPR, cc), v);
       }
     }
@@ -387,13 +394,27 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
   }
 }
 
+// stride-2 3x3 data gradient by parity classes of the output pixels (GemmP::dgrad_classes): a class is whole tiles of any height
+static bool dgrad_classes_ok(const GemmP& p) {
+  return p.stride == 2 && p.KW == 3 && (p.OH & 1) == 0 && (p.OW & 1) == 0 && (p.M & 3) == 0 && ((p.M >> 2) % 256) == 0 &&
+         (long)p.M == (long)(p.M / (p.OH * p.OW)) * p.OH * p.OW && getenv("SATRN_DGRAD_NO_CLASSES") == nullptr /* A/B, read per call (tests) */;
+}
+
 template <typename T, int AM>
 static void launch_gemm_t(const GemmP& p_in, hipStream_t s) {
   GemmP p = p_in;
-  p.dgrad_classes = 0;
-  if (AM == AM_DGRAD && p.stride == 2 && p.KW == 3 && (p.OH & 1) == 0 && (p.OW & 1) == 0 && (p.M & 3) == 0 && ((p.M >> 2) % 256) == 0 &&
-      (long)p.M == (long)(p.M / (p.OH * p.OW)) * p.OH * p.OW && getenv("SATRN_DGRAD_NO_CLASSES") == nullptr /* A/B, read per call (tests) */)
-    p.dgrad_classes = 1;
+  p.dgrad_classes = (AM == AM_DGRAD && dgrad_classes_ok(p)) ? 1 : 0;
+  if constexpr (AM == AM_DGRAD) {
+    // tile height of the narrow (<= 32 channels) parity-class data gradient: tools/dgrad_s2_time.py
+    // (96 -> 24 channels at 32 x 64 x 192: 256 rows 92 us, 128 rows 67 us, 64 rows 75 us; knob read per call)
+    if (p.dgrad_classes && p.N <= 32) {
+      const char* bm = getenv("SATRN_DGRAD_BM");
+      const int h = bm ? atoi(bm) : 128;
+      auto blk = [&](int m) { return (long)((p.M + m - 1) / m) * ((p.N + 31) / 32); };
+      if (h == 128) { hipLaunchKernelGGL((gemm_kernel<T, 128, 32, AM, 1>), dim3(blk(128)), dim3(256), 0, s, p); return; }
+      if (h == 64) { hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, 1>), dim3(blk(64)), dim3(256), 0, s, p); return; }
+    }
+  }
   // tile choice: narrow-N problems get tall tiles; small problems get small tiles to fill 256 CUs; deep-K dense
   // problems stage several k-panels per barrier (64 KiB of LDS per block at most)
   constexpr bool BF = sizeof(T) == 2;
@@ -772,7 +793,10 @@ void launch_gemm(int dt, int amode, const GemmP& p0, hipStream_t s) {
     // SATRN_CONV_BIG=0 (read per call: tests) keeps the halo kernel.
     const char* cb = getenv("SATRN_CONV_BIG");
     const int conv_min_n = getenv("SATRN_CONV_BIG_MIN_N") ? atoi(getenv("SATRN_CONV_BIG_MIN_N")) : 32;   // knob (read per call: tests)
-    if (!(cb && atoi(cb) == 0) && !p.stats_part && dt == DT_BF16 && (amode == AM_CONV || amode == AM_DGRAD) && p.N >= conv_min_n &&
+    // (a stride-2 data gradient that splits into parity classes stays on the tile kernel, which then skips the taps a class never
+    // meets: 192 -> 48 channels at 32 x 32 x 96, 45 us against 66 us here with all nine taps staged -- tools/dgrad_s2_time.py)
+    const bool by_classes = amode == AM_DGRAD && dgrad_classes_ok(p) && getenv("SATRN_DGRAD_CLASSES_BIG") == nullptr;
+    if (!(cb && atoi(cb) == 0) && !p.stats_part && dt == DT_BF16 && (amode == AM_CONV || amode == AM_DGRAD) && p.N >= conv_min_n && !by_classes &&
         gemm_big_conv_launch(amode, p, s)) return;
   }
   if (!p.stats_part && dt == DT_BF16 && amode != AM_DENSE && conv_halo_launch(amode, p, s)) return;
