@@ -124,14 +124,17 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int 
   const int TX = 1 << tx_log2, TY = 256 >> tx_log2;
   const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> tx_log2;
   const int CC = C / CH;
-  const int cbase = blockIdx.y * TX;
+  // consecutive row blocks of one channel group on one XCD (its L2): the depthwise weight gradient's row blocks share their halo image rows
+  const int lin = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+  const int bx = lin % (int)gridDim.x, by = lin / (int)gridDim.x;
+  const int cbase = by * TX;
   const int c = cbase + tx;
   float acc[NO][CH];
 #pragma unroll
   for (int k = 0; k < NO; ++k)
 #pragma unroll
     for (int j = 0; j < CH; ++j) acc[k][j] = 0.f;
-  const long r0 = (long)blockIdx.x * rows_per_block;
+  const long r0 = (long)bx * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > M) r1 = M;
   if (c < CC) {
@@ -149,9 +152,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int 
       for (int y = 0; y < TY; ++y) sum += red[y * TX * CH + i];
       int col = cbase * CH + i;
       if (col < C) {
-        // deterministic mode: this row block's partial goes to its own slot [blockIdx.x][k][col]; colreduce_fold_kernel
+        // deterministic mode: this row block's partial goes to its own slot [row block][k][col]; colreduce_fold_kernel
         // adds the row blocks in ascending order
-        if (part) { part[((size_t)blockIdx.x * NO + k) * C + col] = sum; continue; }
+        if (part) { part[((size_t)bx * NO + k) * C + col] = sum; continue; }
         // nmain < 0: k-major o0[k*C + col] (contiguous atomics).  Else sums k < nmain go to o0[col*nmain + k] and the
         // remaining one to o1[col]
         if (nmain < 0) atomicAdd(o0 + (long)k * C + col, sum);
