@@ -101,6 +101,16 @@ void Exec::join() {
 }
 
 static const bool g_stage_prof = getenv("SATRN_STAGE_PROF") != nullptr;
+// replicas of a GEMM epilogue's column-sum target (BatchNorm statistics / BatchNorm-backward sums): tall products with few columns put
+// thousands of same-address float atomics on 2 x C words; the row tiles spread them over `rep` copies which the consumer adds.
+// SATRN_STATS_REP_SCALE (knob, read once) multiplies the replica count of the shapes that have replicas (tools/ab_bench.sh).
+static int stats_rep_for(int C, long rows) {
+  if (g_det.on) return 1;
+  const int base = (C <= 64 && rows >= 65536) ? 16 : ((C <= 256 && rows >= 16384) ? 4 : 1);
+  static const int sc = getenv("SATRN_STATS_REP_SCALE") ? atoi(getenv("SATRN_STATS_REP_SCALE")) : 1;   // n: times n; -n: divided by n
+  if (base == 1 || sc == 0 || sc == 1) return base;
+  return sc > 0 ? std::min(base * sc, 64) : std::max(base / -sc, 1);
+}
 void Exec::mark(const char* name) {
   if (!g_stage_prof || dry) return;
   hipEvent_t ev; (void)hipEventCreate(&ev);
@@ -729,7 +739,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
   }
   if (want_stats && e.train) {
     // tall, narrow outputs (early backbone stages): many row tiles hit the same 2N addresses -> spread over replicas
-    const int rep = g_det.on ? 1 : ((N <= 64 && M >= 65536) ? 16 : ((N <= 256 && M >= 16384) ? 4 : 1));  // deterministic mode folds into ONE [2N]
+    const int rep = stats_rep_for(N, M);  // deterministic mode folds into ONE [2N]
     y->stats = e.zalloc((size_t)rep * 2 * N); y->stats_rep = rep; p.stats = y->stats; p.stats_rep = rep;
   }
   if (geo) { p.H = geo->H; p.W = geo->W; p.Ci = geo->Ci; p.OH = geo->OH; p.OW = geo->OW; p.KW = geo->KW; p.stride = geo->stride; p.pt = geo->pt; p.pl = geo->pl; }
@@ -801,7 +811,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       memset(&d, 0, sizeof(d));
       d.A = dY; d.Bw = w->bwd; d.C = dx; d.beta = beta;
       if (fuse_bnb) {
-        const int rep = g_det.on ? 1 : ((x->C <= 64 && x->rows >= 65536) ? 16 : ((x->C <= 256 && x->rows >= 16384) ? 4 : 1));
+        const int rep = stats_rep_for(x->C, x->rows);
         x->bn_red = e.zalloc((size_t)rep * 2 * x->C); x->bn_red_rep = rep;
         d.stats = x->bn_red; d.stats_rep = rep; d.bnb_y = x->bn_y; d.bnb_ss = x->bn_ss; d.bnb_mr = x->bn_mr; d.bnb_act = x->bn_act;
       }
