@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
   // PF register sets: small tiles (the latency-bound late-stage products: 192-1152 workgroups, one or two per CU) keep TWO
   // k-stages of global loads in flight -- with one, every k iteration cost a full far round trip (M=1536 N=256 K=1536:
   // 12 iterations, 16-22 us)
-  constexpr int PF = (BM * BN <= 64 * 64 && AM == AM_DENSE) ? 2 : 1;
+  // (the data gradient's loads are unconditional as well since round 3: its narrow tiles -- the stride-2 stage entries by parity class --
+  // get the second register set too)
+  constexpr int PF = ((BM * BN <= 64 * 64 && AM == AM_DENSE) || (BM * BN <= 128 * 64 && BM <= 128 && AM == AM_DGRAD)) ? 2 : 1;
   u32x4 ra[PF][KP / G][NA], rb[PF][KP / G][NB];
   // convolution modes: which of a stage's A chunks are real (inside the image, a tap the pixel meets); the loads themselves are
   // unconditional (an always-valid address) and the zero is selected in store_tiles -- a load under a branch is waited for on the spot
@@ -141,8 +143,10 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
             ok = ok && ty >= 0 && tx >= 0 && sy * p.stride == ty && sx * p.stride == tx;
           }
           ok = ok && sy < p.H && sx < p.W;
-          v = ld16(A + (ok ? ((long)(ri[i].img + sy * p.W + sx)) * p.Ci + ci : 0L));
           am |= (ok ? 1u : 0u) << i;
+          const T* src = A + (ok ? ((long)(ri[i].img + sy * p.W + sx)) * p.Ci + ci : 0L);
+          if constexpr (PF == 2) { ra[S][pj][i] = gload16_async(src); continue; }
+          v = ld16(src);
         }
         ra[S][pj][i] = as_u32x4(v);
       }
@@ -158,7 +162,9 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
           if constexpr (PF == 2) { rb[S][pj][i] = gload16_async(src); continue; }
           v = ld16(src);
         } else {
-          v = ld16(Bw + (ok ? (long)n * p.K + kreal : 0L));   // zero selected in store_tiles
+          const T* src = Bw + (ok ? (long)n * p.K + kreal : 0L);   // zero selected in store_tiles
+          if constexpr (PF == 2) { rb[S][pj][i] = gload16_async(src); continue; }
+          v = ld16(src);
         }
         rb[S][pj][i] = as_u32x4(v);
       }
