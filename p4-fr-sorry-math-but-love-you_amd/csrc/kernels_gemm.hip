@@ -49,7 +49,15 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // position inside the group
   const int ntn = (p.N + BN - 1) / BN;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = wg % ntn, tile_m = wg / ntn;
+  const int tile_n = wg % ntn;
+  int tile_m_ = wg / ntn;
+  if (AM == AM_DGRAD && p.dgrad_classes) {
+    // parity classes (see GemmP::dgrad_classes): the two x-parity tiles over the same pixels run next to each other (same XCD, same
+    // time), so the 128-byte lines they each half-fill meet in one L2 before the write-back; tile_m_ becomes the class-major index
+    const int Tc = (p.M >> 2) / BM, cy = tile_m_ / (2 * Tc), rest = tile_m_ - cy * 2 * Tc;
+    tile_m_ = (cy * 2 + (rest & 1)) * Tc + (rest >> 1);
+  }
+  const int tile_m = tile_m_;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const T* A = (const T*)p.A;
   const T* Bw = (const T*)p.Bw;
@@ -61,10 +69,24 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
   const int Mc = p.M >> 2, cid = cls ? m0 / Mc : 0, cls_y = cid >> 1, cls_x = cid & 1;   // uniform per workgroup (Mc % BM == 0)
   const int cls_nth = cls_y ? 1 : 2, cls_ntw = cls_x ? 1 : 2;
   const int Keff = cls ? cls_nth * cls_ntw * p.Ci : p.K;
+  // (quotients through the float reciprocal + one correction while the operands are exact in a float: an integer division is ~40
+  // instructions and the epilogue maps every accumulator row)
+  const bool small_m = p.M < (1 << 23);
+  auto qdiv = [&](int n, int d, float rd) -> int {
+    if (!small_m) return n / d;
+    int qd = (int)((float)n * rd);
+    const int r = n - qd * d;
+    qd += r >= d ? 1 : (r < 0 ? -1 : 0);
+    return qd;
+  };
+  const float r_ohw = AM != AM_DENSE ? 1.0f / (float)(p.OH * p.OW) : 0.f, r_OW = AM != AM_DENSE ? 1.0f / (float)p.OW : 0.f;
+  const float r_Ci = AM != AM_DENSE ? 1.0f / (float)p.Ci : 0.f;
+  const int ow2 = p.OW >> 1, hw2 = (p.OH >> 1) * ow2;
+  const float r_ow2 = cls ? 1.0f / (float)ow2 : 0.f, r_hw2 = cls ? 1.0f / (float)hw2 : 0.f;
   auto real_row = [&](int ml) -> int {
     if (!cls) return ml;
-    const int q = ml - cid * Mc, ow2 = p.OW >> 1, hw2 = (p.OH >> 1) * ow2;
-    const int b = q / hw2, r = q - b * hw2, yy = r / ow2, xx = r - yy * ow2;
+    const int q = ml - cid * Mc;
+    const int b = qdiv(q, hw2, r_hw2), r = q - b * hw2, yy = qdiv(r, ow2, r_ow2), xx = r - yy * ow2;
     return (b * p.OH + 2 * yy + ((cls_y + p.pt) & 1)) * p.OW + 2 * xx + ((cls_x + p.pl) & 1);
   };
   RowInfo<AM> ri[NA];
@@ -79,9 +101,9 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
       ri[i].img = m;
       ri[i].by = ri[i].bx = 0;
     } else {
-      int ohw = p.OH * p.OW;
-      int b = m / ohw, r = m - b * ohw;
-      int oy = r / p.OW, ox = r - oy * p.OW;
+      const int ohw = p.OH * p.OW;
+      const int b = qdiv(m, ohw, r_ohw), r = m - b * ohw;
+      const int oy = qdiv(r, p.OW, r_OW), ox = r - oy * p.OW;
       ri[i].img = b * p.H * p.W;
       if (AM == AM_CONV) { ri[i].by = oy * p.stride - p.pt; ri[i].bx = ox * p.stride - p.pl; }
       else { ri[i].by = oy + p.pt; ri[i].bx = ox + p.pl; }
@@ -91,9 +113,9 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
   // PF register sets: small tiles (the latency-bound late-stage products: 192-1152 workgroups, one or two per CU) keep TWO
   // k-stages of global loads in flight -- with one, every k iteration cost a full far round trip (M=1536 N=256 K=1536:
   // 12 iterations, 16-22 us)
-  // (the data gradient's loads are unconditional as well since round 3: its narrow tiles -- the stride-2 stage entries by parity class --
-  // get the second register set too)
-  constexpr int PF = ((BM * BN <= 64 * 64 && AM == AM_DENSE) || (BM * BN <= 128 * 64 && BM <= 128 && AM == AM_DGRAD)) ? 2 : 1;
+  // (measured for the data gradient's narrow tiles as well, whose loads are unconditional since round 3: 71.9 / 44.7 us with either
+  // depth on the two stride-2 stage entries -- not kept)
+  constexpr int PF = (BM * BN <= 64 * 64 && AM == AM_DENSE) ? 2 : 1;
   u32x4 ra[PF][KP / G][NA], rb[PF][KP / G][NB];
   // convolution modes: which of a stage's A chunks are real (inside the image, a tap the pixel meets); the loads themselves are
   // unconditional (an always-valid address) and the zero is selected in store_tiles -- a load under a branch is waited for on the spot
@@ -108,7 +130,8 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
       const bool kok = k0 < Keff;
       int kh = 0, kw = 0, ci = 0, kreal = k0;
       if (AM != AM_DENSE) {
-        int tap = k0 / p.Ci;
+        int tap = (int)((float)k0 * r_Ci);   // k0 < 2^23: exact in a float, one correction
+        { const int rr = k0 - tap * p.Ci; tap += rr >= p.Ci ? 1 : (rr < 0 ? -1 : 0); }
         ci = k0 - tap * p.Ci;
         if (AM == AM_DGRAD && cls) {   // the class's taps only: kh = cls_y ? 1 : {0, 2}, kw likewise
           const int th = cls_x ? tap : tap >> 1, tw = tap - th * cls_ntw;
@@ -139,14 +162,14 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
             ok = ok && sy >= 0 && sx >= 0;
           } else {
             const int ty = ri[i].by - kh, tx = ri[i].bx - kw;
-            sy = ty / p.stride; sx = tx / p.stride;
+            if (p.stride == 1) { sy = ty; sx = tx; }
+            else if (p.stride == 2) { sy = ty >> 1; sx = tx >> 1; }
+            else { sy = ty / p.stride; sx = tx / p.stride; }
             ok = ok && ty >= 0 && tx >= 0 && sy * p.stride == ty && sx * p.stride == tx;
           }
           ok = ok && sy < p.H && sx < p.W;
           am |= (ok ? 1u : 0u) << i;
-          const T* src = A + (ok ? ((long)(ri[i].img + sy * p.W + sx)) * p.Ci + ci : 0L);
-          if constexpr (PF == 2) { ra[S][pj][i] = gload16_async(src); continue; }
-          v = ld16(src);
+          v = ld16(A + (ok ? ((long)(ri[i].img + sy * p.W + sx)) * p.Ci + ci : 0L));
         }
         ra[S][pj][i] = as_u32x4(v);
       }
@@ -162,9 +185,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
           if constexpr (PF == 2) { rb[S][pj][i] = gload16_async(src); continue; }
           v = ld16(src);
         } else {
-          const T* src = Bw + (ok ? (long)n * p.K + kreal : 0L);   // zero selected in store_tiles
-          if constexpr (PF == 2) { rb[S][pj][i] = gload16_async(src); continue; }
-          v = ld16(src);
+          v = ld16(Bw + (ok ? (long)n * p.K + kreal : 0L));   // zero selected in store_tiles
         }
         rb[S][pj][i] = as_u32x4(v);
       }
