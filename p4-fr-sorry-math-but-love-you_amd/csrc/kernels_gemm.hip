@@ -912,6 +912,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split
   if (CONV) { xtap = xcol / p.Ci; xci = xcol - xtap * p.Ci; }
   const int xkh = CONV ? ((p.KW == 1) ? 0 : (xtap * 11) >> 5) : 0, xkw = CONV ? xtap - xkh * p.KW : 0;
 
+  const bool small_m = p.M < (1 << 23);
+  const float r_ohw = CONV ? 1.0f / (float)(p.OH * p.OW) : 0.f, r_OW = CONV ? 1.0f / (float)p.OW : 0.f;
   uint4 ry[NCY], rx[NCX];
   auto load_tiles = [&](int mstep) {
 #pragma unroll
@@ -925,9 +927,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split
       uint4 v = zero16();
       if (m < m_end && xok) {
         if (CONV) {
-          int ohw = p.OH * p.OW;
-          int b = m / ohw, r = m - b * ohw;
-          int oy = r / p.OW, ox = r - oy * p.OW;
+          // (quotients through float reciprocals + one correction while m is exact in a float: two integer divisions per chunk and
+          // M-step were ~80 instructions beside 16 bytes of load)
+          const int ohw = p.OH * p.OW;
+          int b, oy;
+          if (small_m) {
+            b = (int)((float)m * r_ohw);
+            { const int rr = m - b * ohw; b += rr >= ohw ? 1 : (rr < 0 ? -1 : 0); }
+          } else b = m / ohw;
+          const int r = m - b * ohw;
+          if (small_m) {
+            oy = (int)((float)r * r_OW);
+            { const int rr = r - oy * p.OW; oy += rr >= p.OW ? 1 : (rr < 0 ? -1 : 0); }
+          } else oy = r / p.OW;
+          const int ox = r - oy * p.OW;
           int sy = oy * p.stride - p.pt + xkh, sx = ox * p.stride - p.pl + xkw;
           if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) v = ld16(A + ((long)(b * p.H * p.W + sy * p.W + sx)) * p.Ci + xci);
         } else {
