@@ -1872,12 +1872,25 @@ void launch_dwconv(int dt, int mode, const void* x, const void* wp, const float*
 static constexpr int DWW_BLK = 512, DWW_RPT = 8;   // target grid / rows per thread of the depthwise weight gradient (tools/elem_bench.cpp sweeps)
 template <typename T> struct DwWgradF {
   const T* x; const T* dy; int H, W, C, OH, OW, stride, pt, pl;
+  float rOW, rOHW; int small;   // reciprocals for the row decomposition while rows are exact in a float (small != 0)
   __device__ void prep(int) {}
   __device__ void operator()(long r, int c0, float (*acc)[TT<T>::CH]) const {
     constexpr int CH = TT<T>::CH;
-    int ox = (int)(r % OW);
-    int oy = (int)((r / OW) % OH);
-    int b = (int)(r / ((long)OW * OH));
+    int ox, oy, b;
+    if (small) {
+      // three 64-bit divisions per row were several hundred instructions beside ten 16-byte loads and 80 multiply-adds
+      const int ri = (int)r, ohw = OW * OH;
+      b = (int)((float)ri * rOHW);
+      { const int rr = ri - b * ohw; b += rr >= ohw ? 1 : (rr < 0 ? -1 : 0); }
+      const int rem = ri - b * ohw;
+      oy = (int)((float)rem * rOW);
+      { const int rr = rem - oy * OW; oy += rr >= OW ? 1 : (rr < 0 ? -1 : 0); }
+      ox = rem - oy * OW;
+    } else {
+      ox = (int)(r % OW);
+      oy = (int)((r / OW) % OH);
+      b = (int)(r / ((long)OW * OH));
+    }
     float d[CH];
     unpack<T>(ld16(dy + r * C + c0), d);
 #pragma unroll
@@ -2143,7 +2156,7 @@ __global__ void dw_wgrad_scatter_kernel(const float* tmp, float* dw, float* dbia
 void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw, float* dbias, float* scratch10C, int B, int H,
                          int W, int C, int OH, int OW, int stride, int pt, int pl, hipStream_t s) {
   DISPATCH_T(dt, {
-    DwWgradF<T> f{(const T*)x, (const T*)dy, H, W, C, OH, OW, stride, pt, pl};
+    DwWgradF<T> f{(const T*)x, (const T*)dy, H, W, C, OH, OW, stride, pt, pl, 1.0f / (float)OW, 1.0f / ((float)OW * (float)OH), (long)B * OH * OW < (1L << 23) ? 1 : 0};
     if (scratch10C) {
       launch_colreduce<T, 10>(f, (long)B * OH * OW, C, scratch10C, nullptr, -1, s, DWW_RPT, DWW_BLK, DWW_BLK);
       hipLaunchKernelGGL(dw_wgrad_scatter_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, s, scratch10C, dw, dbias, C);
