@@ -92,6 +92,7 @@ struct GemmP {
   // [9216][1536], becomes one multiply); the consumer then passes bact = ACT_DFACTOR
   int pre_grad;
   int dbg_no_stats_atomics;   // timing experiment (SATRN_TIMING_NO_STATS_ATOMICS; wrong statistics)
+  int no_stage_y;             // A/B (SATRN_GEMM_NO_STAGE_Y, set by launch_gemm): the BatchNorm-backward operand read element-wise from global
   // AM_DGRAD with stride 2 (set by launch_gemm): rows are dealt to the workgroups by PARITY CLASS of the output pixel ((oy + pt) & 1,
   // (ox + pl) & 1) -- a class meets only 4 / 2 / 2 / 1 of the nine taps, so a workgroup's k loop visits those taps only (2.25 on
   // average instead of 9 of which 6.75 staged zeros).  Needs OH, OW even and M / 4 a multiple of the tile height.

@@ -42,7 +42,10 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
   constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;
   constexpr int MT = BM / 64, NT = BN / 16;
   constexpr int STAGE = KP * (BM + BN) * 32;
-  __shared__ __attribute__((aligned(16))) T lds[2 * STAGE];
+  // small dense bf16 tiles also stage the BatchNorm-backward operand tile of the epilogue (y, see STGY below) behind the output image
+  constexpr bool STGY = sizeof(T) == 2 && AM == AM_DENSE && G == 1 && (32 * BN + 4 * BM * BN) <= 24 * 1024;
+  constexpr int LDS_ELEMS = (STGY && (32 * BN + 4 * BM * BN) / (int)sizeof(T) > 2 * STAGE) ? (32 * BN + 4 * BM * BN) / (int)sizeof(T) : 2 * STAGE;
+  __shared__ __attribute__((aligned(16))) T lds[LDS_ELEMS];
 
   static_assert(G == 1 || (KP % G) == 0, "k-panels per stage must divide among the groups");
   const int grp = G == 1 ? 0 : (int)(threadIdx.x >> 8);   // 0 .. G-1
@@ -325,7 +328,30 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
   constexpr bool STG = sizeof(T) == 2 && (32 * BN + BM * BN * 2 <= 2 * STAGE * (int)sizeof(T));
   T* stg = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(lds) + 32 * BN);
   const bool stage_out = STG && !p.out_f32 && (p.ldc & 7) == 0 && (p.N & 7) == 0 && (((size_t)p.C) & 15) == 0;
-  if (p.stats || stage_out) __syncthreads();  // all waves are done reading the last k-panel
+  // STGY: the BatchNorm-backward operand y[row][col] (row stride N) is read per accumulator element below -- straight from global that is
+  // one 2-byte element per lane, 16 lanes = 32 contiguous bytes per row and instruction.  Its tile is fetched as 16-byte chunks instead
+  // (requested here, before the barrier), laid out like the output image and read back from LDS element by element.
+  const bool stage_y = STGY && p.bnb_y != nullptr && !p.no_stage_y && (p.N & 7) == 0 && ((((size_t)p.bnb_y) & 15) == 0);
+  T* ytile = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(lds) + 32 * BN + BM * BN * 2);
+  constexpr int YCH = STGY ? (BM * (BN / 8) + 255) / 256 : 1;
+  uint4 ych[YCH];
+  if (STGY && stage_y) {
+#pragma unroll
+    for (int q = 0; q < YCH; ++q) {
+      const int idx = tid + q * 256, rl = idx / (BN / 8), cc8 = idx - rl * (BN / 8);
+      const int row = m0 + rl, col = n0 + cc8 * 8;
+      ych[q] = (idx < BM * (BN / 8) && row < p.M && col < p.N) ? ld16((const T*)p.bnb_y + (long)row * p.N + col) : zero16();
+    }
+  }
+  if (p.stats || stage_out || stage_y) __syncthreads();  // all waves are done reading the last k-panel
+  if (STGY && stage_y) {
+#pragma unroll
+    for (int q = 0; q < YCH; ++q) {
+      const int idx = tid + q * 256, rl = idx / (BN / 8), cc8 = idx - rl * (BN / 8);
+      if (idx < BM * (BN / 8)) st16(ytile + rl * BN + ((cc8 ^ ((rl >> 2) & (BN / 8 - 1))) << 3), ych[q]);
+    }
+    __syncthreads();
+  }
   int rrow[MT][4];   // output rows of this lane's accumulator rows (the logical row except in the parity-class data gradient)
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -375,7 +401,13 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
           }
         }
         if (p.bnb_y) {
-          const float yv = to_f(((const T*)p.bnb_y)[(long)row * p.N + col]);
+          float yv;
+          if (STGY && stage_y) {
+            const int rl = wave * (BM / 4) + i * 16 + fq * 4 + r, cl = j * 16 + fr;
+            yv = to_f(ytile[rl * BN + ((((cl >> 3) ^ ((rl >> 2) & (BN / 8 - 1))) << 3) | (cl & 7))]);
+          } else {
+            yv = to_f(((const T*)p.bnb_y)[(long)row * p.N + col]);
+          }
           const float g = tot * act_bwd(yv * bsc + bsh, p.bnb_act);
           s1 += g; s2 += g * ((yv - bmu) * brs);
         } else {
@@ -810,6 +842,7 @@ void launch_gemm(int dt, int amode, const GemmP& p0, hipStream_t s) {
   {
     static const bool nsa = [] { const bool on = getenv("SATRN_TIMING_NO_STATS_ATOMICS") != nullptr; if (on) fprintf(stderr, "[satrn] WARNING: SATRN_TIMING_NO_STATS_ATOMICS is set -- BatchNorm statistics are NOT accumulated (timing experiment)\n"); return on; }();
     p.dbg_no_stats_atomics = nsa ? 1 : 0;
+    p.no_stage_y = getenv("SATRN_GEMM_NO_STAGE_Y") != nullptr ? 1 : 0;   // A/B, read per call (tests)
   }
   const int nslots = (p.M + 63) / 64;
   if (p.stats) p.stats_part = det_scratch(s, (size_t)(nslots + 4) * 2 * p.N);  // null unless the deterministic mode is on
