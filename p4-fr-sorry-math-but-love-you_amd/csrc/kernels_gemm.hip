@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
   constexpr int MT = BM / 64, NT = BN / 16;
   constexpr int STAGE = KP * (BM + BN) * 32;
   // small dense bf16 tiles also stage the BatchNorm-backward operand tile of the epilogue (y, see STGY below) behind the output image
-  constexpr bool STGY = sizeof(T) == 2 && AM == AM_DENSE && G == 1 && (32 * BN + 4 * BM * BN) <= 24 * 1024;
+  constexpr bool STGY = sizeof(T) == 2 && AM == AM_DENSE && (32 * BN + 4 * BM * BN) <= 24 * 1024;
   constexpr int LDS_ELEMS = (STGY && (32 * BN + 4 * BM * BN) / (int)sizeof(T) > 2 * STAGE) ? (32 * BN + 4 * BM * BN) / (int)sizeof(T) : 2 * STAGE;
   __shared__ __attribute__((aligned(16))) T lds[LDS_ELEMS];
 
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
   T* ytile = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(lds) + 32 * BN + BM * BN * 2);
   constexpr int YCH = STGY ? (BM * (BN / 8) + 255) / 256 : 1;
   uint4 ych[YCH];
-  if (STGY && stage_y) {
+  if (STGY && stage_y && grp == 0) {   // (two wave groups: the first one, which alone writes the tile, stages the operand)
 #pragma unroll
     for (int q = 0; q < YCH; ++q) {
       const int idx = tid + q * 256, rl = idx / (BN / 8), cc8 = idx - rl * (BN / 8);
@@ -345,10 +345,12 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
   }
   if (p.stats || stage_out || stage_y) __syncthreads();  // all waves are done reading the last k-panel
   if (STGY && stage_y) {
+    if (grp == 0) {
 #pragma unroll
-    for (int q = 0; q < YCH; ++q) {
-      const int idx = tid + q * 256, rl = idx / (BN / 8), cc8 = idx - rl * (BN / 8);
-      if (idx < BM * (BN / 8)) st16(ytile + rl * BN + ((cc8 ^ ((rl >> 2) & (BN / 8 - 1))) << 3), ych[q]);
+      for (int q = 0; q < YCH; ++q) {
+        const int idx = tid + q * 256, rl = idx / (BN / 8), cc8 = idx - rl * (BN / 8);
+        if (idx < BM * (BN / 8)) st16(ytile + rl * BN + ((cc8 ^ ((rl >> 2) & (BN / 8 - 1))) << 3), ych[q]);
+      }
     }
     __syncthreads();
   }
