@@ -343,13 +343,37 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
       ych[q] = (idx < BM * (BN / 8) && row < p.M && col < p.N) ? ld16((const T*)p.bnb_y + (long)row * p.N + col) : zero16();
     }
   }
-  if (p.stats || stage_out || stage_y) __syncthreads();  // all waves are done reading the last k-panel
-  if (STGY && stage_y) {
-    if (grp == 0) {
+  // STGB: the same for the accumulate operand (beta: the output tile's existing values, read back per element): its chunks go into the
+  // output image itself -- a thread reads and then overwrites exactly its own elements there.  Small tiles only (registers).
+  constexpr bool STGB = STG && BM * BN <= 64 * 64;
+  const bool stage_beta = STGB && stage_out && p.beta && !p.no_stage_y;
+  constexpr int BCH = STGB ? (BM * (BN / 8) + 255) / 256 : 1;
+  uint4 bch[BCH];
+  if (STGB && stage_beta && grp == 0) {
+    const T* c = (const T*)p.C;
 #pragma unroll
-      for (int q = 0; q < YCH; ++q) {
-        const int idx = tid + q * 256, rl = idx / (BN / 8), cc8 = idx - rl * (BN / 8);
-        if (idx < BM * (BN / 8)) st16(ytile + rl * BN + ((cc8 ^ ((rl >> 2) & (BN / 8 - 1))) << 3), ych[q]);
+    for (int q = 0; q < BCH; ++q) {
+      const int idx = tid + q * 256, rl = idx / (BN / 8), cc8 = idx - rl * (BN / 8);
+      const int row = m0 + rl, col = n0 + cc8 * 8;
+      bch[q] = (idx < BM * (BN / 8) && row < p.M && col < p.N) ? ld16(c + (long)(AM == AM_DGRAD ? real_row(row) : row) * p.ldc + col) : zero16();
+    }
+  }
+  if (p.stats || stage_out || stage_y) __syncthreads();  // all waves are done reading the last k-panel
+  if ((STGY && stage_y) || (STGB && stage_beta)) {
+    if (grp == 0) {
+      if (STGY && stage_y) {
+#pragma unroll
+        for (int q = 0; q < YCH; ++q) {
+          const int idx = tid + q * 256, rl = idx / (BN / 8), cc8 = idx - rl * (BN / 8);
+          if (idx < BM * (BN / 8)) st16(ytile + rl * BN + ((cc8 ^ ((rl >> 2) & (BN / 8 - 1))) << 3), ych[q]);
+        }
+      }
+      if (STGB && stage_beta) {
+#pragma unroll
+        for (int q = 0; q < BCH; ++q) {
+          const int idx = tid + q * 256, rl = idx / (BN / 8), cc8 = idx - rl * (BN / 8);
+          if (idx < BM * (BN / 8)) st16(stg + rl * BN + ((cc8 ^ ((rl >> 2) & (BN / 8 - 1))) << 3), bch[q]);
+        }
       }
     }
     __syncthreads();
@@ -394,11 +418,13 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
           c[o] = tot;
         } else {
           T* c = (T*)p.C;
-          tot = p.beta ? to_f(c[o]) + v : v;
           if (STG && stage_out) {
             const int rl = wave * (BM / 4) + i * 16 + fq * 4 + r, cl = j * 16 + fr;
-            stg[rl * BN + ((((cl >> 3) ^ ((rl >> 2) & (BN / 8 - 1))) << 3) | (cl & 7))] = from_f<T>(tot);
+            T* sp = stg + rl * BN + ((((cl >> 3) ^ ((rl >> 2) & (BN / 8 - 1))) << 3) | (cl & 7));
+            tot = p.beta ? ((STGB && stage_beta) ? to_f(*sp) : to_f(c[o])) + v : v;
+            *sp = from_f<T>(tot);
           } else {
+            tot = p.beta ? to_f(c[o]) + v : v;
             c[o] = from_f<T>(tot);
           }
         }
