@@ -152,7 +152,7 @@ int satrn_batchnorm_act_fwd(int dtype, const void* y, const float* weight, const
 /* Training-mode BatchNorm2d + activation + the squeeze-and-excite block behind it (timm MBConv: bn2 -> SiLU -> SqueezeExcite, run by
  * networks/EfficientSATRN.py:74-76): z = act(bn(y)), pooled = mean over the image, u1 = W1 pooled + b1, s1 = silu(u1),
  * gate = sigmoid(W2 s1 + b2), out = z * gate.  One launch on the small maps (bf16, C % 64 == 0, C <= 1536, S <= 64, S % 8 == 0,
- * B * C / 64 workgroups within three per compute unit): the workgroups of an image hand their shares of the hidden layer to each
+ * B * C / 64 workgroups all resident at once -- asked of the occupancy query for the instantiation that would run): the workgroups of an image hand their shares of the hidden layer to each
  * other through `mailbox` -- mailbox_images * 1600 8-byte words that are ZERO before the first call and that nothing else writes
  * (a launch number tags every word, so the mailbox is never cleared between calls).  Other shapes / dtypes: the separate kernels.
  * keep_z == 0: z need not hold the activated tensor afterwards (the engine's backward recomputes it from y); z must be a valid
@@ -232,7 +232,7 @@ int satrn_se_bwd_bnred(int dtype, const void* dy, const void* bn_y, const float*
 /* The same in ONE launch, given a mailbox (mailbox_images * 1600 8-byte words, ZERO before the first use, written by nothing but the
  * mailbox operators -- the one of satrn_batchnorm_act_se_fwd can be shared): the workgroups of an image exchange their shares of
  * W2^T dz2 through it and add them in a fixed order (no float atomics on ds1: that part is deterministic); ds1_zeroed then receives
- * the sums (it need not be zero).  B > mailbox_images, B * 8 workgroups beyond two per compute unit, or mailbox == NULL: the two
+ * the sums (it need not be zero).  B > mailbox_images, B * 8 workgroups beyond what the device holds resident at once (occupancy query for the kernel), or mailbox == NULL: the two
  * launches of satrn_se_bwd_bnred.  A hand-off that times out sets device error bit 2.  (Alone on the device the one launch is
  * shorter; inside the engine's training step, beside the weight-gradient stream, it measured slower and the engine keeps the two.) */
 int satrn_se_bwd_bnred_mbox(int dtype, const void* dy, const void* bn_y, const float* bn_scratch, int act, const void* gate, const float* u1,
@@ -469,6 +469,13 @@ int satrn_model_bind_optimizer(satrn_model* m, float* exp_avg, float* exp_avg_sq
  * train_modules/train_single_opt.py:78); the kernels skip the element and set the bit instead of reading out of bounds.
  * satrn_model_read_loss checks the word too and fails with -6. */
 int satrn_device_error(void* stream);
+/* Diagnostics: how many launches took each kernel ROUTE since the last reset (host-side counters, no synchronisation).  Tests use it
+ * to assert that a shape really ran on the kernel they mean to cover (the large-shape routes are chosen by size thresholds inside the
+ * launchers).  out[i], i < n: 0 persistent GEMM (dense), 1 persistent GEMM (3x3 convolution / data gradient), 2 persistent weight
+ * gradient, 3 tile GEMM (gemm_kernel family incl. halo convolution and skinny), 4 tile weight gradient, 5 BatchNorm + squeeze-and-excite
+ * in one launch, 6 MBConv block forward in one launch (expand .. squeeze-and-excite), 7 MBConv block backward in one launch; the rest 0.
+ * reset != 0 clears them after the read.  Returns the number of defined routes. */
+int satrn_route_counts(long long* out, int n, int reset);
 float* satrn_model_adam_state(satrn_model* m, int which /*0 exp_avg, 1 exp_avg_sq*/);
 int satrn_model_set_step(satrn_model* m, long t);
 long satrn_model_get_step(satrn_model* m);

@@ -788,7 +788,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
         float* bg = bias ? bias->g : nullptr; float* wg = w->g; const int Ci = g.Ci;
         // dense products: the weight-gradient kernel sums the bias gradient from the dY chunks it stages anyway (not in the deterministic mode,
         // whose fixed-order column sums stay a pass of their own)
-        static const bool fold_db = getenv("SATRN_NO_WGRAD_BIAS") == nullptr;
+        const bool fold_db = getenv("SATRN_NO_WGRAD_BIAS") == nullptr;   // read per call (A/B in one process)
         if (bg && fold_db && !hasgeo && !g_det.on) { q.dbias = bg; bg = nullptr; }
         if (e.prof || dry) {
           WORK(e, 0, (double)M * N * e.esz());
@@ -969,7 +969,7 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
   const int B = x->B, H = x->H, W = x->W, C = x->C;
   Tensor* y = e.newt((long)B * OH * OW, C, B, OH, OW);
   if (want_stats && e.train) y->stats = e.zalloc(2 * C);
-  static const bool hold_bwd = getenv("SATRN_NO_FUSED_BN_APPLY_DW") == nullptr;
+  const bool hold_bwd = getenv("SATRN_NO_FUSED_BN_APPLY_DW") == nullptr;   // read per call: tests toggle it in one process
   y->dw_bwd_fuse = hold_bwd && e.rec && e.train && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && dwconv_img_ok(e.dt, H, W, C);
   if (want_stats && !e.train && !e.rec && g_fuse_bn_eval) {
     // inference: the BatchNorm that follows runs in this kernel's epilogue (launched by op_bn_act)

@@ -3,6 +3,10 @@
 // adaptive 2D positional encoding, LayerNorm, embedding, cross-entropy, packing, clip + AdamW.
 #include "common.h"
 #include "kernels.h"
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 #define DISPATCH_T(dt, ...)                      \
   do {                                           \
@@ -25,15 +29,37 @@ DEVI void lds8(const float* p, float* o) {   // 8 floats from LDS / memory throu
 DetCtx g_det;
 WgPartCtx g_wgpart;
 SeBoxCtx g_sebox;
+long long g_route[RT_COUNT] = {0};
 // a mailbox launch must not be captured into a hipGraph: its tag would be replayed and the stale granules of the previous replay would match
 bool se_box_usable(hipStream_t s) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusNone;
 }
 unsigned se_next_tag() {   // one number per launch that uses a mailbox, whichever kernel (0 is what a fresh mailbox holds)
-  static unsigned tag = 0;
-  if (++tag == 0) tag = 1;
-  return tag;
+  static std::atomic<unsigned> tag{0};
+  unsigned t = ++tag;
+  while (t == 0) t = ++tag;
+  return t;
+}
+long resident_capacity(const void* kernel, int threads, size_t lds_bytes) {
+  static std::mutex mu;
+  static std::map<std::tuple<const void*, int, size_t>, long> cache;
+  static int cus = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  const auto key = std::make_tuple(kernel, threads, lds_bytes);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 0;
+  if (per_cu >= 7) per_cu -= 1;
+  if (per_cu > 8) per_cu = 8;
+  const long cap = (long)per_cu * cus;
+  cache[key] = cap;
+  return cap;
 }
 int timing_switch(const char* name) {
   const char* v = getenv(name);
@@ -750,13 +776,6 @@ bool launch_bn_pool_se(int dt, const void* y, const float* sums, int sums_rep, c
   const bool off = getenv("SATRN_NO_FUSED_POOL_SE") != nullptr;   // read per call: tests compare the fused and the plain forms in one process
   if (off || g_det.on || dt != DT_BF16 || !sums || !box || B > box_images || (C % 64) != 0 || C > 1536 || S > 64 || (S % 8) != 0 || HW <= 0) return false;
   if (!se_box_usable(s)) return false;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  }
-  // the image's workgroups wait for each other: the whole grid must fit the chip with room to spare (8 x 256 threads per CU at most)
-  if ((long)B * (C / 64) > 3L * cus) return false;
   BnSeP p;
   p.y = (const bf16_t*)y; p.sums = sums; p.sums_rep = sums_rep < 1 ? 1 : sums_rep; p.w = w; p.b = b; p.rm = rm; p.rv = rv; p.nbt = nbt;
   const long M = (long)B * HW;
@@ -770,7 +789,10 @@ bool launch_bn_pool_se(int dt, const void* y, const float* sums, int sums_rep, c
     const int ppt = HW / G;
     p.tag = se_next_tag();
     const dim3 grid(B, C / 64), blk(G * 8);
-#define BNSE_IMG(P) case P: hipLaunchKernelGGL((bn_pool_se_img_kernel<P>), grid, blk, 0, s, p); return true;
+    // the image's workgroups wait for each other: the whole grid must be resident at once -- asked of the very instantiation that would run
+    // (the 7- and 8-pixel forms hold 176-186 VGPRs: two workgroups per CU, where the 3- to 6-pixel forms hold three)
+#define BNSE_IMG(P) case P: if ((long)B * (C / 64) > resident_capacity((const void*)bn_pool_se_img_kernel<P>, G * 8, 0)) return false; \
+                            hipLaunchKernelGGL((bn_pool_se_img_kernel<P>), grid, blk, 0, s, p); g_route[RT_BN_POOL_SE]++; return true;
     switch (ppt) { BNSE_IMG(1) BNSE_IMG(2) BNSE_IMG(3) BNSE_IMG(4) BNSE_IMG(5) BNSE_IMG(6) BNSE_IMG(7) BNSE_IMG(8) }
 #undef BNSE_IMG
   }
@@ -1620,14 +1642,7 @@ bool launch_dwconv_eval_img(int dt, const void* x, const void* wp, const float* 
     // with the squeeze-and-excite block: the image's workgroups wait for each other, so the WHOLE grid must be resident at once
     if (getenv("SATRN_NO_DW_EVAL_SE") != nullptr || !se->box || B > se->box_images || se->S > 64 || (se->S % 8) != 0 || C > 1536 || !esc) return false;
     if (!se_box_usable(s)) return false;
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dw_eval_img_kernel, NT, lds) != hipSuccess || per_cu < 1) return false;
-    if ((long)B * (C / (8 * BDW_SC)) > (long)per_cu * cus) return false;
+    if ((long)B * (C / (8 * BDW_SC)) > resident_capacity((const void*)dw_eval_img_kernel, NT, lds)) return false;
     sp.box = se->box; sp.tag = se_next_tag(); sp.W1 = (const bf16_t*)se->W1; sp.b1 = se->b1; sp.W2 = (const bf16_t*)se->W2; sp.b2 = se->b2; sp.S = se->S;
   }
   hipLaunchKernelGGL(dw_eval_img_kernel, dim3(B, C / (8 * BDW_SC)), dim3(NT), lds, s, (const bf16_t*)x, (const bf16_t*)wp, dwbias, esc, esh, (bf16_t*)out,

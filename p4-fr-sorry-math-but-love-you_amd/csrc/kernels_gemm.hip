@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, in
 
 // stride-1 SAME 3x3 (forward or data gradient), bf16, no bias / activation / dropout epilogue, C % 8 == 0
 static bool conv_halo_launch(int amode, const GemmP& p, hipStream_t s) {
-  static const bool off = getenv("SATRN_NO_HALO_CONV") != nullptr;
+  const bool off = getenv("SATRN_NO_HALO_CONV") != nullptr;   // read per call: tests compare both forms in one process
   if (off || p.KW != 3 || p.stride != 1 || p.pt != 1 || p.pl != 1 || p.OH != p.H || p.OW != p.W) return false;
   if (p.bias || (p.act && !p.escale) || p.drop_p > 0.f || p.out_f32 || (p.Ci & 7) || p.ldc != p.N) return false;
   const int C = p.Ci, H = p.OH, W = p.OW;
@@ -887,9 +887,10 @@ void launch_gemm(int dt, int amode, const GemmP& p0, hipStream_t s) {
     if (!(cb && atoi(cb) == 0) && !p.stats_part && dt == DT_BF16 && (amode == AM_CONV || amode == AM_DGRAD) && p.N >= conv_min_n && !by_classes &&
         gemm_big_conv_launch(amode, p, s)) return;
   }
+  g_route[RT_GEMM_TILE]++;   // (everything below: halo convolution, skinny and tile kernels)
   if (!p.stats_part && dt == DT_BF16 && amode != AM_DENSE && conv_halo_launch(amode, p, s)) return;
   if (amode == AM_DENSE && (dt == DT_BF16 ? gemm_skinny_launch<bf16_t>(p, s) : gemm_skinny_launch<float>(p, s))) return;
-  if (amode == AM_DENSE && dt == DT_BF16 && gemm_big_launch(p, s)) return;   // large products: persistent 8-wave direct-to-LDS kernel (kernels_gemm_big.hip)
+  if (amode == AM_DENSE && dt == DT_BF16 && gemm_big_launch(p, s)) { g_route[RT_GEMM_TILE]--; return; }   // large products: persistent 8-wave direct-to-LDS kernel (kernels_gemm_big.hip)
   if (dt == DT_BF16) {
     if (amode == AM_DENSE) launch_gemm_t<bf16_t, AM_DENSE>(p, s);
     else if (amode == AM_CONV) launch_gemm_t<bf16_t, AM_CONV>(p, s);
@@ -1154,7 +1155,7 @@ static void launch_wgrad_tile(const WgradP& p, hipStream_t s) {
   rps = ((rps + MS - 1) / MS) * MS;
   splits = (p.M + rps - 1) / rps;
   WgradP q = p;
-  static const bool launch_order = getenv("SATRN_WGRAD_LAUNCH_ORDER") != nullptr;   // A/B (tools/ab_bench.sh), read once
+  const bool launch_order = getenv("SATRN_WGRAD_LAUNCH_ORDER") != nullptr;   // A/B (tools/ab_bench.sh), read per call
   q.launch_order = launch_order ? 1 : 0;
   q.det_part = det ? det_scratch(s, (size_t)splits * p.N * p.K) : nullptr;
   // (measured: the partial-tile slab of the persistent kernel for this kernel's split-M sums instead of atomics -- 10.56 vs 10.47 ms per
@@ -1176,6 +1177,7 @@ void launch_wgrad(int dt, const WgradP& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return;
   const bool big = p.N > 64 && p.K > 64 && (long)p.M * p.N * p.K >= (1L << 28);
   if (dt == DT_BF16 && !g_det.on && wgrad_big_launch(p, s)) return;   // large dense products: persistent direct-to-LDS kernel
+  g_route[RT_WGRAD_TILE]++;
   if (dt == DT_BF16) {
     if (big) launch_wgrad_tile<bf16_t, 128, 128>(p, s); else launch_wgrad_tile<bf16_t, 64, 64>(p, s);
   } else {

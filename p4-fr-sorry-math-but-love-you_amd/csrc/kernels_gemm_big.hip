@@ -934,6 +934,7 @@ static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
   if (best_mt == 4) big_launch_t<4>(p, grid, s);
   else if (best_mt == 3) big_launch_t<3>(p, grid, s);
   else big_launch_t<2>(p, grid, s);
+  g_route[conv ? RT_GEMM_BIG_CONV : RT_GEMM_BIG]++;
   return true;
 }
 
@@ -1003,5 +1004,6 @@ bool wgrad_big_launch(const WgradP& w, hipStream_t s) {
   else if (w.dbias) wgrad_big_go<4, true>(p, grid, s);
   else wgrad_big_go<4, false>(p, grid, s);
   if (p.part) launch_fold4(p.part, splits, (long)w.N * w.K, (long)w.N * w.K, p.dW, s);
+  g_route[RT_WGRAD_BIG]++;
   return true;
 }

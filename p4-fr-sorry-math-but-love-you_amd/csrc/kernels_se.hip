@@ -660,12 +660,8 @@ bool launch_se_bwd_wide(int dt, const void* dy, const void* x, const void* gate,
   // against 10.11 with the two launches): the backward shares the chip with the weight-gradient stream, the workgroups of an image
   // start at different times and the early ones hold their slots while they wait -- so the engine leaves it off (SATRN_SE_BWD_ONE_LAUNCH=1
   // switches it on); the forward twin (launch_bn_pool_se), which runs with nothing beside it, wins 0.23 ms.
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  }
-  if (g_sebox.box && g_sebox.bwd && B <= g_sebox.images && (long)B * G <= 2L * cus && se_box_usable(s)) {
+  // (512 threads x 255 VGPRs: ONE workgroup per CU -- the bound comes from the occupancy query, not from a guess)
+  if (g_sebox.box && g_sebox.bwd && B <= g_sebox.images && (long)B * G <= resident_capacity((const void*)se_bwd_gate_ds_kernel, SEB_NT, 0) && se_box_usable(s)) {
     one.err = device_error_word();
     if (one.err) { one.box = g_sebox.box; one.tag = se_next_tag(); }
   }

@@ -691,6 +691,11 @@ int satrn_image_preprocess(const void* descs, int B, int C, int H, int W, float*
   return done("image_preprocess");
 }
 int satrn_device_error(void* st) { return (int)device_error_read_clear(S(st)); }
+int satrn_route_counts(long long* out, int n, int reset) {
+  for (int i = 0; i < n; ++i) out[i] = i < RT_COUNT ? g_route[i] : 0;
+  if (reset) for (int i = 0; i < RT_COUNT; ++i) g_route[i] = 0;
+  return RT_COUNT;
+}
 int satrn_model_bind_optimizer(satrn_model* h, float* exp_avg, float* exp_avg_sq) { return mret(h, model_bind_optimizer(h->m, exp_avg, exp_avg_sq), "bind_optimizer"); }
 long satrn_model_get_step(satrn_model* h) { return h->m->adam_t; }
 int satrn_model_rng_state(satrn_model* h, uint32_t* seed_io_host, int set, void* st) { return mret(h, model_rng_state(h->m, seed_io_host, set, S(st)), "rng_state"); }

@@ -77,7 +77,9 @@ def sync_bn_buffers(model, mode="broadcast", src=0, group=None):
 
 def state_dict(model, bn_mode="broadcast", src=0, group=None):
     """model.state_dict() of a data-parallel replica: BatchNorm buffers synchronised first (sync_bn_buffers), so that every rank
-    would write the same checkpoint (the reference saves `model.state_dict()`, train_modules/train_single_opt.py:497-512)."""
+    would write the same checkpoint (the reference saves `model.state_dict()`, train_modules/train_single_opt.py:497-512).
+    The rank-shared coin is not part of it (the reference's state_dict has no such key): checkpoint it beside the model with
+    coin.state_dict() / coin.load_state_dict()."""
     sync_bn_buffers(model, bn_mode, src, group)
     return model.state_dict()
 
@@ -98,6 +100,29 @@ class SharedCoin:
 
     def teacher_forced(self, ratio):
         return self.random() < ratio
+
+    def state_dict(self):
+        """generator state + flip count: a resumed run continues the SAME branch sequence on every rank"""
+        return {"rng": self._rng.getstate(), "flips": self.flips}
+
+    def load_state_dict(self, sd):
+        st = sd["rng"]
+        self._rng.setstate((st[0], tuple(st[1]), st[2]))
+        self.flips = int(sd["flips"])
+
+    def check_in_step(self, teacher_forced=None, group=None):
+        """debug aid: raise if the ranks disagree on the flip count (a rank skipped or repeated a step: an uneven last shard, a retry)
+        or on the branch just taken.  One 3-element all-reduce (MIN and MAX folded into one by sending x and -x): call it every N steps."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        tf = -1.0 if teacher_forced is None else float(bool(teacher_forced))
+        v = torch.tensor([float(self.flips), -float(self.flips), tf, -tf], dtype=torch.float64)
+        if dist.get_backend(group) == "nccl":
+            v = v.cuda()
+        dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+        v = v.cpu()
+        if v[0] != -v[1] or v[2] != -v[3]:
+            raise RuntimeError(f"SharedCoin drifted between ranks: flips max {int(v[0])} min {int(-v[1])}, branch max {v[2]} min {-v[3]}")
 
 
 _exposed = None

@@ -567,8 +567,9 @@ class _SATRNBase(nn.Module):
         starts = (int(phase) & 31) in (1, 3) or (int(phase) & 16 and int(phase) & 3 == 0)
         if teacher_forced is None:
             if starts:
-                teacher_forced = True if teacher_forcing_ratio >= 1.0 else \
-                    (self._coin if self._coin is not None else random).random() < teacher_forcing_ratio
+                # one draw per training batch whatever the ratio, as the reference (networks/EfficientSATRN.py:488-489) and forward():
+                # the Python RNG stream -- and a SharedCoin's flip count -- stay in step with them when a run mixes ratio 1.0 with < 1
+                teacher_forced = (self._coin if self._coin is not None else random).random() < teacher_forcing_ratio
             else:
                 teacher_forced = self.last_teacher_forced
         self.last_teacher_forced = bool(teacher_forced)

@@ -1084,7 +1084,8 @@ def test_dropout_statistics(lib):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("B,HW,C,S", [(32, 192, 960, 40), (32, 48, 1536, 64), (5, 24, 128, 8), (3, 192, 256, 16), (2, 35, 96, 8), (2, 48, 1792, 64)])
+@pytest.mark.parametrize("B,HW,C,S", [(32, 192, 960, 40), (32, 48, 1536, 64), (5, 24, 128, 8), (3, 192, 256, 16), (2, 35, 96, 8), (2, 48, 1792, 64),
+                                      (48, 256, 960, 40)])   # last: 720 workgroups of the 8-pixel form (2 per CU resident): must fall back, not spin
 def test_batchnorm_act_squeeze_excite_one_launch(lib, dt, B, HW, C, S, monkeypatch):
     """BatchNorm (batch statistics) + SiLU + the whole squeeze-and-excite block in ONE launch (the image's workgroups exchange their shares
     of the hidden layer through a tagged mailbox; bf16, the MBConv shapes of the late stages) against torch and against the separate
