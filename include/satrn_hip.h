@@ -162,6 +162,25 @@ int satrn_batchnorm_act_se_fwd(int dtype, const void* y, const float* weight, co
                                int64_t* num_batches_tracked, float eps, int act, void* z, int keep_z, const void* W1, const float* b1,
                                const void* W2, const float* b2, float* pooled, float* u1, float* s1, void* gate, void* out, int B, int HW,
                                int C, int S, float* scratch, unsigned long long* mailbox, int mailbox_images, void* stream);
+/* The FRONT of a timm MBConv block (SURVEY Appendix B stages 3-5; networks/EfficientSATRN.py:74,84 -> timm `.blocks`: conv_pw -> bn1 -> SiLU
+ * -> conv_dw -> bn2 -> SiLU -> se) in training mode as ONE launch, bf16 only, on the small maps of the late stages (H * W = 48 with
+ * Cin = 256, or 192 with Cin = 160 / 128; W % 3 == 0, C % 64 == 0, C <= 1536, S <= 64, S % 8 == 0, B <= 64):
+ *   y1 = x W0^T, z1 = SiLU(BatchNorm_1(y1)), y2 = depthwise3x3(z1) (stride 1, "same", no bias), z2 = SiLU(BatchNorm_2(y2)),
+ *   pooled = mean_hw z2, u1 = W1 pooled + b1, s1 = SiLU(u1), gate = sigmoid(W2 s1 + b2), z3 = z2 * gate.
+ * Both BatchNorms use BATCH statistics: the workgroups (image, 64-channel slab) exchange their per-channel sums through `mailbox`
+ * (3 * (C / 64) * B * 128 + B * (C / 64) * 64 8-byte words, ZERO before the first call, written by nothing else; a launch number tags
+ * every word, so it is never cleared) and add them in image order (deterministic statistics).  Everything the separate operators
+ * (satrn_linear_fwd_stats, satrn_batchnorm_act_dwconv3x3_fwd, satrn_batchnorm_act_se_fwd) leave behind is written: y1, z1, y2, z3
+ * [B][H][W][C], z2 when keep_z2, bn*_coef = scale | shift | mean | rstd (4 * C floats each), running statistics (momentum 0.1) and
+ * num_batches_tracked, pooled [B][C], u1 / s1 [B][S], gate [B][C].  x [B][H][W][Cin]; W0 [C][Cin] (satrn_pack_dense fwd); dw_packed
+ * [9][C] (satrn_pack_dwconv3x3); W1 [S][C], W2 [C][S] bf16.  Returns -1 for shapes the one launch does not take (incl. a grid that
+ * would not be resident at once: the workgroups wait for each other); a wait that times out (2 s) sets device error bit 2. */
+int satrn_mbconv_front_fwd(const void* x, const void* W0, void* y1, const float* bn1_weight, const float* bn1_bias, float* bn1_running_mean,
+                           float* bn1_running_var, int64_t* bn1_num_batches_tracked, float* bn1_coef, void* z1, const void* dw_packed, void* y2,
+                           const float* bn2_weight, const float* bn2_bias, float* bn2_running_mean, float* bn2_running_var,
+                           int64_t* bn2_num_batches_tracked, float* bn2_coef, void* z2, int keep_z2, const void* W1, const float* b1, const void* W2,
+                           const float* b2, float* pooled, float* u1, float* s1, void* gate, void* z3, int B, int H, int W, int Cin, int C, int S,
+                           float eps, unsigned long long* mailbox, long mailbox_words, void* stream);
 /* Training-mode BatchNorm2d + activation of y[B][H][W][C] -> z, followed by the stride-1 "same" depthwise 3x3 (+bias) of z -> out,
  * in one launch where the shape allows (the expand-BN-SiLU-depthwise seam of the timm MBConv block in the 8x24 / 4x12 stages;
  * networks/EfficientSATRN.py:74-76 runs those blocks).  Results equal satrn_batchnorm_act_fwd + satrn_dwconv3x3_fwd bit for bit

@@ -510,6 +510,8 @@ Model* model_create(const SatrnConfig& cfg) {
     m->off_wgpart = take(2 * m->wgpart_floats * sizeof(float));
     // mailbox of launch_bn_pool_se (starts zeroed with the workspace; only that kernel writes it, with a new tag per launch)
     m->off_sebox = take((size_t)Model::SEBOX_IMAGES * (1536 + 64) * 8);
+    // mailbox of the MBConv block kernels (kernels_mbconv.hip): three exchanges of (C / 64 <= 24 slabs) x images x 128 sums
+    m->off_mbbox = take(Model::MBBOX_WORDS * 8);
   }
   m->zero_bytes = 40u << 20;
   m->off_zero = take(m->zero_bytes);
@@ -886,6 +888,7 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** poo
   }
   float* ss = (float*)e.alloc((size_t)2 * C * 4);
   float* mr = (float*)e.alloc((size_t)2 * C * 4);
+  e.last_bn_ss = ss; e.last_bn_mr = mr;
   float* sums = nullptr;
   if (e.train) {
     sums = y->stats;
@@ -1650,6 +1653,7 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr, SeHold
   float* s1 = (float*)e.alloc((size_t)B * S * 4);
   Tensor* gate = e.newt(B, C);
   Tensor* y = e.newt(x->rows, C, B, x->H, x->W);
+  e.last_se = Exec::LastSe{pooled, u1, s1, gate->p, true};
   bool fused = false;
   if (sh && sh->armed && sh->dwfn) {
     // inference: depthwise 3x3 + eval BatchNorm + SiLU + pool + MLP + x*gate in ONE launch where the grid is resident at once
@@ -1667,6 +1671,7 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr, SeHold
     const bool bwd_recomputes = g_fuse_bnb && e.dt == DT_BF16 && !g_det.on && S <= 64 && (S % 8) == 0 && (C % 8) == 0 && ((C / 8 + 7) / 8) <= 24 &&
                                 getenv("SATRN_SE_NO_WIDE_BWD") == nullptr && getenv("SATRN_SE_NO_BN_SUMS") == nullptr;
     const bool need_x = e.rec && !(e.train && bwd_recomputes);
+    e.last_se.need_x = need_x;
     // (not under hipGraph capture: the per-launch mailbox tag would be replayed)
     unsigned long long* box = g_sebox.box;
     WORK(e, 4.0 * (double)B * C * S, (double)x->rows * C * e.esz() * (need_x ? 3 : 2) + (double)C * S * e.esz() * 2);
@@ -1760,15 +1765,36 @@ Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
     y2->B = B; y2->H = g.OH; y2->W = g.OW;
     return op_bn_act(e, y2, &eb->bn2, ACT_NONE, skip);
   }
+  // The front of the block -- expand product, BatchNorm + SiLU, depthwise 3x3, BatchNorm + SiLU, squeeze-and-excite -- as ONE launch on the
+  // small maps of the late stages (kernels_mbconv.hip: the batch statistics travel between the workgroups of the launch instead of
+  // across two kernel boundaries).  The ops below then only do their bookkeeping (tensors, tape): same allocations, same backward.
+  const bool front = eb->stride == 1 && e.train && !e.nolaunch && x->C == eb->cin &&
+                     (e.dry ? (e.dt == DT_BF16 && !g_det.on) : mbconv_front_ok(e.dt, B, H, W, eb->cin, eb->c0.N, eb->se, e.s));
+  if (front) e.nolaunch = true;
   Tensor* y = op_gemm(e, x, &eb->c0, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   y->B = B; y->H = H; y->W = W;
   BnHold hold;
   Tensor* z = op_bn_act(e, y, &eb->bn1, ACT_SILU, nullptr, nullptr, &hold);
+  float* ss1 = e.last_bn_ss; float* mr1 = e.last_bn_mr;
   Tensor* y2 = op_dwconv(e, z, &eb->dw, nullptr, eb->stride, g.OH, g.OW, g.pt, g.pl, true, &hold);
   float* poolsum = nullptr;
   SeHold sehold;
   Tensor* z2 = op_bn_act(e, y2, &eb->bn2, ACT_SILU, nullptr, &poolsum, nullptr, &sehold);
+  float* ss2 = e.last_bn_ss; float* mr2 = e.last_bn_mr;
   Tensor* z3 = op_se(e, z2, eb, poolsum, &sehold);
+  if (front) {
+    e.nolaunch = false;
+    const int C = eb->c0.N;
+    const Exec::LastSe se = e.last_se;
+    bool ok = false;
+    WORK(e, 2.0 * (double)x->rows * C * eb->cin + 18.0 * (double)x->rows * C + 4.0 * (double)B * C * eb->se,
+         ((double)x->rows * eb->cin + (double)x->rows * C * (se.need_x ? 5 : 4) + (double)C * eb->cin + 2.0 * (double)C * eb->se) * e.esz());
+    LCH(e, ok = launch_mbconv_front(e.dt, x->p, eb->c0.fwd, y->p, eb->bn1.w.p, eb->bn1.b.p, eb->bn1.rm, eb->bn1.rv, eb->bn1.nbt, ss1, mr1, eb->bn1.eps, z->p,
+                                    eb->dw.fwd, y2->p, eb->bn2.w.p, eb->bn2.b.p, eb->bn2.rm, eb->bn2.rv, eb->bn2.nbt, ss2, mr2, eb->bn2.eps,
+                                    se.need_x ? z2->p : nullptr, eb->se_r.fwd, eb->se_rb.p, eb->se_e.fwd, eb->se_eb.p, se.pooled, se.u1, se.s1, se.gate, z3->p,
+                                    B, H, W, eb->cin, C, eb->se, 0.1f, e.s));
+    if (!ok && !e.dry) { e.m->err = "internal: the MBConv block launch refused a shape its own check accepted"; e.oom = true; }
+  }
   Tensor* y3 = op_gemm(e, z3, &eb->c1, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   y3->B = B; y3->H = g.OH; y3->W = g.OW;
   return op_bn_act(e, y3, &eb->bn3, ACT_NONE, skip);
@@ -2021,6 +2047,9 @@ static void det_activate(Model* m) {
   g_sebox.box = mbox ? (unsigned long long*)(m->ws + m->off_sebox) : nullptr;
   g_sebox.images = mbox ? Model::SEBOX_IMAGES : 0;
   g_sebox.bwd = mbox && getenv("SATRN_SE_BWD_ONE_LAUNCH") != nullptr;   // (measured slower inside the step: off by default)
+  g_mbbox.box = (mbox && m->off_mbbox) ? (unsigned long long*)(m->ws + m->off_mbbox) : nullptr;
+  g_mbbox.words = g_mbbox.box ? Model::MBBOX_WORDS : 0;
+  g_mbbox.images = g_mbbox.box ? Model::MBBOX_IMAGES : 0;
 }
 
 static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) {

@@ -125,6 +125,7 @@ struct Model {
   size_t zero_bytes = 0, zero_hwm = 0;
   size_t off_sumsq = 0;
   static constexpr int SEBOX_IMAGES = 128; size_t off_sebox = 0;
+  static constexpr int MBBOX_IMAGES = 64; static constexpr size_t MBBOX_WORDS = (size_t)3 * 24 * MBBOX_IMAGES * 128; size_t off_mbbox = 0;
   size_t off_wgpart = 0, wgpart_floats = 0;   // two partial-tile slabs of the persistent weight-gradient kernel (bf16)
   size_t off_det = 0, det_floats = 0;  // two scratch slabs of the deterministic reductions (f32 parity mode), 0 = atomics
   size_t off_bn_eval = 0, off_bn_desc = 0; std::vector<BnEvalDesc> bn_desc_host; bool bn_desc_dirty = true;
@@ -177,6 +178,10 @@ struct Exec {
   std::vector<Probe> probes; bool probe_on = false;
   bool nolaunch = false;
   float* last_mr = nullptr; float* last_lse = nullptr; uint32_t last_site = 0; float last_drop = 0.f;
+  // what the last op_bn_act / op_se allocated (scale|shift and mean|rstd; pooled means, hidden layer, gate; whether the activated tensor must
+  // be stored): the MBConv block launch (eff_block) reads them after a nolaunch pass over the ops
+  float* last_bn_ss = nullptr; float* last_bn_mr = nullptr;
+  struct LastSe { float* pooled = nullptr; float* u1 = nullptr; float* s1 = nullptr; void* gate = nullptr; bool need_x = true; } last_se;
   bool serial = false;  // no concurrent side stream (hipGraph capture / profiling): side kernels may fill the chip
   float drop = 0.f;
   char* base = nullptr; size_t cap = 0, off = 0, peak = 0;  // bump arena

@@ -30,6 +30,10 @@ extern WgPartCtx g_wgpart;
 // engine call (the model's workspace); null for operator calls that bring none.
 struct SeBoxCtx { unsigned long long* box = nullptr; int images = 0; bool bwd = false /*the squeeze-and-excite backward may use it too*/; };
 extern SeBoxCtx g_sebox;
+// mailbox of the MBConv block kernels (kernels_mbconv.hip): `words` 8-byte words that start zeroed and that only those kernels write (every
+// launch with its own tag); holds the per-(slab, image) BatchNorm sums of up to three exchanges: 3 x (C / 64) x B x 128 words.
+struct MbBoxCtx { unsigned long long* box = nullptr; size_t words = 0; int images = 0; };
+extern MbBoxCtx g_mbbox;
 unsigned se_next_tag();   // (atomic: host threads driving several models never share a tag)
 bool se_box_usable(hipStream_t s);   // false while `s` is being captured into a hipGraph
 // Workgroups of `kernel` (threads per workgroup, dynamic LDS bytes) the device holds at ONCE: the upper bound for the grid of a launch
@@ -338,6 +342,16 @@ bool launch_bn_pool_se(int dt, const void* y, const float* sums, int sums_rep, c
                        float eps, float mom, float* ss, float* mr, void* z, const void* W1, const float* b1, const void* W2, const float* b2,
                        float* pooled, float* u1, float* s1, void* gate, void* out, unsigned long long* box, int box_images, int B, int HW, int C,
                        int S, int act, hipStream_t s);
+// The front of an MBConv block in ONE launch (kernels_mbconv.hip): expand product -> BatchNorm (batch statistics) + SiLU -> depthwise 3x3 ->
+// BatchNorm + SiLU -> squeeze-and-excite -> z3 = z2 * gate, for x [B][H][W][Cin] bf16 with H * W = 48 or 192 (the 4x12 / 8x24 maps).  Needs
+// g_mbbox and g_sebox; mbconv_front_ok says beforehand whether a shape is taken (incl. the residency of the whole grid) -- a launch that
+// follows a true answer cannot refuse.  Writes everything the separate kernels wrote (see the file header); z2 may be null.
+bool mbconv_front_ok(int dt, int B, int H, int W, int Cin, int C, int S, hipStream_t s);
+bool launch_mbconv_front(int dt, const void* x, const void* W0, void* y1, const float* bn1_w, const float* bn1_b, float* bn1_rm, float* bn1_rv, int64_t* bn1_nbt,
+                         float* bn1_ss, float* bn1_mr, float bn1_eps, void* z1, const void* wdw, void* y2, const float* bn2_w, const float* bn2_b, float* bn2_rm,
+                         float* bn2_rv, int64_t* bn2_nbt, float* bn2_ss, float* bn2_mr, float bn2_eps, void* z2, const void* Wr, const float* br,
+                         const void* We, const float* be, float* pooled, float* u1, float* s1, void* gate, void* z3, int B, int H, int W, int Cin, int C, int S,
+                         float mom, hipStream_t s);
 bool launch_se_mlp_scale(int dt, const void* x, const float* poolsum, const void* W1, const float* b1, const void* W2, const float* b2,
                          float* pooled, float* u1, float* s1, void* gate, void* y, int B, int HW, int C, int S, hipStream_t s);
 void launch_se_fwd(int dt, const void* x, const void* W1, const float* b1, const void* W2, const float* b2, float* pooled,

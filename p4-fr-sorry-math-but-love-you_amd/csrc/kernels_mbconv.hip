@@ -1,0 +1,415 @@
+// One launch for the FRONT of a timm MBConv block of the late EfficientNetV2-S stages in training (bf16):
+//   1x1 expand GEMM -> BatchNorm (batch statistics) -> SiLU -> depthwise 3x3 -> BatchNorm -> SiLU -> squeeze-and-excite -> x * gate
+// (networks/EfficientSATRN.py:74,84 -> timm `.blocks`, SURVEY Appendix B stages 3-5: 8x24 and 4x12 maps at the benchmark size).
+// Until round 3 this was three launches (gemm_kernel with the statistics epilogue | bn_dw_img_kernel | bn_pool_se_img_kernel), i.e. two
+// kernel boundaries whose only purpose is the BATCH statistics of the two BatchNorms: nothing can be normalised before every image's sums
+// are in.  Here the workgroup (image b, 64-channel slab j) keeps its [HW x 64] tile in registers / LDS through the whole chain and the
+// boundaries become exchanges between the workgroups of the launch:
+//   * BatchNorm sums: every workgroup publishes the 2 x 64 per-channel {sum, sum of squares} of ITS image as {tag, f32} granules (8-byte
+//     relaxed agent-scope stores, the data is the flag: cdna_hip_programming.md Guideline 16 R2, the hand-off of the pipelined decoder and
+//     of se_exchange_gates) and gathers the B images' shares of its slab in image order -- everyone adds, nobody computes for the others,
+//     the summation order is fixed (the gathered statistics are deterministic, unlike the float atomics of the GEMM epilogue);
+//   * squeeze-and-excite: se_exchange_gates (tile_dev.h), between the C/64 workgroups of an image.
+// The expand product runs on MFMA straight out of LDS (the image's [HW x Cin] rows, staged once) and registers (this slab's 64 weight
+// rows, requested before anything else).  Everything the backward reads is written exactly as the three kernels wrote it: y1 (BatchNorm 1
+// input), scale/shift + mean/rstd of both BatchNorms, z1 (depthwise input), y2, pooled / u1 / s1 / gate, z3 = z2 * gate (and z2 when
+// asked for); running statistics and num_batches_tracked are updated by the image-0 workgroups.
+// All workgroups of the grid wait for each other, so the launcher takes a shape only if the whole grid is resident at once
+// (resident_capacity); every wait is bounded by the wall clock (2 s -> device error bit 2, reported by the next read_loss).
+#include "common.h"
+#include "kernels.h"
+#include "tile_dev.h"
+
+MbBoxCtx g_mbbox;
+
+// 48-pixel maps (4 x 12): staging buffer 6 912 B + tile (4 + 2) x 15 x 128 B = 11 520 B -> the squeeze-and-excite rows start at 18 432
+#define MB_WROWS_OFF_48 18432
+struct MbBn { const float* w; const float* b; float* rm; float* rv; int64_t* nbt; float* ss; float* mr; float eps; };
+struct MbFrontP {
+  const bf16_t* x;       // [B][HW][Cin]   block input
+  const bf16_t* W0;      // [C][Cin]       expand weights (dense pack)
+  bf16_t* y1;            // [B][HW][C]     expand output = BatchNorm 1 input
+  MbBn bn1;
+  bf16_t* z1;            // SiLU(BatchNorm 1): the depthwise convolution's input
+  const bf16_t* wdw;     // [9][C]         depthwise weights (tap-major pack)
+  bf16_t* y2;            // depthwise output = BatchNorm 2 input
+  MbBn bn2;
+  bf16_t* z2;            // SiLU(BatchNorm 2); null: not kept (the backward recomputes it from y2)
+  const bf16_t* Wr; const float* br; const bf16_t* We; const float* be;   // squeeze-and-excite: reduce [S][C] + bias, expand [C][S] + bias
+  float* pooled; float* u1; float* s1; bf16_t* gate;
+  bf16_t* z3;            // z2 * gate: the projection's input
+  se_box_t* box_bn1; se_box_t* box_bn2;   // [C/64][B][128] granules each
+  se_box_t* box_se;                       // [B][C/64][64]
+  unsigned tag; long long timeout_ticks; unsigned* err;   // device error word (bit 2: a wait timed out)
+  float mom, invM, unbias;
+  int B, H, W, C, S, rowpix;
+};
+
+// the B images' shares of this slab's 128 sums -> gs[group][128] (thread = value v x image group; images group, group + NG, ... in order)
+template <int NT>
+DEVI void mb_gather_sums(se_box_t* sbox /*[B][128] of this slab*/, int B, unsigned tag, long long t_end, unsigned* err, float (*gs)[128]) {
+  constexpr int NG = NT / 128, GB = NT >= 512 ? 8 : 16;   // loads in flight per thread (the 512-thread form has 128 registers)
+  const int tid = threadIdx.x, v = tid & 127, grp = tid >> 7;
+  float a = 0.f;
+  for (int i0 = grp; i0 < B; i0 += NG * GB) {
+    unsigned long long w[GB];
+#pragma unroll
+    for (int k = 0; k < GB; ++k) {
+      const int im = i0 + k * NG;
+      w[k] = im < B ? __hip_atomic_load(sbox + (size_t)im * 128 + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < GB; ++k) {
+      const int im = i0 + k * NG;
+      if (im < B) {
+        float val = __uint_as_float((unsigned)w[k]);
+        if ((unsigned)(w[k] >> 32) != tag) se_box_wait(sbox + (size_t)im * 128 + v, tag, t_end, val, err);
+        a += val;
+      }
+    }
+  }
+  gs[grp][v] = a;
+}
+// gs -> scale / shift of this slab's 64 channels in cf[0] / cf[1] (bn_act_kernel's arithmetic); image 0 publishes them for the backward
+// and updates the running statistics.  Ends with a barrier.
+template <int NT>
+DEVI void mb_bn_finalize(const MbBn& bn, const float (*gs)[128], float (*cf)[64], int cb, int C, int img, float invM, float unbias, float mom) {
+  constexpr int NG = NT / 128;
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if (tid < 64) {
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { sm += gs[g][tid]; sq += gs[g][64 + tid]; }
+    const int cg = cb + tid;
+    const float mean = sm * invM, var = fmaxf(sq * invM - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + bn.eps), sc = bn.w[cg] * rstd, sh = bn.b[cg] - mean * sc;
+    cf[0][tid] = sc; cf[1][tid] = sh;
+    if (img == 0) {
+      bn.ss[cg] = sc; bn.ss[C + cg] = sh; bn.mr[cg] = mean; bn.mr[C + cg] = rstd;
+      bn.rm[cg] = (1.f - mom) * bn.rm[cg] + mom * mean;
+      bn.rv[cg] = (1.f - mom) * bn.rv[cg] + mom * var * unbias;
+    }
+  }
+  __syncthreads();
+}
+
+template <int HWT, int CIN>
+__global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbconv_front_kernel(MbFrontP p) {
+  typedef bf16_t T;
+  constexpr int CH = 8, SC = BDW_SC, RUN = BDW_RUN;
+  constexpr int NT = HWT * 8 / 3, NW = NT / 64, G = NT / SC;
+  constexpr int KS = CIN / 32, XP = CIN + 8, YP = 72;
+  constexpr int RTW = HWT == 48 ? 3 : 6, CTW = HWT == 48 ? 2 : 1;   // MFMA tiles per wave: 6 = RTW row tiles x CTW column tiles
+  constexpr int NXC = HWT * CIN / 8, XPT = (NXC + NT - 1) / NT;
+  // dynamic LDS: image rows [HWT][XP] | overlaid later by: staging buffer [HWT][YP], zero-halo tile behind it, the 16 KB of squeeze-and-
+  // excite rows over the staging buffer (192-pixel maps: it is 27 KB and dead by then) or behind the tile (48-pixel maps)
+  constexpr int WROWS_OFF = HWT * YP * 2 >= 16384 ? 0 : MB_WROWS_OFF_48;
+  static_assert(NT % 128 == 0 && (HWT / 16) * 4 == NW * RTW * CTW, "tile split");
+  extern __shared__ __attribute__((aligned(16))) unsigned char mb_sm[];
+  __shared__ __attribute__((aligned(16))) float cf[2][64];
+  __shared__ float sst[2][2][64];
+  __shared__ uint4 wl[9][SC];
+  __shared__ __attribute__((aligned(16))) float ps[64];
+  __shared__ __attribute__((aligned(16))) float hs[64];
+  __shared__ __attribute__((aligned(16))) float gl[64];
+  __shared__ __attribute__((aligned(16))) float scr[NW * 2 * 64 > 512 ? NW * 2 * 64 : 512];   // gather groups | column-sum partials | hidden-layer partials
+  float (*gs)[128] = reinterpret_cast<float (*)[128]>(scr);
+  float (*sred)[2][64] = reinterpret_cast<float (*)[2][64]>(scr);
+  float (*hq)[64] = reinterpret_cast<float (*)[64]>(scr);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int img = blockIdx.x, slab = blockIdx.y, cb = slab * 64;
+  const int C = p.C, H = p.H, W = p.W, B = p.B, rowpix = p.rowpix;
+  const long long t_end = (long long)wall_clock64() + p.timeout_ticks;
+
+  // ---- phase 1: expand product [HW x 64] = x_b [HW x CIN] * W0[slab]^T ------------------------------------------------------------
+  const bf16_t* xb = p.x + (size_t)img * HWT * CIN;
+  uint4 xr[XPT];
+#pragma unroll
+  for (int k = 0; k < XPT; ++k) {
+    const int idx = tid + k * NT;
+    xr[k] = idx < NXC ? ld16(xb + (size_t)idx * 8) : zero16();
+  }
+  const int ct0 = HWT == 48 ? 2 * wave : (wave & 3), rt0 = HWT == 48 ? 0 : (wave >> 2) * RTW;
+  Frag<T> bfr[CTW][KS];
+#pragma unroll
+  for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bfr[ct][ks].v = ld16(p.W0 + (size_t)(cb + (ct0 + ct) * 16 + fr) * CIN + ks * 32 + fq * 8);
+  bf16_t* xbuf = reinterpret_cast<bf16_t*>(mb_sm);
+#pragma unroll
+  for (int k = 0; k < XPT; ++k) {
+    const int idx = tid + k * NT;
+    if (idx < NXC) {
+      const int row = idx / (CIN / 8), ch = idx - row * (CIN / 8);
+      st16(xbuf + row * XP + ch * 8, xr[k]);
+    }
+  }
+  __syncthreads();
+  f32x4 acc[RTW][CTW];
+#pragma unroll
+  for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt) {
+      Frag<T> a;
+      a.v = ld16(xbuf + ((rt0 + rt) * 16 + fr) * XP + ks * 32 + fq * 8);
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct) mma(a, bfr[ct][ks], acc[rt][ct]);
+    }
+  }
+  __syncthreads();   // every wave has read its last fragment: the staging buffer below overlays the image rows
+  // the tile leaves the accumulators for LDS as bf16 [pixel][64 + 8] (what the next phase -- and the backward -- reads is the ROUNDED
+  // value, as the separate kernels read it back from memory); BatchNorm 1 sums from the f32 accumulators, as the GEMM epilogue takes them
+  bf16_t* ybuf = reinterpret_cast<bf16_t*>(mb_sm);
+#pragma unroll
+  for (int ct = 0; ct < CTW; ++ct) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[rt][ct][r];
+        s1 += v; s2 += v * v;
+        ybuf[((rt0 + rt) * 16 + fq * 4 + r) * YP + (ct0 + ct) * 16 + fr] = from_f<T>(v);
+      }
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (fq == 0) {
+      const int half = HWT == 48 ? 0 : (wave >> 2);
+      sst[half][0][(ct0 + ct) * 16 + fr] = s1; sst[half][1][(ct0 + ct) * 16 + fr] = s2;
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int k = tid >> 6, c = tid & 63;
+    float t = sst[0][k][c];
+    if (HWT != 48) t += sst[1][k][c];
+    se_box_put(p.box_bn1 + ((size_t)slab * B + img) * 128 + tid, p.tag, t);
+  }
+  // ---- phase 1b: the image-tile mapping (thread = 16-byte chunk x pixel lane); y1 to memory ------------------------------------------
+  const int chunk = tid % SC, g = tid / SC;
+  const long base = (long)img * HWT * C + cb + chunk * CH;
+  uint4 raw[RUN];
+#pragma unroll
+  for (int k = 0; k < RUN; ++k) {
+    const int pix = g + k * G;
+    raw[k] = ld16(ybuf + pix * YP + chunk * CH);
+    st16(p.y1 + base + (long)pix * C, raw[k]);
+  }
+  uint4* tile = reinterpret_cast<uint4*>(mb_sm + (size_t)HWT * YP * 2);   // [(H + 2)][rowpix][SC] chunks behind the staging buffer
+  for (int i = tid; i < 9 * SC; i += NT) wl[i / SC][i % SC] = ld16(p.wdw + (long)(i / SC) * C + cb + (i % SC) * CH);
+  bdw_zero_halo(tile, H, W, rowpix, tid, NT);
+  // the squeeze-and-excite rows of this slab (64 rows of the expand matrix, the slab's 64 columns of the <= 64 reduce rows: 1024 16-byte
+  // chunks) are requested now by ALL threads, parked in LDS after the first exchange and read by threads 0..63 two exchanges later
+  const int S = p.S;
+  constexpr int WPT = 1024 / NT;
+  uint4 wrow[WPT];
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) {
+    const int i = tid + k * NT, r = (i >> 3) & 63, u = i & 7;
+    wrow[k] = i < 512 ? ld16(p.We + (long)(cb + r) * S + (u * CH < S ? u * CH : 0)) : ld16(p.Wr + (long)(r < S ? r : 0) * C + cb + u * CH);
+  }
+  float b2v = 0.f, b1v = 0.f;
+  if (tid < 64) { b2v = p.be[cb + tid]; if (tid < S) b1v = p.br[tid]; }
+  // ---- exchange 1: BatchNorm 1 statistics over the batch ---------------------------------------------------------------------------
+  mb_gather_sums<NT>(p.box_bn1 + (size_t)slab * B * 128, B, p.tag, t_end, p.err, gs);
+  mb_bn_finalize<NT>(p.bn1, gs, cf, cb, C, img, p.invM, p.unbias, p.mom);
+  uint4* wrows = reinterpret_cast<uint4*>(mb_sm + WROWS_OFF);   // [expand 64][8] | [reduce 64][8]  (the staging buffer is dead: finalize's barriers)
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) wrows[tid + k * NT] = wrow[k];
+  // ---- phase 2: BatchNorm 1 + SiLU -> z1 (memory + zero-halo tile) -> depthwise 3x3 -> y2 + its column sums (bn_dw_img_kernel) --------
+  {
+    float sc[CH], sh[CH];
+    lds8(cf[0] + chunk * CH, sc); lds8(cf[1] + chunk * CH, sh);
+#pragma unroll
+    for (int k = 0; k < RUN; ++k) {
+      const int pix = g + k * G, py = pix / W, px = pix - py * W;
+      float v[CH];
+      unpack<T>(raw[k], v);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) v[j] = act_fwd(v[j] * sc[j] + sh[j], ACT_SILU);
+      const uint4 q = pack<T>(v);
+      st16(p.z1 + base + (long)pix * C, q);
+      tile[((py + 1) * rowpix + px + 1) * SC + chunk] = q;
+    }
+  }
+  __syncthreads();
+  const int row = g % H, ox0 = (g / H) * RUN;
+  float dacc[RUN][CH];
+#pragma unroll
+  for (int pp = 0; pp < RUN; ++pp)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) dacc[pp][j] = 0.f;
+  bdw_taps<false>(tile, wl, row, ox0, rowpix, chunk, dacc);
+  uint4 y2q[RUN];
+  {
+    float s1[CH], s2[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < RUN; ++pp) {
+      y2q[pp] = pack<T>(dacc[pp]);
+      st16(p.y2 + base + (long)(row * W + ox0 + pp) * C, y2q[pp]);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { s1[j] += dacc[pp][j]; s2[j] += dacc[pp][j] * dacc[pp][j]; }
+    }
+#pragma unroll
+    for (int o = SC; o < 64; o <<= 1) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+    }
+    if (lane < SC) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { sred[wave][0][lane * CH + j] = s1[j]; sred[wave][1][lane * CH + j] = s2[j]; }
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int k = tid >> 6, c = tid & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NW; ++wv) t += sred[wv][k][c];
+    se_box_put(p.box_bn2 + ((size_t)slab * B + img) * 128 + tid, p.tag, t);
+  }
+  __syncthreads();   // sred is read: the gather below reuses the scratch
+  // ---- exchange 2: BatchNorm 2 statistics ---------------------------------------------------------------------------------------------
+  mb_gather_sums<NT>(p.box_bn2 + (size_t)slab * B * 128, B, p.tag, t_end, p.err, gs);
+  mb_bn_finalize<NT>(p.bn2, gs, cf, cb, C, img, p.invM, p.unbias, p.mom);
+  // ---- phase 3: BatchNorm 2 + SiLU -> pool -> squeeze-and-excite between the image's workgroups -> z3 (bn_pool_se_img_kernel) --------
+  uint4 zq[RUN];
+  {
+    float sc[CH], sh[CH], pacc[CH];
+    lds8(cf[0] + chunk * CH, sc); lds8(cf[1] + chunk * CH, sh);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) pacc[j] = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < RUN; ++pp) {
+      float v[CH];
+      unpack<T>(y2q[pp], v);   // the ROUNDED depthwise output, as the separate kernel read it
+#pragma unroll
+      for (int j = 0; j < CH; ++j) v[j] = act_fwd(v[j] * sc[j] + sh[j], ACT_SILU);
+      zq[pp] = pack<T>(v);
+      if (p.z2) st16(p.z2 + base + (long)(row * W + ox0 + pp) * C, zq[pp]);
+      float r[CH];
+      unpack<T>(zq[pp], r);    // the pool averages the ROUNDED values
+#pragma unroll
+      for (int j = 0; j < CH; ++j) pacc[j] += r[j];
+    }
+#pragma unroll
+    for (int o = SC; o < 64; o <<= 1)
+#pragma unroll
+      for (int j = 0; j < CH; ++j) pacc[j] += __shfl_xor(pacc[j], o, 64);
+    if (lane < SC) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) sred[wave][0][lane * CH + j] = pacc[j];
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float sum = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NW; ++wv) sum += sred[wv][0][tid];
+    const float m = sum * (1.0f / (float)HWT);
+    ps[tid] = m;
+    p.pooled[(long)img * C + cb + tid] = m;
+  }
+  __syncthreads();
+  {
+    SeXchg xc;
+    xc.NG = C / 64; xc.S = S; xc.tag = p.tag; xc.t_end = t_end; xc.err = p.err;
+    xc.ibox = p.box_se + (size_t)img * xc.NG * 64;
+    float uu, sv;
+    se_exchange_gates(xc, ps, wrows + 512 + (tid & 63) * 8, wrows + (tid & 63) * 8, b1v, b2v, hq, hs, gl, uu, sv);
+    if (tid < S && slab == 0) { p.u1[(long)img * S + tid] = uu; p.s1[(long)img * S + tid] = sv; }
+    if (tid < 64) p.gate[(long)img * C + cb + tid] = from_f<T>(gl[tid]);
+  }
+  {
+    float gv[CH];
+    lds8(gl + chunk * CH, gv);
+#pragma unroll
+    for (int pp = 0; pp < RUN; ++pp) {
+      float v[CH];
+      unpack<T>(zq[pp], v);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) v[j] *= gv[j];
+      st16(p.z3 + base + (long)(row * W + ox0 + pp) * C, pack<T>(v));
+    }
+  }
+  if (img == 0 && slab == 0 && tid == 0) {
+    if (p.bn1.nbt) *p.bn1.nbt += 1;
+    if (p.bn2.nbt) *p.bn2.nbt += 1;
+  }
+}
+
+template <int HWT, int CIN>
+static size_t mb_front_lds(int H, int rowpix) {
+  const size_t x_bytes = (size_t)HWT * (CIN + 8) * 2;
+  size_t t_bytes = (size_t)HWT * 72 * 2 + (size_t)(H + 2) * rowpix * BDW_SC * 16;
+  if (HWT * 72 * 2 < 16384) t_bytes = (t_bytes > MB_WROWS_OFF_48 ? t_bytes : MB_WROWS_OFF_48) + 16384;
+  return x_bytes > t_bytes ? x_bytes : t_bytes;
+}
+// every workgroup of the grid waits for the others: all of them must be resident at once
+template <int HWT, int CIN>
+static bool mb_front_fits(int B, int H, int C, int rowpix) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)mbconv_front_kernel<HWT, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
+  return (long)B * (C / 64) <= resident_capacity((const void*)mbconv_front_kernel<HWT, CIN>, HWT * 8 / 3, mb_front_lds<HWT, CIN>(H, rowpix));
+}
+template <int HWT, int CIN>
+static bool mb_front_go(const MbFrontP& p, hipStream_t s) {
+  if (!mb_front_fits<HWT, CIN>(p.B, p.H, p.C, p.rowpix)) return false;
+  const size_t lds = mb_front_lds<HWT, CIN>(p.H, p.rowpix);
+  hipLaunchKernelGGL((mbconv_front_kernel<HWT, CIN>), dim3(p.B, p.C / 64), dim3(HWT * 8 / 3), lds, s, p);
+  g_route[RT_MBCONV_FWD]++;
+  return true;
+}
+static bool mb_front_shape(int dt, int B, int H, int W, int Cin, int C, int S, hipStream_t s) {
+  const bool off = getenv("SATRN_NO_MBCONV_FRONT") != nullptr;   // read per call: tests compare the one launch with the three it replaces
+  if (off || g_det.on || dt != DT_BF16 || !g_mbbox.box || !g_sebox.box) return false;
+  const int HW = H * W;
+  if ((HW != 48 && HW != 192) || (W % BDW_RUN) != 0 || (C % 64) != 0 || C > 1536 || S > 64 || (S % 8) != 0 || B < 1 || B > g_mbbox.images || B > g_sebox.images) return false;
+  if ((size_t)3 * (C / 64) * B * 128 > g_mbbox.words) return false;
+  if (!((HW == 48 && Cin == 256) || (HW == 192 && (Cin == 160 || Cin == 128)))) return false;
+  if (HW == 48 && (size_t)48 * 72 * 2 + (size_t)(H + 2) * ((W + 2) | 1) * BDW_SC * 16 > MB_WROWS_OFF_48) return false;   // (4 x 12 fits exactly; 2 x 24 / 6 x 8 do not)
+  return se_box_usable(s) && device_error_word() != nullptr;
+}
+bool mbconv_front_ok(int dt, int B, int H, int W, int Cin, int C, int S, hipStream_t s) {
+  if (!mb_front_shape(dt, B, H, W, Cin, C, S, s)) return false;
+  const int rowpix = (W + 2) | 1;
+  if (H * W == 48) return mb_front_fits<48, 256>(B, H, C, rowpix);
+  return Cin == 160 ? mb_front_fits<192, 160>(B, H, C, rowpix) : mb_front_fits<192, 128>(B, H, C, rowpix);
+}
+
+// false = shape / mode not taken (the caller runs the separate kernels; ask mbconv_front_ok first).  Mailboxes: g_mbbox (BatchNorm sums,
+// [3][C/64][B][128] words) and g_sebox (squeeze-and-excite, [B][C/64][64]).
+bool launch_mbconv_front(int dt, const void* x, const void* W0, void* y1, const float* bn1_w, const float* bn1_b, float* bn1_rm, float* bn1_rv, int64_t* bn1_nbt,
+                         float* bn1_ss, float* bn1_mr, float bn1_eps, void* z1, const void* wdw, void* y2, const float* bn2_w, const float* bn2_b, float* bn2_rm,
+                         float* bn2_rv, int64_t* bn2_nbt, float* bn2_ss, float* bn2_mr, float bn2_eps, void* z2 /*may be null*/, const void* Wr, const float* br,
+                         const void* We, const float* be, float* pooled, float* u1, float* s1, void* gate, void* z3, int B, int H, int W, int Cin, int C, int S,
+                         float mom, hipStream_t s) {
+  if (!mb_front_shape(dt, B, H, W, Cin, C, S, s)) return false;
+  const int HW = H * W;
+  MbFrontP p;
+  p.x = (const bf16_t*)x; p.W0 = (const bf16_t*)W0; p.y1 = (bf16_t*)y1;
+  p.bn1 = MbBn{bn1_w, bn1_b, bn1_rm, bn1_rv, bn1_nbt, bn1_ss, bn1_mr, bn1_eps};
+  p.z1 = (bf16_t*)z1; p.wdw = (const bf16_t*)wdw; p.y2 = (bf16_t*)y2;
+  p.bn2 = MbBn{bn2_w, bn2_b, bn2_rm, bn2_rv, bn2_nbt, bn2_ss, bn2_mr, bn2_eps};
+  p.z2 = (bf16_t*)z2; p.Wr = (const bf16_t*)Wr; p.br = br; p.We = (const bf16_t*)We; p.be = be;
+  p.pooled = pooled; p.u1 = u1; p.s1 = s1; p.gate = (bf16_t*)gate; p.z3 = (bf16_t*)z3;
+  const size_t per = (size_t)(C / 64) * B * 128;
+  p.box_bn1 = (se_box_t*)g_mbbox.box; p.box_bn2 = (se_box_t*)g_mbbox.box + per; p.box_se = (se_box_t*)g_sebox.box;
+  p.timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
+  p.err = device_error_word();
+  if (!p.err) return false;
+  const long M = (long)B * HW;
+  p.mom = mom; p.invM = 1.0f / (float)M; p.unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
+  p.B = B; p.H = H; p.W = W; p.C = C; p.S = S; p.rowpix = (W + 2) | 1;
+  p.tag = se_next_tag();
+  if (HW == 48) return mb_front_go<48, 256>(p, s);
+  return Cin == 160 ? mb_front_go<192, 160>(p, s) : mb_front_go<192, 128>(p, s);
+}

@@ -18,7 +18,7 @@ static int done(const char* what) {
 }
 #define S(x) ((hipStream_t)(x))
 // operator-level calls have no engine workspace behind them: they always use the atomic reduction forms
-#define CHK_DT(dt) do { g_det.on = 0; g_sebox.box = nullptr; g_sebox.images = 0; g_sebox.bwd = false; g_wgpart.cap = 0; if ((dt) != 0 && (dt) != 1) return fail(-1, "dtype must be 0 (f32) or 1 (bf16)"); } while (0)
+#define CHK_DT(dt) do { g_det.on = 0; g_sebox.box = nullptr; g_sebox.images = 0; g_sebox.bwd = false; g_mbbox.box = nullptr; g_mbbox.words = 0; g_mbbox.images = 0; g_wgpart.cap = 0; if ((dt) != 0 && (dt) != 1) return fail(-1, "dtype must be 0 (f32) or 1 (bf16)"); } while (0)
 static int chk_c(int dt, int c, const char* what) {
   int ch = dt == DT_BF16 ? 8 : 4;
   if (c <= 0 || c % ch) return fail(-1, std::string(what) + " must be a positive multiple of " + std::to_string(ch));
@@ -288,6 +288,24 @@ int satrn_batchnorm_act_se_fwd(int dt, const void* y, const float* w, const floa
     launch_se_scale(dt, z, gate, out, B, HW, C, S(st));
   }
   return done("batchnorm_act_se_fwd");
+}
+int satrn_mbconv_front_fwd(const void* x, const void* W0, void* y1, const float* w1, const float* b1n, float* rm1, float* rv1, int64_t* nbt1, float* coef1,
+                           void* z1, const void* dwp, void* y2, const float* w2, const float* b2n, float* rm2, float* rv2, int64_t* nbt2, float* coef2,
+                           void* z2, int keep_z2, const void* W1, const float* b1, const void* W2, const float* b2, float* pooled, float* u1, float* s1,
+                           void* gate, void* z3, int B, int H, int W, int Cin, int C, int S, float eps, unsigned long long* mailbox, long mailbox_words,
+                           void* st) {
+  CHK_DT(DT_BF16);
+  if (B < 1 || C < 64 || (C % 64) || !mailbox) return fail(-1, "mbconv_front_fwd: B >= 1, C a multiple of 64 and a mailbox are required");
+  const long bn_words = 3L * (C / 64) * B * 128, se_words = (long)B * (C / 64) * 64;
+  if (mailbox_words < bn_words + se_words) return fail(-1, "mbconv_front_fwd: mailbox too small (3 * (C / 64) * B * 128 + B * (C / 64) * 64 words)");
+  g_mbbox.box = mailbox; g_mbbox.words = (size_t)bn_words; g_mbbox.images = 64;
+  g_sebox.box = mailbox + bn_words; g_sebox.images = B;
+  const bool okk = mbconv_front_ok(DT_BF16, B, H, W, Cin, C, S, S(st)) &&
+                   launch_mbconv_front(DT_BF16, x, W0, y1, w1, b1n, rm1, rv1, nbt1, coef1, coef1 + 2 * C, eps, z1, dwp, y2, w2, b2n, rm2, rv2, nbt2, coef2,
+                                       coef2 + 2 * C, eps, keep_z2 ? z2 : nullptr, W1, b1, W2, b2, pooled, u1, s1, gate, z3, B, H, W, Cin, C, S, 0.1f, S(st));
+  g_mbbox.box = nullptr; g_mbbox.words = 0; g_mbbox.images = 0; g_sebox.box = nullptr; g_sebox.images = 0;
+  if (!okk) return fail(-1, "mbconv_front_fwd: shape not taken by the one-launch form (use the separate operators)");
+  return done("mbconv_front_fwd");
 }
 int satrn_batchnorm_act_dwconv3x3_fwd(int dt, const void* y, const float* w, const float* b, float* rm, float* rv, int64_t* nbt,
                                       float eps, int act, void* z, const void* dwp, const float* dwb, void* out, float* out_stats,

@@ -1,0 +1,157 @@
+"""GPU: the MBConv block kernels (kernels_mbconv.hip) through the C-ABI -- the front of a timm MBConv block (expand product, BatchNorm +
+SiLU, depthwise 3x3, BatchNorm + SiLU, squeeze-and-excite; SURVEY Appendix B stages 3-5, networks/EfficientSATRN.py:74,84) as ONE launch --
+against an fp32 torch restatement with the same bf16 rounding points AND against the three operators it replaces, at the shapes of
+the benchmark configuration (32 images, 4x12 x 1536 and 8x24 x 960 channels) and at small / ragged batch sizes."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_ops_gpu import P, close, dev, lib, nchw, nhwc, ok, pack_dense, q, rnd, st, _keepalive  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+BF = "bf16"
+
+
+def _mailbox(B, C):
+    return torch.zeros(3 * (C // 64) * B * 128 + B * (C // 64) * 64, dtype=torch.int64, device="cuda")
+
+
+def _inputs(B, H, W, Cin, C, S):
+    x = q(rnd(B, H * W, Cin, seed=1), BF)
+    W0 = q(rnd(C, Cin, seed=2, scale=Cin ** -0.5 * 1.7), BF)
+    g1, be1 = 1 + rnd(C, seed=3, scale=0.2), rnd(C, seed=4, scale=0.1)
+    g2, be2 = 1 + rnd(C, seed=5, scale=0.2), rnd(C, seed=6, scale=0.1)
+    dw = q(rnd(C, 1, 3, 3, seed=7, scale=0.4), BF)
+    W1, W2 = q(rnd(S, C, seed=8, scale=0.05), BF), q(rnd(C, S, seed=9, scale=0.2), BF)
+    b1, b2 = rnd(S, seed=10, scale=0.1), rnd(C, seed=11, scale=0.1)
+    return x, W0, g1, be1, g2, be2, dw, W1, W2, b1, b2
+
+
+def _reference(x, W0, g1, be1, g2, be2, dw, W1, W2, b1, b2, B, H, W, C, eps):
+    """fp32 with the engine's rounding points: y1, z1, y2, z2, gate and z3 are stored in bf16; the statistics come from the f32 products"""
+    M = B * H * W
+    y1f = x.reshape(M, -1) @ W0.t()
+    m1, v1 = y1f.mean(0), y1f.var(0, unbiased=False)
+    y1 = q(y1f, BF)
+    sc1 = g1 / torch.sqrt(v1 + eps)
+    z1 = q(F.silu(y1 * sc1 + (be1 - m1 * sc1)), BF)
+    y2f = nhwc(F.conv2d(nchw(z1.reshape(B, H, W, C)), dw, None, 1, 1, 1, C)).reshape(M, C)
+    m2, v2 = y2f.mean(0), y2f.var(0, unbiased=False)
+    y2 = q(y2f, BF)
+    sc2 = g2 / torch.sqrt(v2 + eps)
+    z2 = q(F.silu(y2 * sc2 + (be2 - m2 * sc2)), BF)
+    pooled = z2.reshape(B, H * W, C).mean(1)
+    u1 = pooled @ W1.t() + b1
+    s1 = F.silu(u1)
+    gate = q(torch.sigmoid(s1 @ W2.t() + b2), BF)
+    z3 = q(z2.reshape(B, H * W, C) * gate[:, None, :], BF)
+    return dict(y1=y1, z1=z1, y2=y2, z2=z2, pooled=pooled, u1=u1, s1=s1, gate=gate, z3=z3.reshape(M, C), m1=m1, v1=v1, m2=m2, v2=v2, sc1=sc1, sc2=sc2)
+
+
+def _run_front(lib, inp, B, H, W, Cin, C, S, eps, box, keep_z2=1):
+    x, W0, g1, be1, g2, be2, dw, W1, W2, b1, b2 = inp
+    M = B * H * W
+    bf = torch.bfloat16
+    W0d, _, _ = pack_dense(lib, W0, BF)
+    wp = torch.empty(9, C, dtype=bf, device="cuda")
+    ok(lib, lib.satrn_pack_dwconv3x3(1, P(dev(dw)), P(wp), C, st()))
+    o = dict(y1=torch.zeros(M, C, dtype=bf, device="cuda"), z1=torch.zeros(M, C, dtype=bf, device="cuda"), y2=torch.zeros(M, C, dtype=bf, device="cuda"),
+             z2=torch.zeros(M, C, dtype=bf, device="cuda"), z3=torch.zeros(M, C, dtype=bf, device="cuda"), pooled=torch.zeros(B, C, device="cuda"),
+             u1=torch.zeros(B, S, device="cuda"), s1=torch.zeros(B, S, device="cuda"), gate=torch.zeros(B, C, dtype=bf, device="cuda"),
+             coef1=torch.zeros(4 * C, device="cuda"), coef2=torch.zeros(4 * C, device="cuda"),
+             rm1=torch.zeros(C, device="cuda"), rv1=torch.ones(C, device="cuda"), rm2=torch.zeros(C, device="cuda"), rv2=torch.ones(C, device="cuda"),
+             nbt1=torch.zeros(1, dtype=torch.int64, device="cuda"), nbt2=torch.zeros(1, dtype=torch.int64, device="cuda"))
+    rc = lib.satrn_mbconv_front_fwd(P(dev(x, BF)), P(W0d), P(o["y1"]), P(dev(g1)), P(dev(be1)), P(o["rm1"]), P(o["rv1"]), P(o["nbt1"]), P(o["coef1"]),
+                                    P(o["z1"]), P(wp), P(o["y2"]), P(dev(g2)), P(dev(be2)), P(o["rm2"]), P(o["rv2"]), P(o["nbt2"]), P(o["coef2"]),
+                                    P(o["z2"]), keep_z2, P(dev(W1, BF)), P(dev(b1)), P(dev(W2, BF)), P(dev(b2)), P(o["pooled"]), P(o["u1"]), P(o["s1"]),
+                                    P(o["gate"]), P(o["z3"]), B, H, W, Cin, C, S, eps, P(box), box.numel(), st())
+    torch.cuda.synchronize()
+    return rc, o
+
+
+@pytest.mark.parametrize("B,H,W,Cin,C,S", [(32, 4, 12, 256, 1536, 64), (32, 8, 24, 160, 960, 40), (5, 8, 24, 128, 512, 32), (3, 4, 12, 256, 1536, 64),
+                                           (1, 4, 12, 256, 128, 8), (17, 8, 24, 160, 192, 16)])
+def test_mbconv_front_one_launch_vs_torch(lib, B, H, W, Cin, C, S):
+    eps = 1e-3
+    inp = _inputs(B, H, W, Cin, C, S)
+    ref = _reference(*inp, B, H, W, C, eps)
+    box = _mailbox(B, C)
+    M = B * H * W
+    for rep in range(3):   # the mailbox is reused as it is (a launch number tags every word)
+        rc, o = _run_front(lib, inp, B, H, W, Cin, C, S, eps, box, keep_z2=rep % 2)
+        assert rc == 0, lib.satrn_last_error().decode()
+        assert lib.satrn_device_error(st()) == 0
+        close(o["y1"], ref["y1"], BF, "front y1", bf16_tol=1e-2)
+        close(o["coef1"][2 * C:3 * C], ref["m1"], "f32", "front mean 1", f32_tol=2e-4)
+        close(o["coef1"][:C], ref["sc1"], "f32", "front scale 1", f32_tol=1e-3)
+        close(o["z1"], ref["z1"], BF, "front z1", bf16_tol=2e-2)
+        close(o["y2"], ref["y2"], BF, "front y2", bf16_tol=2e-2)
+        close(o["coef2"][2 * C:3 * C], ref["m2"], "f32", "front mean 2", f32_tol=5e-3)
+        close(o["coef2"][:C], ref["sc2"], "f32", "front scale 2", f32_tol=1e-2)
+        close(o["pooled"], ref["pooled"], BF, "front pooled", bf16_tol=2e-2)
+        close(o["u1"], ref["u1"], BF, "front u1", bf16_tol=2e-2)
+        close(o["gate"], ref["gate"], BF, "front gate", bf16_tol=1e-2)
+        close(o["z3"], ref["z3"], BF, "front z3", bf16_tol=3e-2)
+        if rep % 2:
+            close(o["z2"], ref["z2"], BF, "front z2", bf16_tol=3e-2)
+        assert o["nbt1"].item() == 1 and o["nbt2"].item() == 1
+        unb = M / (M - 1)
+        close(o["rm1"], 0.1 * ref["m1"], "f32", "front running mean 1", f32_tol=1e-3)
+        close(o["rv1"], 0.9 + 0.1 * ref["v1"] * unb, "f32", "front running var 1", f32_tol=1e-3)
+        close(o["rv2"], 0.9 + 0.1 * ref["v2"] * unb, "f32", "front running var 2", f32_tol=1e-2)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,C,S", [(32, 4, 12, 256, 1536, 64), (32, 8, 24, 160, 960, 40), (7, 8, 24, 128, 512, 32)])
+def test_mbconv_front_one_launch_vs_the_three_operators(lib, B, H, W, Cin, C, S):
+    """the one launch against satrn_linear_fwd_stats -> satrn_batchnorm_act_dwconv3x3_fwd -> satrn_batchnorm_act_se_fwd on the same inputs:
+    same rounding points, so the two forms differ only through the summation order of the statistics (and of the k loop)."""
+    eps = 1e-3
+    inp = _inputs(B, H, W, Cin, C, S)
+    x, W0, g1, be1, g2, be2, dw, W1, W2, b1, b2 = inp
+    M = B * H * W
+    box = _mailbox(B, C)
+    rc, o = _run_front(lib, inp, B, H, W, Cin, C, S, eps, box)
+    assert rc == 0, lib.satrn_last_error().decode()
+    bf = torch.bfloat16
+    W0d, _, _ = pack_dense(lib, W0, BF)
+    wp = torch.empty(9, C, dtype=bf, device="cuda")
+    ok(lib, lib.satrn_pack_dwconv3x3(1, P(dev(dw)), P(wp), C, st()))
+    y1 = torch.zeros(M, C, dtype=bf, device="cuda")
+    stats1 = torch.zeros(2 * C, device="cuda")
+    ok(lib, lib.satrn_linear_fwd_stats(1, P(dev(x, BF)), P(W0d), P(y1), M, C, Cin, P(stats1), 1, None, None, None, 0, 0, st()))
+    scr1b, stats2 = torch.zeros(6 * C, device="cuda"), torch.zeros(2 * C, device="cuda")
+    z1, y2 = torch.zeros(M, C, dtype=bf, device="cuda"), torch.zeros(M, C, dtype=bf, device="cuda")
+    rm, rv, nbt = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    # (the operator recomputes the column sums of y1 itself: they equal the epilogue's up to summation order)
+    ok(lib, lib.satrn_batchnorm_act_dwconv3x3_fwd(1, P(y1), P(dev(g1)), P(dev(be1)), P(rm), P(rv), P(nbt), eps, 2, P(z1), P(wp), None, P(y2), P(stats2),
+                                                  B, H, W, C, P(scr1b), st()))
+    scr2 = torch.zeros(6 * C, device="cuda")
+    z2, z3 = torch.zeros(M, C, dtype=bf, device="cuda"), torch.zeros(M, C, dtype=bf, device="cuda")
+    po, u1, s1 = torch.zeros(B, C, device="cuda"), torch.zeros(B, S, device="cuda"), torch.zeros(B, S, device="cuda")
+    gd = torch.zeros(B, C, dtype=bf, device="cuda")
+    box2 = torch.zeros(128 * 1600, dtype=torch.int64, device="cuda")
+    rm2, rv2, nbt2 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    ok(lib, lib.satrn_batchnorm_act_se_fwd(1, P(y2), P(dev(g2)), P(dev(be2)), P(rm2), P(rv2), P(nbt2), eps, 2, P(z2), 1, P(dev(W1, BF)),
+                                           P(dev(b1)), P(dev(W2, BF)), P(dev(b2)), P(po), P(u1), P(s1), P(gd), P(z3), B, H * W, C, S, P(scr2), P(box2), 128, st()))
+    torch.cuda.synchronize()
+    for name, a, c in (("y1", o["y1"], y1), ("z1", o["z1"], z1), ("y2", o["y2"], y2), ("z3", o["z3"], z3)):
+        same = (a == c).float().mean().item()
+        print(f"[front vs three operators {name}] identical elements {same:.6f}")
+        close(a, c.cpu(), BF, f"front vs three operators {name}", bf16_tol=1.6e-2)
+        assert same > (0.999 if name == "y1" else 0.97)
+    close(o["gate"], gd.cpu(), BF, "front vs three operators gate", bf16_tol=1e-2)
+    close(o["pooled"], po.cpu(), BF, "front vs three operators pooled", bf16_tol=1e-2)
+
+
+def test_mbconv_front_refuses_what_it_cannot_hold(lib):
+    """shapes outside the one-launch form return -1 and touch nothing: a map that is not 48 / 192 pixels, a batch beyond the mailbox"""
+    box = _mailbox(4, 128)
+    inp = _inputs(4, 6, 10, 128, 128, 8)
+    rc, _ = _run_front(lib, inp, 4, 6, 10, 128, 128, 8, 1e-3, box)
+    assert rc == -1
+    inp = _inputs(65, 4, 12, 256, 64, 8)
+    rc, _ = _run_front(lib, inp, 65, 4, 12, 256, 64, 8, 1e-3, _mailbox(65, 64))
+    assert rc == -1
+    assert lib.satrn_device_error(st()) == 0
