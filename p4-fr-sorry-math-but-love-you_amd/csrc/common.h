@@ -234,3 +234,30 @@ DEVI bool se_box_wait(se_box_t* g, unsigned want, long long t_end, float& val, u
   val = __uint_as_float((unsigned)v);
   return true;
 }
+// n (<= MAXN) granules base[i * stride], i < n, into vals[]: ALL requests are in flight together and the ones whose tag does not match yet
+// are requested again together -- a wait for several producers costs one memory round trip per retry, not one per producer (the loop of
+// se_box_wait calls this replaces was a chain of dependent round trips: 12 in the squeeze-and-excite exchange of a 24-slab image).
+template <int MAXN>
+DEVI bool se_box_gather(se_box_t* base, size_t stride, int n, unsigned want, long long t_end, float* vals, unsigned* err) {
+  unsigned pend = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+  unsigned spins = 0;
+  while (pend) {
+    unsigned long long w[MAXN];
+#pragma unroll
+    for (int k = 0; k < MAXN; ++k)
+      if ((pend >> k) & 1u) w[k] = __hip_atomic_load(base + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < MAXN; ++k)
+      if (((pend >> k) & 1u) && (unsigned)(w[k] >> 32) == want) { vals[k] = __uint_as_float((unsigned)w[k]); pend &= ~(1u << k); }
+    if (pend) {
+      if (spins > 4) __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 255u) == 0 && (long long)wall_clock64() > t_end) {
+        atomicOr(err, 4u);
+#pragma unroll
+        for (int k = 0; k < MAXN; ++k) if ((pend >> k) & 1u) vals[k] = 0.f;
+        return false;
+      }
+    }
+  }
+  return true;
+}

@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(512, 4) void dw_eval_img_kernel(const bf16_t* __res
     xc.NG = C / (SC * CH); xc.S = se.S; xc.tag = se.tag; xc.t_end = t_end; xc.err = &g_satrn_errflag;
     xc.ibox = (se_box_t*)se.box + (size_t)img * xc.NG * 64;
     float uu, sv;
-    se_exchange_gates(xc, se_ps, w1r, w2r, b1v, b2v, se_hq, se_hs, se_gl, uu, sv);
+    se_exchange_gates<4>(xc, se_ps, w1r, w2r, b1v, b2v, se_hq, se_hs, se_gl, uu, sv);
     float gv[CH];
     lds8(se_gl + chunk * CH, gv);
 #pragma unroll

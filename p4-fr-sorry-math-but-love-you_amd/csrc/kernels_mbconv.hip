@@ -22,8 +22,6 @@
 
 MbBoxCtx g_mbbox;
 
-// 48-pixel maps (4 x 12): staging buffer 6 912 B + tile (4 + 2) x 15 x 128 B = 11 520 B -> the squeeze-and-excite rows start at 18 432
-#define MB_WROWS_OFF_48 18432
 struct MbBn { const float* w; const float* b; float* rm; float* rv; int64_t* nbt; float* ss; float* mr; float eps; };
 struct MbFrontP {
   const bf16_t* x;       // [B][HW][Cin]   block input
@@ -41,32 +39,24 @@ struct MbFrontP {
   se_box_t* box_bn1; se_box_t* box_bn2;   // [C/64][B][128] granules each
   se_box_t* box_se;                       // [B][C/64][64]
   unsigned tag; long long timeout_ticks; unsigned* err;   // device error word (bit 2: a wait timed out)
+  long long* dbg;        // SATRN_MB_PROF: wall-clock marks of workgroup (0, 0) and of the last one
   float mom, invM, unbias;
   int B, H, W, C, S, rowpix;
 };
 
-// the B images' shares of this slab's 128 sums -> gs[group][128] (thread = value v x image group; images group, group + NG, ... in order)
+// the B images' shares of this slab's 128 sums -> gs[group][128] (thread = value v x image group; images group, group + NG, ... in order;
+// all of a thread's requests in flight together: se_box_gather)
 template <int NT>
 DEVI void mb_gather_sums(se_box_t* sbox /*[B][128] of this slab*/, int B, unsigned tag, long long t_end, unsigned* err, float (*gs)[128]) {
-  constexpr int NG = NT / 128, GB = NT >= 512 ? 8 : 16;   // loads in flight per thread (the 512-thread form has 128 registers)
+  constexpr int NG = NT / 128, GB = NT >= 512 ? 8 : 16;   // requests in flight per thread (the 512-thread form has 128 registers)
   const int tid = threadIdx.x, v = tid & 127, grp = tid >> 7;
   float a = 0.f;
   for (int i0 = grp; i0 < B; i0 += NG * GB) {
-    unsigned long long w[GB];
+    float vals[GB];
+    const int n = min(GB, (B - i0 + NG - 1) / NG);
+    se_box_gather<GB>(sbox + (size_t)i0 * 128 + v, (size_t)NG * 128, n, tag, t_end, vals, err);
 #pragma unroll
-    for (int k = 0; k < GB; ++k) {
-      const int im = i0 + k * NG;
-      w[k] = im < B ? __hip_atomic_load(sbox + (size_t)im * 128 + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    }
-#pragma unroll
-    for (int k = 0; k < GB; ++k) {
-      const int im = i0 + k * NG;
-      if (im < B) {
-        float val = __uint_as_float((unsigned)w[k]);
-        if ((unsigned)(w[k] >> 32) != tag) se_box_wait(sbox + (size_t)im * 128 + v, tag, t_end, val, err);
-        a += val;
-      }
-    }
+    for (int k = 0; k < GB; ++k) if (k < n) a += vals[k];
   }
   gs[grp][v] = a;
 }
@@ -102,9 +92,8 @@ __global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbc
   constexpr int KS = CIN / 32, XP = CIN + 8, YP = 72;
   constexpr int RTW = HWT == 48 ? 3 : 6, CTW = HWT == 48 ? 2 : 1;   // MFMA tiles per wave: 6 = RTW row tiles x CTW column tiles
   constexpr int NXC = HWT * CIN / 8, XPT = (NXC + NT - 1) / NT;
-  // dynamic LDS: image rows [HWT][XP] | overlaid later by: staging buffer [HWT][YP], zero-halo tile behind it, the 16 KB of squeeze-and-
-  // excite rows over the staging buffer (192-pixel maps: it is 27 KB and dead by then) or behind the tile (48-pixel maps)
-  constexpr int WROWS_OFF = HWT * YP * 2 >= 16384 ? 0 : MB_WROWS_OFF_48;
+  // dynamic LDS: image rows [HWT][XP] | overlaid later by: staging buffer [HWT][YP] + zero-halo tile behind it | later still by the 16 KB
+  // of squeeze-and-excite rows
   static_assert(NT % 128 == 0 && (HWT / 16) * 4 == NW * RTW * CTW, "tile split");
   extern __shared__ __attribute__((aligned(16))) unsigned char mb_sm[];
   __shared__ __attribute__((aligned(16))) float cf[2][64];
@@ -122,6 +111,8 @@ __global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbc
   const int img = blockIdx.x, slab = blockIdx.y, cb = slab * 64;
   const int C = p.C, H = p.H, W = p.W, B = p.B, rowpix = p.rowpix;
   const long long t_end = (long long)wall_clock64() + p.timeout_ticks;
+#define MB_MARK(i) do { if (p.dbg && tid == 0 && (img == 0 || img == B - 1) && (slab == 0 || slab == (int)gridDim.y - 1)) p.dbg[((img ? 1 : 0) * 2 + (slab ? 1 : 0)) * 16 + (i)] = (long long)wall_clock64(); } while (0)
+  MB_MARK(0);
 
   // ---- phase 1: expand product [HW x 64] = x_b [HW x CIN] * W0[slab]^T ------------------------------------------------------------
   const bf16_t* xb = p.x + (size_t)img * HWT * CIN;
@@ -147,6 +138,7 @@ __global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbc
     }
   }
   __syncthreads();
+  MB_MARK(1);
   f32x4 acc[RTW][CTW];
 #pragma unroll
   for (int rt = 0; rt < RTW; ++rt)
@@ -191,6 +183,7 @@ __global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbc
     if (HWT != 48) t += sst[1][k][c];
     se_box_put(p.box_bn1 + ((size_t)slab * B + img) * 128 + tid, p.tag, t);
   }
+  MB_MARK(2);
   // ---- phase 1b: the image-tile mapping (thread = 16-byte chunk x pixel lane); y1 to memory ------------------------------------------
   const int chunk = tid % SC, g = tid / SC;
   const long base = (long)img * HWT * C + cb + chunk * CH;
@@ -204,24 +197,12 @@ __global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbc
   uint4* tile = reinterpret_cast<uint4*>(mb_sm + (size_t)HWT * YP * 2);   // [(H + 2)][rowpix][SC] chunks behind the staging buffer
   for (int i = tid; i < 9 * SC; i += NT) wl[i / SC][i % SC] = ld16(p.wdw + (long)(i / SC) * C + cb + (i % SC) * CH);
   bdw_zero_halo(tile, H, W, rowpix, tid, NT);
-  // the squeeze-and-excite rows of this slab (64 rows of the expand matrix, the slab's 64 columns of the <= 64 reduce rows: 1024 16-byte
-  // chunks) are requested now by ALL threads, parked in LDS after the first exchange and read by threads 0..63 two exchanges later
   const int S = p.S;
-  constexpr int WPT = 1024 / NT;
-  uint4 wrow[WPT];
-#pragma unroll
-  for (int k = 0; k < WPT; ++k) {
-    const int i = tid + k * NT, r = (i >> 3) & 63, u = i & 7;
-    wrow[k] = i < 512 ? ld16(p.We + (long)(cb + r) * S + (u * CH < S ? u * CH : 0)) : ld16(p.Wr + (long)(r < S ? r : 0) * C + cb + u * CH);
-  }
-  float b2v = 0.f, b1v = 0.f;
-  if (tid < 64) { b2v = p.be[cb + tid]; if (tid < S) b1v = p.br[tid]; }
+  MB_MARK(3);
   // ---- exchange 1: BatchNorm 1 statistics over the batch ---------------------------------------------------------------------------
   mb_gather_sums<NT>(p.box_bn1 + (size_t)slab * B * 128, B, p.tag, t_end, p.err, gs);
   mb_bn_finalize<NT>(p.bn1, gs, cf, cb, C, img, p.invM, p.unbias, p.mom);
-  uint4* wrows = reinterpret_cast<uint4*>(mb_sm + WROWS_OFF);   // [expand 64][8] | [reduce 64][8]  (the staging buffer is dead: finalize's barriers)
-#pragma unroll
-  for (int k = 0; k < WPT; ++k) wrows[tid + k * NT] = wrow[k];
+  MB_MARK(4);
   // ---- phase 2: BatchNorm 1 + SiLU -> z1 (memory + zero-halo tile) -> depthwise 3x3 -> y2 + its column sums (bn_dw_img_kernel) --------
   {
     float sc[CH], sh[CH];
@@ -277,9 +258,26 @@ __global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbc
     se_box_put(p.box_bn2 + ((size_t)slab * B + img) * 128 + tid, p.tag, t);
   }
   __syncthreads();   // sred is read: the gather below reuses the scratch
+  MB_MARK(5);
+  // the squeeze-and-excite rows of this slab (64 rows of the expand matrix, the slab's 64 columns of the <= 64 reduce rows: 1024 16-byte
+  // chunks) are requested here by ALL threads -- behind the second exchange -- and parked in LDS for threads 0..63 (staging buffer and
+  // tile are dead by then)
+  constexpr int WPT = 1024 / NT;
+  uint4 wrow[WPT];
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) {
+    const int i = tid + k * NT, r = (i >> 3) & 63, u = i & 7;
+    wrow[k] = i < 512 ? ld16(p.We + (long)(cb + r) * S + (u * CH < S ? u * CH : 0)) : ld16(p.Wr + (long)(r < S ? r : 0) * C + cb + u * CH);
+  }
+  float b2v = 0.f, b1v = 0.f;
+  if (tid < 64) { b2v = p.be[cb + tid]; if (tid < S) b1v = p.br[tid]; }
   // ---- exchange 2: BatchNorm 2 statistics ---------------------------------------------------------------------------------------------
   mb_gather_sums<NT>(p.box_bn2 + (size_t)slab * B * 128, B, p.tag, t_end, p.err, gs);
   mb_bn_finalize<NT>(p.bn2, gs, cf, cb, C, img, p.invM, p.unbias, p.mom);
+  uint4* wrows = reinterpret_cast<uint4*>(mb_sm);   // [expand 64][8] | [reduce 64][8]
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) wrows[tid + k * NT] = wrow[k];
+  MB_MARK(6);
   // ---- phase 3: BatchNorm 2 + SiLU -> pool -> squeeze-and-excite between the image's workgroups -> z3 (bn_pool_se_img_kernel) --------
   uint4 zq[RUN];
   {
@@ -319,15 +317,17 @@ __global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbc
     p.pooled[(long)img * C + cb + tid] = m;
   }
   __syncthreads();
+  MB_MARK(7);
   {
     SeXchg xc;
     xc.NG = C / 64; xc.S = S; xc.tag = p.tag; xc.t_end = t_end; xc.err = p.err;
     xc.ibox = p.box_se + (size_t)img * xc.NG * 64;
     float uu, sv;
-    se_exchange_gates(xc, ps, wrows + 512 + (tid & 63) * 8, wrows + (tid & 63) * 8, b1v, b2v, hq, hs, gl, uu, sv);
+    se_exchange_gates<(NT >= 512 ? 4 : 12)>(xc, ps, wrows + 512 + (tid & 63) * 8, wrows + (tid & 63) * 8, b1v, b2v, hq, hs, gl, uu, sv);
     if (tid < S && slab == 0) { p.u1[(long)img * S + tid] = uu; p.s1[(long)img * S + tid] = sv; }
     if (tid < 64) p.gate[(long)img * C + cb + tid] = from_f<T>(gl[tid]);
   }
+  MB_MARK(8);
   {
     float gv[CH];
     lds8(gl + chunk * CH, gv);
@@ -340,6 +340,7 @@ __global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbc
       st16(p.z3 + base + (long)(row * W + ox0 + pp) * C, pack<T>(v));
     }
   }
+  MB_MARK(9);
   if (img == 0 && slab == 0 && tid == 0) {
     if (p.bn1.nbt) *p.bn1.nbt += 1;
     if (p.bn2.nbt) *p.bn2.nbt += 1;
@@ -350,7 +351,7 @@ template <int HWT, int CIN>
 static size_t mb_front_lds(int H, int rowpix) {
   const size_t x_bytes = (size_t)HWT * (CIN + 8) * 2;
   size_t t_bytes = (size_t)HWT * 72 * 2 + (size_t)(H + 2) * rowpix * BDW_SC * 16;
-  if (HWT * 72 * 2 < 16384) t_bytes = (t_bytes > MB_WROWS_OFF_48 ? t_bytes : MB_WROWS_OFF_48) + 16384;
+  if (t_bytes < 16384) t_bytes = 16384;   // the squeeze-and-excite rows
   return x_bytes > t_bytes ? x_bytes : t_bytes;
 }
 // every workgroup of the grid waits for the others: all of them must be resident at once
@@ -358,7 +359,10 @@ template <int HWT, int CIN>
 static bool mb_front_fits(int B, int H, int C, int rowpix) {
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)mbconv_front_kernel<HWT, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
-  return (long)B * (C / 64) <= resident_capacity((const void*)mbconv_front_kernel<HWT, CIN>, HWT * 8 / 3, mb_front_lds<HWT, CIN>(H, rowpix));
+  const long cap = resident_capacity((const void*)mbconv_front_kernel<HWT, CIN>, HWT * 8 / 3, mb_front_lds<HWT, CIN>(H, rowpix));
+  static bool said = false;
+  if (!said && getenv("SATRN_MB_PROF")) { said = true; fprintf(stderr, "[mbconv front <%d, %d>] %ld workgroups resident at once, dynamic LDS %zu B\n", HWT, CIN, cap, mb_front_lds<HWT, CIN>(H, rowpix)); }
+  return (long)B * (C / 64) <= cap;
 }
 template <int HWT, int CIN>
 static bool mb_front_go(const MbFrontP& p, hipStream_t s) {
@@ -375,7 +379,6 @@ static bool mb_front_shape(int dt, int B, int H, int W, int Cin, int C, int S, h
   if ((HW != 48 && HW != 192) || (W % BDW_RUN) != 0 || (C % 64) != 0 || C > 1536 || S > 64 || (S % 8) != 0 || B < 1 || B > g_mbbox.images || B > g_sebox.images) return false;
   if ((size_t)3 * (C / 64) * B * 128 > g_mbbox.words) return false;
   if (!((HW == 48 && Cin == 256) || (HW == 192 && (Cin == 160 || Cin == 128)))) return false;
-  if (HW == 48 && (size_t)48 * 72 * 2 + (size_t)(H + 2) * ((W + 2) | 1) * BDW_SC * 16 > MB_WROWS_OFF_48) return false;   // (4 x 12 fits exactly; 2 x 24 / 6 x 8 do not)
   return se_box_usable(s) && device_error_word() != nullptr;
 }
 bool mbconv_front_ok(int dt, int B, int H, int W, int Cin, int C, int S, hipStream_t s) {
@@ -410,6 +413,27 @@ bool launch_mbconv_front(int dt, const void* x, const void* W0, void* y1, const 
   p.mom = mom; p.invM = 1.0f / (float)M; p.unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.f;
   p.B = B; p.H = H; p.W = W; p.C = C; p.S = S; p.rowpix = (W + 2) | 1;
   p.tag = se_next_tag();
-  if (HW == 48) return mb_front_go<48, 256>(p, s);
-  return Cin == 160 ? mb_front_go<192, 160>(p, s) : mb_front_go<192, 128>(p, s);
+  p.dbg = nullptr;
+  static const bool prof = getenv("SATRN_MB_PROF") != nullptr;   // diagnostics (tools): phase marks of the corner workgroups, printed after a sync
+  static long long* dbg = nullptr;
+  if (prof) {
+    if (!dbg && hipMalloc((void**)&dbg, 64 * sizeof(long long)) != hipSuccess) dbg = nullptr;
+    if (dbg) { (void)hipMemsetAsync(dbg, 0, 64 * sizeof(long long), s); p.dbg = dbg; }
+  }
+  const bool okk = HW == 48 ? mb_front_go<48, 256>(p, s) : (Cin == 160 ? mb_front_go<192, 160>(p, s) : mb_front_go<192, 128>(p, s));
+  if (okk && p.dbg) {
+    long long h[64];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    static const char* nm[] = {"", "x staged", "product + sums published", "y1 stored, requests issued", "exchange 1", "depthwise + sums published", "exchange 2", "pool", "se exchange", "z3 stored"};
+    long long t0 = h[0];
+    for (int w = 1; w < 4; ++w) if (h[w * 16] && h[w * 16] < t0) t0 = h[w * 16];
+    fprintf(stderr, "[mbconv front %dx%d Cin %d C %d B %d] marks in us since the first corner workgroup started (corners: img0/slab0, img0/last, last/slab0, last/last)\n", H, W, Cin, C, B);
+    for (int w = 0; w < 4; ++w) {
+      fprintf(stderr, "  start %6.2f |", (h[w * 16] - t0) * 0.01);
+      for (int i = 1; i < 10; ++i) fprintf(stderr, " %s +%.2f |", nm[i], (h[w * 16 + i] - h[w * 16 + i - 1]) * 0.01);
+      fprintf(stderr, " total %.2f\n", (h[w * 16 + 9] - h[w * 16]) * 0.01);
+    }
+  }
+  return okk;
 }

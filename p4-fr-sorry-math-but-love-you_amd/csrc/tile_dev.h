@@ -15,6 +15,8 @@ DEVI void lds8(const float* p, float* o) {   // 8 floats from LDS / memory throu
 // Out: gl[c] = the gate of channel c of this workgroup as stored (bf16-rounded), after a final barrier; hidden (thread < S, group 0 only
 // meaningful for the caller's u1 / s1 stores) is returned through u_out / s_out.
 struct SeXchg { se_box_t* ibox; unsigned tag; long long t_end; unsigned* err; int NG, S; };
+// GM: shares requested together per thread (registers: 3 per share; the image has NG <= 24 shares per hidden unit, spread over NT / 64 threads)
+template <int GM = 12>
 DEVI void se_exchange_gates(const SeXchg& x, const float* ps, const uint4* w1r, const uint4* w2r, float b1v, float b2v, float (*hq)[64], float* hs, float* gl,
                             float& u_out, float& s_out) {
   constexpr int CH = 8;
@@ -37,10 +39,12 @@ DEVI void se_exchange_gates(const SeXchg& x, const float* ps, const uint4* w1r, 
     const int jj = tid & 63, q = tid >> 6, NQ = NT / 64;
     float a = 0.f;
     if (jj < x.S)
-      for (int yy = q; yy < x.NG; yy += NQ) {
-        float v;
-        se_box_wait(x.ibox + (size_t)yy * 64 + jj, x.tag, x.t_end, v, x.err);
-        a += v;
+      for (int y0 = q; y0 < x.NG; y0 += NQ * GM) {   // the shares of up to GM workgroups requested (and re-requested) together
+        float v[GM];
+        const int n = min(GM, (x.NG - y0 + NQ - 1) / NQ);
+        se_box_gather<GM>(x.ibox + (size_t)y0 * 64 + jj, (size_t)NQ * 64, n, x.tag, x.t_end, v, x.err);
+#pragma unroll
+        for (int k = 0; k < GM; ++k) if (k < n) a += v[k];
       }
     hq[q][jj] = a;
   }
