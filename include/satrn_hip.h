@@ -181,6 +181,18 @@ int satrn_mbconv_front_fwd(const void* x, const void* W0, void* y1, const float*
                            int64_t* bn2_num_batches_tracked, float* bn2_coef, void* z2, int keep_z2, const void* W1, const float* b1, const void* W2,
                            const float* b2, float* pooled, float* u1, float* s1, void* gate, void* z3, int B, int H, int W, int Cin, int C, int S,
                            float eps, unsigned long long* mailbox, long mailbox_words, void* stream);
+/* Backward of the same block, first half of its middle, in ONE launch (bf16, the shapes of satrn_mbconv_front_fwd): the projection's data
+ * gradient dz3 = dy3 W_proj (dy3 [B][H][W][Cout] = the gradient at conv_pwl's output; w_bwd = satrn_pack_dense's backward pack of W_proj,
+ * [C][ldb]) and the squeeze-and-excite backward with z2 RECOMPUTED from BatchNorm 2's input bn2_y and coefficients bn2_coef (scale | shift |
+ * mean | rstd, 4 * C floats):  dgate = sum_hw dz3 * z2, dz2 = dgate * gate * (1 - gate) [B][C] fp32, ds1 = W2^T dz2 and du1 = ds1 * SiLU'(u1)
+ * [B][S] fp32, dpooled = W1^T du1 [B][C] bf16, and bn2_sums[2C] += this batch's BatchNorm-2 backward sums (sum g | sum g * xhat with
+ * g = (dz3 * gate + dpooled / HW) * SiLU'(.)): what satrn_linear_bwd_data + satrn_se_bwd_bnred produce.  dz3 [B][H][W][C] is written for the
+ * depthwise backward (satrn_bn_bwd_apply_dwconv3x3_bwd_data_bnred takes it with gate / dpooled).  Only the C / 64 workgroups of one image
+ * exchange data (mailbox: B * (C / 64) * 64 8-byte words, ZERO before the first call; shareable with the other mailbox operators), so the
+ * launch needs no whole-grid residency.  Returns -1 for shapes it does not take. */
+int satrn_mbconv_bwd_se(const void* dy3, const void* w_bwd, int ldb, void* dz3, const void* bn2_y, const float* bn2_coef, const void* gate,
+                        const float* u1, const void* W1, const void* W2, float* dz2, float* ds1, float* du1, void* dpooled, float* bn2_sums, int B,
+                        int H, int W, int Cout, int C, int S, unsigned long long* mailbox, long mailbox_words, void* stream);
 /* Training-mode BatchNorm2d + activation of y[B][H][W][C] -> z, followed by the stride-1 "same" depthwise 3x3 (+bias) of z -> out,
  * in one launch where the shape allows (the expand-BN-SiLU-depthwise seam of the timm MBConv block in the 8x24 / 4x12 stages;
  * networks/EfficientSATRN.py:74-76 runs those blocks).  Results equal satrn_batchnorm_act_fwd + satrn_dwconv3x3_fwd bit for bit

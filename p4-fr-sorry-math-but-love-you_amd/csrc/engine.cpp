@@ -69,7 +69,7 @@ void Exec::defer(std::function<void(hipStream_t)> fn) {
   // chain's queue + a wait on the side queue; the record alone is 2 us).  Larger batches early in the backward and small
   // ones near the join were tried as well (32 / 8): no change -- what the fewer forks save, the later start of the side work costs
   static const int thr = getenv("SATRN_FLUSH") ? atoi(getenv("SATRN_FLUSH")) : 8;
-  if ((int)pending.size() >= thr) flush_side();
+  if ((int)pending.size() >= thr && !hold_side) flush_side();
 }
 void Exec::flush_side() {
   if (pending.empty()) return;
@@ -825,6 +825,12 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
         d.M = (int)M; d.N = w->K; d.K = w->ldb; d.lda = ldy; d.ldc = x->C;
         e.nflops = 2.0 * (double)d.M * d.N * w->N;
         e.nbytes = ((double)d.M * w->N + (double)d.M * d.N * (beta ? 2 : 1) + (double)w->N * d.N) * e.esz();  // dY + dX (+old dX) + W
+        if (x->se_out && !beta && !fuse_bnb && !d.bact_u && !out_f32 && ldy == N && !e.dry && e.dt == DT_BF16) {
+          // x is a squeeze-and-excite output: its closure (next) runs this product together with its own kernels where it can
+          x->dgrad_hold = std::make_shared<GemmP>(d); x->dgrad_hold_flops = e.nflops; x->dgrad_hold_bytes = e.nbytes;
+          e.nflops = 0; e.nbytes = 0;
+          return;
+        }
         LCH(e, launch_gemm(e.dt, AM_DENSE, d, e.s));
       } else {
         d.M = (int)((long)B * g.H * g.W); d.N = g.Ci; d.K = 9 * w->Co; d.ldc = g.Ci;
@@ -1654,6 +1660,7 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr, SeHold
   Tensor* gate = e.newt(B, C);
   Tensor* y = e.newt(x->rows, C, B, x->H, x->W);
   e.last_se = Exec::LastSe{pooled, u1, s1, gate->p, true};
+  y->se_out = true;
   bool fused = false;
   if (sh && sh->armed && sh->dwfn) {
     // inference: depthwise 3x3 + eval BatchNorm + SiLU + pool + MLP + x*gate in ONE launch where the grid is resident at once
@@ -1698,7 +1705,15 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr, SeHold
   }
   if (e.rec)
     e.tape.push_back([&e, x, y, gate, eb, pooled, u1, s1, B, HW, C, S]() {
-      if (!y->g) return;
+      std::shared_ptr<GemmP> held = y->dgrad_hold;   // the data gradient of the product that consumed y, not launched yet (op_gemm)
+      y->dgrad_hold.reset();
+      auto run_held = [&]() {
+        if (!held) return;
+        WORK(e, y->dgrad_hold_flops, y->dgrad_hold_bytes);
+        LCH(e, launch_gemm(e.dt, AM_DENSE, *held, e.s));
+        held.reset();
+      };
+      if (!y->g) { run_held(); return; }
       void* dgate = e.alloc((size_t)B * C * e.esz());
       void* dpooled = e.alloc((size_t)B * C * e.esz());
       float* dz2 = (float*)e.alloc((size_t)B * C * 4);
@@ -1715,9 +1730,20 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr, SeHold
       const bool bnred = folds && g_fuse_bnb && !x->bn_red && getenv("SATRN_SE_NO_BN_SUMS") == nullptr;   // read per call (tests)
       float* bnP = bnred ? (float*)e.alloc((size_t)4 * B * C * 4) : nullptr;
       float* bnR = bnred ? e.zalloc((size_t)2 * C) : nullptr;
+      if (held && bnred && x->bn_act == ACT_SILU && !e.dry) {
+        // the projection's data gradient + this backward in ONE launch (only the image's own workgroups wait for each other)
+        bool one = false;
+        WORK(e, y->dgrad_hold_flops + 8.0 * (double)B * C * S, y->dgrad_hold_bytes + (double)x->rows * C * e.esz() * 2 + (double)C * S * e.esz() * 2);
+        LCH(e, one = launch_mbconv_bwd_se(dt, held->A, held->Bw, held->K, held->C, x->bn_y, x->bn_ss, x->bn_mr, gp, u1, w2, w1, dz2, ds1, du1, dpooled, bnR,
+                                          B, x->H, x->W, held->lda, C, S, e.s));
+        if (one) { held.reset(); wide = true; }
+      }
+      run_held();
+      if (!wide) {
       WORK(e, 8.0 * (double)B * C * S, (double)x->rows * C * e.esz() * 2 + (double)C * S * e.esz() * 2);
       LCH(e, wide = launch_se_bwd_wide(dt, y->g, x->p, gp, u1, w1, w2, dz2, du1, ds1, dpooled, B, HW, C, S, e.s, bnred ? x->bn_y : nullptr, x->bn_ss, x->bn_mr,
                                        x->bn_act, bnP, bnR));
+      }
       if (wide && bnred && !e.dry) { x->bn_red = bnR; x->bn_red_rep = 1; }
       if (e.dry) wide = true;   // planning pass: same allocations either way
       if (wide) {
@@ -1858,9 +1884,14 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
     x = op_bn_act(e, x, &m->stem_bn, ACT_SILU, nullptr);
     stage_mark("stem");
     probe(e, "stem", x);
+    // experiment (SATRN_HOLD_SIDE_LATE=<first stage index>): weight gradients of the MBConv stages from that block on are queued during
+    // their backward and released when the backward leaves them
+    const int hold_from = getenv("SATRN_HOLD_SIDE_LATE") ? atoi(getenv("SATRN_HOLD_SIDE_LATE")) : -1;
     for (size_t bi = 0; bi < m->blocks.size(); ++bi) {
       if ((int)bi == m->late_block) m->seg_mark[0] = e.tape.size();
+      if (hold_from >= 0 && (int)bi == hold_from && e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->hold_side = false; ep->flush_side(); }); }
       x = eff_block(e, x, &m->blocks[bi]);
+      if (hold_from >= 0 && bi + 1 == m->blocks.size() && e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->flush_side(); ep->hold_side = true; }); }
       if (bi + 1 == m->blocks.size() || m->blocks[bi + 1].cout != m->blocks[bi].cout) {
         stage_mark("cout" + std::to_string(m->blocks[bi].cout));
         probe(e, "backbone_c" + std::to_string(m->blocks[bi].cout), x);
@@ -2057,7 +2088,7 @@ static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) 
   det_activate(m);
   e.s = s; e.dt = m->cfg.dtype; e.train = train; e.rec = rec; e.dry = dry;
   e.drop = train ? m->cfg.dropout : 0.f;
-  e.probes.clear(); e.probe_on = m->probe_on;
+  e.probes.clear(); e.probe_on = m->probe_on; e.hold_side = false;
   if (!e.dry && e.zbase && e.zoff > m->zero_hwm) m->zero_hwm = e.zoff;  // what the previous call dirtied at most
   e.reset(m->ws + m->persist_bytes, m->ws_bytes > m->persist_bytes ? m->ws_bytes - m->persist_bytes : 0,
           m->ws + m->off_zero, m->zero_bytes);

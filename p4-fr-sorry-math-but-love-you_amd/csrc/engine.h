@@ -85,6 +85,9 @@ struct Tensor {
   // output of a depthwise convolution whose backward kernel can also run the backward-apply pass of the BatchNorm that consumes this
   // tensor: that BatchNorm's closure leaves its operands in bhold instead of launching (op_bn_act -> op_dwconv, launch_dwconv_bwd_bn)
   bool dw_bwd_fuse = false; BnBwdHold bhold;
+  // the output of a squeeze-and-excite block (op_se): the dense product that consumes it leaves its data gradient here instead of launching,
+  // and op_se's backward runs both in one launch where the shape allows (launch_mbconv_bwd_se), else launches the held product first
+  bool se_out = false; std::shared_ptr<GemmP> dgrad_hold; double dgrad_hold_flops = 0, dgrad_hold_bytes = 0; int dgrad_hold_ldb = 0; const void* dgrad_hold_w = nullptr;
   // inference: a product whose launch is postponed until the BatchNorm that consumes it is known, so that BatchNorm (eval
   // statistics) + activation + residual run in its epilogue and the raw output is never written (op_gemm -> op_bn_act)
   std::shared_ptr<GemmP> pend; int pend_mode = 0;
@@ -194,6 +197,7 @@ struct Exec {
   hipStream_t s2 = nullptr; std::vector<hipEvent_t> evs; hipEvent_t evj = nullptr; int nfork = 0; bool forked = false;
   hipStream_t side(); void join();
   std::vector<std::function<void(hipStream_t)>> pending; void defer(std::function<void(hipStream_t)> fn); void flush_side();
+  bool hold_side = false;   // weight-gradient launches are queued but not handed to the side stream (while kernels whose workgroups wait for each other run on the chain)
 
   // SATRN_STAGE_PROF=1: events on the main stream at stage boundaries of an ordinary eager step (forward and, through tape
   // closures, backward) -> per-stage wall time of the critical chain, printed by the next step

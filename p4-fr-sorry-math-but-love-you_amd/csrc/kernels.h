@@ -352,6 +352,12 @@ bool launch_mbconv_front(int dt, const void* x, const void* W0, void* y1, const 
                          float* bn2_rv, int64_t* bn2_nbt, float* bn2_ss, float* bn2_mr, float bn2_eps, void* z2, const void* Wr, const float* br,
                          const void* We, const float* be, float* pooled, float* u1, float* s1, void* gate, void* z3, int B, int H, int W, int Cin, int C, int S,
                          float mom, hipStream_t s);
+// Backward: the projection's data gradient dz3 = dy3 W1 and the squeeze-and-excite backward (incl. the sums BatchNorm 2's backward needs) in
+// ONE launch (kernels_mbconv.hip); same shapes as the front.  Wb = the projection's backward pack [C][ldb]; red [2C] is accumulated into.
+// Only the workgroups of one image wait for each other (g_sebox).  false = not taken.
+bool launch_mbconv_bwd_se(int dt, const void* dy3, const void* Wb, int ldb, void* dz3, const void* y2, const float* ss2, const float* mr2, const void* gate,
+                          const float* u1, const void* We, const void* Wr, float* dz2, float* ds1, float* du1, void* dpooled, float* red, int B, int H, int W,
+                          int CN, int C, int S, hipStream_t s);
 bool launch_se_mlp_scale(int dt, const void* x, const float* poolsum, const void* W1, const float* b1, const void* W2, const float* b2,
                          float* pooled, float* u1, float* s1, void* gate, void* y, int B, int HW, int C, int S, hipStream_t s);
 void launch_se_fwd(int dt, const void* x, const void* W1, const float* b1, const void* W2, const float* b2, float* pooled,

@@ -15,12 +15,6 @@
     else { typedef float T; __VA_ARGS__; }       \
   } while (0)
 
-DEVI void ldv(const float* p, float* o, int n) {  // n (multiple of 4) floats through 16-byte loads
-  for (int j = 0; j < n; j += 4) {
-    float4 v = *reinterpret_cast<const float4*>(p + j);
-    o[j] = v.x; o[j + 1] = v.y; o[j + 2] = v.z; o[j + 3] = v.w;
-  }
-}
 
 
 DetCtx g_det;

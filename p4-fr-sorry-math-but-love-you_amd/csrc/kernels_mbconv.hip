@@ -437,3 +437,293 @@ bool launch_mbconv_front(int dt, const void* x, const void* W0, void* y1, const 
   }
   return okk;
 }
+
+// =====================================================================================================================================
+// Backward, first half of the block's middle: the projection's data gradient and the squeeze-and-excite backward in ONE launch
+//   dz3 [HW x 64] = dy3_b [HW x Cout] * W1[:, slab]   (dy3 = gradient at the projection's output, after BatchNorm 3's backward)
+//   dgate = sum_hw dz3 * z2, dz2 = dgate * gate * (1 - gate), ds1 = W2^T dz2, du1 = ds1 * SiLU'(u1), dpooled = W1se^T du1
+//   + the four per-(image, channel) sums from which the backward column sums of BatchNorm 2 follow (z2 is RECOMPUTED from y2)
+// -- gemm_kernel | se_bwd_gate_ds_kernel | se_bwd_pool_kernel until round 3 (11 + 12..27 + 5 us on the chain).  The only dependency
+// across workgroups is the image's own (ds1 sums over all channels of ONE image): se_box_gather between the C/64 workgroups of an image.
+// No batch-wide wait, and the grid is dealt IMAGE-major (blockIdx.x = slab): a workgroup only ever waits for workgroups dispatched right
+// before / after it, so the launch makes progress whatever else holds compute units (the weight-gradient stream runs beside the
+// backward) -- the whole grid need not be resident.
+// Writes what the three kernels wrote: dz3 (bf16, read by the depthwise backward as the gradient of z2 together with gate / dpooled), dz2,
+// ds1, du1 (f32), dpooled (bf16), and adds this image's share to BatchNorm 2's backward sums red[2C] (float atomics, as before).
+struct MbBwdSeP {
+  const bf16_t* dy3;     // [B][HW][CN]
+  const bf16_t* Wb;      // [C][ldb]  the projection's backward pack (W1^T): row = expanded channel, columns = output channels
+  bf16_t* dz3;           // [B][HW][C]
+  const bf16_t* y2; const float* ss2; const float* mr2;   // BatchNorm 2: input, scale | shift, mean | rstd
+  const bf16_t* gate; const float* u1; const bf16_t* We /*[C][S]*/; const bf16_t* Wr /*[S][C]*/;
+  float* dz2; float* ds1; float* du1; bf16_t* dpooled; float* red /*[2C], accumulated*/;
+  se_box_t* box_se; unsigned tag; long long timeout_ticks; unsigned* err;
+  int B, H, W, C, S, ldb;
+};
+
+template <int HWT, int CN>
+__global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbconv_bwd_se_kernel(MbBwdSeP p) {
+  typedef bf16_t T;
+  constexpr int CH = 8, SC = BDW_SC, RUN = BDW_RUN;
+  constexpr int NT = HWT * 8 / 3, NW = NT / 64, G = NT / SC;
+  constexpr int KS = CN / 32, XP = CN + 8, YP = 72;
+  constexpr int RTW = HWT == 48 ? 3 : 6, CTW = HWT == 48 ? 2 : 1;
+  constexpr int NXC = HWT * CN / 8, XPT = (NXC + NT - 1) / NT, WPT = 1024 / NT, RPT = 512 / NT;   // RPT: matrix rows per thread in the small products
+  extern __shared__ __attribute__((aligned(16))) unsigned char mb_sm[];
+  __shared__ float part[5][NW][64];
+  __shared__ __attribute__((aligned(16))) float dzl[64];
+  __shared__ __attribute__((aligned(16))) float dul[64];
+  __shared__ float red[NW][64];
+  __shared__ float sums[5][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int slab = blockIdx.x, img = blockIdx.y, cb = slab * 64;
+  const int C = p.C, W = p.W, H = p.H, S = p.S;
+  const long long t_end = (long long)wall_clock64() + p.timeout_ticks;
+
+  // ---- the product, as in mbconv_front_kernel: image rows through LDS, this slab's 64 weight rows in registers --------------------------
+  const bf16_t* xb = p.dy3 + (size_t)img * HWT * CN;
+  uint4 xr[XPT];
+#pragma unroll
+  for (int k = 0; k < XPT; ++k) {
+    const int idx = tid + k * NT;
+    xr[k] = idx < NXC ? ld16(xb + (size_t)idx * 8) : zero16();
+  }
+  const int ct0 = HWT == 48 ? 2 * wave : (wave & 3), rt0 = HWT == 48 ? 0 : (wave >> 2) * RTW;
+  Frag<T> bfr[CTW][KS];
+#pragma unroll
+  for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bfr[ct][ks].v = ld16(p.Wb + (size_t)(cb + (ct0 + ct) * 16 + fr) * p.ldb + ks * 32 + fq * 8);
+  bf16_t* xbuf = reinterpret_cast<bf16_t*>(mb_sm);
+#pragma unroll
+  for (int k = 0; k < XPT; ++k) {
+    const int idx = tid + k * NT;
+    if (idx < NXC) {
+      const int row = idx / (CN / 8), ch = idx - row * (CN / 8);
+      st16(xbuf + row * XP + ch * 8, xr[k]);
+    }
+  }
+  // operands of the element-wise phase, requested before the product: BatchNorm 2's input of this thread's pixels, its coefficients
+  const int chunk = tid % SC, g = tid / SC;
+  const long base = (long)img * HWT * C + cb + chunk * CH;
+  uint4 y2q[RUN];
+#pragma unroll
+  for (int k = 0; k < RUN; ++k) y2q[k] = ld16(p.y2 + base + (long)(g + k * G) * C);
+  __syncthreads();
+  f32x4 acc[RTW][CTW];
+#pragma unroll
+  for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt) {
+      Frag<T> a;
+      a.v = ld16(xbuf + ((rt0 + rt) * 16 + fr) * XP + ks * 32 + fq * 8);
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct) mma(a, bfr[ct][ks], acc[rt][ct]);
+    }
+  }
+  __syncthreads();
+  bf16_t* ybuf = reinterpret_cast<bf16_t*>(mb_sm);
+#pragma unroll
+  for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ybuf[((rt0 + rt) * 16 + fq * 4 + r) * YP + (ct0 + ct) * 16 + fr] = from_f<T>(acc[rt][ct][r]);
+  // the squeeze-and-excite rows of this slab (expand rows [64][S], the slab's columns of the reduce rows [S][64]): requested by all threads
+  uint4 wrow[WPT];
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) {
+    const int i = tid + k * NT, r = (i >> 3) & 63, u = i & 7;
+    wrow[k] = i < 512 ? ld16(p.We + (long)(cb + r) * S + (u * CH < S ? u * CH : 0)) : ld16(p.Wr + (long)(r < S ? r : 0) * C + cb + u * CH);
+  }
+  __syncthreads();
+  // ---- dz3 to memory; dgate and the BatchNorm-2 sums over this thread's pixels (se_bwd_gate_ds_kernel's arithmetic) ------------------------
+  float a[CH], p1[CH], p2[CH], p3[CH], p4[CH];
+#pragma unroll
+  for (int j = 0; j < CH; ++j) a[j] = p1[j] = p2[j] = p3[j] = p4[j] = 0.f;
+  {
+    float sc[CH], sh[CH], mu[CH], rs[CH];
+    ldv(p.ss2 + cb + chunk * CH, sc, CH); ldv(p.ss2 + C + cb + chunk * CH, sh, CH);
+    ldv(p.mr2 + cb + chunk * CH, mu, CH); ldv(p.mr2 + C + cb + chunk * CH, rs, CH);
+#pragma unroll
+    for (int k = 0; k < RUN; ++k) {
+      const int pix = g + k * G;
+      const uint4 dq = ld16(ybuf + pix * YP + chunk * CH);
+      st16(p.dz3 + base + (long)pix * C, dq);
+      float d[CH], v[CH];
+      unpack<T>(dq, d);
+      unpack<T>(y2q[k], v);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const float u = v[j] * sc[j] + sh[j];
+        const float sg = sigmoidf_(u), xf = u * sg, ab = sg * (1.f + u * (1.f - sg));
+        const float xv = to_f(from_f<T>(xf));   // the stored activation, bit for bit
+        const float da = d[j] * ab, xh = (v[j] - mu[j]) * rs[j];
+        a[j] += d[j] * xv;
+        p1[j] += da; p2[j] += ab; p3[j] += da * xh; p4[j] += ab * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = SC; o < 64; o <<= 1)
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      a[j] += __shfl_xor(a[j], o, 64);
+      p1[j] += __shfl_xor(p1[j], o, 64); p2[j] += __shfl_xor(p2[j], o, 64); p3[j] += __shfl_xor(p3[j], o, 64); p4[j] += __shfl_xor(p4[j], o, 64);
+    }
+  if (lane < SC) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      part[0][wave][lane * CH + j] = a[j]; part[1][wave][lane * CH + j] = p1[j]; part[2][wave][lane * CH + j] = p2[j];
+      part[3][wave][lane * CH + j] = p3[j]; part[4][wave][lane * CH + j] = p4[j];
+    }
+  }
+  __syncthreads();   // (every thread has read its rows of the staging buffer: the matrix rows below overlay it)
+  uint4* wrows = reinterpret_cast<uint4*>(mb_sm);   // [expand 64][8] | [reduce 64][8]
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) wrows[tid + k * NT] = wrow[k];
+  if (tid < 64) {
+    float dg = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dg += part[0][w][tid];
+    const float gt = to_f(p.gate[(long)img * C + cb + tid]);
+    const float v = dg * gt * (1.f - gt);
+    dzl[tid] = v;
+    p.dz2[(long)img * C + cb + tid] = v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sum += part[1 + k][w][tid];
+      sums[1 + k][tid] = sum;
+    }
+  }
+  __syncthreads();
+  // ---- this slab's share of ds1 = W2^T dz2: thread = (chunk q of 8 hidden units, channel lane) ------------------------------------------
+  {
+    const int q = tid & 7, cl = tid >> 3;
+    float acc2[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc2[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int c = cl + (NT / 8) * k;
+      float wv[CH];
+      unpack<T>(wrows[c * 8 + q], wv);
+      const float d = dzl[c];
+#pragma unroll
+      for (int e = 0; e < CH; ++e) acc2[e] += wv[e] * d;
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < CH; ++e) acc2[e] += __shfl_xor(acc2[e], o, 64);
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) red[wave][lane * CH + e] = acc2[e];
+    }
+  }
+  __syncthreads();
+  const int NG = C / 64;
+  se_box_t* ibox = p.box_se + (size_t)img * NG * 64;
+  float dsv = 0.f;
+  if (tid < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += red[w][tid];
+    if (tid < S) {
+      se_box_put(ibox + (size_t)slab * 64 + tid, p.tag, t);
+      for (int y0 = 0; y0 < NG; y0 += 12) {   // slab order: the same sum in every workgroup, whoever arrives when
+        float v[12];
+        const int n = min(12, NG - y0);
+        se_box_gather<12>(ibox + (size_t)y0 * 64 + tid, 64, n, p.tag, t_end, v, p.err);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) if (k < n) dsv += v[k];
+      }
+    }
+    float v = 0.f;
+    if (tid < S) {
+      v = dsv * act_bwd(p.u1[(long)img * S + tid], ACT_SILU);
+      if (slab == 0) { p.du1[(long)img * S + tid] = v; p.ds1[(long)img * S + tid] = dsv; }
+    }
+    dul[tid] = v;
+  }
+  __syncthreads();
+  // ---- dpooled = W1se^T du1 for this slab's channels: thread = (chunk tx of 8 channels, hidden-unit lane) ----------------------------------
+  {
+    const int tx = tid & 7, jl = tid >> 3;
+    float acc2[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) acc2[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int j = jl + (NT / 8) * k;
+      float wv[CH];
+      unpack<T>(wrows[512 + j * 8 + tx], wv);
+      const float d = dul[j];   // 0 beyond S
+#pragma unroll
+      for (int e = 0; e < CH; ++e) acc2[e] += wv[e] * d;
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < CH; ++e) acc2[e] += __shfl_xor(acc2[e], o, 64);
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < CH; ++e) red[wave][lane * CH + e] = acc2[e];
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += red[w][tid];
+    const T vr = from_f<T>(v);
+    const long o = (long)img * C + cb + tid;
+    p.dpooled[o] = vr;
+    // this image's share of BatchNorm 2's backward column sums: the gradient reaching its output is dz3 * gate + dpooled / HW
+    const float gt = to_f(p.gate[o]), dp = to_f(vr) * (1.0f / (float)HWT);
+    atomicAdd(p.red + cb + tid, gt * sums[1][tid] + dp * sums[2][tid]);
+    atomicAdd(p.red + C + cb + tid, gt * sums[3][tid] + dp * sums[4][tid]);
+  }
+}
+
+template <int HWT, int CN>
+static bool mb_bwd_se_go(const MbBwdSeP& p, hipStream_t s) {
+  constexpr int NT = HWT * 8 / 3;
+  size_t lds = (size_t)HWT * (CN + 8) * 2;
+  if (lds < (size_t)HWT * 72 * 2) lds = (size_t)HWT * 72 * 2;
+  if (lds < 16384) lds = 16384;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)mbconv_bwd_se_kernel<HWT, CN>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
+  // only the workgroups of ONE image wait for each other, and they are dispatched back to back: C / 64 <= 24 of them must fit the device
+  if ((long)(p.C / 64) > resident_capacity((const void*)mbconv_bwd_se_kernel<HWT, CN>, NT, lds)) return false;
+  hipLaunchKernelGGL((mbconv_bwd_se_kernel<HWT, CN>), dim3(p.C / 64, p.B), dim3(NT), lds, s, p);
+  g_route[RT_MBCONV_BWD]++;
+  return true;
+}
+// false = shape / mode not taken (the caller runs the data-gradient product and the squeeze-and-excite backward kernels)
+bool launch_mbconv_bwd_se(int dt, const void* dy3, const void* Wb, int ldb, void* dz3, const void* y2, const float* ss2, const float* mr2, const void* gate,
+                          const float* u1, const void* We, const void* Wr, float* dz2, float* ds1, float* du1, void* dpooled, float* red, int B, int H, int W,
+                          int CN, int C, int S, hipStream_t s) {
+  const bool off = getenv("SATRN_NO_MBCONV_BWD_SE") != nullptr || getenv("SATRN_SE_NO_WIDE_BWD") != nullptr || getenv("SATRN_SE_NO_BN_SUMS") != nullptr;   // read per call (tests)
+  if (off || g_det.on || dt != DT_BF16 || !g_sebox.box) return false;
+  const int HW = H * W;
+  if ((HW != 48 && HW != 192) || (W % BDW_RUN) != 0 || (C % 64) != 0 || C > 1536 || S > 64 || (S % 8) != 0 || B < 1 || B > g_sebox.images || ldb < CN || (ldb & 7)) return false;
+  if (!((HW == 48 && CN == 256) || (HW == 192 && (CN == 160 || CN == 128)))) return false;
+  if (!se_box_usable(s)) return false;
+  MbBwdSeP p;
+  p.dy3 = (const bf16_t*)dy3; p.Wb = (const bf16_t*)Wb; p.dz3 = (bf16_t*)dz3; p.y2 = (const bf16_t*)y2; p.ss2 = ss2; p.mr2 = mr2;
+  p.gate = (const bf16_t*)gate; p.u1 = u1; p.We = (const bf16_t*)We; p.Wr = (const bf16_t*)Wr;
+  p.dz2 = dz2; p.ds1 = ds1; p.du1 = du1; p.dpooled = (bf16_t*)dpooled; p.red = red;
+  p.box_se = (se_box_t*)g_sebox.box; p.timeout_ticks = 200000000LL; p.err = device_error_word();
+  if (!p.err) return false;
+  p.B = B; p.H = H; p.W = W; p.C = C; p.S = S; p.ldb = ldb;
+  p.tag = se_next_tag();
+  if (HW == 48) return mb_bwd_se_go<48, 256>(p, s);
+  return CN == 160 ? mb_bwd_se_go<192, 160>(p, s) : mb_bwd_se_go<192, 128>(p, s);
+}

@@ -307,6 +307,18 @@ int satrn_mbconv_front_fwd(const void* x, const void* W0, void* y1, const float*
   if (!okk) return fail(-1, "mbconv_front_fwd: shape not taken by the one-launch form (use the separate operators)");
   return done("mbconv_front_fwd");
 }
+int satrn_mbconv_bwd_se(const void* dy3, const void* w_bwd, int ldb, void* dz3, const void* bn2_y, const float* coef2, const void* gate, const float* u1,
+                        const void* W1, const void* W2, float* dz2, float* ds1, float* du1, void* dpooled, float* bn2_sums, int B, int H, int W, int Cout,
+                        int C, int S, unsigned long long* mailbox, long mailbox_words, void* st) {
+  CHK_DT(DT_BF16);
+  if (B < 1 || C < 64 || (C % 64) || !mailbox || mailbox_words < (long)B * (C / 64) * 64) return fail(-1, "mbconv_bwd_se: a mailbox of B * (C / 64) * 64 words is required");
+  g_sebox.box = mailbox; g_sebox.images = B;
+  const bool okk = launch_mbconv_bwd_se(DT_BF16, dy3, w_bwd, ldb, dz3, bn2_y, coef2, coef2 + 2 * C, gate, u1, W2, W1, dz2, ds1, du1, dpooled, bn2_sums, B, H, W,
+                                        Cout, C, S, S(st));
+  g_sebox.box = nullptr; g_sebox.images = 0;
+  if (!okk) return fail(-1, "mbconv_bwd_se: shape not taken by the one-launch form (use satrn_linear_bwd_data + satrn_se_bwd_bnred)");
+  return done("mbconv_bwd_se");
+}
 int satrn_batchnorm_act_dwconv3x3_fwd(int dt, const void* y, const float* w, const float* b, float* rm, float* rv, int64_t* nbt,
                                       float eps, int act, void* z, const void* dwp, const float* dwb, void* out, float* out_stats,
                                       int B, int H, int W, int C, float* scratch, void* st) {

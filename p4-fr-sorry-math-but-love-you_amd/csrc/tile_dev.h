@@ -4,6 +4,13 @@
 #pragma once
 #include "common.h"
 
+DEVI void ldv(const float* p, float* o, int n) {  // n (multiple of 4) floats through 16-byte loads
+  for (int j = 0; j < n; j += 4) {
+    float4 v = *reinterpret_cast<const float4*>(p + j);
+    o[j] = v.x; o[j + 1] = v.y; o[j + 2] = v.z; o[j + 3] = v.w;
+  }
+}
+
 DEVI void lds8(const float* p, float* o) {   // 8 floats from LDS / memory through two 16-byte reads
   const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
   o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;

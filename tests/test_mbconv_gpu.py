@@ -155,3 +155,74 @@ def test_mbconv_front_refuses_what_it_cannot_hold(lib):
     rc, _ = _run_front(lib, inp, 65, 4, 12, 256, 64, 8, 1e-3, _mailbox(65, 64))
     assert rc == -1
     assert lib.satrn_device_error(st()) == 0
+
+
+@pytest.mark.parametrize("B,H,W,Cout,C,S", [(32, 4, 12, 256, 1536, 64), (32, 8, 24, 160, 960, 40), (6, 8, 24, 128, 512, 32), (3, 4, 12, 256, 192, 16), (1, 4, 12, 256, 64, 8)])
+def test_mbconv_backward_projection_data_gradient_and_squeeze_excite_in_one_launch(lib, B, H, W, Cout, C, S):
+    """satrn_mbconv_bwd_se against (a) the two operators it replaces (satrn_linear_bwd_data, then satrn_se_bwd_bnred on the data gradient
+    that one stored) and (b) torch on the formulas; the forward state (BatchNorm 2 coefficients, gate, u1) comes from the device forward."""
+    bf, HW, M, eps = torch.bfloat16, H * W, B * H * W, 1e-3
+    y2 = q(rnd(M, C, seed=1) * 2 + 0.5, BF)
+    w, b = 1 + rnd(C, seed=3, scale=0.2), rnd(C, seed=4, scale=0.1)
+    W1, W2 = q(rnd(S, C, seed=12, scale=0.05), BF), q(rnd(C, S, seed=13, scale=0.2), BF)
+    b1, b2 = rnd(S, seed=14, scale=0.1), rnd(C, seed=15, scale=0.1)
+    Wp = q(rnd(Cout, C, seed=16, scale=C ** -0.5 * 2), BF)     # the projection [Cout][C]
+    dy3 = q(rnd(M, Cout, seed=6), BF)
+    y2d = dev(y2, BF)
+    rmd, rvd, nbt = dev(torch.zeros(C)), dev(torch.ones(C)), torch.zeros(1, dtype=torch.int64, device="cuda")
+    scratch = torch.zeros(6 * C, device="cuda")
+    z2d = torch.empty(M, C, dtype=bf, device="cuda")
+    ok(lib, lib.satrn_batchnorm_act_fwd(1, P(y2d), P(dev(w)), P(dev(b)), P(rmd), P(rvd), P(nbt), eps, 1, 2, None, P(z2d), M, C, P(scratch), st()))
+    W1d, W2d = dev(W1, BF), dev(W2, BF)
+    pooled_d, u1_d, s1_d = (torch.zeros(B, n, device="cuda") for n in (C, S, S))
+    gate_d = torch.zeros(B, C, dtype=bf, device="cuda")
+    z3d = torch.zeros(B, HW, C, dtype=bf, device="cuda")
+    ok(lib, lib.satrn_se_fwd(1, P(z2d), P(W1d), P(dev(b1)), P(W2d), P(dev(b2)), None, P(pooled_d), P(u1_d), P(s1_d), P(gate_d), P(z3d), B, HW, C, S, st()))
+    _, Wbd, ldb = pack_dense(lib, Wp, BF)
+    dy3d = dev(dy3, BF)
+    # (a) the two operators
+    dz3_a = torch.zeros(M, C, dtype=bf, device="cuda")
+    ok(lib, lib.satrn_linear_bwd_data(1, P(dy3d), Cout, P(Wbd), ldb, P(dz3_a), M, Cout, C, 0, st()))
+    dz2_a, du1_a, ds1_a = torch.zeros(B, C, device="cuda"), torch.zeros(B, S, device="cuda"), torch.zeros(B, S, device="cuda")
+    dpool_a = torch.zeros(B, C, dtype=bf, device="cuda")
+    Pd, red_a = torch.zeros(4 * B * C, device="cuda"), torch.zeros(2 * C, device="cuda")
+    ok(lib, lib.satrn_se_bwd_bnred(1, P(dz3_a), P(y2d), P(scratch), 2, P(gate_d), P(u1_d), P(W1d), P(W2d), P(dz2_a), P(du1_a), P(ds1_a), P(dpool_a),
+                                   P(Pd), P(red_a), B, HW, C, S, st()))
+    # the one launch, three times on a never-cleared mailbox
+    box = torch.zeros(B * (C // 64) * 64, dtype=torch.int64, device="cuda")
+    prev = None
+    for rep in range(3):
+        dz3 = torch.zeros(M, C, dtype=bf, device="cuda")
+        dz2, du1, ds1 = torch.zeros(B, C, device="cuda"), torch.zeros(B, S, device="cuda"), torch.full((B, S), 7.0, device="cuda")
+        dpool, red = torch.zeros(B, C, dtype=bf, device="cuda"), torch.zeros(2 * C, device="cuda")
+        rc = lib.satrn_mbconv_bwd_se(P(dy3d), P(Wbd), ldb, P(dz3), P(y2d), P(scratch[2 * C:]), P(gate_d), P(u1_d), P(W1d), P(W2d), P(dz2), P(ds1), P(du1), P(dpool),
+                                     P(red), B, H, W, Cout, C, S, P(box), box.numel(), st())
+        assert rc == 0, lib.satrn_last_error().decode()
+        torch.cuda.synchronize()
+        assert lib.satrn_device_error(st()) == 0
+        same = (dz3 == dz3_a).float().mean().item()
+        print(f"[bwd se one launch] dz3 identical to the product's {same:.6f}")
+        close(dz3, dz3_a.float().cpu(), BF, "dz3 vs linear_bwd_data", bf16_tol=1e-2)
+        close(dz2, dz2_a.cpu(), BF, "dz2 vs se_bwd_bnred", bf16_tol=1e-2)
+        close(ds1, ds1_a.cpu(), BF, "ds1 vs se_bwd_bnred", bf16_tol=1e-2)
+        close(du1, du1_a.cpu(), BF, "du1 vs se_bwd_bnred", bf16_tol=1e-2)
+        close(dpool, dpool_a.float().cpu(), BF, "dpooled vs se_bwd_bnred", bf16_tol=1.5e-2)
+        close(red, red_a.cpu(), BF, "BatchNorm 2 sums vs se_bwd_bnred", bf16_tol=1e-2)
+        if prev is not None:
+            for u_, v_, what in zip((dz3, dz2, ds1, du1, dpool), prev, ("dz3", "dz2", "ds1", "du1", "dpooled")):
+                assert torch.equal(u_, v_), f"{what}: differs from call to call"
+        prev = (dz3, dz2, ds1, du1, dpool)
+    # (b) torch on the formulas, from the device's forward state
+    dz3_r = q(dy3 @ Wp, BF).reshape(B, HW, C)
+    z2 = z2d.float().cpu().reshape(B, HW, C)
+    gate, u1 = gate_d.float().cpu(), u1_d.cpu()
+    dgate = (dz3_r * z2).sum(1)
+    dz2_r = dgate * gate * (1 - gate)
+    ds1_r = dz2_r @ W2
+    sg = torch.sigmoid(u1)
+    du1_r = ds1_r * (sg * (1 + u1 * (1 - sg)))
+    dpool_r = du1_r @ W1
+    close(dz3, dz3_r.reshape(M, C), BF, "dz3 vs torch", bf16_tol=1e-2)
+    close(dz2, dz2_r, BF, "dz2 vs torch", bf16_tol=2e-2)
+    close(du1, du1_r, BF, "du1 vs torch", bf16_tol=2e-2)
+    close(dpool, dpool_r, BF, "dpooled vs torch", bf16_tol=2e-2)
