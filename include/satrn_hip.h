@@ -504,7 +504,8 @@ int satrn_device_error(void* stream);
  * to assert that a shape really ran on the kernel they mean to cover (the large-shape routes are chosen by size thresholds inside the
  * launchers).  out[i], i < n: 0 persistent GEMM (dense), 1 persistent GEMM (3x3 convolution / data gradient), 2 persistent weight
  * gradient, 3 tile GEMM (gemm_kernel family incl. halo convolution and skinny), 4 tile weight gradient, 5 BatchNorm + squeeze-and-excite
- * in one launch, 6 MBConv block forward in one launch (expand .. squeeze-and-excite), 7 MBConv block backward in one launch; the rest 0.
+ * in one launch, 6 MBConv block front in one launch (expand .. squeeze-and-excite), 7 MBConv backward (projection data gradient + squeeze-and-excite) in
+ * one launch, 8 row-streaming kernel for tall, thin dense products; the rest 0.
  * reset != 0 clears them after the read.  Returns the number of defined routes. */
 int satrn_route_counts(long long* out, int n, int reset);
 float* satrn_model_adam_state(satrn_model* m, int which /*0 exp_avg, 1 exp_avg_sq*/);

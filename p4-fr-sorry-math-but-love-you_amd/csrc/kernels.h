@@ -43,7 +43,7 @@ bool se_box_usable(hipStream_t s);   // false while `s` is being captured into a
 // MI355X_MICROARCH.md "Residency and cooperative launch"); 0 when the query fails.
 long resident_capacity(const void* kernel, int threads, size_t lds_bytes);
 // launches per kernel route (satrn_route_counts, include/satrn_hip.h): host-side diagnostics for tests
-enum { RT_GEMM_BIG = 0, RT_GEMM_BIG_CONV = 1, RT_WGRAD_BIG = 2, RT_GEMM_TILE = 3, RT_WGRAD_TILE = 4, RT_BN_POOL_SE = 5, RT_MBCONV_FWD = 6, RT_MBCONV_BWD = 7, RT_COUNT = 8 };
+enum { RT_GEMM_BIG = 0, RT_GEMM_BIG_CONV = 1, RT_WGRAD_BIG = 2, RT_GEMM_TILE = 3, RT_WGRAD_TILE = 4, RT_BN_POOL_SE = 5, RT_MBCONV_FWD = 6, RT_MBCONV_BWD = 7, RT_GEMM_TALL = 8, RT_COUNT = 9 };
 extern long long g_route[RT_COUNT];
 unsigned* device_error_word();   // device address of the error word (bit 2: a mailbox wait timed out)
 void launch_fold4(const float* part, int nrep, long stride, long n, float* out, hipStream_t s);   // launch_fold with 16-byte accesses (n, stride % 4 == 0)
@@ -119,6 +119,9 @@ void launch_bn_eval_prepare(const BnEvalDesc* descs_dev, int n, hipStream_t s);
 void launch_gemm(int dt, int amode, const GemmP& p, hipStream_t s);
 // large dense bf16 products on the persistent 8-wave direct-to-LDS kernel (kernels_gemm_big.hip); false = shape / epilogue not taken
 bool gemm_big_launch(const GemmP& p, hipStream_t s);
+// tall, thin dense bf16 products (M >= 16 384 rows, N and K <= 256: the 1x1 projections of the fused-MBConv stages and their data gradients) on the
+// row-streaming kernel (kernels_gemm_tall.hip); false = shape / epilogue not taken
+bool gemm_tall_launch(const GemmP& p, hipStream_t s);
 bool gemm_big_conv_launch(int amode, const GemmP& p, hipStream_t s);   // 3x3 stride-1 'same' convolution / its data gradient as a shifted GEMM
 
 // dW[n][k] (+)= sum_m dY[m][n] * gatherA[m][k]

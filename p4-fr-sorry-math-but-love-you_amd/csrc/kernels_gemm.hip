@@ -887,6 +887,7 @@ void launch_gemm(int dt, int amode, const GemmP& p0, hipStream_t s) {
     if (!(cb && atoi(cb) == 0) && !p.stats_part && dt == DT_BF16 && (amode == AM_CONV || amode == AM_DGRAD) && p.N >= conv_min_n && !by_classes &&
         gemm_big_conv_launch(amode, p, s)) return;
   }
+  if (amode == AM_DENSE && dt == DT_BF16 && gemm_tall_launch(p, s)) return;   // tall, thin products: row-streaming kernel (kernels_gemm_tall.hip)
   g_route[RT_GEMM_TILE]++;   // (everything below: halo convolution, skinny and tile kernels)
   if (!p.stats_part && dt == DT_BF16 && amode != AM_DENSE && conv_halo_launch(amode, p, s)) return;
   if (amode == AM_DENSE && (dt == DT_BF16 ? gemm_skinny_launch<bf16_t>(p, s) : gemm_skinny_launch<float>(p, s))) return;

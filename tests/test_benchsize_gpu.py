@@ -18,11 +18,11 @@ H, W, T, B = 128, 384, 128, 32
 def _routes(reset=False):
     import satrn_amd
     lib = satrn_amd._lib.load()
-    out = (ctypes.c_longlong * 8)()
-    n = lib.satrn_route_counts(out, 8, int(reset))
-    assert n == 8
+    out = (ctypes.c_longlong * 9)()
+    n = lib.satrn_route_counts(out, 9, int(reset))
+    assert n == 9
     return dict(gemm_big=out[0], gemm_big_conv=out[1], wgrad_big=out[2], gemm_tile=out[3], wgrad_tile=out[4], bn_pool_se=out[5], mbconv_fwd=out[6],
-                mbconv_bwd=out[7])
+                mbconv_bwd=out[7], gemm_tall=out[8])
 
 
 def _device_error():
@@ -119,6 +119,8 @@ def test_benchmark_configuration_bf16_against_f32_train_mode_and_routes():
     assert r["gemm_big"] >= 4, r
     assert r["gemm_big_conv"] >= 8, r
     assert r["wgrad_big"] >= 2, r
+    assert r["gemm_tall"] >= 8, r          # the 1x1 projections of the fused-MBConv stages and their data gradients
+    assert r["mbconv_bwd"] >= 20, r
     assert r["bn_pool_se"] + r["mbconv_fwd"] >= 20, r     # the late MBConv blocks' squeeze-and-excite seam in one launch (or inside the block kernel)
     assert f["routes"]["gemm_big"] == 0 and f["routes"]["wgrad_big"] == 0
 

@@ -306,6 +306,53 @@ def test_linear_with_batchnorm_sums(lib, big_gemm_mode, mode, M, N, K, rep, bnb)
         close(tot[1], (g * ((by - mean) * rstd)).sum(0), "f32", "sum g xhat", f32_tol=6e-3)
 
 
+@pytest.mark.parametrize("tall", [2, 0])
+@pytest.mark.parametrize("M,N,K,rep,bnb", [(98304, 48, 192, 16, 0), (24576, 64, 256, 4, 0), (98304, 192, 48, 4, 2), (24576, 256, 64, 4, 2), (2064, 48, 192, 1, 0),
+                                           (1616, 192, 48, 2, 2), (1040, 256, 64, 1, 1), (4112, 64, 256, 3, 0), (1616, 192, 32, 1, 2), (32, 64, 192, 1, 0)])
+def test_tall_thin_products_on_the_row_streaming_kernel(lib, monkeypatch, tall, M, N, K, rep, bnb):
+    """the 1x1 projections of the fused-MBConv stages and their data gradients (SURVEY Appendix B stages 1-2, full benchmark sizes and row
+    tails that are not a multiple of the waves) on kernels_gemm_tall.hip (SATRN_GEMM_TALL=2: every shape that fits) against torch, and
+    against the tile kernel (0) on the same inputs; the route counter says which kernel ran"""
+    import ctypes
+    dt = "bf16"
+    monkeypatch.setenv("SATRN_GEMM_TALL", str(tall))
+    monkeypatch.setenv("SATRN_GEMM_BIG", "0")
+    x, w = q(rnd(M, K, seed=1), dt), q(rnd(N, K, seed=2, scale=1 / math.sqrt(K)), dt)
+    fwd, _, _ = pack_dense(lib, w, dt)
+    y = torch.empty(M, N, dtype=tdt(dt), device="cuda")
+    stats = torch.zeros(rep, 2, N, device="cuda")
+    ref = x @ w.t()
+    cnt = (ctypes.c_longlong * 9)()
+    lib.satrn_route_counts(cnt, 9, 1)
+    if not bnb:
+        ok(lib, lib.satrn_linear_fwd_stats(dti(dt), P(dev(x, dt)), P(fwd), P(y), M, N, K, P(stats), rep, None, None, None, 0, 0, st()))
+        torch.cuda.synchronize()
+        close(y, ref, dt, "tall y")
+        tot = stats.sum(0).cpu()
+        close(tot[0], ref.sum(0), "f32", "tall sum v", f32_tol=3e-3)
+        close(tot[1], (ref * ref).sum(0), "f32", "tall sum v^2", f32_tol=3e-3)
+    else:
+        by = q(rnd(M, N, seed=7, scale=2.0), dt)
+        scale, shift = rnd(N, seed=8) + 1.5, rnd(N, seed=9, scale=0.3)
+        mean, rstd = rnd(N, seed=10, scale=0.2), rnd(N, seed=11, scale=0.2) + 1.0
+        ss, mr = dev(torch.cat([scale, shift])), dev(torch.cat([mean, rstd]))
+        ok(lib, lib.satrn_linear_fwd_stats(dti(dt), P(dev(x, dt)), P(fwd), P(y), M, N, K, P(stats), rep, P(dev(by, dt)), P(ss), P(mr), bnb, 0, st()))
+        torch.cuda.synchronize()
+        close(y, ref, dt, "tall(bnb) y")
+        u = by * scale + shift
+        if bnb == 1:
+            d = (u > 0).float()
+        else:
+            sg = torch.sigmoid(u)
+            d = sg * (1 + u * (1 - sg))
+        g = ref * d
+        tot = stats.sum(0).cpu()
+        close(tot[0], g.sum(0), "f32", "tall sum g", f32_tol=6e-3)
+        close(tot[1], (g * ((by - mean) * rstd)).sum(0), "f32", "tall sum g xhat", f32_tol=6e-3)
+    lib.satrn_route_counts(cnt, 9, 0)
+    assert cnt[8] == (1 if tall == 2 else 0), list(cnt)
+
+
 @pytest.mark.parametrize("B,L,D,heads", [(4, 48, 512, 8), (3, 6, 512, 8), (2, 64, 256, 4), (5, 33, 256, 4), (32, 48, 512, 8)])
 def test_encoder_attention_region_fused(lib, B, L, D, heads):
     """kernels_encattn.hip: LayerNorm -> q|k|v -> attention -> output-projection partials in one launch + the LayerNorm that folds the
