@@ -777,7 +777,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       memset(&q, 0, sizeof(q));
       q.dY = dY; q.A = x->p; q.dW = w->g; q.M = (int)M; q.N = N; q.K = w->K; q.ldy = ldy; q.lda = x->C;
       q.nbatch = 1; q.nb_inner = 1;
-      q.full_grid = (e.serial || !e.s2 || e.prof) ? 1 : 0;
+      q.full_grid = (e.serial || !e.s2 || e.prof || e.tail_full) ? 1 : 0;
       float* tmp = nullptr;
       if (hasgeo) {
         q.conv = 1; q.H = g.H; q.W = g.W; q.Ci = g.Ci; q.OH = g.OH; q.OW = g.OW; q.KW = g.KW; q.stride = g.stride; q.pt = g.pt; q.pl = g.pl;
@@ -1887,10 +1887,14 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
     // experiment (SATRN_HOLD_SIDE_LATE=<first stage index>): weight gradients of the MBConv stages from that block on are queued during
     // their backward and released when the backward leaves them
     const int hold_from = getenv("SATRN_HOLD_SIDE_LATE") ? atoi(getenv("SATRN_HOLD_SIDE_LATE")) : -1;
+    // the weight gradients of blocks 0 .. tail_from are the LAST work the side stream receives (the backward reaches them last) and the chain
+    // joins it right after: they get chip-filling grids instead of the small ones that keep out of the chain's way (knob: SATRN_TAIL_FULL_FROM, -1 = off)
+    const int tail_from = getenv("SATRN_TAIL_FULL_FROM") ? atoi(getenv("SATRN_TAIL_FULL_FROM")) : -1;
     for (size_t bi = 0; bi < m->blocks.size(); ++bi) {
       if ((int)bi == m->late_block) m->seg_mark[0] = e.tape.size();
       if (hold_from >= 0 && (int)bi == hold_from && e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->hold_side = false; ep->flush_side(); }); }
       x = eff_block(e, x, &m->blocks[bi]);
+      if ((int)bi == tail_from && e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->tail_full = true; }); }
       if (hold_from >= 0 && bi + 1 == m->blocks.size() && e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->flush_side(); ep->hold_side = true; }); }
       if (bi + 1 == m->blocks.size() || m->blocks[bi + 1].cout != m->blocks[bi].cout) {
         stage_mark("cout" + std::to_string(m->blocks[bi].cout));
@@ -2088,7 +2092,7 @@ static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) 
   det_activate(m);
   e.s = s; e.dt = m->cfg.dtype; e.train = train; e.rec = rec; e.dry = dry;
   e.drop = train ? m->cfg.dropout : 0.f;
-  e.probes.clear(); e.probe_on = m->probe_on; e.hold_side = false;
+  e.probes.clear(); e.probe_on = m->probe_on; e.hold_side = false; e.tail_full = false;
   if (!e.dry && e.zbase && e.zoff > m->zero_hwm) m->zero_hwm = e.zoff;  // what the previous call dirtied at most
   e.reset(m->ws + m->persist_bytes, m->ws_bytes > m->persist_bytes ? m->ws_bytes - m->persist_bytes : 0,
           m->ws + m->off_zero, m->zero_bytes);

@@ -69,11 +69,57 @@ __global__ void fold_kernel(const float* part, int nrep, long stride, long n, fl
     out[i] += a;
   }
 }
+// Many slots (the deterministic mode's BatchNorm statistics of a tall product: one slot per 64 rows, up to 6 144 of them, 2 N <= 3 072 columns):
+// fold_kernel walked them with ONE thread per column -- thousands of serial loads, 0.1-1.4 ms per fold and a third of the f32 step's kernel time
+// (profiles/r04_f32_kernel_stats.csv).  Here a block owns FOLD_CB columns x a range of R slots: 256 threads = FOLD_CB column lanes x row lanes,
+// every row lane adds its slots in ascending order, the row lanes are added in ascending order through LDS.  Level 1 (grid.y = ceil(nrep / R)
+// row ranges) leaves each range's sum IN PLACE in the range's first slot; level 2 (one range over those first slots) adds them to out.  The
+// order of every addition depends on (nrep, n) only: bit-identical from run to run.
+#define FOLD_CB 32
+__global__ __launch_bounds__(256) void fold_par_kernel(float* part, int nrows, long row_step, long stride, long n, int R, float* out) {
+  constexpr int RL = 256 / FOLD_CB;
+  __shared__ float red[RL][FOLD_CB];
+  const int cq = threadIdx.x % FOLD_CB, rl = threadIdx.x / FOLD_CB;
+  const long c = (long)blockIdx.x * FOLD_CB + cq;
+  const int r0 = blockIdx.y * R, r1 = min(nrows, r0 + R);
+  float a = 0.f;
+  if (c < n) {
+    int r = r0 + rl;
+    for (; r + 3 * RL < r1; r += 4 * RL) {   // four slots requested together, added in slot order
+      const float v0 = part[(size_t)r * row_step * stride + c], v1 = part[(size_t)(r + RL) * row_step * stride + c];
+      const float v2 = part[(size_t)(r + 2 * RL) * row_step * stride + c], v3 = part[(size_t)(r + 3 * RL) * row_step * stride + c];
+      a = (((a + v0) + v1) + v2) + v3;
+    }
+    for (; r < r1; r += RL) a += part[(size_t)r * row_step * stride + c];
+  }
+  red[rl][cq] = a;
+  __syncthreads();
+  if (rl == 0 && c < n) {
+    float t = red[0][cq];
+#pragma unroll
+    for (int l = 1; l < RL; ++l) t += red[l][cq];
+    if (out) out[c] += t;
+    else part[(size_t)r0 * row_step * stride + c] = t;
+  }
+}
 void launch_fold(const float* part, int nrep, long stride, long n, float* out, hipStream_t s) {
   if (n <= 0 || nrep <= 0) return;
-  long g = (n + 255) / 256;
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(fold_kernel, dim3((int)g), dim3(256), 0, s, part, nrep, stride, n, out);
+  if (nrep < 32) {
+    long g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(fold_kernel, dim3((int)g), dim3(256), 0, s, part, nrep, stride, n, out);
+    return;
+  }
+  float* pw = const_cast<float*>(part);   // (scratch slabs: level 1 overwrites the first slot of every range with the range's sum)
+  const int gx = (int)((n + FOLD_CB - 1) / FOLD_CB);
+  constexpr int R = 256;
+  if (nrep <= R) {
+    hipLaunchKernelGGL(fold_par_kernel, dim3(gx, 1), dim3(256), 0, s, pw, nrep, 1L, stride, n, nrep, out);
+    return;
+  }
+  const int S = (nrep + R - 1) / R;
+  hipLaunchKernelGGL(fold_par_kernel, dim3(gx, S), dim3(256), 0, s, pw, nrep, 1L, stride, n, R, (float*)nullptr);
+  hipLaunchKernelGGL(fold_par_kernel, dim3(gx, 1), dim3(256), 0, s, pw, S, (long)R, stride, n, S, out);
 }
 
 // G slice groups per column quad: many slices of a small matrix (SwinTRN stage 1: 256 slices of 96 x 96) would otherwise be a handful of
@@ -183,12 +229,12 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, long M, int C, int 
   }
 }
 
-__global__ void colreduce_fold_kernel(const float* part, int gx, int NO, int C, float* o0, float* o1, int nmain) {
+__global__ void colreduce_fold_kernel(const float* part, int gx, int row_step, int NO, int C, float* o0, float* o1, int nmain) {
   const long n = (long)NO * C;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int k = (int)(i / C), col = (int)(i - (long)k * C);
     float a = 0.f;
-    for (int r = 0; r < gx; ++r) a += part[(size_t)r * n + i];
+    for (int r = 0; r < gx; ++r) a += part[(size_t)r * row_step * n + i];
     if (nmain < 0) o0[(long)k * C + col] += a;
     else if (k < nmain) o0[(long)col * nmain + k] += a;
     else if (o1) o1[col] += a;
@@ -233,7 +279,14 @@ static void launch_colreduce(F f, long M, int C, float* o0, float* o1, int nmain
     hipLaunchKernelGGL((colreduce_kernel<T, NO, F, 4>), dim3((int)gx, gy), dim3(256), 0, s, f, M, C, (int)rpb, txl, o0, o1, nmain, part);
   if (part) {
     long n = (long)NO * C;
-    hipLaunchKernelGGL(colreduce_fold_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, part, (int)gx, NO, C, o0, o1, nmain);
+    // (row blocks in ranges of 32 first -- fold_par_kernel, in place -- then the ranges: one thread per output walked up to 1 024 partials)
+    constexpr int FR = 32;
+    if (gx > 2 * FR) {
+      const int S = (int)((gx + FR - 1) / FR);
+      hipLaunchKernelGGL(fold_par_kernel, dim3((int)((n + FOLD_CB - 1) / FOLD_CB), S), dim3(256), 0, s, part, (int)gx, 1L, n, n, FR, (float*)nullptr);
+      hipLaunchKernelGGL(colreduce_fold_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, part, S, FR, NO, C, o0, o1, nmain);
+    } else
+    hipLaunchKernelGGL(colreduce_fold_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, part, (int)gx, 1, NO, C, o0, o1, nmain);
   }
 }
 
@@ -2063,7 +2116,10 @@ void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw, float
   DISPATCH_T(dt, {
     DwWgradF<T> f{(const T*)x, (const T*)dy, H, W, C, OH, OW, stride, pt, pl, 1.0f / (float)OW, 1.0f / ((float)OW * (float)OH), (long)B * OH * OW < (1L << 23) ? 1 : 0};
     if (scratch10C) {
-      launch_colreduce<T, 10>(f, (long)B * OH * OW, C, scratch10C, nullptr, -1, s, DWW_RPT, DWW_BLK, DWW_BLK);
+      // knob (read once, tools/ab_env.sh): workgroups of this side-stream kernel -- 152 registers x 256 threads: two of them on a compute unit
+      // leave no room for the chain's 512-thread kernels
+      static const int blk = getenv("SATRN_DWW_BLOCKS") ? atoi(getenv("SATRN_DWW_BLOCKS")) : DWW_BLK;
+      launch_colreduce<T, 10>(f, (long)B * OH * OW, C, scratch10C, nullptr, -1, s, blk < DWW_BLK ? DWW_RPT * DWW_BLK / (blk > 0 ? blk : 1) : DWW_RPT, blk, blk);
       hipLaunchKernelGGL(dw_wgrad_scatter_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, s, scratch10C, dw, dbias, C);
     } else {
       launch_colreduce<T, 10>(f, (long)B * OH * OW, C, dw, dbias, 9, s, 16, DWW_BLK, DWW_BLK);
