@@ -181,6 +181,19 @@ int satrn_mbconv_front_fwd(const void* x, const void* W0, void* y1, const float*
                            int64_t* bn2_num_batches_tracked, float* bn2_coef, void* z2, int keep_z2, const void* W1, const float* b1, const void* W2,
                            const float* b2, float* pooled, float* u1, float* s1, void* gate, void* z3, int B, int H, int W, int Cin, int C, int S,
                            float eps, unsigned long long* mailbox, long mailbox_words, void* stream);
+/* The same with the block INPUT taken as the output of the BatchNorm that ends the block in front (timm InvertedResidual: bn3, no activation,
+ * + that block's residual): x = BatchNorm(in_y) (+ in_res), batch statistics from in_sums (in_sums_rep replicas of [sum | sum of squares],
+ * 2 * Cin floats each, as satrn_linear_fwd_stats leaves them).  Every workgroup normalises its image's rows while it stages them, x is also
+ * written to x_out [B][H][W][Cin], in_coef receives scale | shift | mean | rstd (4 * Cin floats) and the running statistics are updated --
+ * what satrn_batchnorm_act_fwd(act = none, residual) does, without its launch. */
+int satrn_mbconv_front_fwd_bn_in(const void* in_y, const void* in_res, const float* in_sums, int in_sums_rep, const float* in_weight, const float* in_bias,
+                                 float* in_running_mean, float* in_running_var, int64_t* in_num_batches_tracked, float* in_coef, void* x_out,
+                                 const void* W0, void* y1, const float* bn1_weight, const float* bn1_bias, float* bn1_running_mean,
+                                 float* bn1_running_var, int64_t* bn1_num_batches_tracked, float* bn1_coef, void* z1, const void* dw_packed, void* y2,
+                                 const float* bn2_weight, const float* bn2_bias, float* bn2_running_mean, float* bn2_running_var,
+                                 int64_t* bn2_num_batches_tracked, float* bn2_coef, void* z2, int keep_z2, const void* W1, const float* b1,
+                                 const void* W2, const float* b2, float* pooled, float* u1, float* s1, void* gate, void* z3, int B, int H, int W,
+                                 int Cin, int C, int S, float eps, unsigned long long* mailbox, long mailbox_words, void* stream);
 /* Backward of the same block, first half of its middle, in ONE launch (bf16, the shapes of satrn_mbconv_front_fwd): the projection's data
  * gradient dz3 = dy3 W_proj (dy3 [B][H][W][Cout] = the gradient at conv_pwl's output; w_bwd = satrn_pack_dense's backward pack of W_proj,
  * [C][ldb]) and the squeeze-and-excite backward with z2 RECOMPUTED from BatchNorm 2's input bn2_y and coefficients bn2_coef (scale | shift |

@@ -860,7 +860,8 @@ struct SeHold {
   // inference: the depthwise convolution in front (Tensor::pend_dw), held back with the eval-mode BatchNorm's scale / shift
   std::function<int(const float*, const float*, int, void*, float*, void*, const SeEvalArgs*)> dwfn; const float* esc = nullptr; const float* esh = nullptr;
 };
-Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** pool_out = nullptr, BnHold* hold = nullptr, SeHold* sehold = nullptr) {
+Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** pool_out = nullptr, BnHold* hold = nullptr, SeHold* sehold = nullptr,
+                  Exec::FwdBnHold* fhold = nullptr) {
   const int C = bn->C;
   const long M = y->rows;
   if (y->pend) {
@@ -919,6 +920,10 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** poo
   } else if (hold && e.train && sums && !res) {
     hold->armed = true; hold->y = y->p; hold->sums = sums; hold->rep = y->stats ? y->stats_rep : 1; hold->bn = bn; hold->ss = ss; hold->mr = mr;
     hold->z = z->p; hold->M = M; hold->C = C; hold->act = act;
+    e.nflops = 0; e.nbytes = 0;
+  } else if (fhold && e.train && sums && act == ACT_NONE && !e.dry && !e.nolaunch) {
+    // the consumer (the next MBConv block's front) normalises while it stages its input
+    *fhold = Exec::FwdBnHold{true, y->p, res ? res->p : nullptr, sums, y->stats ? y->stats_rep : 1, bn, ss, mr, z->p, M, C};
     e.nflops = 0; e.nbytes = 0;
   } else
   LCH(e, launch_bn_act(e.dt, y->p, sums, y->stats ? y->stats_rep : 1, bn->w.p, bn->b.p, bn->rm, bn->rv, e.train ? bn->nbt : nullptr, bn->eps, 0.1f, ss, mr,
@@ -1775,11 +1780,21 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr, SeHold
   return y;
 }
 
-Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
+// a held block-ending BatchNorm (Exec::xhold) that its consumer does not take: the launch it stood for
+static void flush_xhold(Exec& e) {
+  Exec::FwdBnHold& h = e.xhold;
+  if (!h.armed) return;
+  h.armed = false;
+  WORK(e, 0, (double)h.M * h.C * e.esz() * (h.res ? 3 : 2));
+  LCH(e, launch_bn_act(e.dt, h.y, h.sums, h.rep, h.bn->w.p, h.bn->b.p, h.bn->rm, h.bn->rv, h.bn->nbt, h.bn->eps, 0.1f, h.ss, h.mr, h.res, h.z, h.M, h.C, ACT_NONE, e.s));
+}
+
+Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb, bool hold_out = false) {
   const int B = x->B, H = x->H, W = x->W;
   Geo g;
   same_geo(H, W, eb->cin, eb->stride, &g);
   Tensor* skip = eb->skip ? x : nullptr;
+  if (eb->type != 2) flush_xhold(e);
   if (eb->type == 0) {
     Tensor* y = op_gemm(e, x, &eb->c0, nullptr, ACT_NONE, 0.f, &g, B, false, nullptr, true);
     return op_bn_act(e, y, &eb->bn1, ACT_SILU, skip);
@@ -1796,6 +1811,10 @@ Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
   // across two kernel boundaries).  The ops below then only do their bookkeeping (tensors, tape): same allocations, same backward.
   const bool front = eb->stride == 1 && e.train && !e.nolaunch && x->C == eb->cin &&
                      (e.dry ? (e.dt == DT_BF16 && !g_det.on) : mbconv_front_ok(e.dt, B, H, W, eb->cin, eb->c0.N, eb->se, e.s));
+  // a BatchNorm (+ residual) held back by the block in front (Exec::xhold): this launch computes x from it; no one-launch front -> launch it now
+  const bool xfold = front && e.xhold.armed && e.xhold.z == x->p && e.xhold.C == eb->cin;
+  Exec::FwdBnHold xh = e.xhold;
+  if (xfold) e.xhold.armed = false; else flush_xhold(e);
   if (front) e.nolaunch = true;
   Tensor* y = op_gemm(e, x, &eb->c0, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   y->B = B; y->H = H; y->W = W;
@@ -1815,7 +1834,9 @@ Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
     bool ok = false;
     WORK(e, 2.0 * (double)x->rows * C * eb->cin + 18.0 * (double)x->rows * C + 4.0 * (double)B * C * eb->se,
          ((double)x->rows * eb->cin + (double)x->rows * C * (se.need_x ? 5 : 4) + (double)C * eb->cin + 2.0 * (double)C * eb->se) * e.esz());
-    LCH(e, ok = launch_mbconv_front(e.dt, x->p, eb->c0.fwd, y->p, eb->bn1.w.p, eb->bn1.b.p, eb->bn1.rm, eb->bn1.rv, eb->bn1.nbt, ss1, mr1, eb->bn1.eps, z->p,
+    MbXinArgs xa{xh.y, xh.res, xh.sums, xh.rep, xfold ? xh.bn->w.p : nullptr, xfold ? xh.bn->b.p : nullptr, xfold ? xh.bn->rm : nullptr, xfold ? xh.bn->rv : nullptr,
+                 xfold ? xh.bn->nbt : nullptr, xh.ss, xh.mr, xfold ? xh.bn->eps : 0.f, xh.z};
+    LCH(e, ok = launch_mbconv_front(e.dt, xfold ? nullptr : x->p, xfold ? &xa : nullptr, eb->c0.fwd, y->p, eb->bn1.w.p, eb->bn1.b.p, eb->bn1.rm, eb->bn1.rv, eb->bn1.nbt, ss1, mr1, eb->bn1.eps, z->p,
                                     eb->dw.fwd, y2->p, eb->bn2.w.p, eb->bn2.b.p, eb->bn2.rm, eb->bn2.rv, eb->bn2.nbt, ss2, mr2, eb->bn2.eps,
                                     se.need_x ? z2->p : nullptr, eb->se_r.fwd, eb->se_rb.p, eb->se_e.fwd, eb->se_eb.p, se.pooled, se.u1, se.s1, se.gate, z3->p,
                                     B, H, W, eb->cin, C, eb->se, 0.1f, e.s));
@@ -1823,7 +1844,7 @@ Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb) {
   }
   Tensor* y3 = op_gemm(e, z3, &eb->c1, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   y3->B = B; y3->H = g.OH; y3->W = g.OW;
-  return op_bn_act(e, y3, &eb->bn3, ACT_NONE, skip);
+  return op_bn_act(e, y3, &eb->bn3, ACT_NONE, skip, nullptr, nullptr, nullptr, hold_out ? &e.xhold : nullptr);
 }
 
 // eval-mode scale/shift of every BatchNorm (running statistics may have changed since the last call: one launch)
@@ -1893,7 +1914,15 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
     for (size_t bi = 0; bi < m->blocks.size(); ++bi) {
       if ((int)bi == m->late_block) m->seg_mark[0] = e.tape.size();
       if (hold_from >= 0 && (int)bi == hold_from && e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->hold_side = false; ep->flush_side(); }); }
-      x = eff_block(e, x, &m->blocks[bi]);
+      // this block's closing BatchNorm (+ residual) rides in the next block's launch when that one is a one-launch MBConv front
+      bool hold_out = false;
+      if (bi + 1 < m->blocks.size() && e.train && !e.dry && getenv("SATRN_NO_MBCONV_XFOLD") == nullptr) {
+        const EffBlock& cbk = m->blocks[bi]; const EffBlock& nb = m->blocks[bi + 1];
+        Geo og;
+        same_geo(x->H, x->W, cbk.cin, cbk.stride, &og);
+        hold_out = cbk.type == 2 && nb.type == 2 && nb.stride == 1 && nb.cin == cbk.cout && mbconv_front_ok(e.dt, B, og.OH, og.OW, nb.cin, nb.c0.N, nb.se, e.s);
+      }
+      x = eff_block(e, x, &m->blocks[bi], hold_out);
       if ((int)bi == tail_from && e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->tail_full = true; }); }
       if (hold_from >= 0 && bi + 1 == m->blocks.size() && e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->flush_side(); ep->hold_side = true; }); }
       if (bi + 1 == m->blocks.size() || m->blocks[bi + 1].cout != m->blocks[bi].cout) {
@@ -1901,6 +1930,7 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
         probe(e, "backbone_c" + std::to_string(m->blocks[bi].cout), x);
       }
     }
+    flush_xhold(e);
     int H = x->H, W = x->W;
     x = op_gemm(e, x, &m->conv_last, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
     x->B = B; x->H = H; x->W = W;
@@ -2092,7 +2122,7 @@ static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) 
   det_activate(m);
   e.s = s; e.dt = m->cfg.dtype; e.train = train; e.rec = rec; e.dry = dry;
   e.drop = train ? m->cfg.dropout : 0.f;
-  e.probes.clear(); e.probe_on = m->probe_on; e.hold_side = false; e.tail_full = false;
+  e.probes.clear(); e.probe_on = m->probe_on; e.hold_side = false; e.tail_full = false; e.xhold.armed = false;
   if (!e.dry && e.zbase && e.zoff > m->zero_hwm) m->zero_hwm = e.zoff;  // what the previous call dirtied at most
   e.reset(m->ws + m->persist_bytes, m->ws_bytes > m->persist_bytes ? m->ws_bytes - m->persist_bytes : 0,
           m->ws + m->off_zero, m->zero_bytes);

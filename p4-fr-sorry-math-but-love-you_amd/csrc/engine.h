@@ -184,6 +184,10 @@ struct Exec {
   // what the last op_bn_act / op_se allocated (scale|shift and mean|rstd; pooled means, hidden layer, gate; whether the activated tensor must
   // be stored): the MBConv block launch (eff_block) reads them after a nolaunch pass over the ops
   float* last_bn_ss = nullptr; float* last_bn_mr = nullptr;
+  // the BatchNorm (+ residual) that ends an MBConv block, not launched: the next block's one-launch front normalises its input while staging it
+  // (MbXinArgs, kernels.h); whoever cannot take it launches it (flush_xhold)
+  struct FwdBnHold { bool armed = false; const void* y = nullptr; const void* res = nullptr; const float* sums = nullptr; int rep = 1; BNp* bn = nullptr;
+                     float* ss = nullptr; float* mr = nullptr; void* z = nullptr; long M = 0; int C = 0; } xhold;
   struct LastSe { float* pooled = nullptr; float* u1 = nullptr; float* s1 = nullptr; void* gate = nullptr; bool need_x = true; } last_se;
   bool serial = false;  // no concurrent side stream (hipGraph capture / profiling): side kernels may fill the chip
   float drop = 0.f;

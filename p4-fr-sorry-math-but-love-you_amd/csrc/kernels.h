@@ -350,7 +350,11 @@ bool launch_bn_pool_se(int dt, const void* y, const float* sums, int sums_rep, c
 // g_mbbox and g_sebox; mbconv_front_ok says beforehand whether a shape is taken (incl. the residency of the whole grid) -- a launch that
 // follows a true answer cannot refuse.  Writes everything the separate kernels wrote (see the file header); z2 may be null.
 bool mbconv_front_ok(int dt, int B, int H, int W, int Cin, int C, int S, hipStream_t s);
-bool launch_mbconv_front(int dt, const void* x, const void* W0, void* y1, const float* bn1_w, const float* bn1_b, float* bn1_rm, float* bn1_rv, int64_t* bn1_nbt,
+// xin != null (then x == null): the block input is the output of a BatchNorm (batch statistics from `sums`, `rep` replicas of [2 Cin]; no
+// activation) plus an optional residual -- normalised while the kernel stages it and written to `out` for later readers (launch_bn_act's job)
+struct MbXinArgs { const void* y; const void* res; const float* sums; int rep; const float* w; const float* b; float* rm; float* rv; int64_t* nbt;
+                   float* ss; float* mr; float eps; void* out; };
+bool launch_mbconv_front(int dt, const void* x, const MbXinArgs* xin, const void* W0, void* y1, const float* bn1_w, const float* bn1_b, float* bn1_rm, float* bn1_rv, int64_t* bn1_nbt,
                          float* bn1_ss, float* bn1_mr, float bn1_eps, void* z1, const void* wdw, void* y2, const float* bn2_w, const float* bn2_b, float* bn2_rm,
                          float* bn2_rv, int64_t* bn2_nbt, float* bn2_ss, float* bn2_mr, float bn2_eps, void* z2, const void* Wr, const float* br,
                          const void* We, const float* be, float* pooled, float* u1, float* s1, void* gate, void* z3, int B, int H, int W, int Cin, int C, int S,

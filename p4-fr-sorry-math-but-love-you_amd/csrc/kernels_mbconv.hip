@@ -23,8 +23,14 @@
 MbBoxCtx g_mbbox;
 
 struct MbBn { const float* w; const float* b; float* rm; float* rv; int64_t* nbt; float* ss; float* mr; float eps; };
+// the block input as the OUTPUT of the BatchNorm in front of it (the previous block's bn3, no activation, + that block's residual):
+// x = y * scale + shift (+ res), batch statistics from the column sums of the product that wrote y (`rep` replicas of [2 Cin]).  Every
+// workgroup derives the coefficients and normalises its image's rows while it stages them; workgroup (image, slab 0) also writes x out,
+// workgroup (0, 0) publishes the coefficients and updates the running statistics -- bn_act_kernel's job, without its launch.
+struct MbXin { const bf16_t* y; const bf16_t* res; const float* sums; int rep; MbBn bn; bf16_t* out; };
 struct MbFrontP {
-  const bf16_t* x;       // [B][HW][Cin]   block input
+  const bf16_t* x;       // [B][HW][Cin]   block input (null: xin)
+  MbXin xin;
   const bf16_t* W0;      // [C][Cin]       expand weights (dense pack)
   bf16_t* y1;            // [B][HW][C]     expand output = BatchNorm 1 input
   MbBn bn1;
@@ -115,28 +121,69 @@ __global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbc
   MB_MARK(0);
 
   // ---- phase 1: expand product [HW x 64] = x_b [HW x CIN] * W0[slab]^T ------------------------------------------------------------
-  const bf16_t* xb = p.x + (size_t)img * HWT * CIN;
-  uint4 xr[XPT];
+  const bool xfold = p.x == nullptr;
+  const bf16_t* xb = (xfold ? p.xin.y : p.x) + (size_t)img * HWT * CIN;
+  uint4 xr[XPT], rr[XPT];
 #pragma unroll
   for (int k = 0; k < XPT; ++k) {
     const int idx = tid + k * NT;
     xr[k] = idx < NXC ? ld16(xb + (size_t)idx * 8) : zero16();
+    rr[k] = (xfold && p.xin.res && idx < NXC) ? ld16(p.xin.res + (size_t)img * HWT * CIN + (size_t)idx * 8) : zero16();
   }
   const int ct0 = HWT == 48 ? 2 * wave : (wave & 3), rt0 = HWT == 48 ? 0 : (wave >> 2) * RTW;
   Frag<T> bfr[CTW][KS];
+  auto load_w = [&]() {
 #pragma unroll
-  for (int ct = 0; ct < CTW; ++ct)
+    for (int ct = 0; ct < CTW; ++ct)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) bfr[ct][ks].v = ld16(p.W0 + (size_t)(cb + (ct0 + ct) * 16 + fr) * CIN + ks * 32 + fq * 8);
+      for (int ks = 0; ks < KS; ++ks) bfr[ct][ks].v = ld16(p.W0 + (size_t)(cb + (ct0 + ct) * 16 + fr) * CIN + ks * 32 + fq * 8);
+  };
+  if (NT < 512) load_w();   // (the 512-thread form has 128 registers: its weight rows are requested behind the staging)
   bf16_t* xbuf = reinterpret_cast<bf16_t*>(mb_sm);
+  if (xfold) {
+    // coefficients of the BatchNorm in front (bn_act_kernel's arithmetic), one thread per input channel
+    float* cfx = reinterpret_cast<float*>(mb_sm + (size_t)HWT * XP * 2);   // [2][CIN] behind the image rows
+    for (int c = tid; c < CIN; c += NT) {
+      float sm = 0.f, sq = 0.f;
+      for (int rp = 0; rp < p.xin.rep; ++rp) { sm += p.xin.sums[(size_t)rp * 2 * CIN + c]; sq += p.xin.sums[(size_t)rp * 2 * CIN + CIN + c]; }
+      const float mean = sm * p.invM, var = fmaxf(sq * p.invM - mean * mean, 0.f);
+      const float rstd = rsqrtf(var + p.xin.bn.eps), sc = p.xin.bn.w[c] * rstd, sh = p.xin.bn.b[c] - mean * sc;
+      cfx[c] = sc; cfx[CIN + c] = sh;
+      if (img == 0 && slab == 0) {
+        p.xin.bn.ss[c] = sc; p.xin.bn.ss[CIN + c] = sh; p.xin.bn.mr[c] = mean; p.xin.bn.mr[CIN + c] = rstd;
+        p.xin.bn.rm[c] = (1.f - p.mom) * p.xin.bn.rm[c] + p.mom * mean;
+        p.xin.bn.rv[c] = (1.f - p.mom) * p.xin.bn.rv[c] + p.mom * var * p.unbias;
+      }
+    }
+    if (img == 0 && slab == 0 && tid == 0 && p.xin.bn.nbt) *p.xin.bn.nbt += 1;
+    __syncthreads();
 #pragma unroll
-  for (int k = 0; k < XPT; ++k) {
-    const int idx = tid + k * NT;
-    if (idx < NXC) {
-      const int row = idx / (CIN / 8), ch = idx - row * (CIN / 8);
-      st16(xbuf + row * XP + ch * 8, xr[k]);
+    for (int k = 0; k < XPT; ++k) {
+      __builtin_amdgcn_sched_barrier(0);   // one chunk at a time: interleaved, the eight-element temporaries of several chunks spill the 512-thread form
+      const int idx = tid + k * NT;
+      if (idx < NXC) {
+        const int row = idx / (CIN / 8), ch = idx - row * (CIN / 8);
+        float v[CH], r[CH], sc[CH], sh[CH];
+        unpack<T>(xr[k], v); unpack<T>(rr[k], r);
+        lds8(cfx + ch * 8, sc); lds8(cfx + CIN + ch * 8, sh);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) v[j] = v[j] * sc[j] + sh[j] + r[j];
+        const uint4 q = pack<T>(v);
+        st16(xbuf + row * XP + ch * 8, q);
+        if (slab == 0) st16(p.xin.out + (size_t)img * HWT * CIN + (size_t)idx * 8, q);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+      const int idx = tid + k * NT;
+      if (idx < NXC) {
+        const int row = idx / (CIN / 8), ch = idx - row * (CIN / 8);
+        st16(xbuf + row * XP + ch * 8, xr[k]);
+      }
     }
   }
+  if (NT >= 512) load_w();
   __syncthreads();
   MB_MARK(1);
   f32x4 acc[RTW][CTW];
@@ -349,7 +396,7 @@ __global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbc
 
 template <int HWT, int CIN>
 static size_t mb_front_lds(int H, int rowpix) {
-  const size_t x_bytes = (size_t)HWT * (CIN + 8) * 2;
+  const size_t x_bytes = (size_t)HWT * (CIN + 8) * 2 + (size_t)2 * CIN * 4;   // image rows + the coefficients of a folded input BatchNorm
   size_t t_bytes = (size_t)HWT * 72 * 2 + (size_t)(H + 2) * rowpix * BDW_SC * 16;
   if (t_bytes < 16384) t_bytes = 16384;   // the squeeze-and-excite rows
   return x_bytes > t_bytes ? x_bytes : t_bytes;
@@ -390,7 +437,7 @@ bool mbconv_front_ok(int dt, int B, int H, int W, int Cin, int C, int S, hipStre
 
 // false = shape / mode not taken (the caller runs the separate kernels; ask mbconv_front_ok first).  Mailboxes: g_mbbox (BatchNorm sums,
 // [3][C/64][B][128] words) and g_sebox (squeeze-and-excite, [B][C/64][64]).
-bool launch_mbconv_front(int dt, const void* x, const void* W0, void* y1, const float* bn1_w, const float* bn1_b, float* bn1_rm, float* bn1_rv, int64_t* bn1_nbt,
+bool launch_mbconv_front(int dt, const void* x, const MbXinArgs* xin, const void* W0, void* y1, const float* bn1_w, const float* bn1_b, float* bn1_rm, float* bn1_rv, int64_t* bn1_nbt,
                          float* bn1_ss, float* bn1_mr, float bn1_eps, void* z1, const void* wdw, void* y2, const float* bn2_w, const float* bn2_b, float* bn2_rm,
                          float* bn2_rv, int64_t* bn2_nbt, float* bn2_ss, float* bn2_mr, float bn2_eps, void* z2 /*may be null*/, const void* Wr, const float* br,
                          const void* We, const float* be, float* pooled, float* u1, float* s1, void* gate, void* z3, int B, int H, int W, int Cin, int C, int S,
@@ -399,6 +446,12 @@ bool launch_mbconv_front(int dt, const void* x, const void* W0, void* y1, const 
   const int HW = H * W;
   MbFrontP p;
   p.x = (const bf16_t*)x; p.W0 = (const bf16_t*)W0; p.y1 = (bf16_t*)y1;
+  p.xin = MbXin{nullptr, nullptr, nullptr, 1, MbBn{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f}, nullptr};
+  if (xin) {
+    if (x || !xin->y || !xin->sums || !xin->out || xin->rep < 1) return false;
+    p.xin = MbXin{(const bf16_t*)xin->y, (const bf16_t*)xin->res, xin->sums, xin->rep,
+                  MbBn{xin->w, xin->b, xin->rm, xin->rv, xin->nbt, xin->ss, xin->mr, xin->eps}, (bf16_t*)xin->out};
+  } else if (!x) return false;
   p.bn1 = MbBn{bn1_w, bn1_b, bn1_rm, bn1_rv, bn1_nbt, bn1_ss, bn1_mr, bn1_eps};
   p.z1 = (bf16_t*)z1; p.wdw = (const bf16_t*)wdw; p.y2 = (bf16_t*)y2;
   p.bn2 = MbBn{bn2_w, bn2_b, bn2_rm, bn2_rv, bn2_nbt, bn2_ss, bn2_mr, bn2_eps};

@@ -289,11 +289,11 @@ int satrn_batchnorm_act_se_fwd(int dt, const void* y, const float* w, const floa
   }
   return done("batchnorm_act_se_fwd");
 }
-int satrn_mbconv_front_fwd(const void* x, const void* W0, void* y1, const float* w1, const float* b1n, float* rm1, float* rv1, int64_t* nbt1, float* coef1,
-                           void* z1, const void* dwp, void* y2, const float* w2, const float* b2n, float* rm2, float* rv2, int64_t* nbt2, float* coef2,
-                           void* z2, int keep_z2, const void* W1, const float* b1, const void* W2, const float* b2, float* pooled, float* u1, float* s1,
-                           void* gate, void* z3, int B, int H, int W, int Cin, int C, int S, float eps, unsigned long long* mailbox, long mailbox_words,
-                           void* st) {
+static int mbconv_front_impl(const void* x, const MbXinArgs* xin, const void* W0, void* y1, const float* w1, const float* b1n, float* rm1, float* rv1, int64_t* nbt1,
+                             float* coef1, void* z1, const void* dwp, void* y2, const float* w2, const float* b2n, float* rm2, float* rv2, int64_t* nbt2, float* coef2,
+                             void* z2, int keep_z2, const void* W1, const float* b1, const void* W2, const float* b2, float* pooled, float* u1, float* s1,
+                             void* gate, void* z3, int B, int H, int W, int Cin, int C, int S, float eps, unsigned long long* mailbox, long mailbox_words,
+                             void* st) {
   CHK_DT(DT_BF16);
   if (B < 1 || C < 64 || (C % 64) || !mailbox) return fail(-1, "mbconv_front_fwd: B >= 1, C a multiple of 64 and a mailbox are required");
   const long bn_words = 3L * (C / 64) * B * 128, se_words = (long)B * (C / 64) * 64;
@@ -301,11 +301,31 @@ int satrn_mbconv_front_fwd(const void* x, const void* W0, void* y1, const float*
   g_mbbox.box = mailbox; g_mbbox.words = (size_t)bn_words; g_mbbox.images = 64;
   g_sebox.box = mailbox + bn_words; g_sebox.images = B;
   const bool okk = mbconv_front_ok(DT_BF16, B, H, W, Cin, C, S, S(st)) &&
-                   launch_mbconv_front(DT_BF16, x, W0, y1, w1, b1n, rm1, rv1, nbt1, coef1, coef1 + 2 * C, eps, z1, dwp, y2, w2, b2n, rm2, rv2, nbt2, coef2,
+                   launch_mbconv_front(DT_BF16, x, xin, W0, y1, w1, b1n, rm1, rv1, nbt1, coef1, coef1 + 2 * C, eps, z1, dwp, y2, w2, b2n, rm2, rv2, nbt2, coef2,
                                        coef2 + 2 * C, eps, keep_z2 ? z2 : nullptr, W1, b1, W2, b2, pooled, u1, s1, gate, z3, B, H, W, Cin, C, S, 0.1f, S(st));
   g_mbbox.box = nullptr; g_mbbox.words = 0; g_mbbox.images = 0; g_sebox.box = nullptr; g_sebox.images = 0;
   if (!okk) return fail(-1, "mbconv_front_fwd: shape not taken by the one-launch form (use the separate operators)");
   return done("mbconv_front_fwd");
+}
+int satrn_mbconv_front_fwd(const void* x, const void* W0, void* y1, const float* w1, const float* b1n, float* rm1, float* rv1, int64_t* nbt1, float* coef1,
+                           void* z1, const void* dwp, void* y2, const float* w2, const float* b2n, float* rm2, float* rv2, int64_t* nbt2, float* coef2,
+                           void* z2, int keep_z2, const void* W1, const float* b1, const void* W2, const float* b2, float* pooled, float* u1, float* s1,
+                           void* gate, void* z3, int B, int H, int W, int Cin, int C, int S, float eps, unsigned long long* mailbox, long mailbox_words,
+                           void* st) {
+  if (!x) return fail(-1, "mbconv_front_fwd: x is required");
+  return mbconv_front_impl(x, nullptr, W0, y1, w1, b1n, rm1, rv1, nbt1, coef1, z1, dwp, y2, w2, b2n, rm2, rv2, nbt2, coef2, z2, keep_z2, W1, b1, W2, b2, pooled, u1,
+                           s1, gate, z3, B, H, W, Cin, C, S, eps, mailbox, mailbox_words, st);
+}
+int satrn_mbconv_front_fwd_bn_in(const void* in_y, const void* in_res, const float* in_sums, int in_sums_rep, const float* in_weight, const float* in_bias,
+                                 float* in_rm, float* in_rv, int64_t* in_nbt, float* in_coef, void* x_out, const void* W0, void* y1, const float* w1,
+                                 const float* b1n, float* rm1, float* rv1, int64_t* nbt1, float* coef1, void* z1, const void* dwp, void* y2, const float* w2,
+                                 const float* b2n, float* rm2, float* rv2, int64_t* nbt2, float* coef2, void* z2, int keep_z2, const void* W1, const float* b1,
+                                 const void* W2, const float* b2, float* pooled, float* u1, float* s1, void* gate, void* z3, int B, int H, int W, int Cin, int C,
+                                 int S, float eps, unsigned long long* mailbox, long mailbox_words, void* st) {
+  if (!in_y || !in_sums || !in_coef || !x_out) return fail(-1, "mbconv_front_fwd_bn_in: in_y, in_sums, in_coef and x_out are required");
+  MbXinArgs xa{in_y, in_res, in_sums, in_sums_rep, in_weight, in_bias, in_rm, in_rv, in_nbt, in_coef, in_coef + 2 * Cin, eps, x_out};
+  return mbconv_front_impl(nullptr, &xa, W0, y1, w1, b1n, rm1, rv1, nbt1, coef1, z1, dwp, y2, w2, b2n, rm2, rv2, nbt2, coef2, z2, keep_z2, W1, b1, W2, b2, pooled, u1,
+                           s1, gate, z3, B, H, W, Cin, C, S, eps, mailbox, mailbox_words, st);
 }
 int satrn_mbconv_bwd_se(const void* dy3, const void* w_bwd, int ldb, void* dz3, const void* bn2_y, const float* coef2, const void* gate, const float* u1,
                         const void* W1, const void* W2, float* dz2, float* ds1, float* du1, void* dpooled, float* bn2_sums, int B, int H, int W, int Cout,

@@ -226,3 +226,63 @@ def test_mbconv_backward_projection_data_gradient_and_squeeze_excite_in_one_laun
     close(dz2, dz2_r, BF, "dz2 vs torch", bf16_tol=2e-2)
     close(du1, du1_r, BF, "du1 vs torch", bf16_tol=2e-2)
     close(dpool, dpool_r, BF, "dpooled vs torch", bf16_tol=2e-2)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,C,S,res", [(32, 4, 12, 256, 1536, 64, True), (32, 8, 24, 160, 960, 40, True), (5, 8, 24, 128, 512, 32, False), (3, 4, 12, 256, 128, 8, True)])
+def test_mbconv_front_with_the_input_batchnorm_folded_in(lib, B, H, W, Cin, C, S, res):
+    """satrn_mbconv_front_fwd_bn_in: the block input = BatchNorm(in_y) (+ residual), normalised while the kernel stages it -- against
+    satrn_batchnorm_act_fwd followed by satrn_mbconv_front_fwd on the tensor that one wrote (same coefficients, same rounding point: the
+    block then runs on bit-identical inputs)."""
+    eps, M, bf = 1e-3, B * H * W, torch.bfloat16
+    inp = _inputs(B, H, W, Cin, C, S)
+    _, W0, g1, be1, g2, be2, dw, W1, W2, b1, b2 = inp
+    in_y = q(rnd(M, Cin, seed=21) * 1.5 + 0.3, BF)
+    in_res = q(rnd(M, Cin, seed=22), BF) if res else None
+    gw, gb = 1 + rnd(Cin, seed=23, scale=0.2), rnd(Cin, seed=24, scale=0.1)
+    rep = 3
+    sums = torch.zeros(rep, 2, Cin)
+    yf = in_y.float()
+    for r in range(rep):   # the column sums split over replicas, as a statistics epilogue leaves them
+        rows = yf[r::rep]
+        sums[r, 0], sums[r, 1] = rows.sum(0), (rows * rows).sum(0)
+    in_yd, in_resd, sumsd = dev(in_y, BF), (dev(in_res, BF) if res else None), dev(sums)
+    # reference route: the BatchNorm as its own launch, then the block on its output
+    rm, rv, nbt = torch.zeros(Cin, device="cuda"), torch.ones(Cin, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    scr = torch.zeros(6 * Cin, device="cuda")   # (the operator sums the columns of in_y itself)
+    xd = torch.zeros(M, Cin, dtype=bf, device="cuda")
+    ok(lib, lib.satrn_batchnorm_act_fwd(1, P(in_yd), P(dev(gw)), P(dev(gb)), P(rm), P(rv), P(nbt), eps, 1, 0, P(in_resd), P(xd), M, Cin, P(scr), st()))
+    torch.cuda.synchronize()
+    inp2 = (xd.float().cpu().reshape(B, H * W, Cin),) + inp[1:]
+    box = _mailbox(B, C)
+    rc, o_ref = _run_front(lib, inp2, B, H, W, Cin, C, S, eps, box)
+    assert rc == 0, lib.satrn_last_error().decode()
+    # folded route
+    W0d, _, _ = pack_dense(lib, W0, BF)
+    wp = torch.empty(9, C, dtype=bf, device="cuda")
+    ok(lib, lib.satrn_pack_dwconv3x3(1, P(dev(dw)), P(wp), C, st()))
+    o = dict(y1=torch.zeros(M, C, dtype=bf, device="cuda"), z1=torch.zeros(M, C, dtype=bf, device="cuda"), y2=torch.zeros(M, C, dtype=bf, device="cuda"),
+             z2=torch.zeros(M, C, dtype=bf, device="cuda"), z3=torch.zeros(M, C, dtype=bf, device="cuda"), pooled=torch.zeros(B, C, device="cuda"),
+             u1=torch.zeros(B, S, device="cuda"), s1=torch.zeros(B, S, device="cuda"), gate=torch.zeros(B, C, dtype=bf, device="cuda"),
+             coef1=torch.zeros(4 * C, device="cuda"), coef2=torch.zeros(4 * C, device="cuda"))
+    rm1, rv1, rm2, rv2 = (torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"))
+    n1, n2, n0 = (torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(3))
+    irm, irv, icoef = torch.zeros(Cin, device="cuda"), torch.ones(Cin, device="cuda"), torch.zeros(4 * Cin, device="cuda")
+    xo = torch.zeros(M, Cin, dtype=bf, device="cuda")
+    rc = lib.satrn_mbconv_front_fwd_bn_in(P(in_yd), P(in_resd), P(sumsd), rep, P(dev(gw)), P(dev(gb)), P(irm), P(irv), P(n0), P(icoef), P(xo), P(W0d), P(o["y1"]),
+                                          P(dev(g1)), P(dev(be1)), P(rm1), P(rv1), P(n1), P(o["coef1"]), P(o["z1"]), P(wp), P(o["y2"]), P(dev(g2)), P(dev(be2)),
+                                          P(rm2), P(rv2), P(n2), P(o["coef2"]), P(o["z2"]), 1, P(dev(W1, BF)), P(dev(b1)), P(dev(W2, BF)), P(dev(b2)),
+                                          P(o["pooled"]), P(o["u1"]), P(o["s1"]), P(o["gate"]), P(o["z3"]), B, H, W, Cin, C, S, eps, P(box), box.numel(), st())
+    assert rc == 0, lib.satrn_last_error().decode()
+    torch.cuda.synchronize()
+    assert lib.satrn_device_error(st()) == 0
+    same_x = (xo == xd).float().mean().item()
+    print(f"[front with folded input BatchNorm] x identical to batchnorm_act_fwd's {same_x:.6f}")
+    close(xo, xd.float().cpu(), BF, "folded input x", bf16_tol=1e-2)
+    assert same_x > 0.99   # (the replicas are added in another order: a last-bit difference of scale / shift may move a rounding)
+    close(icoef, scr[2 * Cin:].cpu(), "f32", "input BatchNorm coefficients", f32_tol=1e-5)
+    close(irm, rm.cpu(), "f32", "input BatchNorm running mean", f32_tol=1e-5)
+    close(irv, rv.cpu(), "f32", "input BatchNorm running var", f32_tol=1e-5)
+    assert n0.item() == 1
+    for k in ("y1", "z1", "y2", "z3"):
+        close(o[k], o_ref[k].float().cpu(), BF, f"folded input: {k}", bf16_tol=2e-2)
+    close(o["gate"], o_ref["gate"].float().cpu(), BF, "folded input: gate", bf16_tol=1e-2)
