@@ -206,6 +206,15 @@ int satrn_mbconv_front_fwd_bn_in(const void* in_y, const void* in_res, const flo
 int satrn_mbconv_bwd_se(const void* dy3, const void* w_bwd, int ldb, void* dz3, const void* bn2_y, const float* bn2_coef, const void* gate,
                         const float* u1, const void* W1, const void* W2, float* dz2, float* ds1, float* du1, void* dpooled, float* bn2_sums, int B,
                         int H, int W, int Cout, int C, int S, unsigned long long* mailbox, long mailbox_words, void* stream);
+/* The same with dy3 taken as the BACKWARD of the block-ending BatchNorm (timm InvertedResidual.bn3: batch statistics, no activation) applied to
+ * the gradient dz at the block's output: bn3_y = that BatchNorm's input, bn3_coef = its scale | shift | mean | rstd (4 * Cout floats),
+ * bn3_sums = [sum dz | sum dz * xhat] (2 * Cout floats; what satrn_linear_fwd_stats's bnb form or satrn_batchnorm_act_bwd's reduction leaves).
+ * dy3_out [B][H][W][Cout] receives the result (the projection's weight gradient reads it), bn3_dweight / bn3_dbias accumulate the BatchNorm's
+ * parameter gradients -- satrn_batchnorm_act_bwd_apply's job, without its launch. */
+int satrn_mbconv_bwd_se_bn_in(const void* dz, const void* bn3_y, const float* bn3_coef, const float* bn3_weight, const float* bn3_sums, void* dy3_out,
+                              float* bn3_dweight, float* bn3_dbias, const void* w_bwd, int ldb, void* dz3, const void* bn2_y, const float* bn2_coef,
+                              const void* gate, const float* u1, const void* W1, const void* W2, float* dz2, float* ds1, float* du1, void* dpooled,
+                              float* bn2_sums, int B, int H, int W, int Cout, int C, int S, unsigned long long* mailbox, long mailbox_words, void* stream);
 /* Training-mode BatchNorm2d + activation of y[B][H][W][C] -> z, followed by the stride-1 "same" depthwise 3x3 (+bias) of z -> out,
  * in one launch where the shape allows (the expand-BN-SiLU-depthwise seam of the timm MBConv block in the 8x24 / 4x12 stages;
  * networks/EfficientSATRN.py:74-76 runs those blocks).  Results equal satrn_batchnorm_act_fwd + satrn_dwconv3x3_fwd bit for bit

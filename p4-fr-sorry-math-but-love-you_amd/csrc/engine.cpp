@@ -773,6 +773,17 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       }
       else if (act == ACT_SIGMOID) LCH(e, launch_act_bwd(e.dt, dY, y->p, dY, M * N, ACT_SIGMOID, 0.f, e.s));
       else if (drop_p > 0.f) LCH(e, launch_dropout_bwd(e.dt, dY, dY, M, N, drop_p, seed, site, e.s));
+      // y's BatchNorm backward-apply held back (MBConv projection, see Tensor::bn_bwd_hold_ok): dY does not exist yet
+      const bool bnheld = y->bhold.armed && y->bn_bwd_hold_ok;
+      auto flush_bn = [&e, y]() {
+        BnBwdHold& h = y->bhold;
+        if (!h.armed) return;
+        h.armed = false;
+        WORK(e, 0, (double)h.M * h.C * e.esz() * 3);
+        LCH(e, launch_bn_bwd_apply(e.dt, h.dz, h.y, h.ss, h.mr, h.w, h.red, h.M, h.C, h.act, h.dy, h.dwp, h.dbp, e.s, h.rep, nullptr, nullptr, 0, 0));
+      };
+      const bool can_hold_dgrad = !hasgeo && x->se_out && !fuse_bnb && !out_f32 && ldy == N && !e.dry && e.dt == DT_BF16 && !x->g && x->ncons == 1;
+      if (bnheld && !can_hold_dgrad) flush_bn();
       WgradP q;
       memset(&q, 0, sizeof(q));
       q.dY = dY; q.A = x->p; q.dW = w->g; q.M = (int)M; q.N = N; q.K = w->K; q.ldy = ldy; q.lda = x->C;
@@ -785,7 +796,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
         tmp = e.zalloc((size_t)N * w->K);
         q.conv_packed_out = 1; q.dW = tmp;
       }
-      {
+      auto do_wgrad = [&e, q, tmp, bias, w, g, hasgeo, M, N, dY, ldy, x]() mutable {
         const int dt = e.dt; const bool dry = e.dry;
         float* bg = bias ? bias->g : nullptr; float* wg = w->g; const int Ci = g.Ci;
         // dense products: the weight-gradient kernel sums the bias gradient from the dY chunks it stages anyway (not in the deterministic mode,
@@ -806,7 +817,9 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
           });
           if (tmp) e.flush_side();  // the heavy 3x3 weight gradients of the last backward stages start at once (join wait 0.19 -> 0.08 ms)
         }
-      }
+      };
+      const bool defer_wgrad = bnheld && y->bhold.armed;   // dY is produced by the block's backward launch: the weight gradient is issued behind it
+      if (!defer_wgrad) do_wgrad();
       int beta;
       void* dx = e.grad(x, &beta);
       GemmP d;
@@ -828,9 +841,11 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
         if (x->se_out && !beta && !fuse_bnb && !d.bact_u && !out_f32 && ldy == N && !e.dry && e.dt == DT_BF16) {
           // x is a squeeze-and-excite output: its closure (next) runs this product together with its own kernels where it can
           x->dgrad_hold = std::make_shared<GemmP>(d); x->dgrad_hold_flops = e.nflops; x->dgrad_hold_bytes = e.nbytes;
+          if (defer_wgrad) { x->bhold = y->bhold; y->bhold.armed = false; x->after_fused = do_wgrad; }
           e.nflops = 0; e.nbytes = 0;
           return;
         }
+        if (defer_wgrad) { const double fl = e.nflops, by = e.nbytes; flush_bn(); do_wgrad(); WORK(e, fl, by); }
         LCH(e, launch_gemm(e.dt, AM_DENSE, d, e.s));
       } else {
         d.M = (int)((long)B * g.H * g.W); d.N = g.Ci; d.K = 9 * w->Co; d.ldc = g.Ci;
@@ -946,6 +961,12 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** poo
         BnBwdHold& h = y->bhold;
         h.armed = true; h.dz = z->g; h.y = y->p; h.ss = ss; h.mr = mr; h.w = bn->w.p; h.red = red; h.M = M; h.C = C; h.act = act; h.dy = dy;
         h.dwp = bn->w.g; h.dbp = bn->b.g; h.se_gate = z->se_gate; h.se_dpool = z->se_dpool; h.se_hw = z->se_hw;
+      } else if (y->bn_bwd_hold_ok && !eval_stats && act == ACT_NONE && !z->se_gate && !e.dry && e.dt == DT_BF16 && getenv("SATRN_NO_MBCONV_DFOLD") == nullptr) {
+        // y is an MBConv block's projection output: its closure (next) and the squeeze-and-excite closure behind it run this pass inside the
+        // block's backward launch (launch_mbconv_bwd_se with MbDinArgs), or launch it themselves
+        BnBwdHold& h = y->bhold;
+        h.armed = true; h.dz = z->g; h.y = y->p; h.ss = ss; h.mr = mr; h.w = bn->w.p; h.red = red; h.M = M; h.C = C; h.act = act; h.dy = dy;
+        h.dwp = bn->w.g; h.dbp = bn->b.g; h.se_gate = nullptr; h.se_dpool = nullptr; h.se_hw = 0; h.rep = z->bn_red ? z->bn_red_rep : 1;
       } else {
         e.nbytes = (double)M * C * e.esz() * 3;
         LCH(e, launch_bn_bwd_apply(e.dt, z->g, y->p, ss, mr, bn->w.p, red, M, C, act, dy, bn->w.g, bn->b.g, e.s, z->bn_red ? z->bn_red_rep : 1,
@@ -1712,7 +1733,17 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr, SeHold
     e.tape.push_back([&e, x, y, gate, eb, pooled, u1, s1, B, HW, C, S]() {
       std::shared_ptr<GemmP> held = y->dgrad_hold;   // the data gradient of the product that consumed y, not launched yet (op_gemm)
       y->dgrad_hold.reset();
+      BnBwdHold bb = y->bhold;                       // the backward-apply pass of the BatchNorm behind that product, not launched yet either
+      y->bhold.armed = false;
+      std::function<void()> after = std::move(y->after_fused);   // ... and that product's weight gradient, which reads the pass's output
+      y->after_fused = nullptr;
       auto run_held = [&]() {
+        if (bb.armed) {
+          bb.armed = false;
+          WORK(e, 0, (double)bb.M * bb.C * e.esz() * 3);
+          LCH(e, launch_bn_bwd_apply(e.dt, bb.dz, bb.y, bb.ss, bb.mr, bb.w, bb.red, bb.M, bb.C, bb.act, bb.dy, bb.dwp, bb.dbp, e.s, bb.rep, nullptr, nullptr, 0, 0));
+        }
+        if (after) { after(); after = nullptr; }
         if (!held) return;
         WORK(e, y->dgrad_hold_flops, y->dgrad_hold_bytes);
         LCH(e, launch_gemm(e.dt, AM_DENSE, *held, e.s));
@@ -1739,9 +1770,10 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr, SeHold
         // the projection's data gradient + this backward in ONE launch (only the image's own workgroups wait for each other)
         bool one = false;
         WORK(e, y->dgrad_hold_flops + 8.0 * (double)B * C * S, y->dgrad_hold_bytes + (double)x->rows * C * e.esz() * 2 + (double)C * S * e.esz() * 2);
-        LCH(e, one = launch_mbconv_bwd_se(dt, held->A, held->Bw, held->K, held->C, x->bn_y, x->bn_ss, x->bn_mr, gp, u1, w2, w1, dz2, ds1, du1, dpooled, bnR,
-                                          B, x->H, x->W, held->lda, C, S, e.s));
-        if (one) { held.reset(); wide = true; }
+        MbDinArgs da{bb.dz, bb.y, bb.ss, bb.mr, bb.w, bb.red, bb.rep, bb.dy, bb.dwp, bb.dbp};
+        LCH(e, one = launch_mbconv_bwd_se(dt, bb.armed ? nullptr : held->A, bb.armed ? &da : nullptr, held->Bw, held->K, held->C, x->bn_y, x->bn_ss, x->bn_mr, gp, u1,
+                                          w2, w1, dz2, ds1, du1, dpooled, bnR, B, x->H, x->W, held->lda, C, S, e.s));
+        if (one) { held.reset(); wide = true; bb.armed = false; if (after) { after(); after = nullptr; } }
       }
       run_held();
       if (!wide) {
@@ -1844,6 +1876,7 @@ Tensor* eff_block(Exec& e, Tensor* x, EffBlock* eb, bool hold_out = false) {
   }
   Tensor* y3 = op_gemm(e, z3, &eb->c1, nullptr, ACT_NONE, 0.f, nullptr, 0, false, nullptr, true);
   y3->B = B; y3->H = g.OH; y3->W = g.OW;
+  y3->bn_bwd_hold_ok = e.train && e.rec && e.dt == DT_BF16 && !g_det.on;   // (the backward closures decide; every refusal launches the held pass itself)
   return op_bn_act(e, y3, &eb->bn3, ACT_NONE, skip, nullptr, nullptr, nullptr, hold_out ? &e.xhold : nullptr);
 }
 

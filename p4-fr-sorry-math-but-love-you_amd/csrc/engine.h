@@ -87,6 +87,10 @@ struct Tensor {
   bool dw_bwd_fuse = false; BnBwdHold bhold;
   // the output of a squeeze-and-excite block (op_se): the dense product that consumes it leaves its data gradient here instead of launching,
   // and op_se's backward runs both in one launch where the shape allows (launch_mbconv_bwd_se), else launches the held product first
+  // ... and, one step earlier: the output y3 of the block's projection is marked (bn_bwd_hold_ok) so that the backward-apply pass of the BatchNorm
+  // behind it (bn3) is not launched either (bhold); the projection's closure moves it -- with its own weight-gradient launch, which reads the dy3
+  // that does not exist yet -- to the squeeze-and-excite output (after_fused), whose closure runs all of it in one launch or in the old order
+  bool bn_bwd_hold_ok = false; std::function<void()> after_fused;
   bool se_out = false; std::shared_ptr<GemmP> dgrad_hold; double dgrad_hold_flops = 0, dgrad_hold_bytes = 0; int dgrad_hold_ldb = 0; const void* dgrad_hold_w = nullptr;
   // inference: a product whose launch is postponed until the BatchNorm that consumes it is known, so that BatchNorm (eval
   // statistics) + activation + residual run in its epilogue and the raw output is never written (op_gemm -> op_bn_act)

@@ -245,7 +245,7 @@ struct BnBwdHold {
   bool armed = false;
   const void* dz = nullptr; const void* y = nullptr; const float* ss = nullptr; const float* mr = nullptr; const float* w = nullptr; const float* red = nullptr;
   long M = 0; int C = 0, act = 0; void* dy = nullptr; float* dwp = nullptr; float* dbp = nullptr;
-  const void* se_gate = nullptr; const void* se_dpool = nullptr; int se_hw = 0;
+  const void* se_gate = nullptr; const void* se_dpool = nullptr; int se_hw = 0; int rep = 1 /*replicas of red*/;
 };
 // y == nullptr: no BatchNorm sums (plain data gradient).  ap != nullptr: dy is NOT read -- it is first produced as the BatchNorm
 // backward-apply result of *ap (written to ap->dy = dy for the weight-gradient pass, parameter gradients accumulated) and consumed
@@ -362,7 +362,11 @@ bool launch_mbconv_front(int dt, const void* x, const MbXinArgs* xin, const void
 // Backward: the projection's data gradient dz3 = dy3 W1 and the squeeze-and-excite backward (incl. the sums BatchNorm 2's backward needs) in
 // ONE launch (kernels_mbconv.hip); same shapes as the front.  Wb = the projection's backward pack [C][ldb]; red [2C] is accumulated into.
 // Only the workgroups of one image wait for each other (g_sebox).  false = not taken.
-bool launch_mbconv_bwd_se(int dt, const void* dy3, const void* Wb, int ldb, void* dz3, const void* y2, const float* ss2, const float* mr2, const void* gate,
+// din != null (then dy3 == null): dy3 = the backward of the block-ending BatchNorm (batch statistics, no activation; column sums in `red`)
+// applied to dz while the kernel stages it, written to dy_out for the weight gradient; dw / db (may be null) receive the BatchNorm's
+// parameter gradients -- launch_bn_bwd_apply's job
+struct MbDinArgs { const void* dz; const void* y; const float* ss; const float* mr; const float* w; const float* red; int rep; void* dy_out; float* dw; float* db; };
+bool launch_mbconv_bwd_se(int dt, const void* dy3, const MbDinArgs* din, const void* Wb, int ldb, void* dz3, const void* y2, const float* ss2, const float* mr2, const void* gate,
                           const float* u1, const void* We, const void* Wr, float* dz2, float* ds1, float* du1, void* dpooled, float* red, int B, int H, int W,
                           int CN, int C, int S, hipStream_t s);
 bool launch_se_mlp_scale(int dt, const void* x, const float* poolsum, const void* W1, const float* b1, const void* W2, const float* b2,

@@ -503,8 +503,14 @@ bool launch_mbconv_front(int dt, const void* x, const MbXinArgs* xin, const void
 // backward) -- the whole grid need not be resident.
 // Writes what the three kernels wrote: dz3 (bf16, read by the depthwise backward as the gradient of z2 together with gate / dpooled), dz2,
 // ds1, du1 (f32), dpooled (bf16), and adds this image's share to BatchNorm 2's backward sums red[2C] (float atomics, as before).
+// dy3 as the BACKWARD of the BatchNorm that ends the block (bn3: batch statistics, no activation) applied to the gradient dz at the block's
+// output:  dy3 = w rstd (dz - mean(dz) - xhat mean(dz xhat)),  xhat = (y - mean) rstd,  with the two column sums in `red` (rep replicas of
+// [2 CN]) -- bn_bwd_apply_kernel's arithmetic, computed by every workgroup while it stages its image's rows; workgroup (image, slab 0) writes
+// dy3 out (the projection's weight gradient reads it), workgroup (0, 0) adds the BatchNorm's parameter gradients.
+struct MbDin { const bf16_t* dz; const bf16_t* y; const float* ss; const float* mr; const float* w; const float* red; int rep; float invM; bf16_t* dy_out; float* dw; float* db; };
 struct MbBwdSeP {
-  const bf16_t* dy3;     // [B][HW][CN]
+  const bf16_t* dy3;     // [B][HW][CN]  (null: din)
+  MbDin din;
   const bf16_t* Wb;      // [C][ldb]  the projection's backward pack (W1^T): row = expanded channel, columns = output channels
   bf16_t* dz3;           // [B][HW][C]
   const bf16_t* y2; const float* ss2; const float* mr2;   // BatchNorm 2: input, scale | shift, mean | rstd
@@ -534,34 +540,69 @@ __global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbc
   const long long t_end = (long long)wall_clock64() + p.timeout_ticks;
 
   // ---- the product, as in mbconv_front_kernel: image rows through LDS, this slab's 64 weight rows in registers --------------------------
-  const bf16_t* xb = p.dy3 + (size_t)img * HWT * CN;
-  uint4 xr[XPT];
+  const bool dfold = p.dy3 == nullptr;
+  const bf16_t* xb = (dfold ? p.din.dz : p.dy3) + (size_t)img * HWT * CN;
+  uint4 xr[XPT], yr[XPT];
 #pragma unroll
   for (int k = 0; k < XPT; ++k) {
     const int idx = tid + k * NT;
     xr[k] = idx < NXC ? ld16(xb + (size_t)idx * 8) : zero16();
+    yr[k] = (dfold && idx < NXC) ? ld16(p.din.y + (size_t)img * HWT * CN + (size_t)idx * 8) : zero16();
   }
   const int ct0 = HWT == 48 ? 2 * wave : (wave & 3), rt0 = HWT == 48 ? 0 : (wave >> 2) * RTW;
   Frag<T> bfr[CTW][KS];
-#pragma unroll
-  for (int ct = 0; ct < CTW; ++ct)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) bfr[ct][ks].v = ld16(p.Wb + (size_t)(cb + (ct0 + ct) * 16 + fr) * p.ldb + ks * 32 + fq * 8);
-  bf16_t* xbuf = reinterpret_cast<bf16_t*>(mb_sm);
-#pragma unroll
-  for (int k = 0; k < XPT; ++k) {
-    const int idx = tid + k * NT;
-    if (idx < NXC) {
-      const int row = idx / (CN / 8), ch = idx - row * (CN / 8);
-      st16(xbuf + row * XP + ch * 8, xr[k]);
-    }
-  }
-  // operands of the element-wise phase, requested before the product: BatchNorm 2's input of this thread's pixels, its coefficients
+  // operands of the element-wise phase: BatchNorm 2's input of this thread's pixels
   const int chunk = tid % SC, g = tid / SC;
   const long base = (long)img * HWT * C + cb + chunk * CH;
   uint4 y2q[RUN];
+  auto load_w = [&]() {
 #pragma unroll
-  for (int k = 0; k < RUN; ++k) y2q[k] = ld16(p.y2 + base + (long)(g + k * G) * C);
+    for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) bfr[ct][ks].v = ld16(p.Wb + (size_t)(cb + (ct0 + ct) * 16 + fr) * p.ldb + ks * 32 + fq * 8);
+#pragma unroll
+    for (int k = 0; k < RUN; ++k) y2q[k] = ld16(p.y2 + base + (long)(g + k * G) * C);
+  };
+  if (NT < 512) load_w();   // (the 512-thread form has 128 registers: requested behind the staging)
+  bf16_t* xbuf = reinterpret_cast<bf16_t*>(mb_sm);
+  if (dfold) {
+    float* cfd = reinterpret_cast<float*>(mb_sm + (size_t)HWT * XP * 2);   // A | B | C [3][CN] behind the image rows
+    for (int c = tid; c < CN; c += NT) {
+      float r0 = 0.f, r1 = 0.f;
+      for (int rp = 0; rp < p.din.rep; ++rp) { r0 += p.din.red[(size_t)rp * 2 * CN + c]; r1 += p.din.red[(size_t)rp * 2 * CN + CN + c]; }
+      const float mu = p.din.mr[c], rs = p.din.mr[CN + c];
+      const float a = p.din.w[c] * rs, m1 = r0 * p.din.invM, m2 = r1 * p.din.invM;
+      cfd[c] = a; cfd[CN + c] = -a * m1 + a * rs * mu * m2; cfd[2 * CN + c] = -a * rs * m2;
+      if (img == 0 && slab == 0 && p.din.dw) { p.din.dw[c] += r1; p.din.db[c] += r0; }   // (gradient buffers are zeroed per step: accumulate)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int idx = tid + k * NT;
+      if (idx < NXC) {
+        const int row = idx / (CN / 8), ch = idx - row * (CN / 8);
+        float d[CH], v[CH], ca[CH], cb2[CH], cc[CH];
+        unpack<T>(xr[k], d); unpack<T>(yr[k], v);
+        lds8(cfd + ch * 8, ca); lds8(cfd + CN + ch * 8, cb2); lds8(cfd + 2 * CN + ch * 8, cc);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) d[j] = ca[j] * d[j] + cb2[j] + cc[j] * v[j];
+        const uint4 q = pack<T>(d);
+        st16(xbuf + row * XP + ch * 8, q);
+        if (slab == 0) st16(p.din.dy_out + (size_t)img * HWT * CN + (size_t)idx * 8, q);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+      const int idx = tid + k * NT;
+      if (idx < NXC) {
+        const int row = idx / (CN / 8), ch = idx - row * (CN / 8);
+        st16(xbuf + row * XP + ch * 8, xr[k]);
+      }
+    }
+  }
+  if (NT >= 512) load_w();
   __syncthreads();
   f32x4 acc[RTW][CTW];
 #pragma unroll
@@ -748,7 +789,7 @@ __global__ __launch_bounds__(HWT * 8 / 3, (HWT * 8 / 3) >= 512 ? 4 : 1) void mbc
 template <int HWT, int CN>
 static bool mb_bwd_se_go(const MbBwdSeP& p, hipStream_t s) {
   constexpr int NT = HWT * 8 / 3;
-  size_t lds = (size_t)HWT * (CN + 8) * 2;
+  size_t lds = (size_t)HWT * (CN + 8) * 2 + (size_t)3 * CN * 4;   // image rows + the coefficients of a folded BatchNorm backward
   if (lds < (size_t)HWT * 72 * 2) lds = (size_t)HWT * 72 * 2;
   if (lds < 16384) lds = 16384;
   static bool attr = false;
@@ -760,7 +801,7 @@ static bool mb_bwd_se_go(const MbBwdSeP& p, hipStream_t s) {
   return true;
 }
 // false = shape / mode not taken (the caller runs the data-gradient product and the squeeze-and-excite backward kernels)
-bool launch_mbconv_bwd_se(int dt, const void* dy3, const void* Wb, int ldb, void* dz3, const void* y2, const float* ss2, const float* mr2, const void* gate,
+bool launch_mbconv_bwd_se(int dt, const void* dy3, const MbDinArgs* din, const void* Wb, int ldb, void* dz3, const void* y2, const float* ss2, const float* mr2, const void* gate,
                           const float* u1, const void* We, const void* Wr, float* dz2, float* ds1, float* du1, void* dpooled, float* red, int B, int H, int W,
                           int CN, int C, int S, hipStream_t s) {
   const bool off = getenv("SATRN_NO_MBCONV_BWD_SE") != nullptr || getenv("SATRN_SE_NO_WIDE_BWD") != nullptr || getenv("SATRN_SE_NO_BN_SUMS") != nullptr;   // read per call (tests)
@@ -770,7 +811,12 @@ bool launch_mbconv_bwd_se(int dt, const void* dy3, const void* Wb, int ldb, void
   if (!((HW == 48 && CN == 256) || (HW == 192 && (CN == 160 || CN == 128)))) return false;
   if (!se_box_usable(s)) return false;
   MbBwdSeP p;
-  p.dy3 = (const bf16_t*)dy3; p.Wb = (const bf16_t*)Wb; p.dz3 = (bf16_t*)dz3; p.y2 = (const bf16_t*)y2; p.ss2 = ss2; p.mr2 = mr2;
+  p.dy3 = (const bf16_t*)dy3; p.Wb = (const bf16_t*)Wb; p.dz3 = (bf16_t*)dz3;
+  p.din = MbDin{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0.f, nullptr, nullptr, nullptr};
+  if (din) {
+    if (dy3 || !din->dz || !din->y || !din->red || !din->dy_out || din->rep < 1) return false;
+    p.din = MbDin{(const bf16_t*)din->dz, (const bf16_t*)din->y, din->ss, din->mr, din->w, din->red, din->rep, 1.0f / (float)((long)B * HW), (bf16_t*)din->dy_out, din->dw, din->db};
+  } else if (!dy3) return false; p.y2 = (const bf16_t*)y2; p.ss2 = ss2; p.mr2 = mr2;
   p.gate = (const bf16_t*)gate; p.u1 = u1; p.We = (const bf16_t*)We; p.Wr = (const bf16_t*)Wr;
   p.dz2 = dz2; p.ds1 = ds1; p.du1 = du1; p.dpooled = (bf16_t*)dpooled; p.red = red;
   p.box_se = (se_box_t*)g_sebox.box; p.timeout_ticks = 200000000LL; p.err = device_error_word();

@@ -333,11 +333,26 @@ int satrn_mbconv_bwd_se(const void* dy3, const void* w_bwd, int ldb, void* dz3, 
   CHK_DT(DT_BF16);
   if (B < 1 || C < 64 || (C % 64) || !mailbox || mailbox_words < (long)B * (C / 64) * 64) return fail(-1, "mbconv_bwd_se: a mailbox of B * (C / 64) * 64 words is required");
   g_sebox.box = mailbox; g_sebox.images = B;
-  const bool okk = launch_mbconv_bwd_se(DT_BF16, dy3, w_bwd, ldb, dz3, bn2_y, coef2, coef2 + 2 * C, gate, u1, W2, W1, dz2, ds1, du1, dpooled, bn2_sums, B, H, W,
+  const bool okk = launch_mbconv_bwd_se(DT_BF16, dy3, nullptr, w_bwd, ldb, dz3, bn2_y, coef2, coef2 + 2 * C, gate, u1, W2, W1, dz2, ds1, du1, dpooled, bn2_sums, B, H, W,
                                         Cout, C, S, S(st));
   g_sebox.box = nullptr; g_sebox.images = 0;
   if (!okk) return fail(-1, "mbconv_bwd_se: shape not taken by the one-launch form (use satrn_linear_bwd_data + satrn_se_bwd_bnred)");
   return done("mbconv_bwd_se");
+}
+int satrn_mbconv_bwd_se_bn_in(const void* dz, const void* bn3_y, const float* coef3, const float* w3, const float* sums3, void* dy3_out, float* dw3, float* db3,
+                              const void* w_bwd, int ldb, void* dz3, const void* bn2_y, const float* coef2, const void* gate, const float* u1, const void* W1,
+                              const void* W2, float* dz2, float* ds1, float* du1, void* dpooled, float* bn2_sums, int B, int H, int W, int Cout, int C, int S,
+                              unsigned long long* mailbox, long mailbox_words, void* st) {
+  CHK_DT(DT_BF16);
+  if (B < 1 || C < 64 || (C % 64) || !mailbox || mailbox_words < (long)B * (C / 64) * 64) return fail(-1, "mbconv_bwd_se_bn_in: a mailbox of B * (C / 64) * 64 words is required");
+  if (!dz || !bn3_y || !coef3 || !w3 || !sums3 || !dy3_out) return fail(-1, "mbconv_bwd_se_bn_in: dz, bn3_y, bn3_coef, bn3_weight, bn3_sums and dy3_out are required");
+  g_sebox.box = mailbox; g_sebox.images = B;
+  MbDinArgs da{dz, bn3_y, coef3, coef3 + 2 * Cout, w3, sums3, 1, dy3_out, dw3, db3};
+  const bool okk = launch_mbconv_bwd_se(DT_BF16, nullptr, &da, w_bwd, ldb, dz3, bn2_y, coef2, coef2 + 2 * C, gate, u1, W2, W1, dz2, ds1, du1, dpooled, bn2_sums, B, H, W,
+                                        Cout, C, S, S(st));
+  g_sebox.box = nullptr; g_sebox.images = 0;
+  if (!okk) return fail(-1, "mbconv_bwd_se_bn_in: shape not taken by the one-launch form");
+  return done("mbconv_bwd_se_bn_in");
 }
 int satrn_batchnorm_act_dwconv3x3_fwd(int dt, const void* y, const float* w, const float* b, float* rm, float* rv, int64_t* nbt,
                                       float eps, int act, void* z, const void* dwp, const float* dwb, void* out, float* out_stats,

@@ -286,3 +286,68 @@ def test_mbconv_front_with_the_input_batchnorm_folded_in(lib, B, H, W, Cin, C, S
     for k in ("y1", "z1", "y2", "z3"):
         close(o[k], o_ref[k].float().cpu(), BF, f"folded input: {k}", bf16_tol=2e-2)
     close(o["gate"], o_ref["gate"].float().cpu(), BF, "folded input: gate", bf16_tol=1e-2)
+
+
+@pytest.mark.parametrize("B,H,W,Cout,C,S", [(32, 4, 12, 256, 1536, 64), (32, 8, 24, 160, 960, 40), (6, 8, 24, 128, 512, 32), (2, 4, 12, 256, 128, 8)])
+def test_mbconv_backward_with_the_closing_batchnorm_backward_folded_in(lib, B, H, W, Cout, C, S):
+    """satrn_mbconv_bwd_se_bn_in: dy3 = backward of the block-ending BatchNorm applied while the kernel stages it -- against
+    satrn_batchnorm_act_bwd_apply followed by satrn_mbconv_bwd_se on the dy3 that one wrote."""
+    bf, HW, M, eps = torch.bfloat16, H * W, B * H * W, 1e-3
+    y2 = q(rnd(M, C, seed=1) * 2 + 0.5, BF)
+    w, b = 1 + rnd(C, seed=3, scale=0.2), rnd(C, seed=4, scale=0.1)
+    W1, W2 = q(rnd(S, C, seed=12, scale=0.05), BF), q(rnd(C, S, seed=13, scale=0.2), BF)
+    b1, b2 = rnd(S, seed=14, scale=0.1), rnd(C, seed=15, scale=0.1)
+    Wp = q(rnd(Cout, C, seed=16, scale=C ** -0.5 * 2), BF)
+    y3 = q(rnd(M, Cout, seed=17) * 1.3 + 0.2, BF)
+    w3, b3 = 1 + rnd(Cout, seed=18, scale=0.2), rnd(Cout, seed=19, scale=0.1)
+    dz = q(rnd(M, Cout, seed=6), BF)
+    y2d, y3d, dzd = dev(y2, BF), dev(y3, BF), dev(dz, BF)
+    # forward state of bn2 / se (as in the test above) and of bn3
+    rmd, rvd, nbt = dev(torch.zeros(C)), dev(torch.ones(C)), torch.zeros(1, dtype=torch.int64, device="cuda")
+    scr2 = torch.zeros(6 * C, device="cuda")
+    z2d = torch.empty(M, C, dtype=bf, device="cuda")
+    ok(lib, lib.satrn_batchnorm_act_fwd(1, P(y2d), P(dev(w)), P(dev(b)), P(rmd), P(rvd), P(nbt), eps, 1, 2, None, P(z2d), M, C, P(scr2), st()))
+    W1d, W2d = dev(W1, BF), dev(W2, BF)
+    pooled_d, u1_d, s1_d = (torch.zeros(B, n, device="cuda") for n in (C, S, S))
+    gate_d = torch.zeros(B, C, dtype=bf, device="cuda")
+    z3d = torch.zeros(B, HW, C, dtype=bf, device="cuda")
+    ok(lib, lib.satrn_se_fwd(1, P(z2d), P(W1d), P(dev(b1)), P(W2d), P(dev(b2)), None, P(pooled_d), P(u1_d), P(s1_d), P(gate_d), P(z3d), B, HW, C, S, st()))
+    rm3, rv3 = dev(torch.zeros(Cout)), dev(torch.ones(Cout))
+    scr3 = torch.zeros(6 * Cout, device="cuda")
+    outd = torch.empty(M, Cout, dtype=bf, device="cuda")
+    ok(lib, lib.satrn_batchnorm_act_fwd(1, P(y3d), P(dev(w3)), P(dev(b3)), P(rm3), P(rv3), P(nbt), eps, 1, 0, None, P(outd), M, Cout, P(scr3), st()))
+    # bn3's backward sums from torch (sum dz, sum dz * xhat)
+    mu, rs = scr3[4 * Cout:5 * Cout].cpu(), scr3[5 * Cout:6 * Cout].cpu()
+    xh = (y3 - mu) * rs
+    sums3 = dev(torch.cat([dz.sum(0), (dz * xh).sum(0)]))
+    _, Wbd, ldb = pack_dense(lib, Wp, BF)
+    # reference route: apply pass, then the one-launch backward on its output
+    dy3_a = torch.zeros(M, Cout, dtype=bf, device="cuda")
+    dw_a, db_a = torch.zeros(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+    ok(lib, lib.satrn_batchnorm_act_bwd_apply(1, P(dzd), P(y3d), P(dev(w3)), P(scr3), 0, P(dy3_a), P(dw_a), P(db_a), M, Cout, P(sums3), st()))
+    box = torch.zeros(B * (C // 64) * 64, dtype=torch.int64, device="cuda")
+
+    def outs():
+        return dict(dz3=torch.zeros(M, C, dtype=bf, device="cuda"), dz2=torch.zeros(B, C, device="cuda"), ds1=torch.zeros(B, S, device="cuda"),
+                    du1=torch.zeros(B, S, device="cuda"), dpool=torch.zeros(B, C, dtype=bf, device="cuda"), red=torch.zeros(2 * C, device="cuda"))
+    a = outs()
+    rc = lib.satrn_mbconv_bwd_se(P(dy3_a), P(Wbd), ldb, P(a["dz3"]), P(y2d), P(scr2[2 * C:]), P(gate_d), P(u1_d), P(W1d), P(W2d), P(a["dz2"]), P(a["ds1"]), P(a["du1"]),
+                                 P(a["dpool"]), P(a["red"]), B, H, W, Cout, C, S, P(box), box.numel(), st())
+    assert rc == 0, lib.satrn_last_error().decode()
+    f = outs()
+    dy3_f = torch.zeros(M, Cout, dtype=bf, device="cuda")
+    dw_f, db_f = torch.zeros(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+    rc = lib.satrn_mbconv_bwd_se_bn_in(P(dzd), P(y3d), P(scr3[2 * Cout:]), P(dev(w3)), P(sums3), P(dy3_f), P(dw_f), P(db_f), P(Wbd), ldb, P(f["dz3"]), P(y2d),
+                                       P(scr2[2 * C:]), P(gate_d), P(u1_d), P(W1d), P(W2d), P(f["dz2"]), P(f["ds1"]), P(f["du1"]), P(f["dpool"]), P(f["red"]),
+                                       B, H, W, Cout, C, S, P(box), box.numel(), st())
+    assert rc == 0, lib.satrn_last_error().decode()
+    torch.cuda.synchronize()
+    assert lib.satrn_device_error(st()) == 0
+    same = (dy3_f == dy3_a).float().mean().item()
+    print(f"[bwd with folded BatchNorm backward] dy3 identical to batchnorm_act_bwd_apply's {same:.6f}")
+    assert same > 0.999
+    close(dy3_f, dy3_a.float().cpu(), BF, "folded dy3", bf16_tol=1e-2)
+    close(dw_f, dw_a.cpu(), "f32", "bn3 dweight", f32_tol=1e-5)
+    close(db_f, db_a.cpu(), "f32", "bn3 dbias", f32_tol=1e-5)
+    for k in ("dz3", "dz2", "ds1", "du1", "dpool", "red"):
+        close(f[k], a[k].float().cpu(), BF, f"folded: {k}", bf16_tol=1e-2)
