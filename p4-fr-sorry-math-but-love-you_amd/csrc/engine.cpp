@@ -961,7 +961,9 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** poo
         BnBwdHold& h = y->bhold;
         h.armed = true; h.dz = z->g; h.y = y->p; h.ss = ss; h.mr = mr; h.w = bn->w.p; h.red = red; h.M = M; h.C = C; h.act = act; h.dy = dy;
         h.dwp = bn->w.g; h.dbp = bn->b.g; h.se_gate = z->se_gate; h.se_dpool = z->se_dpool; h.se_hw = z->se_hw;
-      } else if (y->bn_bwd_hold_ok && !eval_stats && act == ACT_NONE && !z->se_gate && !e.dry && e.dt == DT_BF16 && getenv("SATRN_NO_MBCONV_DFOLD") == nullptr) {
+      } else if (y->bn_bwd_hold_ok && !eval_stats && act == ACT_NONE && !z->se_gate && !e.dry && e.dt == DT_BF16 && getenv("SATRN_MBCONV_DFOLD") != nullptr) {
+        // (OFF by default, SATRN_MBCONV_DFOLD=1 switches it on: measured flat -- 8.72 vs 8.70-8.72 ms per step, same box -- the 24 / 15 workgroups of an
+        // image each repeat the image's pass: the block launch grows by 5-9 us where the 5 us launch disappears)
         // y is an MBConv block's projection output: its closure (next) and the squeeze-and-excite closure behind it run this pass inside the
         // block's backward launch (launch_mbconv_bwd_se with MbDinArgs), or launch it themselves
         BnBwdHold& h = y->bhold;
