@@ -484,7 +484,8 @@ def main():
                                                         note="latency-bound, not HBM-bound: a token is a dependent chain of 13 role hops per step (3 layers x [Q/K/V, self-attention + out-projection, LayerNorm + cross-attention, LayerNorm + feed-forward] + generator), and at batch 64 the 244 role workgroups are ~80 % busy; the weights never leave LDS, so the 38 MB/step figure is what a weight-streaming decoder would move, kept as the algorithmic unit of SURVEY 8d")
                 # the per-image kernel of round 1 (one workgroup per image streams every weight each step), kept as the
                 # fallback for shapes the pipeline does not take; timed beside it
-                os.environ["SATRN_DECODE_NO_PIPE"] = "1"
+                from satrn_amd import switches as sw
+                sw.off("decode_pipe")
                 try:
                     model.greedy(dimg, 231)
                     torch.cuda.synchronize()
@@ -494,7 +495,7 @@ def main():
                     out["greedy_decode"]["per_image_kernel"] = dict(ms_per_batch=round((time.perf_counter() - t1) * 1e3, 2), decoder_path=model.last_decode_path()[0],
                                                                     note="round-1 decoder (fallback path), same batch")
                 finally:
-                    os.environ.pop("SATRN_DECODE_NO_PIPE", None)
+                    sw.on("decode_pipe")
                 # the same decode with the DecodingManager rules evaluated inside the decode kernel (the reference's default
                 # at inference, inference.py:48); rule table = the reference RULES as compiled into tests/golden/rules.npz
                 rules_npz = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "rules.npz")

@@ -4,6 +4,7 @@ from . import _lib
 from ._lib import SatrnError
 from .networks import EfficientSATRN, LiteSATRN, SWIN, EfficientSATRN_encoder, EfficientSATRN_decoder, SATRNCrossEntropy, loss_fn_kd
 from . import decoding
+from . import switches
 from . import metrics
 from .metrics import StepMetrics
 from .decoding import DeviceDecodingManager, compile_rules, decode

@@ -33,7 +33,7 @@ void Exec::prof_begin(const char* call) {
   std::string nm = p ? p : call;
   size_t q = nm.find('(');
   if (q != std::string::npos) nm = nm.substr(0, q);
-  static const bool shapes = getenv("SATRN_PROF_SHAPES") != nullptr;  // split families by problem size
+  static const bool shapes = sw_prof("shapes");  // split families by problem size
   if (shapes) { char b[64]; snprintf(b, sizeof(b), " B%.0f F%.0f", nbytes, nflops); nm += b; }
   r.name = nm; r.flops = nflops; r.bytes = nbytes;
   (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
@@ -56,10 +56,7 @@ void Exec::defer(std::function<void(hipStream_t)> fn) {
   // timing experiment only (the chain alone; WRONG gradients): announced loudly, once, so that a stray variable cannot give a
   // silently non-training model
   static const bool skip = [] {
-    const bool on = getenv("SATRN_TIMING_SKIP_WGRAD") != nullptr;
-    if (on) fprintf(stderr, "[satrn] WARNING: SATRN_TIMING_SKIP_WGRAD is set -- weight / bias gradients are NOT computed; this process measures the "
-                            "data-gradient chain only and must not be used for training\n");
-    return on;
+    return sw_timing("skip_wgrad") != 0;   // (weight / bias gradients are NOT computed: the data-gradient chain alone; never for training)
   }();
   if (skip && !dry) return;
   if (!s2 || dry) { fn(s); return; }
@@ -68,8 +65,8 @@ void Exec::defer(std::function<void(hipStream_t)> fn) {
   // never -> 14.6 ms/step): every hand-over costs the chain 11-15 us (tools/micro/fork_cost.hip: an event record on the
   // chain's queue + a wait on the side queue; the record alone is 2 us).  Larger batches early in the backward and small
   // ones near the join were tried as well (32 / 8): no change -- what the fewer forks save, the later start of the side work costs
-  static const int thr = getenv("SATRN_FLUSH") ? atoi(getenv("SATRN_FLUSH")) : 8;
-  if ((int)pending.size() >= thr && !hold_side) flush_side();
+  static const int thr = (int)sw_knob("flush", 8);
+  if ((int)pending.size() >= thr) flush_side();
 }
 void Exec::flush_side() {
   if (pending.empty()) return;
@@ -87,7 +84,7 @@ void Exec::join() {
   flush_side();
   if (!s2 || dry || !forked) return;
   if (!evj) (void)hipEventCreateWithFlags(&evj, hipEventDisableTiming);
-  static const bool jprof = getenv("SATRN_JOIN_PROF") != nullptr;  // how long the main chain waits for the side stream
+  static const bool jprof = sw_prof("join");  // how long the main chain waits for the side stream
   static hipEvent_t ja = nullptr, jb = nullptr;
   if (jprof) {
     if (!ja) { (void)hipEventCreate(&ja); (void)hipEventCreate(&jb); }
@@ -100,14 +97,14 @@ void Exec::join() {
   forked = false;
 }
 
-static const bool g_stage_prof = getenv("SATRN_STAGE_PROF") != nullptr;
+static const bool g_stage_prof = sw_prof("stage");
 // replicas of a GEMM epilogue's column-sum target (BatchNorm statistics / BatchNorm-backward sums): tall products with few columns put
 // thousands of same-address float atomics on 2 x C words; the row tiles spread them over `rep` copies which the consumer adds.
 // SATRN_STATS_REP_SCALE (knob, read once) multiplies the replica count of the shapes that have replicas (tools/ab_bench.sh).
 static int stats_rep_for(int C, long rows) {
   if (g_det.on) return 1;
   const int base = (C <= 64 && rows >= 65536) ? 16 : ((C <= 256 && rows >= 16384) ? 4 : 1);
-  static const int sc = getenv("SATRN_STATS_REP_SCALE") ? atoi(getenv("SATRN_STATS_REP_SCALE")) : 1;   // n: times n; -n: divided by n
+  static const int sc = (int)sw_knob("stats_rep_scale", 1);   // n: times n; -n: divided by n
   if (base == 1 || sc == 0 || sc == 1) return base;
   return sc > 0 ? std::min(base * sc, 64) : std::max(base / -sc, 1);
 }
@@ -518,7 +515,7 @@ Model* model_create(const SatrnConfig& cfg) {
   m->persist_bytes = (o + 255) & ~(size_t)255;
   m->ex = new Exec();
   m->ex->m = m;
-  if (!getenv("SATRN_NO_SIDE_STREAM")) {
+  if (!sw_off("side_stream")) {
     // optimizer-only work (weight gradients) runs on a LOW-priority stream: whenever both queues have a kernel ready, the
     // data-gradient chain (the critical path) is dispatched first
     int lo = 0, hi = 0;
@@ -788,7 +785,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
       memset(&q, 0, sizeof(q));
       q.dY = dY; q.A = x->p; q.dW = w->g; q.M = (int)M; q.N = N; q.K = w->K; q.ldy = ldy; q.lda = x->C;
       q.nbatch = 1; q.nb_inner = 1;
-      q.full_grid = (e.serial || !e.s2 || e.prof || e.tail_full) ? 1 : 0;
+      q.full_grid = (e.serial || !e.s2 || e.prof) ? 1 : 0;
       float* tmp = nullptr;
       if (hasgeo) {
         q.conv = 1; q.H = g.H; q.W = g.W; q.Ci = g.Ci; q.OH = g.OH; q.OW = g.OW; q.KW = g.KW; q.stride = g.stride; q.pt = g.pt; q.pl = g.pl;
@@ -801,7 +798,7 @@ Tensor* op_gemm(Exec& e, Tensor* x, Wt* w, Vec* bias, int act, float drop_p, con
         float* bg = bias ? bias->g : nullptr; float* wg = w->g; const int Ci = g.Ci;
         // dense products: the weight-gradient kernel sums the bias gradient from the dY chunks it stages anyway (not in the deterministic mode,
         // whose fixed-order column sums stay a pass of their own)
-        const bool fold_db = getenv("SATRN_NO_WGRAD_BIAS") == nullptr;   // read per call (A/B in one process)
+        const bool fold_db = !sw_off("wgrad_bias");   // read per call (A/B in one process)
         if (bg && fold_db && !hasgeo && !g_det.on) { q.dbias = bg; bg = nullptr; }
         if (e.prof || dry) {
           WORK(e, 0, (double)M * N * e.esz());
@@ -961,8 +958,8 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** poo
         BnBwdHold& h = y->bhold;
         h.armed = true; h.dz = z->g; h.y = y->p; h.ss = ss; h.mr = mr; h.w = bn->w.p; h.red = red; h.M = M; h.C = C; h.act = act; h.dy = dy;
         h.dwp = bn->w.g; h.dbp = bn->b.g; h.se_gate = z->se_gate; h.se_dpool = z->se_dpool; h.se_hw = z->se_hw;
-      } else if (y->bn_bwd_hold_ok && !eval_stats && act == ACT_NONE && !z->se_gate && !e.dry && e.dt == DT_BF16 && getenv("SATRN_MBCONV_DFOLD") != nullptr) {
-        // (OFF by default, SATRN_MBCONV_DFOLD=1 switches it on: measured flat -- 8.72 vs 8.70-8.72 ms per step, same box -- the 24 / 15 workgroups of an
+      } else if (y->bn_bwd_hold_ok && !eval_stats && act == ACT_NONE && !z->se_gate && !e.dry && e.dt == DT_BF16 && sw_knob("mbconv_dfold", 0) != 0) {
+        // (OFF by default, SATRN_KNOBS=mbconv_dfold=1 switches it on: measured flat -- 8.72 vs 8.70-8.72 ms per step, same box -- the 24 / 15 workgroups of an
         // image each repeat the image's pass: the block launch grows by 5-9 us where the 5 us launch disappears)
         // y is an MBConv block's projection output: its closure (next) and the squeeze-and-excite closure behind it run this pass inside the
         // block's backward launch (launch_mbconv_bwd_se with MbDinArgs), or launch it themselves
@@ -1006,7 +1003,7 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
   const int B = x->B, H = x->H, W = x->W, C = x->C;
   Tensor* y = e.newt((long)B * OH * OW, C, B, OH, OW);
   if (want_stats && e.train) y->stats = e.zalloc(2 * C);
-  const bool hold_bwd = getenv("SATRN_NO_FUSED_BN_APPLY_DW") == nullptr;   // read per call: tests toggle it in one process
+  const bool hold_bwd = !sw_off("bn_apply_dw");   // read per call: tests toggle it in one process
   y->dw_bwd_fuse = hold_bwd && e.rec && e.train && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && dwconv_img_ok(e.dt, H, W, C);
   if (want_stats && !e.train && !e.rec && g_fuse_bn_eval) {
     // inference: the BatchNorm that follows runs in this kernel's epilogue (launched by op_bn_act)
@@ -1520,8 +1517,8 @@ Tensor* swin_block(Exec& e, Tensor* x, SwinBlock* sb, int B, SwinPend* pend, boo
   // shift + window partition ride on the LayerNorm in front of the attention (it writes window order) and on the residual add behind
   // it (it reads window order): no permutation passes (SATRN_SWIN_PERM_PASS=1 keeps the four separate ones, for tests)
   RowMap wmap;
-  const bool perm_pass = getenv("SATRN_SWIN_PERM_PASS") != nullptr;   // read per call
-  const bool fuse_add = getenv("SATRN_SWIN_NO_ADD_LN") == nullptr;
+  const bool perm_pass = sw_off("swin_rowmap");   // read per call
+  const bool fuse_add = !sw_off("swin_add_ln");
   if ((nW > 1 || sb->shift) && !perm_pass) { wmap.H = R; wmap.W = R; wmap.ws = sb->ws; wmap.shift = sb->shift; }
   Tensor* y;
   if (pend->o) {
@@ -1549,7 +1546,7 @@ Tensor* swin_block(Exec& e, Tensor* x, SwinBlock* sb, int B, SwinPend* pend, boo
     y2 = op_ln(e, x1, nullptr, &sb->n2);
   }
   Tensor* g;
-  if (getenv("SATRN_SWIN_GELU_PASS") == nullptr) {   // read per call (tests compare both forms in one process)
+  if (!sw_off("swin_gelu_epilogue")) {   // read per call (tests compare both forms in one process)
     g = op_gemm(e, y2, &sb->fc1, &sb->b1, ACT_GELU, 0.f, nullptr);   // GELU in the product's epilogue, its derivative kept beside it
   } else {
     Tensor* h = op_gemm(e, y2, &sb->fc1, &sb->b1, ACT_NONE, 0.f, nullptr);
@@ -1704,7 +1701,7 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr, SeHold
     // the wide squeeze-and-excite backward with the folded BatchNorm sums applies (the closure below decides the same way).
     BNp* bn = sh->bn;
     const bool bwd_recomputes = g_fuse_bnb && e.dt == DT_BF16 && !g_det.on && S <= 64 && (S % 8) == 0 && (C % 8) == 0 && ((C / 8 + 7) / 8) <= 24 &&
-                                getenv("SATRN_SE_NO_WIDE_BWD") == nullptr && getenv("SATRN_SE_NO_BN_SUMS") == nullptr;
+                                !sw_off("se_wide_bwd") && !sw_off("se_bn_sums");
     const bool need_x = e.rec && !(e.train && bwd_recomputes);
     e.last_se.need_x = need_x;
     // (not under hipGraph capture: the per-launch mailbox tag would be replayed)
@@ -1765,7 +1762,7 @@ Tensor* op_se(Exec& e, Tensor* x, EffBlock* eb, float* poolsum = nullptr, SeHold
       // tensor se_bwd_x would write is never materialised -- and (round 2) that BatchNorm's backward column sums come out of the
       // two SE kernels as well
       const bool folds = fold && x->bn_y && !x->bn_has_res && x->ncons == 1 && !x->g;
-      const bool bnred = folds && g_fuse_bnb && !x->bn_red && getenv("SATRN_SE_NO_BN_SUMS") == nullptr;   // read per call (tests)
+      const bool bnred = folds && g_fuse_bnb && !x->bn_red && !sw_off("se_bn_sums");   // read per call (tests)
       float* bnP = bnred ? (float*)e.alloc((size_t)4 * B * C * 4) : nullptr;
       float* bnR = bnred ? e.zalloc((size_t)2 * C) : nullptr;
       if (held && bnred && x->bn_act == ACT_SILU && !e.dry) {
@@ -1940,26 +1937,17 @@ Tensor* encoder_forward(Exec& e, const float* img, int B) {
     x = op_bn_act(e, x, &m->stem_bn, ACT_SILU, nullptr);
     stage_mark("stem");
     probe(e, "stem", x);
-    // experiment (SATRN_HOLD_SIDE_LATE=<first stage index>): weight gradients of the MBConv stages from that block on are queued during
-    // their backward and released when the backward leaves them
-    const int hold_from = getenv("SATRN_HOLD_SIDE_LATE") ? atoi(getenv("SATRN_HOLD_SIDE_LATE")) : -1;
-    // the weight gradients of blocks 0 .. tail_from are the LAST work the side stream receives (the backward reaches them last) and the chain
-    // joins it right after: they get chip-filling grids instead of the small ones that keep out of the chain's way (knob: SATRN_TAIL_FULL_FROM, -1 = off)
-    const int tail_from = getenv("SATRN_TAIL_FULL_FROM") ? atoi(getenv("SATRN_TAIL_FULL_FROM")) : -1;
     for (size_t bi = 0; bi < m->blocks.size(); ++bi) {
       if ((int)bi == m->late_block) m->seg_mark[0] = e.tape.size();
-      if (hold_from >= 0 && (int)bi == hold_from && e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->hold_side = false; ep->flush_side(); }); }
       // this block's closing BatchNorm (+ residual) rides in the next block's launch when that one is a one-launch MBConv front
       bool hold_out = false;
-      if (bi + 1 < m->blocks.size() && e.train && !e.dry && getenv("SATRN_NO_MBCONV_XFOLD") == nullptr) {
+      if (bi + 1 < m->blocks.size() && e.train && !e.dry && !sw_off("mbconv_xfold")) {
         const EffBlock& cbk = m->blocks[bi]; const EffBlock& nb = m->blocks[bi + 1];
         Geo og;
         same_geo(x->H, x->W, cbk.cin, cbk.stride, &og);
         hold_out = cbk.type == 2 && nb.type == 2 && nb.stride == 1 && nb.cin == cbk.cout && mbconv_front_ok(e.dt, B, og.OH, og.OW, nb.cin, nb.c0.N, nb.se, e.s);
       }
       x = eff_block(e, x, &m->blocks[bi], hold_out);
-      if ((int)bi == tail_from && e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->tail_full = true; }); }
-      if (hold_from >= 0 && bi + 1 == m->blocks.size() && e.rec) { Exec* ep = &e; e.tape.push_back([ep]() { ep->flush_side(); ep->hold_side = true; }); }
       if (bi + 1 == m->blocks.size() || m->blocks[bi + 1].cout != m->blocks[bi].cout) {
         stage_mark("cout" + std::to_string(m->blocks[bi].cout));
         probe(e, "backbone_c" + std::to_string(m->blocks[bi].cout), x);
@@ -2146,7 +2134,7 @@ static void det_activate(Model* m) {
   const bool mbox = wp && m->off_sebox && !(m->ex && m->ex->serial);
   g_sebox.box = mbox ? (unsigned long long*)(m->ws + m->off_sebox) : nullptr;
   g_sebox.images = mbox ? Model::SEBOX_IMAGES : 0;
-  g_sebox.bwd = mbox && getenv("SATRN_SE_BWD_ONE_LAUNCH") != nullptr;   // (measured slower inside the step: off by default)
+  g_sebox.bwd = mbox && sw_knob("se_bwd_one_launch", 0) != 0;   // (measured slower inside the step: off by default)
   g_mbbox.box = (mbox && m->off_mbbox) ? (unsigned long long*)(m->ws + m->off_mbbox) : nullptr;
   g_mbbox.words = g_mbbox.box ? Model::MBBOX_WORDS : 0;
   g_mbbox.images = g_mbbox.box ? Model::MBBOX_IMAGES : 0;
@@ -2157,7 +2145,7 @@ static void exec_begin(Model* m, hipStream_t s, bool train, bool rec, bool dry) 
   det_activate(m);
   e.s = s; e.dt = m->cfg.dtype; e.train = train; e.rec = rec; e.dry = dry;
   e.drop = train ? m->cfg.dropout : 0.f;
-  e.probes.clear(); e.probe_on = m->probe_on; e.hold_side = false; e.tail_full = false; e.xhold.armed = false;
+  e.probes.clear(); e.probe_on = m->probe_on; e.xhold.armed = false;
   if (!e.dry && e.zbase && e.zoff > m->zero_hwm) m->zero_hwm = e.zoff;  // what the previous call dirtied at most
   e.reset(m->ws + m->persist_bytes, m->ws_bytes > m->persist_bytes ? m->ws_bytes - m->persist_bytes : 0,
           m->ws + m->off_zero, m->zero_bytes);
@@ -2376,7 +2364,7 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
     hd[7] = 1.0f - powf(hd[2], (float)m->adam_t);
     (void)hipMemcpyAsync(scal(m) + SC_HYPER2, hd, 9 * sizeof(float), hipMemcpyHostToDevice, s);
   }
-  static const bool host_prof = getenv("SATRN_HOST_PROF") != nullptr;  // host time spent ISSUING the forward / backward / optimizer
+  static const bool host_prof = sw_prof("host");  // host time spent ISSUING the forward / backward / optimizer
   auto hnow = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto body = [&]() -> int {
     const double h0 = host_prof ? hnow() : 0.0;
@@ -2614,7 +2602,7 @@ static int greedy_body(Model* m, const float* img, const float* src_in, int B, i
   int64_t* sos = (int64_t*)e.alloc((size_t)B * 8);
   launch_fill_i64(sos, c.sos_id, B, s);
   // ---- fast path: the persistent one-launch decoders
-  if (!getenv("SATRN_DECODE_STEPWISE") && L <= 4) {
+  if (!sw_off("decode_kernel") && L <= 4) {
     DecodeP dp;
     fill_decode_params(m, dp, crossKV, cache, B, steps, Nsrc, s);
     dp.logits = logits_out; dp.ids = ids_out; dp.rules = rules; dp.forced = forced; dp.ld_forced = steps;

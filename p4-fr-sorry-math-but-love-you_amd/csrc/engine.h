@@ -205,8 +205,7 @@ struct Exec {
   hipStream_t s2 = nullptr; std::vector<hipEvent_t> evs; hipEvent_t evj = nullptr; int nfork = 0; bool forked = false;
   hipStream_t side(); void join();
   std::vector<std::function<void(hipStream_t)>> pending; void defer(std::function<void(hipStream_t)> fn); void flush_side();
-  bool tail_full = false;   // the backward has reached the first backbone stages: what the side stream still receives decides when the step ends -> chip-filling grids
-  bool hold_side = false;   // weight-gradient launches are queued but not handed to the side stream (while kernels whose workgroups wait for each other run on the chain)
+
 
   // SATRN_STAGE_PROF=1: events on the main stream at stage boundaries of an ordinary eager step (forward and, through tape
   // closures, backward) -> per-stage wall time of the critical chain, printed by the next step

@@ -48,8 +48,22 @@ extern long long g_route[RT_COUNT];
 unsigned* device_error_word();   // device address of the error word (bit 2: a mailbox wait timed out)
 void launch_fold4(const float* part, int nrep, long stride, long n, float* out, hipStream_t s);   // launch_fold with 16-byte accesses (n, stride % 4 == 0)
 void det_overflow_warn(size_t need_floats);
-// value of a timing-experiment switch (results are WRONG when it is set): read once, announced once on stderr
-int timing_switch(const char* name);
+// ---- run-time switches: FOUR environment variables (round 4; the library used to read ~70 SATRN_* names) -------------------------------
+//   SATRN_OFF    = comma-separated features whose current form is switched OFF, i.e. the form it replaced runs (A/B levers of tests and
+//                  tools; read per call unless noted), e.g. SATRN_OFF=mbconv_front,gemm_g2
+//   SATRN_KNOBS  = name=value,...  tuning knobs, opt-in forms and the tri-state routes (gemm_big / wgrad_big / conv_big / gemm_tall = 0 off,
+//                  1 by size, 2 every shape that fits)
+//   SATRN_PROF   = comma-separated diagnostics: stage, host, join, shapes, pipe, dec, mb
+//   SATRN_TIMING = name[=value],...  timing experiments that SKIP work (results are WRONG; announced once on stderr): skip_wgrad,
+//                  no_stats_atomics, big_dbg, a2_dbg, ea_dbg
+// (modes keep their own names: SATRN_DETERMINISTIC, SATRN_NONDET, SATRN_PIPE_STRICT)
+bool sw_off(const char* name);
+bool sw_knob_set(const char* name);
+long sw_knob(const char* name, long dflt);
+double sw_knobf(const char* name, double dflt);
+const char* sw_knob_str(const char* name);   // pointer to the value inside the environment string (ends at ',' / ' ' / 0), or null
+bool sw_prof(const char* name);
+int sw_timing(const char* name);   // 0 = not set; value (1 if none given) otherwise
 static inline float* det_scratch(hipStream_t s, size_t need_floats) {
   if (!g_det.on) return nullptr;
   if (need_floats > g_det.cap) { det_overflow_warn(need_floats); return nullptr; }

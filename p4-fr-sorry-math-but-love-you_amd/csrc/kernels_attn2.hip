@@ -757,7 +757,7 @@ static size_t a2_rel_bytes(const AttnP& p) {
 }
 
 bool attn2_ok(int dt, const AttnP& p) {
-  const bool off = getenv("SATRN_NO_ATTN2") != nullptr;   // read per call: tests compare the two kernels in one process
+  const bool off = sw_off("attn2");   // read per call: tests compare the two kernels in one process
   if (off || dt != DT_BF16 || (p.hd != 32 && p.hd != 64) || p.Lq < 1 || p.Lq > 144 || p.Lk < 1 || p.Lk > 160) return false;
   if (p.bias || p.wmask) return false;                                  // the tensor forms of the window bias stay with attn_kernel
   if ((p.ldq & 7) || (p.ldk & 7) || (p.ldv & 7) || (p.ldo & 3)) return false;
@@ -772,7 +772,7 @@ bool launch_attn2_fwd(const AttnP& p, hipStream_t s) {
   const dim3 grid(p.H, p.B), block(nw * 64);
   // (head_dim 32 only: every SwinTRN geometry of the reference and of the tests has embed_dim / heads = 32; 64 takes the general kernel)
   const bool win = p.hd == 32 && p.rel_table && !p.text && !p.causal && p.drop_p == 0.f && p.rel_ws * p.rel_ws <= 160 && p.Lq == p.Lk &&
-                   (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 8 < 65536 && nw * 64 == 576 && getenv("SATRN_NO_ATTN2_WIN") == nullptr;
+                   (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 8 < 65536 && nw * 64 == 576 && !sw_off("attn2_win");
   if (win) {
     const size_t shw = (size_t)2 * LkP * p.hd * 2 + 160 * 4 + (size_t)2 * (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 4 + 16;
     hipLaunchKernelGGL((attn2_fwd_win_kernel<32>), grid, block, shw, s, p);
@@ -791,11 +791,11 @@ bool launch_attn2_bwd(const AttnP& p, hipStream_t s) {
   if (p.rel_table) sh += (((size_t)(2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 8 + 640 + (size_t)p.Lq + 15) & ~(size_t)15);
   const dim3 grid(p.H, p.B), block(nw * 64);
   AttnP pp = p;
-  static const int a2_dbg = timing_switch("SATRN_A2_DBG");
+  static const int a2_dbg = sw_timing("a2_dbg");
   pp.dbg = a2_dbg;   // timing experiments (wrong results): 1 no histogram, 2 no phase A, 4 no phase B, 8 no delta / lse, 16 no relative-position tables, 32 no staging
   // window form: relative-position table, no pad / causal mask, no dropout, gradients written (not accumulated), table gradient through dS
   const bool win = p.hd == 32 && p.rel_table && !p.text && !p.causal && p.drop_p == 0.f && !p.kv_accum && !p.drel && p.rel_ws * p.rel_ws <= 160 && p.Lq == p.Lk &&
-                   (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 8 < 65536 && nw * 64 == 576 && getenv("SATRN_NO_ATTN2_WIN") == nullptr;
+                   (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 8 < 65536 && nw * 64 == 576 && !sw_off("attn2_win");
   if (win) {
     const size_t shw = (size_t)(2 * LkP + 2 * LqP) * p.hd * 2 + (size_t)4 * 160 * 4 + (size_t)2 * (2 * p.rel_ws - 1) * (2 * p.rel_ws - 1) * 4 + 16;
     static bool a = false;

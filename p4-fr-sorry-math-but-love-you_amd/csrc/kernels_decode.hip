@@ -940,18 +940,18 @@ static int pipe_cu_budget() {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
     cus = n;
   }
-  const int margin = getenv("SATRN_PIPE_CU_MARGIN") ? atoi(getenv("SATRN_PIPE_CU_MARGIN")) : 6;
+  const int margin = (int)sw_knob("pipe_cu_margin", 6);
   return cus - margin;
 }
 int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_bytes, hipStream_t s) {
-  const bool off = getenv("SATRN_DECODE_NO_PIPE") != nullptr;  // read per call: tests switch between the two decoders in one process
+  const bool off = sw_off("decode_pipe");  // read per call: tests switch between the two decoders in one process
   g_pipe_reason = "";
-  if (off) { g_pipe_reason = "SATRN_DECODE_NO_PIPE is set"; return -1; }
+  if (off) { g_pipe_reason = "switched off (SATRN_OFF=decode_pipe)"; return -1; }
   if (g_pipe_disabled[0]) { g_pipe_reason = g_pipe_disabled; return -1; }
-  const int max_b = getenv("SATRN_PIPE_MAX_B") ? atoi(getenv("SATRN_PIPE_MAX_B")) : 112;   // larger batches: the per-image kernel (1 workgroup per image, no hand-offs) wins
+  const int max_b = (int)sw_knob("pipe_max_b", 112);   // larger batches: the per-image kernel (1 workgroup per image, no hand-offs) wins
   if (dt != DT_BF16 || d.D != 256 || d.F != 1024 || d.H * (d.D / d.H) != d.D || (d.D / d.H) % 8 || (d.H & 1) || d.V > 256 || d.B > max_b || d.nlayers < 1 || d.nlayers > 4 ||
       d.B < 1 || scratch_bytes < decode_pipe_scratch_bytes(d)) {
-    g_pipe_reason = "shape outside the pipeline (bf16, D = 256, F = 1024, even heads, V <= 256, B <= SATRN_PIPE_MAX_B)";
+    g_pipe_reason = "shape outside the pipeline (bf16, D = 256, F = 1024, even heads, V <= 256, B <= pipe_max_b)";
     return -1;
   }
   const int cu_budget = pipe_cu_budget();
@@ -970,13 +970,13 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
   const int D = d.D, F = d.F, B = d.B;
   // every role is sharded over images: a shard is one workgroup (one compute unit) serving a contiguous range of the batch.
   // Attention roles do the most work per item (two passes over the image's KV history), matrix-vector roles the least.
-  auto knob = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+  auto knob = [](const char* name, int dflt) { return (int)sw_knob(name, dflt); };
   // shards sized from the measured service times per item (SATRN_PIPE_PROF: matrix-vector 2.3 us, +LayerNorm 3.8, cross-attention
   // 5.5, self-attention 8.6 at 231 steps) so that no role is busy for more than ~60 us of a step at batch 64
-  int SA = knob("SATRN_PIPE_ATT_SHARDS", 8), SX = knob("SATRN_PIPE_XATT_SHARDS", 6), SM = knob("SATRN_PIPE_MV_SHARDS", 4);
+  int SA = knob("pipe_att_shards", 8), SX = knob("pipe_xatt_shards", 6), SM = knob("pipe_mv_shards", 4);
   // SQ: q / k(in) / v(in) projections (on every image's path, with the LayerNorm recompute); SH: the history projections and the
   // combine role (off the path: throughput only); SM: feed-forward slabs; ST: the two LayerNorm publishers (off the path)
-  int SQ = knob("SATRN_PIPE_QKV_SHARDS", 4), SH = knob("SATRN_PIPE_HIST_SHARDS", 2), ST = knob("SATRN_PIPE_LN_SHARDS", 2), SG = knob("SATRN_PIPE_GEN_SHARDS", d.rules ? 6 : 4);
+  int SQ = knob("pipe_qkv_shards", 4), SH = knob("pipe_hist_shards", 2), ST = knob("pipe_ln_shards", 2), SG = knob("pipe_gen_shards", d.rules ? 6 : 4);
   {  // one workgroup per compute unit: scale the shard counts down until the role count fits the chip
     auto count = [&]() { return d.nlayers * (3 * SQ + 3 * SH + 2 * SA + 2 * ST + 2 * SX + PIPE_NFF * SM) + SG; };
     while (count() > cu_budget && (SA > 1 || SX > 1 || SM > 1 || ST > 1 || SQ > 1 || SH > 1)) {
@@ -1076,7 +1076,7 @@ int launch_decode_pipe(int dt, const DecodeP& d, void* scratch, size_t scratch_b
     }
   }
   p.forced = d.forced; p.ld_forced = d.ld_forced;
-  static const bool want_prof = getenv("SATRN_PIPE_PROF") != nullptr;  // debugging aid: per-role wait / total wall-clock ticks
+  static const bool want_prof = sw_prof("pipe");  // debugging aid: per-role wait / total wall-clock ticks
   static long long* prof_buf = nullptr;
   if (want_prof) {
     if (!prof_buf) (void)hipMalloc((void**)&prof_buf, 2048 * sizeof(long long));
@@ -1143,7 +1143,7 @@ int launch_decode_greedy(int dt, const DecodeP& p0, hipStream_t s) {
     const int ch = dt == DT_BF16 ? 8 : 4, cpr = p.D / ch;
     if ((p.D / p.H) % ch || cpr > 64 || (cpr & (cpr - 1))) return -1;  // attend(): 16-byte chunks, shuffle reduction
   }
-  static const bool want_prof = getenv("SATRN_DEC_PROF") != nullptr;  // debugging aid: per-phase clocks of workgroup 0
+  static const bool want_prof = sw_prof("dec");  // debugging aid: per-phase clocks of workgroup 0
   static long long* prof_buf = nullptr;
   if (want_prof) {
     if (!prof_buf) (void)hipMalloc((void**)&prof_buf, 16 * sizeof(long long));

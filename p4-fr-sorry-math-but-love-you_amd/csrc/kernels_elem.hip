@@ -5,6 +5,7 @@
 #include "kernels.h"
 #include "tile_dev.h"
 #include <atomic>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -52,10 +53,29 @@ long resident_capacity(const void* kernel, int threads, size_t lds_bytes) {
   cache[key] = cap;
   return cap;
 }
-int timing_switch(const char* name) {
-  const char* v = getenv(name);
-  const int x = v ? atoi(v) : 0;
-  if (x) fprintf(stderr, "[satrn] WARNING: %s=%d -- a timing experiment: parts of a kernel are skipped and its results are WRONG\n", name, x);
+// -> just behind `name` inside the list held by environment variable `env` (at '=', a separator or the end), or null
+static const char* sw_find(const char* env, const char* name) {
+  const char* s = getenv(env);
+  if (!s) return nullptr;
+  const size_t n = strlen(name);
+  while (*s) {
+    while (*s == ',' || *s == ' ') ++s;
+    if (!strncmp(s, name, n) && (s[n] == 0 || s[n] == ',' || s[n] == ' ' || s[n] == '=')) return s + n;
+    while (*s && *s != ',' && *s != ' ') ++s;
+  }
+  return nullptr;
+}
+bool sw_off(const char* name) { return sw_find("SATRN_OFF", name) != nullptr; }
+bool sw_knob_set(const char* name) { const char* p = sw_find("SATRN_KNOBS", name); return p && *p == '='; }
+long sw_knob(const char* name, long dflt) { const char* p = sw_find("SATRN_KNOBS", name); return (p && *p == '=') ? atol(p + 1) : dflt; }
+double sw_knobf(const char* name, double dflt) { const char* p = sw_find("SATRN_KNOBS", name); return (p && *p == '=') ? atof(p + 1) : dflt; }
+const char* sw_knob_str(const char* name) { const char* p = sw_find("SATRN_KNOBS", name); return (p && *p == '=') ? p + 1 : nullptr; }
+bool sw_prof(const char* name) { return sw_find("SATRN_PROF", name) != nullptr; }
+int sw_timing(const char* name) {
+  const char* p = sw_find("SATRN_TIMING", name);
+  if (!p) return 0;
+  const int x = *p == '=' ? atoi(p + 1) : 1;
+  if (x) fprintf(stderr, "[satrn] WARNING: SATRN_TIMING %s=%d -- a timing experiment: work is skipped and results are WRONG\n", name, x);
   return x;
 }
 void det_overflow_warn(size_t need_floats) {
@@ -547,7 +567,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const T* __restrict__ 
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
 }
 bool bn_act_pool_ok(long M, int C, int HW) {
-  const bool off = getenv("SATRN_NO_FUSED_POOL") != nullptr;   // read per call: tests compare the fused and the plain forms in one process
+  const bool off = sw_off("fused_pool");   // read per call: tests compare the fused and the plain forms in one process
   return !off && !g_det.on && HW > 0 && (HW % BNP_ROWS) == 0 && (M % HW) == 0;
 }
 // The same pass as an image kernel for the small maps of the late stages (bf16): workgroup = one image x 64 channels (full 128-byte
@@ -753,7 +773,7 @@ bool launch_bn_pool_se(int dt, const void* y, const float* sums, int sums_rep, c
                        float eps, float mom, float* ss, float* mr, void* z /*may be null*/, const void* W1, const float* b1, const void* W2,
                        const float* b2, float* pooled, float* u1, float* s1, void* gate, void* out, unsigned long long* box, int box_images,
                        int B, int HW, int C, int S, int act, hipStream_t s) {
-  const bool off = getenv("SATRN_NO_FUSED_POOL_SE") != nullptr;   // read per call: tests compare the fused and the plain forms in one process
+  const bool off = sw_off("fused_pool_se");   // read per call: tests compare the fused and the plain forms in one process
   if (off || g_det.on || dt != DT_BF16 || !sums || !box || B > box_images || (C % 64) != 0 || C > 1536 || S > 64 || (S % 8) != 0 || HW <= 0) return false;
   if (!se_box_usable(s)) return false;
   BnSeP p;
@@ -1438,7 +1458,7 @@ __global__ __launch_bounds__(512, 4) void bn_dw_img_kernel(const bf16_t* __restr
 bool launch_bn_dwconv(int dt, const void* y, const float* sums, int sums_rep, const float* w, const float* b, float* rm, float* rv, int64_t* nbt,
                       float eps, float mom, float* ss, float* mr, void* z, const void* wp, const float* dwbias, void* out, float* red, int B, int H,
                       int W, int C, int act, hipStream_t s) {
-  const bool off = getenv("SATRN_NO_FUSED_BN_DW") != nullptr;   // read per call: tests compare the fused and the plain forms in one process
+  const bool off = sw_off("fused_bn_dw");   // read per call: tests compare the fused and the plain forms in one process
   if (off || g_det.on || dt != DT_BF16 || !sums || !red || (C % (8 * BDW_SC)) != 0 || (W % BDW_RUN) != 0) return false;
   const int HW = H * W, NT = (HW / BDW_RUN) * BDW_SC;
   if (NT > 512 || (NT % 64) != 0) return false;
@@ -1572,7 +1592,7 @@ __global__ __launch_bounds__(512, 4) void dw_eval_img_kernel(const bf16_t* __res
 // false = shape not taken (the caller launches launch_dwconv with the eval epilogue; the pool stays with the SE kernel)
 bool launch_dwconv_eval_img(int dt, const void* x, const void* wp, const float* dwbias, const float* esc, const float* esh, int act, void* out,
                             float* pool, int B, int H, int W, int C, hipStream_t s, const SeEvalArgs* se) {
-  const bool off = getenv("SATRN_NO_DW_EVAL_IMG") != nullptr;   // read per call: tests compare the two forms in one process
+  const bool off = sw_off("dw_eval_img");   // read per call: tests compare the two forms in one process
   if (off || dt != DT_BF16 || (C % (8 * BDW_SC)) != 0 || (W % BDW_RUN) != 0) return false;
   const int HW = H * W, NT = (HW / BDW_RUN) * BDW_SC;
   if (NT > 512 || (NT % 64) != 0) return false;
@@ -1583,7 +1603,7 @@ bool launch_dwconv_eval_img(int dt, const void* x, const void* wp, const float* 
   sp.box = nullptr; sp.tag = 0; sp.timeout_ticks = 200000000LL; sp.W1 = nullptr; sp.b1 = nullptr; sp.W2 = nullptr; sp.b2 = nullptr; sp.S = 0;
   if (se) {
     // with the squeeze-and-excite block: the image's workgroups wait for each other, so the WHOLE grid must be resident at once
-    if (getenv("SATRN_NO_DW_EVAL_SE") != nullptr || !se->box || B > se->box_images || se->S > 64 || (se->S % 8) != 0 || C > 1536 || !esc) return false;
+    if (sw_off("dw_eval_se") || !se->box || B > se->box_images || se->S > 64 || (se->S % 8) != 0 || C > 1536 || !esc) return false;
     if (!se_box_usable(s)) return false;
     if ((long)B * (C / (8 * BDW_SC)) > resident_capacity((const void*)dw_eval_img_kernel, NT, lds)) return false;
     sp.box = se->box; sp.tag = se_next_tag(); sp.W1 = (const bf16_t*)se->W1; sp.b1 = se->b1; sp.W2 = (const bf16_t*)se->W2; sp.b2 = se->b2; sp.S = se->S;
@@ -1758,14 +1778,14 @@ bool dwconv_img_ok(int dt, int H, int W, int C) {
 }
 bool launch_dwconv_bwd_bn(int dt, const void* dy, const void* wp, void* dz, int beta, const void* y, const float* ss, const float* mr, int act,
                           float* red, int B, int H, int W, int C, hipStream_t s, const BnBwdHold* hold) {
-  const bool off = getenv("SATRN_NO_FUSED_DW_BWD") != nullptr;   // read per call (tests)
+  const bool off = sw_off("fused_dw_bwd");   // read per call (tests)
   if (off || !dwconv_img_ok(dt, H, W, C) || (y && !red) || (!y && !hold)) return false;
   const int HW = H * W, NT = (HW / BDW_RUN) * BDW_SC;
   const int rowpix = (W + 2) | 1;
   const size_t lds = (size_t)(H + 2) * rowpix * BDW_SC * 16;
   BnApplyP ap = {};
   if (hold) {
-    if (getenv("SATRN_NO_FUSED_BN_APPLY_DW") != nullptr || hold->C != C || hold->M != (long)B * HW) return false;
+    if (sw_off("bn_apply_dw") || hold->C != C || hold->M != (long)B * HW) return false;
     ap.dz = (const bf16_t*)hold->dz; ap.y = (const bf16_t*)hold->y; ap.ss = hold->ss; ap.mr = hold->mr; ap.w = hold->w; ap.red = hold->red;
     ap.dy = (bf16_t*)hold->dy; ap.dwp = hold->dwp; ap.dbp = hold->dbp; ap.se_gate = (const bf16_t*)hold->se_gate; ap.se_dpool = (const bf16_t*)hold->se_dpool;
     ap.se_scale = hold->se_hw > 0 ? 1.0f / (float)hold->se_hw : 0.f; ap.invM = 1.0f / (float)hold->M; ap.act = hold->act;
@@ -1780,7 +1800,7 @@ bool launch_dwconv_bwd_bn(int dt, const void* dy, const void* wp, void* dz, int 
 }
 
 static bool dwconv_fuses_stats(int H, int W, int OH, int OW, int stride, int pt, int pl) {
-  const bool off = getenv("SATRN_DW_NO_FUSED_RED") != nullptr;   // read per call (tests)
+  const bool off = sw_off("dw_fused_red");   // read per call (tests)
   return !off && !g_det.on && stride == 1 && pt == 1 && pl == 1 && OH == H && OW == W && (W & 1) == 0;
 }
 
@@ -2116,10 +2136,8 @@ void launch_dwconv_wgrad(int dt, const void* x, const void* dy, float* dw, float
   DISPATCH_T(dt, {
     DwWgradF<T> f{(const T*)x, (const T*)dy, H, W, C, OH, OW, stride, pt, pl, 1.0f / (float)OW, 1.0f / ((float)OW * (float)OH), (long)B * OH * OW < (1L << 23) ? 1 : 0};
     if (scratch10C) {
-      // knob (read once, tools/ab_env.sh): workgroups of this side-stream kernel -- 152 registers x 256 threads: two of them on a compute unit
-      // leave no room for the chain's 512-thread kernels
-      static const int blk = getenv("SATRN_DWW_BLOCKS") ? atoi(getenv("SATRN_DWW_BLOCKS")) : DWW_BLK;
-      launch_colreduce<T, 10>(f, (long)B * OH * OW, C, scratch10C, nullptr, -1, s, blk < DWW_BLK ? DWW_RPT * DWW_BLK / (blk > 0 ? blk : 1) : DWW_RPT, blk, blk);
+      // (512 workgroups: 256 -> +0.23 ms, 128 -> +0.93 ms, 1024 -> +0.25 ms per step, round 4: the side stream's duration is on the critical path)
+      launch_colreduce<T, 10>(f, (long)B * OH * OW, C, scratch10C, nullptr, -1, s, DWW_RPT, DWW_BLK, DWW_BLK);
       hipLaunchKernelGGL(dw_wgrad_scatter_kernel, dim3((C * 10 + 255) / 256), dim3(256), 0, s, scratch10C, dw, dbias, C);
     } else {
       launch_colreduce<T, 10>(f, (long)B * OH * OW, C, dw, dbias, 9, s, 16, DWW_BLK, DWW_BLK);

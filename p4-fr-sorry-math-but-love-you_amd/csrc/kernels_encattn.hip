@@ -256,7 +256,7 @@ __global__ __launch_bounds__(EA_THREADS) void enc_attn_fwd_kernel(EncAttnP p) {
 }
 
 bool enc_attn_fused_ok(int dt, int L, int D, int H) {
-  const bool off = getenv("SATRN_NO_FUSED_ENC_ATTN") != nullptr;   // read per call: the A/B test switches forms in one process
+  const bool off = sw_off("fused_enc_attn");   // read per call: the A/B test switches forms in one process
   return !off && dt == DT_BF16 && L >= 1 && L <= 64 && (D == 512 || D == 256) && H * 64 == D && (H & 1) == 0;
 }
 
@@ -264,7 +264,7 @@ bool launch_enc_attn_fwd(const EncAttnP& p, hipStream_t s) {
   if (!enc_attn_fused_ok(DT_BF16, p.L, p.D, p.H)) return false;
   const dim3 grid(p.H / 2, p.B), block(EA_THREADS);
   EncAttnP pp = p;
-  static const int ea_dbg = timing_switch("SATRN_EA_DBG");
+  static const int ea_dbg = sw_timing("ea_dbg");
   pp.dbg = ea_dbg;   // timing experiments: leave after phase N (wrong results)
   const size_t sh = (size_t)p.D * 128 + 3 * 4 * 64 * 32 * 2;
   if (p.D == 512) {

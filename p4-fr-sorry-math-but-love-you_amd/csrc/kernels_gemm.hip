@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256 * G) void gemm_kernel(GemmP p) {
 // stride-2 3x3 data gradient by parity classes of the output pixels (GemmP::dgrad_classes): a class is whole tiles of any height
 static bool dgrad_classes_ok(const GemmP& p) {
   return p.stride == 2 && p.KW == 3 && (p.OH & 1) == 0 && (p.OW & 1) == 0 && (p.M & 3) == 0 && ((p.M >> 2) % 256) == 0 &&
-         (long)p.M == (long)(p.M / (p.OH * p.OW)) * p.OH * p.OW && getenv("SATRN_DGRAD_NO_CLASSES") == nullptr /* A/B, read per call (tests) */;
+         (long)p.M == (long)(p.M / (p.OH * p.OW)) * p.OH * p.OW && !sw_off("dgrad_classes") /* A/B, read per call (tests) */;
 }
 
 template <typename T, int AM>
@@ -495,7 +495,7 @@ static void launch_gemm_t(const GemmP& p_in, hipStream_t s) {
     // tile height of the narrow (<= 32 channels) parity-class data gradient: tools/dgrad_s2_time.py
     // (96 -> 24 channels at 32 x 64 x 192: 256 rows 92 us, 128 rows 67 us, 64 rows 75 us; knob read per call)
     if (p.dgrad_classes && p.N <= 32) {
-      const char* bm = getenv("SATRN_DGRAD_BM");
+      const char* bm = sw_knob_str("dgrad_bm");
       const int h = bm ? atoi(bm) : 128;
       auto blk = [&](int m) { return (long)((p.M + m - 1) / m) * ((p.N + 31) / 32); };
       if (h == 128) { hipLaunchKernelGGL((gemm_kernel<T, 128, 32, AM, 1>), dim3(blk(128)), dim3(256), 0, s, p); return; }
@@ -507,7 +507,7 @@ static void launch_gemm_t(const GemmP& p_in, hipStream_t s) {
   constexpr bool BF = sizeof(T) == 2;
   auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
   // tuning hook (tools/gemm_bench.py): SATRN_GEMM_FORCE=<bm>x<bn>x<kp> forces one dense bf16 configuration
-  static const char* force = getenv("SATRN_GEMM_FORCE");
+  static const char* force = sw_knob_str("gemm_force");
   if (force && AM == AM_DENSE && BF) {
     int bm = 0, bn = 0, kp = 0;
     if (sscanf(force, "%dx%dx%d", &bm, &bn, &kp) == 3) {
@@ -556,7 +556,7 @@ static void launch_gemm_t(const GemmP& p_in, hipStream_t s) {
   } else if (D && p.N >= 64 && blocks(64, 64) <= 800) {
     // small grids (late stages: M <= 6144): 64x32 tiles double the number of workgroups; 13-20 % faster on the
     // M=1536/6144 shapes of tools/gemm_bench.py (SMALLN=1), deep K staged 4 panels per barrier
-    const bool no_g2 = getenv("SATRN_GEMM_NO_G2") != nullptr;   // A/B switch, read per call (tests)
+    const bool no_g2 = sw_off("gemm_g2");   // A/B switch, read per call (tests)
     if (nk32 >= 24 && BF && !no_g2 && blocks(64, 32) <= 512) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D && BF ? 4 : 1), (D && BF ? 2 : 1)>), dim3(blocks(64, 32)), dim3(D && BF ? 512 : 256), 0, s, p);
     else if (nk32 >= 24 && BF) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D && BF ? 4 : 1)>), dim3(blocks(64, 32)), dim3(256), 0, s, p);
     else if (nk32 >= 4) hipLaunchKernelGGL((gemm_kernel<T, 64, 32, AM, (D ? 2 : 1)>), dim3(blocks(64, 32)), dim3(256), 0, s, p);
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(GemmP p, int Himg, in
 
 // stride-1 SAME 3x3 (forward or data gradient), bf16, no bias / activation / dropout epilogue, C % 8 == 0
 static bool conv_halo_launch(int amode, const GemmP& p, hipStream_t s) {
-  const bool off = getenv("SATRN_NO_HALO_CONV") != nullptr;   // read per call: tests compare both forms in one process
+  const bool off = sw_off("halo_conv");   // read per call: tests compare both forms in one process
   if (off || p.KW != 3 || p.stride != 1 || p.pt != 1 || p.pl != 1 || p.OH != p.H || p.OW != p.W) return false;
   if (p.bias || (p.act && !p.escale) || p.drop_p > 0.f || p.out_f32 || (p.Ci & 7) || p.ldc != p.N) return false;
   const int C = p.Ci, H = p.OH, W = p.OW;
@@ -868,9 +868,9 @@ void launch_gemm(int dt, int amode, const GemmP& p0, hipStream_t s) {
   GemmP p = p0;
   p.stats_part = nullptr;
   {
-    static const bool nsa = [] { const bool on = getenv("SATRN_TIMING_NO_STATS_ATOMICS") != nullptr; if (on) fprintf(stderr, "[satrn] WARNING: SATRN_TIMING_NO_STATS_ATOMICS is set -- BatchNorm statistics are NOT accumulated (timing experiment)\n"); return on; }();
+    static const bool nsa = sw_timing("no_stats_atomics") != 0;   // (BatchNorm statistics are NOT accumulated)
     p.dbg_no_stats_atomics = nsa ? 1 : 0;
-    p.no_stage_y = getenv("SATRN_GEMM_NO_STAGE_Y") != nullptr ? 1 : 0;   // A/B, read per call (tests)
+    p.no_stage_y = sw_off("gemm_stage_y") ? 1 : 0;   // A/B, read per call (tests)
   }
   const int nslots = (p.M + 63) / 64;
   if (p.stats) p.stats_part = det_scratch(s, (size_t)(nslots + 4) * 2 * p.N);  // null unless the deterministic mode is on
@@ -879,11 +879,11 @@ void launch_gemm(int dt, int amode, const GemmP& p0, hipStream_t s) {
     // GEMMs on the persistent kernel, 64-column tiles for the narrow data gradients: forward 66 -> 58 us (48 -> 192 channels at 32 x 96) and
     // 30 -> 23 us (64 -> 256 at 16 x 48), data gradients 98 -> 80 us (192 -> 48) and 63 -> 41 us (256 -> 64) against the halo-tiled kernel.
     // SATRN_CONV_BIG=0 (read per call: tests) keeps the halo kernel.
-    const char* cb = getenv("SATRN_CONV_BIG");
-    const int conv_min_n = getenv("SATRN_CONV_BIG_MIN_N") ? atoi(getenv("SATRN_CONV_BIG_MIN_N")) : 32;   // knob (read per call: tests)
+    const char* cb = sw_knob_str("conv_big");
+    const int conv_min_n = (int)sw_knob("conv_big_min_n", 32);   // knob (read per call: tests)
     // (a stride-2 data gradient that splits into parity classes stays on the tile kernel, which then skips the taps a class never
     // meets: 192 -> 48 channels at 32 x 32 x 96, 45 us against 66 us here with all nine taps staged -- tools/dgrad_s2_time.py)
-    const bool by_classes = amode == AM_DGRAD && dgrad_classes_ok(p) && getenv("SATRN_DGRAD_CLASSES_BIG") == nullptr;
+    const bool by_classes = amode == AM_DGRAD && dgrad_classes_ok(p) && !sw_off("dgrad_classes_tile");
     if (!(cb && atoi(cb) == 0) && !p.stats_part && dt == DT_BF16 && (amode == AM_CONV || amode == AM_DGRAD) && p.N >= conv_min_n && !by_classes &&
         gemm_big_conv_launch(amode, p, s)) return;
   }
@@ -1136,9 +1136,9 @@ static void launch_wgrad_tile(const WgradP& p, hipStream_t s) {
     // weight gradients run on the low-priority side stream beside the data-gradient chain and have ~2.5x slack: a grid
     // that fills the chip (768 blocks) only takes CUs away from the chain.  Measured on the bs32 step: 768/768 blocks
     // 2 429 img/s, 96 dense / 384 conv 2 535 img/s, 32 dense 2 526, 64 (all) 2 358 (side stream becomes the critical path)
-    static const long tgt_env = getenv("SATRN_WGRAD_BLOCKS") ? atol(getenv("SATRN_WGRAD_BLOCKS")) : 0;
+    static const long tgt_env = sw_knob("wgrad_blocks", 0);
     const long tgt_d = tgt_env > 0 ? tgt_env : (g_wgrad_dense_blocks > 0 ? g_wgrad_dense_blocks : 96);
-    static const long tgt_c = getenv("SATRN_WGRAD_BLOCKS_CONV") ? atol(getenv("SATRN_WGRAD_BLOCKS_CONV")) : 384;
+    static const long tgt_c = sw_knob("wgrad_blocks_conv", 384);
     // deterministic mode: the split count (= the summation grouping) must not depend on which stream / graph mode runs the kernel
     const long tgt = g_det.on ? 256 : (p.full_grid ? 768 : (p.conv ? tgt_c : tgt_d));
     splits = (int)((tgt + (long)tiles * nb - 1) / ((long)tiles * nb));
@@ -1156,7 +1156,7 @@ static void launch_wgrad_tile(const WgradP& p, hipStream_t s) {
   rps = ((rps + MS - 1) / MS) * MS;
   splits = (p.M + rps - 1) / rps;
   WgradP q = p;
-  const bool launch_order = getenv("SATRN_WGRAD_LAUNCH_ORDER") != nullptr;   // A/B (tools/ab_bench.sh), read per call
+  const bool launch_order = sw_off("wgrad_xcd_order");   // A/B (tools/ab_bench.sh), read per call
   q.launch_order = launch_order ? 1 : 0;
   q.det_part = det ? det_scratch(s, (size_t)splits * p.N * p.K) : nullptr;
   // (measured: the partial-tile slab of the persistent kernel for this kernel's split-M sums instead of atomics -- 10.56 vs 10.47 ms per

@@ -793,7 +793,7 @@ __global__ __launch_bounds__(BIG_THREADS, 2) void wgrad_big_kernel(BigWP p) {
   }
 }
 
-static int big_dbg() { static const int v = timing_switch("SATRN_BIG_DBG"); return v; }
+static int big_dbg() { static const int v = sw_timing("big_dbg"); return v; }
 static int big_cu_count() {
   static int cus = 0;
   if (!cus) {
@@ -873,7 +873,7 @@ bool gemm_big_conv_launch(int amode, const GemmP& g, hipStream_t s) {
   return gemm_big_go(g, s, true, amode == AM_DGRAD ? 1 : 0);
 }
 static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
-  const char* mode_env = getenv("SATRN_GEMM_BIG");   // read per call (tests and tools switch it): 0 = off, 2 = take every shape that fits
+  const char* mode_env = sw_knob_str("gemm_big");   // read per call (tests and tools switch it): 0 = off, 2 = take every shape that fits
   const int mode = mode_env ? atoi(mode_env) : 1;
   if (!mode) return false;
   if (g.out_f32 || g.drop_p > 0.f || (g.eres && !g.escale)) return false;
@@ -888,9 +888,9 @@ static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
     // step (tools/shape_prof.py, SATRN_GEMM_BIG_MIN_GFLOP=0.5 against the default): its 1x1 convolutions -- 0.5 .. 2 GFLOP each, inputs
     // just written by another kernel, a weight-gradient kernel running beside them -- gain nothing from the persistent form (4.66 ->
     // 4.91 ms over the family): a 160 KB workgroup needs a whole drained CU to start and leaves no room for the side stream
-    static const double min_gflop = getenv("SATRN_GEMM_BIG_MIN_GFLOP") ? atof(getenv("SATRN_GEMM_BIG_MIN_GFLOP")) : 2.0;
+    static const double min_gflop = sw_knobf("gemm_big_min_gflop", 2.0);
     const double flops = 2.0 * g.M * g.N * g.K;
-    static const int min_n = getenv("SATRN_GEMM_BIG_MIN_N") ? atoi(getenv("SATRN_GEMM_BIG_MIN_N")) : 128;
+    static const int min_n = (int)sw_knob("gemm_big_min_n", 128);
     // (inference products -- escale set -- run with no weight-gradient stream beside them: the smaller ones gain as well, 13 -> 7 us at 1.6 GFLOP)
     const double mg = g.escale ? std::min(min_gflop, 1.0) : min_gflop;
     if (mode != 2 && (flops < mg * 1e9 || g.N < (conv ? 32 : min_n) || g.M < 2048)) return false;
@@ -912,7 +912,7 @@ static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
   p.dbg = big_dbg();
   const int cus = big_cu_count();
   // tile height: the candidate whose tile count leaves the smallest idle share in the last round of the persistent grid
-  const int force_mt = getenv("SATRN_GEMM_BIG_MT") ? atoi(getenv("SATRN_GEMM_BIG_MT")) : 0;
+  const int force_mt = (int)sw_knob("gemm_big_mt", 0);
   int best_mt = 3;
   double best_cost = 1e30;
   const bool aux_form = g.pre_out || g.bact_u || g.beta || g.escale;
@@ -929,7 +929,7 @@ static bool gemm_big_go(const GemmP& g, hipStream_t s, bool conv, int flip) {
   p.ntm = (g.M + 64 * best_mt - 1) / (64 * best_mt);
   p.ntiles = p.ntm * p.ntn;
   int grid = p.ntiles < cus ? p.ntiles : cus;
-  static const int grid_env = getenv("SATRN_BIG_GRID") ? atoi(getenv("SATRN_BIG_GRID")) : 0;   // experiment (tools/gemm_big_grid.sh): fewer CUs, same tiles
+  static const int grid_env = (int)sw_knob("big_grid", 0);   // experiment (tools/gemm_big_grid.sh): fewer CUs, same tiles
   if (grid_env > 0) grid = std::min(grid, grid_env);
   if (best_mt == 4) big_launch_t<4>(p, grid, s);
   else if (best_mt == 3) big_launch_t<3>(p, grid, s);
@@ -949,13 +949,13 @@ static void wgrad_big_go(const BigWP& p, int grid, hipStream_t s) {
 
 // dense bf16 weight gradient (fp32 atomics into dW, optional bias gradient); true = launched
 bool wgrad_big_launch(const WgradP& w, hipStream_t s) {
-  const char* mode_env = getenv("SATRN_WGRAD_BIG");   // read per call: 0 = off, 2 = every shape that fits
+  const char* mode_env = sw_knob_str("wgrad_big");   // read per call: 0 = off, 2 = every shape that fits
   const int mode = mode_env ? atoi(mode_env) : 1;
   if (!mode || w.conv || w.out_t || w.det_part || (w.nbatch > 1)) return false;
   if ((w.N & 7) || (w.K & 7) || (w.ldy & 7) || (w.lda & 7) || w.M < 64) return false;
   if ((size_t)w.M * w.ldy * 2 >= (1ull << 31) || (size_t)w.M * w.lda * 2 >= (1ull << 31)) return false;
   const double flops = 2.0 * w.M * w.N * w.K;
-  static const double wenv = getenv("SATRN_WGRAD_BIG_MIN_GFLOP") ? atof(getenv("SATRN_WGRAD_BIG_MIN_GFLOP")) : 0.0;   // knob: overrides the per-network value
+  static const double wenv = sw_knobf("wgrad_big_min_gflop", 0.0);   // knob: overrides the per-network value
   const double wmin = wenv > 0.0 ? wenv : (double)g_wgrad_big_min_gflop;
   if (mode != 2 && (flops < wmin * 1e9 || w.M < 2048)) return false;
   BigWP p;
@@ -993,7 +993,7 @@ bool wgrad_big_launch(const WgradP& w, hipStream_t s) {
   // (measured: 2-4x more, shorter items on the side stream, one per workgroup, so that CUs are released more often for the chain's
   // persistent kernels -- SwinTRN 17.9 -> 19.4-20.3 ms per step: the extra partial-tile traffic and fold work cost more)
   p.splits = splits; p.rows_per_split = rps; p.nitems = tiles * splits;
-  static const bool wgrad_atomics = getenv("SATRN_WGRAD_BIG_ATOMICS") != nullptr;   // A/B: keep the float atomics
+  static const bool wgrad_atomics = sw_off("wgrad_big_partials");   // A/B: keep the float atomics
   // partial tiles instead of atomics when a slab is there (engine calls) and there is something to fold
   p.part = nullptr;
   const size_t need = (size_t)splits * w.N * w.K;

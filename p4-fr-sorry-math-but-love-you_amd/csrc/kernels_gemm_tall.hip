@@ -183,7 +183,7 @@ static bool tall_go(const TallP& p, hipStream_t s) {
   }
   const int ntile = p.M / 16;
   int grid = cus * per_cu;
-  if (const char* e = getenv("SATRN_TALL_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // knob (tools/gemm_tall_bench.py)
+  if (sw_knob("tall_grid", 0) > 0) grid = (int)sw_knob("tall_grid", 0);   // knob (tools/gemm_tall_bench.py)
   if (grid * 4 > ntile) grid = (ntile + 3) / 4;
   hipLaunchKernelGGL((gemm_tall_kernel<NCT, KS, BNB>), dim3(grid), dim3(256), lds, s, p);
   return true;
@@ -192,7 +192,7 @@ static bool tall_go(const TallP& p, hipStream_t s) {
 // true = launched.  Dense bf16 products with many rows and N, K <= 256: plain, with output statistics, or the data-gradient form with
 // BatchNorm-backward sums.  Everything else (bias, activation, dropout, accumulate, inference epilogues, f32 output) stays on gemm_kernel.
 bool gemm_tall_launch(const GemmP& g, hipStream_t s) {
-  const char* mode_env = getenv("SATRN_GEMM_TALL");   // read per call (tests, A/B): 0 = off, 2 = every shape that fits
+  const char* mode_env = sw_knob_str("gemm_tall");   // read per call (tests, A/B): 0 = off, 2 = every shape that fits
   const int mode = mode_env ? atoi(mode_env) : 1;
   if (!mode) return false;
   if (g.bias || g.act || g.drop_p > 0.f || g.beta || g.out_f32 || g.escale || g.eres || g.pre_out || g.bact_u || g.stats_part) return false;

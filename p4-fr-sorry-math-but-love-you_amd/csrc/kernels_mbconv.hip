@@ -408,7 +408,7 @@ static bool mb_front_fits(int B, int H, int C, int rowpix) {
   if (!attr) { (void)hipFuncSetAttribute((const void*)mbconv_front_kernel<HWT, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
   const long cap = resident_capacity((const void*)mbconv_front_kernel<HWT, CIN>, HWT * 8 / 3, mb_front_lds<HWT, CIN>(H, rowpix));
   static bool said = false;
-  if (!said && getenv("SATRN_MB_PROF")) { said = true; fprintf(stderr, "[mbconv front <%d, %d>] %ld workgroups resident at once, dynamic LDS %zu B\n", HWT, CIN, cap, mb_front_lds<HWT, CIN>(H, rowpix)); }
+  if (!said && sw_prof("mb")) { said = true; fprintf(stderr, "[mbconv front <%d, %d>] %ld workgroups resident at once, dynamic LDS %zu B\n", HWT, CIN, cap, mb_front_lds<HWT, CIN>(H, rowpix)); }
   return (long)B * (C / 64) <= cap;
 }
 template <int HWT, int CIN>
@@ -420,7 +420,7 @@ static bool mb_front_go(const MbFrontP& p, hipStream_t s) {
   return true;
 }
 static bool mb_front_shape(int dt, int B, int H, int W, int Cin, int C, int S, hipStream_t s) {
-  const bool off = getenv("SATRN_NO_MBCONV_FRONT") != nullptr;   // read per call: tests compare the one launch with the three it replaces
+  const bool off = sw_off("mbconv_front");   // read per call: tests compare the one launch with the three it replaces
   if (off || g_det.on || dt != DT_BF16 || !g_mbbox.box || !g_sebox.box) return false;
   const int HW = H * W;
   if ((HW != 48 && HW != 192) || (W % BDW_RUN) != 0 || (C % 64) != 0 || C > 1536 || S > 64 || (S % 8) != 0 || B < 1 || B > g_mbbox.images || B > g_sebox.images) return false;
@@ -467,7 +467,7 @@ bool launch_mbconv_front(int dt, const void* x, const MbXinArgs* xin, const void
   p.B = B; p.H = H; p.W = W; p.C = C; p.S = S; p.rowpix = (W + 2) | 1;
   p.tag = se_next_tag();
   p.dbg = nullptr;
-  static const bool prof = getenv("SATRN_MB_PROF") != nullptr;   // diagnostics (tools): phase marks of the corner workgroups, printed after a sync
+  static const bool prof = sw_prof("mb");   // diagnostics (tools): phase marks of the corner workgroups, printed after a sync
   static long long* dbg = nullptr;
   if (prof) {
     if (!dbg && hipMalloc((void**)&dbg, 64 * sizeof(long long)) != hipSuccess) dbg = nullptr;
@@ -804,7 +804,7 @@ static bool mb_bwd_se_go(const MbBwdSeP& p, hipStream_t s) {
 bool launch_mbconv_bwd_se(int dt, const void* dy3, const MbDinArgs* din, const void* Wb, int ldb, void* dz3, const void* y2, const float* ss2, const float* mr2, const void* gate,
                           const float* u1, const void* We, const void* Wr, float* dz2, float* ds1, float* du1, void* dpooled, float* red, int B, int H, int W,
                           int CN, int C, int S, hipStream_t s) {
-  const bool off = getenv("SATRN_NO_MBCONV_BWD_SE") != nullptr || getenv("SATRN_SE_NO_WIDE_BWD") != nullptr || getenv("SATRN_SE_NO_BN_SUMS") != nullptr;   // read per call (tests)
+  const bool off = sw_off("mbconv_bwd_se") || sw_off("se_wide_bwd") || sw_off("se_bn_sums");   // read per call (tests)
   if (off || g_det.on || dt != DT_BF16 || !g_sebox.box) return false;
   const int HW = H * W;
   if ((HW != 48 && HW != 192) || (W % BDW_RUN) != 0 || (C % 64) != 0 || C > 1536 || S > 64 || (S % 8) != 0 || B < 1 || B > g_sebox.images || ldb < CN || (ldb & 7)) return false;

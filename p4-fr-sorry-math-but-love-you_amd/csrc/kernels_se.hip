@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void se_bwd_pool_kernel(const float* __restric
 bool launch_se_bwd_wide(int dt, const void* dy, const void* x, const void* gate, const float* u1, const void* W1, const void* W2, float* dz2,
                         float* du1, float* ds1_zeroed, void* dpooled, int B, int HW, int C, int S, hipStream_t s, const void* bn_y,
                         const float* bn_ss, const float* bn_mr, int bn_act, float* bn_P, float* bn_red) {
-  const bool off = getenv("SATRN_SE_NO_WIDE_BWD") != nullptr;   // read per call (tests)
+  const bool off = sw_off("se_wide_bwd");   // read per call (tests)
   // channel groups: slabs of exactly 64 channels where C allows (every row of a slab is one aligned 128-byte line: 960 channels in 8
   // groups were 240-byte rows straddling three lines), else SEB_G groups
   const int G = SEB_G;   // 4 / 6 / 16 groups and 64-channel slabs (C / 64 groups) were measured: 25.6 / 20.2 / 33.4 / 32.9 us against 20.9
@@ -771,7 +771,7 @@ bool launch_se_mlp_scale(int dt, const void* x, const float* poolsum, const void
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   }
   int G = SE_G;
-  if (const char* e = getenv("SATRN_SE_GROUPS")) G = atoi(e) > 0 ? atoi(e) : G;   // A/B (tools)
+  if (sw_knob("se_groups", 0) > 0) G = (int)sw_knob("se_groups", 0);   // A/B (tools)
   else while (G > 2 && (long)B * G > cus) G >>= 1;
   const int cs = (((C / 8) + G - 1) / G) * 8;
   if (cs > 1024) return false;

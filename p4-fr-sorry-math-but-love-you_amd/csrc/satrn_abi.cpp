@@ -105,7 +105,7 @@ int satrn_linear_bwd_weight_ws(int dt, const void* dy, int ldy, const void* x, f
   WgradP q;
   memset(&q, 0, sizeof(q));
   q.dY = dy; q.A = x; q.dW = dw; q.M = M; q.N = N; q.K = K; q.ldy = ldy; q.lda = K; q.nbatch = 1; q.nb_inner = 1;
-  if (db && getenv("SATRN_NO_WGRAD_BIAS") == nullptr) q.dbias = db;
+  if (db && !sw_off("wgrad_bias")) q.dbias = db;
   g_wgpart.cap = ws_floats; g_wgpart.scratch[0] = g_wgpart.scratch[1] = ws; g_wgpart.side = nullptr;
   launch_wgrad(dt, q, S(st));
   g_wgpart.cap = 0;
@@ -145,7 +145,7 @@ int satrn_linear_bwd_weight(int dt, const void* dy, int ldy, const void* x, floa
   WgradP q;
   memset(&q, 0, sizeof(q));
   q.dY = dy; q.A = x; q.dW = dw; q.M = M; q.N = N; q.K = K; q.ldy = ldy; q.lda = K; q.nbatch = 1; q.nb_inner = 1;
-  const bool fold = db && !g_det.on && getenv("SATRN_NO_WGRAD_BIAS") == nullptr;   // bias gradient summed inside the weight-gradient kernel
+  const bool fold = db && !g_det.on && !sw_off("wgrad_bias");   // bias gradient summed inside the weight-gradient kernel
   if (fold) q.dbias = db;
   launch_wgrad(dt, q, S(st));
   if (db && !fold) launch_colsum(dt, dy, M, N, ldy, db, S(st));

@@ -15,3 +15,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _restore_switches():
+    """the library's run-time switches (SATRN_OFF / SATRN_KNOBS / SATRN_PROF / SATRN_TIMING) are process-global: every test starts from, and
+    leaves behind, the state it found"""
+    import satrn_amd
+    snap = satrn_amd.switches.snapshot()
+    yield
+    satrn_amd.switches.restore(snap)

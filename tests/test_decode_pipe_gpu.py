@@ -10,6 +10,7 @@ inside bf16 noise legitimately changes everything after it); those tests stay, o
 Every test asserts WHICH kernel produced the result (satrn_model_last_decode_path): a pipeline that gave up and was re-run on
 the per-image kernel fails the test instead of passing on the fallback."""
 import os
+from satrn_amd import switches as sw
 
 import numpy as np
 import pytest
@@ -32,9 +33,9 @@ KERNEL_MAX_REL = 0.012
 
 def _greedy(model, img, steps, pipe, forced=None):
     if pipe:
-        os.environ.pop("SATRN_DECODE_NO_PIPE", None)
+        sw.on("decode_pipe")
     else:
-        os.environ["SATRN_DECODE_NO_PIPE"] = "1"
+        sw.off("decode_pipe")
     try:
         lg, ids = model.greedy(img, steps, forced=forced)
         torch.cuda.synchronize()
@@ -43,7 +44,7 @@ def _greedy(model, img, steps, pipe, forced=None):
         assert path == ("pipe" if pipe else "per_image"), f"decoder path {path!r} ({note})"
         return lg.clone(), ids.clone()
     finally:
-        os.environ.pop("SATRN_DECODE_NO_PIPE", None)
+        sw.on("decode_pipe")
 
 
 def _oracle_decode(cfg, sd, img, steps):
@@ -157,15 +158,15 @@ def test_decode_path_is_reported():
     model.greedy(img.cuda(), 5)
     path, giveups, note = model.last_decode_path()
     assert path == "per_image" and giveups == 0 and "shape" in note
-    os.environ["SATRN_DECODE_NO_PIPE"] = "1"
+    sw.off("decode_pipe")
     try:
         mb, _ = build(cfg, 128, 384, "bf16", 8)
         mb.eval()
         mb.greedy(img.cuda(), 5)
         path, giveups, note = mb.last_decode_path()
-        assert path == "per_image" and "SATRN_DECODE_NO_PIPE" in note
+        assert path == "per_image" and "decode_pipe" in note
     finally:
-        os.environ.pop("SATRN_DECODE_NO_PIPE", None)
+        sw.on("decode_pipe")
     mb.greedy(img.cuda(), 5)
     assert mb.last_decode_path()[0] == "pipe"
 

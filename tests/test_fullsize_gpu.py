@@ -5,6 +5,7 @@ import os
 import pytest
 import torch
 import torch.nn.functional as F
+from satrn_amd import switches as sw
 
 from oracle import satrn_oracle as O
 from tests.test_model_gpu import build, relerr, _DS
@@ -99,11 +100,11 @@ def test_full_size_decode_rows_are_independent_and_beam1_is_greedy():
     assert (seq[:, 0] == O.SOS_ID).all()
     # the search kernel runs the per-image decoder step: it must walk the per-image greedy kernel's chain EXACTLY, and the
     # pipelined greedy decoder's chain (same mathematics, partial sums added in another order) up to its first near-tie
-    os.environ["SATRN_DECODE_NO_PIPE"] = "1"
+    sw.off("decode_pipe")
     try:
         _, ids_pi = model.greedy(img, 231)
     finally:
-        os.environ.pop("SATRN_DECODE_NO_PIPE", None)
+        sw.on("decode_pipe")
     margin = logits.topk(2, -1).values
     sure_all = ((margin[..., 0] - margin[..., 1]) > 5e-2).cpu()
     for b in range(64):

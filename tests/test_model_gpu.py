@@ -3,6 +3,7 @@
 f32 mode carries the parity claim (<= 1e-3 on logits, greedy token ids bit-exact where the golden top-1/top-2 margin is
 clear); bf16 mode (the throughput mode) is checked against looser, stated tolerances."""
 import os
+from satrn_amd import switches as sw
 
 import numpy as np
 import pytest
@@ -337,7 +338,7 @@ def test_train_autoregressive_branch_with_gradients(dtype):
 @pytest.mark.parametrize("net,H,W,B", [("eff", 128, 384, 4), ("eff", 64, 96, 3), ("lite", 64, 192, 3)])
 def test_fused_encoder_attention_region_equals_the_four_launches(net, H, W, B):
     """kernels_encattn.hip (LayerNorm -> q|k|v -> attention -> output-projection partials in ONE launch, partials folded by the LayerNorm
-    behind the block) against the four launches it replaces (SATRN_NO_FUSED_ENC_ATTN=1), bf16, through the whole model.  The operator
+    behind the block) against the four launches it replaces (SATRN_OFF=fused_enc_attn), bf16, through the whole model.  The operator
     test (test_ops_gpu.py::test_encoder_attention_region_fused) pins every tensor the kernel writes to fp32 torch; here: (1) eval-mode
     encoder output, (2) the flat gradient of a step with BatchNorm in running-statistics mode (train_step(bn_eval=True): with BATCH
     statistics on 4 x 12 maps a bf16 rounding anywhere moves the gradient by tens of percent -- bench.py's accuracy_bf16_vs_f32 -- so two
@@ -351,9 +352,9 @@ def test_fused_encoder_attention_region_equals_the_four_launches(net, H, W, B):
     res = {}
     for name, env in (("fused", None), ("four", "1")):
         if env:
-            os.environ["SATRN_NO_FUSED_ENC_ATTN"] = env
+            sw.off("fused_enc_attn")
         else:
-            os.environ.pop("SATRN_NO_FUSED_ENC_ATTN", None)
+            sw.on("fused_enc_attn")
         try:
             model, sd = build(cfg, H, W, "bf16", 9, dropout=0.1)
             model.eval()
@@ -367,7 +368,7 @@ def test_fused_encoder_attention_region_equals_the_four_launches(net, H, W, B):
             torch.cuda.synchronize()
             res[name] = (src, g_eval, l_eval, model.read_loss()[0], model.flat_grad().detach().float().cpu().clone())
         finally:
-            os.environ.pop("SATRN_NO_FUSED_ENC_ATTN", None)
+            sw.on("fused_enc_attn")
     (s0, g0, le0, l0, gt0), (s1, g1, le1, l1, gt1) = res["fused"], res["four"]
     es = (s0 - s1).abs().max().item() / s1.abs().max().item()
     eg = (g0 - g1).norm().item() / g1.norm().item()
@@ -486,7 +487,9 @@ def test_segmented_backward_equals_whole_backward(golden_dir, name):
         model.train_step(imgd, expd, 0.0, phase=18)  # out of order
 
 
-_FUSED_SWITCHES = ("SATRN_NO_FUSED_POOL_SE", "SATRN_NO_FUSED_POOL", "SATRN_DW_NO_FUSED_RED", "SATRN_GEMM_NO_G2", "SATRN_SE_NO_WIDE_BWD", "SATRN_NO_FUSED_BN_DW", "SATRN_NO_FUSED_DW_BWD", "SATRN_SE_NO_BN_SUMS", "SATRN_NO_FUSED_BN_APPLY_DW")
+# SATRN_OFF names of the chain fusions of rounds 2-4 (each falls back to the kernels it replaced)
+_FUSED_SWITCHES = ("fused_pool_se", "fused_pool", "dw_fused_red", "gemm_g2", "se_wide_bwd", "fused_bn_dw", "fused_dw_bwd", "se_bn_sums", "bn_apply_dw", "mbconv_front", "mbconv_bwd_se",
+                   "mbconv_xfold", "gemm_tall_off")
 
 
 def test_fused_chain_kernels_equal_their_plain_forms(golden_dir, monkeypatch):
@@ -503,10 +506,12 @@ def test_fused_chain_kernels_equal_their_plain_forms(golden_dir, monkeypatch):
 
     def run(plain, only=None):
         for k in _FUSED_SWITCHES:
-            if plain or k == only:
-                monkeypatch.setenv(k, "1")
+            if k == "gemm_tall_off":   # (a tri-state route, not an on/off feature)
+                sw.knob("gemm_tall", 0 if (plain or k == only) else None)
+            elif plain or k == only:
+                sw.off(k)
             else:
-                monkeypatch.delenv(k, raising=False)
+                sw.on(k)
         model, _ = build(cfg, H, W, "bf16", int(meta["wseed"]))
         model.train()
         logits = model(imgd, expd, True, 1.0)
@@ -529,7 +534,7 @@ def test_fused_chain_kernels_equal_their_plain_forms(golden_dir, monkeypatch):
     assert fg < 2.0 * ng + 5e-2
     # round 3: BatchNorm + activation + the whole squeeze-and-excite block as one launch (the image's workgroups hand the pool and the
     # hidden layer to each other through a tagged mailbox) against the same step with only that kernel switched off
-    s0 = run(False, only="SATRN_NO_FUSED_POOL_SE")
+    s0 = run(False, only="fused_pool_se")
     sl, sg = dist(s0, f0)
     print(f"[one-launch BatchNorm + squeeze-and-excite vs its two launches] logits rel err {sl:.3e}, gradient rel-L2 {sg:.3e}")
     assert sl < 2.0 * nl + 5e-3
@@ -550,9 +555,9 @@ def test_eval_encoder_image_tile_depthwise_equals_generic(golden_dir, monkeypatc
     model.eval()
     img, _ = O.det_inputs(4, cfg["rgb"], H, W, 8, seed=5, pad_tail=0)
     imgd = img.cuda()
-    monkeypatch.setenv("SATRN_NO_DW_EVAL_IMG", "1")
+    sw.off("dw_eval_img")
     a = model.encode(imgd).float().clone()
-    monkeypatch.delenv("SATRN_NO_DW_EVAL_IMG")
+    sw.on("dw_eval_img")
     b = model.encode(imgd).float().clone()
     err = relerr(b, a)
     print(f"[eval encoder, image-tile depthwise vs generic] rel err {err:.3e}")
@@ -563,9 +568,9 @@ def test_eval_encoder_image_tile_depthwise_equals_generic(golden_dir, monkeypatc
     for B2 in (4, 64):
         img2, _ = O.det_inputs(B2, cfg["rgb"], H, W, 8, seed=6, pad_tail=0)
         img2 = img2.cuda()
-        monkeypatch.setenv("SATRN_NO_DW_EVAL_SE", "1")
+        sw.off("dw_eval_se")
         a2 = model.encode(img2).float().clone()
-        monkeypatch.delenv("SATRN_NO_DW_EVAL_SE")
+        sw.on("dw_eval_se")
         for _ in range(3):
             b2 = model.encode(img2).float().clone()
         err2 = relerr(b2, a2)

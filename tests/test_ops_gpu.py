@@ -4,6 +4,7 @@ Tolerances: f32 mode = exact-f32 MFMA, compared at 2e-4 of the output scale; bf1
 accumulation, compared at 3e-2 of the output scale (inputs are rounded to bf16 on both sides first)."""
 import ctypes
 import math
+from satrn_amd import switches as sw
 
 import pytest
 import torch
@@ -131,15 +132,15 @@ def test_linear(lib, dt, M, N, K, act):
 
 @pytest.fixture
 def big_gemm_mode():
-    """SATRN_GEMM_BIG is read per call: '2' = every dense bf16 product that fits takes the persistent direct-to-LDS kernel
+    """SATRN_KNOBS gemm_big is read per call: '2' = every dense bf16 product that fits takes the persistent direct-to-LDS kernel
     (kernels_gemm_big.hip), '0' = the 4-wave tile kernel"""
     import os
 
     def set_mode(m):
-        os.environ["SATRN_GEMM_BIG"] = str(m)
+        sw.knob("gemm_big", str(m))
     yield set_mode
-    os.environ.pop("SATRN_GEMM_BIG", None)
-    os.environ.pop("SATRN_GEMM_BIG_MT", None)
+    sw.knob("gemm_big", None)
+    sw.knob("gemm_big_mt", None)
 
 
 @pytest.mark.parametrize("M,N,K,act,mt", [(256, 128, 64, 0, 0), (300, 136, 192, 1, 0), (1000, 384, 512, 4, 0), (777, 128, 64, 0, 4), (6144, 960, 160, 0, 3), (1000, 48, 96, 0, 2),
@@ -151,7 +152,7 @@ def test_linear_big_kernel(lib, big_gemm_mode, M, N, K, act, mt):
     dt = "bf16"
     big_gemm_mode(2)
     if mt:
-        os.environ["SATRN_GEMM_BIG_MT"] = str(mt)
+        sw.knob("gemm_big_mt", str(mt))
     x, w, b = q(rnd(M, K, seed=1), dt), q(rnd(N, K, seed=2, scale=1 / math.sqrt(K)), dt), rnd(N, seed=3, scale=0.1)
     fwd, bwd, ldb = pack_dense(lib, w, dt)
     y = torch.full((M, N), 7.0, dtype=tdt(dt), device="cuda")
@@ -221,7 +222,7 @@ def test_linear_bwd_weight_partial_tiles(lib, M, N, K, bias):
     ws = torch.empty(320 * 16384, device="cuda")
     outs = []
     import os
-    os.environ["SATRN_WGRAD_BIG"] = "2"     # (read per call) every shape that fits, not only the >= 2 GFLOP ones
+    sw.knob("wgrad_big", "2")   # (read per call) every shape that fits, not only the >= 2 GFLOP ones
     try:
         for rep in range(2):
             dw = torch.full((N, K), 0.5, device="cuda")
@@ -229,7 +230,7 @@ def test_linear_bwd_weight_partial_tiles(lib, M, N, K, bias):
             ok(lib, lib.satrn_linear_bwd_weight_ws(dti(dt), P(dyd), N, P(xd), P(dw), P(db), M, N, K, P(ws), ws.numel(), st()))
             outs.append(dw.clone())
     finally:
-        os.environ.pop("SATRN_WGRAD_BIG", None)
+        sw.knob("wgrad_big", None)
     ref = dy.double().t() @ x.double()
     err = (outs[0].double().cpu() - 0.5 - ref).norm() / ref.norm()
     assert err < 2e-3, f"wgrad partial tiles {M}x{N}x{K}: rel err {err:.3e}"
@@ -245,7 +246,7 @@ def test_linear_bwd_weight_big_kernel(lib, M, N, K, bias):
     atomics, bias gradient as a ones-column product; M / N / K tails; against fp32 torch"""
     import os
     dt = "bf16"
-    os.environ["SATRN_WGRAD_BIG"] = "2"
+    sw.knob("wgrad_big", "2")
     try:
         x, dy = q(rnd(M, K, seed=1), dt), q(rnd(M, N, seed=4), dt)
         ldy = (N + 7) // 8 * 8 + 8    # a padded gradient buffer (row stride > N)
@@ -261,7 +262,7 @@ def test_linear_bwd_weight_big_kernel(lib, M, N, K, bias):
         ok(lib, lib.satrn_linear_bwd_weight(dti(dt), P(dyp), ldy, P(dev(x, dt)), P(dw), P(db), M, N, K, st()))
         close(dw, 2 * (dy.t() @ x), dt, "big linear_bwd_weight (accumulated)", bf16_tol=2e-3)
     finally:
-        os.environ.pop("SATRN_WGRAD_BIG", None)
+        sw.knob("wgrad_big", None)
 
 
 @pytest.mark.parametrize("mode", [0, 2])
@@ -311,12 +312,12 @@ def test_linear_with_batchnorm_sums(lib, big_gemm_mode, mode, M, N, K, rep, bnb)
                                            (1616, 192, 48, 2, 2), (1040, 256, 64, 1, 1), (4112, 64, 256, 3, 0), (1616, 192, 32, 1, 2), (32, 64, 192, 1, 0)])
 def test_tall_thin_products_on_the_row_streaming_kernel(lib, monkeypatch, tall, M, N, K, rep, bnb):
     """the 1x1 projections of the fused-MBConv stages and their data gradients (SURVEY Appendix B stages 1-2, full benchmark sizes and row
-    tails that are not a multiple of the waves) on kernels_gemm_tall.hip (SATRN_GEMM_TALL=2: every shape that fits) against torch, and
+    tails that are not a multiple of the waves) on kernels_gemm_tall.hip (SATRN_KNOBS=gemm_tall=2: every shape that fits) against torch, and
     against the tile kernel (0) on the same inputs; the route counter says which kernel ran"""
     import ctypes
     dt = "bf16"
-    monkeypatch.setenv("SATRN_GEMM_TALL", str(tall))
-    monkeypatch.setenv("SATRN_GEMM_BIG", "0")
+    sw.knob("gemm_tall", str(tall))
+    sw.knob("gemm_big", "0")
     x, w = q(rnd(M, K, seed=1), dt), q(rnd(N, K, seed=2, scale=1 / math.sqrt(K)), dt)
     fwd, _, _ = pack_dense(lib, w, dt)
     y = torch.empty(M, N, dtype=tdt(dt), device="cuda")
@@ -437,7 +438,7 @@ def test_conv3x3_stride2_data_gradient_by_parity_classes(lib, monkeypatch, dt, B
     output pixels dealt to the workgroups by parity class, each class visiting only the taps that reach it (4 / 2 / 2 / 1 of 9):
     against fp32 torch, and EQUAL to the all-taps form where a tap is whole k-steps (the skipped ones only ever added zeros), also when
     accumulating."""
-    monkeypatch.setenv("SATRN_CONV_BIG", "0")   # the tile kernel (the persistent kernel takes N >= 32 in bf16 otherwise)
+    sw.knob("conv_big", "0")   # the tile kernel (the persistent kernel takes N >= 32 in bf16 otherwise)
     s = 2
     x, w = q(rnd(B, Ci, H, W, seed=1), dt), q(rnd(Co, Ci, 3, 3, seed=2, scale=1 / math.sqrt(9 * Ci)), dt)
     OH, OW = H // 2, W // 2
@@ -454,7 +455,7 @@ def test_conv3x3_stride2_data_gradient_by_parity_classes(lib, monkeypatch, dt, B
     base = q(rnd(B, H, W, Ci, seed=9), dt)
     outs = []
     for no_classes in (False, True):
-        if no_classes: monkeypatch.setenv("SATRN_DGRAD_NO_CLASSES", "1")
+        if no_classes: sw.off("dgrad_classes")
         dx = torch.empty(B, H, W, Ci, dtype=tdt(dt), device="cuda")
         ok(lib, lib.satrn_conv3x3_bwd_data(dti(dt), P(dyd), P(bwd), P(dx), B, H, W, Ci, Co, OH, OW, s, pt, pl, 0, st()))
         acc = dev(base, dt)
@@ -494,8 +495,8 @@ def test_conv3x3_as_shifted_gemm_on_the_persistent_kernel(lib, big_gemm_mode, B,
     try:
         for name, mode, cb in (("persistent", 2, "1"), ("other", 0, "0")):
             big_gemm_mode(mode)
-            os.environ["SATRN_CONV_BIG"] = cb
-            os.environ["SATRN_CONV_BIG_MIN_N"] = "16"
+            sw.knob("conv_big", cb)
+            sw.knob("conv_big_min_n", "16")
             y = torch.empty(B, OH, OW, Co, dtype=tdt(dt), device="cuda")
             ok(lib, lib.satrn_conv3x3_fwd(dti(dt), P(xd), P(fwd), P(y), B, H, W, Ci, Co, OH, OW, s, pt, pl, st()))
             dx = torch.empty(B, H, W, Ci, dtype=tdt(dt), device="cuda")
@@ -504,8 +505,8 @@ def test_conv3x3_as_shifted_gemm_on_the_persistent_kernel(lib, big_gemm_mode, B,
             close(nchw(y.float()), ref, dt, f"conv3x3_fwd s{s} ({name})")
             close(nchw(dx.float()), xr.grad, dt, f"conv3x3_bwd_data s{s} ({name})")
     finally:
-        os.environ.pop("SATRN_CONV_BIG", None)
-        os.environ.pop("SATRN_CONV_BIG_MIN_N", None)
+        sw.knob("conv_big", None)
+        sw.knob("conv_big_min_n", None)
     close(outs["persistent"][0], outs["other"][0], dt, "persistent vs tile kernel forward", bf16_tol=1e-2)
     close(outs["persistent"][1], outs["other"][1], dt, "persistent vs tile kernel data gradient", bf16_tol=1e-2)
 
@@ -547,8 +548,8 @@ def test_inference_epilogue_on_the_persistent_kernel(lib, big_gemm_mode, kind, s
     try:
         for name, mode, cb in (("persistent", 2, "1"), ("other", 0, "0")):
             big_gemm_mode(mode)
-            os.environ["SATRN_CONV_BIG"] = cb
-            os.environ["SATRN_CONV_BIG_MIN_N"] = "16"
+            sw.knob("conv_big", cb)
+            sw.knob("conv_big_min_n", "16")
             y = torch.empty(M, N, dtype=tdt(dt), device="cuda")
             if kind == "linear":
                 ok(lib, lib.satrn_linear_bn_eval_act_fwd(dti(dt), P(xd), P(wd), P(dev(esc)), P(dev(esh)), act, P(rd) if res else None, P(y), M, N, K, st()))
@@ -559,8 +560,8 @@ def test_inference_epilogue_on_the_persistent_kernel(lib, big_gemm_mode, kind, s
             outs[name] = y.float().cpu()
             close(y, ref, dt, f"inference epilogue {kind} ({name})")
     finally:
-        os.environ.pop("SATRN_CONV_BIG", None)
-        os.environ.pop("SATRN_CONV_BIG_MIN_N", None)
+        sw.knob("conv_big", None)
+        sw.knob("conv_big_min_n", None)
     close(outs["persistent"], outs["other"], dt, "persistent vs tile kernel, inference epilogue", bf16_tol=1e-2)
 
 
@@ -668,9 +669,9 @@ def test_batchnorm_act_dwconv_fused(lib, dt, B, H, W, C, bias, monkeypatch):
 
     def run(fused):
         if fused:
-            monkeypatch.delenv("SATRN_NO_FUSED_BN_DW", raising=False)
+            sw.on("fused_bn_dw")
         else:
-            monkeypatch.setenv("SATRN_NO_FUSED_BN_DW", "1")
+            sw.off("fused_bn_dw")
         rmd, rvd = dev(rm.clone()), dev(rv.clone())
         nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
         scratch, stats = torch.zeros(6 * C, device="cuda"), torch.zeros(2 * C, device="cuda")
@@ -723,9 +724,9 @@ def test_dwconv_bn_eval_act_pool(lib, dt, B, H, W, C, bias, pool, monkeypatch):
 
     def run(img_kernel):
         if img_kernel:
-            monkeypatch.delenv("SATRN_NO_DW_EVAL_IMG", raising=False)
+            sw.on("dw_eval_img")
         else:
-            monkeypatch.setenv("SATRN_NO_DW_EVAL_IMG", "1")
+            sw.off("dw_eval_img")
         y = torch.empty(B, H, W, C, dtype=tdt(dt), device="cuda")
         ps = torch.full((B, C), float("nan"), device="cuda")
         ok(lib, lib.satrn_dwconv3x3_bn_eval_act_pool_fwd(dti(dt), P(xd), P(wp), P(dev(db)) if bias else None, P(dev(esc)), P(dev(esh)), 2, P(y),
@@ -775,9 +776,9 @@ def test_dwconv_bwd_data_with_batchnorm_sums(lib, dt, B, H, W, C, acc, monkeypat
 
     def run(fused):
         if fused:
-            monkeypatch.delenv("SATRN_NO_FUSED_DW_BWD", raising=False)
+            sw.on("fused_dw_bwd")
         else:
-            monkeypatch.setenv("SATRN_NO_FUSED_DW_BWD", "1")
+            sw.off("fused_dw_bwd")
         dz = dev(nhwc(dz0), dt).clone() if acc else torch.empty(B, H, W, C, dtype=tdt(dt), device="cuda")
         s2 = torch.zeros(2 * C, device="cuda")
         ok(lib, lib.satrn_dwconv3x3_bwd_data_bnred(dti(dt), P(doutd), P(wp), P(dz), acc, P(yd), P(scratch), 2, P(s2), B, H, W, C, st()))
@@ -1156,9 +1157,9 @@ def test_batchnorm_act_squeeze_excite_one_launch(lib, dt, B, HW, C, S, monkeypat
 
     def run(one_launch, keep_z):
         if one_launch:
-            monkeypatch.delenv("SATRN_NO_FUSED_POOL_SE", raising=False)
+            sw.on("fused_pool_se")
         else:
-            monkeypatch.setenv("SATRN_NO_FUSED_POOL_SE", "1")
+            sw.off("fused_pool_se")
         rmd, rvd = dev(rm.clone()), dev(rv.clone())
         nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
         scratch = torch.zeros(6 * C, device="cuda")

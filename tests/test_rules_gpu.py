@@ -2,6 +2,7 @@
 (rules inside the persistent decode kernel and on the step-wise path) and the ensemble driver loop with a manager, against
 the reference manager's own vectors (tests/golden/rules.npz) and the oracle."""
 import os
+from satrn_amd import switches as sw
 
 import numpy as np
 import pytest
@@ -58,7 +59,7 @@ def test_managed_greedy_decode_matches_reference_golden_and_oracle(monkeypatch, 
     table = z["table"]
     mb, H, W, steps, wseed, iseed = (int(v) for v in z["lite_meta"])
     if stepwise:
-        monkeypatch.setenv("SATRN_DECODE_STEPWISE", "1")
+        sw.off("decode_kernel")
     cfg = dict(O.CFG_LITE)
     model, sd = build(cfg, H, W, "f32", wseed)
     model.decoder.manager = _manager(table)

@@ -3,6 +3,7 @@ reference's own SwinTransformer + TransformerDecoder produced (tests/golden/swin
 seeded inputs.  f32 carries the parity claim (logits <= 1e-3, greedy ids exact where the margin is clear); bf16 is checked
 against stated, looser bounds."""
 import os
+from satrn_amd import switches as sw
 
 import numpy as np
 import pytest
@@ -160,9 +161,9 @@ def test_gelu_in_product_epilogue_equals_separate_passes(golden_dir, dtype, monk
 
     def run(passes):
         if passes:
-            monkeypatch.setenv("SATRN_SWIN_GELU_PASS", "1")
+            sw.off("swin_gelu_epilogue")
         else:
-            monkeypatch.delenv("SATRN_SWIN_GELU_PASS", raising=False)
+            sw.on("swin_gelu_epilogue")
         model, _ = build(scfg, dcfg, dtype, int(meta["wseed"]))
         model.train()
         logits = model(imgd, expd, True, 1.0)
@@ -192,9 +193,9 @@ def test_window_order_folded_into_layernorm_and_residual(golden_dir, dtype, monk
 
     def run(passes):
         if passes:
-            monkeypatch.setenv("SATRN_SWIN_PERM_PASS", "1")
+            sw.off("swin_rowmap")
         else:
-            monkeypatch.delenv("SATRN_SWIN_PERM_PASS", raising=False)
+            sw.on("swin_rowmap")
         model, _ = build(scfg, dcfg, dtype, int(meta["wseed"]))
         model.train()
         logits = model(imgd, expd, True, 1.0)
@@ -225,9 +226,9 @@ def test_residual_adds_folded_into_layernorm(golden_dir, dtype, drop_path, monke
 
     def run(separate):
         if separate:
-            monkeypatch.setenv("SATRN_SWIN_NO_ADD_LN", "1")
+            sw.off("swin_add_ln")
         else:
-            monkeypatch.delenv("SATRN_SWIN_NO_ADD_LN", raising=False)
+            sw.on("swin_add_ln")
         model, _ = build(scfg, dcfg, dtype, int(meta["wseed"]), drop_path=drop_path)
         model.train()
         logits = model(imgd, expd, True, 1.0)

@@ -1,6 +1,6 @@
-# where the fused attention backward spends its time inside the SwinTRN step (GPU box): kernel averages under the SATRN_A2_DBG bits
+# where the fused attention backward spends its time inside the SwinTRN step (GPU box): kernel averages under the SATRN_TIMING=a2_dbg=<bits> experiments
 for d in 0 6 14 30 62 2 4; do
-  bash tools/swin_kstats.sh gpurun_out/a2abl_$d.csv SATRN_A2_DBG=$d SATRN_NO_SIDE_STREAM=1 > /dev/null 2>&1
+ bash tools/swin_kstats.sh gpurun_out/a2abl_$d.csv SATRN_OFF=side_stream SATRN_TIMING=a2_dbg=$d > /dev/null 2>&1
   python3 - $d <<'PY'
 import csv, sys
 d = sys.argv[1]

@@ -6,6 +6,7 @@ import numpy as np
 import torch
 import bench
 import satrn_amd
+from satrn_amd import switches as sw
 
 dev = torch.device("cuda", 0)
 torch.manual_seed(21)
@@ -24,8 +25,8 @@ mgr._table_host = table.astype(np.int32)
 model.decoder.manager = mgr
 img, _ = bench.synth(64, 128, 384, 4, 5, dev)
 for name, env in (("per-image", "1"), ("pipelined", None)):
-    if env: os.environ["SATRN_DECODE_NO_PIPE"] = env
-    else: os.environ.pop("SATRN_DECODE_NO_PIPE", None)
+    if env: sw.off("decode_pipe")
+    else: sw.on("decode_pipe")
     model.greedy(img, 231); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5): model.greedy(img, 231)

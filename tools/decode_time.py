@@ -4,6 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
+from satrn_amd import switches as sw
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 231
@@ -18,8 +19,8 @@ for _ in range(3): model.encode(img)
 torch.cuda.synchronize()
 enc = (time.perf_counter() - t0) / 3 * 1e3
 for name, env in (("per-image", "1"), ("pipelined", None)):
-    if env: os.environ["SATRN_DECODE_NO_PIPE"] = env
-    else: os.environ.pop("SATRN_DECODE_NO_PIPE", None)
+    if env: sw.off("decode_pipe")
+    else: sw.on("decode_pipe")
     model.greedy(img, steps); torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 5

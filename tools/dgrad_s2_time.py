@@ -1,5 +1,5 @@
 """Time the stride-2 3x3 data gradient (C-ABI satrn_conv3x3_bwd_data) on the two stage entries of EfficientNetV2-S at the benchmark
-batch, parity-class form against the all-taps form (SATRN_DGRAD_NO_CLASSES=1); tile kernel (SATRN_CONV_BIG=0) and default routing."""
+batch, parity-class form against the all-taps form (SATRN_OFF=dgrad_classes); tile kernel (SATRN_KNOBS=conv_big=0) and default routing."""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,10 +24,10 @@ for B, H, W, Ci, Co in [(32, 64, 192, 24, 96), (32, 32, 96, 48, 192)]:
     assert lib.satrn_pack_conv3x3(1, P(w), P(fwd), P(bwd), Co, Ci, st()) == 0
     dy = torch.randn(B, OH, OW, Co, device="cuda").bfloat16()
     dx = torch.empty(B, H, W, Ci, dtype=torch.bfloat16, device="cuda")
-    for label, env in (("classes, tile kernel (default)", {}), ("all taps, tile kernel", {"SATRN_DGRAD_NO_CLASSES": "1", "SATRN_CONV_BIG": "0"}),
-                       ("persistent kernel where it applies", {"SATRN_DGRAD_CLASSES_BIG": "1"}),
-                       ("classes, 256-row tiles (<= 32 ch)", {"SATRN_DGRAD_BM": "256"}), ("classes, 64-row tiles (<= 32 ch)", {"SATRN_DGRAD_BM": "64"})):
-        for k in ("SATRN_CONV_BIG", "SATRN_DGRAD_NO_CLASSES", "SATRN_DGRAD_CLASSES_BIG", "SATRN_DGRAD_BM"): os.environ.pop(k, None)
+    for label, env in (("classes, tile kernel (default)", {}), ("all taps, tile kernel", {"SATRN_OFF": "dgrad_classes", "SATRN_KNOBS": "conv_big=0"}),
+                       ("persistent kernel where it applies", {"SATRN_OFF": "dgrad_classes_tile"}),
+                       ("classes, 256-row tiles (<= 32 ch)", {"SATRN_KNOBS": "dgrad_bm=256"}), ("classes, 64-row tiles (<= 32 ch)", {"SATRN_KNOBS": "dgrad_bm=64"})):
+        for k in ("SATRN_OFF", "SATRN_KNOBS"): os.environ.pop(k, None)
         os.environ.update(env)
         us = bench(lambda: lib.satrn_conv3x3_bwd_data(1, P(dy), P(bwd), P(dx), B, H, W, Ci, Co, OH, OW, 2, 0, 0, 0, st()))
         mb = (dy.numel() + dx.numel()) * 2 / 1e6

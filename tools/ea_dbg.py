@@ -1,4 +1,4 @@
-"""Phase timing of the fused encoder self-attention region kernel (SATRN_EA_DBG = leave after phase N; wrong results)."""
+"""Phase timing of the fused encoder self-attention region kernel (SATRN_TIMING=ea_dbg=N: leave after phase N; wrong results)."""
 import ctypes, os, sys, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,7 +19,7 @@ mr1, mr2, lse = torch.empty(2 * M, device="cuda"), torch.empty(2 * M, device="cu
 def run():
     lib.satrn_enc_attn_region_fwd(P(x), P(lnw), P(lnb), P(wqkv), P(bqkv), P(wo), P(bo), B, L, D, H, 0.0, 0.0, None, 0, 0, P(y1), P(mr1), P(qkv), P(att), P(lse), P(parts), P(o), P(y2), P(mr2), st())
 for dbg in (1, 2, 3, 0):
-    os.environ["SATRN_EA_DBG"] = str(dbg)
+    os.environ["SATRN_TIMING"] = "ea_dbg=" + str(str(dbg))
     for _ in range(5): run()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

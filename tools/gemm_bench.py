@@ -28,4 +28,4 @@ for M, N, K in shapes:
         us = bench(lambda: lib.satrn_linear_fwd(1, P(x), P(w), None, P(y), M, N, K, 0, 0, 0.0, None, 0, st()))
     else:
         us = bench(lambda: lib.satrn_linear_bwd_weight(1, P(dy), N, P(x), P(dw), None, M, N, K, st()))
-    print(f"{which} M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:8.1f} TFLOP/s  force={os.environ.get('SATRN_GEMM_FORCE','-')}")
+    print(f"{which} M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:8.1f} TFLOP/s  knobs={os.environ.get('SATRN_KNOBS', '-')}")

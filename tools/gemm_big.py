@@ -37,4 +37,4 @@ for M, N, K in SHAPES:
         us = bench(lambda: lib.satrn_linear_fwd(1, P(x), P(w), P(b), P(y), M, N, K, 0, 0, 0.0, None, 0, st()))
     else:
         us = bench(lambda: lib.satrn_linear_fwd(1, P(x), P(w), None, P(y), M, N, K, 0, 0, 0.0, None, 0, st()))
-    print(f"M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TFLOP/s  force={os.environ.get('SATRN_GEMM_FORCE','-')}")
+    print(f"M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TFLOP/s  knobs={os.environ.get('SATRN_KNOBS', '-')}")

@@ -1,9 +1,10 @@
 """Correctness + throughput of the persistent direct-to-LDS GEMM (kernels_gemm_big.hip) through the C-ABI linear operator
-(run on the GPU box).  SATRN_GEMM_BIG=2 makes every shape that fits take the kernel; =0 is the 4-wave tile kernel."""
+(run on the GPU box).  SATRN_KNOBS=gemm_big=2 makes every shape that fits take the kernel; gemm_big=0 is the 4-wave tile kernel."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import satrn_amd
+from satrn_amd import switches as sw
 lib = satrn_amd._lib.load()
 P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -20,7 +21,7 @@ def bench(fn, iters=50):
 
 
 def run(M, N, K, bias, act, mode):
-    os.environ["SATRN_GEMM_BIG"] = str(mode)
+    sw.knob("gemm_big", str(mode))
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = (torch.rand(M, K, device="cuda", generator=g) * 2 - 1).bfloat16(); w = (torch.rand(N, K, device="cuda", generator=g) * 2 - 1).bfloat16()
     b = (torch.rand(N, device="cuda", generator=g) * 2 - 1) if bias else None
@@ -63,14 +64,14 @@ if __name__ == "__main__":
             y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             line = f"M={M:6d} N={N:5d} K={K:5d}:"
             for mode in ("0", "2"):
-                os.environ["SATRN_GEMM_BIG"] = mode
+                sw.knob("gemm_big", mode)
                 us = bench(lambda: lib.satrn_linear_fwd(1, P(x), P(w), None, P(y), M, N, K, 0, 0, 0.0, None, 0, st()))
                 gb = (M * K + N * K + M * N) * 2 / us / 1e3
                 line += f"  [{'old' if mode == '0' else 'big'}] {us:8.1f} us {2.0*M*N*K/us/1e6:7.1f} TF {gb:6.0f} GB/s"
             if (M, N, K) in ((9216, 2048, 512), (147456, 512, 128)):
                 b = torch.rand(N, device="cuda")
                 for mode in ("0", "2"):
-                    os.environ["SATRN_GEMM_BIG"] = mode
+                    sw.knob("gemm_big", mode)
                     us = bench(lambda: lib.satrn_linear_fwd(1, P(x), P(w), P(b), P(y), M, N, K, 4, 0, 0.0, None, 0, st()))
                     line += f"  [{'old' if mode == '0' else 'big'} +bias+GELU] {us:8.1f} us"
             print(line, flush=True)

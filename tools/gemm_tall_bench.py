@@ -1,10 +1,11 @@
 """The tall, thin dense products of the fused-MBConv stages through the C-ABI (satrn_linear_fwd_stats): row-streaming kernel
-(SATRN_GEMM_TALL=2) against the tile kernel (SATRN_GEMM_TALL=0), cold operands (a rotation of buffer sets larger than the Infinity Cache).
+(SATRN_KNOBS=gemm_tall=2) against the tile kernel (gemm_tall=0), cold operands (a rotation of buffer sets larger than the Infinity Cache).
 GPU box:  python tools/gemm_tall_bench.py  -> one line per shape and kernel: us, algorithmic GB/s"""
 import ctypes, math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import satrn_amd
+from satrn_amd import switches as sw
 lib = satrn_amd._lib.load()
 P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
 st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -21,8 +22,8 @@ for M, N, K, bnb in SHAPES:
     stats = torch.zeros(rep * 2 * N, device="cuda")
     byt = (M * K + M * N * (2 if bnb else 1) + N * K) * 2
     for mode in ("0", "2"):
-        os.environ["SATRN_GEMM_TALL"] = mode
-        os.environ["SATRN_GEMM_BIG"] = "0"
+        sw.knob("gemm_tall", mode)
+        sw.knob("gemm_big", "0")
         def call(i):
             lib.satrn_linear_fwd_stats(1, P(xs[i % nset]), P(w), P(ys[i % nset]), M, N, K, P(stats), rep, P(bys[i % nset]), P(ss) if bnb else None, P(mr) if bnb else None, bnb, 0, st())
         for i in range(6): call(i)

@@ -1,7 +1,7 @@
 """Host time needed to ISSUE one training step vs the GPU time it takes (run on the GPU box).
   python3 tools/host_issue.py            # steps queued back to back
   python3 tools/host_issue.py --sync     # the GPU is idle when every step starts
-With SATRN_HOST_PROF=1 the engine also prints the forward / backward / optimizer split of the issue time."""
+With SATRN_PROF=host the engine also prints the forward / backward / optimizer split of the issue time."""
 import os
 import sys
 import time

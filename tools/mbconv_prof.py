@@ -1,7 +1,7 @@
-"""Phase marks of the MBConv front kernel inside the training step (GPU box):  SATRN_MB_PROF=1 python tools/mbconv_prof.py 2> marks.txt
+"""Phase marks of the MBConv front kernel inside the training step (GPU box):  SATRN_PROF=mb python tools/mbconv_prof.py 2> marks.txt
 Every launch of the kernel synchronises and prints the wall-clock marks of its four corner workgroups (kernels_mbconv.hip)."""
 import os, sys
-os.environ.setdefault("SATRN_MB_PROF", "1")
+os.environ.setdefault("SATRN_PROF", "mb")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench

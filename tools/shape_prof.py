@@ -1,6 +1,6 @@
-"""Per-launch event profile of one training step split by problem size (SATRN_PROF_SHAPES=1)."""
+"""Per-launch event profile of one training step split by problem size (SATRN_PROF=shapes)."""
 import os, sys
-os.environ["SATRN_PROF_SHAPES"] = "1"
+os.environ["SATRN_PROF"] = "shapes"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench

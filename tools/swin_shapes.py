@@ -1,4 +1,4 @@
-"""Per-launch event profile of one SwinTRN training step split by problem size (SATRN_PROF_SHAPES=1; run on the GPU box)."""
+"""Per-launch event profile of one SwinTRN training step split by problem size (SATRN_PROF=shapes; run on the GPU box)."""
 import os, sys
 os.environ["SATRN_PROF_SHAPES"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """Dense bf16 weight-gradient throughput of the C-ABI operator (run on the GPU box): dW[N][K] += dY^T X over M rows, on the shapes
-of the SwinTRN and EfficientSATRN steps.  SATRN_WGRAD_BLOCKS sets the grid target (default 96: the partial grid of the side stream)."""
+of the SwinTRN and EfficientSATRN steps.  SATRN_KNOBS=wgrad_blocks=N sets the grid target (default 96: the partial grid of the side stream)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -39,4 +39,4 @@ for M, N, K in SHAPES:
         print(f"M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TFLOP/s  cold ({nset} operand sets)")
         continue
     us = bench(lambda: lib.satrn_linear_bwd_weight(1, P(dy), N, P(x), P(dw), P(db) if WITH_BIAS else None, M, N, K, st()))
-    print(f"M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TFLOP/s  blocks={os.environ.get('SATRN_WGRAD_BLOCKS','96')} ms128={'off' if os.environ.get('SATRN_WGRAD_NO_MS128') else 'on'}")
+    print(f"M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TFLOP/s  knobs={os.environ.get('SATRN_KNOBS', '-')} ms128={'off' if os.environ.get('SATRN_WGRAD_NO_MS128') else 'on'}")

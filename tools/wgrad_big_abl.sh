@@ -3,8 +3,8 @@ export SHAPES="9216,1536,384;9216,384,1536;9216,1152,384;9216,384,384;36864,768,
 for wb in 1 ""; do
 for dbg in 0 1 2 4 8; do
   echo "== WITH_BIAS=$wb DBG=$dbg"
-  WITH_BIAS=$wb SATRN_BIG_DBG=$dbg python3 tools/wgrad_big.py 2>&1 | grep "M="
+ WITH_BIAS=$wb SATRN_TIMING=big_dbg=$dbg python3 tools/wgrad_big.py 2>&1 | grep "M="
 done
 done
 echo "== old kernel"
-SATRN_WGRAD_BIG=0 python3 tools/wgrad_big.py 2>&1 | grep "M="
+SATRN_KNOBS=wgrad_big=0 python3 tools/wgrad_big.py 2>&1 | grep "M="

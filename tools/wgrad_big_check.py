@@ -10,7 +10,7 @@ for M, N, K in SHAPES:
     dw = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda")
     line = f"M={M:6d} N={N:5d} K={K:5d}:"
     for mode in ("0", "2"):
-        os.environ["SATRN_WGRAD_BIG"] = mode
+        sw.knob("wgrad_big", mode)
         us = bench(lambda: lib.satrn_linear_bwd_weight(1, P(dy), N, P(x), P(dw), P(db), M, N, K, st()))
         us2 = bench(lambda: lib.satrn_linear_bwd_weight(1, P(dy), N, P(x), P(dw), None, M, N, K, st()))
         line += f"  [{'old' if mode == '0' else 'big'}] +db {us:7.1f} us {2.0*M*N*K/us/1e6:6.1f} TF | no db {us2:7.1f} us {2.0*M*N*K/us2/1e6:6.1f} TF"
