@@ -7,7 +7,7 @@
 #   5. the default bench line                                      -> profiles/<tag>_bench_default.json
 # Every rocprofv3 command has the program itself after `--` and never mixes --pmc with the trace domains gpurun refuses.
 set -e -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT" gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma gpurun_out/pmc_region
