@@ -253,6 +253,7 @@ const StageDef kEffV2S[6] = {{0, 2, 1, 1, 24, 0.f},   {1, 4, 2, 4, 48, 0.f},   {
 static void segment_ranges(Model* m);
 
 Model* model_create(const SatrnConfig& cfg) {
+  sw_refresh();
   Model* m = new Model();
   m->cfg = cfg;
   Builder b{m};
@@ -2118,6 +2119,7 @@ Tensor* decoder_tf(Exec& e, Tensor* src, const int64_t* expected, int B, int L, 
 // the reduction mode is process-global state of the kernel launchers: every engine entry point that launches work selects
 // its own model's mode first
 static void det_activate(Model* m) {
+  sw_refresh();
   g_det.on = (m->det_floats && m->ws) ? 1 : 0;
   g_det.cap = m->det_floats;
   g_det.scratch[0] = g_det.on ? (float*)(m->ws + m->off_det) : nullptr;

@@ -50,13 +50,14 @@ void launch_fold4(const float* part, int nrep, long stride, long n, float* out, 
 void det_overflow_warn(size_t need_floats);
 // ---- run-time switches: FOUR environment variables (round 4; the library used to read ~70 SATRN_* names) -------------------------------
 //   SATRN_OFF    = comma-separated features whose current form is switched OFF, i.e. the form it replaced runs (A/B levers of tests and
-//                  tools; read per call unless noted), e.g. SATRN_OFF=mbconv_front,gemm_g2
+//                  tools; re-read at every C-ABI call), e.g. SATRN_OFF=mbconv_front,gemm_g2
 //   SATRN_KNOBS  = name=value,...  tuning knobs, opt-in forms and the tri-state routes (gemm_big / wgrad_big / conv_big / gemm_tall = 0 off,
 //                  1 by size, 2 every shape that fits)
 //   SATRN_PROF   = comma-separated diagnostics: stage, host, join, shapes, pipe, dec, mb
 //   SATRN_TIMING = name[=value],...  timing experiments that SKIP work (results are WRONG; announced once on stderr): skip_wgrad,
 //                  no_stats_atomics, big_dbg, a2_dbg, ea_dbg
 // (modes keep their own names: SATRN_DETERMINISTIC, SATRN_NONDET, SATRN_PIPE_STRICT)
+void sw_refresh();   // re-read the four variables (every C-ABI entry point calls it; launches consult the snapshot)
 bool sw_off(const char* name);
 bool sw_knob_set(const char* name);
 long sw_knob(const char* name, long dflt);

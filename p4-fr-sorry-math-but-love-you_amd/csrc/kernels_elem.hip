@@ -6,6 +6,7 @@
 #include "tile_dev.h"
 #include <atomic>
 #include <cstring>
+#include <string>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -53,10 +54,24 @@ long resident_capacity(const void* kernel, int threads, size_t lds_bytes) {
   cache[key] = cap;
   return cap;
 }
-// -> just behind `name` inside the list held by environment variable `env` (at '=', a separator or the end), or null
-static const char* sw_find(const char* env, const char* name) {
-  const char* s = getenv(env);
-  if (!s) return nullptr;
+// The four lists are read from the environment by sw_refresh() -- once per C-ABI call (operator entry points, every engine entry point) --
+// and kept parsed-ready here: a launch consults the snapshot (an empty list answers at once) instead of scanning `environ` several times
+// per launch (6-8 getenv calls of ~0.3 us each per product: a third of the host's time per launch on the launch-bound paths, e.g. the
+// 16 000 launches of the autoregressive training branch).
+static std::string g_sw[4];   // SATRN_OFF, SATRN_KNOBS, SATRN_PROF, SATRN_TIMING
+void sw_refresh() {
+  static const char* names[4] = {"SATRN_OFF", "SATRN_KNOBS", "SATRN_PROF", "SATRN_TIMING"};
+  for (int i = 0; i < 4; ++i) {
+    const char* v = getenv(names[i]);
+    if (!v) { if (!g_sw[i].empty()) g_sw[i].clear(); }
+    else if (g_sw[i] != v) g_sw[i] = v;
+  }
+}
+static const bool g_sw_init = (sw_refresh(), true);
+// -> just behind `name` inside list `which` (at '=', a separator or the end), or null
+static const char* sw_find(int which, const char* name) {
+  if (g_sw[which].empty()) return nullptr;
+  const char* s = g_sw[which].c_str();
   const size_t n = strlen(name);
   while (*s) {
     while (*s == ',' || *s == ' ') ++s;
@@ -65,14 +80,14 @@ static const char* sw_find(const char* env, const char* name) {
   }
   return nullptr;
 }
-bool sw_off(const char* name) { return sw_find("SATRN_OFF", name) != nullptr; }
-bool sw_knob_set(const char* name) { const char* p = sw_find("SATRN_KNOBS", name); return p && *p == '='; }
-long sw_knob(const char* name, long dflt) { const char* p = sw_find("SATRN_KNOBS", name); return (p && *p == '=') ? atol(p + 1) : dflt; }
-double sw_knobf(const char* name, double dflt) { const char* p = sw_find("SATRN_KNOBS", name); return (p && *p == '=') ? atof(p + 1) : dflt; }
-const char* sw_knob_str(const char* name) { const char* p = sw_find("SATRN_KNOBS", name); return (p && *p == '=') ? p + 1 : nullptr; }
-bool sw_prof(const char* name) { return sw_find("SATRN_PROF", name) != nullptr; }
+bool sw_off(const char* name) { return sw_find(0, name) != nullptr; }
+bool sw_knob_set(const char* name) { const char* p = sw_find(1, name); return p && *p == '='; }
+long sw_knob(const char* name, long dflt) { const char* p = sw_find(1, name); return (p && *p == '=') ? atol(p + 1) : dflt; }
+double sw_knobf(const char* name, double dflt) { const char* p = sw_find(1, name); return (p && *p == '=') ? atof(p + 1) : dflt; }
+const char* sw_knob_str(const char* name) { const char* p = sw_find(1, name); return (p && *p == '=') ? p + 1 : nullptr; }
+bool sw_prof(const char* name) { return sw_find(2, name) != nullptr; }
 int sw_timing(const char* name) {
-  const char* p = sw_find("SATRN_TIMING", name);
+  const char* p = sw_find(3, name);
   if (!p) return 0;
   const int x = *p == '=' ? atoi(p + 1) : 1;
   if (x) fprintf(stderr, "[satrn] WARNING: SATRN_TIMING %s=%d -- a timing experiment: work is skipped and results are WRONG\n", name, x);

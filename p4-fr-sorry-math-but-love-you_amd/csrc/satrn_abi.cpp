@@ -18,7 +18,7 @@ static int done(const char* what) {
 }
 #define S(x) ((hipStream_t)(x))
 // operator-level calls have no engine workspace behind them: they always use the atomic reduction forms
-#define CHK_DT(dt) do { g_det.on = 0; g_sebox.box = nullptr; g_sebox.images = 0; g_sebox.bwd = false; g_mbbox.box = nullptr; g_mbbox.words = 0; g_mbbox.images = 0; g_wgpart.cap = 0; if ((dt) != 0 && (dt) != 1) return fail(-1, "dtype must be 0 (f32) or 1 (bf16)"); } while (0)
+#define CHK_DT(dt) do { sw_refresh(); g_det.on = 0; g_sebox.box = nullptr; g_sebox.images = 0; g_sebox.bwd = false; g_mbbox.box = nullptr; g_mbbox.words = 0; g_mbbox.images = 0; g_wgpart.cap = 0; if ((dt) != 0 && (dt) != 1) return fail(-1, "dtype must be 0 (f32) or 1 (bf16)"); } while (0)
 static int chk_c(int dt, int c, const char* what) {
   int ch = dt == DT_BF16 ? 8 : 4;
   if (c <= 0 || c % ch) return fail(-1, std::string(what) + " must be a positive multiple of " + std::to_string(ch));
