@@ -40,9 +40,13 @@ def kind_of(name, p):
     return "weight"
 
 
-def run(dt, img, exp, H, W, bn_eval):
+def run(dt, img, exp, H, W, bn_eval, round_w=False):
     torch.manual_seed(21)
     m = bench.make_model(dt, H, W, 0.0).to(img.device)
+    if round_w:   # master weights made bf16-representable: what the bf16 mode's compute copies hold
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.copy_(p_.bfloat16().float())
     m.train()
     m.enable_probes(True)
     if bn_eval:
@@ -76,12 +80,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--bn-eval", action="store_true")
+    ap.add_argument("--split", choices=["none", "weights", "acts"], default="none",
+                    help="weights: f32 engine with bf16-rounded weights against the f32 engine; acts: bf16 engine against the f32 engine, both on bf16-rounded weights")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     H, W, T, B = 128, 384, 128, a.batch
     img, exp = bench.synth(B, H, W, T, 21, dev)
-    f = run("f32", img, exp, H, W, a.bn_eval)
-    b = run("bf16", img, exp, H, W, a.bn_eval)
+    f = run("f32", img, exp, H, W, a.bn_eval, a.split == "acts")
+    b = run("f32" if a.split == "weights" else "bf16", img, exp, H, W, a.bn_eval, a.split != "none")
     out = dict(config=f"EfficientSATRN B={B} 1x{H}x{W} T={T}, dropout off, training-mode BatchNorm (batch statistics); bf16 engine against the f32 engine, same weights and batch",
                loss_f32=f["loss"], loss_bf16=b["loss"], logits_rel_err=rel(b["logits"], f["logits"]),
                flat_grad_rel_l2=rel(b["flat"], f["flat"]), flat_grad_cosine=cos(b["flat"], f["flat"]))
