@@ -239,6 +239,18 @@ int satrn_bn_bwd_apply_dwconv3x3_bwd_data_bnred(int dtype, const void* dz2, cons
                                                 const float* scratch2_b, void* dy2, float* dweight_b, float* dbias_b, const void* dw_packed,
                                                 void* dz, int accumulate, const void* y, const float* scratch, int act, float* scratch2, int B,
                                                 int H, int W, int C, void* stream);
+/* ... and the WHOLE backward of the BatchNorm in front of the convolution as well (bf16; z = act(bn_a(y)) is what the convolution read):
+ * satrn_bn_bwd_apply_dwconv3x3_bwd_data_bnred + satrn_batchnorm_act_bwd_apply(dz, y, weight_a, scratch, act, ...) in one launch.  The B
+ * workgroups of a 64-channel slab exchange their shares of that BatchNorm's two column sums through `mailbox` (B * (C / 64) * 128 8-byte
+ * words, ZERO before the first call, shareable with the other mailbox operators) and write dy1 = the gradient of bn_a's input straight from
+ * their registers; dz (the gradient of z) is never stored.  dweight_a / dbias_a (+)= bn_a's parameter gradients.  The launch needs the
+ * whole grid resident: returns -1 for shapes / batch sizes it does not take (call the two operators instead).
+ * Reference: the backward of timm's InvertedResidual bn1 -> act1 -> conv_dw -> bn2 (networks/EfficientSATRN.py:74,84). */
+int satrn_bn_bwd_apply_dwconv3x3_bwd_data_bn_bwd(const void* dz2, const void* y2, const float* weight_b, const float* scratch_b, int act_b,
+                                                 const float* scratch2_b, void* dy2, float* dweight_b, float* dbias_b, const void* dw_packed,
+                                                 const void* y, const float* weight_a, const float* scratch, int act, void* dy1, float* dweight_a,
+                                                 float* dbias_a, int B, int H, int W, int C, unsigned long long* mailbox, long mailbox_words,
+                                                 void* stream);
 /* the second half of satrn_batchnorm_act_bwd for callers that already hold the column sums in scratch2 */
 int satrn_batchnorm_act_bwd_apply(int dtype, const void* dz, const void* y, const float* weight, const float* scratch, int act,
                                   void* dy, float* dweight, float* dbias, long M, int C, const float* scratch2, void* stream);
@@ -527,7 +539,8 @@ int satrn_device_error(void* stream);
  * launchers).  out[i], i < n: 0 persistent GEMM (dense), 1 persistent GEMM (3x3 convolution / data gradient), 2 persistent weight
  * gradient, 3 tile GEMM (gemm_kernel family incl. halo convolution and skinny), 4 tile weight gradient, 5 BatchNorm + squeeze-and-excite
  * in one launch, 6 MBConv block front in one launch (expand .. squeeze-and-excite), 7 MBConv backward (projection data gradient + squeeze-and-excite) in
- * one launch, 8 row-streaming kernel for tall, thin dense products; the rest 0.
+ * one launch, 8 row-streaming kernel for tall, thin dense products, 9 autoregressive training branch as one forward launch
+ * (kernels_ar.hip); the rest 0.
  * reset != 0 clears them after the read.  Returns the number of defined routes. */
 int satrn_route_counts(long long* out, int n, int reset);
 float* satrn_model_adam_state(satrn_model* m, int which /*0 exp_avg, 1 exp_avg_sq*/);

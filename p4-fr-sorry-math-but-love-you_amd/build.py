@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsatrn_hip.so")
-SOURCES = ["kernels_gemm.hip", "kernels_gemm_big.hip", "kernels_gemm_tall.hip", "kernels_elem.hip", "kernels_attn.hip", "kernels_attn2.hip", "kernels_encattn.hip", "kernels_se.hip", "kernels_mbconv.hip", "kernels_decode.hip", "kernels_image.hip", "kernels_swin.hip", "engine.cpp", "satrn_abi.cpp"]
+SOURCES = ["kernels_gemm.hip", "kernels_gemm_big.hip", "kernels_gemm_tall.hip", "kernels_elem.hip", "kernels_attn.hip", "kernels_attn2.hip", "kernels_encattn.hip", "kernels_se.hip", "kernels_mbconv.hip", "kernels_ar.hip", "kernels_decode.hip", "kernels_image.hip", "kernels_swin.hip", "engine.cpp", "satrn_abi.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 

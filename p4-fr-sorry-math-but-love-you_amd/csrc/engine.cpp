@@ -943,10 +943,11 @@ Tensor* op_bn_act(Exec& e, Tensor* y, BNp* bn, int act, Tensor* res, float** poo
                        res ? res->p : nullptr, z->p, M, C, act, e.s));
   used(y); used(res);
   if (e.rec) {
-    if (e.train) { z->bn_y = y->p; z->bn_ss = ss; z->bn_mr = mr; z->bn_act = act; z->bn_has_res = res != nullptr; }
+    if (e.train) { z->bn_y = y->p; z->bn_ss = ss; z->bn_mr = mr; z->bn_act = act; z->bn_has_res = res != nullptr; z->bn_src = y; z->bn_p = bn; }
     const int eval_stats = e.train ? 0 : 1;  // recorded forward with running statistics: dy = dz * act' * w * rstd, no batch terms
     e.tape.push_back([&e, y, z, bn, act, res, ss, mr, M, C, eval_stats]() {
       if (!z->g) return;
+      if (z->bn_applied) return;   // the kernel that produced z's gradient went on through this BatchNorm (op_dwconv's closure, no residual)
       float* red = z->bn_red;  // already produced by the epilogue of the last kernel that wrote z's gradient?
       if (!red) {
         red = e.zalloc(2 * C);
@@ -1058,7 +1059,17 @@ Tensor* op_dwconv(Exec& e, Tensor* x, Wt* w, Vec* bias, int stride, int OH, int 
       void* dx = e.grad(x, &beta);
       BnBwdHold* hold = y->bhold.armed ? &y->bhold : nullptr;
       bool fused = false;
-      if ((fuse_bnb || hold) && !e.dry && !x->bn_red) {
+      if (fuse_bnb && hold && !beta && !e.dry && !x->bn_red && x->bn_src && x->bn_p && e.train) {
+        // ... and through the BatchNorm in front as well: x's gradient never leaves the kernel, the gradient of that BatchNorm's input does
+        Tensor* src = x->bn_src;
+        const bool had = src->g != nullptr;
+        BnBwdTail tl;
+        tl.dy = e.grad(src, nullptr); tl.w = x->bn_p->w.p; tl.dwp = x->bn_p->w.g; tl.dbp = x->bn_p->b.g;
+        WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * OH * OW * 4 + (double)B * H * W * 2) * C * e.esz());
+        if (!had) LCH(e, fused = launch_dwconv_bwd_bn(e.dt, y->g, w->fwd, dx, 0, x->bn_y, x->bn_ss, x->bn_mr, x->bn_act, nullptr, B, H, W, C, e.s, hold, &tl));
+        if (fused) x->bn_applied = true;
+      }
+      if (!fused && (fuse_bnb || hold) && !e.dry && !x->bn_red) {
         float* red = fuse_bnb ? e.zalloc((size_t)2 * C) : nullptr;
         WORK(e, 18.0 * (double)B * OH * OW * C, ((double)B * OH * OW * (hold ? 4 : 2) + (double)B * H * W * (beta ? 2 : 1)) * C * e.esz());
         LCH(e, fused = launch_dwconv_bwd_bn(e.dt, y->g, w->fwd, dx, beta, fuse_bnb ? x->bn_y : nullptr, x->bn_ss, x->bn_mr, x->bn_act, red, B, H, W, C, e.s, hold));
@@ -2089,6 +2100,141 @@ Tensor* decoder_ar(Exec& e, Tensor* src, int B, int L, float* logits_out) {
   return full;
 }
 
+// one weight gradient over a [M][N] slab of output gradients and the [M][K] slab of the product's inputs (the side stream's work, as in
+// op_gemm's closure; the bias gradient rides in the same launch)
+static void wgrad_slab(Exec& e, Wt* w, Vec* bias, const void* dY, int ldy, const void* A, int lda, long M, int N) {
+  WgradP q;
+  memset(&q, 0, sizeof(q));
+  q.dY = dY; q.A = A; q.dW = w->g; q.M = (int)M; q.N = N; q.K = w->K; q.ldy = ldy; q.lda = lda;
+  q.nbatch = 1; q.nb_inner = 1;
+  q.full_grid = (e.serial || !e.s2 || e.prof) ? 1 : 0;
+  float* bg = bias ? bias->g : nullptr;
+  if (bg && !sw_off("wgrad_bias") && !g_det.on) { q.dbias = bg; bg = nullptr; }
+  const int dt = e.dt;
+  if (e.prof || e.dry) {
+    if (bg) { WORK(e, 0, (double)M * N * e.esz()); LCH(e, launch_colsum(dt, dY, M, N, ldy, bg, e.s)); }
+    WORK(e, 2.0 * (double)M * N * w->K, ((double)M * N + (double)M * w->K) * e.esz() + (double)N * w->K * 4);
+    LCH(e, launch_wgrad(dt, q, e.s));
+  } else {
+    e.defer([=](hipStream_t ws) {
+      if (bg) launch_colsum(dt, dY, M, N, ldy, bg, ws);
+      launch_wgrad(dt, q, ws);
+    });
+  }
+}
+
+// The same branch as decoder_ar in two launches (kernels_ar.hip: one workgroup per image runs all T steps of a direction) plus one
+// product per weight over [B*T]-row slabs: 2 + 26 launches instead of ~126 per step.
+Tensor* decoder_ar_fused(Exec& e, Tensor* src, int B, int L, float* logits_out) {
+  Model* m = e.m;
+  const SatrnConfig& c = m->cfg;
+  const int T = L - 1, D = c.dec_hidden, F = c.dec_filter, V = c.num_classes, Nsrc = (int)(src->rows / B), H = c.dec_heads;
+  const int nl = (int)m->dec.size();
+  const size_t es = e.esz();
+  const long R = (long)B * T;
+  std::vector<Tensor*> crossKV(nl);
+  for (int l = 0; l < nl; ++l) crossKV[l] = op_gemm(e, src, &m->dec[l].cross_att.kv, &m->dec[l].cross_att.bkv, ACT_NONE, 0.f, nullptr);
+  e.tens.emplace_back(new Tensor());
+  Tensor* full = e.tens.back().get();
+  if (!logits_out) logits_out = (float*)e.alloc((size_t)R * V * sizeof(float));
+  full->rows = R; full->C = V; full->f32 = true; full->p = logits_out;
+  auto ap = std::make_shared<ArP>();
+  memset(ap.get(), 0, sizeof(ArP));
+  auto slab = [&](int C) { return e.alloc((size_t)R * C * es); };
+  // k-panel-major copies of every weight and of its transpose (the packed backward copy is W^T row-major): re-made per call, the
+  // weights change every step
+  auto kp = [&](const void* w, int N, int K) -> const void* {
+    void* d = e.alloc((size_t)N * K * es);
+    WORK(e, 0, (double)N * K * es * 2);
+    if (d) LCH(e, launch_repack_kpanel(e.dt, w, d, N, K, e.s));
+    return d;
+  };
+  for (int l = 0; l < nl; ++l) {
+    DecLayer& dl = m->dec[l];
+    ArLayer& w = ap->L[l];
+    w.wqkv = kp(dl.self_att.qkv.fwd, 3 * D, D); w.wqkvT = kp(dl.self_att.qkv.bwd, D, 3 * D);
+    w.wo = kp(dl.self_att.out.fwd, D, D); w.woT = kp(dl.self_att.out.bwd, D, D);
+    w.wq2 = kp(dl.cross_att.qkv.fwd, D, D); w.wq2T = kp(dl.cross_att.qkv.bwd, D, D);
+    w.wo2 = kp(dl.cross_att.out.fwd, D, D); w.wo2T = kp(dl.cross_att.out.bwd, D, D);
+    w.w0 = kp(dl.lin0.fwd, F, D); w.w0T = kp(dl.lin0.bwd, D, F);
+    w.w1 = kp(dl.lin1.fwd, D, F); w.w1T = kp(dl.lin1.bwd, F, D);
+    w.bqkv = dl.self_att.bqkv.p; w.bo = dl.self_att.bout.p; w.bq2 = dl.cross_att.bqkv.p; w.bo2 = dl.cross_att.bout.p; w.b0 = dl.b0.p; w.b1 = dl.b1.p;
+    w.ln1w = dl.ln1.w.p; w.ln1b = dl.ln1.b.p; w.ln2w = dl.ln2.w.p; w.ln2b = dl.ln2.b.p; w.ln3w = dl.ln3.w.p; w.ln3b = dl.ln3.b.p;
+    w.dln1w = dl.ln1.w.g; w.dln1b = dl.ln1.b.g; w.dln2w = dl.ln2.w.g; w.dln2b = dl.ln2.b.g; w.dln3w = dl.ln3.w.g; w.dln3b = dl.ln3.b.g;
+    w.crossKV = crossKV[l]->p;
+    w.cache = slab(2 * D);
+    w.q = slab(D); w.kvin = slab(2 * D); w.att = slab(D); w.s1 = slab(D); w.t1 = slab(D); w.q2 = slab(D); w.a2 = slab(D); w.s2 = slab(D);
+    w.t2 = slab(D); w.f0 = slab(F); w.f1d = slab(D);
+  }
+  for (int l = 0; l <= nl; ++l) ap->xs[l] = slab(D);
+  ap->nlayers = nl; ap->embed = m->embed.p; ap->pe = (const float*)(m->ws + m->off_pe1d); ap->wgen = kp(m->gen.fwd, V, D); ap->bgen = m->gen_b.p;
+  ap->logits = logits_out;
+  ap->ids = (int64_t*)e.alloc((size_t)R * 8); ap->in_ids = (int64_t*)e.alloc((size_t)R * 8);
+  ap->B = B; ap->T = T; ap->D = D; ap->F = F; ap->V = V; ap->H = H; ap->Nsrc = Nsrc; ap->sos = c.sos_id;
+  const bool drop = e.train && e.drop > 0.f;
+  ap->p_att = drop ? e.drop : 0.f; ap->p_res = drop ? e.drop : 0.f;
+  ap->p_ff = drop ? 0.1f : 0.f;   // Feedforward dropout is hard-wired to 0.1 (networks/EfficientSATRN.py:327)
+  ap->seed = (const uint32_t*)(scal(m) + SC_SEED); ap->site = drop ? e.site++ : 0;
+  // per step and image: 15 D^2 + 2 D F multiply-accumulates per layer + the generator; the weights are streamed once per step and image
+  WORK(e, 2.0 * (double)R * (nl * (7.0 * D * D + 2.0 * D * F) + (double)D * V), (double)R * (nl * (7.0 * D * D + 2.0 * D * F) + (double)D * V) * es);
+  LCH(e, launch_ar_fwd(e.dt, *ap, e.s));
+  if (e.rec)
+    e.tape.push_back([&e, m, ap, full, crossKV, B, T, D, F, V, Nsrc, nl, R, es]() {
+      if (!full->g) return;
+      const int Vp = m->gen.ldb;
+      // generator: its data gradient for all steps in one product, its weight gradient over the slab
+      void* dxtop = e.alloc((size_t)R * D * es);
+      {
+        GemmP d;
+        memset(&d, 0, sizeof(d));
+        d.A = full->g; d.Bw = m->gen.bwd; d.C = dxtop; d.M = (int)R; d.N = D; d.K = Vp; d.lda = Vp; d.ldc = D;
+        WORK(e, 2.0 * (double)R * D * V, ((double)R * Vp + (double)R * D + (double)V * D) * es);
+        LCH(e, launch_gemm(e.dt, AM_DENSE, d, e.s));
+      }
+      wgrad_slab(e, &m->gen, &m->gen_b, full->g, Vp, ap->xs[nl], D, R, V);
+      ap->dxtop = dxtop; ap->dx0 = e.alloc((size_t)R * D * es);
+      ap->lnpart = (float*)e.alloc((size_t)B * nl * 6 * D * 4);
+      for (int l = 0; l < nl; ++l) {
+        ArLayer& w = ap->L[l];
+        w.dqkvi = e.alloc((size_t)R * 3 * D * es); w.dkvo = e.alloc((size_t)R * 2 * D * es); w.dout = e.alloc((size_t)R * D * es);
+        w.dq2 = e.alloc((size_t)R * D * es); w.dout2 = e.alloc((size_t)R * D * es); w.df0 = e.alloc((size_t)R * F * es); w.df1 = e.alloc((size_t)R * D * es);
+        w.dkvacc = (float*)e.alloc((size_t)R * 2 * D * 4);
+        w.dcross = (float*)e.alloc((size_t)B * Nsrc * 2 * D * 4);
+        WORK(e, 0, (double)R * 2 * D * 4);
+        if (w.dkvacc) LCH(e, launch_fill(w.dkvacc, 0, (size_t)R * 2 * D * 4, e.s));
+        WORK(e, 0, (double)B * Nsrc * 2 * D * 4);
+        if (w.dcross) LCH(e, launch_fill(w.dcross, 0, (size_t)B * Nsrc * 2 * D * 4, e.s));
+      }
+      WORK(e, 2.0 * (double)R * nl * (8.0 * D * D + 2.0 * D * F), (double)R * nl * (8.0 * D * D + 2.0 * D * F) * es);
+      LCH(e, launch_ar_bwd(e.dt, *ap, e.s));
+      for (int l = 0; l < nl; ++l) {
+        DecLayer& dl = m->dec[l];
+        ArLayer& w = ap->L[l];
+        wgrad_slab(e, &dl.self_att.qkv, &dl.self_att.bqkv, w.dqkvi, 3 * D, ap->xs[l], D, R, 3 * D);
+        wgrad_slab(e, &dl.self_att.kv, &dl.self_att.bkv, w.dkvo, 2 * D, ap->xs[l + 1], D, R, 2 * D);
+        wgrad_slab(e, &dl.self_att.out, &dl.self_att.bout, w.dout, D, w.att, D, R, D);
+        wgrad_slab(e, &dl.cross_att.qkv, &dl.cross_att.bqkv, w.dq2, D, w.t1, D, R, D);
+        wgrad_slab(e, &dl.cross_att.out, &dl.cross_att.bout, w.dout2, D, w.a2, D, R, D);
+        wgrad_slab(e, &dl.lin0, &dl.b0, w.df0, F, w.t2, D, R, F);
+        wgrad_slab(e, &dl.lin1, &dl.b1, w.df1, D, w.f0, F, R, D);
+        // the cross-attention keys / values: their product's closure (recorded before this one) takes it from here
+        Tensor* kvt = crossKV[l];
+        kvt->g = e.alloc((size_t)kvt->rows * kvt->C * es);
+        kvt->g_init = true;
+        WORK(e, 0, (double)kvt->rows * kvt->C * (4 + es));
+        if (kvt->g && w.dcross) LCH(e, launch_cast(DT_F32, e.dt, w.dcross, kvt->g, kvt->rows * kvt->C, e.s));
+      }
+      WORK(e, 0, (double)R * D * (4 + es));
+      LCH(e, launch_embed_bwd(e.dt, ap->in_ids, ap->dx0, m->embed.g, B, T, T, D, 0.f, ap->seed, 0, e.s, m->embed.N));
+    });
+  return full;
+}
+
+static bool ar_fused_ok(Exec& e, Tensor* src, int B, int L) {
+  const SatrnConfig& c = e.m->cfg;
+  return ar_train_ok(e.dt, c.dec_hidden, c.dec_filter, c.num_classes, c.dec_heads, L - 1, (int)(src->rows / B), (int)e.m->dec.size());
+}
+
 Tensor* decoder_tf(Exec& e, Tensor* src, const int64_t* expected, int B, int L, float* logits_out) {
   Model* m = e.m;
   const SatrnConfig& c = m->cfg;
@@ -2183,6 +2329,19 @@ size_t model_workspace_bytes(Model* m, int B, int L) {
     if (e.peak > train_peak) train_peak = e.peak;
     e.tape.clear(); e.tens.clear();
   }
+  {   // ... and its two-launch form (kernels_ar.hip): slabs instead of per-step tensors
+    exec_begin(m, nullptr, true, true, true);
+    e.cap = (size_t)1 << 60; e.zcap = m->zero_bytes;
+    Tensor* s2 = encoder_forward(e, nullptr, B);
+    if (ar_fused_ok(e, s2, B, L)) {
+      Tensor* l2 = decoder_ar_fused(e, s2, B, L, nullptr);
+      l2->g = e.alloc((size_t)l2->rows * m->gen.ldb * e.esz());
+      e.alloc((size_t)l2->rows * 4);
+      for (auto it = e.tape.rbegin(); it != e.tape.rend(); ++it) (*it)();
+      if (e.peak > train_peak) train_peak = e.peak;
+    }
+    e.tape.clear(); e.tens.clear();
+  }
   // module.eval() semantics WITH gradients (train_step phase + 32: BatchNorm running statistics, the unfused BatchNorm-backward forms):
   // its backward allocates differently from the training-mode tape (found at bs4 128x384 bf16: "workspace exhausted in backward")
   {
@@ -2224,7 +2383,8 @@ int model_forward(Model* m, const float* img, const int64_t* expected, int B, in
   e.src = encoder_forward(e, img, B);
   m->seg_mark[2] = e.tape.size();  // end of the encoder
   m->seg_next = 0;
-  e.logits = teacher_forced ? decoder_tf(e, e.src, expected, B, L, logits_out) : decoder_ar(e, e.src, B, L, logits_out);
+  e.logits = teacher_forced ? decoder_tf(e, e.src, expected, B, L, logits_out)
+                            : (ar_fused_ok(e, e.src, B, L) ? decoder_ar_fused(e, e.src, B, L, logits_out) : decoder_ar(e, e.src, B, L, logits_out));
   m->logits_epoch = m->epoch;
   if (e.oom) { if (m->err.empty()) m->err = "workspace exhausted"; return -2; }
   return 0;

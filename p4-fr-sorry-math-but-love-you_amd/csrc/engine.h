@@ -74,6 +74,9 @@ struct Tensor {
   int ncons = 0;
   const void* bn_y = nullptr; const float* bn_ss = nullptr; const float* bn_mr = nullptr; int bn_act = 0;
   float* bn_red = nullptr; int bn_red_rep = 1;
+  // ... or runs that BatchNorm's whole backward itself (launch_dwconv_bwd_bn with a tail): bn_src = the BatchNorm's input tensor, bn_p its
+  // parameters; bn_applied tells the BatchNorm's closure that its input gradient and parameter gradients are already there
+  Tensor* bn_src = nullptr; BNp* bn_p = nullptr; bool bn_applied = false;
   // squeeze-and-excite backward folded into this BatchNorm output's backward: g holds the SE OUTPUT's gradient and the
   // true gradient is g*se_gate[b] + se_dpool[b]/se_hw
   const void* se_gate = nullptr; const void* se_dpool = nullptr; int se_hw = 0;

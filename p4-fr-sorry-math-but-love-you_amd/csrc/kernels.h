@@ -43,7 +43,7 @@ bool se_box_usable(hipStream_t s);   // false while `s` is being captured into a
 // MI355X_MICROARCH.md "Residency and cooperative launch"); 0 when the query fails.
 long resident_capacity(const void* kernel, int threads, size_t lds_bytes);
 // launches per kernel route (satrn_route_counts, include/satrn_hip.h): host-side diagnostics for tests
-enum { RT_GEMM_BIG = 0, RT_GEMM_BIG_CONV = 1, RT_WGRAD_BIG = 2, RT_GEMM_TILE = 3, RT_WGRAD_TILE = 4, RT_BN_POOL_SE = 5, RT_MBCONV_FWD = 6, RT_MBCONV_BWD = 7, RT_GEMM_TALL = 8, RT_COUNT = 9 };
+enum { RT_GEMM_BIG = 0, RT_GEMM_BIG_CONV = 1, RT_WGRAD_BIG = 2, RT_GEMM_TILE = 3, RT_WGRAD_TILE = 4, RT_BN_POOL_SE = 5, RT_MBCONV_FWD = 6, RT_MBCONV_BWD = 7, RT_GEMM_TALL = 8, RT_AR_FUSED = 9, RT_COUNT = 10 };
 extern long long g_route[RT_COUNT];
 unsigned* device_error_word();   // device address of the error word (bit 2: a mailbox wait timed out)
 void launch_fold4(const float* part, int nrep, long stride, long n, float* out, hipStream_t s);   // launch_fold with 16-byte accesses (n, stride % 4 == 0)
@@ -154,6 +154,7 @@ struct WgradP {
   int ldw;                                 // out_t==1: row stride of dW
   float* det_part;                         // deterministic mode (set by launch_wgrad): [split][N][K] partial slabs
   int launch_order;                        // 1: (tile, slice) in launch order instead of slice-major per XCD (A/B: SATRN_WGRAD_LAUNCH_ORDER, set by launch_wgrad)
+  int dbg_no_atomics;                      // timing experiment (SATRN_TIMING=wgrad_no_atomics)
   float* dbias;                            // optional (dense, !out_t): dbias[n] += sum_m dY[m][n], accumulated by the k-tile-0 workgroups from the dY
                                            // chunks they stage anyway (was a separate launch_colsum pass over dY)
 };
@@ -265,8 +266,12 @@ struct BnBwdHold {
 // y == nullptr: no BatchNorm sums (plain data gradient).  ap != nullptr: dy is NOT read -- it is first produced as the BatchNorm
 // backward-apply result of *ap (written to ap->dy = dy for the weight-gradient pass, parameter gradients accumulated) and consumed
 // from LDS: launch_bn_bwd_apply + the data gradient + the next BatchNorm's sums in one launch
+// tail != nullptr (needs ap, y, beta == 0): the backward-apply pass of the BatchNorm in FRONT too -- the slab's workgroups exchange their
+// shares of its column sums (g_mbbox) and tail->dy receives what launch_bn_bwd_apply(dz, y, red) would have written; dz and red are not
+// written.  false when the shape / residency / mode does not allow it (the caller retries without tail).
+struct BnBwdTail { void* dy = nullptr; const float* w = nullptr; float* dwp = nullptr; float* dbp = nullptr; };
 bool launch_dwconv_bwd_bn(int dt, const void* dy, const void* wp, void* dz, int beta, const void* y, const float* ss, const float* mr, int act,
-                          float* red, int B, int H, int W, int C, hipStream_t s, const BnBwdHold* ap = nullptr);
+                          float* red, int B, int H, int W, int C, hipStream_t s, const BnBwdHold* ap = nullptr, const BnBwdTail* tail = nullptr);
 bool dwconv_img_ok(int dt, int H, int W, int C);   // shape / dtype / mode test of the two image-tile depthwise kernels
 // BatchNorm(batch statistics)+activation of y -> z AND the stride-1 depthwise 3x3 of z -> out with out's column sums in red (zeroed
 // [2C]), one launch (bf16, whole image x 64 channels per workgroup); false = shape / mode not taken, nothing launched
@@ -436,6 +441,34 @@ const char* decode_pipe_reason();
 // a pipeline that timed out is not tried again in this process (every later decode would burn the same timeout): sticky
 void decode_pipe_disable(const char* why);
 int decode_pipe_error(void* scratch, hipStream_t s);  // weights in DecLayerW / wgen: k-panel-major copies
+// training-time autoregressive branch (kernels_ar.hip): one workgroup per image, all T steps of a direction in one launch.  Slabs are
+// [B*T][C] in the compute dtype, row b*T + t.  Weights: k-panel-major copies ([K/32][N][32], launch_repack_kpanel) of W and of W^T.
+struct ArLayer {
+  const void *wqkv, *wo, *wq2, *wo2, *w0, *w1;          // forward: [3D][D], [D][D], [D][D], [D][D], [F][D], [D][F]
+  const void *wqkvT, *woT, *wq2T, *wo2T, *w0T, *w1T;    // the transposes (backward)
+  const float *bqkv, *bo, *bq2, *bo2, *b0, *b1, *ln1w, *ln1b, *ln2w, *ln2b, *ln3w, *ln3b;
+  float *dln1w, *dln1b, *dln2w, *dln2b, *dln3w, *dln3b; // LayerNorm parameter gradients (+=)
+  const void* crossKV;   // [B][Nsrc][2D]
+  void* cache;           // [B][T][2D]: k|v of the layer outputs (of the inputs while a step runs)
+  void *q, *kvin, *att, *s1, *t1, *q2, *a2, *s2, *t2, *f0, *f1d;   // saved by the forward: widths D, 2D, D, D, D, D, D, D, D, F, D
+  void *dqkvi, *dkvo, *dout, *dq2, *dout2, *df0, *df1;             // written by the backward: widths 3D, 2D, D, D, D, F, D
+  float* dkvacc;         // [B][T][2D] f32, ZERO before the backward: gradient of the history entries
+  float* dcross;         // [B][Nsrc][2D] f32, ZERO before the backward: gradient of crossKV
+};
+struct ArP {
+  ArLayer L[4];
+  int nlayers;
+  void* xs[5];           // xs[0] = embedding + PE, xs[l + 1] = output of layer l
+  const float* embed; const float* pe; const void* wgen; const float* bgen;
+  float* logits /*[B*T][V] f32*/; int64_t* ids /*[B][T] argmax*/; int64_t* in_ids /*[B][T] the token fed to each step*/;
+  const void* dxtop /*[B*T][D] gradient of xs[nlayers]*/; void* dx0 /*[B*T][D] gradient of xs[0]*/;
+  float* lnpart /*[B][nlayers][6][D] scratch of the backward: per-image LayerNorm parameter gradients*/;
+  int B, T, D, F, V, H, Nsrc, sos;
+  float p_att, p_res, p_ff; const uint32_t* seed; uint32_t site;
+};
+bool ar_train_ok(int dt, int D, int F, int V, int H, int T, int Nsrc, int nlayers);
+int launch_ar_fwd(int dt, const ArP& p, hipStream_t s);
+int launch_ar_bwd(int dt, const ArP& p, hipStream_t s);
 // best-first beam search (networks/EfficientSATRN.py:708-867): DecodeP.steps = max_sequence - 1 expansions (= cache rows per
 // image); node tables are per image [NN], NN >= 1 + bw*steps; path [steps][pstride] uint16; out int64 [B][max_seq]
 struct BeamP {

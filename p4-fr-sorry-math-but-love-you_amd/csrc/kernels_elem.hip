@@ -1675,10 +1675,19 @@ struct BnApplyP {
   const bf16_t* dz; const bf16_t* y; const float* ss; const float* mr; const float* w; const float* red; bf16_t* dy; float* dwp; float* dbp;
   const bf16_t* se_gate; const bf16_t* se_dpool; float se_scale; float invM; int act;
 };
-template <bool APPLY>
+// TAIL: the backward-apply pass of the BatchNorm in FRONT as well (the tensor this kernel differentiates is z = act(bn(y))): its column sums
+// are over the whole batch, so the B workgroups of a slab exchange their shares through tagged granules (tl.box[slab][img][128], the
+// pattern of mbconv_front_kernel's statistics exchanges: everyone publishes its own share, everyone adds all B in image order -- the same
+// bits in every workgroup), then  dyf = A*g + Bc + Cc*y  goes to tl.dy from the registers and dz is never written.  Replaces
+// bn_bwd_apply_kernel behind this launch (one kernel boundary + one write and one read of the expanded gradient).  A slab's
+// workgroups are consecutive in dispatch order (blockIdx.x = image) and wait for nobody else.
+struct BnTailP {
+  bf16_t* dy; const float* w; float* dwp; float* dbp; se_box_t* box; unsigned* err; float invM; unsigned tag; long long timeout_ticks;
+};
+template <bool APPLY, bool TAIL>
 __global__ __launch_bounds__(512, 4) void dw_bwd_img_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ wp, bf16_t* __restrict__ dz,
                                                             const bf16_t* __restrict__ y, const float* ss, const float* mr, float* red, int H, int W,
-                                                            int C, int rowpix, int act, int beta, BnApplyP ap) {
+                                                            int C, int rowpix, int act, int beta, BnApplyP ap, BnTailP tl) {
   typedef bf16_t T;
   constexpr int CH = 8, SC = BDW_SC, RUN = BDW_RUN;
   extern __shared__ __attribute__((aligned(16))) unsigned char bdw_sm[];
@@ -1750,7 +1759,7 @@ __global__ __launch_bounds__(512, 4) void dw_bwd_img_kernel(const bf16_t* __rest
 #pragma unroll
   for (int p = 0; p < RUN; ++p) {
     yq[p] = y ? ld16(y + base + (long)(row * W + ox0 + p) * C) : zero16();
-    oq[p] = beta ? ld16(dz + base + (long)(row * W + ox0 + p) * C) : zero16();
+    oq[p] = (!TAIL && beta) ? ld16(dz + base + (long)(row * W + ox0 + p) * C) : zero16();   // (TAIL: beta == 0, launcher)
   }
   float acc[RUN][CH];
 #pragma unroll
@@ -1762,16 +1771,18 @@ __global__ __launch_bounds__(512, 4) void dw_bwd_img_kernel(const bf16_t* __rest
 #pragma unroll
   for (int j = 0; j < CH; ++j) s1[j] = s2[j] = sc[j] = sh[j] = mu[j] = rs[j] = 0.f;
   if (y) { lds8(cf[0] + chunk * CH, sc); lds8(cf[1] + chunk * CH, sh); lds8(cf[2] + chunk * CH, mu); lds8(cf[3] + chunk * CH, rs); }
+  uint4 dq[RUN];   // TAIL: dz as it would have been stored (bf16), kept for the apply pass
 #pragma unroll
   for (int p = 0; p < RUN; ++p) {
-    if (beta) {
+    if (!TAIL && beta) {
       float o[CH];
       unpack<T>(oq[p], o);
 #pragma unroll
       for (int j = 0; j < CH; ++j) acc[p][j] += o[j];
     }
     const uint4 q = pack<T>(acc[p]);
-    st16(dz + base + (long)(row * W + ox0 + p) * C, q);
+    if (TAIL) dq[p] = q;
+    else st16(dz + base + (long)(row * W + ox0 + p) * C, q);
     float d[CH], v[CH];
     unpack<T>(q, d);
     unpack<T>(yq[p], v);
@@ -1783,7 +1794,74 @@ __global__ __launch_bounds__(512, 4) void dw_bwd_img_kernel(const bf16_t* __rest
     }
   }
   if (!y) return;   // plain data gradient (uniform: no barrier is skipped by part of the workgroup)
-  bdw_colsums(s1, s2, sred, red, C, tid, NT);
+  if (!TAIL) { bdw_colsums(s1, s2, sred, red, C, tid, NT); return; }
+  // ---- this image's share of the 2 x 64 column sums -> mailbox; all B shares of the slab <- mailbox --------------------------------------
+  const long long t_end = (long long)wall_clock64() + tl.timeout_ticks;
+#pragma unroll
+  for (int o = SC; o < 64; o <<= 1) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { s1[j] += __shfl_xor(s1[j], o, 64); s2[j] += __shfl_xor(s2[j], o, 64); }
+  }
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < SC) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { sred[wave][0][lane * CH + j] = s1[j]; sred[wave][1][lane * CH + j] = s2[j]; }
+    }
+  }
+  __syncthreads();
+  const int B = gridDim.x;
+  se_box_t* sbox = tl.box + (size_t)blockIdx.y * B * 128;
+  if (tid < 128) {
+    const int k = tid >> 6, c = tid & 63;
+    float sum = 0.f;
+    for (int wv = 0; wv < NT / 64; ++wv) sum += sred[wv][k][c];
+    se_box_put(sbox + (size_t)img * 128 + tid, tl.tag, sum);
+  }
+  __syncthreads();   // sred is reused for the gathered totals
+  {
+    // thread = (column v of 128, image group grp of NT / 128): every workgroup adds the same shares in the same order
+    const int v = tid & 127, grp = tid >> 7, NG = NT >> 7;
+    constexpr int GB = 8;
+    float a = 0.f;
+    for (int i0 = grp; i0 < B; i0 += NG * GB) {
+      float vals[GB];
+      const int n = min(GB, (B - i0 + NG - 1) / NG);
+      se_box_gather<GB>(sbox + (size_t)i0 * 128 + v, (size_t)NG * 128, n, tl.tag, t_end, vals, tl.err);
+#pragma unroll
+      for (int k = 0; k < GB; ++k) if (k < n) a += vals[k];
+    }
+    sred[grp][v >> 6][v & 63] = a;
+  }
+  __syncthreads();
+  if (tid < SC * CH) {
+    float r0 = 0.f, r1 = 0.f;
+    for (int gq = 0; gq < (NT >> 7); ++gq) { r0 += sred[gq][0][tid]; r1 += sred[gq][1][tid]; }
+    const int cg = cb + tid;
+    const float amu = cf[2][tid], ars = cf[3][tid];
+    const float a = tl.w[cg] * ars, m1 = r0 * tl.invM, m2 = r1 * tl.invM;
+    if (img == 0 && tl.dwp) { tl.dwp[cg] += r1; tl.dbp[cg] += r0; }   // parameter gradients (zeroed per step: accumulate)
+    cf[2][tid] = a; cf[3][tid] = -a * m1 + a * ars * amu * m2;
+    sred[4][0][tid] = -a * ars * m2;
+  }
+  __syncthreads();
+  {
+    float A[CH], Bc[CH], Cc[CH];
+    lds8(cf[0] + chunk * CH, sc); lds8(cf[1] + chunk * CH, sh);   // (again: not held in registers across the exchange)
+    lds8(cf[2] + chunk * CH, A); lds8(cf[3] + chunk * CH, Bc); lds8(sred[4][0] + chunk * CH, Cc);
+#pragma unroll
+    for (int p = 0; p < RUN; ++p) {
+      float d[CH], v[CH];
+      unpack<T>(dq[p], d);
+      unpack<T>(yq[p], v);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const float gg = d[j] * act_bwd(v[j] * sc[j] + sh[j], act);
+        d[j] = A[j] * gg + Bc[j] + Cc[j] * v[j];
+      }
+      st16(tl.dy + base + (long)(row * W + ox0 + p) * C, pack<T>(d));
+    }
+  }
 }
 // false = shape / mode not taken (the caller launches launch_dwconv(mode 1) and leaves the sums to launch_bn_bwd_reduce)
 bool dwconv_img_ok(int dt, int H, int W, int C) {
@@ -1792,9 +1870,10 @@ bool dwconv_img_ok(int dt, int H, int W, int C) {
   return NT <= 512 && (NT % 64) == 0 && (size_t)(H + 2) * ((W + 2) | 1) * BDW_SC * 16 <= 60 * 1024;
 }
 bool launch_dwconv_bwd_bn(int dt, const void* dy, const void* wp, void* dz, int beta, const void* y, const float* ss, const float* mr, int act,
-                          float* red, int B, int H, int W, int C, hipStream_t s, const BnBwdHold* hold) {
+                          float* red, int B, int H, int W, int C, hipStream_t s, const BnBwdHold* hold, const BnBwdTail* tail) {
   const bool off = sw_off("fused_dw_bwd");   // read per call (tests)
-  if (off || !dwconv_img_ok(dt, H, W, C) || (y && !red) || (!y && !hold)) return false;
+  if (off || !dwconv_img_ok(dt, H, W, C) || (y && !red && !tail) || (!y && !hold)) return false;
+  if (tail && (!hold || !y || beta || !tail->dy || !tail->w || sw_off("dw_bwd_tail"))) return false;
   const int HW = H * W, NT = (HW / BDW_RUN) * BDW_SC;
   const int rowpix = (W + 2) | 1;
   const size_t lds = (size_t)(H + 2) * rowpix * BDW_SC * 16;
@@ -1805,11 +1884,24 @@ bool launch_dwconv_bwd_bn(int dt, const void* dy, const void* wp, void* dz, int 
     ap.dy = (bf16_t*)hold->dy; ap.dwp = hold->dwp; ap.dbp = hold->dbp; ap.se_gate = (const bf16_t*)hold->se_gate; ap.se_dpool = (const bf16_t*)hold->se_dpool;
     ap.se_scale = hold->se_hw > 0 ? 1.0f / (float)hold->se_hw : 0.f; ap.invM = 1.0f / (float)hold->M; ap.act = hold->act;
     if (hold->se_gate && hold->se_hw != HW) return false;
-    hipLaunchKernelGGL(dw_bwd_img_kernel<true>, dim3(B, C / (8 * BDW_SC)), dim3(NT), lds, s, (const bf16_t*)dy, (const bf16_t*)wp, (bf16_t*)dz, (const bf16_t*)y,
-                       ss, mr, red, H, W, C, rowpix, act, beta, ap);
+    BnTailP tl = {};
+    if (tail) {
+      // workgroups wait for each other: the whole grid has to be resident, the mailbox has to hold B x slabs x 128 granules
+      const long nwg = (long)B * (C / (8 * BDW_SC));
+      if (!g_mbbox.box || B > g_mbbox.images || (size_t)nwg * 128 > g_mbbox.words) return false;
+      if (nwg > resident_capacity((const void*)dw_bwd_img_kernel<true, true>, NT, lds)) return false;
+      tl.dy = (bf16_t*)tail->dy; tl.w = tail->w; tl.dwp = tail->dwp; tl.dbp = tail->dbp; tl.box = (se_box_t*)g_mbbox.box;
+      tl.err = device_error_word(); tl.invM = 1.0f / (float)((long)B * HW); tl.tag = se_next_tag(); tl.timeout_ticks = 200000000LL;   // 2 s at 100 MHz
+      if (!tl.err) return false;
+      hipLaunchKernelGGL((dw_bwd_img_kernel<true, true>), dim3(B, C / (8 * BDW_SC)), dim3(NT), lds, s, (const bf16_t*)dy, (const bf16_t*)wp, (bf16_t*)dz,
+                         (const bf16_t*)y, ss, mr, red, H, W, C, rowpix, act, beta, ap, tl);
+      return true;
+    }
+    hipLaunchKernelGGL((dw_bwd_img_kernel<true, false>), dim3(B, C / (8 * BDW_SC)), dim3(NT), lds, s, (const bf16_t*)dy, (const bf16_t*)wp, (bf16_t*)dz,
+                       (const bf16_t*)y, ss, mr, red, H, W, C, rowpix, act, beta, ap, tl);
   } else {
-    hipLaunchKernelGGL(dw_bwd_img_kernel<false>, dim3(B, C / (8 * BDW_SC)), dim3(NT), lds, s, (const bf16_t*)dy, (const bf16_t*)wp, (bf16_t*)dz, (const bf16_t*)y,
-                       ss, mr, red, H, W, C, rowpix, act, beta, ap);
+    hipLaunchKernelGGL((dw_bwd_img_kernel<false, false>), dim3(B, C / (8 * BDW_SC)), dim3(NT), lds, s, (const bf16_t*)dy, (const bf16_t*)wp, (bf16_t*)dz,
+                       (const bf16_t*)y, ss, mr, red, H, W, C, rowpix, act, beta, ap, BnTailP{});
   }
   return true;
 }

@@ -1104,6 +1104,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p, int rows_per_split
           if (p.det_part) { p.det_part[((size_t)split * p.N + n) * p.K + k] = acc[i][j][r]; continue; }  // folded afterwards
           if (CONV && !p.conv_packed_out) { int tp = k / p.Ci, c = k - tp * p.Ci; dst = ((long)n * p.Ci + c) * taps + tp; }
           else dst = (long)n * p.K + k;
+          if (p.dbg_no_atomics && acc[i][j][r] != 12345.678f) continue;   // timing experiment (SATRN_TIMING=wgrad_no_atomics; wrong gradients)
           atomicAdd((float*)p.dW + dst, acc[i][j][r]);
         }
       }
@@ -1158,6 +1159,8 @@ static void launch_wgrad_tile(const WgradP& p, hipStream_t s) {
   WgradP q = p;
   const bool launch_order = sw_off("wgrad_xcd_order");   // A/B (tools/ab_bench.sh), read per call
   q.launch_order = launch_order ? 1 : 0;
+  static const bool no_at = sw_timing("wgrad_no_atomics") != 0;
+  q.dbg_no_atomics = no_at ? 1 : 0;
   q.det_part = det ? det_scratch(s, (size_t)splits * p.N * p.K) : nullptr;
   // (measured: the partial-tile slab of the persistent kernel for this kernel's split-M sums instead of atomics -- 10.56 vs 10.47 ms per
   // EfficientSATRN step, one more side launch per weight gradient -- not kept)

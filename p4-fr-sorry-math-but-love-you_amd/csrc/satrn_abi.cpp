@@ -396,6 +396,26 @@ int satrn_bn_bwd_apply_dwconv3x3_bwd_data_bnred(int dt, const void* dz2, const v
   }
   return done("bn_bwd_apply_dwconv3x3_bwd_data_bnred");
 }
+int satrn_bn_bwd_apply_dwconv3x3_bwd_data_bn_bwd(const void* dz2, const void* y2, const float* wb, const float* scratch_b, int act_b, const float* scratch2_b,
+                                                 void* dy2, float* dwb, float* dbb, const void* dwp, const void* y, const float* wa, const float* scratch,
+                                                 int act, void* dy1, float* dwa, float* dba, int B, int H, int W, int C, unsigned long long* mailbox,
+                                                 long mailbox_words, void* st) {
+  CHK_DT(DT_BF16);
+  if (chk_c(DT_BF16, C, "C")) return -1;
+  if (B < 1 || (C % 64) || !mailbox || mailbox_words < (long)B * (C / 64) * 128)
+    return fail(-1, "bn_bwd_apply_dwconv3x3_bwd_data_bn_bwd: a mailbox of B * (C / 64) * 128 words is required");
+  const long M = (long)B * H * W;
+  BnBwdHold h;
+  h.armed = true; h.dz = dz2; h.y = y2; h.ss = scratch_b + 2 * C; h.mr = scratch_b + 4 * C; h.w = wb; h.red = scratch2_b; h.M = M; h.C = C; h.act = act_b;
+  h.dy = dy2; h.dwp = dwb; h.dbp = dbb;
+  BnBwdTail tl;
+  tl.dy = dy1; tl.w = wa; tl.dwp = dwa; tl.dbp = dba;
+  g_mbbox.box = mailbox; g_mbbox.words = (size_t)mailbox_words; g_mbbox.images = B;
+  const bool okk = launch_dwconv_bwd_bn(DT_BF16, dy2, dwp, nullptr, 0, y, scratch + 2 * C, scratch + 4 * C, act, nullptr, B, H, W, C, S(st), &h, &tl);
+  g_mbbox.box = nullptr; g_mbbox.words = 0; g_mbbox.images = 0;
+  if (!okk) return fail(-1, "bn_bwd_apply_dwconv3x3_bwd_data_bn_bwd: shape not taken by the one-launch form (use satrn_bn_bwd_apply_dwconv3x3_bwd_data_bnred + satrn_batchnorm_act_bwd_apply)");
+  return done("bn_bwd_apply_dwconv3x3_bwd_data_bn_bwd");
+}
 int satrn_batchnorm_act_bwd_apply(int dt, const void* dz, const void* y, const float* w, const float* scratch, int act, void* dy, float* dw,
                                   float* db, long M, int C, const float* scratch2, void* st) {
   CHK_DT(dt);

@@ -18,11 +18,11 @@ H, W, T, B = 128, 384, 128, 32
 def _routes(reset=False):
     import satrn_amd
     lib = satrn_amd._lib.load()
-    out = (ctypes.c_longlong * 9)()
-    n = lib.satrn_route_counts(out, 9, int(reset))
-    assert n == 9
+    out = (ctypes.c_longlong * 16)()
+    n = lib.satrn_route_counts(out, 16, int(reset))
+    assert n >= 10
     return dict(gemm_big=out[0], gemm_big_conv=out[1], wgrad_big=out[2], gemm_tile=out[3], wgrad_tile=out[4], bn_pool_se=out[5], mbconv_fwd=out[6],
-                mbconv_bwd=out[7], gemm_tall=out[8])
+                mbconv_bwd=out[7], gemm_tall=out[8], ar_fused=out[9])
 
 
 def _device_error():

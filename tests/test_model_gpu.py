@@ -335,6 +335,88 @@ def test_train_autoregressive_branch_with_gradients(dtype):
         assert float(np.median([e_ for e_, _ in errs])) < 1e-3 and worst[0][0] < 3e-2
 
 
+def _ar_routes(reset=False):
+    import ctypes
+    import satrn_amd
+    out = (ctypes.c_longlong * 16)()
+    satrn_amd._lib.load().satrn_route_counts(out, 16, int(reset))
+    return out[9]
+
+
+@pytest.mark.parametrize("dtype,net,T", [("f32", "lite", 9), ("bf16", "lite", 9), ("f32", "eff", 6)])
+def test_autoregressive_branch_two_launch_form_equals_operator_form(dtype, net, T):
+    """kernels_ar.hip (one workgroup per image runs all steps of a direction, weight gradients as products over [B*T]-row slabs) against
+    the operator-level form it replaces (SATRN_OFF=ar_fused: ~126 launches per step): same logits, same predicted ids, same gradients.
+    f32 pins it tightly; bf16 rounds at different places (f32 residual stream inside the kernel) and is held to the bf16 yardstick."""
+    cfg = dict(O.CFG_LITE if net == "lite" else O.CFG_EFF)
+    B, H, W = 3, 64, 192
+    img, expected = O.det_inputs(B, cfg["rgb"], H, W, T, seed=44, pad_tail=2)
+    res = {}
+    for name in ("fused", "ops"):
+        (sw.off if name == "ops" else sw.on)("ar_fused")
+        model, sd = build(cfg, H, W, dtype, 6)
+        model.train()
+        _ar_routes(reset=True)
+        logits = model(img.cuda(), expected.cuda(), True, 0.0)
+        loss = model.criterion(logits.transpose(1, 2), expected.cuda()[:, 1:])
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        assert (_ar_routes() > 0) == (name == "fused"), "the route under test must be the one that ran"
+        res[name] = (logits.detach().float().cpu(), loss.item(), {n_: p_.grad.detach().float().cpu().clone() for n_, p_ in model.named_parameters()})
+    sw.on("ar_fused")
+    (lf, lossf, gf), (lo, losso, go) = res["fused"], res["ops"]
+    f32 = dtype == "f32"
+    print(f"[ar two-launch:{dtype}:{net}] loss {lossf:.6f} vs {losso:.6f}; logits rel err {relerr(lf, lo):.3e}")
+    assert torch.equal(lf.argmax(-1), lo.argmax(-1)) or not f32
+    assert abs(lossf - losso) < (1e-5 if f32 else 5e-2)
+    assert relerr(lf, lo) < (2e-5 if f32 else 5e-2)
+    rms = lambda t_: t_.norm().item() / max(t_.numel(), 1) ** 0.5
+    gl2 = max(rms(g) for g in go.values())
+    errs = sorted(((rms(gf[n_] - g) / max(rms(g), 1e-3 * gl2), n_) for n_, g in go.items()), reverse=True)
+    print(f"[ar two-launch:{dtype}:{net}] worst grad rel-L2: " + ", ".join(f"{n_}={e_:.2e}" for e_, n_ in errs[:4]))
+    if f32:
+        assert errs[0][0] < 2e-3 and float(np.median([e_ for e_, _ in errs])) < 1e-4
+    else:
+        flat_f = torch.cat([gf[n_].flatten() for n_ in go]); flat_o = torch.cat([g.flatten() for g in go.values()])
+        cs = torch.dot(flat_f, flat_o) / (flat_f.norm() * flat_o.norm())
+        print(f"[ar two-launch:{dtype}:{net}] flat gradient cosine {cs.item():.5f}")
+        assert cs.item() > 0.98
+
+
+def test_autoregressive_branch_two_launch_form_with_dropout():
+    """Dropout inside the two-launch form: the backward regenerates the masks of the forward (counter hash), so two runs from the same
+    seed agree bit for bit in f32 with fixed-order reductions, the loss differs from the dropout-free one, and every gradient is finite;
+    the masks keep the expectation: the mean loss over seeds is within a few percent of the dropout-free loss's neighbourhood."""
+    cfg = dict(O.CFG_LITE)
+    B, H, W, T = 3, 64, 192, 9
+    img, expected = O.det_inputs(B, cfg["rgb"], H, W, T, seed=44, pad_tail=2)
+
+    def run(dropout, seed):
+        import ctypes
+        import satrn_amd
+        model, sd = build(cfg, H, W, "f32", 6, dropout=dropout)
+        model.train()
+        model.reserve(B, T + 1, "cuda")
+        word = ctypes.c_uint32(seed)
+        assert satrn_amd._lib.load().satrn_model_rng_state(model._h, ctypes.byref(word), 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        logits = model(img.cuda(), expected.cuda(), True, 0.0)
+        loss = model.criterion(logits.transpose(1, 2), expected.cuda()[:, 1:])
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), model.flat_grad().detach().float().cpu().clone()
+
+    l0, g0 = run(0.0, 5)
+    l1, g1 = run(0.1, 5)
+    l2, g2 = run(0.1, 5)
+    l3, g3 = run(0.1, 6)
+    print(f"[ar dropout] loss {l0:.5f} (p = 0), {l1:.5f} / {l2:.5f} (p = 0.1, same seed), {l3:.5f} (another seed)")
+    assert torch.isfinite(g1).all() and l1 == l2 and torch.equal(g1, g2)
+    assert l1 != l0 and l3 != l1 and not torch.equal(g1, g3)
+    assert abs(l1 - l0) < 0.5 and abs(l3 - l0) < 0.5
+
+
 @pytest.mark.parametrize("net,H,W,B", [("eff", 128, 384, 4), ("eff", 64, 96, 3), ("lite", 64, 192, 3)])
 def test_fused_encoder_attention_region_equals_the_four_launches(net, H, W, B):
     """kernels_encattn.hip (LayerNorm -> q|k|v -> attention -> output-projection partials in ONE launch, partials folded by the LayerNorm

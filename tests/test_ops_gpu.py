@@ -851,6 +851,81 @@ def test_bn_backward_apply_inside_dwconv_backward(lib, B, H, W, C, acc, monkeypa
     close(a[4], b[4].cpu(), "f32", "next BatchNorm's sums: one launch vs two", f32_tol=2e-4)
 
 
+@pytest.mark.parametrize("B,H,W,C", [(3, 8, 24, 128), (4, 4, 12, 192), (32, 8, 24, 960), (32, 4, 12, 1536), (32, 4, 12, 1024), (5, 6, 9, 64)])
+def test_dwconv_backward_through_both_batchnorms(lib, B, H, W, C):
+    """bf16: BatchNorm-behind backward-apply + depthwise data gradient + the WHOLE backward of the BatchNorm in front in one launch (the
+    slab's workgroups exchange the column sums through the mailbox, dz never stored) against the one-launch seam operator followed by
+    satrn_batchnorm_act_bwd_apply, and against autograd through bn -> SiLU -> depthwise conv."""
+    dt = "bf16"
+    M = B * H * W
+    y1 = q(rnd(M, C, seed=1) * 2 + 0.5, dt)
+    y2 = q(rnd(M, C, seed=2) * 1.5 - 0.2, dt)
+    dz2 = q(rnd(M, C, seed=3), dt)
+    w1, b1 = 1 + rnd(C, seed=4, scale=0.2), rnd(C, seed=5, scale=0.1)
+    w2, b2 = 1 + rnd(C, seed=6, scale=0.2), rnd(C, seed=7, scale=0.1)
+    dwk = q(rnd(C, 1, 3, 3, seed=8, scale=0.3), dt)
+    eps = 1e-3
+    wp = torch.empty(9, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_pack_dwconv3x3(dti(dt), P(dev(dwk)), P(wp), C, st()))
+    y1d, y2d, dz2d = dev(y1, dt), dev(y2, dt), dev(dz2, dt)
+    scr = []
+    for yy, ww, bb in ((y1d, w1, b1), (y2d, w2, b2)):
+        sc = torch.zeros(6 * C, device="cuda")
+        zz = torch.empty(M, C, dtype=tdt(dt), device="cuda")
+        nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ok(lib, lib.satrn_batchnorm_act_fwd(dti(dt), P(yy), P(dev(ww)), P(dev(bb)), P(dev(torch.zeros(C))), P(dev(torch.ones(C))), P(nbt), eps, 1, 2, None,
+                                            P(zz), M, C, P(sc), st()))
+        scr.append(sc)
+    red2 = torch.zeros(2 * C, device="cuda")
+    dy_tmp = torch.empty(M, C, dtype=tdt(dt), device="cuda")
+    ok(lib, lib.satrn_batchnorm_act_bwd(dti(dt), P(dz2d), P(y2d), P(dev(w2)), P(scr[1]), 2, P(dy_tmp), P(torch.zeros(C, device="cuda")),
+                                        P(torch.zeros(C, device="cuda")), M, C, P(red2), st()))
+    box = torch.zeros(B * (C // 64) * 128, dtype=torch.int64, device="cuda")
+
+    def run(one_launch):
+        dy2 = torch.empty(M, C, dtype=tdt(dt), device="cuda")
+        dy1 = torch.empty(M, C, dtype=tdt(dt), device="cuda")
+        dwb, dbb, dwa, dba = (torch.zeros(C, device="cuda") for _ in range(4))
+        if one_launch:
+            rc = lib.satrn_bn_bwd_apply_dwconv3x3_bwd_data_bn_bwd(P(dz2d), P(y2d), P(dev(w2)), P(scr[1]), 2, P(red2), P(dy2), P(dwb), P(dbb), P(wp), P(y1d),
+                                                                  P(dev(w1)), P(scr[0]), 2, P(dy1), P(dwa), P(dba), B, H, W, C, P(box), box.numel(), st())
+            if rc != 0:
+                return None
+        else:
+            dz = torch.empty(M, C, dtype=tdt(dt), device="cuda")
+            s1 = torch.zeros(2 * C, device="cuda")
+            ok(lib, lib.satrn_bn_bwd_apply_dwconv3x3_bwd_data_bnred(dti(dt), P(dz2d), P(y2d), P(dev(w2)), P(scr[1]), 2, P(red2), P(dy2), P(dwb), P(dbb), P(wp), P(dz),
+                                                                    0, P(y1d), P(scr[0]), 2, P(s1), B, H, W, C, st()))
+            ok(lib, lib.satrn_batchnorm_act_bwd_apply(dti(dt), P(dz), P(y1d), P(dev(w1)), P(scr[0]), 2, P(dy1), P(dwa), P(dba), M, C, P(s1), st()))
+        torch.cuda.synchronize()
+        assert lib.satrn_device_error(st()) == 0
+        return dy2, dwb, dbb, dy1, dwa, dba
+
+    a, b = run(True), run(False)
+    if (W % 3) != 0 or ((H * W // 3) * 8) % 64 != 0:
+        assert a is None, "a shape the image-tile kernels do not take must be refused"
+        return
+    assert a is not None, lib.satrn_last_error().decode()
+    for u, v, what in zip(a[:3], b[:3], ("dy2", "bn_b dweight", "bn_b dbias")):
+        assert torch.equal(u, v), f"{what}: one launch vs two"
+    # the column sums are added in a different order (mailbox fold vs atomics): equal up to that
+    close(a[3], b[3].float().cpu(), dt, "dy1: one launch vs seam operator + apply", bf16_tol=1e-2)
+    close(a[4], b[4].cpu(), "f32", "bn_a dweight", f32_tol=2e-4)
+    close(a[5], b[5].cpu(), "f32", "bn_a dbias", f32_tol=2e-4)
+    a2 = run(True)   # a second launch over the same mailbox (new tag)
+    assert torch.equal(a[3], a2[3]), "the result must not depend on what an earlier launch left in the mailbox"
+    # autograd: dy2 (gradient of the convolution's output, as the first BatchNorm's backward left it) through conv^T, SiLU', bn_a
+    yr = y1.clone().requires_grad_(True)
+    wr, br = w1.clone().requires_grad_(True), b1.clone().requires_grad_(True)
+    x4 = yr.view(B, H, W, C).permute(0, 3, 1, 2)
+    z = torch.nn.functional.silu(torch.nn.functional.batch_norm(x4, None, None, wr, br, True, 0.1, eps))
+    o = torch.nn.functional.conv2d(z, dwk, None, 1, 1, 1, C)
+    o.backward(a[0].float().cpu().view(B, H, W, C).permute(0, 3, 1, 2))
+    close(a[3], yr.grad, dt, "dy1 vs autograd", bf16_tol=6e-2)
+    close(a[4], wr.grad, "f32", "bn_a dweight vs autograd", f32_tol=3e-2)
+    close(a[5], br.grad, "f32", "bn_a dbias vs autograd", f32_tol=3e-2)
+
+
 @pytest.mark.parametrize("B,HW,C,S", [(3, 192, 512, 32), (4, 48, 1536, 64), (2, 192, 960, 40), (5, 48, 64, 8), (32, 48, 1536, 64), (32, 192, 960, 40)])
 def test_squeeze_excite_backward_with_batchnorm_sums(lib, B, HW, C, S):
     """BatchNorm -> SiLU -> SqueezeExcite seam of the MBConv block, backward (bf16): the SE input is recomputed from the
