@@ -29,13 +29,15 @@ DEVI const T* kp_addr(const T* W, int Ntot, int row, int kk, int fq) { return W 
 
 template <typename T, int GU = 2 /*16-output groups per wave iteration: GU x 8 weight loads in flight per lane*/, int NT = DEC_THREADS>
 DEVI void gemv(const T* __restrict__ W, int Ntot, int row0, const float* __restrict__ bias, const T* xT, float* y, int N, int K,
-               int act, T* yT = nullptr /*optional: the output also in the compute dtype (the next product's input)*/) {
+               int act, T* yT = nullptr /*optional: the output also in the compute dtype (the next product's input)*/,
+               int wv0 = 0, int nwv = NT / 64 /*only waves [wv0, wv0 + nwv) of the workgroup take part (two products side by side)*/) {
   constexpr int CH = TT<T>::CH;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) - wv0;
+  if (wave < 0 || wave >= nwv) return;
   const int fr = lane & 15, fq = lane >> 4;
   const int ng = (N + 15) >> 4;
   const T* xr = xT + fq * 8;
-  for (int g0 = wave * GU; g0 < ng; g0 += (NT / 64) * GU) {
+  for (int g0 = wave * GU; g0 < ng; g0 += nwv * GU) {
     int rowu[GU];
     f32x4 acc[GU];
 #pragma unroll

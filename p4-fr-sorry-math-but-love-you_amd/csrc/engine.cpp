@@ -2167,6 +2167,7 @@ Tensor* decoder_ar_fused(Exec& e, Tensor* src, int B, int L, float* logits_out) 
     w.t2 = slab(D); w.f0 = slab(F); w.f1d = slab(D);
   }
   for (int l = 0; l <= nl; ++l) ap->xs[l] = slab(D);
+  ap->Ltab = (ArLayer*)e.alloc(4 * sizeof(ArLayer));
   ap->nlayers = nl; ap->embed = m->embed.p; ap->pe = (const float*)(m->ws + m->off_pe1d); ap->wgen = kp(m->gen.fwd, V, D); ap->bgen = m->gen_b.p;
   ap->logits = logits_out;
   ap->ids = (int64_t*)e.alloc((size_t)R * 8); ap->in_ids = (int64_t*)e.alloc((size_t)R * 8);
@@ -2177,7 +2178,14 @@ Tensor* decoder_ar_fused(Exec& e, Tensor* src, int B, int L, float* logits_out) 
   ap->seed = (const uint32_t*)(scal(m) + SC_SEED); ap->site = drop ? e.site++ : 0;
   // per step and image: 15 D^2 + 2 D F multiply-accumulates per layer + the generator; the weights are streamed once per step and image
   WORK(e, 2.0 * (double)R * (nl * (7.0 * D * D + 2.0 * D * F) + (double)D * V), (double)R * (nl * (7.0 * D * D + 2.0 * D * F) + (double)D * V) * es);
-  LCH(e, launch_ar_fwd(e.dt, *ap, e.s));
+  ap->G = ar_fwd_slices(e.dt, D, F, H);
+  ap->fbox = ap->G > 1 ? (unsigned long long*)e.alloc(ar_fwd_box_bytes(B, ap->G, D)) : nullptr;
+  {
+    int rc = 0;
+    LCH(e, rc = launch_ar_fwd(e.dt, *ap, e.s));
+    if (rc && ap->G > 1) { ap->G = 1; LCH(e, rc = launch_ar_fwd(e.dt, *ap, e.s)); }   // the sliced form could not be resident: one workgroup per image
+    if (rc) { m->err = "autoregressive forward: launch refused"; e.oom = true; }
+  }
   if (e.rec)
     e.tape.push_back([&e, m, ap, full, crossKV, B, T, D, F, V, Nsrc, nl, R, es]() {
       if (!full->g) return;
@@ -2194,6 +2202,7 @@ Tensor* decoder_ar_fused(Exec& e, Tensor* src, int B, int L, float* logits_out) 
       wgrad_slab(e, &m->gen, &m->gen_b, full->g, Vp, ap->xs[nl], D, R, V);
       ap->dxtop = dxtop; ap->dx0 = e.alloc((size_t)R * D * es);
       ap->lnpart = (float*)e.alloc((size_t)B * nl * 6 * D * 4);
+      ap->gbox = (unsigned long long*)e.alloc(ar_bwd_box_bytes(B, T, D, nl));
       for (int l = 0; l < nl; ++l) {
         ArLayer& w = ap->L[l];
         w.dqkvi = e.alloc((size_t)R * 3 * D * es); w.dkvo = e.alloc((size_t)R * 2 * D * es); w.dout = e.alloc((size_t)R * D * es);
@@ -2206,7 +2215,9 @@ Tensor* decoder_ar_fused(Exec& e, Tensor* src, int B, int L, float* logits_out) 
         if (w.dcross) LCH(e, launch_fill(w.dcross, 0, (size_t)B * Nsrc * 2 * D * 4, e.s));
       }
       WORK(e, 2.0 * (double)R * nl * (8.0 * D * D + 2.0 * D * F), (double)R * nl * (8.0 * D * D + 2.0 * D * F) * es);
-      LCH(e, launch_ar_bwd(e.dt, *ap, e.s));
+      int rc = 0;
+      LCH(e, rc = launch_ar_bwd(e.dt, *ap, e.s));
+      if (rc) { m->err = "autoregressive backward: the layer pipeline cannot be resident on this device (SATRN_OFF=ar_fused runs the operator form)"; e.oom = true; }
       for (int l = 0; l < nl; ++l) {
         DecLayer& dl = m->dec[l];
         ArLayer& w = ap->L[l];

@@ -457,18 +457,26 @@ struct ArLayer {
 };
 struct ArP {
   ArLayer L[4];
+  ArLayer* Ltab;         // device memory, 4 entries: the launchers copy L[] there (the kernels index it with the runtime layer number)
   int nlayers;
   void* xs[5];           // xs[0] = embedding + PE, xs[l + 1] = output of layer l
   const float* embed; const float* pe; const void* wgen; const float* bgen;
   float* logits /*[B*T][V] f32*/; int64_t* ids /*[B][T] argmax*/; int64_t* in_ids /*[B][T] the token fed to each step*/;
   const void* dxtop /*[B*T][D] gradient of xs[nlayers]*/; void* dx0 /*[B*T][D] gradient of xs[0]*/;
   float* lnpart /*[B][nlayers][6][D] scratch of the backward: per-image LayerNorm parameter gradients*/;
+  unsigned long long* gbox /*ar_bwd_box_bytes(): hand-off of the backward's layer pipeline*/; unsigned tag; unsigned* err; long long timeout_ticks;
   int B, T, D, F, V, H, Nsrc, sos;
   float p_att, p_res, p_ff; const uint32_t* seed; uint32_t site;
+  long long* prof;   // optional [16] wall-clock ticks per phase family of workgroup 0 (SATRN_PROF=ar)
+  int G;             // forward: workgroups (weight slices) per image, ar_fwd_slices()
+  unsigned long long* fbox;   // forward, G > 1: ar_fwd_box_bytes() mailbox of the slices' exchanges
 };
 bool ar_train_ok(int dt, int D, int F, int V, int H, int T, int Nsrc, int nlayers);
-int launch_ar_fwd(int dt, const ArP& p, hipStream_t s);
-int launch_ar_bwd(int dt, const ArP& p, hipStream_t s);
+int launch_ar_fwd(int dt, const ArP& p, hipStream_t s);   // -1: not launched
+int ar_fwd_slices(int dt, int D, int F, int H);
+size_t ar_fwd_box_bytes(int B, int G, int D);
+int launch_ar_bwd(int dt, const ArP& p, hipStream_t s);   // -1: not launched (shape / residency / no mailbox)
+size_t ar_bwd_box_bytes(int B, int T, int D, int nlayers);
 // best-first beam search (networks/EfficientSATRN.py:708-867): DecodeP.steps = max_sequence - 1 expansions (= cache rows per
 // image); node tables are per image [NN], NN >= 1 + bw*steps; path [steps][pstride] uint16; out int64 [B][max_seq]
 struct BeamP {

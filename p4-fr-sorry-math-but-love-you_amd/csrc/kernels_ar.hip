@@ -16,6 +16,7 @@
 // Replaces ~126 launches per step (46 forward, 80 backward: 16 000 for T = 127) of the operator-level form (engine.cpp decoder_ar).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "common.h"
 #include "kernels.h"
@@ -23,6 +24,11 @@
 
 namespace {
 
+// Workgroup barrier that orders LDS traffic only (the decode pipeline's LDS_BARRIER): __syncthreads() also waits for every outstanding
+// GLOBAL access of the wave (vmcnt(0)), which would expose the round trip of each slab store issued in front of it -- a dozen per layer
+// and step.  Nothing a slab store writes is read again inside these kernels; the two places where global data written by one thread is
+// read by another (history rows of earlier steps, their gradient accumulators) are separated by the one __syncthreads() per step.
+#define AR_BAR() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #define AR_DSTRIDE 4096u   // dropout index space of one (image, step, layer, site)
 enum { AR_S_ATT = 0, AR_S_OUT = 1, AR_S_ATT2 = 2, AR_S_OUT2 = 3, AR_S_F0 = 4, AR_S_F1 = 5, AR_NSITE = 6 };
 
@@ -34,9 +40,9 @@ DEVI uint32_t ar_didx(const ArP& p, int b, int t, int l, int s) {
 DEVI void block_sum2(float a, float b, float* red, float& A, float& B) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   a = wave_sum(a); b = wave_sum(b);
-  __syncthreads();   // red may still be read by the previous reduction
+  AR_BAR();   // red may still be read by the previous reduction
   if (lane == 0) { red[wave] = a; red[DEC_WAVES + wave] = b; }
-  __syncthreads();
+  AR_BAR();
   A = 0.f; B = 0.f;
 #pragma unroll
   for (int i = 0; i < DEC_WAVES; ++i) { A += red[i]; B += red[DEC_WAVES + i]; }
@@ -58,33 +64,40 @@ DEVI void ar_layernorm(float* v, const float* w, const float* b, int D, float* r
     v[tid] = o;
     vT[tid] = from_f<T>(o);
   }
-  __syncthreads();
+  AR_BAR();
 }
 
 // o[0..D) = dropout(softmax(q K^T / temp)) V over nk keys (rows kv[j * ld]: K at [h * hd], V at [D + h * hd]); the probabilities
 // are dropped with site index didx + h * nkP + j.  attend() of the greedy decoder with the dropout of nn.Dropout on the attention
 // weights (networks/EfficientSATRN.py:168,181).
 template <typename T>
-DEVI void ar_attend(const float* q, const T* kv, long ld, int nk, int H, int hd, float inv_temp, float* sc, int nkP, float* o, float* wred, T* oT,
-                    uint32_t seed, uint32_t site, uint32_t didx, float pdrop) {
+DEVI void ar_attend(const float* q, const T* kv, long ld, int voff, int nk, int H, int hd, int h0, float inv_temp, float* sc, int nkP, float* o,
+                    float* wred, T* oT, uint32_t seed, uint32_t site, uint32_t didx, float pdrop, const T* tail = nullptr /*LDS: the LAST key's
+                    row (k | v), when the caller has just produced it*/) {
+  // H heads starting at global head h0 (the dropout index space is the whole attention's); q, kv, tail, o, oT point at head h0's columns,
+  // V sits voff elements behind K
   constexpr int CH = TT<T>::CH, NT = DEC_THREADS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = H * hd, cph = hd / CH;
   for (int idx = tid; idx < nk * H; idx += NT) {
     const int j = idx / H, h = idx - j * H;
-    const T* kp = kv + (long)j * ld + h * hd;
+    const bool in_tail = tail && j == nk - 1;
+    const T* kp = kv + (long)(in_tail ? 0 : j) * ld + h * hd;
     const float* qp = q + h * hd;
     float acc = 0.f;
 #pragma unroll 4
     for (int c = 0; c < cph; ++c) {
       float f[CH];
-      unpack<T>(ld16(kp + c * CH), f);
+      uint4 raw;
+      // (two loads selected by value, not one load through a selected pointer: the rows live in different address spaces)
+      if (in_tail) raw = ld16(tail + h * hd + c * CH); else raw = ld16(kp + c * CH);
+      unpack<T>(raw, f);
 #pragma unroll
       for (int e = 0; e < CH; ++e) acc += f[e] * qp[c * CH + e];
     }
     sc[h * nkP + j] = acc * inv_temp;
   }
-  __syncthreads();
+  AR_BAR();
   for (int h = wave; h < H; h += (NT / 64)) {
     float m = -INFINITY;
     for (int j = lane; j < nk; j += 64) m = fmaxf(m, sc[h * nkP + j]);
@@ -95,22 +108,24 @@ DEVI void ar_attend(const float* q, const T* kv, long ld, int nk, int H, int hd,
     const float inv = 1.0f / s;
     for (int j = lane; j < nk; j += 64) {
       float pv = sc[h * nkP + j] * inv;
-      if (pdrop > 0.f) pv *= drop_scale(seed, site, didx + (uint32_t)(h * nkP + j), pdrop);
+      if (pdrop > 0.f) pv *= drop_scale(seed, site, didx + (uint32_t)((h0 + h) * nkP + j), pdrop);
       sc[h * nkP + j] = pv;
     }
   }
-  __syncthreads();
+  AR_BAR();
   const int cpr = D / CH, KG = NT / cpr;
   const int dc = tid % cpr, kg = tid / cpr;
   const int h = (dc * CH) / hd;
   float acc[CH];
 #pragma unroll
   for (int e = 0; e < CH; ++e) acc[e] = 0.f;
-  const T* vp = kv + D + dc * CH;
+  const T* vp = kv + voff + dc * CH;
   for (int j = kg; j < nk; j += 2 * KG) {
     const int j1 = j + KG;
     const int j1c = j1 < nk ? j1 : 0;
-    const uint4 r0 = ld16(vp + (long)j * ld), r1 = ld16(vp + (long)j1c * ld);
+    uint4 r0, r1;
+    if (tail && j == nk - 1) r0 = ld16(tail + voff + dc * CH); else r0 = ld16(vp + (long)j * ld);
+    if (tail && j1c == nk - 1) r1 = ld16(tail + voff + dc * CH); else r1 = ld16(vp + (long)j1c * ld);
     const float p0 = sc[h * nkP + j], p1 = j1 < nk ? sc[h * nkP + j1c] : 0.f;
     float f[CH];
     unpack<T>(r0, f);
@@ -128,7 +143,7 @@ DEVI void ar_attend(const float* q, const T* kv, long ld, int nk, int H, int hd,
 #pragma unroll
     for (int e = 0; e < CH; ++e) wred[wave * D + dc * CH + e] = acc[e];
   }
-  __syncthreads();
+  AR_BAR();
   if (tid < D) {
     float v = 0.f;
 #pragma unroll
@@ -136,20 +151,21 @@ DEVI void ar_attend(const float* q, const T* kv, long ld, int nk, int H, int hd,
     o[tid] = v;
     oT[tid] = from_f<T>(v);
   }
-  __syncthreads();
+  AR_BAR();
 }
 
 // LDS carve-up (floats); forward and backward share it
 template <typename T> struct ArSm {
   float *x, *qkv, *att, *tmp, *res, *ff, *sc, *dsc, *red, *lg, *wred, *lnacc;
   T* xT;   // [3D + F] product inputs in the compute dtype
+  T* kvT;  // [2D] forward: k | v of the layer input (the step's own history row)
   int nkP;
 };
 static size_t ar_lds_floats(const ArP& p, bool bwd) {
   const int nkP = ((p.T > p.Nsrc ? p.T : p.Nsrc) + 3) & ~3;
   const int lgn = ((p.V + 3) & ~3) > p.D ? ((p.V + 3) & ~3) : p.D;
-  size_t n = (size_t)p.D * 7 + p.F + (size_t)2 * p.H * nkP + 2 * DEC_WAVES + lgn + (size_t)DEC_WAVES * p.D + (3 * p.D + p.F);
-  if (bwd) n += (size_t)p.nlayers * 6 * p.D;
+  size_t n = (size_t)p.D * 9 + p.F + (size_t)2 * p.H * nkP + 2 * DEC_WAVES + lgn + (size_t)DEC_WAVES * p.D + (3 * p.D + p.F);
+  if (bwd) n += (size_t)6 * p.D;
   return n;
 }
 template <typename T> DEVI ArSm<T> ar_carve(float* sm, const ArP& p, bool bwd) {
@@ -168,27 +184,72 @@ template <typename T> DEVI ArSm<T> ar_carve(float* sm, const ArP& p, bool bwd) {
   S.lg = S.red + 2 * DEC_WAVES;   // [max(V padded, D)]: logits (forward), the saved query (backward)
   S.wred = S.lg + (((p.V + 3) & ~3) > D ? ((p.V + 3) & ~3) : D);   // [DEC_WAVES][D]
   S.xT = reinterpret_cast<T*>(S.wred + DEC_WAVES * D);   // [3D + F] (an f32 slot per element)
-  S.lnacc = S.wred + DEC_WAVES * D + (3 * D + F);         // backward: [nlayers][6][D] LayerNorm parameter gradients
+  S.kvT = reinterpret_cast<T*>(S.wred + DEC_WAVES * D + (3 * D + F));   // [2D] (an f32 slot per element)
+  S.lnacc = S.wred + DEC_WAVES * D + (3 * D + F) + 2 * D;         // backward: [6][D] LayerNorm parameter gradients of the workgroup's layer
   (void)bwd;
   return S;
 }
 
+// the layer's parameter block -> LDS from the device copy of the table (p.Ltab, written by ar_table_kernel: indexing the by-value kernel
+// argument with a runtime layer number would put the whole block into private memory); the ~50
+// pointers of a layer are then fetched where they are used instead of living in scalar registers for the whole kernel
+DEVI void ar_load_layer(const ArP& p, int l, ArLayer* dst) {
+  AR_BAR();
+  constexpr int NW = (int)(sizeof(ArLayer) / 8);
+  if ((int)threadIdx.x < NW)
+    reinterpret_cast<unsigned long long*>(dst)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(p.Ltab + l)[threadIdx.x];
+  AR_BAR();
+}
 template <typename T> DEVI T* ar_row(void* slab, long r, int C) { return (T*)slab + r * C; }
 template <typename T> DEVI const T* ar_crow(const void* slab, long r, int C) { return (const T*)slab + r * C; }
 
+#define AR_TICK(k) do { if (p.prof && b == 0 && blockIdx.x == 0 && tid == 0) { long long now_ = (long long)wall_clock64(); p.prof[k] += now_ - tlast; tlast = now_; } } while (0)
+
 // ===================================================================================== forward
+// Workgroup = (image, SLICE): the G = gridDim.x workgroups of an image split every weight matrix -- slice g owns H / G attention heads (their
+// q | k | v rows, their history columns, their columns of the two output projections) and F / G hidden units of the feed-forward block --
+// because one compute unit streams weights at ~50 GB/s and the 5.8 MB of a step were two thirds of its time.  Each of the three blocks of a
+// layer ends in ONE exchange: every slice publishes its partial D-vector of the block's output projection as {tag, f32} granules, every
+// slice adds the G partials in slice order (the same bits everywhere) and carries on alone -- residual, dropout, LayerNorm, generator and
+// argmax are replicated, so the slices stay in lock step without a second hand-off.  Mailbox p.fbox: [B][2][G][D] granules, zero before
+// the launch, tag = the exchange's number; two buffers by parity (a slice can be at most one exchange ahead of the slowest).
 template <typename T>
 __global__ __launch_bounds__(DEC_THREADS) void ar_fwd_kernel(ArP p) {
   extern __shared__ float sm[];
   const ArSm<T> S = ar_carve<T>(sm, p, false);
   const int D = p.D, F = p.F, V = p.V, H = p.H, hd = D / H, T_ = p.T, nkP = S.nkP;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int G = gridDim.x, gi = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int Hg = H / G, Dg = Hg * hd, h0 = gi * Hg, c0 = h0 * hd;   // this slice's heads = columns [c0, c0 + Dg) of q, k, v and the attention output
+  const int Fg = F / G, f0 = gi * Fg;                                // ... and hidden units [f0, f0 + Fg) of the feed-forward block
   const float inv_temp = rsqrtf((float)D), emb_scale = sqrtf((float)D);
   const uint32_t seed = p.seed ? *p.seed : 0u;
+  const long long t_end = (long long)wall_clock64() + p.timeout_ticks;
   __shared__ int s_tok;
   float *x = S.x, *qkv = S.qkv, *att = S.att, *tmp = S.tmp, *ff = S.ff, *sc = S.sc, *red = S.red, *wred = S.wred, *lg = S.lg;
   T* xT = S.xT;
+  T* aT = xT + D;        // attention output (this slice's columns), input of the output projection's K-slice
+  T* ffT = xT + 3 * D;   // hidden units (this slice's), input of the second feed-forward product's K-slice
+  unsigned xn = 0;       // exchanges so far
+  // out[0..D) = bias + sum over the slices (ascending) of their part[0..D)
+  auto xsum = [&](const float* part, float* out, const float* bias) {
+    ++xn;
+    if (tid < D) {
+      float a = bias ? bias[tid] : 0.f;
+      if (G == 1) a += part[tid];
+      else {
+        se_box_t* base = (se_box_t*)p.fbox + (((size_t)b * 2 + (xn & 1u)) * G) * D;
+        se_box_put(base + (size_t)gi * D + tid, xn, part[tid]);
+        float vals[8];
+        se_box_gather<8>(base + tid, (size_t)D, G, xn, t_end, vals, p.err);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k < G) a += vals[k];
+      }
+      out[tid] = a;
+    }
+    AR_BAR();
+  };
   int tok = p.sos;
+  long long tlast = p.prof ? (long long)wall_clock64() : 0;
   for (int t = 0; t < T_; ++t) {
     const long r = (long)b * T_ + t;
     // ---- embedding * sqrt(D) + PE(t)   (networks/EfficientSATRN.py:480-483, :425; no dropout on this path)
@@ -197,88 +258,128 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_fwd_kernel(ArP p) {
       x[tid] = v0;
       const T vt = from_f<T>(v0);
       xT[tid] = vt;
-      ar_row<T>(p.xs[0], r, D)[tid] = vt;
+      if (gi == 0) ar_row<T>(p.xs[0], r, D)[tid] = vt;
     }
-    if (tid == 0) p.in_ids[r] = tok;
-    __syncthreads();
+    if (tid == 0 && gi == 0) p.in_ids[r] = tok;
+    AR_BAR();
     for (int l = 0; l < p.nlayers; ++l) {
-      const ArLayer& w = p.L[l];
+      const ArLayer& w = p.Ltab[l];   // (device copy of the table: uniform scalar loads)
       T* cache = (T*)w.cache + (long)b * T_ * 2 * D;
-      // q | k | v of the layer INPUT
-      gemv<T>((const T*)w.wqkv, 3 * D, 0, w.bqkv, xT, qkv, 3 * D, D, ACT_NONE);
-      __syncthreads();
-      if (tid < D) ar_row<T>(w.q, r, D)[tid] = from_f<T>(qkv[tid]);
-      for (int i = tid; i < 2 * D; i += DEC_THREADS) {
-        const T v = from_f<T>(qkv[D + i]);
-        cache[(long)t * 2 * D + i] = v;
-        ar_row<T>(w.kvin, r, 2 * D)[i] = v;
+      AR_TICK(0);
+      // ---- q | k | v of the layer INPUT, this slice's heads: three Dg-row products side by side
+      {
+        constexpr int W3 = DEC_WAVES / 3;
+        gemv<T>((const T*)w.wqkv, 3 * D, c0, w.bqkv + c0, xT, qkv + c0, Dg, D, ACT_NONE, nullptr, 0, W3);
+        gemv<T>((const T*)w.wqkv, 3 * D, D + c0, w.bqkv + D + c0, xT, qkv + D + c0, Dg, D, ACT_NONE, nullptr, W3, W3);
+        gemv<T>((const T*)w.wqkv, 3 * D, 2 * D + c0, w.bqkv + 2 * D + c0, xT, qkv + 2 * D + c0, Dg, D, ACT_NONE, nullptr, 2 * W3, W3);
       }
-      __syncthreads();
-      ar_attend<T>(qkv, cache, 2 * D, t + 1, H, hd, inv_temp, sc, nkP, att, wred, xT, seed, p.site, ar_didx(p, b, t, l, AR_S_ATT), p.p_att);
-      if (tid < D) ar_row<T>(w.att, r, D)[tid] = xT[tid];
-      gemv<T>((const T*)w.wo, D, 0, w.bo, xT, tmp, D, D, ACT_NONE);
-      __syncthreads();
+      AR_BAR();
+      AR_TICK(1);
+      if (tid < Dg) ar_row<T>(w.q, r, D)[c0 + tid] = from_f<T>(qkv[c0 + tid]);
+      for (int i = tid; i < 2 * Dg; i += DEC_THREADS) {   // the step's own history row: attended from LDS, kept for the backward
+        const int col = (i / Dg) * D + c0 + (i % Dg);
+        const T v = from_f<T>(qkv[D + col]);
+        S.kvT[col] = v;
+        ar_row<T>(w.kvin, r, 2 * D)[col] = v;
+      }
+      AR_BAR();
+      ar_attend<T>(qkv + c0, cache + c0, 2 * D, D, t + 1, Hg, hd, h0, inv_temp, sc, nkP, att + c0, wred, aT + c0, seed, p.site,
+                   ar_didx(p, b, t, l, AR_S_ATT), p.p_att, S.kvT + c0);
+      AR_TICK(2);
+      if (tid < Dg) ar_row<T>(w.att, r, D)[c0 + tid] = aT[c0 + tid];
+      gemv<T>((const T*)w.wo + (long)(c0 / 32) * D * 32, D, 0, nullptr, aT + c0, tmp, D, Dg, ACT_NONE);   // this slice's K columns: a partial
+      AR_BAR();
+      xsum(tmp, tmp, w.bo);
+      AR_TICK(3);
       if (tid < D) {
         float o = tmp[tid];
         if (p.p_res > 0.f) o *= drop_scale(seed, p.site, ar_didx(p, b, t, l, AR_S_OUT) + tid, p.p_res);
         const float s1 = x[tid] + o;
         tmp[tid] = s1;
-        ar_row<T>(w.s1, r, D)[tid] = from_f<T>(s1);
+        if (gi == 0) ar_row<T>(w.s1, r, D)[tid] = from_f<T>(s1);
       }
-      __syncthreads();
+      AR_BAR();
       ar_layernorm<T>(tmp, w.ln1w, w.ln1b, D, red, xT);   // tmp = t1
-      if (tid < D) ar_row<T>(w.t1, r, D)[tid] = xT[tid];
-      gemv<T>((const T*)w.wq2, D, 0, w.bq2, xT, qkv, D, D, ACT_NONE);
-      __syncthreads();
-      if (tid < D) ar_row<T>(w.q2, r, D)[tid] = from_f<T>(qkv[tid]);
-      ar_attend<T>(qkv, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D, 2 * D, p.Nsrc, H, hd, inv_temp, sc, nkP, att, wred, xT, seed, p.site,
-                   ar_didx(p, b, t, l, AR_S_ATT2), p.p_att);
-      if (tid < D) ar_row<T>(w.a2, r, D)[tid] = xT[tid];
-      gemv<T>((const T*)w.wo2, D, 0, w.bo2, xT, x, D, D, ACT_NONE);
-      __syncthreads();
+      AR_TICK(4);
+      if (tid < D && gi == 0) ar_row<T>(w.t1, r, D)[tid] = xT[tid];
+      // ---- cross attention, this slice's heads
+      gemv<T>((const T*)w.wq2, D, c0, w.bq2 + c0, xT, qkv + c0, Dg, D, ACT_NONE);
+      AR_BAR();
+      AR_TICK(3);
+      if (tid < Dg) ar_row<T>(w.q2, r, D)[c0 + tid] = from_f<T>(qkv[c0 + tid]);
+      ar_attend<T>(qkv + c0, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D + c0, 2 * D, D, p.Nsrc, Hg, hd, h0, inv_temp, sc, nkP, att + c0, wred,
+                   aT + c0, seed, p.site, ar_didx(p, b, t, l, AR_S_ATT2), p.p_att);
+      AR_TICK(5);
+      if (tid < Dg) ar_row<T>(w.a2, r, D)[c0 + tid] = aT[c0 + tid];
+      gemv<T>((const T*)w.wo2 + (long)(c0 / 32) * D * 32, D, 0, nullptr, aT + c0, x, D, Dg, ACT_NONE);
+      AR_BAR();
+      xsum(x, x, w.bo2);
+      AR_TICK(3);
       if (tid < D) {
         float o = x[tid];
         if (p.p_res > 0.f) o *= drop_scale(seed, p.site, ar_didx(p, b, t, l, AR_S_OUT2) + tid, p.p_res);
         const float s2 = tmp[tid] + o;
         x[tid] = s2;
-        ar_row<T>(w.s2, r, D)[tid] = from_f<T>(s2);
+        if (gi == 0) ar_row<T>(w.s2, r, D)[tid] = from_f<T>(s2);
       }
-      __syncthreads();
+      AR_BAR();
       ar_layernorm<T>(x, w.ln2w, w.ln2b, D, red, xT);     // x = t2
-      if (tid < D) ar_row<T>(w.t2, r, D)[tid] = xT[tid];
-      T* ffT = xT + 3 * D;
-      gemv<T>((const T*)w.w0, F, 0, w.b0, xT, ff, F, D, ACT_RELU);
-      __syncthreads();
-      for (int i = tid; i < F; i += DEC_THREADS) {
-        float v = ff[i];
-        if (p.p_ff > 0.f) v *= drop_scale(seed, p.site, ar_didx(p, b, t, l, AR_S_F0) + i, p.p_ff);
+      AR_TICK(4);
+      if (tid < D && gi == 0) ar_row<T>(w.t2, r, D)[tid] = xT[tid];
+      // ---- feed-forward block, this slice's hidden units
+      gemv<T>((const T*)w.w0, F, f0, w.b0 + f0, xT, ff + f0, Fg, D, ACT_RELU);
+      AR_BAR();
+      AR_TICK(6);
+      for (int i = tid; i < Fg; i += DEC_THREADS) {
+        float v = ff[f0 + i];
+        if (p.p_ff > 0.f) v *= drop_scale(seed, p.site, ar_didx(p, b, t, l, AR_S_F0) + f0 + i, p.p_ff);
         const T vt = from_f<T>(v);
-        ffT[i] = vt;
-        ar_row<T>(w.f0, r, F)[i] = vt;
+        ffT[f0 + i] = vt;
+        ar_row<T>(w.f0, r, F)[f0 + i] = vt;
       }
-      __syncthreads();
-      gemv<T>((const T*)w.w1, D, 0, w.b1, ffT, tmp, D, F, ACT_RELU);
-      __syncthreads();
+      AR_BAR();
+      // N / 16 = 16 output groups keep 8 waves busy: the two halves of this slice's K run side by side and meet in the exchange's input
+      if (Fg % 64 == 0) {
+        gemv<T>((const T*)w.w1 + (long)(f0 / 32) * D * 32, D, 0, nullptr, ffT + f0, tmp, D, Fg / 2, ACT_NONE, nullptr, 0, DEC_WAVES / 2);
+        gemv<T>((const T*)w.w1 + (long)((f0 + Fg / 2) / 32) * D * 32, D, 0, nullptr, ffT + f0 + Fg / 2, att, D, Fg / 2, ACT_NONE, nullptr, DEC_WAVES / 2,
+                DEC_WAVES / 2);
+        AR_BAR();
+        if (tid < D) tmp[tid] += att[tid];
+      } else {
+        gemv<T>((const T*)w.w1 + (long)(f0 / 32) * D * 32, D, 0, nullptr, ffT + f0, tmp, D, Fg, ACT_NONE);
+      }
+      AR_BAR();
+      xsum(tmp, tmp, w.b1);
+      AR_TICK(7);
       if (tid < D) {
-        float v = tmp[tid];
+        float v = fmaxf(tmp[tid], 0.f);
         if (p.p_ff > 0.f) v *= drop_scale(seed, p.site, ar_didx(p, b, t, l, AR_S_F1) + tid, p.p_ff);
         const T vt = from_f<T>(v);
-        ar_row<T>(w.f1d, r, D)[tid] = vt;
+        if (gi == 0) ar_row<T>(w.f1d, r, D)[tid] = vt;
         x[tid] = x[tid] + v;     // s3
       }
-      __syncthreads();
+      AR_BAR();
       ar_layernorm<T>(x, w.ln3w, w.ln3b, D, red, xT);     // x = layer output
-      if (tid < D) ar_row<T>(p.xs[l + 1], r, D)[tid] = xT[tid];
-      // history entry for the later steps: k/v of the layer OUTPUT
-      gemv<T>((const T*)w.wqkv, 3 * D, D, w.bqkv + D, xT, qkv, 2 * D, D, ACT_NONE);
-      __syncthreads();
-      for (int i = tid; i < 2 * D; i += DEC_THREADS) cache[(long)t * 2 * D + i] = from_f<T>(qkv[i]);
-      __syncthreads();
+      AR_TICK(4);
+      if (tid < D && gi == 0) ar_row<T>(p.xs[l + 1], r, D)[tid] = xT[tid];
+      // ---- history entry for the later steps: k | v of the layer OUTPUT, this slice's columns
+      gemv<T>((const T*)w.wqkv, 3 * D, D + c0, w.bqkv + D + c0, xT, qkv + c0, Dg, D, ACT_NONE, nullptr, 0, DEC_WAVES / 2);
+      gemv<T>((const T*)w.wqkv, 3 * D, 2 * D + c0, w.bqkv + 2 * D + c0, xT, qkv + D + c0, Dg, D, ACT_NONE, nullptr, DEC_WAVES / 2, DEC_WAVES / 2);
+      AR_BAR();
+      for (int i = tid; i < 2 * Dg; i += DEC_THREADS) {
+        const int col = (i / Dg) * D + c0 + (i % Dg);
+        cache[(long)t * 2 * D + col] = from_f<T>(qkv[col]);
+      }
+      AR_BAR();
+      AR_TICK(8);
     }
-    gemv<T>((const T*)p.wgen, V, 0, p.bgen, xT, lg, V, D, ACT_NONE);
-    __syncthreads();
-    float* out = p.logits + r * V;
-    for (int i = tid; i < V; i += DEC_THREADS) out[i] = lg[i];
+    gemv<T>((const T*)p.wgen, V, 0, p.bgen, xT, lg, V, D, ACT_NONE);   // (replicated: every slice needs the next token)
+    AR_BAR();
+    AR_TICK(9);
+    if (gi == 0) {
+      float* out = p.logits + r * V;
+      for (int i = tid; i < V; i += DEC_THREADS) out[i] = lg[i];
+    }
     if (tid < 64) {   // argmax, lowest index wins ties (torch.argmax)
       float best = -INFINITY;
       int bi = 0x7fffffff;
@@ -289,11 +390,12 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_fwd_kernel(ArP p) {
         int oi = __shfl_xor(bi, o, 64);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
       }
-      if (tid == 0) { s_tok = bi; p.ids[r] = bi; }
+      if (tid == 0) { s_tok = bi; if (gi == 0) p.ids[r] = bi; }
     }
-    __syncthreads();
+    __syncthreads();   // (full: the step's history rows are in memory before the next step reads them)
     tok = s_tok;
-    __syncthreads();
+    AR_BAR();
+    AR_TICK(10);
   }
 }
 
@@ -319,7 +421,7 @@ DEVI void ar_ln_bwd(const float* dy, const T* s_a, const T* s_b, const float* w,
     dgw[tid] += g * xh;
     dgb[tid] += g;
   }
-  __syncthreads();
+  AR_BAR();
 }
 
 // Backward of one attention row (the forward's ar_attend): q, da in LDS; key rows kv[j * ld] for j < nk, except the LAST one when
@@ -352,7 +454,7 @@ DEVI void ar_attend_bwd(const float* q, const float* da, const T* kv, long ld, i
     sc[h * nkP + j] = a1 * inv_temp;
     dsc[h * nkP + j] = a2;
   }
-  __syncthreads();
+  AR_BAR();
   // softmax again, its backward: sc <- dropped probabilities, dsc <- d(scores) * inv_temp
   for (int h = wave; h < H; h += (NT / 64)) {
     float m = -INFINITY;
@@ -379,7 +481,7 @@ DEVI void ar_attend_bwd(const float* q, const float* da, const T* kv, long ld, i
       sc[h * nkP + j] = pv * ms;
     }
   }
-  __syncthreads();
+  AR_BAR();
   // one thread per (key group, 16-byte chunk of the D dims): dK_j, dV_j out, dq accumulated
   const int cpr = D / CH, KG = NT / cpr;
   const int dc = tid % cpr, kg = tid / cpr;
@@ -418,14 +520,14 @@ DEVI void ar_attend_bwd(const float* q, const float* da, const T* kv, long ld, i
 #pragma unroll
     for (int e = 0; e < CH; ++e) wred[wave * D + dc * CH + e] = aq[e];
   }
-  __syncthreads();
+  AR_BAR();
   if (tid < D) {
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < (NT / 64); ++w) v += wred[w * D + tid];
     dq[tid] = v;
   }
-  __syncthreads();
+  AR_BAR();
 }
 
 template <typename T>
@@ -433,23 +535,35 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
   extern __shared__ float sm[];
   const ArSm<T> S = ar_carve<T>(sm, p, true);
   const int D = p.D, F = p.F, H = p.H, hd = D / H, T_ = p.T, nkP = S.nkP, NL = p.nlayers;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  // workgroup = (image, LAYER): step t of layer l needs the layer above at step t (its input gradient) and this layer at steps > t (the
+  // history entries' gradients), so the layers of an image form a pipeline over the steps -- the layer below runs one step behind.  The
+  // hand-off is one D-vector of {tag, f32} granules per (image, layer, step), written once (p.gbox zeroed before the launch).
+  const int b = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;
   const float inv_temp = rsqrtf((float)D);
   const uint32_t seed = p.seed ? *p.seed : 0u;
-  // g: gradient of the current layer output; res: gradient that travels on through the residual connections
+  const long long t_end = (long long)wall_clock64() + p.timeout_ticks;
+  // g: gradient of the layer output; res: gradient that travels on through the residual connections
   float *g = S.x, *qkv = S.qkv, *att = S.att, *tmp = S.tmp, *res = S.res, *ff = S.ff, *sc = S.sc, *dsc = S.dsc, *red = S.red, *wred = S.wred;
   float* qv = S.lg;   // [D] the saved query of the attention being differentiated
   T* xT = S.xT;
   float* lnacc = S.lnacc;
-  for (int i = tid; i < NL * 6 * D; i += DEC_THREADS) lnacc[i] = 0.f;
-  __syncthreads();
+  __shared__ ArLayer sL;
+  for (int i = tid; i < 6 * D; i += DEC_THREADS) lnacc[i] = 0.f;
+  ar_load_layer(p, l, &sL);
   for (int t = T_ - 1; t >= 0; --t) {
     const long r = (long)b * T_ + t;
-    if (tid < D) g[tid] = to_f(ar_crow<T>(p.dxtop, r, D)[tid]);   // generator's data gradient (one product before this launch)
-    __syncthreads();
-    for (int l = NL - 1; l >= 0; --l) {
-      const ArLayer& w = p.L[l];
-      float* la = lnacc + (size_t)l * 6 * D;
+    if (tid < D) {
+      if (l == NL - 1) g[tid] = to_f(ar_crow<T>(p.dxtop, r, D)[tid]);   // generator's data gradient (one product before this launch)
+      else {
+        float v;
+        se_box_wait((se_box_t*)p.gbox + (((size_t)b * NL + l) * T_ + t) * D + tid, p.tag, t_end, v, p.err);
+        g[tid] = v;
+      }
+    }
+    __syncthreads();   // (full: the later steps' additions to this step's history-entry gradients are in memory)
+    {
+      const ArLayer& w = sL;
+      float* la = lnacc;
       const T* cache = (const T*)w.cache + (long)b * T_ * 2 * D;
       float* dkva = w.dkvacc + (long)b * T_ * 2 * D;
       // ---- the history entry k/v(output_t): its gradient is complete (steps t+1.. are done) -> slab, and on into the output
@@ -458,11 +572,11 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
         xT[i] = v;
         ar_row<T>(w.dkvo, r, 2 * D)[i] = v;
       }
-      __syncthreads();
+      AR_BAR();
       gemv<T>((const T*)w.wqkvT + (long)(D / 32) * D * 32, D, 0, nullptr, xT, tmp, D, 2 * D, ACT_NONE);
-      __syncthreads();
+      AR_BAR();
       if (tid < D) g[tid] += tmp[tid];
-      __syncthreads();
+      AR_BAR();
       // ---- LayerNorm 3 (input s3 = t2 + f1d) -> res = d(t2) so far; d(f1 before ReLU / dropout)
       ar_ln_bwd<T>(g, ar_crow<T>(w.t2, r, D), ar_crow<T>(w.f1d, r, D), w.ln3w, D, red, res, la + 4 * D, la + 5 * D);
       if (tid < D) {
@@ -473,9 +587,9 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
         xT[tid] = vt;
         ar_row<T>(w.df1, r, D)[tid] = vt;
       }
-      __syncthreads();
+      AR_BAR();
       gemv<T>((const T*)w.w1T, F, 0, nullptr, xT, ff, F, D, ACT_NONE);
-      __syncthreads();
+      AR_BAR();
       T* ffT = xT + 3 * D;
       for (int i = tid; i < F; i += DEC_THREADS) {
         const float f0v = to_f(ar_crow<T>(w.f0, r, F)[i]);
@@ -485,11 +599,12 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
         ffT[i] = vt;
         ar_row<T>(w.df0, r, F)[i] = vt;
       }
-      __syncthreads();
-      gemv<T>((const T*)w.w0T, D, 0, nullptr, ffT, tmp, D, F, ACT_NONE);
-      __syncthreads();
-      if (tid < D) res[tid] += tmp[tid];     // d(t2)
-      __syncthreads();
+      AR_BAR();
+      gemv<T>((const T*)w.w0T, D, 0, nullptr, ffT, tmp, D, F / 2, ACT_NONE, nullptr, 0, DEC_WAVES / 2);
+      gemv<T>((const T*)w.w0T + (long)(F / 64) * D * 32, D, 0, nullptr, ffT + F / 2, att, D, F / 2, ACT_NONE, nullptr, DEC_WAVES / 2, DEC_WAVES / 2);
+      AR_BAR();
+      if (tid < D) res[tid] += tmp[tid] + att[tid];     // d(t2)
+      AR_BAR();
       // ---- LayerNorm 2 (input s2) -> res = d(t1) so far; d(o2)
       ar_ln_bwd<T>(res, ar_crow<T>(w.s2, r, D), (const T*)nullptr, w.ln2w, D, red, res, la + 2 * D, la + 3 * D);
       if (tid < D) {
@@ -500,9 +615,9 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
         ar_row<T>(w.dout2, r, D)[tid] = vt;
         qv[tid] = to_f(ar_crow<T>(w.q2, r, D)[tid]);
       }
-      __syncthreads();
+      AR_BAR();
       gemv<T>((const T*)w.wo2T, D, 0, nullptr, xT, att, D, D, ACT_NONE);   // d(a2)
-      __syncthreads();
+      AR_BAR();
       ar_attend_bwd<T>(qv, att, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D, 2 * D, p.Nsrc, (const T*)nullptr,
                        w.dcross + (long)b * p.Nsrc * 2 * D, nullptr, H, hd, inv_temp, sc, dsc, nkP, qkv, wred, seed, p.site,
                        ar_didx(p, b, t, l, AR_S_ATT2), p.p_att);
@@ -511,11 +626,11 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
         xT[tid] = vt;
         ar_row<T>(w.dq2, r, D)[tid] = vt;
       }
-      __syncthreads();
+      AR_BAR();
       gemv<T>((const T*)w.wq2T, D, 0, nullptr, xT, tmp, D, D, ACT_NONE);
-      __syncthreads();
+      AR_BAR();
       if (tid < D) res[tid] += tmp[tid];     // d(t1)
-      __syncthreads();
+      AR_BAR();
       // ---- LayerNorm 1 (input s1) -> res = d(layer input) through the residual; d(o)
       ar_ln_bwd<T>(res, ar_crow<T>(w.s1, r, D), (const T*)nullptr, w.ln1w, D, red, res, la, la + D);
       if (tid < D) {
@@ -526,9 +641,9 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
         ar_row<T>(w.dout, r, D)[tid] = vt;
         qv[tid] = to_f(ar_crow<T>(w.q, r, D)[tid]);
       }
-      __syncthreads();
+      AR_BAR();
       gemv<T>((const T*)w.woT, D, 0, nullptr, xT, att, D, D, ACT_NONE);    // d(att)
-      __syncthreads();
+      AR_BAR();
       // self-attention over the t earlier outputs' entries (cache rows) and the step's own input entry (saved kvin row)
       ar_attend_bwd<T>(qv, att, cache, 2 * D, t + 1, ar_crow<T>(w.kvin, r, 2 * D), dkva, qkv + D, H, hd, inv_temp, sc, dsc, nkP, qkv, wred, seed,
                        p.site, ar_didx(p, b, t, l, AR_S_ATT), p.p_att);
@@ -537,17 +652,27 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
         xT[i] = vt;
         ar_row<T>(w.dqkvi, r, 3 * D)[i] = vt;
       }
-      __syncthreads();
+      AR_BAR();
       gemv<T>((const T*)w.wqkvT, D, 0, nullptr, xT, tmp, D, 3 * D, ACT_NONE);
-      __syncthreads();
-      if (tid < D) g[tid] = res[tid] + tmp[tid];     // gradient of the layer input = of the layer below's output
-      __syncthreads();
+      AR_BAR();
+      if (tid < D) {
+        const float gi = res[tid] + tmp[tid];     // gradient of the layer input = of the layer below's output
+        if (l == 0) ar_row<T>(p.dx0, r, D)[tid] = from_f<T>(gi);   // -> embedding table (launch_embed_bwd over the slab)
+        else se_box_put((se_box_t*)p.gbox + (((size_t)b * NL + (l - 1)) * T_ + t) * D + tid, p.tag, gi);
+      }
+      AR_BAR();
     }
-    if (tid < D) ar_row<T>(p.dx0, r, D)[tid] = from_f<T>(g[tid]);   // -> embedding table (launch_embed_bwd over the slab)
-    __syncthreads();
   }
   // LayerNorm parameter gradients of this image's T steps -> per-image partials (folded over the images in fixed order by ar_ln_fold_kernel)
-  for (int i = tid; i < NL * 6 * D; i += DEC_THREADS) p.lnpart[(size_t)b * NL * 6 * D + i] = lnacc[i];
+  for (int i = tid; i < 6 * D; i += DEC_THREADS) p.lnpart[((size_t)b * NL + l) * 6 * D + i] = lnacc[i];
+}
+
+// device copy of the layer table (constant indices: scalar loads from the kernel argument)
+__global__ void ar_table_kernel(ArP p, ArLayer* out) {
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = p.L[k];
+  }
 }
 
 // dln*[c] += sum over the images (ascending) of lnpart[b][l][k][c]
@@ -558,7 +683,7 @@ __global__ void ar_ln_fold_kernel(ArP p) {
   const int l = i / (6 * D), k = (i / D) % 6, c = i % D;
   float a = 0.f;
   for (int b = 0; b < p.B; ++b) a += p.lnpart[(size_t)b * NL * 6 * D + i];
-  const ArLayer& w = p.L[l];
+  const ArLayer& w = p.Ltab[l];
   float* dst = k == 0 ? w.dln1w : k == 1 ? w.dln1b : k == 2 ? w.dln2w : k == 3 ? w.dln2b : k == 4 ? w.dln3w : w.dln3b;
   dst[c] += a;
 }
@@ -569,8 +694,8 @@ template <typename T> static int ar_launch(const ArP& p, bool bwd, hipStream_t s
   const void* fn = bwd ? (const void*)ar_bwd_kernel<T> : (const void*)ar_fwd_kernel<T>;
   static bool attr[2] = {false, false};
   if (!attr[bwd ? 1 : 0]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr[bwd ? 1 : 0] = true; }
-  if (bwd) hipLaunchKernelGGL((ar_bwd_kernel<T>), dim3(p.B), dim3(DEC_THREADS), sh, s, p);
-  else hipLaunchKernelGGL((ar_fwd_kernel<T>), dim3(p.B), dim3(DEC_THREADS), sh, s, p);
+  if (bwd) hipLaunchKernelGGL((ar_bwd_kernel<T>), dim3(p.B, p.nlayers), dim3(DEC_THREADS), sh, s, p);
+  else hipLaunchKernelGGL((ar_fwd_kernel<T>), dim3(p.G, p.B), dim3(DEC_THREADS), sh, s, p);
   return 0;
 }
 
@@ -578,7 +703,7 @@ template <typename T> static int ar_launch(const ArP& p, bool bwd, hipStream_t s
 
 bool ar_train_ok(int dt, int D, int F, int V, int H, int T, int Nsrc, int nlayers) {
   if (sw_off("ar_fused")) return false;
-  if (D % 32 || F % 32 || D > DEC_THREADS || nlayers > 4 || nlayers < 1 || H < 1 || D % H) return false;
+  if (D % 32 || F % 64 || D > DEC_THREADS || nlayers > 4 || nlayers < 1 || H < 1 || D % H) return false;
   const int ch = dt == DT_BF16 ? 8 : 4, cpr = D / ch, hd = D / H;
   if (hd % ch || cpr > 64 || (cpr & (cpr - 1))) return false;
   const int nkP = ((T > Nsrc ? T : Nsrc) + 3) & ~3;
@@ -588,12 +713,71 @@ bool ar_train_ok(int dt, int D, int F, int V, int H, int T, int Nsrc, int nlayer
   return ar_lds_floats(p, true) * sizeof(float) <= 150 * 1024;
 }
 
-int launch_ar_fwd(int dt, const ArP& p, hipStream_t s) {
-  g_route[RT_AR_FUSED]++;
-  return dt == DT_BF16 ? ar_launch<bf16_t>(p, false, s) : ar_launch<float>(p, false, s);
+// slices per image of the forward: the largest of 8, 4, 2, 1 (or the ar_split knob) that divides the heads into whole 32-column
+// groups and the hidden units into whole 32-unit panels
+int ar_fwd_slices(int dt, int D, int F, int H) {
+  const int ch = dt == DT_BF16 ? 8 : 4, hd = D / H;
+  const int want = (int)sw_knob("ar_split", 4);
+  for (int G = want > 8 ? 8 : want; G > 1; G >>= 1) {
+    if (H % G || F % G) continue;
+    const int Dg = (H / G) * hd, Fg = F / G, cpr = Dg / ch;
+    if (Dg % 32 || Fg % 32 || cpr < 1 || (cpr & (cpr - 1))) continue;
+    return G;
+  }
+  return 1;
 }
-int launch_ar_bwd(int dt, const ArP& p, hipStream_t s) {
-  if (!p.lnpart) return -1;
+size_t ar_fwd_box_bytes(int B, int G, int D) { return (size_t)B * 2 * G * D * 8; }
+int launch_ar_fwd(int dt, const ArP& p0, hipStream_t s) {
+  if (!p0.Ltab || p0.G < 1 || p0.G > 8 || (p0.G > 1 && !p0.fbox)) return -1;
+  ArP p = p0;
+  if (p.G > 1) {
+    // the slices of an image wait for each other: B * G workgroups of 1024 threads, one per compute unit
+    const size_t sh = ar_lds_floats(p, false) * sizeof(float);
+    const void* fn = dt == DT_BF16 ? (const void*)ar_fwd_kernel<bf16_t> : (const void*)ar_fwd_kernel<float>;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if ((long)p.B * p.G > resident_capacity(fn, DEC_THREADS, sh)) return -1;
+    p.err = device_error_word();
+    if (!p.err) return -1;
+    p.timeout_ticks = 500000000LL;   // 5 s at 100 MHz
+    launch_fill(p.fbox, 0, ar_fwd_box_bytes(p.B, p.G, p.D), s);
+  }
+  g_route[RT_AR_FUSED]++;
+  static const bool want_prof = sw_prof("ar");   // debugging aid: per-phase clocks of workgroup 0 (synchronises)
+  static long long* prof_buf = nullptr;
+  p.prof = nullptr;
+  if (want_prof) {
+    if (!prof_buf) (void)hipMalloc((void**)&prof_buf, 16 * sizeof(long long));
+    (void)hipMemsetAsync(prof_buf, 0, 16 * sizeof(long long), s);
+    p.prof = prof_buf;
+  }
+  hipLaunchKernelGGL(ar_table_kernel, dim3(1), dim3(64), 0, s, p, p.Ltab);
+  const int rc = dt == DT_BF16 ? ar_launch<bf16_t>(p, false, s) : ar_launch<float>(p, false, s);
+  if (want_prof && rc == 0) {
+    long long h[16];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, prof_buf, sizeof(h), hipMemcpyDeviceToHost);
+    const char* nm[11] = {"slab stores / residual / dropout passes", "q|k|v product", "self attention", "DxD products (wo, q2, wo2)", "layernorm", "cross attention",
+                          "ffn w0", "ffn w1", "k|v of the output", "generator", "argmax / step end"};
+    double tot = 0;
+    for (int i = 0; i < 11; ++i) tot += (double)h[i];
+    for (int i = 0; i < 11; ++i) fprintf(stderr, "[ar prof] %-42s %8.2f ms (%.1f%%)\n", nm[i], h[i] / 1e5, 100.0 * h[i] / tot);
+  }
+  return rc;
+}
+size_t ar_bwd_box_bytes(int B, int T, int D, int nlayers) { return (size_t)B * nlayers * T * D * 8; }
+int launch_ar_bwd(int dt, const ArP& p0, hipStream_t s) {
+  if (!p0.lnpart || !p0.gbox || !p0.Ltab) return -1;
+  ArP p = p0;
+  // the layer workgroups of an image wait for each other: B * nlayers workgroups of 1024 threads, one per compute unit
+  const size_t sh = ar_lds_floats(p, true) * sizeof(float);
+  const void* fn = dt == DT_BF16 ? (const void*)ar_bwd_kernel<bf16_t> : (const void*)ar_bwd_kernel<float>;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  if ((long)p.B * p.nlayers > resident_capacity(fn, DEC_THREADS, sh)) return -1;
+  p.err = device_error_word();
+  if (!p.err) return -1;
+  p.tag = se_next_tag(); p.timeout_ticks = 500000000LL;   // 5 s at 100 MHz
+  launch_fill(p.gbox, 0, ar_bwd_box_bytes(p.B, p.T, p.D, p.nlayers), s);
+  hipLaunchKernelGGL(ar_table_kernel, dim3(1), dim3(64), 0, s, p, p.Ltab);   // (the backward's slabs and accumulators joined the table)   // (a kernel, not a memset node: see engine.cpp on captured memsets)
   const int rc = dt == DT_BF16 ? ar_launch<bf16_t>(p, true, s) : ar_launch<float>(p, true, s);
   if (rc) return rc;
   const int n = p.nlayers * 6 * p.D;
