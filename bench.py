@@ -575,7 +575,7 @@ def main():
                 out["train_tf_schedule"] = dict(teacher_forced_ms=round(ms, 3), autoregressive_ms=round(ar_ms, 3), ratio=round(ar_ms / ms, 2),
                                                 mean_ms_at_tf_0_55=round(0.55 * ms + 0.45 * ar_ms, 3),
                                                 images_per_s_at_tf_0_55=round(B / (0.55 * ms + 0.45 * ar_ms) * 1e3, 1),
-                                                note="autoregressive branch = 127 dependent decoder steps with gradients (~46 launches forward, ~80 backward per step): launch-bound (hipGraph replay of the same step measured slower: 112 vs 88 ms, DESIGN 10.14), not rebuilt this round; reachable from the fused / data-parallel step (train_step(teacher_forcing_ratio=...), rank-shared coin)")
+                                                note="autoregressive branch = 127 dependent decoder steps with gradients (networks/EfficientSATRN.py:496-525) in two launches (kernels_ar.hip): forward = 4 weight slices per image, one exchange per block; backward = one workgroup per image and layer, pipelined over the steps; weight gradients as products over [B*T]-row slabs. The operator-level form (SATRN_OFF=ar_fused, ~126 launches per step) measured 95 ms. Reachable from the fused / data-parallel step (train_step(teacher_forcing_ratio=...), rank-shared coin)")
             except Exception as ex:  # noqa: BLE001
                 import traceback
                 traceback.print_exc()
