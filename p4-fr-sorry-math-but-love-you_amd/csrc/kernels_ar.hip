@@ -154,6 +154,82 @@ DEVI void ar_attend(const float* q, const T* kv, long ld, int voff, int nk, int 
   AR_BAR();
 }
 
+// The same attention with ONE WAVE PER HEAD and no workgroup barrier inside (the caller's barrier behind it is the only one): for a slice of two
+// heads ar_attend's four barriers and two dependent round trips were 6 us of a 40 us layer step.  Scores: a lane per key (two for nk <= 128);
+// the V rows are requested BEFORE the softmax (they do not depend on it); probabilities pass through LDS inside the wave; P V: lane = (key
+// group, 16-byte chunk of the head), reduced over the key groups by shuffles.  Needs hd / CH (chunks per head) a power of two <= 16.
+template <typename T>
+DEVI void ar_attend_w(const float* q, const T* kv, long ld, int voff, int nk, int H, int hd, int h0, float inv_temp, float* sc, int nkP, float* o, T* oT,
+                      uint32_t seed, uint32_t site, uint32_t didx, float pdrop, const T* tail = nullptr) {
+  constexpr int CH = TT<T>::CH;
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+  if (h >= H) return;
+  const int cph = hd / CH, KGW = 64 / cph;   // chunks per head, key groups of the wave
+  const float* qp = q + h * hd;
+  float* sch = sc + h * nkP;
+  // ---- scores
+  float m = -INFINITY;
+  for (int j = lane; j < nk; j += 64) {
+    const bool in_tail = tail && j == nk - 1;
+    const T* kp = kv + (long)(in_tail ? 0 : j) * ld + h * hd;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int c = 0; c < cph; ++c) {
+      float f[CH];
+      uint4 raw;
+      if (in_tail) raw = ld16(tail + h * hd + c * CH); else raw = ld16(kp + c * CH);
+      unpack<T>(raw, f);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) acc += f[e] * qp[c * CH + e];
+    }
+    acc *= inv_temp;
+    sch[j] = acc;
+    m = fmaxf(m, acc);
+  }
+  // ---- V rows of this lane's (key group, chunk): up to 8 keys per pass, requested now
+  const int c = lane % cph, kg = lane / cph;
+  float out[CH];
+#pragma unroll
+  for (int e = 0; e < CH; ++e) out[e] = 0.f;
+  m = wave_max(m);
+  float ssum = 0.f;
+  for (int j = lane; j < nk; j += 64) { const float e = __expf(sch[j] - m); sch[j] = e; ssum += e; }
+  ssum = wave_sum(ssum);
+  const float inv = 1.0f / ssum;
+  for (int j = lane; j < nk; j += 64) {
+    float pv = sch[j] * inv;
+    if (pdrop > 0.f) pv *= drop_scale(seed, site, didx + (uint32_t)((h0 + h) * nkP + j), pdrop);
+    sch[j] = pv;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's LDS writes are done before its lanes read each other's probabilities
+  for (int j0 = kg; j0 < nk; j0 += 8 * KGW) {
+    uint4 raw[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u * KGW;
+      const int jc = j < nk ? j : 0;
+      if (tail && jc == nk - 1) raw[u] = ld16(tail + voff + h * hd + c * CH); else raw[u] = ld16(kv + (long)jc * ld + voff + h * hd + c * CH);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + u * KGW;
+      const float pv = j < nk ? sch[j] : 0.f;
+      float f[CH];
+      unpack<T>(raw[u], f);
+#pragma unroll
+      for (int e = 0; e < CH; ++e) out[e] += pv * f[e];
+    }
+  }
+  for (int o2 = cph; o2 < 64; o2 <<= 1) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) out[e] += __shfl_xor(out[e], o2, 64);
+  }
+  if (lane < cph) {
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { o[h * hd + c * CH + e] = out[e]; oT[h * hd + c * CH + e] = from_f<T>(out[e]); }
+  }
+}
+
 // LDS carve-up (floats); forward and backward share it
 template <typename T> struct ArSm {
   float *x, *qkv, *att, *tmp, *res, *ff, *sc, *dsc, *red, *lg, *wred, *lnacc;
@@ -230,21 +306,61 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_fwd_kernel(ArP p) {
   T* aT = xT + D;        // attention output (this slice's columns), input of the output projection's K-slice
   T* ffT = xT + 3 * D;   // hidden units (this slice's), input of the second feed-forward product's K-slice
   unsigned xn = 0;       // exchanges so far
-  // out[0..D) = bias + sum over the slices (ascending) of their part[0..D)
-  auto xsum = [&](const float* part, float* out, const float* bias) {
+  // End of a block, all in wave 0 (no workgroup barrier inside: the sums of the LayerNorm are wave reductions over D / 64 elements per lane):
+  //   a = act(bias + sum over the slices (ascending) of their part)  ->  dropout(site)  ->  [act_slab]  ->  s = resid + a  ->  [s_slab]
+  //   ->  out = LayerNorm(s) * gamma + beta  (f32 in `out`, compute dtype in xT, [o_slab])
+  auto block_end = [&](const float* part, const float* bias, bool relu, int site, float pdrop, const float* resid, const float* gamma,
+                       const float* beta, float* out, void* act_slab, void* s_slab, void* o_slab, int l, int t, long r) {
     ++xn;
-    if (tid < D) {
-      float a = bias ? bias[tid] : 0.f;
-      if (G == 1) a += part[tid];
-      else {
+    if (tid < 64) {
+      constexpr int MAXE = 4;   // D <= 256 (ar_train_ok)
+      const int NE = D >> 6;
+      float sv[MAXE];
+      if (G > 1) {
         se_box_t* base = (se_box_t*)p.fbox + (((size_t)b * 2 + (xn & 1u)) * G) * D;
-        se_box_put(base + (size_t)gi * D + tid, xn, part[tid]);
-        float vals[8];
-        se_box_gather<8>(base + tid, (size_t)D, G, xn, t_end, vals, p.err);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (k < G) a += vals[k];
+        for (int k = 0; k < MAXE; ++k) if (k < NE) se_box_put(base + (size_t)gi * D + tid + 64 * k, xn, part[tid + 64 * k]);
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k)
+          if (k < NE) {
+            float vals[8];
+            se_box_gather<8>(base + tid + 64 * k, (size_t)D, G, xn, t_end, vals, p.err);
+            float a = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < 8; ++g2) if (g2 < G) a += vals[g2];
+            sv[k] = a;
+          }
+      } else {
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) if (k < NE) sv[k] = part[tid + 64 * k];
       }
-      out[tid] = a;
+      float sum = 0.f, sq = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXE; ++k)
+        if (k < NE) {
+          const int e = tid + 64 * k;
+          float a = sv[k] + bias[e];
+          if (relu) a = fmaxf(a, 0.f);
+          if (pdrop > 0.f) a *= drop_scale(seed, p.site, ar_didx(p, b, t, l, site) + e, pdrop);
+          if (act_slab && gi == 0) ar_row<T>(act_slab, r, D)[e] = from_f<T>(a);
+          const float sx = resid[e] + a;
+          if (s_slab && gi == 0) ar_row<T>(s_slab, r, D)[e] = from_f<T>(sx);
+          sv[k] = sx;
+          sum += sx; sq += sx * sx;
+        }
+      sum = wave_sum(sum); sq = wave_sum(sq);
+      const float mean = sum / (float)D;
+      const float rstd = rsqrtf(fmaxf(sq / (float)D - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+      for (int k = 0; k < MAXE; ++k)
+        if (k < NE) {
+          const int e = tid + 64 * k;
+          const float o = (sv[k] - mean) * rstd * gamma[e] + beta[e];
+          out[e] = o;
+          const T ot = from_f<T>(o);
+          xT[e] = ot;
+          if (gi == 0) ar_row<T>(o_slab, r, D)[e] = ot;
+        }
     }
     AR_BAR();
   };
@@ -283,49 +399,31 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_fwd_kernel(ArP p) {
         ar_row<T>(w.kvin, r, 2 * D)[col] = v;
       }
       AR_BAR();
-      ar_attend<T>(qkv + c0, cache + c0, 2 * D, D, t + 1, Hg, hd, h0, inv_temp, sc, nkP, att + c0, wred, aT + c0, seed, p.site,
-                   ar_didx(p, b, t, l, AR_S_ATT), p.p_att, S.kvT + c0);
+      ar_attend_w<T>(qkv + c0, cache + c0, 2 * D, D, t + 1, Hg, hd, h0, inv_temp, sc, nkP, att + c0, aT + c0, seed, p.site,
+                     ar_didx(p, b, t, l, AR_S_ATT), p.p_att, S.kvT + c0);
+      AR_BAR();
       AR_TICK(2);
       if (tid < Dg) ar_row<T>(w.att, r, D)[c0 + tid] = aT[c0 + tid];
       gemv<T>((const T*)w.wo + (long)(c0 / 32) * D * 32, D, 0, nullptr, aT + c0, tmp, D, Dg, ACT_NONE);   // this slice's K columns: a partial
       AR_BAR();
-      xsum(tmp, tmp, w.bo);
       AR_TICK(3);
-      if (tid < D) {
-        float o = tmp[tid];
-        if (p.p_res > 0.f) o *= drop_scale(seed, p.site, ar_didx(p, b, t, l, AR_S_OUT) + tid, p.p_res);
-        const float s1 = x[tid] + o;
-        tmp[tid] = s1;
-        if (gi == 0) ar_row<T>(w.s1, r, D)[tid] = from_f<T>(s1);
-      }
-      AR_BAR();
-      ar_layernorm<T>(tmp, w.ln1w, w.ln1b, D, red, xT);   // tmp = t1
+      block_end(tmp, w.bo, false, AR_S_OUT, p.p_res, x, w.ln1w, w.ln1b, tmp, nullptr, w.s1, w.t1, l, t, r);   // tmp = t1
       AR_TICK(4);
-      if (tid < D && gi == 0) ar_row<T>(w.t1, r, D)[tid] = xT[tid];
       // ---- cross attention, this slice's heads
       gemv<T>((const T*)w.wq2, D, c0, w.bq2 + c0, xT, qkv + c0, Dg, D, ACT_NONE);
       AR_BAR();
       AR_TICK(3);
       if (tid < Dg) ar_row<T>(w.q2, r, D)[c0 + tid] = from_f<T>(qkv[c0 + tid]);
-      ar_attend<T>(qkv + c0, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D + c0, 2 * D, D, p.Nsrc, Hg, hd, h0, inv_temp, sc, nkP, att + c0, wred,
-                   aT + c0, seed, p.site, ar_didx(p, b, t, l, AR_S_ATT2), p.p_att);
+      ar_attend_w<T>(qkv + c0, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D + c0, 2 * D, D, p.Nsrc, Hg, hd, h0, inv_temp, sc, nkP, att + c0, aT + c0,
+                     seed, p.site, ar_didx(p, b, t, l, AR_S_ATT2), p.p_att);
+      AR_BAR();
       AR_TICK(5);
       if (tid < Dg) ar_row<T>(w.a2, r, D)[c0 + tid] = aT[c0 + tid];
       gemv<T>((const T*)w.wo2 + (long)(c0 / 32) * D * 32, D, 0, nullptr, aT + c0, x, D, Dg, ACT_NONE);
       AR_BAR();
-      xsum(x, x, w.bo2);
       AR_TICK(3);
-      if (tid < D) {
-        float o = x[tid];
-        if (p.p_res > 0.f) o *= drop_scale(seed, p.site, ar_didx(p, b, t, l, AR_S_OUT2) + tid, p.p_res);
-        const float s2 = tmp[tid] + o;
-        x[tid] = s2;
-        if (gi == 0) ar_row<T>(w.s2, r, D)[tid] = from_f<T>(s2);
-      }
-      AR_BAR();
-      ar_layernorm<T>(x, w.ln2w, w.ln2b, D, red, xT);     // x = t2
+      block_end(x, w.bo2, false, AR_S_OUT2, p.p_res, tmp, w.ln2w, w.ln2b, x, nullptr, w.s2, w.t2, l, t, r);   // x = t2
       AR_TICK(4);
-      if (tid < D && gi == 0) ar_row<T>(w.t2, r, D)[tid] = xT[tid];
       // ---- feed-forward block, this slice's hidden units
       gemv<T>((const T*)w.w0, F, f0, w.b0 + f0, xT, ff + f0, Fg, D, ACT_RELU);
       AR_BAR();
@@ -349,19 +447,9 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_fwd_kernel(ArP p) {
         gemv<T>((const T*)w.w1 + (long)(f0 / 32) * D * 32, D, 0, nullptr, ffT + f0, tmp, D, Fg, ACT_NONE);
       }
       AR_BAR();
-      xsum(tmp, tmp, w.b1);
       AR_TICK(7);
-      if (tid < D) {
-        float v = fmaxf(tmp[tid], 0.f);
-        if (p.p_ff > 0.f) v *= drop_scale(seed, p.site, ar_didx(p, b, t, l, AR_S_F1) + tid, p.p_ff);
-        const T vt = from_f<T>(v);
-        if (gi == 0) ar_row<T>(w.f1d, r, D)[tid] = vt;
-        x[tid] = x[tid] + v;     // s3
-      }
-      AR_BAR();
-      ar_layernorm<T>(x, w.ln3w, w.ln3b, D, red, xT);     // x = layer output
+      block_end(tmp, w.b1, true, AR_S_F1, p.p_ff, x, w.ln3w, w.ln3b, x, w.f1d, nullptr, p.xs[l + 1], l, t, r);   // x = layer output
       AR_TICK(4);
-      if (tid < D && gi == 0) ar_row<T>(p.xs[l + 1], r, D)[tid] = xT[tid];
       // ---- history entry for the later steps: k | v of the layer OUTPUT, this slice's columns
       gemv<T>((const T*)w.wqkv, 3 * D, D + c0, w.bqkv + D + c0, xT, qkv + c0, Dg, D, ACT_NONE, nullptr, 0, DEC_WAVES / 2);
       gemv<T>((const T*)w.wqkv, 3 * D, 2 * D + c0, w.bqkv + 2 * D + c0, xT, qkv + D + c0, Dg, D, ACT_NONE, nullptr, DEC_WAVES / 2, DEC_WAVES / 2);
@@ -703,9 +791,10 @@ template <typename T> static int ar_launch(const ArP& p, bool bwd, hipStream_t s
 
 bool ar_train_ok(int dt, int D, int F, int V, int H, int T, int Nsrc, int nlayers) {
   if (sw_off("ar_fused")) return false;
-  if (D % 32 || F % 64 || D > DEC_THREADS || nlayers > 4 || nlayers < 1 || H < 1 || D % H) return false;
+  if (D % 64 || F % 64 || D > 256 || nlayers > 4 || nlayers < 1 || H < 1 || D % H) return false;
   const int ch = dt == DT_BF16 ? 8 : 4, cpr = D / ch, hd = D / H;
   if (hd % ch || cpr > 64 || (cpr & (cpr - 1))) return false;
+  { const int cph = hd / ch; if (cph > 16 || (cph & (cph - 1)) || H > DEC_WAVES) return false; }   // ar_attend_w: one wave per head
   const int nkP = ((T > Nsrc ? T : Nsrc) + 3) & ~3;
   if ((long)H * nkP > (long)AR_DSTRIDE || F > (int)AR_DSTRIDE) return false;
   ArP p = {};

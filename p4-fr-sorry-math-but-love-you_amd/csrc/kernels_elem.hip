@@ -1888,6 +1888,7 @@ bool launch_dwconv_bwd_bn(int dt, const void* dy, const void* wp, void* dz, int 
     if (tail) {
       // workgroups wait for each other: the whole grid has to be resident, the mailbox has to hold B x slabs x 128 granules
       const long nwg = (long)B * (C / (8 * BDW_SC));
+      if ((NT % 128) != 0) return false;   // 128 publishers, image groups of 128 threads in the gather
       if (!g_mbbox.box || B > g_mbbox.images || (size_t)nwg * 128 > g_mbbox.words) return false;
       if (nwg > resident_capacity((const void*)dw_bwd_img_kernel<true, true>, NT, lds)) return false;
       tl.dy = (bf16_t*)tail->dy; tl.w = tail->w; tl.dwp = tail->dwp; tl.dbp = tail->dbp; tl.box = (se_box_t*)g_mbbox.box;
