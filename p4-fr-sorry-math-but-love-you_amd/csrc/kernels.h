@@ -469,6 +469,7 @@ struct ArP {
   float p_att, p_res, p_ff; const uint32_t* seed; uint32_t site;
   long long* prof;   // optional [16] wall-clock ticks per phase family of workgroup 0 (SATRN_PROF=ar)
   int G;             // forward: workgroups (weight slices) per image, ar_fwd_slices()
+  int kv_lds;        // forward (set by the launcher): history and cross-attention keys / values of the slice held in LDS
   unsigned long long* fbox;   // forward, G > 1: ar_fwd_box_bytes() mailbox of the slices' exchanges
 };
 bool ar_train_ok(int dt, int D, int F, int V, int H, int T, int Nsrc, int nlayers);

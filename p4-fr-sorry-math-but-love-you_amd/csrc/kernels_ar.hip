@@ -29,6 +29,10 @@ namespace {
 // and step.  Nothing a slab store writes is read again inside these kernels; the two places where global data written by one thread is
 // read by another (history rows of earlier steps, their gradient accumulators) are separated by the one __syncthreads() per step.
 #define AR_BAR() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+// the forward runs 512-thread workgroups: 256 registers per lane (the 1024-thread form spilled ~100 of its 128), and a slice's products have
+// 4 .. 16 output groups -- eight waves cover them in one pass
+#define ARF_THREADS 512
+#define ARF_WAVES (ARF_THREADS / 64)
 #define AR_DSTRIDE 4096u   // dropout index space of one (image, step, layer, site)
 enum { AR_S_ATT = 0, AR_S_OUT = 1, AR_S_ATT2 = 2, AR_S_OUT2 = 3, AR_S_F0 = 4, AR_S_F1 = 5, AR_NSITE = 6 };
 
@@ -37,15 +41,16 @@ DEVI uint32_t ar_didx(const ArP& p, int b, int t, int l, int s) {
 }
 
 // block-wide sums of two values (tid-uniform result); red: 2 * DEC_WAVES floats
+template <int NW = DEC_WAVES>
 DEVI void block_sum2(float a, float b, float* red, float& A, float& B) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   a = wave_sum(a); b = wave_sum(b);
   AR_BAR();   // red may still be read by the previous reduction
-  if (lane == 0) { red[wave] = a; red[DEC_WAVES + wave] = b; }
+  if (lane == 0) { red[wave] = a; red[NW + wave] = b; }
   AR_BAR();
   A = 0.f; B = 0.f;
 #pragma unroll
-  for (int i = 0; i < DEC_WAVES; ++i) { A += red[i]; B += red[DEC_WAVES + i]; }
+  for (int i = 0; i < NW; ++i) { A += red[i]; B += red[NW + i]; }
 }
 
 // v[0..D) <- LayerNorm(v) * w + b in place (v already holds the residual sum); vT receives the compute-dtype copy
@@ -276,6 +281,31 @@ DEVI void ar_load_layer(const ArP& p, int l, ArLayer* dst) {
     reinterpret_cast<unsigned long long*>(dst)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(p.Ltab + l)[threadIdx.x];
   AR_BAR();
 }
+// forward layout (compact: the backward's buffers are not in it).  kv_lds: this slice's columns of the self-attention history and of the
+// cross-attention keys / values of every layer live in LDS for the whole launch (rows padded by 8 elements: a lane per key reads rows a
+// multiple of 256 bytes apart otherwise) -- the attentions then issue no global load at all
+struct ArFwdLay { size_t x, qkv, att, tmp, ff, sc, red, lg, xT, kvT, kvs, kvc, total; int nkP, ldr; };
+static __host__ __device__ inline ArFwdLay ar_fwd_layout(int D, int F, int V, int H, int G, int T, int Nsrc, int nlayers, int es, int kv_lds) {
+  ArFwdLay L;
+  L.nkP = ((T > Nsrc ? T : Nsrc) + 3) & ~3;
+  L.ldr = 2 * (D / G) + 8;
+  const int lgn = ((V + 3) & ~3) > D ? ((V + 3) & ~3) : D;
+  size_t o = 0;
+  L.x = o; o += (size_t)D * 4;
+  L.qkv = o; o += (size_t)3 * D * 4;
+  L.att = o; o += (size_t)D * 4;
+  L.tmp = o; o += (size_t)D * 4;
+  L.ff = o; o += (size_t)F * 4;
+  L.sc = o; o += (size_t)(H / G) * L.nkP * 4;
+  L.red = o; o += (size_t)2 * DEC_WAVES * 4;   // (sized for either thread count)
+  L.lg = o; o += (size_t)lgn * 4;
+  L.xT = o; o += (size_t)(3 * D + F) * es;
+  L.kvT = o; o += (size_t)2 * D * es;
+  L.kvs = o; if (kv_lds) o += (size_t)nlayers * L.nkP * L.ldr * es;
+  L.kvc = o; if (kv_lds) o += (size_t)nlayers * Nsrc * L.ldr * es;
+  L.total = (o + 15) & ~(size_t)15;
+  return L;
+}
 template <typename T> DEVI T* ar_row(void* slab, long r, int C) { return (T*)slab + r * C; }
 template <typename T> DEVI const T* ar_crow(const void* slab, long r, int C) { return (const T*)slab + r * C; }
 
@@ -290,80 +320,85 @@ template <typename T> DEVI const T* ar_crow(const void* slab, long r, int C) { r
 // argmax are replicated, so the slices stay in lock step without a second hand-off.  Mailbox p.fbox: [B][2][G][D] granules, zero before
 // the launch, tag = the exchange's number; two buffers by parity (a slice can be at most one exchange ahead of the slowest).
 template <typename T>
-__global__ __launch_bounds__(DEC_THREADS) void ar_fwd_kernel(ArP p) {
+__global__ __launch_bounds__(ARF_THREADS) void ar_fwd_kernel(ArP p) {
   extern __shared__ float sm[];
-  const ArSm<T> S = ar_carve<T>(sm, p, false);
-  const int D = p.D, F = p.F, V = p.V, H = p.H, hd = D / H, T_ = p.T, nkP = S.nkP;
+  const int D = p.D, F = p.F, V = p.V, H = p.H, hd = D / H, T_ = p.T;
   const int G = gridDim.x, gi = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const ArFwdLay LY = ar_fwd_layout(D, F, V, H, G, T_, p.Nsrc, p.nlayers, (int)sizeof(T), p.kv_lds);
+  const int nkP = LY.nkP, LDR = LY.ldr;
+  unsigned char* smb = reinterpret_cast<unsigned char*>(sm);
+  const bool kvl = p.kv_lds != 0;
+  T* kvT = reinterpret_cast<T*>(smb + LY.kvT);
+  T* kvs = reinterpret_cast<T*>(smb + LY.kvs);   // [nlayers][nkP][LDR]: k (this slice's Dg columns) | v | pad
+  T* kvc = reinterpret_cast<T*>(smb + LY.kvc);   // [nlayers][Nsrc][LDR]
   const int Hg = H / G, Dg = Hg * hd, h0 = gi * Hg, c0 = h0 * hd;   // this slice's heads = columns [c0, c0 + Dg) of q, k, v and the attention output
   const int Fg = F / G, f0 = gi * Fg;                                // ... and hidden units [f0, f0 + Fg) of the feed-forward block
   const float inv_temp = rsqrtf((float)D), emb_scale = sqrtf((float)D);
   const uint32_t seed = p.seed ? *p.seed : 0u;
   const long long t_end = (long long)wall_clock64() + p.timeout_ticks;
   __shared__ int s_tok;
-  float *x = S.x, *qkv = S.qkv, *att = S.att, *tmp = S.tmp, *ff = S.ff, *sc = S.sc, *red = S.red, *wred = S.wred, *lg = S.lg;
-  T* xT = S.xT;
+  float* x = reinterpret_cast<float*>(smb + LY.x);
+  float* qkv = reinterpret_cast<float*>(smb + LY.qkv);
+  float* att = reinterpret_cast<float*>(smb + LY.att);
+  float* tmp = reinterpret_cast<float*>(smb + LY.tmp);
+  float* ff = reinterpret_cast<float*>(smb + LY.ff);
+  float* sc = reinterpret_cast<float*>(smb + LY.sc);
+  float* lg = reinterpret_cast<float*>(smb + LY.lg);
+  T* xT = reinterpret_cast<T*>(smb + LY.xT);
   T* aT = xT + D;        // attention output (this slice's columns), input of the output projection's K-slice
   T* ffT = xT + 3 * D;   // hidden units (this slice's), input of the second feed-forward product's K-slice
   unsigned xn = 0;       // exchanges so far
-  // End of a block, all in wave 0 (no workgroup barrier inside: the sums of the LayerNorm are wave reductions over D / 64 elements per lane):
+  // End of a block: thread e < D takes element e --
   //   a = act(bias + sum over the slices (ascending) of their part)  ->  dropout(site)  ->  [act_slab]  ->  s = resid + a  ->  [s_slab]
   //   ->  out = LayerNorm(s) * gamma + beta  (f32 in `out`, compute dtype in xT, [o_slab])
+  float* red = reinterpret_cast<float*>(smb + LY.red);
   auto block_end = [&](const float* part, const float* bias, bool relu, int site, float pdrop, const float* resid, const float* gamma,
                        const float* beta, float* out, void* act_slab, void* s_slab, void* o_slab, int l, int t, long r) {
     ++xn;
-    if (tid < 64) {
-      constexpr int MAXE = 4;   // D <= 256 (ar_train_ok)
-      const int NE = D >> 6;
-      float sv[MAXE];
-      if (G > 1) {
+    float sx = 0.f, gm = 0.f, bt = 0.f;
+    if (tid < D) {
+      float a = bias[tid];
+      gm = gamma[tid]; bt = beta[tid];
+      if (G == 1) a += part[tid];
+      else {
         se_box_t* base = (se_box_t*)p.fbox + (((size_t)b * 2 + (xn & 1u)) * G) * D;
+        se_box_put(base + (size_t)gi * D + tid, xn, part[tid]);
+        float vals[4];
+        se_box_gather<4>(base + tid, (size_t)D, G, xn, t_end, vals, p.err);
 #pragma unroll
-        for (int k = 0; k < MAXE; ++k) if (k < NE) se_box_put(base + (size_t)gi * D + tid + 64 * k, xn, part[tid + 64 * k]);
-#pragma unroll
-        for (int k = 0; k < MAXE; ++k)
-          if (k < NE) {
-            float vals[8];
-            se_box_gather<8>(base + tid + 64 * k, (size_t)D, G, xn, t_end, vals, p.err);
-            float a = 0.f;
-#pragma unroll
-            for (int g2 = 0; g2 < 8; ++g2) if (g2 < G) a += vals[g2];
-            sv[k] = a;
-          }
-      } else {
-#pragma unroll
-        for (int k = 0; k < MAXE; ++k) if (k < NE) sv[k] = part[tid + 64 * k];
+        for (int k = 0; k < 4; ++k) if (k < G) a += vals[k];
       }
-      float sum = 0.f, sq = 0.f;
-#pragma unroll
-      for (int k = 0; k < MAXE; ++k)
-        if (k < NE) {
-          const int e = tid + 64 * k;
-          float a = sv[k] + bias[e];
-          if (relu) a = fmaxf(a, 0.f);
-          if (pdrop > 0.f) a *= drop_scale(seed, p.site, ar_didx(p, b, t, l, site) + e, pdrop);
-          if (act_slab && gi == 0) ar_row<T>(act_slab, r, D)[e] = from_f<T>(a);
-          const float sx = resid[e] + a;
-          if (s_slab && gi == 0) ar_row<T>(s_slab, r, D)[e] = from_f<T>(sx);
-          sv[k] = sx;
-          sum += sx; sq += sx * sx;
-        }
-      sum = wave_sum(sum); sq = wave_sum(sq);
-      const float mean = sum / (float)D;
-      const float rstd = rsqrtf(fmaxf(sq / (float)D - mean * mean, 0.f) + 1e-5f);
-#pragma unroll
-      for (int k = 0; k < MAXE; ++k)
-        if (k < NE) {
-          const int e = tid + 64 * k;
-          const float o = (sv[k] - mean) * rstd * gamma[e] + beta[e];
-          out[e] = o;
-          const T ot = from_f<T>(o);
-          xT[e] = ot;
-          if (gi == 0) ar_row<T>(o_slab, r, D)[e] = ot;
-        }
+      if (relu) a = fmaxf(a, 0.f);
+      if (pdrop > 0.f) a *= drop_scale(seed, p.site, ar_didx(p, b, t, l, site) + tid, pdrop);
+      if (act_slab && gi == 0) ar_row<T>(act_slab, r, D)[tid] = from_f<T>(a);
+      sx = resid[tid] + a;
+      if (s_slab && gi == 0) ar_row<T>(s_slab, r, D)[tid] = from_f<T>(sx);
+    }
+    float sum, sq;
+    block_sum2<ARF_WAVES>(sx, sx * sx, red, sum, sq);
+    const float mean = sum / (float)D;
+    const float rstd = rsqrtf(fmaxf(sq / (float)D - mean * mean, 0.f) + 1e-5f);
+    if (tid < D) {
+      const float o = (sx - mean) * rstd * gm + bt;
+      out[tid] = o;
+      const T ot = from_f<T>(o);
+      xT[tid] = ot;
+      if (gi == 0) ar_row<T>(o_slab, r, D)[tid] = ot;
     }
     AR_BAR();
   };
+  if (kvl) {   // the cross-attention keys / values of this image, this slice's columns, every layer
+    constexpr int CH = TT<T>::CH;
+    const int cpp = Dg / CH;   // chunks per part (k or v) of a row
+    for (int l = 0; l < p.nlayers; ++l) {
+      const T* src = (const T*)p.Ltab[l].crossKV + (long)b * p.Nsrc * 2 * D;
+      for (int i = tid; i < p.Nsrc * 2 * cpp; i += ARF_THREADS) {
+        const int j = i / (2 * cpp), rem = i - j * 2 * cpp, part = rem / cpp, ch = rem - part * cpp;
+        st16(kvc + ((size_t)l * p.Nsrc + j) * LDR + part * Dg + ch * CH, ld16(src + (long)j * 2 * D + part * D + c0 + ch * CH));
+      }
+    }
+    AR_BAR();
+  }
   int tok = p.sos;
   long long tlast = p.prof ? (long long)wall_clock64() : 0;
   for (int t = 0; t < T_; ++t) {
@@ -384,51 +419,59 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_fwd_kernel(ArP p) {
       AR_TICK(0);
       // ---- q | k | v of the layer INPUT, this slice's heads: three Dg-row products side by side
       {
-        constexpr int W3 = DEC_WAVES / 3;
-        gemv<T>((const T*)w.wqkv, 3 * D, c0, w.bqkv + c0, xT, qkv + c0, Dg, D, ACT_NONE, nullptr, 0, W3);
-        gemv<T>((const T*)w.wqkv, 3 * D, D + c0, w.bqkv + D + c0, xT, qkv + D + c0, Dg, D, ACT_NONE, nullptr, W3, W3);
-        gemv<T>((const T*)w.wqkv, 3 * D, 2 * D + c0, w.bqkv + 2 * D + c0, xT, qkv + 2 * D + c0, Dg, D, ACT_NONE, nullptr, 2 * W3, W3);
+        constexpr int W3 = ARF_WAVES / 3;
+        gemv<T, 2, ARF_THREADS>((const T*)w.wqkv, 3 * D, c0, w.bqkv + c0, xT, qkv + c0, Dg, D, ACT_NONE, nullptr, 0, W3);
+        gemv<T, 2, ARF_THREADS>((const T*)w.wqkv, 3 * D, D + c0, w.bqkv + D + c0, xT, qkv + D + c0, Dg, D, ACT_NONE, nullptr, W3, W3);
+        gemv<T, 2, ARF_THREADS>((const T*)w.wqkv, 3 * D, 2 * D + c0, w.bqkv + 2 * D + c0, xT, qkv + 2 * D + c0, Dg, D, ACT_NONE, nullptr, 2 * W3, W3);
       }
       AR_BAR();
       AR_TICK(1);
       if (tid < Dg) ar_row<T>(w.q, r, D)[c0 + tid] = from_f<T>(qkv[c0 + tid]);
-      for (int i = tid; i < 2 * Dg; i += DEC_THREADS) {   // the step's own history row: attended from LDS, kept for the backward
+      for (int i = tid; i < 2 * Dg; i += ARF_THREADS) {   // the step's own history row: attended from LDS, kept for the backward
         const int col = (i / Dg) * D + c0 + (i % Dg);
         const T v = from_f<T>(qkv[D + col]);
-        S.kvT[col] = v;
+        if (kvl) kvs[((size_t)l * nkP + t) * LDR + i] = v; else kvT[col] = v;
         ar_row<T>(w.kvin, r, 2 * D)[col] = v;
       }
       AR_BAR();
-      ar_attend_w<T>(qkv + c0, cache + c0, 2 * D, D, t + 1, Hg, hd, h0, inv_temp, sc, nkP, att + c0, aT + c0, seed, p.site,
-                     ar_didx(p, b, t, l, AR_S_ATT), p.p_att, S.kvT + c0);
+      if (kvl)
+        ar_attend_w<T>(qkv + c0, kvs + (size_t)l * nkP * LDR, LDR, Dg, t + 1, Hg, hd, h0, inv_temp, sc, nkP, att + c0, aT + c0, seed, p.site,
+                       ar_didx(p, b, t, l, AR_S_ATT), p.p_att);
+      else
+        ar_attend_w<T>(qkv + c0, cache + c0, 2 * D, D, t + 1, Hg, hd, h0, inv_temp, sc, nkP, att + c0, aT + c0, seed, p.site,
+                       ar_didx(p, b, t, l, AR_S_ATT), p.p_att, kvT + c0);
       AR_BAR();
       AR_TICK(2);
       if (tid < Dg) ar_row<T>(w.att, r, D)[c0 + tid] = aT[c0 + tid];
-      gemv<T>((const T*)w.wo + (long)(c0 / 32) * D * 32, D, 0, nullptr, aT + c0, tmp, D, Dg, ACT_NONE);   // this slice's K columns: a partial
+      gemv<T, 2, ARF_THREADS>((const T*)w.wo + (long)(c0 / 32) * D * 32, D, 0, nullptr, aT + c0, tmp, D, Dg, ACT_NONE);   // this slice's K columns: a partial
       AR_BAR();
       AR_TICK(3);
       block_end(tmp, w.bo, false, AR_S_OUT, p.p_res, x, w.ln1w, w.ln1b, tmp, nullptr, w.s1, w.t1, l, t, r);   // tmp = t1
       AR_TICK(4);
       // ---- cross attention, this slice's heads
-      gemv<T>((const T*)w.wq2, D, c0, w.bq2 + c0, xT, qkv + c0, Dg, D, ACT_NONE);
+      gemv<T, 2, ARF_THREADS>((const T*)w.wq2, D, c0, w.bq2 + c0, xT, qkv + c0, Dg, D, ACT_NONE);
       AR_BAR();
       AR_TICK(3);
       if (tid < Dg) ar_row<T>(w.q2, r, D)[c0 + tid] = from_f<T>(qkv[c0 + tid]);
-      ar_attend_w<T>(qkv + c0, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D + c0, 2 * D, D, p.Nsrc, Hg, hd, h0, inv_temp, sc, nkP, att + c0, aT + c0,
-                     seed, p.site, ar_didx(p, b, t, l, AR_S_ATT2), p.p_att);
+      if (kvl)
+        ar_attend_w<T>(qkv + c0, kvc + (size_t)l * p.Nsrc * LDR, LDR, Dg, p.Nsrc, Hg, hd, h0, inv_temp, sc, nkP, att + c0, aT + c0, seed, p.site,
+                       ar_didx(p, b, t, l, AR_S_ATT2), p.p_att);
+      else
+        ar_attend_w<T>(qkv + c0, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D + c0, 2 * D, D, p.Nsrc, Hg, hd, h0, inv_temp, sc, nkP, att + c0, aT + c0,
+                       seed, p.site, ar_didx(p, b, t, l, AR_S_ATT2), p.p_att);
       AR_BAR();
       AR_TICK(5);
       if (tid < Dg) ar_row<T>(w.a2, r, D)[c0 + tid] = aT[c0 + tid];
-      gemv<T>((const T*)w.wo2 + (long)(c0 / 32) * D * 32, D, 0, nullptr, aT + c0, x, D, Dg, ACT_NONE);
+      gemv<T, 2, ARF_THREADS>((const T*)w.wo2 + (long)(c0 / 32) * D * 32, D, 0, nullptr, aT + c0, x, D, Dg, ACT_NONE);
       AR_BAR();
       AR_TICK(3);
       block_end(x, w.bo2, false, AR_S_OUT2, p.p_res, tmp, w.ln2w, w.ln2b, x, nullptr, w.s2, w.t2, l, t, r);   // x = t2
       AR_TICK(4);
       // ---- feed-forward block, this slice's hidden units
-      gemv<T>((const T*)w.w0, F, f0, w.b0 + f0, xT, ff + f0, Fg, D, ACT_RELU);
+      gemv<T, 2, ARF_THREADS>((const T*)w.w0, F, f0, w.b0 + f0, xT, ff + f0, Fg, D, ACT_RELU);
       AR_BAR();
       AR_TICK(6);
-      for (int i = tid; i < Fg; i += DEC_THREADS) {
+      for (int i = tid; i < Fg; i += ARF_THREADS) {
         float v = ff[f0 + i];
         if (p.p_ff > 0.f) v *= drop_scale(seed, p.site, ar_didx(p, b, t, l, AR_S_F0) + f0 + i, p.p_ff);
         const T vt = from_f<T>(v);
@@ -437,36 +480,38 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_fwd_kernel(ArP p) {
       }
       AR_BAR();
       // N / 16 = 16 output groups keep 8 waves busy: the two halves of this slice's K run side by side and meet in the exchange's input
-      if (Fg % 64 == 0) {
-        gemv<T>((const T*)w.w1 + (long)(f0 / 32) * D * 32, D, 0, nullptr, ffT + f0, tmp, D, Fg / 2, ACT_NONE, nullptr, 0, DEC_WAVES / 2);
-        gemv<T>((const T*)w.w1 + (long)((f0 + Fg / 2) / 32) * D * 32, D, 0, nullptr, ffT + f0 + Fg / 2, att, D, Fg / 2, ACT_NONE, nullptr, DEC_WAVES / 2,
-                DEC_WAVES / 2);
+      if (Fg % 64 == 0 && Fg > 256) {
+        gemv<T, 2, ARF_THREADS>((const T*)w.w1 + (long)(f0 / 32) * D * 32, D, 0, nullptr, ffT + f0, tmp, D, Fg / 2, ACT_NONE, nullptr, 0, ARF_WAVES / 2);
+        gemv<T, 2, ARF_THREADS>((const T*)w.w1 + (long)((f0 + Fg / 2) / 32) * D * 32, D, 0, nullptr, ffT + f0 + Fg / 2, att, D, Fg / 2, ACT_NONE, nullptr, ARF_WAVES / 2,
+                ARF_WAVES / 2);
         AR_BAR();
         if (tid < D) tmp[tid] += att[tid];
       } else {
-        gemv<T>((const T*)w.w1 + (long)(f0 / 32) * D * 32, D, 0, nullptr, ffT + f0, tmp, D, Fg, ACT_NONE);
+        gemv<T, 2, ARF_THREADS>((const T*)w.w1 + (long)(f0 / 32) * D * 32, D, 0, nullptr, ffT + f0, tmp, D, Fg, ACT_NONE);
       }
       AR_BAR();
       AR_TICK(7);
       block_end(tmp, w.b1, true, AR_S_F1, p.p_ff, x, w.ln3w, w.ln3b, x, w.f1d, nullptr, p.xs[l + 1], l, t, r);   // x = layer output
       AR_TICK(4);
       // ---- history entry for the later steps: k | v of the layer OUTPUT, this slice's columns
-      gemv<T>((const T*)w.wqkv, 3 * D, D + c0, w.bqkv + D + c0, xT, qkv + c0, Dg, D, ACT_NONE, nullptr, 0, DEC_WAVES / 2);
-      gemv<T>((const T*)w.wqkv, 3 * D, 2 * D + c0, w.bqkv + 2 * D + c0, xT, qkv + D + c0, Dg, D, ACT_NONE, nullptr, DEC_WAVES / 2, DEC_WAVES / 2);
+      gemv<T, 2, ARF_THREADS>((const T*)w.wqkv, 3 * D, D + c0, w.bqkv + D + c0, xT, qkv + c0, Dg, D, ACT_NONE, nullptr, 0, ARF_WAVES / 2);
+      gemv<T, 2, ARF_THREADS>((const T*)w.wqkv, 3 * D, 2 * D + c0, w.bqkv + 2 * D + c0, xT, qkv + D + c0, Dg, D, ACT_NONE, nullptr, ARF_WAVES / 2, ARF_WAVES / 2);
       AR_BAR();
-      for (int i = tid; i < 2 * Dg; i += DEC_THREADS) {
+      for (int i = tid; i < 2 * Dg; i += ARF_THREADS) {
         const int col = (i / Dg) * D + c0 + (i % Dg);
-        cache[(long)t * 2 * D + col] = from_f<T>(qkv[col]);
+        const T v = from_f<T>(qkv[col]);
+        cache[(long)t * 2 * D + col] = v;      // (the backward reads the history from memory)
+        if (kvl) kvs[((size_t)l * nkP + t) * LDR + i] = v;
       }
       AR_BAR();
       AR_TICK(8);
     }
-    gemv<T>((const T*)p.wgen, V, 0, p.bgen, xT, lg, V, D, ACT_NONE);   // (replicated: every slice needs the next token)
+    gemv<T, 2, ARF_THREADS>((const T*)p.wgen, V, 0, p.bgen, xT, lg, V, D, ACT_NONE);   // (replicated: every slice needs the next token)
     AR_BAR();
     AR_TICK(9);
     if (gi == 0) {
       float* out = p.logits + r * V;
-      for (int i = tid; i < V; i += DEC_THREADS) out[i] = lg[i];
+      for (int i = tid; i < V; i += ARF_THREADS) out[i] = lg[i];
     }
     if (tid < 64) {   // argmax, lowest index wins ties (torch.argmax)
       float best = -INFINITY;
@@ -776,14 +821,15 @@ __global__ void ar_ln_fold_kernel(ArP p) {
   dst[c] += a;
 }
 
+static size_t ar_fwd_lds_bytes(const ArP& p, int es) { return ar_fwd_layout(p.D, p.F, p.V, p.H, p.G, p.T, p.Nsrc, p.nlayers, es, p.kv_lds).total; }
 template <typename T> static int ar_launch(const ArP& p, bool bwd, hipStream_t s) {
-  const size_t sh = ar_lds_floats(p, bwd) * sizeof(float);
-  if (sh > 150 * 1024) return -1;
+  const size_t sh = bwd ? ar_lds_floats(p, bwd) * sizeof(float) : ar_fwd_lds_bytes(p, (int)sizeof(T));
+  if (sh > (bwd ? 150 : 159) * 1024) return -1;
   const void* fn = bwd ? (const void*)ar_bwd_kernel<T> : (const void*)ar_fwd_kernel<T>;
   static bool attr[2] = {false, false};
-  if (!attr[bwd ? 1 : 0]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr[bwd ? 1 : 0] = true; }
+  if (!attr[bwd ? 1 : 0]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr[bwd ? 1 : 0] = true; }
   if (bwd) hipLaunchKernelGGL((ar_bwd_kernel<T>), dim3(p.B, p.nlayers), dim3(DEC_THREADS), sh, s, p);
-  else hipLaunchKernelGGL((ar_fwd_kernel<T>), dim3(p.G, p.B), dim3(DEC_THREADS), sh, s, p);
+  else hipLaunchKernelGGL((ar_fwd_kernel<T>), dim3(p.G, p.B), dim3(ARF_THREADS), sh, s, p);
   return 0;
 }
 
@@ -794,7 +840,7 @@ bool ar_train_ok(int dt, int D, int F, int V, int H, int T, int Nsrc, int nlayer
   if (D % 64 || F % 64 || D > 256 || nlayers > 4 || nlayers < 1 || H < 1 || D % H) return false;
   const int ch = dt == DT_BF16 ? 8 : 4, cpr = D / ch, hd = D / H;
   if (hd % ch || cpr > 64 || (cpr & (cpr - 1))) return false;
-  { const int cph = hd / ch; if (cph > 16 || (cph & (cph - 1)) || H > DEC_WAVES) return false; }   // ar_attend_w: one wave per head
+  { const int cph = hd / ch; if (cph > 16 || (cph & (cph - 1)) || H > ARF_WAVES) return false; }   // ar_attend_w: one wave per head
   const int nkP = ((T > Nsrc ? T : Nsrc) + 3) & ~3;
   if ((long)H * nkP > (long)AR_DSTRIDE || F > (int)AR_DSTRIDE) return false;
   ArP p = {};
@@ -802,12 +848,12 @@ bool ar_train_ok(int dt, int D, int F, int V, int H, int T, int Nsrc, int nlayer
   return ar_lds_floats(p, true) * sizeof(float) <= 150 * 1024;
 }
 
-// slices per image of the forward: the largest of 8, 4, 2, 1 (or the ar_split knob) that divides the heads into whole 32-column
+// slices per image of the forward: the largest of 4, 2, 1 (or the ar_split knob; 8 measured the same as 4) that divides the heads into whole 32-column
 // groups and the hidden units into whole 32-unit panels
 int ar_fwd_slices(int dt, int D, int F, int H) {
   const int ch = dt == DT_BF16 ? 8 : 4, hd = D / H;
   const int want = (int)sw_knob("ar_split", 4);
-  for (int G = want > 8 ? 8 : want; G > 1; G >>= 1) {
+  for (int G = want > 4 ? 4 : want; G > 1; G >>= 1) {
     if (H % G || F % G) continue;
     const int Dg = (H / G) * hd, Fg = F / G, cpr = Dg / ch;
     if (Dg % 32 || Fg % 32 || cpr < 1 || (cpr & (cpr - 1))) continue;
@@ -817,14 +863,18 @@ int ar_fwd_slices(int dt, int D, int F, int H) {
 }
 size_t ar_fwd_box_bytes(int B, int G, int D) { return (size_t)B * 2 * G * D * 8; }
 int launch_ar_fwd(int dt, const ArP& p0, hipStream_t s) {
-  if (!p0.Ltab || p0.G < 1 || p0.G > 8 || (p0.G > 1 && !p0.fbox)) return -1;
+  if (!p0.Ltab || p0.G < 1 || p0.G > 4 || (p0.G > 1 && !p0.fbox)) return -1;
   ArP p = p0;
+  const int es = dt == DT_BF16 ? 2 : 4;
+  // history + cross-attention keys / values in LDS where they fit beside the working set (bf16, four slices at the benchmark's shape)
+  p.kv_lds = sw_off("ar_kv_lds") ? 0 : 1;
+  if (p.kv_lds && ar_fwd_lds_bytes(p, es) > 159 * 1024) p.kv_lds = 0;
   if (p.G > 1) {
     // the slices of an image wait for each other: B * G workgroups of 1024 threads, one per compute unit
-    const size_t sh = ar_lds_floats(p, false) * sizeof(float);
+    const size_t sh = ar_fwd_lds_bytes(p, es);
     const void* fn = dt == DT_BF16 ? (const void*)ar_fwd_kernel<bf16_t> : (const void*)ar_fwd_kernel<float>;
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if ((long)p.B * p.G > resident_capacity(fn, DEC_THREADS, sh)) return -1;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    if ((long)p.B * p.G > resident_capacity(fn, ARF_THREADS, sh)) return -1;
     p.err = device_error_word();
     if (!p.err) return -1;
     p.timeout_ticks = 500000000LL;   // 5 s at 100 MHz
