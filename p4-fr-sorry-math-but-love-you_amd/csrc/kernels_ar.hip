@@ -33,6 +33,9 @@ namespace {
 // 4 .. 16 output groups -- eight waves cover them in one pass
 #define ARF_THREADS 512
 #define ARF_WAVES (ARF_THREADS / 64)
+// ... and so does the backward (1024 threads: 40 spilled registers, 10.4 ms; 512: none, 9.5 ms)
+#define ARB_THREADS 512
+#define ARB_WAVES (ARB_THREADS / 64)
 #define AR_DSTRIDE 4096u   // dropout index space of one (image, step, layer, site)
 enum { AR_S_ATT = 0, AR_S_OUT = 1, AR_S_ATT2 = 2, AR_S_OUT2 = 3, AR_S_F0 = 4, AR_S_F1 = 5, AR_NSITE = 6 };
 
@@ -53,114 +56,10 @@ DEVI void block_sum2(float a, float b, float* red, float& A, float& B) {
   for (int i = 0; i < NW; ++i) { A += red[i]; B += red[NW + i]; }
 }
 
-// v[0..D) <- LayerNorm(v) * w + b in place (v already holds the residual sum); vT receives the compute-dtype copy
-template <typename T>
-DEVI void ar_layernorm(float* v, const float* w, const float* b, int D, float* red, T* vT) {
-  const int tid = threadIdx.x;
-  float wt = 0.f, bt = 0.f, x = 0.f;
-  if (tid < D) { wt = w[tid]; bt = b[tid]; x = v[tid]; }
-  float s, q;
-  block_sum2(x, x * x, red, s, q);
-  const float mean = s / (float)D;
-  const float var = fmaxf(q / (float)D - mean * mean, 0.f);
-  const float rstd = rsqrtf(var + 1e-5f);
-  if (tid < D) {
-    const float o = (x - mean) * rstd * wt + bt;
-    v[tid] = o;
-    vT[tid] = from_f<T>(o);
-  }
-  AR_BAR();
-}
-
-// o[0..D) = dropout(softmax(q K^T / temp)) V over nk keys (rows kv[j * ld]: K at [h * hd], V at [D + h * hd]); the probabilities
-// are dropped with site index didx + h * nkP + j.  attend() of the greedy decoder with the dropout of nn.Dropout on the attention
-// weights (networks/EfficientSATRN.py:168,181).
-template <typename T>
-DEVI void ar_attend(const float* q, const T* kv, long ld, int voff, int nk, int H, int hd, int h0, float inv_temp, float* sc, int nkP, float* o,
-                    float* wred, T* oT, uint32_t seed, uint32_t site, uint32_t didx, float pdrop, const T* tail = nullptr /*LDS: the LAST key's
-                    row (k | v), when the caller has just produced it*/) {
-  // H heads starting at global head h0 (the dropout index space is the whole attention's); q, kv, tail, o, oT point at head h0's columns,
-  // V sits voff elements behind K
-  constexpr int CH = TT<T>::CH, NT = DEC_THREADS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int D = H * hd, cph = hd / CH;
-  for (int idx = tid; idx < nk * H; idx += NT) {
-    const int j = idx / H, h = idx - j * H;
-    const bool in_tail = tail && j == nk - 1;
-    const T* kp = kv + (long)(in_tail ? 0 : j) * ld + h * hd;
-    const float* qp = q + h * hd;
-    float acc = 0.f;
-#pragma unroll 4
-    for (int c = 0; c < cph; ++c) {
-      float f[CH];
-      uint4 raw;
-      // (two loads selected by value, not one load through a selected pointer: the rows live in different address spaces)
-      if (in_tail) raw = ld16(tail + h * hd + c * CH); else raw = ld16(kp + c * CH);
-      unpack<T>(raw, f);
-#pragma unroll
-      for (int e = 0; e < CH; ++e) acc += f[e] * qp[c * CH + e];
-    }
-    sc[h * nkP + j] = acc * inv_temp;
-  }
-  AR_BAR();
-  for (int h = wave; h < H; h += (NT / 64)) {
-    float m = -INFINITY;
-    for (int j = lane; j < nk; j += 64) m = fmaxf(m, sc[h * nkP + j]);
-    m = wave_max(m);
-    float s = 0.f;
-    for (int j = lane; j < nk; j += 64) { float e = __expf(sc[h * nkP + j] - m); sc[h * nkP + j] = e; s += e; }
-    s = wave_sum(s);
-    const float inv = 1.0f / s;
-    for (int j = lane; j < nk; j += 64) {
-      float pv = sc[h * nkP + j] * inv;
-      if (pdrop > 0.f) pv *= drop_scale(seed, site, didx + (uint32_t)((h0 + h) * nkP + j), pdrop);
-      sc[h * nkP + j] = pv;
-    }
-  }
-  AR_BAR();
-  const int cpr = D / CH, KG = NT / cpr;
-  const int dc = tid % cpr, kg = tid / cpr;
-  const int h = (dc * CH) / hd;
-  float acc[CH];
-#pragma unroll
-  for (int e = 0; e < CH; ++e) acc[e] = 0.f;
-  const T* vp = kv + voff + dc * CH;
-  for (int j = kg; j < nk; j += 2 * KG) {
-    const int j1 = j + KG;
-    const int j1c = j1 < nk ? j1 : 0;
-    uint4 r0, r1;
-    if (tail && j == nk - 1) r0 = ld16(tail + voff + dc * CH); else r0 = ld16(vp + (long)j * ld);
-    if (tail && j1c == nk - 1) r1 = ld16(tail + voff + dc * CH); else r1 = ld16(vp + (long)j1c * ld);
-    const float p0 = sc[h * nkP + j], p1 = j1 < nk ? sc[h * nkP + j1c] : 0.f;
-    float f[CH];
-    unpack<T>(r0, f);
-#pragma unroll
-    for (int e = 0; e < CH; ++e) acc[e] += p0 * f[e];
-    unpack<T>(r1, f);
-#pragma unroll
-    for (int e = 0; e < CH; ++e) acc[e] += p1 * f[e];
-  }
-  for (int o2 = cpr; o2 < 64; o2 <<= 1) {
-#pragma unroll
-    for (int e = 0; e < CH; ++e) acc[e] += __shfl_xor(acc[e], o2, 64);
-  }
-  if (lane < cpr) {
-#pragma unroll
-    for (int e = 0; e < CH; ++e) wred[wave * D + dc * CH + e] = acc[e];
-  }
-  AR_BAR();
-  if (tid < D) {
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < (NT / 64); ++w) v += wred[w * D + tid];
-    o[tid] = v;
-    oT[tid] = from_f<T>(v);
-  }
-  AR_BAR();
-}
-
-// The same attention with ONE WAVE PER HEAD and no workgroup barrier inside (the caller's barrier behind it is the only one): for a slice of two
-// heads ar_attend's four barriers and two dependent round trips were 6 us of a 40 us layer step.  Scores: a lane per key (two for nk <= 128);
+// o[0..D) = dropout(softmax(q K^T / temp)) V over nk keys (rows kv[j * ld]: K at [h * hd], V voff elements behind); the probabilities are
+// dropped with site index didx + (h0 + h) * nkP + j: the dropout of nn.Dropout on the attention weights (networks/EfficientSATRN.py:168,181).
+// ONE WAVE PER HEAD and no workgroup barrier inside (the caller's barrier behind it is the only one): for a slice of two heads the
+// workgroup-wide form (a thread per (key, head), four barriers, two dependent round trips) was 6 us of a 40 us layer step.  Scores: a lane per key (two for nk <= 128);
 // the V rows are requested BEFORE the softmax (they do not depend on it); probabilities pass through LDS inside the wave; P V: lane = (key
 // group, 16-byte chunk of the head), reduced over the key groups by shuffles.  Needs hd / CH (chunks per head) a power of two <= 16.
 template <typename T>
@@ -541,14 +440,14 @@ DEVI void ar_ln_bwd(const float* dy, const T* s_a, const T* s_b, const float* w,
   float sv = 0.f, wt = 0.f, g = 0.f;
   if (tid < D) { sv = to_f(s_a[tid]) + (s_b ? to_f(s_b[tid]) : 0.f); wt = w[tid]; g = dy[tid]; }
   float s, q;
-  block_sum2(sv, sv * sv, red, s, q);
+  block_sum2<ARB_WAVES>(sv, sv * sv, red, s, q);
   const float mean = s / (float)D;
   const float var = fmaxf(q / (float)D - mean * mean, 0.f);
   const float rstd = rsqrtf(var + 1e-5f);
   const float xh = tid < D ? (sv - mean) * rstd : 0.f;
   const float dxh = g * wt;
   float a, c;
-  block_sum2(dxh, dxh * xh, red, a, c);
+  block_sum2<ARB_WAVES>(dxh, dxh * xh, red, a, c);
   if (tid < D) {
     ds[tid] = rstd * (dxh - a / (float)D - xh * c / (float)D);
     dgw[tid] += g * xh;
@@ -564,7 +463,7 @@ template <typename T>
 DEVI void ar_attend_bwd(const float* q, const float* da, const T* kv, long ld, int nk, const T* cur, float* acc, float* dcur, int H, int hd,
                         float inv_temp, float* sc, float* dsc, int nkP, float* dq, float* wred, uint32_t seed, uint32_t site, uint32_t didx,
                         float pdrop) {
-  constexpr int CH = TT<T>::CH, NT = DEC_THREADS;
+  constexpr int CH = TT<T>::CH, NT = ARB_THREADS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = H * hd, cph = hd / CH;
   // scores and d(dropped probabilities): one thread per (key, head)
@@ -664,7 +563,7 @@ DEVI void ar_attend_bwd(const float* q, const float* da, const T* kv, long ld, i
 }
 
 template <typename T>
-__global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
+__global__ __launch_bounds__(ARB_THREADS) void ar_bwd_kernel(ArP p) {
   extern __shared__ float sm[];
   const ArSm<T> S = ar_carve<T>(sm, p, true);
   const int D = p.D, F = p.F, H = p.H, hd = D / H, T_ = p.T, nkP = S.nkP, NL = p.nlayers;
@@ -681,7 +580,7 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
   T* xT = S.xT;
   float* lnacc = S.lnacc;
   __shared__ ArLayer sL;
-  for (int i = tid; i < 6 * D; i += DEC_THREADS) lnacc[i] = 0.f;
+  for (int i = tid; i < 6 * D; i += ARB_THREADS) lnacc[i] = 0.f;
   ar_load_layer(p, l, &sL);
   for (int t = T_ - 1; t >= 0; --t) {
     const long r = (long)b * T_ + t;
@@ -700,13 +599,13 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
       const T* cache = (const T*)w.cache + (long)b * T_ * 2 * D;
       float* dkva = w.dkvacc + (long)b * T_ * 2 * D;
       // ---- the history entry k/v(output_t): its gradient is complete (steps t+1.. are done) -> slab, and on into the output
-      for (int i = tid; i < 2 * D; i += DEC_THREADS) {
+      for (int i = tid; i < 2 * D; i += ARB_THREADS) {
         const T v = from_f<T>(dkva[(long)t * 2 * D + i]);
         xT[i] = v;
         ar_row<T>(w.dkvo, r, 2 * D)[i] = v;
       }
       AR_BAR();
-      gemv<T>((const T*)w.wqkvT + (long)(D / 32) * D * 32, D, 0, nullptr, xT, tmp, D, 2 * D, ACT_NONE);
+      gemv<T, 2, ARB_THREADS>((const T*)w.wqkvT + (long)(D / 32) * D * 32, D, 0, nullptr, xT, tmp, D, 2 * D, ACT_NONE);
       AR_BAR();
       if (tid < D) g[tid] += tmp[tid];
       AR_BAR();
@@ -721,10 +620,10 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
         ar_row<T>(w.df1, r, D)[tid] = vt;
       }
       AR_BAR();
-      gemv<T>((const T*)w.w1T, F, 0, nullptr, xT, ff, F, D, ACT_NONE);
+      gemv<T, 2, ARB_THREADS>((const T*)w.w1T, F, 0, nullptr, xT, ff, F, D, ACT_NONE);
       AR_BAR();
       T* ffT = xT + 3 * D;
-      for (int i = tid; i < F; i += DEC_THREADS) {
+      for (int i = tid; i < F; i += ARB_THREADS) {
         const float f0v = to_f(ar_crow<T>(w.f0, r, F)[i]);
         float dv = f0v > 0.f ? ff[i] : 0.f;
         if (p.p_ff > 0.f) dv *= drop_scale(seed, p.site, ar_didx(p, b, t, l, AR_S_F0) + i, p.p_ff);
@@ -733,8 +632,8 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
         ar_row<T>(w.df0, r, F)[i] = vt;
       }
       AR_BAR();
-      gemv<T>((const T*)w.w0T, D, 0, nullptr, ffT, tmp, D, F / 2, ACT_NONE, nullptr, 0, DEC_WAVES / 2);
-      gemv<T>((const T*)w.w0T + (long)(F / 64) * D * 32, D, 0, nullptr, ffT + F / 2, att, D, F / 2, ACT_NONE, nullptr, DEC_WAVES / 2, DEC_WAVES / 2);
+      gemv<T, 2, ARB_THREADS>((const T*)w.w0T, D, 0, nullptr, ffT, tmp, D, F / 2, ACT_NONE, nullptr, 0, ARB_WAVES / 2);
+      gemv<T, 2, ARB_THREADS>((const T*)w.w0T + (long)(F / 64) * D * 32, D, 0, nullptr, ffT + F / 2, att, D, F / 2, ACT_NONE, nullptr, ARB_WAVES / 2, ARB_WAVES / 2);
       AR_BAR();
       if (tid < D) res[tid] += tmp[tid] + att[tid];     // d(t2)
       AR_BAR();
@@ -749,7 +648,7 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
         qv[tid] = to_f(ar_crow<T>(w.q2, r, D)[tid]);
       }
       AR_BAR();
-      gemv<T>((const T*)w.wo2T, D, 0, nullptr, xT, att, D, D, ACT_NONE);   // d(a2)
+      gemv<T, 2, ARB_THREADS>((const T*)w.wo2T, D, 0, nullptr, xT, att, D, D, ACT_NONE);   // d(a2)
       AR_BAR();
       ar_attend_bwd<T>(qv, att, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D, 2 * D, p.Nsrc, (const T*)nullptr,
                        w.dcross + (long)b * p.Nsrc * 2 * D, nullptr, H, hd, inv_temp, sc, dsc, nkP, qkv, wred, seed, p.site,
@@ -760,7 +659,7 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
         ar_row<T>(w.dq2, r, D)[tid] = vt;
       }
       AR_BAR();
-      gemv<T>((const T*)w.wq2T, D, 0, nullptr, xT, tmp, D, D, ACT_NONE);
+      gemv<T, 2, ARB_THREADS>((const T*)w.wq2T, D, 0, nullptr, xT, tmp, D, D, ACT_NONE);
       AR_BAR();
       if (tid < D) res[tid] += tmp[tid];     // d(t1)
       AR_BAR();
@@ -775,18 +674,18 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
         qv[tid] = to_f(ar_crow<T>(w.q, r, D)[tid]);
       }
       AR_BAR();
-      gemv<T>((const T*)w.woT, D, 0, nullptr, xT, att, D, D, ACT_NONE);    // d(att)
+      gemv<T, 2, ARB_THREADS>((const T*)w.woT, D, 0, nullptr, xT, att, D, D, ACT_NONE);    // d(att)
       AR_BAR();
       // self-attention over the t earlier outputs' entries (cache rows) and the step's own input entry (saved kvin row)
       ar_attend_bwd<T>(qv, att, cache, 2 * D, t + 1, ar_crow<T>(w.kvin, r, 2 * D), dkva, qkv + D, H, hd, inv_temp, sc, dsc, nkP, qkv, wred, seed,
                        p.site, ar_didx(p, b, t, l, AR_S_ATT), p.p_att);
-      for (int i = tid; i < 3 * D; i += DEC_THREADS) {
+      for (int i = tid; i < 3 * D; i += ARB_THREADS) {
         const T vt = from_f<T>(qkv[i]);
         xT[i] = vt;
         ar_row<T>(w.dqkvi, r, 3 * D)[i] = vt;
       }
       AR_BAR();
-      gemv<T>((const T*)w.wqkvT, D, 0, nullptr, xT, tmp, D, 3 * D, ACT_NONE);
+      gemv<T, 2, ARB_THREADS>((const T*)w.wqkvT, D, 0, nullptr, xT, tmp, D, 3 * D, ACT_NONE);
       AR_BAR();
       if (tid < D) {
         const float gi = res[tid] + tmp[tid];     // gradient of the layer input = of the layer below's output
@@ -797,7 +696,7 @@ __global__ __launch_bounds__(DEC_THREADS) void ar_bwd_kernel(ArP p) {
     }
   }
   // LayerNorm parameter gradients of this image's T steps -> per-image partials (folded over the images in fixed order by ar_ln_fold_kernel)
-  for (int i = tid; i < 6 * D; i += DEC_THREADS) p.lnpart[((size_t)b * NL + l) * 6 * D + i] = lnacc[i];
+  for (int i = tid; i < 6 * D; i += ARB_THREADS) p.lnpart[((size_t)b * NL + l) * 6 * D + i] = lnacc[i];
 }
 
 // device copy of the layer table (constant indices: scalar loads from the kernel argument)
@@ -828,7 +727,7 @@ template <typename T> static int ar_launch(const ArP& p, bool bwd, hipStream_t s
   const void* fn = bwd ? (const void*)ar_bwd_kernel<T> : (const void*)ar_fwd_kernel<T>;
   static bool attr[2] = {false, false};
   if (!attr[bwd ? 1 : 0]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024); attr[bwd ? 1 : 0] = true; }
-  if (bwd) hipLaunchKernelGGL((ar_bwd_kernel<T>), dim3(p.B, p.nlayers), dim3(DEC_THREADS), sh, s, p);
+  if (bwd) hipLaunchKernelGGL((ar_bwd_kernel<T>), dim3(p.B, p.nlayers), dim3(ARB_THREADS), sh, s, p);
   else hipLaunchKernelGGL((ar_fwd_kernel<T>), dim3(p.G, p.B), dim3(ARF_THREADS), sh, s, p);
   return 0;
 }
@@ -911,7 +810,7 @@ int launch_ar_bwd(int dt, const ArP& p0, hipStream_t s) {
   const size_t sh = ar_lds_floats(p, true) * sizeof(float);
   const void* fn = dt == DT_BF16 ? (const void*)ar_bwd_kernel<bf16_t> : (const void*)ar_bwd_kernel<float>;
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-  if ((long)p.B * p.nlayers > resident_capacity(fn, DEC_THREADS, sh)) return -1;
+  if ((long)p.B * p.nlayers > resident_capacity(fn, ARB_THREADS, sh)) return -1;
   p.err = device_error_word();
   if (!p.err) return -1;
   p.tag = se_next_tag(); p.timeout_ticks = 500000000LL;   // 5 s at 100 MHz
