@@ -2521,21 +2521,20 @@ int model_train_step(Model* m, const float* img, const int64_t* expected, int B,
   if (!train_mode) use_graph = 0;  // the captured graphs are the training-mode step
   // hyper-parameters for this step (lr changes every iteration in the reference's scheduler)
   if (phase & 2) m->adam_t += 1;
-  if (!m->hy_pinned && hipHostMalloc((void**)&m->hy_pinned, 64 * 16 * sizeof(float), 0) != hipSuccess) { m->err = "hipHostMalloc failed"; return -5; }
-  // one pinned slot per CALL: the async copy below reads the slot when the GPU gets there, and the host may be several
-  // calls ahead by then (a slot keyed by the optimizer step was overwritten by the next step's phase-1 call while the
-  // phase-2 copy of the previous step was still queued: wrong grad_scale on whichever rank lost that race)
-  float* hy = m->hy_pinned + (m->hy_seq++ % 64) * 16;
-  memcpy(hy, hyper9, 9 * sizeof(float));
-  hy[6] = 1.0f - powf(hy[1], (float)m->adam_t);
-  hy[7] = 1.0f - powf(hy[2], (float)m->adam_t);
-  (void)hipMemcpyAsync(scal(m) + SC_HYPER, hy, 9 * sizeof(float), hipMemcpyHostToDevice, s);
-  if (hyper9_dec) {
-    float* hd = m->hy_pinned + (m->hy_seq++ % 64) * 16;
-    memcpy(hd, hyper9_dec, 9 * sizeof(float));
-    hd[6] = 1.0f - powf(hd[1], (float)m->adam_t);
-    hd[7] = 1.0f - powf(hd[2], (float)m->adam_t);
-    (void)hipMemcpyAsync(scal(m) + SC_HYPER2, hd, 9 * sizeof(float), hipMemcpyHostToDevice, s);
+  // (as kernel arguments: a pinned-memory copy of 36 bytes ran as a blit on another queue, ~50 us of idle chain per step boundary)
+  {
+    float hy[9];
+    memcpy(hy, hyper9, 9 * sizeof(float));
+    hy[6] = 1.0f - powf(hy[1], (float)m->adam_t);
+    hy[7] = 1.0f - powf(hy[2], (float)m->adam_t);
+    launch_set_scalars(scal(m) + SC_HYPER, hy, 9, s);
+    if (hyper9_dec) {
+      float hd[9];
+      memcpy(hd, hyper9_dec, 9 * sizeof(float));
+      hd[6] = 1.0f - powf(hd[1], (float)m->adam_t);
+      hd[7] = 1.0f - powf(hd[2], (float)m->adam_t);
+      launch_set_scalars(scal(m) + SC_HYPER2, hd, 9, s);
+    }
   }
   static const bool host_prof = sw_prof("host");  // host time spent ISSUING the forward / backward / optimizer
   auto hnow = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

@@ -334,6 +334,7 @@ void launch_pack_dense_ld(int dt, const float* w, void* fwd, void* bwd, int N, i
 int launch_attn_checked(int dt, int mode, const AttnP& p, hipStream_t s);
 void launch_cast(int dt_in, int dt_out, const void* in, void* out, long n, hipStream_t s);
 void launch_fill(void* p, int value_byte, size_t bytes, hipStream_t s);
+void launch_set_scalars(float* dst, const float* src /*host, n <= 12*/, int n, hipStream_t s);   // by kernel argument, no copy engine
 void launch_add(int dt, const void* a, const void* b, void* out, long n, hipStream_t s);
 void launch_argmax(const float* logits, int64_t* ids, int R, int V, int ld_in, int ld_out, hipStream_t s);
 void launch_seed_advance(uint32_t* seed, hipStream_t s);

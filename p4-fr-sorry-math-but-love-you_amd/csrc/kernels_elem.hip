@@ -3095,6 +3095,15 @@ __global__ void fill_i64_kernel(int64_t* p, int64_t v, long n) {
 void launch_fill_i64(int64_t* p, int64_t v, long n, hipStream_t s) { hipLaunchKernelGGL(fill_i64_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, v, n); }
 __global__ void seed_advance_kernel(uint32_t* seed) { *seed = mix32(*seed + 0x9E3779B9u); }
 void launch_seed_advance(uint32_t* seed, hipStream_t s) { hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, s, seed); }
+// a handful of scalars into device memory as KERNEL ARGUMENTS: a host-to-device copy of 36 bytes runs as a blit on another queue and cost
+// the chain ~50 us of idle time at every step boundary (tools/step_boundary.sh); a one-wave kernel stays in the stream's own queue
+struct Scalars12 { float v[12]; };
+__global__ void set_scalars_kernel(float* dst, Scalars12 h, int n) { if ((int)threadIdx.x < n) dst[threadIdx.x] = h.v[threadIdx.x]; }
+void launch_set_scalars(float* dst, const float* src, int n, hipStream_t s) {
+  Scalars12 h;
+  for (int i = 0; i < 12; ++i) h.v[i] = i < n ? src[i] : 0.f;
+  hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(64), 0, s, dst, h, n > 12 ? 12 : n);
+}
 
 // ---- weight packing (fp32 master -> compute dtype, contraction-major copies) --------------------------------
 template <typename T>
