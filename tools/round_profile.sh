@@ -4,6 +4,7 @@
 #   2. two PMC passes (FETCH_SIZE / WRITE_SIZE, kernel-trace only) -> profiles/<tag>_pmc_traffic.json (read by bench.py)
 #   3. MFMA-busy PMC pass of the whole step and of the encoder self-attention region alone -> profiles/<tag>_mfma_busy*.json
 #   4. kernel stats of the SwinTRN step and of the greedy decode     -> profiles/<tag>_swin_kernel_stats.csv, _decode_kernel_stats.csv
+#   4b. kernel stats of the autoregressive training step                -> profiles/<tag>_ar_kernel_stats.csv, _ar_time.log
 #   5. the default bench line                                      -> profiles/<tag>_bench_default.json
 # Every rocprofv3 command has the program itself after `--` and never mixes --pmc with the trace domains gpurun refuses.
 set -e -o pipefail
@@ -48,6 +49,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_dec -- pyt
 cp "$(ls gpurun_out/kt_dec/*/*kernel_stats.csv | head -1)" "profiles/${TAG}_decode_kernel_stats.csv"
 rm -rf gpurun_out/kt_swin gpurun_out/kt_dec gpurun_out/pmc_swin
 echo "swin / decode kernel stats done"
+# autoregressive training branch (bs32, T = 128): its two launches beside the rest of the step
+rm -rf gpurun_out/kt_ar
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_ar -- python3 tools/ar_time.py > "profiles/${TAG}_ar_time.log" 2>&1
+cp "$(ls gpurun_out/kt_ar/*/*kernel_stats.csv | head -1)" "profiles/${TAG}_ar_kernel_stats.csv"
+rm -rf gpurun_out/kt_ar
+echo "ar kernel stats done"
 python3 bench.py > "$OUT/default.log" 2>&1
 grep '^{' "$OUT/default.log" > "profiles/${TAG}_bench_default.json"
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
