@@ -2243,7 +2243,7 @@ Tensor* decoder_ar_fused(Exec& e, Tensor* src, int B, int L, float* logits_out) 
 
 static bool ar_fused_ok(Exec& e, Tensor* src, int B, int L) {
   const SatrnConfig& c = e.m->cfg;
-  return ar_train_ok(e.dt, c.dec_hidden, c.dec_filter, c.num_classes, c.dec_heads, L - 1, (int)(src->rows / B), (int)e.m->dec.size());
+  return ar_train_ok(e.dt, B, c.dec_hidden, c.dec_filter, c.num_classes, c.dec_heads, L - 1, (int)(src->rows / B), (int)e.m->dec.size());
 }
 
 Tensor* decoder_tf(Exec& e, Tensor* src, const int64_t* expected, int B, int L, float* logits_out) {

@@ -473,7 +473,7 @@ struct ArP {
   int kv_lds;        // forward (set by the launcher): history and cross-attention keys / values of the slice held in LDS
   unsigned long long* fbox;   // forward, G > 1: ar_fwd_box_bytes() mailbox of the slices' exchanges
 };
-bool ar_train_ok(int dt, int D, int F, int V, int H, int T, int Nsrc, int nlayers);
+bool ar_train_ok(int dt, int B, int D, int F, int V, int H, int T, int Nsrc, int nlayers);
 int launch_ar_fwd(int dt, const ArP& p, hipStream_t s);   // -1: not launched
 int ar_fwd_slices(int dt, int D, int F, int H);
 size_t ar_fwd_box_bytes(int B, int G, int D);

@@ -734,7 +734,7 @@ template <typename T> static int ar_launch(const ArP& p, bool bwd, hipStream_t s
 
 }  // namespace
 
-bool ar_train_ok(int dt, int D, int F, int V, int H, int T, int Nsrc, int nlayers) {
+bool ar_train_ok(int dt, int B, int D, int F, int V, int H, int T, int Nsrc, int nlayers) {
   if (sw_off("ar_fused")) return false;
   if (D % 64 || F % 64 || D > 256 || nlayers > 4 || nlayers < 1 || H < 1 || D % H) return false;
   const int ch = dt == DT_BF16 ? 8 : 4, cpr = D / ch, hd = D / H;
@@ -744,7 +744,13 @@ bool ar_train_ok(int dt, int D, int F, int V, int H, int T, int Nsrc, int nlayer
   if ((long)H * nkP > (long)AR_DSTRIDE || F > (int)AR_DSTRIDE) return false;
   ArP p = {};
   p.D = D; p.F = F; p.V = V; p.H = H; p.T = T; p.Nsrc = Nsrc; p.nlayers = nlayers;
-  return ar_lds_floats(p, true) * sizeof(float) <= 150 * 1024;
+  const size_t shb = ar_lds_floats(p, true) * sizeof(float);
+  if (shb > 150 * 1024) return false;
+  // the backward's layer workgroups of an image wait for each other: B * nlayers of them have to be resident (the forward falls back to one
+  // workgroup per image by itself; the backward has no such form, so batches beyond the device take the operator-level branch)
+  const void* fn = dt == DT_BF16 ? (const void*)ar_bwd_kernel<bf16_t> : (const void*)ar_bwd_kernel<float>;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  return (long)B * nlayers <= resident_capacity(fn, ARB_THREADS, shb);
 }
 
 // slices per image of the forward: the largest of 4, 2, 1 (or the ar_split knob; 8 measured the same as 4) that divides the heads into whole 32-column

@@ -384,6 +384,24 @@ def test_autoregressive_branch_two_launch_form_equals_operator_form(dtype, net, 
         assert cs.item() > 0.98
 
 
+def test_autoregressive_branch_beyond_the_resident_batch_takes_the_operator_form():
+    """The backward's layer pipeline needs batch x layers workgroups resident (256 on an MI355X: 85 images at three layers, 128 at two); a larger batch
+    must take the operator-level branch by itself -- not fail, not hang."""
+    cfg = dict(O.CFG_LITE)
+    B, H, W, T = 136, 64, 192, 4   # (LiteSATRN: two decoder layers)
+    img, expected = O.det_inputs(B, cfg["rgb"], H, W, T, seed=45, pad_tail=1)
+    model, sd = build(cfg, H, W, "bf16", 6)
+    model.train()
+    _ar_routes(reset=True)
+    logits = model(img.cuda(), expected.cuda(), True, 0.0)
+    loss = model.criterion(logits.transpose(1, 2), expected.cuda()[:, 1:])
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _ar_routes() == 0
+    assert torch.isfinite(loss).item() and torch.isfinite(model.flat_grad()).all().item()
+
+
 def test_autoregressive_branch_two_launch_form_with_dropout():
     """Dropout inside the two-launch form: the backward regenerates the masks of the forward (counter hash), so two runs from the same
     seed agree bit for bit in f32 with fixed-order reductions, the loss differs from the dropout-free one, and every gradient is finite;
