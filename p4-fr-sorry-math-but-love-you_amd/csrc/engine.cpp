@@ -65,7 +65,8 @@ void Exec::defer(std::function<void(hipStream_t)> fn) {
   // never -> 14.6 ms/step): every hand-over costs the chain 11-15 us (tools/micro/fork_cost.hip: an event record on the
   // chain's queue + a wait on the side queue; the record alone is 2 us).  Larger batches early in the backward and small
   // ones near the join were tried as well (32 / 8): no change -- what the fewer forks save, the later start of the side work costs
-  static const int thr = (int)sw_knob("flush", 8);
+  // (round 4, with the chain at 421 launches: 4 -> 8.55, 8 -> 8.68, 2 / 3 -> 8.64-8.69 ms with 160 weight-gradient workgroups)
+  static const int thr = (int)sw_knob("flush", 4);
   if ((int)pending.size() >= thr) flush_side();
 }
 void Exec::flush_side() {
@@ -2282,7 +2283,7 @@ static void det_activate(Model* m) {
   g_det.scratch[0] = g_det.on ? (float*)(m->ws + m->off_det) : nullptr;
   g_det.scratch[1] = g_det.on ? (float*)(m->ws + m->off_det) + m->det_floats : nullptr;
   g_det.side = m->ex ? m->ex->s2 : nullptr;
-  g_wgrad_dense_blocks = m->cfg.network == 2 ? 160 : 0;
+  g_wgrad_dense_blocks = 160;   // (SATRN: 96 until round 4; 160-192 measured best once the chain got shorter: 8.55 vs 8.60 ms; 224 -> 8.59, 256 -> 8.63)
   g_wgrad_big_min_gflop = m->cfg.network == 2 ? 1.0f : 2.0f;
   const bool wp = m->wgpart_floats && m->ws;
   g_wgpart.cap = wp ? m->wgpart_floats : 0;
