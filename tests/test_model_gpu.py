@@ -384,6 +384,34 @@ def test_autoregressive_branch_two_launch_form_equals_operator_form(dtype, net, 
         assert cs.item() > 0.98
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_autoregressive_forward_history_in_lds_or_in_memory(dtype):
+    """The sliced forward keeps its slice of the attention history and of the cross-attention keys / values in LDS where they fit; longer
+    targets / f32 at the full size read them from memory (the step's own row from LDS).  Same arithmetic either way: same bits."""
+    cfg = dict(O.CFG_EFF)
+    B, H, W, T = 3, 64, 192, 7
+    img, expected = O.det_inputs(B, cfg["rgb"], H, W, T, seed=46, pad_tail=1)
+    res = {}
+    for name in ("lds", "mem"):
+        (sw.off if name == "mem" else sw.on)("ar_kv_lds")
+        model, sd = build(cfg, H, W, dtype, 6)
+        model.train()
+        _ar_routes(reset=True)
+        logits = model(img.cuda(), expected.cuda(), True, 0.0)
+        loss = model.criterion(logits.transpose(1, 2), expected.cuda()[:, 1:])
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        assert _ar_routes() > 0
+        res[name] = (logits.detach().float().cpu().clone(), model.flat_grad().detach().float().cpu().clone())
+    sw.on("ar_kv_lds")
+    assert torch.equal(res["lds"][0], res["mem"][0]), "logits"
+    if dtype == "f32":
+        assert torch.equal(res["lds"][1], res["mem"][1]), "gradients (fixed-order reductions)"
+    else:
+        assert relerr(res["lds"][1], res["mem"][1]) < 2e-2   # (weight gradients through fp32 atomics: order varies)
+
+
 def test_autoregressive_branch_beyond_the_resident_batch_takes_the_operator_form():
     """The backward's layer pipeline needs batch x layers workgroups resident (256 on an MI355X: 85 images at three layers, 128 at two); a larger batch
     must take the operator-level branch by itself -- not fail, not hang."""
