@@ -13,6 +13,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 void launch_act_fwd(int dt, const void* u, void* z, long n, int act, hipStream_t s);
 
@@ -519,11 +521,25 @@ Model* model_create(const SatrnConfig& cfg) {
   m->ex->m = m;
   if (!sw_off("side_stream")) {
     // optimizer-only work (weight gradients) runs on a LOW-priority stream: whenever both queues have a kernel ready, the
-    // data-gradient chain (the critical path) is dispatched first
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically greatest = lowest priority
-    if (hipStreamCreateWithPriority(&m->ex->s2, hipStreamNonBlocking, lo) != hipSuccess)
-      (void)hipStreamCreateWithFlags(&m->ex->s2, hipStreamNonBlocking);
+    // data-gradient chain (the critical path) is dispatched first.  ONE side stream per device and process, shared by every model: the
+    // runtime deals streams onto a few hardware queues in creation / first-use order, and the side stream of a SECOND model used to land on
+    // the queue of the chain it was meant to run beside (bench.py's f32 leg, created after the bf16 model had run: 43 ms per step in the
+    // bench process against 23 ms alone -- tools/f32_in_process.py).  Models of one process share the caller's stream anyway.
+    static std::mutex mu;
+    static std::map<int, hipStream_t> side;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto it = side.find(dev);
+    if (it == side.end()) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically greatest = lowest priority
+      hipStream_t s2 = nullptr;
+      if (hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, lo) != hipSuccess)
+        (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+      it = side.emplace(dev, s2).first;
+    }
+    m->ex->s2 = it->second;
   }
   segment_ranges(m);
   return m;
