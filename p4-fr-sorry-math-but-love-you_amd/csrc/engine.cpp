@@ -255,6 +255,33 @@ const StageDef kEffV2S[6] = {{0, 2, 1, 1, 24, 0.f},   {1, 4, 2, 4, 48, 0.f},   {
 
 static void segment_ranges(Model* m);
 
+// ---- the side stream ----------------------------------------------------------------------------------------------------------------
+// Optimizer-only work (weight gradients) runs on a second, low-priority stream beside the data-gradient chain.  ONE side stream per device
+// and process, shared by every model.  Whether two streams really run side by side is decided by the runtime: it deals streams onto
+// hardware queues, and a chain and a side stream whose queues share a dispatch pipe slow each other down instead of overlapping (seen
+// in bench.py's process: with a chain stream and a side stream per MODEL the f32 leg ran at 43 ms per step against 23 ms alone, and with
+// only the side stream shared the SwinTRN leg at 32 against 16: its chain sat on hardware queue 5, the side stream on queue 1; alone: 3
+// and 1 -- tools/f32_in_process.py, tools/swin_in_process.py).  The Python module shares its chain stream the same way (networks.py
+// _chain_stream), so every model of a process runs on the pair the first one got.  A timed probe (two spin kernels, one per stream)
+// was tried as a detector and dropped: it called a pair good that then ran the step at 28 ms.
+static std::mutex g_side_mu;
+static std::map<int, hipStream_t> g_side;
+static hipStream_t side_stream_get() {
+  std::lock_guard<std::mutex> lock(g_side_mu);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto it = g_side.find(dev);
+  if (it == g_side.end()) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically greatest = lowest priority
+    hipStream_t s2 = nullptr;
+    if (hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, lo) != hipSuccess)
+      (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+    it = g_side.emplace(dev, s2).first;
+  }
+  return it->second;
+}
+
 Model* model_create(const SatrnConfig& cfg) {
   sw_refresh();
   Model* m = new Model();
@@ -519,28 +546,8 @@ Model* model_create(const SatrnConfig& cfg) {
   m->persist_bytes = (o + 255) & ~(size_t)255;
   m->ex = new Exec();
   m->ex->m = m;
-  if (!sw_off("side_stream")) {
-    // optimizer-only work (weight gradients) runs on a LOW-priority stream: whenever both queues have a kernel ready, the
-    // data-gradient chain (the critical path) is dispatched first.  ONE side stream per device and process, shared by every model: the
-    // runtime deals streams onto a few hardware queues in creation / first-use order, and the side stream of a SECOND model used to land on
-    // the queue of the chain it was meant to run beside (bench.py's f32 leg, created after the bf16 model had run: 43 ms per step in the
-    // bench process against 23 ms alone -- tools/f32_in_process.py).  Models of one process share the caller's stream anyway.
-    static std::mutex mu;
-    static std::map<int, hipStream_t> side;
-    std::lock_guard<std::mutex> lock(mu);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    auto it = side.find(dev);
-    if (it == side.end()) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = numerically greatest = lowest priority
-      hipStream_t s2 = nullptr;
-      if (hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, lo) != hipSuccess)
-        (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
-      it = side.emplace(dev, s2).first;
-    }
-    m->ex->s2 = it->second;
-  }
+  if (!sw_off("side_stream")) m->ex->s2 = side_stream_get();
+
   segment_ranges(m);
   return m;
 }
