@@ -1649,7 +1649,10 @@ Tensor* encoder_layer(Exec& e, Tensor* x, EncLayer* el) {
   // MultiHeadAttention.dropout followed by EncoderLayer.dropout0: two independent masks == one mask with 1-(1-p)^2
   const float out_drop = 1.f - (1.f - p) * (1.f - p);
   Tensor* y2;
-  if (enc_attn_fused_ok(e.dt, H * W, el->att.D, el->att.heads) && !g_det.on) {
+  // the one-launch region re-streams the weights per (image, head pair): it wins up to ~96 images (B = 64: 43.9 vs 50.6 us for the four
+  // launches) and loses beyond (128: 78.9 vs 58.9; 512: 301 vs 129; 1024: 600 vs 254 -- tools/enc_attn_region.py --batch)
+  static const long ea_max_b = sw_knob("enc_attn_max_b", 96);
+  if (enc_attn_fused_ok(e.dt, H * W, el->att.D, el->att.heads) && !g_det.on && B <= ea_max_b) {
     // ONE launch for LayerNorm -> q|k|v -> attention -> output-projection partials (kernels_encattn.hip).  The four ops are run with
     // nolaunch: they allocate their outputs and record their (unfused) backward closures exactly as before; the fused kernel then fills
     // those outputs, and the LayerNorm behind the block adds the partial projections (+ bias, dropout) in a fixed order.
