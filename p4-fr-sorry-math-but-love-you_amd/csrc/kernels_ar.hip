@@ -456,24 +456,28 @@ DEVI void ar_ln_bwd(const float* dy, const T* s_a, const T* s_b, const float* w,
   AR_BAR();
 }
 
-// Backward of one attention row (the forward's ar_attend): q, da in LDS; key rows kv[j * ld] for j < nk, except the LAST one when
+// Backward of one attention row (the forward's ar_attend_w): q, da in LDS; key rows kv[j * ld] for j < nk, except the LAST one when
 // cur != null (the step's own input entry).  Outputs: dq (LDS [D]); d(k|v) of row j added into acc[j * 2D ..] (global f32, rows owned by
-// this workgroup) -- or written to dcur (LDS [2D]) for the cur row.
+// this workgroup, always by the same lane) -- or written to dcur (LDS [2D]) for the cur row.
+// ONE WAVE PER HEAD and no workgroup barrier inside (the caller's barrier behind it is the only one; needs H <= the
+// workgroup's waves and hd / CH a power of two <= 16): scores, softmax and its backward stay inside the wave (probabilities pass through
+// the head's row of sc / dsc in LDS), then lane = (key group, 16-byte chunk of the head) adds d(k | v) of its keys and reduces dq by shuffles.
 template <typename T>
-DEVI void ar_attend_bwd(const float* q, const float* da, const T* kv, long ld, int nk, const T* cur, float* acc, float* dcur, int H, int hd,
-                        float inv_temp, float* sc, float* dsc, int nkP, float* dq, float* wred, uint32_t seed, uint32_t site, uint32_t didx,
-                        float pdrop) {
-  constexpr int CH = TT<T>::CH, NT = ARB_THREADS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int D = H * hd, cph = hd / CH;
-  // scores and d(dropped probabilities): one thread per (key, head)
-  for (int idx = tid; idx < nk * H; idx += NT) {
-    const int j = idx / H, h = idx - j * H;
+DEVI void ar_attend_bwd_w(const float* q, const float* da, const T* kv, long ld, int nk, const T* cur, float* acc, float* dcur, int H, int hd,
+                          float inv_temp, float* sc, float* dsc, int nkP, float* dq, uint32_t seed, uint32_t site, uint32_t didx, float pdrop) {
+  constexpr int CH = TT<T>::CH;
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+  if (h >= H) return;
+  const int D = H * hd, cph = hd / CH, KGW = 64 / cph;
+  const float* qp = q + h * hd;
+  const float* dp = da + h * hd;
+  float* sch = sc + h * nkP;
+  float* dsh = dsc + h * nkP;
+  float m = -INFINITY;
+  for (int j = lane; j < nk; j += 64) {
     const T* row = (cur && j == nk - 1) ? cur : kv + (long)j * ld;
     const T* kp = row + h * hd;
     const T* vp = row + D + h * hd;
-    const float* qp = q + h * hd;
-    const float* dp = da + h * hd;
     float a1 = 0.f, a2 = 0.f;
 #pragma unroll 4
     for (int c = 0; c < cph; ++c) {
@@ -483,57 +487,50 @@ DEVI void ar_attend_bwd(const float* q, const float* da, const T* kv, long ld, i
 #pragma unroll
       for (int e = 0; e < CH; ++e) { a1 += f[e] * qp[c * CH + e]; a2 += g[e] * dp[c * CH + e]; }
     }
-    sc[h * nkP + j] = a1 * inv_temp;
-    dsc[h * nkP + j] = a2;
+    a1 *= inv_temp;
+    sch[j] = a1;
+    dsh[j] = a2;
+    m = fmaxf(m, a1);
   }
-  AR_BAR();
-  // softmax again, its backward: sc <- dropped probabilities, dsc <- d(scores) * inv_temp
-  for (int h = wave; h < H; h += (NT / 64)) {
-    float m = -INFINITY;
-    for (int j = lane; j < nk; j += 64) m = fmaxf(m, sc[h * nkP + j]);
-    m = wave_max(m);
-    float s = 0.f;
-    for (int j = lane; j < nk; j += 64) { float e = __expf(sc[h * nkP + j] - m); sc[h * nkP + j] = e; s += e; }
-    s = wave_sum(s);
-    const float inv = 1.0f / s;
-    float rs = 0.f;
-    for (int j = lane; j < nk; j += 64) {
-      const float pv = sc[h * nkP + j] * inv;
-      const float ms = pdrop > 0.f ? drop_scale(seed, site, didx + (uint32_t)(h * nkP + j), pdrop) : 1.f;
-      const float dpv = dsc[h * nkP + j] * ms;    // d(probability)
-      sc[h * nkP + j] = pv;
-      dsc[h * nkP + j] = dpv;
-      rs += pv * dpv;
-    }
-    rs = wave_sum(rs);
-    for (int j = lane; j < nk; j += 64) {
-      const float pv = sc[h * nkP + j];
-      const float ms = pdrop > 0.f ? drop_scale(seed, site, didx + (uint32_t)(h * nkP + j), pdrop) : 1.f;
-      dsc[h * nkP + j] = pv * (dsc[h * nkP + j] - rs) * inv_temp;
-      sc[h * nkP + j] = pv * ms;
-    }
+  m = wave_max(m);
+  float ssum = 0.f;
+  for (int j = lane; j < nk; j += 64) { const float e = __expf(sch[j] - m); sch[j] = e; ssum += e; }
+  ssum = wave_sum(ssum);
+  const float inv = 1.0f / ssum;
+  float rs = 0.f;
+  for (int j = lane; j < nk; j += 64) {
+    const float pv = sch[j] * inv;
+    const float ms = pdrop > 0.f ? drop_scale(seed, site, didx + (uint32_t)(h * nkP + j), pdrop) : 1.f;
+    const float dpv = dsh[j] * ms;    // d(probability)
+    sch[j] = pv;
+    dsh[j] = dpv;
+    rs += pv * dpv;
   }
-  AR_BAR();
-  // one thread per (key group, 16-byte chunk of the D dims): dK_j, dV_j out, dq accumulated
-  const int cpr = D / CH, KG = NT / cpr;
-  const int dc = tid % cpr, kg = tid / cpr;
-  const int h = (dc * CH) / hd;
+  rs = wave_sum(rs);
+  for (int j = lane; j < nk; j += 64) {
+    const float pv = sch[j];
+    const float ms = pdrop > 0.f ? drop_scale(seed, site, didx + (uint32_t)(h * nkP + j), pdrop) : 1.f;
+    dsh[j] = pv * (dsh[j] - rs) * inv_temp;   // d(score) * inv_temp
+    sch[j] = pv * ms;                         // dropped probability
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's LDS writes are done before its lanes read each other's values
+  const int c = lane % cph, kg = lane / cph;
   float aq[CH], qv[CH], dav[CH];
 #pragma unroll
-  for (int e = 0; e < CH; ++e) { aq[e] = 0.f; qv[e] = q[dc * CH + e]; dav[e] = da[dc * CH + e]; }
-  for (int j = kg; j < nk; j += KG) {
+  for (int e = 0; e < CH; ++e) { aq[e] = 0.f; qv[e] = qp[c * CH + e]; dav[e] = dp[c * CH + e]; }
+  for (int j = kg; j < nk; j += KGW) {
     const bool is_cur = cur && j == nk - 1;
     const T* row = is_cur ? cur : kv + (long)j * ld;
     float f[CH];
-    unpack<T>(ld16(row + dc * CH), f);
-    const float pd = sc[h * nkP + j], dsv = dsc[h * nkP + j];
+    unpack<T>(ld16(row + h * hd + c * CH), f);
+    const float pd = sch[j], dsv = dsh[j];
 #pragma unroll
     for (int e = 0; e < CH; ++e) aq[e] += dsv * f[e];
     if (is_cur) {
 #pragma unroll
-      for (int e = 0; e < CH; ++e) { dcur[dc * CH + e] = dsv * qv[e]; dcur[D + dc * CH + e] = pd * dav[e]; }
+      for (int e = 0; e < CH; ++e) { dcur[h * hd + c * CH + e] = dsv * qv[e]; dcur[D + h * hd + c * CH + e] = pd * dav[e]; }
     } else {
-      float* a = acc + (long)j * 2 * D + dc * CH;
+      float* a = acc + (long)j * 2 * D + h * hd + c * CH;
 #pragma unroll
       for (int e4 = 0; e4 < CH; e4 += 4) {
         float4 k4 = *reinterpret_cast<float4*>(a + e4), v4 = *reinterpret_cast<float4*>(a + D + e4);
@@ -544,22 +541,14 @@ DEVI void ar_attend_bwd(const float* q, const float* da, const T* kv, long ld, i
       }
     }
   }
-  for (int o2 = cpr; o2 < 64; o2 <<= 1) {
+  for (int o2 = cph; o2 < 64; o2 <<= 1) {
 #pragma unroll
     for (int e = 0; e < CH; ++e) aq[e] += __shfl_xor(aq[e], o2, 64);
   }
-  if (lane < cpr) {
+  if (lane < cph) {
 #pragma unroll
-    for (int e = 0; e < CH; ++e) wred[wave * D + dc * CH + e] = aq[e];
+    for (int e = 0; e < CH; ++e) dq[h * hd + c * CH + e] = aq[e];
   }
-  AR_BAR();
-  if (tid < D) {
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < (NT / 64); ++w) v += wred[w * D + tid];
-    dq[tid] = v;
-  }
-  AR_BAR();
 }
 
 template <typename T>
@@ -650,9 +639,10 @@ __global__ __launch_bounds__(ARB_THREADS) void ar_bwd_kernel(ArP p) {
       AR_BAR();
       gemv<T, 2, ARB_THREADS>((const T*)w.wo2T, D, 0, nullptr, xT, att, D, D, ACT_NONE);   // d(a2)
       AR_BAR();
-      ar_attend_bwd<T>(qv, att, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D, 2 * D, p.Nsrc, (const T*)nullptr,
-                       w.dcross + (long)b * p.Nsrc * 2 * D, nullptr, H, hd, inv_temp, sc, dsc, nkP, qkv, wred, seed, p.site,
-                       ar_didx(p, b, t, l, AR_S_ATT2), p.p_att);
+      ar_attend_bwd_w<T>(qv, att, (const T*)w.crossKV + (long)b * p.Nsrc * 2 * D, 2 * D, p.Nsrc, (const T*)nullptr,
+                         w.dcross + (long)b * p.Nsrc * 2 * D, nullptr, H, hd, inv_temp, sc, dsc, nkP, qkv, seed, p.site,
+                         ar_didx(p, b, t, l, AR_S_ATT2), p.p_att);
+      AR_BAR();
       if (tid < D) {
         const T vt = from_f<T>(qkv[tid]);
         xT[tid] = vt;
@@ -677,8 +667,9 @@ __global__ __launch_bounds__(ARB_THREADS) void ar_bwd_kernel(ArP p) {
       gemv<T, 2, ARB_THREADS>((const T*)w.woT, D, 0, nullptr, xT, att, D, D, ACT_NONE);    // d(att)
       AR_BAR();
       // self-attention over the t earlier outputs' entries (cache rows) and the step's own input entry (saved kvin row)
-      ar_attend_bwd<T>(qv, att, cache, 2 * D, t + 1, ar_crow<T>(w.kvin, r, 2 * D), dkva, qkv + D, H, hd, inv_temp, sc, dsc, nkP, qkv, wred, seed,
-                       p.site, ar_didx(p, b, t, l, AR_S_ATT), p.p_att);
+      ar_attend_bwd_w<T>(qv, att, cache, 2 * D, t + 1, ar_crow<T>(w.kvin, r, 2 * D), dkva, qkv + D, H, hd, inv_temp, sc, dsc, nkP, qkv, seed,
+                         p.site, ar_didx(p, b, t, l, AR_S_ATT), p.p_att);
+      AR_BAR();
       for (int i = tid; i < 3 * D; i += ARB_THREADS) {
         const T vt = from_f<T>(qkv[i]);
         xT[i] = vt;
